@@ -1,0 +1,216 @@
+/*
+ * libtfmq_hip.so -- C ABI of the MI355X (gfx950) kernels behind the TFMQ-DM hot path.
+ *
+ * The reference (ModelTC/TFMQ-DM) has no FFI/plugin boundary: its hot path is plain
+ * PyTorch.  This ABI is therefore the *new* boundary that the Python
+ * mirror of the reference's `quant/` surface binds with ctypes.
+ * Each entry point names the reference code it replaces (paths relative to the
+ * reference root).
+ *
+ * Conventions
+ *   - every function returns 0 on success, <0 on error; tfmq_last_error() gives text.
+ *   - all pointers are DEVICE pointers unless the name ends in _host; the caller owns
+ *     every buffer (the library allocates nothing after tfmq_create, so every call is
+ *     legal inside a HIP stream capture).
+ *   - `stream` is a hipStream_t passed as void*; NULL = the legacy default stream.
+ *   - activations are NHWC ("pixel-major"): [B][H][W][C]; token tensors [B][T][C] are the
+ *     same layout.  fp32 unless stated.  Quantised activations are stored as
+ *     int8 = bin_index - 128 (bin_index in [0,255], quant/quant_layer.py:225).
+ *   - a "qparam" is a device float2 {delta, zero_point} of one activation quantizer; the
+ *     kernels read it from qtable[(*step_ptr) * q_stride + qid] so that one captured
+ *     hipGraph serves every Finite-Set-Calibration step (`act_k`).
+ *   - a handle is bound to one device and is not thread-safe.
+ */
+#ifndef TFMQ_HIP_H
+#define TFMQ_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct tfmq_ctx* tfmq_handle;
+
+#define TFMQ_OK 0
+#define TFMQ_ERR_ARG (-1)
+#define TFMQ_ERR_HIP (-2)
+#define TFMQ_ERR_UNSUPPORTED (-3)
+
+/* ---- handle ---------------------------------------------------------------------- */
+int tfmq_create(int device, tfmq_handle* out);
+int tfmq_destroy(tfmq_handle h);
+const char* tfmq_last_error(tfmq_handle h);
+/* cu_count, max clock (kHz), total HBM bytes of the bound device */
+int tfmq_device_info(tfmq_handle h, int* cu_count, int* clock_khz, size_t* hbm_bytes);
+int tfmq_abi_version(void);
+
+/* Activation-quantizer parameter selector (FSC table lookup, replaces the per-step
+ * `model.load_state_dict(act_k)` of ddim/functions/denoising.py:26-29 and
+ * ldm/models/diffusion/ddpm.py:1403-1405). */
+typedef struct tfmq_qsel {
+  const float* qtable;   /* [n_steps][q_stride][2] = {delta, zero_point}; NULL = no act-quant */
+  const int32_t* step;   /* device scalar: current FSC group k; NULL = row 0 */
+  int32_t q_stride;      /* quantizers per step row */
+  int32_t qid;           /* which quantizer */
+} tfmq_qsel;
+
+/* ---- K1: activation quantizer (UniformAffineQuantizer.forward, quant_layer.py:223-226) */
+/* q[i] = clamp(rint(x[i]/delta)+zp, 0, level-1) - 128   (level <= 256) */
+int tfmq_quantize_act(tfmq_handle h, const float* x, int8_t* q, size_t n, tfmq_qsel qs, int level, void* stream);
+/* y[i] = delta * (clamp(rint(x/delta)+zp,0,level-1) - zp); delta/zp per tensor (rows=1)
+ * or per row ([rows] arrays, the per-output-channel weight quantizer, quant_layer.py:193-204) */
+int tfmq_fake_quant(tfmq_handle h, const float* x, float* y, uint8_t* idx_or_null, size_t rows, size_t cols,
+                    const float* delta, const float* zp, int level, void* stream);
+
+/* ---- K2: min/max statistics (minmax, quant_layer.py:20-35; act_momentum_update :229-244) */
+/* out[r] = {min, max} of row r ([rows][cols] fp32); rows=1 => whole tensor.
+ * ws: caller workspace of at least tfmq_minmax_ws_bytes(rows, cols) bytes. */
+size_t tfmq_minmax_ws_bytes(size_t rows, size_t cols);
+int tfmq_minmax(tfmq_handle h, const float* x, size_t rows, size_t cols, float* out, void* ws, void* stream);
+/* MINMAX scaler from {min,max}: qparam[r] = {delta, zp} exactly as quant_layer.py:23-35
+ * (double subtraction, fp32 delta, zp = rint(fp32(-lo)/delta)); always_zero per :29-30,34. */
+int tfmq_minmax_to_qparam(tfmq_handle h, const float* mm, size_t rows, int level, int always_zero, float* qparam, void* stream);
+/* running-stat EMA (quant_layer.py:233-244): state = {x_min, x_max}; mm = batch {min,max};
+ * state <- m*state + (1-m)*mm, qparam <- MINMAX(state).  init!=0: state <- mm first (:206-207). */
+int tfmq_act_range_update(tfmq_handle h, const float* mm, float* state, float* qparam, double momentum, int level,
+                          int init, void* stream);
+
+/* ---- K3: MSE scale search (mse, quant_layer.py:38-64) ------------------------------- */
+/* For every row: 80 shrink candidates (computed on device in double exactly as the Python),
+ * L2.4 loss of each in ONE pass over the data, first strict minimum.  Outputs per row:
+ * qparam[r] = {delta, zp}; losses_or_null [rows][80]; best_or_null [rows].
+ * mm: [rows][2] from tfmq_minmax.  ws: tfmq_mse_ws_bytes(rows, cols) bytes. */
+size_t tfmq_mse_ws_bytes(size_t rows, size_t cols);
+int tfmq_mse_search(tfmq_handle h, const float* x, size_t rows, size_t cols, const float* mm, int level,
+                    int always_zero, float* qparam, float* losses_or_null, int32_t* best_or_null, void* ws,
+                    void* stream);
+
+/* ---- K4: int4 weight packing (weight fake-quant recomputed every forward in the reference:
+ * UniformAffineQuantizer.forward quant_layer.py:223-226 / AdaRoundQuantizer.forward
+ * adaptive_rounding.py:51-69) ------------------------------------------------------------ */
+/* w: [cout][cin][kh][kw] fp32 (PyTorch OIHW; Linear = kh=kw=1).  alpha NULL => nearest
+ * rounding, else hard AdaRound (floor + [alpha>=0]).  delta/zp: [cout].
+ * packed: [cout][K/2] bytes, K = kh*kw*cin ordered (kh,kw,cin) to match NHWC activations;
+ *   each 32-bit word holds 8 consecutive k: byte i = q[k+i] | q[k+4+i] << 4  (i=0..3).
+ * wmeta: [cout][4] int32 = {zp, rowsum_q = sum_k q, 0, 0}.  cin must be a multiple of 8. */
+int tfmq_pack_w4(tfmq_handle h, const float* w, const float* alpha_or_null, const float* delta, const float* zp,
+                 int cout, int cin, int kh, int kw, uint8_t* packed, int32_t* wmeta, void* stream);
+/* inverse (tests): idx[cout][cin][kh][kw] u8 */
+int tfmq_unpack_w4(tfmq_handle h, const uint8_t* packed, int cout, int cin, int kh, int kw, uint8_t* idx, void* stream);
+/* fp16 weights for the un-quantised convs, reordered to [cout][kh][kw][cin_pad],
+ * cin_pad = cin rounded up to a multiple of 32 (zero filled) */
+int tfmq_pack_w_f16(tfmq_handle h, const float* w, int cout, int cin, int kh, int kw, uint16_t* out, void* stream);
+
+/* ---- K5/K6: conv / linear as implicit GEMM on MFMA (QuantLayer.forward, quant_layer.py:306-340) */
+typedef struct tfmq_conv_desc {
+  /* geometry */
+  int32_t B, H, W, Cin;          /* input  [B][H][W][Cin] */
+  int32_t Cout, KH, KW, stride;  /* 1x1 stride 1 == Linear over B*H*W tokens */
+  int32_t pad_t, pad_l;          /* zero padding before the first row/col */
+  int32_t Ho, Wo;                /* output spatial size */
+  int32_t up2x;                  /* !=0: the conv reads a virtual nearest-2x upsample of the input
+                                    (Upsample.forward, ddim/models/diffusion.py:47-52): H,W are the
+                                    stored input size, the conv sees 2H x 2W */
+  /* operands */
+  const void* x;                 /* int8 (w4a8) or fp32 (f16 path) NHWC */
+  const void* w;                 /* packed int4 (tfmq_pack_w4) or fp16 (tfmq_pack_w_f16) */
+  const int32_t* wmeta;          /* [Cout][4] from tfmq_pack_w4 (w4a8 only) */
+  const float* wscale;           /* [Cout] delta_w (w4a8 only) */
+  const float* bias;             /* [Cout] or NULL */
+  tfmq_qsel aq;                  /* activation quantizer of x (w4a8 only) */
+  /* fused epilogue: y = conv + bias (+ rowadd[b][c]) (+ residual[b][ho][wo][c]) */
+  const float* rowadd;           /* [B][Cout] (temb projection, quant_block.py:429) or NULL */
+  const float* residual;         /* fp32 NHWC [B][Ho][Wo][Cout] or NULL */
+  float* y;                      /* fp32 NHWC [B][Ho][Wo][ldy]  (written at channel offset y_coff) */
+  int32_t ldy, y_coff;           /* output row stride in floats (>= Cout) and channel offset: lets q/k/v or a
+                                    concat target share one buffer */
+} tfmq_conv_desc;
+int tfmq_conv2d_w4a8(tfmq_handle h, const tfmq_conv_desc* d, void* stream);
+int tfmq_conv2d_f16(tfmq_handle h, const tfmq_conv_desc* d, void* stream);
+
+/* ---- K7: temporal-information block GEMVs (QuantTemporalInformationBlockDDIM.forward,
+ * quant_block.py:52-64; ddim/models/diffusion.py:6-24,310-313) -------------------------- */
+/* emb[m][dim] = [sin(t f_i), cos(t f_i)] (DDIM order, denominator half-1) or
+ * [cos, sin] with denominator half (LDM order, ldm util.py:161-166) when ldm_order != 0 */
+int tfmq_timestep_embedding(tfmq_handle h, const float* t, int m, int dim, int ldm_order, float* emb, void* stream);
+/* y[m][n] = act_in(x[m][k]) @ W^T + b.  silu_in: apply x*sigmoid(x) first.  W fp32 [n][k]. */
+int tfmq_linear_small_f32(tfmq_handle h, const float* x, const float* w, const float* bias, float* y, int m, int n,
+                          int k, int silu_in, void* stream);
+/* same with packed int4 weights (+ optional 8-bit quantisation of the SiLU'd input) */
+int tfmq_linear_small_w4(tfmq_handle h, const float* x, const uint8_t* wpacked, const int32_t* wmeta,
+                         const float* wscale, const float* bias, tfmq_qsel aq, float* y, int m, int n, int k,
+                         int silu_in, void* stream);
+
+/* ---- K8: GroupNorm (+SiLU) (+quantise) (Normalize+nonlinearity, ddim/models/diffusion.py:27-33,
+ * 117-118,123-124; feeding QuantLayer's aqtizer, quant_layer.py:318-325) ------------------ */
+typedef struct tfmq_gn_desc {
+  int32_t B, HW, C1, C2;   /* input = channel concat of x1 [B][HW][C1] and x2 [B][HW][C2] (C2 may be 0):
+                              torch.cat([h, hs.pop()], 1) of ddim/models/diffusion.py:341 never materialises */
+  const float* x1;
+  const float* x2;
+  const float* gamma;      /* [C1+C2] */
+  const float* beta;
+  float eps;
+  int32_t groups;          /* 32 */
+  int32_t silu;            /* apply x*sigmoid(x) after the affine */
+  tfmq_qsel aq;            /* qtable!=NULL: write int8 (bin-128) to yq; else write fp32 to yf */
+  int8_t* yq;
+  float* yf;
+  float* xcat_or_null;     /* optional: also materialise the fp32 concat (input of the FP nin_shortcut) */
+} tfmq_gn_desc;
+int tfmq_groupnorm(tfmq_handle h, const tfmq_gn_desc* d, void* stream);
+
+/* ---- K10: attention core on un-quantised q,k,v (QuantAttnBlock.forward quant_block.py:483-500:
+ * bmm, *c^-1/2, softmax, bmm; attention quantizers are never enabled) ---- */
+/* q,k,v: fp32, token t of batch b head hd at ptr[(b*T + t)*ld + hd*d ...]; out likewise (ldo).
+ * If yq != NULL the result is also quantised (proj_out's aqtizer) to int8. */
+int tfmq_attention(tfmq_handle h, const float* q, const float* k, const float* v, int ldq, int ldk, int ldv,
+                   float* out, int ldo, int8_t* yq, tfmq_qsel aq, int B, int heads, int Tq, int Tk, int d,
+                   float scale, void* stream);
+
+/* ---- K11: sampler elementwise (generalized_steps, ddim/functions/denoising.py:31-37) ----- */
+/* coef: device [n_steps][4] = {sqrt(1-a_t), 1/sqrt(a_t)... see DESIGN.md}; step: device scalar.
+ * x_next = sqrt(a_next)*x0 + c1*z + c2*eps with x0 = (x - eps*sqrt(1-a_t))/sqrt(a_t). */
+int tfmq_ddim_update(tfmq_handle h, const float* x, const float* eps, const float* noise_or_null, float* x_next,
+                     float* x0_or_null, size_t n, const float* coef, const int32_t* step, void* stream);
+int tfmq_step_advance(tfmq_handle h, int32_t* step, int delta, void* stream);
+int tfmq_nchw_to_nhwc(tfmq_handle h, const float* x, float* y, int B, int C, int HW, void* stream);
+int tfmq_nhwc_to_nchw(tfmq_handle h, const float* x, float* y, int B, int C, int HW, void* stream);
+
+/* ---- K12-K14: AdaRound (adaptive_rounding.py; reconstruction_util.py:50-91; Adam) --------- */
+/* alpha = -log(1.2/(w/delta - floor(w/delta) + 0.1) - 1)   (init_alpha :31-38); delta per row */
+int tfmq_adaround_init(tfmq_handle h, const float* w, const float* delta, float* alpha, size_t rows, size_t cols,
+                       void* stream);
+/* soft forward (:40-41,51,59-60,67-69): w_hat = delta*(clamp(floor(w/delta)+h(alpha)+zp,0,L-1)-zp) */
+int tfmq_adaround_soft_fwd(tfmq_handle h, const float* w, const float* alpha, const float* delta, const float* zp,
+                           float* w_hat, size_t rows, size_t cols, int level, void* stream);
+/* backward of the soft forward + rounding regulariser, fused with one Adam step
+ * (torch.optim.Adam defaults lr=1e-3, betas .9/.999, eps 1e-8; reconstruction.py:42):
+ *   g = g_what * delta * [0<floor+h+zp<L-1] * h'(alpha) + w_reg * d/dalpha (1-|2h-1|^b)
+ * g_what: dL/dw_hat from the block backward; b_temp<=0 disables the regulariser (warm-up).
+ * round_loss_or_null accumulates w_reg * sum(1-|2h-1|^b) (one float, atomically). */
+int tfmq_adaround_bwd_adam(tfmq_handle h, const float* w, float* alpha, const float* delta, const float* zp,
+                           const float* g_what, float* m, float* v, size_t rows, size_t cols, int level, float w_reg,
+                           float b_temp, float lr, int t, float* round_loss_or_null, void* stream);
+/* rec = mean over all-but-dim1 of sum_dim1 |pred-tgt|^2 for NHWC tensors == sum(|d|^2)/(n/C)
+ * (lp_loss, quant_layer.py:152-153); also writes g = dL/dpred.  loss: one device float. */
+int tfmq_recon_loss(tfmq_handle h, const float* pred, const float* tgt, float* g_or_null, size_t n, size_t denom,
+                    float* loss, void* stream);
+
+/* ---- stream-capture helpers: a sampler step is captured once into a hipGraph and replayed */
+int tfmq_graph_begin(tfmq_handle h, void* stream);
+int tfmq_graph_end(tfmq_handle h, void* stream, int* graph_id);
+int tfmq_graph_launch(tfmq_handle h, int graph_id, void* stream);
+int tfmq_graph_destroy(tfmq_handle h, int graph_id);
+/* HIP-event timing on a given stream (bench.py roofline leg) */
+int tfmq_event_create(tfmq_handle h, int* event_id);
+int tfmq_event_record(tfmq_handle h, int event_id, void* stream);
+int tfmq_event_elapsed_ms(tfmq_handle h, int start_id, int stop_id, float* ms);
+int tfmq_stream_sync(tfmq_handle h, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TFMQ_HIP_H */

@@ -1,0 +1,165 @@
+"""ctypes binding of libtfmq_hip.so (C ABI in include/tfmq_hip.h).
+
+The product path has no CPU fallback: if the shared library cannot be loaded, or a GPU is
+required and absent, every entry point raises.  PyTorch is used only as the owner of device
+memory (``tensor.data_ptr()``) and of the HIP stream.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libtfmq_hip.so")
+
+c_void_p, c_int, c_size_t, c_float, c_double = C.c_void_p, C.c_int, C.c_size_t, C.c_float, C.c_double
+
+
+class TfmqError(RuntimeError):
+    pass
+
+
+class QSel(C.Structure):
+    """tfmq_qsel: selects {delta, zero_point} of one activation quantizer for the current FSC group."""
+    _fields_ = [("qtable", c_void_p), ("step", c_void_p), ("q_stride", C.c_int32), ("qid", C.c_int32)]
+
+
+class ConvDesc(C.Structure):
+    """tfmq_conv_desc"""
+    _fields_ = [
+        ("B", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("Cin", C.c_int32),
+        ("Cout", C.c_int32), ("KH", C.c_int32), ("KW", C.c_int32), ("stride", C.c_int32),
+        ("pad_t", C.c_int32), ("pad_l", C.c_int32), ("Ho", C.c_int32), ("Wo", C.c_int32),
+        ("up2x", C.c_int32),
+        ("x", c_void_p), ("w", c_void_p), ("wmeta", c_void_p), ("wscale", c_void_p), ("bias", c_void_p),
+        ("aq", QSel),
+        ("rowadd", c_void_p), ("residual", c_void_p), ("y", c_void_p),
+        ("ldy", C.c_int32), ("y_coff", C.c_int32),
+    ]
+
+
+class GnDesc(C.Structure):
+    """tfmq_gn_desc"""
+    _fields_ = [
+        ("B", C.c_int32), ("HW", C.c_int32), ("C1", C.c_int32), ("C2", C.c_int32),
+        ("x1", c_void_p), ("x2", c_void_p), ("gamma", c_void_p), ("beta", c_void_p),
+        ("eps", c_float), ("groups", C.c_int32), ("silu", C.c_int32),
+        ("aq", QSel),
+        ("yq", c_void_p), ("yf", c_void_p), ("xcat", c_void_p),
+    ]
+
+
+# name -> (restype, argtypes); every symbol declared in include/tfmq_hip.h
+_SIGS = {
+    "tfmq_abi_version": (c_int, []),
+    "tfmq_create": (c_int, [c_int, C.POINTER(c_void_p)]),
+    "tfmq_destroy": (c_int, [c_void_p]),
+    "tfmq_last_error": (C.c_char_p, [c_void_p]),
+    "tfmq_device_info": (c_int, [c_void_p, C.POINTER(c_int), C.POINTER(c_int), C.POINTER(c_size_t)]),
+    "tfmq_quantize_act": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, QSel, c_int, c_void_p]),
+    "tfmq_fake_quant": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_size_t, c_void_p, c_void_p, c_int, c_void_p]),
+    "tfmq_minmax_ws_bytes": (c_size_t, [c_size_t, c_size_t]),
+    "tfmq_minmax": (c_int, [c_void_p, c_void_p, c_size_t, c_size_t, c_void_p, c_void_p, c_void_p]),
+    "tfmq_minmax_to_qparam": (c_int, [c_void_p, c_void_p, c_size_t, c_int, c_int, c_void_p, c_void_p]),
+    "tfmq_act_range_update": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_double, c_int, c_int, c_void_p]),
+    "tfmq_mse_ws_bytes": (c_size_t, [c_size_t, c_size_t]),
+    "tfmq_mse_search": (c_int, [c_void_p, c_void_p, c_size_t, c_size_t, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "tfmq_pack_w4": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "tfmq_unpack_w4": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "tfmq_pack_w_f16": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "tfmq_conv2d_w4a8": (c_int, [c_void_p, C.POINTER(ConvDesc), c_void_p]),
+    "tfmq_conv2d_f16": (c_int, [c_void_p, C.POINTER(ConvDesc), c_void_p]),
+    "tfmq_timestep_embedding": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "tfmq_linear_small_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "tfmq_linear_small_w4": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, QSel, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "tfmq_groupnorm": (c_int, [c_void_p, C.POINTER(GnDesc), c_void_p]),
+    "tfmq_attention": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p, QSel,
+                               c_int, c_int, c_int, c_int, c_int, c_float, c_void_p]),
+    "tfmq_ddim_update": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p]),
+    "tfmq_step_advance": (c_int, [c_void_p, c_void_p, c_int, c_void_p]),
+    "tfmq_nchw_to_nhwc": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "tfmq_nhwc_to_nchw": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "tfmq_adaround_init": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_size_t, c_void_p]),
+    "tfmq_adaround_soft_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_size_t, c_int, c_void_p]),
+    "tfmq_adaround_bwd_adam": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_size_t,
+                                       c_int, c_float, c_float, c_float, c_int, c_void_p, c_void_p]),
+    "tfmq_recon_loss": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_size_t, c_void_p, c_void_p]),
+    "tfmq_graph_begin": (c_int, [c_void_p, c_void_p]),
+    "tfmq_graph_end": (c_int, [c_void_p, c_void_p, C.POINTER(c_int)]),
+    "tfmq_graph_launch": (c_int, [c_void_p, c_int, c_void_p]),
+    "tfmq_graph_destroy": (c_int, [c_void_p, c_int]),
+    "tfmq_event_create": (c_int, [c_void_p, C.POINTER(c_int)]),
+    "tfmq_event_record": (c_int, [c_void_p, c_int, c_void_p]),
+    "tfmq_event_elapsed_ms": (c_int, [c_void_p, c_int, c_int, C.POINTER(c_float)]),
+    "tfmq_stream_sync": (c_int, [c_void_p, c_void_p]),
+}
+
+EXPORTED_SYMBOLS = tuple(_SIGS)
+
+_lib: Optional[C.CDLL] = None
+
+
+def load() -> C.CDLL:
+    """Load the shared library (no GPU needed for this step) and type every entry point."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise TfmqError(
+            f"{LIB_PATH} is missing: build it with `python tfmq-dm_amd/build.py` (or __graft_entry__.build()). "
+            "There is no CPU fallback for the TFMQ hot path.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGS.items():
+        fn = getattr(lib, name)  # AttributeError if the library does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+class Handle:
+    """One tfmq_handle bound to a device.  `h.call("conv2d_w4a8", ...)` raises TfmqError on failure."""
+
+    def __init__(self, device: int = 0):
+        self.lib = load()
+        hp = c_void_p()
+        rc = self.lib.tfmq_create(int(device), C.byref(hp))
+        if rc != 0 or not hp.value:
+            raise TfmqError(f"tfmq_create(device={device}) failed with {rc}: no usable HIP device "
+                            "(the TFMQ hot path has no CPU fallback)")
+        self.h = hp
+        self.device = device
+
+    def call(self, name: str, *args):
+        fn = getattr(self.lib, "tfmq_" + name)
+        rc = fn(self.h, *args)
+        if rc != 0:
+            msg = self.lib.tfmq_last_error(self.h)
+            raise TfmqError(f"tfmq_{name} failed ({rc}): {msg.decode() if msg else '?'}")
+        return rc
+
+    def device_info(self):
+        cu, khz, mem = c_int(), c_int(), c_size_t()
+        self.call("device_info", C.byref(cu), C.byref(khz), C.byref(mem))
+        return cu.value, khz.value, mem.value
+
+    def close(self):
+        if getattr(self, "h", None) is not None and self.h.value:
+            self.lib.tfmq_destroy(self.h)
+            self.h = c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+_handles = {}
+
+
+def handle(device: int = 0) -> Handle:
+    if device not in _handles:
+        _handles[device] = Handle(device)
+    return _handles[device]

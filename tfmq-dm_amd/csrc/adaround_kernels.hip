@@ -1,0 +1,144 @@
+// K12-K14: AdaRound soft rounding forward / backward, rounding regulariser, Adam step and the
+// reconstruction loss (quant/adaptive_rounding.py; quant/reconstruction_util.py:50-91;
+// quant/quant_layer.py:146-156; torch.optim.Adam defaults, quant/reconstruction.py:42).
+// Elementwise over weight-sized tensors, HBM-bound: one fused pass reads w, alpha, m, v, g and
+// writes alpha, m, v (32 B/element) instead of the ~20 ATen passes of one reference iteration.
+#include "common.hpp"
+
+#define ADA_GAMMA (-0.1f)
+#define ADA_ZETA_M_GAMMA (1.2f)  // fp32(1.1 - (-0.1))
+
+__device__ __forceinline__ float sigmoid_f(float a) { return 1.0f / (1.0f + expf(-a)); }
+
+__global__ __launch_bounds__(256) void k_adaround_init(const float* __restrict__ w, const float* __restrict__ delta,
+                                                       float* __restrict__ alpha, size_t rows, size_t cols) {
+  const size_t n = rows * cols, stride = static_cast<size_t>(gridDim.x) * blockDim.x;
+  for (size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const float d = delta[i / cols];
+    const float t = w[i] / d;
+    const float rest = t - floorf(t);
+    alpha[i] = -logf(ADA_ZETA_M_GAMMA / (rest - ADA_GAMMA) - 1.0f);
+  }
+}
+
+extern "C" int tfmq_adaround_init(tfmq_handle h, const float* w, const float* delta, float* alpha, size_t rows,
+                                  size_t cols, void* stream) {
+  TFMQ_CHECK_ARG(h, h && w && delta && alpha && rows > 0 && cols > 0, "adaround_init: bad argument");
+  int blocks = ceil_div(static_cast<long>(rows * cols), 256);
+  if (blocks > h->cu_count * 8) blocks = h->cu_count * 8;
+  hipLaunchKernelGGL(k_adaround_init, dim3(blocks), dim3(256), 0, as_stream(stream), w, delta, alpha, rows, cols);
+  TFMQ_LAUNCH_CHECK(h);
+  return TFMQ_OK;
+}
+
+__global__ __launch_bounds__(256) void k_adaround_soft_fwd(const float* __restrict__ w, const float* __restrict__ alpha,
+                                                           const float* __restrict__ delta, const float* __restrict__ zp,
+                                                           float* __restrict__ w_hat, size_t rows, size_t cols,
+                                                           float lmax) {
+  const size_t n = rows * cols, stride = static_cast<size_t>(gridDim.x) * blockDim.x;
+  for (size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const size_t r = i / cols;
+    const float d = delta[r], z = zp[r];
+    float hsoft = sigmoid_f(alpha[i]) * ADA_ZETA_M_GAMMA + ADA_GAMMA;
+    hsoft = fminf(fmaxf(hsoft, 0.0f), 1.0f);
+    float q = floorf(w[i] / d) + hsoft;
+    q = fminf(fmaxf(q + z, 0.0f), lmax);
+    w_hat[i] = d * (q - z);
+  }
+}
+
+extern "C" int tfmq_adaround_soft_fwd(tfmq_handle h, const float* w, const float* alpha, const float* delta,
+                                      const float* zp, float* w_hat, size_t rows, size_t cols, int level, void* stream) {
+  TFMQ_CHECK_ARG(h, h && w && alpha && delta && zp && w_hat && rows > 0 && cols > 0, "adaround_soft_fwd: bad argument");
+  int blocks = ceil_div(static_cast<long>(rows * cols), 256);
+  if (blocks > h->cu_count * 8) blocks = h->cu_count * 8;
+  hipLaunchKernelGGL(k_adaround_soft_fwd, dim3(blocks), dim3(256), 0, as_stream(stream), w, alpha, delta, zp, w_hat,
+                     rows, cols, static_cast<float>(level - 1));
+  TFMQ_LAUNCH_CHECK(h);
+  return TFMQ_OK;
+}
+
+// backward through w_hat = d*(clamp(floor(w/d) + h(alpha) + z, 0, L-1) - z) and the regulariser
+// w_reg*sum(1 - |2h-1|^b), then Adam.  torch.clamp passes the gradient on the closed interval.
+__global__ __launch_bounds__(256) void k_adaround_bwd_adam(const float* __restrict__ w, float* __restrict__ alpha,
+                                                           const float* __restrict__ delta, const float* __restrict__ zp,
+                                                           const float* __restrict__ g_what, float* __restrict__ m,
+                                                           float* __restrict__ v, size_t rows, size_t cols, float lmax,
+                                                           float w_reg, float b_temp, float step_size, float bc2_sqrt,
+                                                           float* __restrict__ round_loss) {
+  const float beta1 = 0.9f, beta2 = 0.999f, eps = 1e-8f;
+  const size_t n = rows * cols, stride = static_cast<size_t>(gridDim.x) * blockDim.x;
+  float rl = 0.0f;
+  for (size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const size_t r = i / cols;
+    const float d = delta[r], z = zp[r];
+    const float a = alpha[i];
+    const float sg = sigmoid_f(a);
+    const float hs = sg * ADA_ZETA_M_GAMMA + ADA_GAMMA;
+    const float hsoft = fminf(fmaxf(hs, 0.0f), 1.0f);
+    const float qv = floorf(w[i] / d) + hsoft + z;
+    float gh = (qv >= 0.0f && qv <= lmax) ? g_what[i] * d : 0.0f;
+    if (b_temp > 0.0f) {
+      const float c = hsoft - 0.5f;
+      const float u = fabsf(c) * 2.0f;
+      const float ub1 = powf(u, b_temp - 1.0f);
+      rl += 1.0f - ub1 * u;
+      const float sgn = c > 0.0f ? 1.0f : (c < 0.0f ? -1.0f : 0.0f);
+      gh += -w_reg * b_temp * ub1 * 2.0f * sgn;
+    }
+    const float g = (hs >= 0.0f && hs <= 1.0f) ? gh * (ADA_ZETA_M_GAMMA * sg * (1.0f - sg)) : 0.0f;
+    // Adam (torch single-tensor form)
+    const float mi = m[i] + (g - m[i]) * (1.0f - beta1);
+    const float vi = v[i] * beta2 + (1.0f - beta2) * g * g;
+    m[i] = mi;
+    v[i] = vi;
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    alpha[i] = a - step_size * (mi / denom);
+  }
+  if (round_loss && b_temp > 0.0f) {
+    rl = wave_reduce_sum(rl);
+    if ((threadIdx.x & 63) == 0) atomicAdd(round_loss, w_reg * rl);
+  }
+}
+
+extern "C" int tfmq_adaround_bwd_adam(tfmq_handle h, const float* w, float* alpha, const float* delta, const float* zp,
+                                      const float* g_what, float* m, float* v, size_t rows, size_t cols, int level,
+                                      float w_reg, float b_temp, float lr, int t, float* round_loss, void* stream) {
+  TFMQ_CHECK_ARG(h, h && w && alpha && delta && zp && g_what && m && v && rows > 0 && cols > 0 && t >= 1,
+                 "adaround_bwd_adam: bad argument");
+  const double bc1 = 1.0 - pow(0.9, t), bc2 = 1.0 - pow(0.999, t);
+  int blocks = ceil_div(static_cast<long>(rows * cols), 256);
+  if (blocks > h->cu_count * 8) blocks = h->cu_count * 8;
+  hipLaunchKernelGGL(k_adaround_bwd_adam, dim3(blocks), dim3(256), 0, as_stream(stream), w, alpha, delta, zp, g_what, m,
+                     v, rows, cols, static_cast<float>(level - 1), w_reg, b_temp, static_cast<float>(lr / bc1),
+                     static_cast<float>(sqrt(bc2)), round_loss);
+  TFMQ_LAUNCH_CHECK(h);
+  return TFMQ_OK;
+}
+
+// loss = sum |pred - tgt|^2 / denom  (lp_loss p=2: sum over dim 1, mean over the rest => denom =
+// numel / size(1)); g = 2 (pred - tgt) / denom
+__global__ __launch_bounds__(256) void k_recon_loss(const float* __restrict__ pred, const float* __restrict__ tgt,
+                                                    float* __restrict__ g, size_t n, float inv_denom,
+                                                    float* __restrict__ loss) {
+  const size_t stride = static_cast<size_t>(gridDim.x) * blockDim.x;
+  double acc = 0.0;
+  for (size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const float dlt = pred[i] - tgt[i];
+    acc += static_cast<double>(dlt) * dlt;
+    if (g) g[i] = 2.0f * dlt * inv_denom;
+  }
+  acc = wave_reduce_sum_d(acc);
+  if ((threadIdx.x & 63) == 0) atomicAdd(loss, static_cast<float>(acc * inv_denom));
+}
+
+extern "C" int tfmq_recon_loss(tfmq_handle h, const float* pred, const float* tgt, float* g, size_t n, size_t denom,
+                               float* loss, void* stream) {
+  TFMQ_CHECK_ARG(h, h && pred && tgt && loss && n > 0 && denom > 0, "recon_loss: bad argument");
+  int blocks = ceil_div(static_cast<long>(n), 1024);
+  if (blocks > h->cu_count * 4) blocks = h->cu_count * 4;
+  hipLaunchKernelGGL(k_recon_loss, dim3(blocks), dim3(256), 0, as_stream(stream), pred, tgt, g, n,
+                     static_cast<float>(1.0 / static_cast<double>(denom)), loss);
+  TFMQ_LAUNCH_CHECK(h);
+  return TFMQ_OK;
+}

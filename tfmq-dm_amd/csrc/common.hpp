@@ -1,0 +1,87 @@
+// Internal helpers shared by the gfx950 kernels of libtfmq_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+#include "../../include/tfmq_hip.h"
+
+struct tfmq_ctx {
+  int device = 0;
+  int cu_count = 256;
+  int clock_khz = 2400000;
+  size_t hbm_bytes = 0;
+  std::string err;
+  std::vector<hipGraphExec_t> graphs;
+  std::vector<hipEvent_t> events;
+};
+
+#define TFMQ_CHECK_ARG(h, cond, msg)          \
+  do {                                        \
+    if (!(cond)) {                            \
+      if (h) (h)->err = std::string("bad argument: ") + (msg); \
+      return TFMQ_ERR_ARG;                    \
+    }                                         \
+  } while (0)
+
+#define TFMQ_HIP(h, expr)                                                            \
+  do {                                                                               \
+    hipError_t e__ = (expr);                                                         \
+    if (e__ != hipSuccess) {                                                         \
+      if (h) (h)->err = std::string(#expr) + ": " + hipGetErrorString(e__);          \
+      return TFMQ_ERR_HIP;                                                           \
+    }                                                                                \
+  } while (0)
+
+#define TFMQ_LAUNCH_CHECK(h)                                                         \
+  do {                                                                               \
+    hipError_t e__ = hipGetLastError();                                              \
+    if (e__ != hipSuccess) {                                                         \
+      if (h) (h)->err = std::string("kernel launch: ") + hipGetErrorString(e__);     \
+      return TFMQ_ERR_HIP;                                                           \
+    }                                                                                \
+  } while (0)
+
+static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+// ---------------------------------------------------------------- device helpers
+__device__ __forceinline__ float2 load_qparam(const tfmq_qsel& qs) {
+  // {delta, zero_point} of the current FSC group
+  int k = qs.step ? *qs.step : 0;
+  const float* p = qs.qtable + (static_cast<size_t>(k) * qs.q_stride + qs.qid) * 2;
+  return make_float2(p[0], p[1]);
+}
+
+// q = clamp(rint(x/delta)+zp, 0, L-1): true IEEE division, round-half-even
+// (quant/quant_layer.py:225).  Compiled without fast-math.
+__device__ __forceinline__ float quant_index_f(float x, float delta, float zp, float lmax) {
+  float q = rintf(x / delta) + zp;
+  return fminf(fmaxf(q, 0.0f), lmax);
+}
+
+__device__ __forceinline__ float wave_reduce_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ double wave_reduce_sum_d(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_reduce_min(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ float wave_reduce_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+__device__ __forceinline__ float silu_f(float x) { return x * (1.0f / (1.0f + expf(-x))); }
+
+static inline int ceil_div(long a, long b) { return static_cast<int>((a + b - 1) / b); }

@@ -1,0 +1,324 @@
+// K5/K6: Conv2d / Linear as implicit GEMM on the gfx950 matrix cores.
+//
+//   w4a8 path : A = int8 NHWC activations (bin-128), B = packed int4 weights unpacked to
+//               int8 while staging, v_mfma_i32_32x32x32_i8, exact int32 accumulation.
+//               y = da*dw[c] * ( sum a'.q_w - zw[c]*sum_k a' + (128-za)*(sum_k q_w - K*zw[c]) ) + b[c]
+//               which equals the reference's F.conv2d on the two fake-quantised operands
+//               (quant/quant_layer.py:318-338) up to fp32 rounding of the final scale.
+//               Zero padding must be a *real* zero => padded taps carry a' = za-128.
+//   f16  path : un-quantised layers (conv_in/conv_out, nin_shortcut, downsample.conv;
+//               quant/quant_model.py:57-58,103-120): A = fp32 NHWC converted to f16 while
+//               staging, B = f16, v_mfma_f32_32x32x16_f16 with fp32 accumulation.
+//
+// GEMM view: M = B*Ho*Wo output pixels, N = Cout, K = KH*KW*Cin ordered (kh,kw,cin) so a
+// K-step is 64 contiguous bytes of one input pixel.  256 threads = 4 waves; LDS rows are
+// 64 bytes (64 int8 or 32 f16) with a 16-byte-slot XOR swizzle so ds_read_b128 fragment
+// reads and ds_write_b128 staging writes are bank-conflict free.  Register-prefetched,
+// double-buffered LDS, one barrier per K-step.
+#include "common.hpp"
+#include <type_traits>
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v16i __attribute__((ext_vector_type(16)));
+typedef float v16f __attribute__((ext_vector_type(16)));
+typedef _Float16 v8h __attribute__((ext_vector_type(8)));
+
+struct ConvP {
+  tfmq_conv_desc d;
+  int M;        // B*Ho*Wo
+  int chunks;   // K-steps per tap
+  int nsteps;   // KH*KW*chunks
+  int Ktot;     // KH*KW*Cin
+  int cin_pad;  // f16 path: padded Cin of the weight layout
+  int Hv, Wv;   // virtual input size (2H,2W when up2x)
+  int tiles_n;
+};
+
+__device__ __forceinline__ int swz(int row, int slot) { return row * 64 + ((slot ^ ((row >> 2) & 3)) << 4); }
+
+template <bool INT8, int WAVES_M, int WAVES_N, int WM_TILES, int WN_TILES>
+__global__ __launch_bounds__(256) void k_conv_igemm(ConvP p) {
+  constexpr int BM = WAVES_M * WM_TILES * 32;
+  constexpr int BN = WAVES_N * WN_TILES * 32;
+  constexpr int CK = INT8 ? 64 : 32;            // channels per K-step
+  constexpr int A_ITEMS = BM * 4 / 256;         // 16-byte LDS items per thread (A)
+  constexpr int B_TOTAL = INT8 ? BN * 2 : BN * 4;
+  constexpr int B_ITEMS = (B_TOTAL + 255) / 256;
+  static_assert(WAVES_M * WAVES_N == 4, "4 waves");
+  static_assert(BM * 4 % 256 == 0, "A items");
+
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * (BM + BN) * 64 + BM * 4];
+  auto ldsA = [&](int buf) -> unsigned char* { return lds + buf * ((BM + BN) * 64); };
+  auto ldsB = [&](int buf) -> unsigned char* { return lds + buf * ((BM + BN) * 64) + BM * 64; };
+  int* ldsS = reinterpret_cast<int*>(lds + 2 * (BM + BN) * 64);
+
+  const tfmq_conv_desc& d = p.d;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid / WAVES_N, wn = wid % WAVES_N;
+  const int tile_n = blockIdx.x % p.tiles_n, tile_m = blockIdx.x / p.tiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+  float2 aqp = make_float2(1.0f, 0.0f);
+  int za = 0;
+  unsigned pad_word = 0;
+  if constexpr (INT8) {
+    aqp = load_qparam(d.aq);
+    za = static_cast<int>(aqp.y);
+    const unsigned pb = static_cast<unsigned>(za - 128) & 0xffu;  // real zero == bin za
+    pad_word = pb * 0x01010101u;
+  }
+
+  // ---- per-thread A rows (fixed for the whole K loop)
+  int a_row[A_ITEMS], a_slot[A_ITEMS], a_b[A_ITEMS], a_ho[A_ITEMS], a_wo[A_ITEMS];
+  bool a_ok[A_ITEMS];
+#pragma unroll
+  for (int it = 0; it < A_ITEMS; ++it) {
+    const int item = tid + it * 256;
+    a_row[it] = item >> 2;
+    a_slot[it] = item & 3;
+    const int m = m0 + a_row[it];
+    a_ok[it] = m < p.M;
+    const int mm = a_ok[it] ? m : 0;
+    const int hw = d.Ho * d.Wo;
+    a_b[it] = mm / hw;
+    const int r = mm - a_b[it] * hw;
+    a_ho[it] = r / d.Wo;
+    a_wo[it] = r - a_ho[it] * d.Wo;
+  }
+  int a_sum[A_ITEMS];
+#pragma unroll
+  for (int it = 0; it < A_ITEMS; ++it) a_sum[it] = 0;
+
+  uint4 a_reg[A_ITEMS];
+  uint4 b_reg[B_ITEMS];
+
+  auto load_step = [&](int s) {
+    const int tap = s / p.chunks;
+    const int c0 = (s - tap * p.chunks) * CK;
+    const int kh = tap / d.KW, kw = tap - kh * d.KW;
+    // ---- A
+#pragma unroll
+    for (int it = 0; it < A_ITEMS; ++it) {
+      int hi = a_ho[it] * d.stride + kh - d.pad_t;
+      int wi = a_wo[it] * d.stride + kw - d.pad_l;
+      const bool ok = a_ok[it] && hi >= 0 && hi < p.Hv && wi >= 0 && wi < p.Wv;
+      if (d.up2x) {
+        hi >>= 1;
+        wi >>= 1;
+      }
+      const size_t pix = (static_cast<size_t>(a_b[it]) * d.H + hi) * d.W + wi;
+      if constexpr (INT8) {
+        uint4 v = make_uint4(pad_word, pad_word, pad_word, pad_word);
+        if (ok) v = *reinterpret_cast<const uint4*>(static_cast<const int8_t*>(d.x) + pix * d.Cin + c0 + a_slot[it] * 16);
+        a_reg[it] = v;
+      } else {
+        const int c = c0 + a_slot[it] * 8;
+        float f[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f[j] = 0.0f;
+        if (ok) {
+          const float* src = static_cast<const float*>(d.x) + pix * d.Cin + c;
+          if ((d.Cin & 3) == 0 && c + 8 <= d.Cin) {
+            const float4 v0 = *reinterpret_cast<const float4*>(src);
+            const float4 v1 = *reinterpret_cast<const float4*>(src + 4);
+            f[0] = v0.x; f[1] = v0.y; f[2] = v0.z; f[3] = v0.w;
+            f[4] = v1.x; f[5] = v1.y; f[6] = v1.z; f[7] = v1.w;
+          } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+              if (c + j < d.Cin) f[j] = src[j];
+          }
+        }
+        v8h hv;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) hv[j] = static_cast<_Float16>(f[j]);
+        a_reg[it] = *reinterpret_cast<uint4*>(&hv);
+      }
+    }
+    // ---- B
+#pragma unroll
+    for (int it = 0; it < B_ITEMS; ++it) {
+      const int item = tid + it * 256;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (item < B_TOTAL) {
+        if constexpr (INT8) {
+          const int n = n0 + (item >> 1);
+          if (n < d.Cout)
+            v = *reinterpret_cast<const uint4*>(static_cast<const uint8_t*>(d.w) + static_cast<size_t>(n) * (p.Ktot >> 1) +
+                                                ((tap * d.Cin + c0) >> 1) + (item & 1) * 16);
+        } else {
+          const int n = n0 + (item >> 2);
+          if (n < d.Cout)
+            v = *reinterpret_cast<const uint4*>(static_cast<const __half*>(d.w) +
+                                                (static_cast<size_t>(n) * (d.KH * d.KW) + tap) * p.cin_pad + c0 + (item & 3) * 8);
+        }
+      }
+      b_reg[it] = v;
+    }
+  };
+
+  auto store_step = [&](int buf) {
+#pragma unroll
+    for (int it = 0; it < A_ITEMS; ++it) {
+      *reinterpret_cast<uint4*>(ldsA(buf) + swz(a_row[it], a_slot[it])) = a_reg[it];
+      if constexpr (INT8) {
+        int s = a_sum[it];
+        s = __builtin_amdgcn_sdot4(static_cast<int>(a_reg[it].x), 0x01010101, s, false);
+        s = __builtin_amdgcn_sdot4(static_cast<int>(a_reg[it].y), 0x01010101, s, false);
+        s = __builtin_amdgcn_sdot4(static_cast<int>(a_reg[it].z), 0x01010101, s, false);
+        s = __builtin_amdgcn_sdot4(static_cast<int>(a_reg[it].w), 0x01010101, s, false);
+        a_sum[it] = s;
+      }
+    }
+#pragma unroll
+    for (int it = 0; it < B_ITEMS; ++it) {
+      const int item = tid + it * 256;
+      if (item < B_TOTAL) {
+        if constexpr (INT8) {
+          const int row = item >> 1, half = item & 1;
+          const uint4 v = b_reg[it];
+          uint4 lo, hi;  // word j of the packed 16 B holds k = 8j..8j+7
+          lo.x = v.x & 0x0f0f0f0fu; lo.y = (v.x >> 4) & 0x0f0f0f0fu;
+          lo.z = v.y & 0x0f0f0f0fu; lo.w = (v.y >> 4) & 0x0f0f0f0fu;
+          hi.x = v.z & 0x0f0f0f0fu; hi.y = (v.z >> 4) & 0x0f0f0f0fu;
+          hi.z = v.w & 0x0f0f0f0fu; hi.w = (v.w >> 4) & 0x0f0f0f0fu;
+          *reinterpret_cast<uint4*>(ldsB(buf) + swz(row, half * 2)) = lo;
+          *reinterpret_cast<uint4*>(ldsB(buf) + swz(row, half * 2 + 1)) = hi;
+        } else {
+          *reinterpret_cast<uint4*>(ldsB(buf) + swz(item >> 2, item & 3)) = b_reg[it];
+        }
+      }
+    }
+  };
+
+  using acc_t = typename std::conditional<INT8, v16i, v16f>::type;
+  acc_t acc[WM_TILES][WN_TILES];
+#pragma unroll
+  for (int i = 0; i < WM_TILES; ++i)
+#pragma unroll
+    for (int j = 0; j < WN_TILES; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0;
+
+  load_step(0);
+  for (int s = 0; s < p.nsteps; ++s) {
+    const int buf = s & 1;
+    store_step(buf);
+    __syncthreads();
+    if (s + 1 < p.nsteps) load_step(s + 1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      uint4 af[WM_TILES], bf[WN_TILES];
+      const int kslot = ks * 2 + (lane >> 5);
+#pragma unroll
+      for (int i = 0; i < WM_TILES; ++i)
+        af[i] = *reinterpret_cast<const uint4*>(ldsA(buf) + swz((wm * WM_TILES + i) * 32 + (lane & 31), kslot));
+#pragma unroll
+      for (int j = 0; j < WN_TILES; ++j)
+        bf[j] = *reinterpret_cast<const uint4*>(ldsB(buf) + swz((wn * WN_TILES + j) * 32 + (lane & 31), kslot));
+#pragma unroll
+      for (int i = 0; i < WM_TILES; ++i)
+#pragma unroll
+        for (int j = 0; j < WN_TILES; ++j) {
+          if constexpr (INT8) {
+            acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(*reinterpret_cast<v4i*>(&af[i]),
+                                                              *reinterpret_cast<v4i*>(&bf[j]), acc[i][j], 0, 0, 0);
+          } else {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<v8h*>(&af[i]),
+                                                               *reinterpret_cast<v8h*>(&bf[j]), acc[i][j], 0, 0, 0);
+          }
+        }
+    }
+  }
+
+  // ---- per-row activation sums (w4a8): 4 adjacent lanes share a row
+  if constexpr (INT8) {
+#pragma unroll
+    for (int it = 0; it < A_ITEMS; ++it) {
+      int s = a_sum[it];
+      s += __shfl_xor(s, 1, 64);
+      s += __shfl_xor(s, 2, 64);
+      if (a_slot[it] == 0) ldsS[a_row[it]] = s;
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+  const int hw = d.Ho * d.Wo;
+#pragma unroll
+  for (int j = 0; j < WN_TILES; ++j) {
+    const int n = n0 + (wn * WN_TILES + j) * 32 + (lane & 31);
+    if (n >= d.Cout) continue;
+    float sc = 1.0f, bias = d.bias ? d.bias[n] : 0.0f;
+    int zw = 0, corr = 0;
+    if constexpr (INT8) {
+      const int4 wmv = reinterpret_cast<const int4*>(d.wmeta)[n];
+      zw = wmv.x;
+      corr = (128 - za) * (wmv.y - p.Ktot * zw);
+      sc = aqp.x * d.wscale[n];
+    }
+#pragma unroll
+    for (int i = 0; i < WM_TILES; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (wm * WM_TILES + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        const int m = m0 + row;
+        if (m >= p.M) continue;
+        float v;
+        if constexpr (INT8) {
+          const int t = acc[i][j][r] - zw * ldsS[row] + corr;
+          v = sc * static_cast<float>(t) + bias;
+        } else {
+          v = acc[i][j][r] + bias;
+        }
+        if (d.rowadd) v += d.rowadd[static_cast<size_t>(m / hw) * d.Cout + n];
+        if (d.residual) v += d.residual[static_cast<size_t>(m) * d.Cout + n];
+        d.y[static_cast<size_t>(m) * d.ldy + d.y_coff + n] = v;
+      }
+    }
+  }
+}
+
+template <bool INT8>
+static int launch_conv(tfmq_handle h, const tfmq_conv_desc* dd, void* stream) {
+  TFMQ_CHECK_ARG(h, h && dd, "conv: null pointer");
+  const tfmq_conv_desc& d = *dd;
+  TFMQ_CHECK_ARG(h, d.x && d.w && d.y, "conv: null operand");
+  TFMQ_CHECK_ARG(h, d.B > 0 && d.H > 0 && d.W > 0 && d.Cin > 0 && d.Cout > 0 && d.KH > 0 && d.KW > 0 && d.stride > 0,
+                 "conv: bad geometry");
+  TFMQ_CHECK_ARG(h, d.Ho > 0 && d.Wo > 0 && d.ldy >= d.Cout + d.y_coff, "conv: bad output geometry");
+  ConvP p;
+  p.d = d;
+  p.M = d.B * d.Ho * d.Wo;
+  p.Hv = d.up2x ? 2 * d.H : d.H;
+  p.Wv = d.up2x ? 2 * d.W : d.W;
+  p.Ktot = d.KH * d.KW * d.Cin;
+  if (INT8) {
+    TFMQ_CHECK_ARG(h, d.Cin % 64 == 0, "conv_w4a8: Cin must be a multiple of 64");
+    TFMQ_CHECK_ARG(h, d.wmeta && d.wscale && d.aq.qtable, "conv_w4a8: wmeta/wscale/aq required");
+    p.chunks = d.Cin / 64;
+    p.cin_pad = d.Cin;
+  } else {
+    p.chunks = (d.Cin + 31) / 32;
+    p.cin_pad = p.chunks * 32;
+  }
+  p.nsteps = d.KH * d.KW * p.chunks;
+  const bool narrow = d.Cout <= 32;
+  const int BM = 128, BN = narrow ? 32 : 128;
+  p.tiles_n = (d.Cout + BN - 1) / BN;
+  const int tiles_m = (p.M + BM - 1) / BM;
+  dim3 grid(static_cast<unsigned>(p.tiles_n) * tiles_m);
+  if (narrow)
+    hipLaunchKernelGGL((k_conv_igemm<INT8, 4, 1, 1, 1>), grid, dim3(256), 0, as_stream(stream), p);
+  else
+    hipLaunchKernelGGL((k_conv_igemm<INT8, 2, 2, 2, 2>), grid, dim3(256), 0, as_stream(stream), p);
+  TFMQ_LAUNCH_CHECK(h);
+  return TFMQ_OK;
+}
+
+extern "C" int tfmq_conv2d_w4a8(tfmq_handle h, const tfmq_conv_desc* d, void* stream) {
+  return launch_conv<true>(h, d, stream);
+}
+extern "C" int tfmq_conv2d_f16(tfmq_handle h, const tfmq_conv_desc* d, void* stream) {
+  return launch_conv<false>(h, d, stream);
+}

@@ -1,0 +1,435 @@
+// K1-K4: activation quantiser, min/max statistics, MSE scale search, int4 weight packing.
+// HBM-bound scan/reduce kernels: 16-byte loads, wave shuffles for the reductions, one pass
+// over the data per statistic (the reference makes 6-8 elementwise passes per call,
+// quant/quant_layer.py:20-64,223-244).
+#include "common.hpp"
+
+// ------------------------------------------------------------------------------ K1
+__global__ __launch_bounds__(256) void k_quantize_act(const float* __restrict__ x, int8_t* __restrict__ q, size_t n,
+                                                      tfmq_qsel qs, float lmax) {
+  const float2 p = load_qparam(qs);
+  const size_t n4 = n >> 2;
+  const size_t stride = static_cast<size_t>(gridDim.x) * blockDim.x;
+  const float4* x4 = reinterpret_cast<const float4*>(x);
+  char4* q4 = reinterpret_cast<char4*>(q);
+  for (size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    float4 v = x4[i];
+    char4 o;
+    o.x = static_cast<signed char>(static_cast<int>(quant_index_f(v.x, p.x, p.y, lmax)) - 128);
+    o.y = static_cast<signed char>(static_cast<int>(quant_index_f(v.y, p.x, p.y, lmax)) - 128);
+    o.z = static_cast<signed char>(static_cast<int>(quant_index_f(v.z, p.x, p.y, lmax)) - 128);
+    o.w = static_cast<signed char>(static_cast<int>(quant_index_f(v.w, p.x, p.y, lmax)) - 128);
+    q4[i] = o;
+  }
+  // tail
+  if (blockIdx.x == 0) {
+    for (size_t i = (n4 << 2) + threadIdx.x; i < n; i += blockDim.x)
+      q[i] = static_cast<int8_t>(static_cast<int>(quant_index_f(x[i], p.x, p.y, lmax)) - 128);
+  }
+}
+
+extern "C" int tfmq_quantize_act(tfmq_handle h, const float* x, int8_t* q, size_t n, tfmq_qsel qs, int level,
+                                 void* stream) {
+  TFMQ_CHECK_ARG(h, h && x && q && qs.qtable, "quantize_act: null pointer");
+  TFMQ_CHECK_ARG(h, level >= 2 && level <= 256, "quantize_act: level must be in [2,256]");
+  TFMQ_CHECK_ARG(h, (reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(q) & 3) == 0,
+                 "quantize_act: x must be 16-byte and q 4-byte aligned");
+  if (n == 0) return TFMQ_OK;
+  int blocks = ceil_div(static_cast<long>((n + 3) / 4), 256);
+  if (blocks > h->cu_count * 8) blocks = h->cu_count * 8;
+  hipLaunchKernelGGL(k_quantize_act, dim3(blocks), dim3(256), 0, as_stream(stream), x, q, n, qs,
+                     static_cast<float>(level - 1));
+  TFMQ_LAUNCH_CHECK(h);
+  return TFMQ_OK;
+}
+
+// fake-quant with per-row (or per-tensor, rows==1) parameters; optional index output
+__global__ __launch_bounds__(256) void k_fake_quant(const float* __restrict__ x, float* __restrict__ y,
+                                                    uint8_t* __restrict__ idx, size_t rows, size_t cols,
+                                                    const float* __restrict__ delta, const float* __restrict__ zp,
+                                                    float lmax) {
+  const size_t n = rows * cols;
+  const size_t stride = static_cast<size_t>(gridDim.x) * blockDim.x;
+  for (size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const size_t r = i / cols;
+    const float d = delta[r], z = zp[r];
+    const float q = quant_index_f(x[i], d, z, lmax);
+    if (y) y[i] = d * (q - z);
+    if (idx) idx[i] = static_cast<uint8_t>(static_cast<int>(q));
+  }
+}
+
+extern "C" int tfmq_fake_quant(tfmq_handle h, const float* x, float* y, uint8_t* idx, size_t rows, size_t cols,
+                               const float* delta, const float* zp, int level, void* stream) {
+  TFMQ_CHECK_ARG(h, h && x && delta && zp && (y || idx), "fake_quant: null pointer");
+  TFMQ_CHECK_ARG(h, level >= 2 && level <= 256, "fake_quant: level must be in [2,256]");
+  const size_t n = rows * cols;
+  if (n == 0) return TFMQ_OK;
+  int blocks = ceil_div(static_cast<long>(n), 256);
+  if (blocks > h->cu_count * 8) blocks = h->cu_count * 8;
+  hipLaunchKernelGGL(k_fake_quant, dim3(blocks), dim3(256), 0, as_stream(stream), x, y, idx, rows, cols, delta, zp,
+                     static_cast<float>(level - 1));
+  TFMQ_LAUNCH_CHECK(h);
+  return TFMQ_OK;
+}
+
+// ------------------------------------------------------------------------------ K2
+// grid = (bpr, rows): block (j, r) reduces a contiguous slice of row r.
+static inline int blocks_per_row(size_t rows, size_t cols, int cu) {
+  long want = static_cast<long>(cu) * 8 / static_cast<long>(rows ? rows : 1);
+  if (want < 1) want = 1;
+  long maxb = static_cast<long>((cols + 4095) / 4096);  // >= 16 elements per thread
+  if (maxb < 1) maxb = 1;
+  if (want > maxb) want = maxb;
+  if (want > 1024) want = 1024;
+  return static_cast<int>(want);
+}
+
+__global__ __launch_bounds__(256) void k_minmax_partial(const float* __restrict__ x, size_t cols, int bpr,
+                                                        float2* __restrict__ part) {
+  const size_t r = blockIdx.y;
+  const float* row = x + r * cols;
+  const size_t chunk = (cols + bpr - 1) / bpr;
+  const size_t beg = static_cast<size_t>(blockIdx.x) * chunk;
+  size_t end = beg + chunk;
+  if (end > cols) end = cols;
+  float lo = INFINITY, hi = -INFINITY;
+  // vector body when the slice start is 16-byte aligned
+  size_t i = beg + threadIdx.x;
+  if (((reinterpret_cast<uintptr_t>(row + beg)) & 15) == 0) {
+    const float4* p = reinterpret_cast<const float4*>(row + beg);
+    const size_t n4 = (end > beg) ? (end - beg) >> 2 : 0;
+    for (size_t j = threadIdx.x; j < n4; j += blockDim.x) {
+      float4 v = p[j];
+      lo = fminf(fminf(lo, v.x), fminf(v.y, fminf(v.z, v.w)));
+      hi = fmaxf(fmaxf(hi, v.x), fmaxf(v.y, fmaxf(v.z, v.w)));
+    }
+    i = beg + (n4 << 2) + threadIdx.x;
+  }
+  for (; i < end; i += blockDim.x) {
+    float v = row[i];
+    lo = fminf(lo, v);
+    hi = fmaxf(hi, v);
+  }
+  lo = wave_reduce_min(lo);
+  hi = wave_reduce_max(hi);
+  __shared__ float2 s[4];
+  const int wid = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) s[wid] = make_float2(lo, hi);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float2 a = s[0];
+    for (int w = 1; w < 4; ++w) {
+      a.x = fminf(a.x, s[w].x);
+      a.y = fmaxf(a.y, s[w].y);
+    }
+    part[r * bpr + blockIdx.x] = a;
+  }
+}
+
+__global__ void k_minmax_final(const float2* __restrict__ part, int bpr, float2* __restrict__ out) {
+  const size_t r = blockIdx.x;
+  float lo = INFINITY, hi = -INFINITY;
+  for (int j = threadIdx.x; j < bpr; j += 64) {
+    float2 a = part[r * bpr + j];
+    lo = fminf(lo, a.x);
+    hi = fmaxf(hi, a.y);
+  }
+  lo = wave_reduce_min(lo);
+  hi = wave_reduce_max(hi);
+  if (threadIdx.x == 0) out[r] = make_float2(lo, hi);
+}
+
+extern "C" size_t tfmq_minmax_ws_bytes(size_t rows, size_t cols) {
+  (void)cols;
+  return rows * 1024 * sizeof(float2);
+}
+
+extern "C" int tfmq_minmax(tfmq_handle h, const float* x, size_t rows, size_t cols, float* out, void* ws,
+                           void* stream) {
+  TFMQ_CHECK_ARG(h, h && x && out && ws, "minmax: null pointer");
+  TFMQ_CHECK_ARG(h, rows > 0 && cols > 0 && rows < 65536, "minmax: rows must be in [1,65535], cols > 0");
+  const int bpr = blocks_per_row(rows, cols, h->cu_count);
+  hipLaunchKernelGGL(k_minmax_partial, dim3(bpr, rows), dim3(256), 0, as_stream(stream), x, cols, bpr,
+                     reinterpret_cast<float2*>(ws));
+  TFMQ_LAUNCH_CHECK(h);
+  hipLaunchKernelGGL(k_minmax_final, dim3(rows), dim3(64), 0, as_stream(stream),
+                     reinterpret_cast<const float2*>(ws), bpr, reinterpret_cast<float2*>(out));
+  TFMQ_LAUNCH_CHECK(h);
+  return TFMQ_OK;
+}
+
+// MINMAX scaler arithmetic (quant_layer.py:23-35), identical operation order on device:
+// double subtraction and division, round to fp32, zp = rint(fp32(-lo) / delta).
+__device__ __forceinline__ float2 minmax_qparam(float mn, float mx, int level, int always_zero) {
+  const double lo = fmin(static_cast<double>(mn), 0.0), hi = fmax(static_cast<double>(mx), 0.0);
+  float delta = static_cast<float>((hi - lo) / static_cast<double>(level - 1));
+  if (always_zero) delta = static_cast<float>(hi / static_cast<double>(level - 1));
+  if (delta < 1e-8f) delta = 1e-8f;  // the reference crashes here; defined behaviour instead
+  const float zp = always_zero ? 0.0f : rintf(static_cast<float>(-lo) / delta);
+  return make_float2(delta, zp);
+}
+
+__global__ void k_minmax_to_qparam(const float2* __restrict__ mm, size_t rows, int level, int always_zero,
+                                   float2* __restrict__ qp) {
+  size_t r = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (r < rows) qp[r] = minmax_qparam(mm[r].x, mm[r].y, level, always_zero);
+}
+
+extern "C" int tfmq_minmax_to_qparam(tfmq_handle h, const float* mm, size_t rows, int level, int always_zero,
+                                     float* qparam, void* stream) {
+  TFMQ_CHECK_ARG(h, h && mm && qparam && rows > 0, "minmax_to_qparam: bad argument");
+  hipLaunchKernelGGL(k_minmax_to_qparam, dim3(ceil_div(rows, 256)), dim3(256), 0, as_stream(stream),
+                     reinterpret_cast<const float2*>(mm), rows, level, always_zero, reinterpret_cast<float2*>(qparam));
+  TFMQ_LAUNCH_CHECK(h);
+  return TFMQ_OK;
+}
+
+__global__ void k_act_range_update(const float2* __restrict__ mm, float2* __restrict__ state, float2* __restrict__ qp,
+                                   float momentum, float om, int level, int init) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  float2 s = state[0];
+  const float2 b = mm[0];
+  if (init) {
+    s = b;  // _init_quantization_param leaf_param branch (quant_layer.py:206-207)
+  } else {
+    // x_min * m + batch_min * (1 - m): fp32 tensor * Python double -> fp32 ops (quant_layer.py:237-238)
+    s.x = s.x * momentum + b.x * om;
+    s.y = s.y * momentum + b.y * om;
+  }
+  state[0] = s;
+  qp[0] = minmax_qparam(s.x, s.y, level, 0);
+}
+
+extern "C" int tfmq_act_range_update(tfmq_handle h, const float* mm, float* state, float* qparam, double momentum,
+                                     int level, int init, void* stream) {
+  TFMQ_CHECK_ARG(h, h && mm && state && qparam, "act_range_update: null pointer");
+  hipLaunchKernelGGL(k_act_range_update, dim3(1), dim3(64), 0, as_stream(stream), reinterpret_cast<const float2*>(mm),
+                     reinterpret_cast<float2*>(state), reinterpret_cast<float2*>(qparam), static_cast<float>(momentum),
+                     static_cast<float>(1.0 - momentum), level, init);
+  TFMQ_LAUNCH_CHECK(h);
+  return TFMQ_OK;
+}
+
+// ------------------------------------------------------------------------------ K3
+#define NCAND 80
+// The 80 (delta_i, zp_i) of quant_layer.py:45-55 in the Python's own operation order:
+// double shrink factor 1.0 - (i*0.01), double range, fp32 delta, zp = rint(fp32(-new_min)/delta).
+__device__ __forceinline__ float2 mse_candidate(float mn, float mx, int i, int level, int always_zero) {
+  const double f = 1.0 - (static_cast<double>(i) * 0.01);
+  const double nmin = static_cast<double>(mn) * f, nmax = static_cast<double>(mx) * f;
+  float nd = static_cast<float>((nmax - nmin) / static_cast<double>(level - 1));
+  if (always_zero) nd = static_cast<float>(nmax / static_cast<double>(level - 1));
+  const float nz = always_zero ? 0.0f : rintf(static_cast<float>(-nmin) / nd);
+  return make_float2(nd, nz);
+}
+
+// |d|^2.4 (lp_loss p=2.4, quant_layer.py:59)
+__device__ __forceinline__ float pow24(float a) { return a == 0.0f ? 0.0f : exp2f(2.4f * log2f(a)); }
+
+template <int CPT>  // candidates per thread-pass
+__global__ __launch_bounds__(256) void k_mse_partial(const float* __restrict__ x, size_t cols, int bpr,
+                                                     const float2* __restrict__ mm, int level, int always_zero,
+                                                     double* __restrict__ part /*[rows][bpr][80]*/) {
+  __shared__ float2 cand[NCAND];
+  __shared__ double red[4][NCAND];
+  const size_t r = blockIdx.y;
+  const float2 m = mm[r];
+  if (threadIdx.x < NCAND) cand[threadIdx.x] = mse_candidate(m.x, m.y, threadIdx.x, level, always_zero);
+  __syncthreads();
+  const float lmax = static_cast<float>(level - 1);
+  const float* row = x + r * cols;
+  const size_t chunk = (cols + bpr - 1) / bpr;
+  const size_t beg = static_cast<size_t>(blockIdx.x) * chunk;
+  size_t end = beg + chunk;
+  if (end > cols) end = cols;
+  const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  // candidates are processed CPT at a time so the accumulators stay in registers; the row
+  // slice is re-read from L2 for each group (it was just streamed by this same block).
+  for (int c0 = 0; c0 < NCAND; c0 += CPT) {
+    float acc[CPT];
+    float2 cd[CPT];
+#pragma unroll
+    for (int c = 0; c < CPT; ++c) {
+      acc[c] = 0.0f;
+      cd[c] = cand[c0 + c];
+    }
+    for (size_t i = beg + threadIdx.x; i < end; i += blockDim.x) {
+      const float v = row[i];
+#pragma unroll
+      for (int c = 0; c < CPT; ++c) {
+        const float q = quant_index_f(v, cd[c].x, cd[c].y, lmax);
+        const float dq = cd[c].x * (q - cd[c].y);
+        acc[c] += pow24(fabsf(dq - v));
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < CPT; ++c) {
+      double s = wave_reduce_sum_d(static_cast<double>(acc[c]));
+      if (lane == 0) red[wid][c0 + c] = s;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < NCAND)
+    part[(r * bpr + blockIdx.x) * NCAND + threadIdx.x] =
+        red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+
+__global__ void k_mse_final(const double* __restrict__ part, int bpr, size_t cols, const float2* __restrict__ mm,
+                            int level, int always_zero, float2* __restrict__ qp, float* __restrict__ losses,
+                            int32_t* __restrict__ best_out) {
+  __shared__ float mean[NCAND];
+  const size_t r = blockIdx.x;
+  if (threadIdx.x < NCAND) {
+    double s = 0.0;
+    for (int j = 0; j < bpr; ++j) s += part[(r * bpr + j) * NCAND + threadIdx.x];
+    const float mu = static_cast<float>(s / static_cast<double>(cols));
+    mean[threadIdx.x] = mu;
+    if (losses) losses[r * NCAND + threadIdx.x] = mu;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    // first strict minimum, initial s = 1e10 (quant_layer.py:44,60-62)
+    float s = 1e10f;
+    int best = -1;
+    for (int i = 0; i < NCAND; ++i)
+      if (mean[i] < s) {
+        s = mean[i];
+        best = i;
+      }
+    if (best_out) best_out[r] = best;
+    const float2 m = mm[r];
+    qp[r] = best >= 0 ? mse_candidate(m.x, m.y, best, level, always_zero) : make_float2(NAN, NAN);
+  }
+}
+
+extern "C" size_t tfmq_mse_ws_bytes(size_t rows, size_t cols) {
+  (void)cols;
+  return rows * 1024 * NCAND * sizeof(double);
+}
+
+extern "C" int tfmq_mse_search(tfmq_handle h, const float* x, size_t rows, size_t cols, const float* mm, int level,
+                               int always_zero, float* qparam, float* losses, int32_t* best, void* ws, void* stream) {
+  TFMQ_CHECK_ARG(h, h && x && mm && qparam && ws, "mse_search: null pointer");
+  TFMQ_CHECK_ARG(h, rows > 0 && cols > 0 && rows < 65536, "mse_search: rows must be in [1,65535], cols > 0");
+  TFMQ_CHECK_ARG(h, level >= 2 && level <= 65536, "mse_search: bad level");
+  int bpr = blocks_per_row(rows, cols, h->cu_count);
+  hipLaunchKernelGGL(k_mse_partial<8>, dim3(bpr, rows), dim3(256), 0, as_stream(stream), x, cols, bpr,
+                     reinterpret_cast<const float2*>(mm), level, always_zero, reinterpret_cast<double*>(ws));
+  TFMQ_LAUNCH_CHECK(h);
+  hipLaunchKernelGGL(k_mse_final, dim3(rows), dim3(128), 0, as_stream(stream), reinterpret_cast<const double*>(ws),
+                     bpr, cols, reinterpret_cast<const float2*>(mm), level, always_zero,
+                     reinterpret_cast<float2*>(qparam), losses, best);
+  TFMQ_LAUNCH_CHECK(h);
+  return TFMQ_OK;
+}
+
+// ------------------------------------------------------------------------------ K4
+// one block per output channel; thread handles groups of 8 consecutive k (one packed dword)
+__global__ __launch_bounds__(256) void k_pack_w4(const float* __restrict__ w, const float* __restrict__ alpha,
+                                                 const float* __restrict__ delta, const float* __restrict__ zp,
+                                                 int cin, int kh, int kw, uint32_t* __restrict__ packed,
+                                                 int32_t* __restrict__ wmeta) {
+  const int co = blockIdx.x;
+  const int K = kh * kw * cin;
+  const int khw = kh * kw;
+  const float d = delta[co], z = zp[co];
+  const float* wr = w + static_cast<size_t>(co) * K;
+  const float* ar = alpha ? alpha + static_cast<size_t>(co) * K : nullptr;
+  int sum = 0;
+  for (int g = threadIdx.x; g < K / 8; g += blockDim.x) {
+    const int k0 = g * 8;
+    const int tap = k0 / cin, ci0 = k0 - tap * cin;  // cin % 8 == 0 => the 8 values share a tap
+    uint32_t word = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const size_t src = static_cast<size_t>(ci0 + i) * khw + tap;  // OIHW: [ci][kh][kw]
+      const float v = wr[src];
+      float q;
+      if (ar) {  // AdaRound hard rounding (adaptive_rounding.py:51,63,67-68)
+        q = floorf(v / d) + (ar[src] >= 0.0f ? 1.0f : 0.0f) + z;
+      } else {   // nearest (quant_layer.py:225)
+        q = rintf(v / d) + z;
+      }
+      q = fminf(fmaxf(q, 0.0f), 15.0f);
+      const uint32_t qi = static_cast<uint32_t>(static_cast<int>(q));
+      sum += static_cast<int>(qi);
+      word |= qi << ((i & 3) * 8 + (i >> 2) * 4);
+    }
+    packed[static_cast<size_t>(co) * (K / 8) + g] = word;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+  __shared__ int s[4];
+  if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = sum;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int4 m;
+    m.x = static_cast<int>(z);
+    m.y = s[0] + s[1] + s[2] + s[3];
+    m.z = 0;
+    m.w = 0;
+    reinterpret_cast<int4*>(wmeta)[co] = m;
+  }
+}
+
+extern "C" int tfmq_pack_w4(tfmq_handle h, const float* w, const float* alpha, const float* delta, const float* zp,
+                            int cout, int cin, int kh, int kw, uint8_t* packed, int32_t* wmeta, void* stream) {
+  TFMQ_CHECK_ARG(h, h && w && delta && zp && packed && wmeta, "pack_w4: null pointer");
+  TFMQ_CHECK_ARG(h, cout > 0 && cin > 0 && kh > 0 && kw > 0, "pack_w4: bad shape");
+  TFMQ_CHECK_ARG(h, cin % 8 == 0, "pack_w4: cin must be a multiple of 8");
+  hipLaunchKernelGGL(k_pack_w4, dim3(cout), dim3(256), 0, as_stream(stream), w, alpha, delta, zp, cin, kh, kw,
+                     reinterpret_cast<uint32_t*>(packed), wmeta);
+  TFMQ_LAUNCH_CHECK(h);
+  return TFMQ_OK;
+}
+
+__global__ void k_unpack_w4(const uint32_t* __restrict__ packed, int cout, int cin, int kh, int kw,
+                            uint8_t* __restrict__ idx) {
+  const int K = kh * kw * cin, khw = kh * kw;
+  const size_t total = static_cast<size_t>(cout) * (K / 8);
+  for (size_t g = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; g < total;
+       g += static_cast<size_t>(gridDim.x) * blockDim.x) {
+    const int co = g / (K / 8), k0 = (g % (K / 8)) * 8;
+    const int tap = k0 / cin, ci0 = k0 - tap * cin;
+    const uint32_t word = packed[g];
+    for (int i = 0; i < 8; ++i) {
+      const uint32_t qi = (word >> ((i & 3) * 8 + (i >> 2) * 4)) & 15u;
+      idx[static_cast<size_t>(co) * K + static_cast<size_t>(ci0 + i) * khw + tap] = static_cast<uint8_t>(qi);
+    }
+  }
+}
+
+extern "C" int tfmq_unpack_w4(tfmq_handle h, const uint8_t* packed, int cout, int cin, int kh, int kw, uint8_t* idx,
+                              void* stream) {
+  TFMQ_CHECK_ARG(h, h && packed && idx && cin % 8 == 0, "unpack_w4: bad argument");
+  const size_t total = static_cast<size_t>(cout) * (kh * kw * cin / 8);
+  hipLaunchKernelGGL(k_unpack_w4, dim3(ceil_div(total, 256)), dim3(256), 0, as_stream(stream),
+                     reinterpret_cast<const uint32_t*>(packed), cout, cin, kh, kw, idx);
+  TFMQ_LAUNCH_CHECK(h);
+  return TFMQ_OK;
+}
+
+__global__ void k_pack_w_f16(const float* __restrict__ w, int cout, int cin, int cin_pad, int khw,
+                             __half* __restrict__ out) {
+  const size_t total = static_cast<size_t>(cout) * cin_pad * khw;
+  for (size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < total;
+       i += static_cast<size_t>(gridDim.x) * blockDim.x) {
+    // destination index: [co][tap][ci] with ci padded (zeros) to a multiple of 32
+    const int ci = i % cin_pad;
+    const int tap = (i / cin_pad) % khw;
+    const int co = i / (static_cast<size_t>(cin_pad) * khw);
+    out[i] = ci < cin ? __float2half_rn(w[(static_cast<size_t>(co) * cin + ci) * khw + tap]) : __float2half_rn(0.0f);
+  }
+}
+
+extern "C" int tfmq_pack_w_f16(tfmq_handle h, const float* w, int cout, int cin, int kh, int kw, uint16_t* out,
+                               void* stream) {
+  TFMQ_CHECK_ARG(h, h && w && out && cout > 0 && cin > 0, "pack_w_f16: bad argument");
+  const int cin_pad = (cin + 31) / 32 * 32;
+  const size_t total = static_cast<size_t>(cout) * cin_pad * kh * kw;
+  hipLaunchKernelGGL(k_pack_w_f16, dim3(ceil_div(total, 256)), dim3(256), 0, as_stream(stream), w, cout, cin, cin_pad,
+                     kh * kw, reinterpret_cast<__half*>(out));
+  TFMQ_LAUNCH_CHECK(h);
+  return TFMQ_OK;
+}

@@ -1,0 +1,235 @@
+// K7 (temporal-information block GEMVs) and K11 (sampler elementwise, layout transforms).
+#include "common.hpp"
+
+// ------------------------------------------------------------------------------ K11
+// coef row of the current step: {sqrt(1-a_t), sqrt(a_t), sqrt(a_next), c1, c2, 0, 0, 0}
+// (all fp32, computed on the host exactly as ddim/functions/denoising.py:21-22,31-37 does).
+//   x0 = (x - eps*sqrt(1-a_t)) / sqrt(a_t);  x_next = sqrt(a_next)*x0 + c1*z + c2*eps
+__global__ __launch_bounds__(256) void k_ddim_update(const float* __restrict__ x, const float* __restrict__ eps,
+                                                     const float* __restrict__ z, float* __restrict__ xn,
+                                                     float* __restrict__ x0o, size_t n, const float* __restrict__ coef,
+                                                     const int32_t* __restrict__ step) {
+  const float* c = coef + static_cast<size_t>(step ? *step : 0) * 8;
+  const float s1m = c[0], sa = c[1], san = c[2], c1 = c[3], c2 = c[4];
+  const size_t stride = static_cast<size_t>(gridDim.x) * blockDim.x;
+  for (size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const float e = eps[i];
+    const float x0 = (x[i] - e * s1m) / sa;
+    if (x0o) x0o[i] = x0;
+    float r = san * x0;
+    r = r + c1 * (z ? z[i] : 0.0f);   // the reference adds c1*randn even when c1 == 0 (eta = 0)
+    r = r + c2 * e;
+    xn[i] = r;
+  }
+}
+
+extern "C" int tfmq_ddim_update(tfmq_handle h, const float* x, const float* eps, const float* noise, float* x_next,
+                                float* x0, size_t n, const float* coef, const int32_t* step, void* stream) {
+  TFMQ_CHECK_ARG(h, h && x && eps && x_next && coef, "ddim_update: null pointer");
+  if (n == 0) return TFMQ_OK;
+  int blocks = ceil_div(static_cast<long>(n), 256);
+  if (blocks > h->cu_count * 8) blocks = h->cu_count * 8;
+  hipLaunchKernelGGL(k_ddim_update, dim3(blocks), dim3(256), 0, as_stream(stream), x, eps, noise, x_next, x0, n, coef,
+                     step);
+  TFMQ_LAUNCH_CHECK(h);
+  return TFMQ_OK;
+}
+
+__global__ void k_step_advance(int32_t* step, int delta) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) *step += delta;
+}
+extern "C" int tfmq_step_advance(tfmq_handle h, int32_t* step, int delta, void* stream) {
+  TFMQ_CHECK_ARG(h, h && step, "step_advance: null pointer");
+  hipLaunchKernelGGL(k_step_advance, dim3(1), dim3(64), 0, as_stream(stream), step, delta);
+  TFMQ_LAUNCH_CHECK(h);
+  return TFMQ_OK;
+}
+
+// [B][C][HW] <-> [B][HW][C] through a padded LDS tile (coalesced on both sides)
+template <bool TO_NHWC>
+__global__ __launch_bounds__(256) void k_layout(const float* __restrict__ x, float* __restrict__ y, int C, int HW) {
+  __shared__ float tile[32][33];
+  const int b = blockIdx.z;
+  const int c0 = blockIdx.y * 32, p0 = blockIdx.x * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  const float* xb = x + static_cast<size_t>(b) * C * HW;
+  float* yb = y + static_cast<size_t>(b) * C * HW;
+  if (TO_NHWC) {
+    for (int j = ty; j < 32; j += 8) {
+      const int c = c0 + j, px = p0 + tx;
+      if (c < C && px < HW) tile[j][tx] = xb[static_cast<size_t>(c) * HW + px];
+    }
+    __syncthreads();
+    for (int j = ty; j < 32; j += 8) {
+      const int px = p0 + j, c = c0 + tx;
+      if (c < C && px < HW) yb[static_cast<size_t>(px) * C + c] = tile[tx][j];
+    }
+  } else {
+    for (int j = ty; j < 32; j += 8) {
+      const int px = p0 + j, c = c0 + tx;
+      if (c < C && px < HW) tile[j][tx] = xb[static_cast<size_t>(px) * C + c];
+    }
+    __syncthreads();
+    for (int j = ty; j < 32; j += 8) {
+      const int c = c0 + j, px = p0 + tx;
+      if (c < C && px < HW) yb[static_cast<size_t>(c) * HW + px] = tile[tx][j];
+    }
+  }
+}
+
+extern "C" int tfmq_nchw_to_nhwc(tfmq_handle h, const float* x, float* y, int B, int C, int HW, void* stream) {
+  TFMQ_CHECK_ARG(h, h && x && y && B > 0 && C > 0 && HW > 0 && B < 65536, "nchw_to_nhwc: bad argument");
+  hipLaunchKernelGGL(k_layout<true>, dim3((HW + 31) / 32, (C + 31) / 32, B), dim3(256), 0, as_stream(stream), x, y, C, HW);
+  TFMQ_LAUNCH_CHECK(h);
+  return TFMQ_OK;
+}
+extern "C" int tfmq_nhwc_to_nchw(tfmq_handle h, const float* x, float* y, int B, int C, int HW, void* stream) {
+  TFMQ_CHECK_ARG(h, h && x && y && B > 0 && C > 0 && HW > 0 && B < 65536, "nhwc_to_nchw: bad argument");
+  hipLaunchKernelGGL(k_layout<false>, dim3((HW + 31) / 32, (C + 31) / 32, B), dim3(256), 0, as_stream(stream), x, y, C, HW);
+  TFMQ_LAUNCH_CHECK(h);
+  return TFMQ_OK;
+}
+
+// ------------------------------------------------------------------------------ K7
+__global__ void k_timestep_embedding(const float* __restrict__ t, int m, int dim, int ldm_order, float* __restrict__ emb) {
+  const int half = dim / 2;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= m * half) return;
+  const int r = i / half, j = i - r * half;
+  // freq_j = exp(j * -(ln 1e4 / denom)) in fp32 like the reference
+  // (ddim/models/diffusion.py:16-18: denom = half-1; ldm util.py:161-163: denom = half)
+  float f;
+  if (ldm_order) {
+    f = expf(-logf(10000.0f) * static_cast<float>(j) / static_cast<float>(half));
+  } else {
+    const float e = static_cast<float>(log(10000.0) / static_cast<double>(half - 1));
+    f = expf(static_cast<float>(j) * -e);
+  }
+  const float a = t[r] * f;
+  float* o = emb + static_cast<size_t>(r) * dim;
+  if (ldm_order) {
+    o[j] = cosf(a);
+    o[half + j] = sinf(a);
+  } else {
+    o[j] = sinf(a);
+    o[half + j] = cosf(a);
+  }
+  if ((dim & 1) && j == 0) o[dim - 1] = 0.0f;
+}
+
+extern "C" int tfmq_timestep_embedding(tfmq_handle h, const float* t, int m, int dim, int ldm_order, float* emb,
+                                       void* stream) {
+  TFMQ_CHECK_ARG(h, h && t && emb && m > 0 && dim >= 4, "timestep_embedding: bad argument");
+  hipLaunchKernelGGL(k_timestep_embedding, dim3(ceil_div(static_cast<long>(m) * (dim / 2), 256)), dim3(256), 0,
+                     as_stream(stream), t, m, dim, ldm_order, emb);
+  TFMQ_LAUNCH_CHECK(h);
+  return TFMQ_OK;
+}
+
+// y[m][n] = act(x[m][:]) . W[n][:] + b[n]; one wave per output column n, all (<= 8) rows of a
+// row-block at once: the weight row is streamed exactly once (GEMV: weight-bandwidth bound).
+#define LS_ROWS 8
+__global__ __launch_bounds__(256) void k_linear_small_f32(const float* __restrict__ x, const float* __restrict__ w,
+                                                          const float* __restrict__ bias, float* __restrict__ y, int m,
+                                                          int n, int k, int silu_in) {
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+  if (wave >= n) return;
+  const int r0 = blockIdx.y * LS_ROWS;
+  float acc[LS_ROWS];
+#pragma unroll
+  for (int r = 0; r < LS_ROWS; ++r) acc[r] = 0.0f;
+  const float* wr = w + static_cast<size_t>(wave) * k;
+  for (int j = lane; j < k; j += 64) {
+    const float wv = wr[j];
+#pragma unroll
+    for (int r = 0; r < LS_ROWS; ++r) {
+      if (r0 + r < m) {
+        float xv = x[static_cast<size_t>(r0 + r) * k + j];
+        if (silu_in) xv = silu_f(xv);
+        acc[r] += xv * wv;
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < LS_ROWS; ++r) {
+    const float s = wave_reduce_sum(acc[r]);
+    if (lane == 0 && r0 + r < m) y[static_cast<size_t>(r0 + r) * n + wave] = s + (bias ? bias[wave] : 0.0f);
+  }
+}
+
+extern "C" int tfmq_linear_small_f32(tfmq_handle h, const float* x, const float* w, const float* bias, float* y, int m,
+                                     int n, int k, int silu_in, void* stream) {
+  TFMQ_CHECK_ARG(h, h && x && w && y && m > 0 && n > 0 && k > 0, "linear_small_f32: bad argument");
+  hipLaunchKernelGGL(k_linear_small_f32, dim3(ceil_div(n, 4), ceil_div(m, LS_ROWS)), dim3(256), 0, as_stream(stream), x,
+                     w, bias, y, m, n, k, silu_in);
+  TFMQ_LAUNCH_CHECK(h);
+  return TFMQ_OK;
+}
+
+// int4-weight variant: y = da*dw[n] * sum (qa - za)(qw - zw) + b  or, without an activation
+// quantiser (weight-only layer, quant_model.py:110-120), y = dw[n] * sum x*(qw - zw) + b.
+__global__ __launch_bounds__(256) void k_linear_small_w4(const float* __restrict__ x, const uint32_t* __restrict__ wp,
+                                                         const int32_t* __restrict__ wmeta,
+                                                         const float* __restrict__ wscale, const float* __restrict__ bias,
+                                                         tfmq_qsel aq, float* __restrict__ y, int m, int n, int k,
+                                                         int silu_in) {
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+  if (wave >= n) return;
+  const int r0 = blockIdx.y * LS_ROWS;
+  const bool quant = aq.qtable != nullptr;
+  float2 qp = make_float2(1.0f, 0.0f);
+  if (quant) qp = load_qparam(aq);
+  const int zw = wmeta[wave * 4];
+  float facc[LS_ROWS];
+  int iacc[LS_ROWS];
+#pragma unroll
+  for (int r = 0; r < LS_ROWS; ++r) {
+    facc[r] = 0.0f;
+    iacc[r] = 0;
+  }
+  const uint32_t* wr = wp + static_cast<size_t>(wave) * (k / 8);
+  for (int g = lane; g < k / 8; g += 64) {
+    const uint32_t word = wr[g];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int qw = static_cast<int>((word >> ((i & 3) * 8 + (i >> 2) * 4)) & 15u) - zw;
+#pragma unroll
+      for (int r = 0; r < LS_ROWS; ++r) {
+        if (r0 + r < m) {
+          float xv = x[static_cast<size_t>(r0 + r) * k + g * 8 + i];
+          if (silu_in) xv = silu_f(xv);
+          if (quant) {
+            const int qa = static_cast<int>(quant_index_f(xv, qp.x, qp.y, 255.0f)) - static_cast<int>(qp.y);
+            iacc[r] += qa * qw;
+          } else {
+            facc[r] += xv * static_cast<float>(qw);
+          }
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < LS_ROWS; ++r) {
+    float s;
+    if (quant) {
+      int t = iacc[r];
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
+      s = (qp.x * wscale[wave]) * static_cast<float>(t);
+    } else {
+      s = wscale[wave] * wave_reduce_sum(facc[r]);
+    }
+    if (lane == 0 && r0 + r < m) y[static_cast<size_t>(r0 + r) * n + wave] = s + (bias ? bias[wave] : 0.0f);
+  }
+}
+
+extern "C" int tfmq_linear_small_w4(tfmq_handle h, const float* x, const uint8_t* wpacked, const int32_t* wmeta,
+                                    const float* wscale, const float* bias, tfmq_qsel aq, float* y, int m, int n, int k,
+                                    int silu_in, void* stream) {
+  TFMQ_CHECK_ARG(h, h && x && wpacked && wmeta && wscale && y && m > 0 && n > 0 && k > 0 && k % 8 == 0,
+                 "linear_small_w4: bad argument");
+  hipLaunchKernelGGL(k_linear_small_w4, dim3(ceil_div(n, 4), ceil_div(m, LS_ROWS)), dim3(256), 0, as_stream(stream), x,
+                     reinterpret_cast<const uint32_t*>(wpacked), wmeta, wscale, bias, aq, y, m, n, k, silu_in);
+  TFMQ_LAUNCH_CHECK(h);
+  return TFMQ_OK;
+}

@@ -1,0 +1,374 @@
+"""Thin typed wrappers: torch CUDA tensors (device memory only) -> C ABI calls.
+
+Nothing here computes anything on the host or in torch; each function validates shapes,
+allocates outputs with torch (allocator plumbing) and launches the HIP kernels on torch's
+current stream.  There is no CPU path: a CPU tensor raises TfmqError.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Tuple
+
+import torch
+
+from ._lib import ConvDesc, GnDesc, QSel, TfmqError, handle
+
+NULL = None
+
+
+def _dev(t: torch.Tensor) -> int:
+    if not t.is_cuda:
+        raise TfmqError("TFMQ hot path got a CPU tensor: the HIP kernels are the only implementation "
+                        "(no CPU fallback); move the tensor to an MI355X device")
+    return t.device.index or 0
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _stream(dev: int):
+    return C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+
+
+def _chk(t: torch.Tensor, dtype, name: str):
+    if t.dtype != dtype or not t.is_contiguous():
+        raise TfmqError(f"{name}: expected contiguous {dtype}, got {t.dtype} contiguous={t.is_contiguous()}")
+
+
+def qsel(qtable: Optional[torch.Tensor], qid: int = 0, step: Optional[torch.Tensor] = None) -> QSel:
+    """qtable: float32 [n_steps, n_q, 2] (or [n_q, 2] / [2]) device tensor."""
+    if qtable is None:
+        return QSel(None, None, 0, 0)
+    _chk(qtable, torch.float32, "qtable")
+    stride = qtable.shape[-2] if qtable.dim() >= 2 else 1
+    return QSel(qtable.data_ptr(), None if step is None else step.data_ptr(), int(stride), int(qid))
+
+
+# ------------------------------------------------------------------------------ K1 / K2 / K3
+def quantize_act(x: torch.Tensor, qs: QSel, level: int = 256, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    d = _dev(x)
+    _chk(x, torch.float32, "x")
+    q = out if out is not None else torch.empty(x.shape, dtype=torch.int8, device=x.device)
+    handle(d).call("quantize_act", _p(x), _p(q), x.numel(), qs, level, _stream(d))
+    return q
+
+
+def fake_quant(x: torch.Tensor, delta: torch.Tensor, zp: torch.Tensor, level: int, want_idx: bool = False):
+    """Per-tensor (delta/zp numel 1) or per-row (first dim) fake quantisation."""
+    d = _dev(x)
+    _chk(x, torch.float32, "x")
+    rows = delta.numel()
+    cols = x.numel() // rows
+    dl = delta.reshape(-1).contiguous().float()
+    z = zp.reshape(-1).contiguous().float()
+    y = torch.empty_like(x)
+    idx = torch.empty(x.shape, dtype=torch.uint8, device=x.device) if want_idx else None
+    handle(d).call("fake_quant", _p(x), _p(y), _p(idx), rows, cols, _p(dl), _p(z), level, _stream(d))
+    return (y, idx) if want_idx else y
+
+
+def minmax(x: torch.Tensor, rows: int = 1) -> torch.Tensor:
+    """-> float32 [rows, 2] = {min, max} per row of x viewed as [rows, -1]."""
+    d = _dev(x)
+    _chk(x, torch.float32, "x")
+    cols = x.numel() // rows
+    h = handle(d)
+    ws = torch.empty(h.lib.tfmq_minmax_ws_bytes(rows, cols), dtype=torch.uint8, device=x.device)
+    out = torch.empty(rows, 2, dtype=torch.float32, device=x.device)
+    h.call("minmax", _p(x), rows, cols, _p(out), _p(ws), _stream(d))
+    return out
+
+
+def minmax_to_qparam(mm: torch.Tensor, level: int, always_zero: bool = False) -> torch.Tensor:
+    d = _dev(mm)
+    rows = mm.shape[0]
+    qp = torch.empty(rows, 2, dtype=torch.float32, device=mm.device)
+    handle(d).call("minmax_to_qparam", _p(mm), rows, level, int(always_zero), _p(qp), _stream(d))
+    return qp
+
+
+def act_range_update(mm: torch.Tensor, state: torch.Tensor, qparam: torch.Tensor, momentum: float, level: int, init: bool):
+    d = _dev(mm)
+    handle(d).call("act_range_update", _p(mm), _p(state), _p(qparam), float(momentum), level, int(init), _stream(d))
+
+
+def mse_search(x: torch.Tensor, rows: int, level: int, always_zero: bool = False, want_losses: bool = False):
+    """80-candidate L2.4 search per row of x viewed [rows, -1] -> qparam [rows, 2] (+losses, best)."""
+    d = _dev(x)
+    _chk(x, torch.float32, "x")
+    cols = x.numel() // rows
+    h = handle(d)
+    mm = minmax(x, rows)
+    ws = torch.empty(h.lib.tfmq_mse_ws_bytes(rows, cols), dtype=torch.uint8, device=x.device)
+    qp = torch.empty(rows, 2, dtype=torch.float32, device=x.device)
+    losses = torch.empty(rows, 80, dtype=torch.float32, device=x.device) if want_losses else None
+    best = torch.empty(rows, dtype=torch.int32, device=x.device) if want_losses else None
+    h.call("mse_search", _p(x), rows, cols, _p(mm), level, int(always_zero), _p(qp), _p(losses), _p(best), _p(ws), _stream(d))
+    return (qp, losses, best) if want_losses else qp
+
+
+# ------------------------------------------------------------------------------ K4
+class PackedW4:
+    """int4 weights of one QuantLayer, resident on the device."""
+
+    def __init__(self, packed, wmeta, wscale, bias, cout, cin, kh, kw):
+        self.packed, self.wmeta, self.wscale, self.bias = packed, wmeta, wscale, bias
+        self.cout, self.cin, self.kh, self.kw = cout, cin, kh, kw
+
+
+def pack_w4(w: torch.Tensor, delta: torch.Tensor, zp: torch.Tensor, alpha: Optional[torch.Tensor] = None,
+            bias: Optional[torch.Tensor] = None) -> PackedW4:
+    d = _dev(w)
+    _chk(w, torch.float32, "w")
+    if w.dim() == 2:
+        cout, cin, kh, kw = w.shape[0], w.shape[1], 1, 1
+    else:
+        cout, cin, kh, kw = w.shape
+    dl = delta.reshape(-1).contiguous().float()
+    z = zp.reshape(-1).contiguous().float()
+    if dl.numel() != cout or z.numel() != cout:
+        raise TfmqError("pack_w4: delta/zp must have one entry per output channel")
+    if float(z.abs().max()) > 255:
+        raise TfmqError("pack_w4: |weight zero-point| > 255 is not supported by the int32 epilogue")
+    if alpha is not None:
+        _chk(alpha, torch.float32, "alpha")
+    packed = torch.empty(cout, kh * kw * cin // 2, dtype=torch.uint8, device=w.device)
+    wmeta = torch.empty(cout, 4, dtype=torch.int32, device=w.device)
+    handle(d).call("pack_w4", _p(w), _p(alpha), _p(dl), _p(z), cout, cin, kh, kw, _p(packed), _p(wmeta), _stream(d))
+    return PackedW4(packed, wmeta, dl, None if bias is None else bias.contiguous().float(), cout, cin, kh, kw)
+
+
+def unpack_w4(pw: PackedW4) -> torch.Tensor:
+    d = _dev(pw.packed)
+    idx = torch.empty(pw.cout, pw.cin, pw.kh, pw.kw, dtype=torch.uint8, device=pw.packed.device)
+    handle(d).call("unpack_w4", _p(pw.packed), pw.cout, pw.cin, pw.kh, pw.kw, _p(idx), _stream(d))
+    return idx
+
+
+class PackedF16:
+    def __init__(self, w16, bias, cout, cin, kh, kw):
+        self.w16, self.bias = w16, bias
+        self.cout, self.cin, self.kh, self.kw = cout, cin, kh, kw
+
+
+def pack_w_f16(w: torch.Tensor, bias: Optional[torch.Tensor] = None) -> PackedF16:
+    d = _dev(w)
+    _chk(w, torch.float32, "w")
+    if w.dim() == 2:
+        cout, cin, kh, kw = w.shape[0], w.shape[1], 1, 1
+    else:
+        cout, cin, kh, kw = w.shape
+    cin_pad = (cin + 31) // 32 * 32
+    out = torch.empty(cout, kh * kw, cin_pad, dtype=torch.float16, device=w.device)
+    handle(d).call("pack_w_f16", _p(w), cout, cin, kh, kw, _p(out), _stream(d))
+    return PackedF16(out, None if bias is None else bias.contiguous().float(), cout, cin, kh, kw)
+
+
+# ------------------------------------------------------------------------------ K5 / K6
+def _conv_desc(x, B, H, W, cin, cout, kh, kw, stride, pad_t, pad_l, Ho, Wo, up2x, y, ldy, y_coff, rowadd, residual):
+    dsc = ConvDesc()
+    dsc.B, dsc.H, dsc.W, dsc.Cin = B, H, W, cin
+    dsc.Cout, dsc.KH, dsc.KW, dsc.stride = cout, kh, kw, stride
+    dsc.pad_t, dsc.pad_l, dsc.Ho, dsc.Wo, dsc.up2x = pad_t, pad_l, Ho, Wo, int(up2x)
+    dsc.x = x.data_ptr()
+    dsc.rowadd = None if rowadd is None else rowadd.data_ptr()
+    dsc.residual = None if residual is None else residual.data_ptr()
+    dsc.y = y.data_ptr()
+    dsc.ldy, dsc.y_coff = ldy, y_coff
+    return dsc
+
+
+def out_hw(H, W, kh, kw, stride, pad_t, pad_l, pad_b, pad_r, up2x=False):
+    if up2x:
+        H, W = 2 * H, 2 * W
+    return (H + pad_t + pad_b - kh) // stride + 1, (W + pad_l + pad_r - kw) // stride + 1
+
+
+def conv2d_w4a8(xq: torch.Tensor, pw: PackedW4, aq: QSel, stride: int = 1, pad: Tuple[int, int, int, int] = (0, 0, 0, 0),
+                up2x: bool = False, rowadd: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
+                out: Optional[torch.Tensor] = None, y_coff: int = 0) -> torch.Tensor:
+    """xq: int8 NHWC [B,H,W,Cin] (bin-128).  pad = (top, left, bottom, right).  -> fp32 NHWC."""
+    d = _dev(xq)
+    _chk(xq, torch.int8, "xq")
+    B, H, W, cin = xq.shape
+    if cin != pw.cin:
+        raise TfmqError(f"conv2d_w4a8: Cin mismatch {cin} vs {pw.cin}")
+    Ho, Wo = out_hw(H, W, pw.kh, pw.kw, stride, pad[0], pad[1], pad[2], pad[3], up2x)
+    y = out if out is not None else torch.empty(B, Ho, Wo, pw.cout, dtype=torch.float32, device=xq.device)
+    dsc = _conv_desc(xq, B, H, W, cin, pw.cout, pw.kh, pw.kw, stride, pad[0], pad[1], Ho, Wo, up2x, y, y.shape[-1], y_coff,
+                     rowadd, residual)
+    dsc.w, dsc.wmeta, dsc.wscale = pw.packed.data_ptr(), pw.wmeta.data_ptr(), pw.wscale.data_ptr()
+    dsc.bias = None if pw.bias is None else pw.bias.data_ptr()
+    dsc.aq = aq
+    handle(d).call("conv2d_w4a8", C.byref(dsc), _stream(d))
+    return y
+
+
+def conv2d_f16(x: torch.Tensor, pf: PackedF16, stride: int = 1, pad: Tuple[int, int, int, int] = (0, 0, 0, 0),
+               up2x: bool = False, rowadd: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
+               out: Optional[torch.Tensor] = None, y_coff: int = 0) -> torch.Tensor:
+    """x: fp32 NHWC.  Un-quantised layers (f16 MFMA, fp32 accumulate)."""
+    d = _dev(x)
+    _chk(x, torch.float32, "x")
+    B, H, W, cin = x.shape
+    if cin != pf.cin:
+        raise TfmqError(f"conv2d_f16: Cin mismatch {cin} vs {pf.cin}")
+    Ho, Wo = out_hw(H, W, pf.kh, pf.kw, stride, pad[0], pad[1], pad[2], pad[3], up2x)
+    y = out if out is not None else torch.empty(B, Ho, Wo, pf.cout, dtype=torch.float32, device=x.device)
+    dsc = _conv_desc(x, B, H, W, cin, pf.cout, pf.kh, pf.kw, stride, pad[0], pad[1], Ho, Wo, up2x, y, y.shape[-1], y_coff,
+                     rowadd, residual)
+    dsc.w = pf.w16.data_ptr()
+    dsc.bias = None if pf.bias is None else pf.bias.data_ptr()
+    dsc.aq = QSel(None, None, 0, 0)
+    handle(d).call("conv2d_f16", C.byref(dsc), _stream(d))
+    return y
+
+
+# ------------------------------------------------------------------------------ K7
+def timestep_embedding(t: torch.Tensor, dim: int, ldm_order: bool = False) -> torch.Tensor:
+    d = _dev(t)
+    _chk(t, torch.float32, "t")
+    emb = torch.empty(t.numel(), dim, dtype=torch.float32, device=t.device)
+    handle(d).call("timestep_embedding", _p(t), t.numel(), dim, int(ldm_order), _p(emb), _stream(d))
+    return emb
+
+
+def linear_small_f32(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], silu_in: bool = False) -> torch.Tensor:
+    d = _dev(x)
+    m, k = x.shape
+    n = w.shape[0]
+    y = torch.empty(m, n, dtype=torch.float32, device=x.device)
+    handle(d).call("linear_small_f32", _p(x), _p(w), _p(bias), _p(y), m, n, k, int(silu_in), _stream(d))
+    return y
+
+
+def linear_small_w4(x: torch.Tensor, pw: PackedW4, aq: QSel, silu_in: bool = False) -> torch.Tensor:
+    d = _dev(x)
+    m, k = x.shape
+    y = torch.empty(m, pw.cout, dtype=torch.float32, device=x.device)
+    handle(d).call("linear_small_w4", _p(x), _p(pw.packed), _p(pw.wmeta), _p(pw.wscale), _p(pw.bias), aq, _p(y), m, pw.cout,
+                   k, int(silu_in), _stream(d))
+    return y
+
+
+# ------------------------------------------------------------------------------ K8
+def groupnorm(x1: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float, silu: bool, aq: Optional[QSel] = None,
+              x2: Optional[torch.Tensor] = None, groups: int = 32, want_f32: bool = False, want_cat: bool = False):
+    """x1 (and optional x2, concatenated on channels): fp32 NHWC.  Returns (yq int8 | None, yf | None, xcat | None)."""
+    d = _dev(x1)
+    _chk(x1, torch.float32, "x1")
+    B = x1.shape[0]
+    C1 = x1.shape[-1]
+    HW = x1.numel() // (B * C1)
+    C2 = 0 if x2 is None else x2.shape[-1]
+    shape = tuple(x1.shape[:-1]) + (C1 + C2,)
+    g = GnDesc()
+    g.B, g.HW, g.C1, g.C2 = B, HW, C1, C2
+    g.x1, g.x2 = x1.data_ptr(), (None if x2 is None else x2.data_ptr())
+    g.gamma, g.beta, g.eps, g.groups, g.silu = gamma.data_ptr(), beta.data_ptr(), float(eps), groups, int(silu)
+    yq = yf = xcat = None
+    if aq is not None and aq.qtable:
+        g.aq = aq
+        yq = torch.empty(shape, dtype=torch.int8, device=x1.device)
+        g.yq = yq.data_ptr()
+    else:
+        g.aq = QSel(None, None, 0, 0)
+    if want_f32 or yq is None:
+        yf = torch.empty(shape, dtype=torch.float32, device=x1.device)
+        g.yf = yf.data_ptr()
+    if want_cat:
+        xcat = torch.empty(shape, dtype=torch.float32, device=x1.device)
+        g.xcat = xcat.data_ptr()
+    handle(d).call("groupnorm", C.byref(g), _stream(d))
+    return yq, yf, xcat
+
+
+# ------------------------------------------------------------------------------ K10
+def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int, scale: float, aq: Optional[QSel] = None,
+              want_f32: bool = True):
+    """q: [B,Tq,*] view with last-dim stride 1 (may be a column slice of a fused qkv buffer); same for k, v.
+    Returns (out fp32 [B,Tq,heads*d] | None, yq int8 | None)."""
+    d_ = _dev(q)
+    B, Tq, Cq = q.shape
+    Tk = k.shape[1]
+    dh = Cq // heads
+    for t in (q, k, v):
+        if t.dtype != torch.float32 or t.stride(-1) != 1 or t.stride(0) != t.shape[1] * t.stride(1):
+            raise TfmqError("attention: q/k/v must be fp32 [B,T,C] with unit channel stride and dense batch/token strides")
+    out = torch.empty(B, Tq, Cq, dtype=torch.float32, device=q.device) if want_f32 else None
+    yq = None
+    sel = QSel(None, None, 0, 0)
+    if aq is not None and aq.qtable:
+        yq = torch.empty(B, Tq, Cq, dtype=torch.int8, device=q.device)
+        sel = aq
+    handle(d_).call("attention", _p(q), _p(k), _p(v), q.stride(1), k.stride(1), v.stride(1), _p(out), Cq, _p(yq), sel, B,
+                    heads, Tq, Tk, dh, float(scale), _stream(d_))
+    return out, yq
+
+
+# ------------------------------------------------------------------------------ K11
+def ddim_update(x, eps, coef, step=None, noise=None, want_x0=False):
+    d = _dev(x)
+    xn = torch.empty_like(x)
+    x0 = torch.empty_like(x) if want_x0 else None
+    handle(d).call("ddim_update", _p(x), _p(eps), _p(noise), _p(xn), _p(x0), x.numel(), _p(coef), _p(step), _stream(d))
+    return (xn, x0) if want_x0 else xn
+
+
+def step_advance(step: torch.Tensor, delta: int = 1):
+    d = _dev(step)
+    handle(d).call("step_advance", _p(step), delta, _stream(d))
+
+
+def nchw_to_nhwc(x: torch.Tensor) -> torch.Tensor:
+    d = _dev(x)
+    _chk(x, torch.float32, "x")
+    B, Cc, H, W = x.shape
+    y = torch.empty(B, H, W, Cc, dtype=torch.float32, device=x.device)
+    handle(d).call("nchw_to_nhwc", _p(x), _p(y), B, Cc, H * W, _stream(d))
+    return y
+
+
+def nhwc_to_nchw(x: torch.Tensor) -> torch.Tensor:
+    d = _dev(x)
+    _chk(x, torch.float32, "x")
+    B, H, W, Cc = x.shape
+    y = torch.empty(B, Cc, H, W, dtype=torch.float32, device=x.device)
+    handle(d).call("nhwc_to_nchw", _p(x), _p(y), B, Cc, H * W, _stream(d))
+    return y
+
+
+# ------------------------------------------------------------------------------ K12-K14
+def adaround_init(w: torch.Tensor, delta: torch.Tensor) -> torch.Tensor:
+    d = _dev(w)
+    rows = delta.numel()
+    alpha = torch.empty_like(w)
+    handle(d).call("adaround_init", _p(w), _p(delta.reshape(-1).contiguous()), _p(alpha), rows, w.numel() // rows, _stream(d))
+    return alpha
+
+
+def adaround_soft_fwd(w, alpha, delta, zp, level: int) -> torch.Tensor:
+    d = _dev(w)
+    rows = delta.numel()
+    w_hat = torch.empty_like(w)
+    handle(d).call("adaround_soft_fwd", _p(w), _p(alpha), _p(delta.reshape(-1).contiguous()), _p(zp.reshape(-1).contiguous()),
+                   _p(w_hat), rows, w.numel() // rows, level, _stream(d))
+    return w_hat
+
+
+def adaround_bwd_adam(w, alpha, delta, zp, g_what, m, v, level: int, w_reg: float, b_temp: float, lr: float, t: int,
+                      round_loss: Optional[torch.Tensor] = None):
+    d = _dev(w)
+    rows = delta.numel()
+    handle(d).call("adaround_bwd_adam", _p(w), _p(alpha), _p(delta.reshape(-1).contiguous()), _p(zp.reshape(-1).contiguous()),
+                   _p(g_what), _p(m), _p(v), rows, w.numel() // rows, level, float(w_reg), float(b_temp), float(lr), int(t),
+                   _p(round_loss), _stream(d))
+
+
+def recon_loss(pred, tgt, denom: int, want_grad: bool = True):
+    d = _dev(pred)
+    loss = torch.zeros(1, dtype=torch.float32, device=pred.device)
+    g = torch.empty_like(pred) if want_grad else None
+    handle(d).call("recon_loss", _p(pred), _p(tgt), _p(g), pred.numel(), int(denom), _p(loss), _stream(d))
+    return loss, g
