@@ -100,8 +100,11 @@ int tfmq_pack_w4(tfmq_handle h, const float* w, const float* alpha_or_null, cons
 /* inverse (tests): idx[cout][cin][kh][kw] u8 */
 int tfmq_unpack_w4(tfmq_handle h, const uint8_t* packed, int cout, int cin, int kh, int kw, uint8_t* idx, void* stream);
 /* fp16 weights for the un-quantised convs, reordered to [cout][kh][kw][cin_pad],
- * cin_pad = cin rounded up to a multiple of 32 (zero filled) */
-int tfmq_pack_w_f16(tfmq_handle h, const float* w, int cout, int cin, int kh, int kw, uint16_t* out, void* stream);
+ * cin_pad = cin rounded up to a multiple of 32 (zero filled).  With delta/zp (and optional
+ * alpha) non-NULL the stored value is the integer grid coordinate q - zp (exact in f16) of the
+ * 4-bit weight quantizer, for weight-only layers (disable_aq, quant_model.py:110-120). */
+int tfmq_pack_w_f16(tfmq_handle h, const float* w, const float* alpha_or_null, const float* delta_or_null,
+                    const float* zp_or_null, int level, int cout, int cin, int kh, int kw, uint16_t* out, void* stream);
 
 /* ---- K5/K6: conv / linear as implicit GEMM on MFMA (QuantLayer.forward, quant_layer.py:306-340) */
 typedef struct tfmq_conv_desc {
@@ -117,11 +120,16 @@ typedef struct tfmq_conv_desc {
   const void* x;                 /* int8 (w4a8) or fp32 (f16 path) NHWC */
   const void* w;                 /* packed int4 (tfmq_pack_w4) or fp16 (tfmq_pack_w_f16) */
   const int32_t* wmeta;          /* [Cout][4] from tfmq_pack_w4 (w4a8 only) */
-  const float* wscale;           /* [Cout] delta_w (w4a8 only) */
+  const float* wscale;           /* [Cout] delta_w.  w4a8: required.  f16 path: optional per-channel output scale
+                                    (weight-only layers store the integer grid q-z exactly in f16) */
   const float* bias;             /* [Cout] or NULL */
   tfmq_qsel aq;                  /* activation quantizer of x (w4a8 only) */
   /* fused epilogue: y = conv + bias (+ rowadd[b][c]) (+ residual[b][ho][wo][c]) */
-  const float* rowadd;           /* [B][Cout] (temb projection, quant_block.py:429) or NULL */
+  const float* rowadd;           /* per-image channel bias (temb projection, quant_block.py:429) or NULL:
+                                    value = rowadd[(*rowadd_step)*rowadd_step_stride + b*rowadd_ld + c] */
+  const int32_t* rowadd_step;    /* device scalar selecting a precomputed TIB row (NULL = 0) */
+  int32_t rowadd_ld;             /* floats between images (0 = one row broadcast to the whole batch) */
+  int32_t rowadd_step_stride;    /* floats between steps */
   const float* residual;         /* fp32 NHWC [B][Ho][Wo][Cout] or NULL */
   float* y;                      /* fp32 NHWC [B][Ho][Wo][ldy]  (written at channel offset y_coff) */
   int32_t ldy, y_coff;           /* output row stride in floats (>= Cout) and channel offset: lets q/k/v or a

@@ -312,8 +312,10 @@ def test_timestep_embedding_and_small_linears(ops, golden):
     t = T(g["temb_t"])
     for dim in (128, 32):
         emb = ops.timestep_embedding(t.to(DEV), dim).cpu()
-        # sin/cos of arguments up to ~1e3: device vs libm differ by a few ulp of the *argument*
-        np.testing.assert_allclose(emb.numpy(), g[f"temb_{dim}"], atol=2e-6, rtol=0)
+        # arguments reach ~1e3: a 1-ulp difference in the fp32 frequency (device exp vs CPU libm)
+        # moves sin/cos by up to 1e3 * 6e-8 = 6e-5; everything else agrees to ~1e-6.
+        err = np.abs(emb.numpy() - g[f"temb_{dim}"])
+        assert err.max() <= 1e-4 and (err <= 2e-6).mean() >= 0.97
     gen = torch.Generator().manual_seed(5)
     x = torch.randn(5, 128, generator=gen)
     w = torch.randn(512, 128, generator=gen) * 0.05

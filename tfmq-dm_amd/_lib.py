@@ -34,7 +34,8 @@ class ConvDesc(C.Structure):
         ("up2x", C.c_int32),
         ("x", c_void_p), ("w", c_void_p), ("wmeta", c_void_p), ("wscale", c_void_p), ("bias", c_void_p),
         ("aq", QSel),
-        ("rowadd", c_void_p), ("residual", c_void_p), ("y", c_void_p),
+        ("rowadd", c_void_p), ("rowadd_step", c_void_p), ("rowadd_ld", C.c_int32), ("rowadd_step_stride", C.c_int32),
+        ("residual", c_void_p), ("y", c_void_p),
         ("ldy", C.c_int32), ("y_coff", C.c_int32),
     ]
 
@@ -67,7 +68,7 @@ _SIGS = {
     "tfmq_mse_search": (c_int, [c_void_p, c_void_p, c_size_t, c_size_t, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "tfmq_pack_w4": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "tfmq_unpack_w4": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
-    "tfmq_pack_w_f16": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "tfmq_pack_w_f16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "tfmq_conv2d_w4a8": (c_int, [c_void_p, C.POINTER(ConvDesc), c_void_p]),
     "tfmq_conv2d_f16": (c_int, [c_void_p, C.POINTER(ConvDesc), c_void_p]),
     "tfmq_timestep_embedding": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),

@@ -36,16 +36,19 @@ struct ConvP {
 
 __device__ __forceinline__ int swz(int row, int slot) { return row * 64 + ((slot ^ ((row >> 2) & 3)) << 4); }
 
-template <bool INT8, int WAVES_M, int WAVES_N, int WM_TILES, int WN_TILES>
+template <bool INT8, int CK8, int WAVES_M, int WAVES_N, int WM_TILES, int WN_TILES>
 __global__ __launch_bounds__(256) void k_conv_igemm(ConvP p) {
   constexpr int BM = WAVES_M * WM_TILES * 32;
   constexpr int BN = WAVES_N * WN_TILES * 32;
-  constexpr int CK = INT8 ? 64 : 32;            // channels per K-step
-  constexpr int A_ITEMS = BM * 4 / 256;         // 16-byte LDS items per thread (A)
-  constexpr int B_TOTAL = INT8 ? BN * 2 : BN * 4;
+  constexpr int CK = INT8 ? CK8 : 32;           // channels per K-step (CK8 = 64 or 32 int8 channels)
+  constexpr int SLOTS = INT8 ? CK8 / 16 : 4;    // 16-byte slots used per 64-byte LDS row
+  constexpr int KSUB = INT8 ? CK8 / 32 : 2;     // MFMA k-sub-steps per K-step
+  constexpr int BPR = INT8 ? CK8 / 32 : 4;      // 16-byte global items per B row
+  constexpr int A_ITEMS = BM * SLOTS / 256;     // 16-byte LDS items per thread (A)
+  constexpr int B_TOTAL = BN * BPR;
   constexpr int B_ITEMS = (B_TOTAL + 255) / 256;
   static_assert(WAVES_M * WAVES_N == 4, "4 waves");
-  static_assert(BM * 4 % 256 == 0, "A items");
+  static_assert(BM * SLOTS % 256 == 0, "A items");
 
   __shared__ __attribute__((aligned(16))) unsigned char lds[2 * (BM + BN) * 64 + BM * 4];
   auto ldsA = [&](int buf) -> unsigned char* { return lds + buf * ((BM + BN) * 64); };
@@ -74,8 +77,8 @@ __global__ __launch_bounds__(256) void k_conv_igemm(ConvP p) {
 #pragma unroll
   for (int it = 0; it < A_ITEMS; ++it) {
     const int item = tid + it * 256;
-    a_row[it] = item >> 2;
-    a_slot[it] = item & 3;
+    a_row[it] = item / SLOTS;
+    a_slot[it] = item % SLOTS;
     const int m = m0 + a_row[it];
     a_ok[it] = m < p.M;
     const int mm = a_ok[it] ? m : 0;
@@ -142,10 +145,10 @@ __global__ __launch_bounds__(256) void k_conv_igemm(ConvP p) {
       uint4 v = make_uint4(0, 0, 0, 0);
       if (item < B_TOTAL) {
         if constexpr (INT8) {
-          const int n = n0 + (item >> 1);
+          const int n = n0 + item / BPR;
           if (n < d.Cout)
             v = *reinterpret_cast<const uint4*>(static_cast<const uint8_t*>(d.w) + static_cast<size_t>(n) * (p.Ktot >> 1) +
-                                                ((tap * d.Cin + c0) >> 1) + (item & 1) * 16);
+                                                ((tap * d.Cin + c0) >> 1) + (item % BPR) * 16);
         } else {
           const int n = n0 + (item >> 2);
           if (n < d.Cout)
@@ -175,7 +178,7 @@ __global__ __launch_bounds__(256) void k_conv_igemm(ConvP p) {
       const int item = tid + it * 256;
       if (item < B_TOTAL) {
         if constexpr (INT8) {
-          const int row = item >> 1, half = item & 1;
+          const int row = item / BPR, half = item % BPR;
           const uint4 v = b_reg[it];
           uint4 lo, hi;  // word j of the packed 16 B holds k = 8j..8j+7
           lo.x = v.x & 0x0f0f0f0fu; lo.y = (v.x >> 4) & 0x0f0f0f0fu;
@@ -207,7 +210,7 @@ __global__ __launch_bounds__(256) void k_conv_igemm(ConvP p) {
     __syncthreads();
     if (s + 1 < p.nsteps) load_step(s + 1);
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
+    for (int ks = 0; ks < KSUB; ++ks) {
       uint4 af[WM_TILES], bf[WN_TILES];
       const int kslot = ks * 2 + (lane >> 5);
 #pragma unroll
@@ -237,7 +240,7 @@ __global__ __launch_bounds__(256) void k_conv_igemm(ConvP p) {
     for (int it = 0; it < A_ITEMS; ++it) {
       int s = a_sum[it];
       s += __shfl_xor(s, 1, 64);
-      s += __shfl_xor(s, 2, 64);
+      if constexpr (SLOTS == 4) s += __shfl_xor(s, 2, 64);
       if (a_slot[it] == 0) ldsS[a_row[it]] = s;
     }
     __syncthreads();
@@ -245,11 +248,13 @@ __global__ __launch_bounds__(256) void k_conv_igemm(ConvP p) {
 
   // ---- epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
   const int hw = d.Ho * d.Wo;
+  const float* rowadd = d.rowadd;
+  if (rowadd && d.rowadd_step) rowadd += static_cast<size_t>(*d.rowadd_step) * d.rowadd_step_stride;
 #pragma unroll
   for (int j = 0; j < WN_TILES; ++j) {
     const int n = n0 + (wn * WN_TILES + j) * 32 + (lane & 31);
     if (n >= d.Cout) continue;
-    float sc = 1.0f, bias = d.bias ? d.bias[n] : 0.0f;
+    float sc = (!INT8 && d.wscale) ? d.wscale[n] : 1.0f, bias = d.bias ? d.bias[n] : 0.0f;
     int zw = 0, corr = 0;
     if constexpr (INT8) {
       const int4 wmv = reinterpret_cast<const int4*>(d.wmeta)[n];
@@ -269,9 +274,9 @@ __global__ __launch_bounds__(256) void k_conv_igemm(ConvP p) {
           const int t = acc[i][j][r] - zw * ldsS[row] + corr;
           v = sc * static_cast<float>(t) + bias;
         } else {
-          v = acc[i][j][r] + bias;
+          v = d.wscale ? sc * acc[i][j][r] + bias : acc[i][j][r] + bias;
         }
-        if (d.rowadd) v += d.rowadd[static_cast<size_t>(m / hw) * d.Cout + n];
+        if (d.rowadd) v += rowadd[static_cast<size_t>(m / hw) * d.rowadd_ld + n];
         if (d.residual) v += d.residual[static_cast<size_t>(m) * d.Cout + n];
         d.y[static_cast<size_t>(m) * d.ldy + d.y_coff + n] = v;
       }
@@ -294,9 +299,9 @@ static int launch_conv(tfmq_handle h, const tfmq_conv_desc* dd, void* stream) {
   p.Wv = d.up2x ? 2 * d.W : d.W;
   p.Ktot = d.KH * d.KW * d.Cin;
   if (INT8) {
-    TFMQ_CHECK_ARG(h, d.Cin % 64 == 0, "conv_w4a8: Cin must be a multiple of 64");
+    TFMQ_CHECK_ARG(h, d.Cin % 32 == 0, "conv_w4a8: Cin must be a multiple of 32");
     TFMQ_CHECK_ARG(h, d.wmeta && d.wscale && d.aq.qtable, "conv_w4a8: wmeta/wscale/aq required");
-    p.chunks = d.Cin / 64;
+    p.chunks = d.Cin % 64 == 0 ? d.Cin / 64 : d.Cin / 32;
     p.cin_pad = d.Cin;
   } else {
     p.chunks = (d.Cin + 31) / 32;
@@ -308,10 +313,14 @@ static int launch_conv(tfmq_handle h, const tfmq_conv_desc* dd, void* stream) {
   p.tiles_n = (d.Cout + BN - 1) / BN;
   const int tiles_m = (p.M + BM - 1) / BM;
   dim3 grid(static_cast<unsigned>(p.tiles_n) * tiles_m);
-  if (narrow)
-    hipLaunchKernelGGL((k_conv_igemm<INT8, 4, 1, 1, 1>), grid, dim3(256), 0, as_stream(stream), p);
-  else
-    hipLaunchKernelGGL((k_conv_igemm<INT8, 2, 2, 2, 2>), grid, dim3(256), 0, as_stream(stream), p);
+  const bool k32 = INT8 && (d.Cin % 64 != 0);
+  if (narrow) {
+    if (k32) hipLaunchKernelGGL((k_conv_igemm<INT8, 32, 4, 1, 1, 1>), grid, dim3(256), 0, as_stream(stream), p);
+    else hipLaunchKernelGGL((k_conv_igemm<INT8, 64, 4, 1, 1, 1>), grid, dim3(256), 0, as_stream(stream), p);
+  } else {
+    if (k32) hipLaunchKernelGGL((k_conv_igemm<INT8, 32, 2, 2, 2, 2>), grid, dim3(256), 0, as_stream(stream), p);
+    else hipLaunchKernelGGL((k_conv_igemm<INT8, 64, 2, 2, 2, 2>), grid, dim3(256), 0, as_stream(stream), p);
+  }
   TFMQ_LAUNCH_CHECK(h);
   return TFMQ_OK;
 }

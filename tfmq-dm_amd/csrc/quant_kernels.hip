@@ -410,8 +410,9 @@ extern "C" int tfmq_unpack_w4(tfmq_handle h, const uint8_t* packed, int cout, in
   return TFMQ_OK;
 }
 
-__global__ void k_pack_w_f16(const float* __restrict__ w, int cout, int cin, int cin_pad, int khw,
-                             __half* __restrict__ out) {
+__global__ void k_pack_w_f16(const float* __restrict__ w, const float* __restrict__ alpha,
+                             const float* __restrict__ delta, const float* __restrict__ zp, float lmax, int cout,
+                             int cin, int cin_pad, int khw, __half* __restrict__ out) {
   const size_t total = static_cast<size_t>(cout) * cin_pad * khw;
   for (size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < total;
        i += static_cast<size_t>(gridDim.x) * blockDim.x) {
@@ -419,17 +420,29 @@ __global__ void k_pack_w_f16(const float* __restrict__ w, int cout, int cin, int
     const int ci = i % cin_pad;
     const int tap = (i / cin_pad) % khw;
     const int co = i / (static_cast<size_t>(cin_pad) * khw);
-    out[i] = ci < cin ? __float2half_rn(w[(static_cast<size_t>(co) * cin + ci) * khw + tap]) : __float2half_rn(0.0f);
+    float v = 0.0f;
+    if (ci < cin) {
+      const size_t src = (static_cast<size_t>(co) * cin + ci) * khw + tap;
+      v = w[src];
+      if (delta) {  // integer grid coordinate of the weight quantizer (exact in f16)
+        const float d = delta[co], z = zp[co];
+        float q = alpha ? floorf(v / d) + (alpha[src] >= 0.0f ? 1.0f : 0.0f) + z : rintf(v / d) + z;
+        q = fminf(fmaxf(q, 0.0f), lmax);
+        v = q - z;
+      }
+    }
+    out[i] = __float2half_rn(v);
   }
 }
 
-extern "C" int tfmq_pack_w_f16(tfmq_handle h, const float* w, int cout, int cin, int kh, int kw, uint16_t* out,
-                               void* stream) {
+extern "C" int tfmq_pack_w_f16(tfmq_handle h, const float* w, const float* alpha, const float* delta, const float* zp,
+                               int level, int cout, int cin, int kh, int kw, uint16_t* out, void* stream) {
   TFMQ_CHECK_ARG(h, h && w && out && cout > 0 && cin > 0, "pack_w_f16: bad argument");
+  TFMQ_CHECK_ARG(h, (delta == nullptr) == (zp == nullptr) && (!alpha || delta), "pack_w_f16: delta/zp/alpha mismatch");
   const int cin_pad = (cin + 31) / 32 * 32;
   const size_t total = static_cast<size_t>(cout) * cin_pad * kh * kw;
-  hipLaunchKernelGGL(k_pack_w_f16, dim3(ceil_div(total, 256)), dim3(256), 0, as_stream(stream), w, cout, cin, cin_pad,
-                     kh * kw, reinterpret_cast<__half*>(out));
+  hipLaunchKernelGGL(k_pack_w_f16, dim3(ceil_div(total, 256)), dim3(256), 0, as_stream(stream), w, alpha, delta, zp,
+                     static_cast<float>(level - 1), cout, cin, cin_pad, kh * kw, reinterpret_cast<__half*>(out));
   TFMQ_LAUNCH_CHECK(h);
   return TFMQ_OK;
 }

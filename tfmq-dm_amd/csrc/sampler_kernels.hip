@@ -98,12 +98,16 @@ __global__ void k_timestep_embedding(const float* __restrict__ t, int m, int dim
   const int r = i / half, j = i - r * half;
   // freq_j = exp(j * -(ln 1e4 / denom)) in fp32 like the reference
   // (ddim/models/diffusion.py:16-18: denom = half-1; ldm util.py:161-163: denom = half)
+  // The fp32 argument of exp() is formed exactly as the reference does; exp itself is evaluated
+  // in double and rounded once (correctly rounded fp32), so it can differ from the CPU libm of
+  // the reference by at most 1 ulp of the frequency.
   float f;
   if (ldm_order) {
-    f = expf(-logf(10000.0f) * static_cast<float>(j) / static_cast<float>(half));
+    const float arg = static_cast<float>(-log(10000.0)) * static_cast<float>(j) / static_cast<float>(half);
+    f = static_cast<float>(exp(static_cast<double>(arg)));
   } else {
     const float e = static_cast<float>(log(10000.0) / static_cast<double>(half - 1));
-    f = expf(static_cast<float>(j) * -e);
+    f = static_cast<float>(exp(static_cast<double>(static_cast<float>(j) * -e)));
   }
   const float a = t[r] * f;
   float* o = emb + static_cast<size_t>(r) * dim;

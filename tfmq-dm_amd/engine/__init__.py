@@ -1,0 +1,2 @@
+"""Device execution plans: the module tree of a (Quant)Model lowered to C-ABI kernel launches."""
+from .ddim_unet import DdimUNetEngine, LayerQ  # noqa: F401

@@ -1,0 +1,290 @@
+"""DDPM/DDIM pixel-space UNet lowered to the HIP kernels.
+
+Mirrors the dataflow of the reference's `Model.forward` (ddim/models/diffusion.py:306-354)
+with its quantised blocks (`QuantResnetBlock` quant/quant_block.py:415-444, `QuantAttnBlock`
+:474-505) but never runs a torch op on the data path: every step is a launch through the C ABI
+(include/tfmq_hip.h).  Fusions:
+  GroupNorm -> SiLU -> 8-bit quantise   one kernel, reading the *virtual* concat [h, skip]
+  conv + bias + temb-projection row + residual      implicit-GEMM epilogue
+  q/k/v 1x1 convs                                   one concatenated-N GEMM (sibling quantizers equal)
+  softmax(QK^T c^-1/2)V -> quantise                 one flash-attention kernel
+  nearest-2x upsample                               address arithmetic of the consumer conv
+  TIB (time-embedding MLP + 22 projections)         depends only on t: a per-step table
+
+Layer modes (QuantLayer.forward, quant/quant_layer.py:306-340):
+  'fp'    original fp32 weights        -> f16 MFMA, fp32 accumulate
+  'w4'    4-bit weights, fp activations (disable_aq layers / asymmetric reconstruction inputs)
+          -> f16 MFMA on the exact integer grid (q - z) with a per-channel output scale
+  'w4a8'  4-bit weights, 8-bit activations -> int8 MFMA, exact int32 accumulation
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Sequence
+
+import torch
+
+from .. import ops
+from .._lib import TfmqError
+
+
+class LayerQ:
+    """Quantisation state of one QuantLayer handed to the engine."""
+
+    def __init__(self, delta: torch.Tensor, zp: torch.Tensor, alpha: Optional[torch.Tensor] = None,
+                 qid: Optional[int] = None):
+        self.delta, self.zp, self.alpha, self.qid = delta, zp, alpha, qid
+
+
+class _Layer:
+    def __init__(self, kind, packed, aq):
+        self.kind, self.p, self.aq = kind, packed, aq
+
+    def run(self, x, **kw):
+        if self.kind == "w4a8":
+            return ops.conv2d_w4a8(x, self.p, self.aq, **kw)
+        return ops.conv2d_f16(x, self.p, **kw)
+
+
+def ddim_resblock_names(cfg) -> List[str]:
+    nres, nlev = cfg["num_res_blocks"], len(cfg["ch_mult"])
+    names = []
+    for i in range(nlev):
+        names += [f"down.{i}.block.{j}" for j in range(nres)]
+    names += ["mid.block_1", "mid.block_2"]
+    for i in range(nlev):
+        names += [f"up.{i}.block.{j}" for j in range(nres + 1)]
+    return names
+
+
+class DdimUNetEngine:
+    def __init__(self, sd: Dict[str, torch.Tensor], cfg: dict, device="cuda:0"):
+        self.cfg = dict(cfg)
+        self.dev = torch.device(device)
+        if self.dev.type != "cuda":
+            raise TfmqError("DdimUNetEngine needs an MI355X device: the HIP kernels are the only implementation")
+        self.sd = {k: v.detach().to(self.dev, torch.float32).contiguous() for k, v in sd.items()}
+        self.res_names = ddim_resblock_names(cfg)
+        self.layers: Dict[str, _Layer] = {}
+        self.lin: Dict[str, tuple] = {}
+        self.qtable = None
+        self.step = None
+        self.tib_table = None
+        self.tib_off: Dict[str, int] = {}
+        self.prepared = False
+
+    # ------------------------------------------------------------------ weights
+    def _conv_names(self):
+        return [k[:-7] for k in self.sd if k.endswith(".weight") and self.sd[k].dim() == 4]
+
+    def prepare(self, wq: Optional[Dict[str, LayerQ]] = None, qtable: Optional[torch.Tensor] = None,
+                step: Optional[torch.Tensor] = None):
+        """wq: name -> LayerQ for every weight-quantised layer (absent => FP layer).  A layer with
+        LayerQ.qid != None and a qtable runs w4a8; qtable: fp32 [n_steps, n_q, 2] on the device."""
+        wq = wq or {}
+        self.qtable = None if qtable is None else qtable.to(self.dev, torch.float32).contiguous()
+        self.step = step
+        self.layers.clear()
+        self.lin.clear()
+        sd = self.sd
+
+        def aq_of(q: Optional[LayerQ]):
+            if q is None or q.qid is None or self.qtable is None:
+                return None
+            return ops.qsel(self.qtable, q.qid, self.step)
+
+        for n in self._conv_names():
+            w, b = sd[n + ".weight"], sd.get(n + ".bias")
+            q = wq.get(n)
+            aq = aq_of(q)
+            if q is None:
+                self.layers[n] = _Layer("fp", ops.pack_w_f16(w, b), None)
+            elif aq is None:
+                a = None if q.alpha is None else q.alpha.to(self.dev).contiguous()
+                self.layers[n] = _Layer("w4", ops.pack_w_f16(w, b, q.delta.to(self.dev), q.zp.to(self.dev), a), None)
+            else:
+                a = None if q.alpha is None else q.alpha.to(self.dev).contiguous()
+                self.layers[n] = _Layer("w4a8", ops.pack_w4(w, q.delta.to(self.dev), q.zp.to(self.dev), a, b), aq)
+        # linears of the temporal-information block
+        for n in ["temb.dense.0", "temb.dense.1"] + [r + ".temb_proj" for r in self.res_names]:
+            w, b = sd[n + ".weight"], sd.get(n + ".bias")
+            q = wq.get(n)
+            if q is None:
+                self.lin[n] = ("fp", w, b, None)
+            else:
+                a = None if q.alpha is None else q.alpha.to(self.dev).contiguous()
+                self.lin[n] = ("w4", ops.pack_w4(w, q.delta.to(self.dev), q.zp.to(self.dev), a, b), None, aq_of(q))
+        # fused q/k/v GEMM where the three sibling quantizers agree at every step
+        self.fused_qkv: Dict[str, _Layer] = {}
+        for n in list(self.layers):
+            if not n.endswith(".q"):
+                continue
+            p = n[:-2]
+            ls = [self.layers[p + s] for s in (".q", ".k", ".v")]
+            if all(l.kind == "w4a8" for l in ls):
+                ids = [wq[p + s].qid for s in (".q", ".k", ".v")]
+                same = all(bool(torch.equal(self.qtable[:, ids[0]], self.qtable[:, i])) for i in ids[1:])
+                if same:
+                    pk = ops.PackedW4(torch.cat([l.p.packed for l in ls]), torch.cat([l.p.wmeta for l in ls]),
+                                      torch.cat([l.p.wscale for l in ls]), torch.cat([l.p.bias for l in ls]),
+                                      3 * ls[0].p.cout, ls[0].p.cin, 1, 1)
+                    self.fused_qkv[p] = _Layer("w4a8", pk, ls[0].aq)
+            elif all(l.kind in ("fp", "w4") for l in ls) and len({l.kind for l in ls}) == 1:
+                pf = ls[0].p
+                ws = None if pf.wscale is None else torch.cat([l.p.wscale for l in ls])
+                pk = ops.PackedF16(torch.cat([l.p.w16 for l in ls]), torch.cat([l.p.bias for l in ls]), 3 * pf.cout,
+                                   pf.cin, 1, 1, ws)
+                self.fused_qkv[p] = _Layer(ls[0].kind, pk, None)
+        self.tib_table = None
+        self.prepared = True
+
+    # ------------------------------------------------------------------ temporal information block
+    def _linear(self, name, x, silu_in):
+        ent = self.lin[name]
+        if ent[0] == "fp":
+            return ops.linear_small_f32(x, ent[1], ent[2], silu_in=silu_in)
+        return ops.linear_small_w4(x, ent[1], ent[3] if ent[3] is not None else ops.qsel(None), silu_in=silu_in)
+
+    def tib(self, t: torch.Tensor) -> List[torch.Tensor]:
+        """QuantTemporalInformationBlockDDIM.forward (quant/quant_block.py:52-64): t [m] fp32 ->
+        list of the per-ResnetBlock projections [m, Cout_i]."""
+        emb = ops.timestep_embedding(t, self.cfg["ch"])
+        h = self._linear("temb.dense.0", emb, False)
+        temb = self._linear("temb.dense.1", h, True)
+        return [self._linear(r + ".temb_proj", temb, True) for r in self.res_names]
+
+    def build_tib_table(self, t_values: Sequence[float]):
+        """The TIB depends only on the step: evaluate it once per sampling step (with that
+        step's activation parameters) into a [n_steps, sum Cout] table; the conv epilogues then
+        index it with the device-side step counter (K7)."""
+        if self.step is None and self.qtable is not None and self.qtable.shape[0] > 1:
+            raise TfmqError("build_tib_table: a multi-step qtable needs a device step counter")
+        rows = []
+        for s, tv in enumerate(t_values):
+            if self.step is not None:
+                self.step.fill_(s)
+            t = torch.full((1,), float(tv), dtype=torch.float32, device=self.dev)
+            rows.append(torch.cat(self.tib(t), dim=1))
+        self.tib_table = torch.cat(rows, dim=0).contiguous()
+        off = 0
+        for r in self.res_names:
+            self.tib_off[r] = off
+            off += self.sd[r + ".temb_proj.weight"].shape[0]
+        if self.step is not None:
+            self.step.zero_()
+        return self.tib_table
+
+    # ------------------------------------------------------------------ blocks
+    def _gn(self, name, x1, x2, silu, layer: Optional[_Layer], want_cat=False):
+        aq = layer.aq if (layer is not None and layer.kind == "w4a8") else None
+        yq, yf, xcat = ops.groupnorm(x1, self.sd[name + ".weight"], self.sd[name + ".bias"], 1e-6, silu, aq, x2=x2,
+                                     want_cat=want_cat)
+        return (yq if aq is not None else yf), xcat
+
+    def _resblock(self, p, x1, x2, rowadd_kw):
+        L = self.layers
+        has_sc = (p + ".nin_shortcut") in L
+        if x2 is not None and not has_sc:
+            raise TfmqError(f"{p}: concatenated input without nin_shortcut is not a DDPM-UNet block")
+        h, xcat = self._gn(p + ".norm1", x1, x2, True, L[p + ".conv1"], want_cat=has_sc and x2 is not None)
+        h = L[p + ".conv1"].run(h, pad=(1, 1, 1, 1), **rowadd_kw)
+        h, _ = self._gn(p + ".norm2", h, None, True, L[p + ".conv2"])
+        if has_sc:
+            sc = L[p + ".nin_shortcut"].run(xcat if x2 is not None else x1)
+        else:
+            sc = x1
+        return L[p + ".conv2"].run(h, pad=(1, 1, 1, 1), residual=sc)
+
+    def _attnblock(self, p, x):
+        L = self.layers
+        B, H, W, Cc = x.shape
+        po = L[p + ".proj_out"]
+        if p in self.fused_qkv:
+            f = self.fused_qkv[p]
+            h, _ = self._gn(p + ".norm", x, None, False, f)
+            qkv = f.run(h)
+        else:
+            qkv = ops._alloc(B, H, W, 3 * Cc, dtype=torch.float32, device=x.device)
+            cache = {}
+            for i, s in enumerate((".q", ".k", ".v")):
+                l = L[p + s]
+                key = (l.kind == "w4a8", l.aq.qid if l.aq is not None else -1)
+                if key not in cache:
+                    cache[key], _ = self._gn(p + ".norm", x, None, False, l)
+                l.run(cache[key], out=qkv, y_coff=i * Cc)
+        qkv = qkv.reshape(B, H * W, 3 * Cc)
+        aq = po.aq if po.kind == "w4a8" else None
+        out, oq = ops.attention(qkv[..., :Cc], qkv[..., Cc:2 * Cc], qkv[..., 2 * Cc:], 1, float(int(Cc) ** (-0.5)), aq,
+                                want_f32=aq is None)
+        a = (oq if aq is not None else out).reshape(B, H, W, Cc)
+        return po.run(a, residual=x)
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, x: torch.Tensor, t: Optional[torch.Tensor] = None, taps: Optional[dict] = None) -> torch.Tensor:
+        """x: fp32 NHWC [B,H,W,C].  t: [B] fp32 timesteps, or None to use the per-step TIB table
+        (build_tib_table) indexed by the device step counter."""
+        if not self.prepared:
+            raise TfmqError("DdimUNetEngine.forward before prepare()")
+        cfg, L = self.cfg, self.layers
+        nlev, nres = len(cfg["ch_mult"]), cfg["num_res_blocks"]
+        if t is not None:
+            projs = dict(zip(self.res_names, self.tib(t)))
+
+            def rowadd(p):
+                return dict(rowadd=projs[p])
+        else:
+            if self.tib_table is None:
+                raise TfmqError("forward(t=None) needs build_tib_table() first")
+
+            def rowadd(p):
+                o = self.tib_off[p]
+                return dict(rowadd=self.tib_table[0, o:], rowadd_ld=0, rowadd_step=self.step,
+                            rowadd_step_stride=self.tib_table.shape[1])
+
+        def tap(name, a, b):
+            if taps is not None:
+                taps[name] = (a, b)
+
+        hs = [L["conv_in"].run(x, pad=(1, 1, 1, 1))]
+        res = cfg["resolution"]
+        for i in range(nlev):
+            for j in range(nres):
+                p = f"down.{i}.block.{j}"
+                h = self._resblock(p, hs[-1], None, rowadd(p))
+                tap(p, hs[-1], h)
+                if res in cfg["attn_resolutions"]:
+                    hin = h
+                    h = self._attnblock(f"down.{i}.attn.{j}", h)
+                    tap(f"down.{i}.attn.{j}", hin, h)
+                hs.append(h)
+            if i != nlev - 1:
+                # Downsample (ddim/models/diffusion.py:65-72): pad (0,1,0,1), 3x3 stride 2, un-quantised
+                hs.append(L[f"down.{i}.downsample.conv"].run(hs[-1], stride=2, pad=(0, 0, 1, 1)))
+                res //= 2
+        h = hs[-1]
+        hin = h
+        h = self._resblock("mid.block_1", h, None, rowadd("mid.block_1"))
+        tap("mid.block_1", hin, h)
+        hin = h
+        h = self._attnblock("mid.attn_1", h)
+        tap("mid.attn_1", hin, h)
+        hin = h
+        h = self._resblock("mid.block_2", h, None, rowadd("mid.block_2"))
+        tap("mid.block_2", hin, h)
+        for i in reversed(range(nlev)):
+            for j in range(nres + 1):
+                p = f"up.{i}.block.{j}"
+                skip = hs.pop()
+                hin = h
+                h = self._resblock(p, h, skip, rowadd(p))
+                tap(p, (hin, skip), h)
+                if res in cfg["attn_resolutions"]:
+                    hin = h
+                    h = self._attnblock(f"up.{i}.attn.{j}", h)
+                    tap(f"up.{i}.attn.{j}", hin, h)
+            if i != 0:
+                up = L[f"up.{i}.upsample.conv"]
+                hq = ops.quantize_act(h, up.aq) if up.kind == "w4a8" else h
+                h = up.run(hq, pad=(1, 1, 1, 1), up2x=True)
+                res *= 2
+        h, _ = self._gn("norm_out", h, None, True, None)
+        return L["conv_out"].run(h, pad=(1, 1, 1, 1))

@@ -16,6 +16,72 @@ from ._lib import ConvDesc, GnDesc, QSel, TfmqError, handle
 NULL = None
 
 
+class Arena:
+    """Replayable allocation log.  The first pass through a plan allocates (torch caching
+    allocator) and records every tensor; later passes hand out the same tensors in the same
+    order, so (a) the sequence of launches is legal inside a HIP stream capture (no hipMalloc)
+    and (b) the pointers baked into the captured hipGraph stay owned by the plan."""
+
+    def __init__(self):
+        self.tensors = []
+        self.cursor = 0
+        self.frozen = False
+
+    def rewind(self):
+        self.cursor = 0
+        self.frozen = len(self.tensors) > 0
+
+    def take(self, shape, dtype, device):
+        shape = tuple(int(s) for s in (shape if isinstance(shape, (tuple, list, torch.Size)) else (shape,)))
+        if self.frozen:
+            if self.cursor >= len(self.tensors):
+                raise TfmqError("Arena: replay allocates more tensors than the recorded pass")
+            t = self.tensors[self.cursor]
+            if tuple(t.shape) != shape or t.dtype != dtype:
+                raise TfmqError(f"Arena: replay mismatch at #{self.cursor}: {tuple(t.shape)}/{t.dtype} vs {shape}/{dtype}")
+        else:
+            t = torch.empty(shape, dtype=dtype, device=device)
+            self.tensors.append(t)
+        self.cursor += 1
+        return t
+
+    def nbytes(self):
+        return sum(t.numel() * t.element_size() for t in self.tensors)
+
+
+_arena: Optional[Arena] = None
+
+
+class use_arena:
+    def __init__(self, arena: Optional[Arena]):
+        self.arena = arena
+
+    def __enter__(self):
+        global _arena
+        self.prev = _arena
+        _arena = self.arena
+        if self.arena is not None:
+            self.arena.rewind()
+        return self.arena
+
+    def __exit__(self, *exc):
+        global _arena
+        _arena = self.prev
+        return False
+
+
+def _alloc(*shape, dtype=torch.float32, device=None):
+    if len(shape) == 1 and isinstance(shape[0], (tuple, list, torch.Size)):
+        shape = tuple(shape[0])
+    if _arena is not None:
+        return _arena.take(shape, dtype, device)
+    return torch.empty(shape, dtype=dtype, device=device)
+
+
+def _alloc_like(t: torch.Tensor):
+    return _alloc(tuple(t.shape), dtype=t.dtype, device=t.device)
+
+
 def _dev(t: torch.Tensor) -> int:
     if not t.is_cuda:
         raise TfmqError("TFMQ hot path got a CPU tensor: the HIP kernels are the only implementation "
@@ -42,14 +108,16 @@ def qsel(qtable: Optional[torch.Tensor], qid: int = 0, step: Optional[torch.Tens
         return QSel(None, None, 0, 0)
     _chk(qtable, torch.float32, "qtable")
     stride = qtable.shape[-2] if qtable.dim() >= 2 else 1
-    return QSel(qtable.data_ptr(), None if step is None else step.data_ptr(), int(stride), int(qid))
+    sel = QSel(qtable.data_ptr(), None if step is None else step.data_ptr(), int(stride), int(qid))
+    sel._keep = (qtable, step)  # the struct only holds raw pointers: keep the tensors alive with it
+    return sel
 
 
 # ------------------------------------------------------------------------------ K1 / K2 / K3
 def quantize_act(x: torch.Tensor, qs: QSel, level: int = 256, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     d = _dev(x)
     _chk(x, torch.float32, "x")
-    q = out if out is not None else torch.empty(x.shape, dtype=torch.int8, device=x.device)
+    q = out if out is not None else _alloc(x.shape, dtype=torch.int8, device=x.device)
     handle(d).call("quantize_act", _p(x), _p(q), x.numel(), qs, level, _stream(d))
     return q
 
@@ -62,8 +130,8 @@ def fake_quant(x: torch.Tensor, delta: torch.Tensor, zp: torch.Tensor, level: in
     cols = x.numel() // rows
     dl = delta.reshape(-1).contiguous().float()
     z = zp.reshape(-1).contiguous().float()
-    y = torch.empty_like(x)
-    idx = torch.empty(x.shape, dtype=torch.uint8, device=x.device) if want_idx else None
+    y = _alloc_like(x)
+    idx = _alloc(x.shape, dtype=torch.uint8, device=x.device) if want_idx else None
     handle(d).call("fake_quant", _p(x), _p(y), _p(idx), rows, cols, _p(dl), _p(z), level, _stream(d))
     return (y, idx) if want_idx else y
 
@@ -74,8 +142,8 @@ def minmax(x: torch.Tensor, rows: int = 1) -> torch.Tensor:
     _chk(x, torch.float32, "x")
     cols = x.numel() // rows
     h = handle(d)
-    ws = torch.empty(h.lib.tfmq_minmax_ws_bytes(rows, cols), dtype=torch.uint8, device=x.device)
-    out = torch.empty(rows, 2, dtype=torch.float32, device=x.device)
+    ws = _alloc(h.lib.tfmq_minmax_ws_bytes(rows, cols), dtype=torch.uint8, device=x.device)
+    out = _alloc(rows, 2, dtype=torch.float32, device=x.device)
     h.call("minmax", _p(x), rows, cols, _p(out), _p(ws), _stream(d))
     return out
 
@@ -83,7 +151,7 @@ def minmax(x: torch.Tensor, rows: int = 1) -> torch.Tensor:
 def minmax_to_qparam(mm: torch.Tensor, level: int, always_zero: bool = False) -> torch.Tensor:
     d = _dev(mm)
     rows = mm.shape[0]
-    qp = torch.empty(rows, 2, dtype=torch.float32, device=mm.device)
+    qp = _alloc(rows, 2, dtype=torch.float32, device=mm.device)
     handle(d).call("minmax_to_qparam", _p(mm), rows, level, int(always_zero), _p(qp), _stream(d))
     return qp
 
@@ -100,10 +168,10 @@ def mse_search(x: torch.Tensor, rows: int, level: int, always_zero: bool = False
     cols = x.numel() // rows
     h = handle(d)
     mm = minmax(x, rows)
-    ws = torch.empty(h.lib.tfmq_mse_ws_bytes(rows, cols), dtype=torch.uint8, device=x.device)
-    qp = torch.empty(rows, 2, dtype=torch.float32, device=x.device)
-    losses = torch.empty(rows, 80, dtype=torch.float32, device=x.device) if want_losses else None
-    best = torch.empty(rows, dtype=torch.int32, device=x.device) if want_losses else None
+    ws = _alloc(h.lib.tfmq_mse_ws_bytes(rows, cols), dtype=torch.uint8, device=x.device)
+    qp = _alloc(rows, 2, dtype=torch.float32, device=x.device)
+    losses = _alloc(rows, 80, dtype=torch.float32, device=x.device) if want_losses else None
+    best = _alloc(rows, dtype=torch.int32, device=x.device) if want_losses else None
     h.call("mse_search", _p(x), rows, cols, _p(mm), level, int(always_zero), _p(qp), _p(losses), _p(best), _p(ws), _stream(d))
     return (qp, losses, best) if want_losses else qp
 
@@ -133,26 +201,29 @@ def pack_w4(w: torch.Tensor, delta: torch.Tensor, zp: torch.Tensor, alpha: Optio
         raise TfmqError("pack_w4: |weight zero-point| > 255 is not supported by the int32 epilogue")
     if alpha is not None:
         _chk(alpha, torch.float32, "alpha")
-    packed = torch.empty(cout, kh * kw * cin // 2, dtype=torch.uint8, device=w.device)
-    wmeta = torch.empty(cout, 4, dtype=torch.int32, device=w.device)
+    packed = _alloc(cout, kh * kw * cin // 2, dtype=torch.uint8, device=w.device)
+    wmeta = _alloc(cout, 4, dtype=torch.int32, device=w.device)
     handle(d).call("pack_w4", _p(w), _p(alpha), _p(dl), _p(z), cout, cin, kh, kw, _p(packed), _p(wmeta), _stream(d))
     return PackedW4(packed, wmeta, dl, None if bias is None else bias.contiguous().float(), cout, cin, kh, kw)
 
 
 def unpack_w4(pw: PackedW4) -> torch.Tensor:
     d = _dev(pw.packed)
-    idx = torch.empty(pw.cout, pw.cin, pw.kh, pw.kw, dtype=torch.uint8, device=pw.packed.device)
+    idx = _alloc(pw.cout, pw.cin, pw.kh, pw.kw, dtype=torch.uint8, device=pw.packed.device)
     handle(d).call("unpack_w4", _p(pw.packed), pw.cout, pw.cin, pw.kh, pw.kw, _p(idx), _stream(d))
     return idx
 
 
 class PackedF16:
-    def __init__(self, w16, bias, cout, cin, kh, kw):
-        self.w16, self.bias = w16, bias
+    """f16 weights [cout][tap][cin_pad]; wscale != None => integer grid of a weight-only quantised layer."""
+
+    def __init__(self, w16, bias, cout, cin, kh, kw, wscale=None):
+        self.w16, self.bias, self.wscale = w16, bias, wscale
         self.cout, self.cin, self.kh, self.kw = cout, cin, kh, kw
 
 
-def pack_w_f16(w: torch.Tensor, bias: Optional[torch.Tensor] = None) -> PackedF16:
+def pack_w_f16(w: torch.Tensor, bias: Optional[torch.Tensor] = None, delta: Optional[torch.Tensor] = None,
+               zp: Optional[torch.Tensor] = None, alpha: Optional[torch.Tensor] = None, level: int = 16) -> PackedF16:
     d = _dev(w)
     _chk(w, torch.float32, "w")
     if w.dim() == 2:
@@ -160,19 +231,25 @@ def pack_w_f16(w: torch.Tensor, bias: Optional[torch.Tensor] = None) -> PackedF1
     else:
         cout, cin, kh, kw = w.shape
     cin_pad = (cin + 31) // 32 * 32
-    out = torch.empty(cout, kh * kw, cin_pad, dtype=torch.float16, device=w.device)
-    handle(d).call("pack_w_f16", _p(w), cout, cin, kh, kw, _p(out), _stream(d))
-    return PackedF16(out, None if bias is None else bias.contiguous().float(), cout, cin, kh, kw)
+    out = _alloc(cout, kh * kw, cin_pad, dtype=torch.float16, device=w.device)
+    dl = None if delta is None else delta.reshape(-1).contiguous().float()
+    z = None if zp is None else zp.reshape(-1).contiguous().float()
+    handle(d).call("pack_w_f16", _p(w), _p(alpha), _p(dl), _p(z), level, cout, cin, kh, kw, _p(out), _stream(d))
+    return PackedF16(out, None if bias is None else bias.contiguous().float(), cout, cin, kh, kw, wscale=dl)
 
 
 # ------------------------------------------------------------------------------ K5 / K6
-def _conv_desc(x, B, H, W, cin, cout, kh, kw, stride, pad_t, pad_l, Ho, Wo, up2x, y, ldy, y_coff, rowadd, residual):
+def _conv_desc(x, B, H, W, cin, cout, kh, kw, stride, pad_t, pad_l, Ho, Wo, up2x, y, ldy, y_coff, rowadd, residual,
+               rowadd_ld=None, rowadd_step=None, rowadd_step_stride=0):
     dsc = ConvDesc()
     dsc.B, dsc.H, dsc.W, dsc.Cin = B, H, W, cin
     dsc.Cout, dsc.KH, dsc.KW, dsc.stride = cout, kh, kw, stride
     dsc.pad_t, dsc.pad_l, dsc.Ho, dsc.Wo, dsc.up2x = pad_t, pad_l, Ho, Wo, int(up2x)
     dsc.x = x.data_ptr()
     dsc.rowadd = None if rowadd is None else rowadd.data_ptr()
+    dsc.rowadd_ld = cout if rowadd_ld is None else int(rowadd_ld)
+    dsc.rowadd_step = None if rowadd_step is None else rowadd_step.data_ptr()
+    dsc.rowadd_step_stride = int(rowadd_step_stride)
     dsc.residual = None if residual is None else residual.data_ptr()
     dsc.y = y.data_ptr()
     dsc.ldy, dsc.y_coff = ldy, y_coff
@@ -187,7 +264,8 @@ def out_hw(H, W, kh, kw, stride, pad_t, pad_l, pad_b, pad_r, up2x=False):
 
 def conv2d_w4a8(xq: torch.Tensor, pw: PackedW4, aq: QSel, stride: int = 1, pad: Tuple[int, int, int, int] = (0, 0, 0, 0),
                 up2x: bool = False, rowadd: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
-                out: Optional[torch.Tensor] = None, y_coff: int = 0) -> torch.Tensor:
+                out: Optional[torch.Tensor] = None, y_coff: int = 0, rowadd_ld=None, rowadd_step=None,
+                rowadd_step_stride: int = 0) -> torch.Tensor:
     """xq: int8 NHWC [B,H,W,Cin] (bin-128).  pad = (top, left, bottom, right).  -> fp32 NHWC."""
     d = _dev(xq)
     _chk(xq, torch.int8, "xq")
@@ -195,9 +273,9 @@ def conv2d_w4a8(xq: torch.Tensor, pw: PackedW4, aq: QSel, stride: int = 1, pad: 
     if cin != pw.cin:
         raise TfmqError(f"conv2d_w4a8: Cin mismatch {cin} vs {pw.cin}")
     Ho, Wo = out_hw(H, W, pw.kh, pw.kw, stride, pad[0], pad[1], pad[2], pad[3], up2x)
-    y = out if out is not None else torch.empty(B, Ho, Wo, pw.cout, dtype=torch.float32, device=xq.device)
+    y = out if out is not None else _alloc(B, Ho, Wo, pw.cout, dtype=torch.float32, device=xq.device)
     dsc = _conv_desc(xq, B, H, W, cin, pw.cout, pw.kh, pw.kw, stride, pad[0], pad[1], Ho, Wo, up2x, y, y.shape[-1], y_coff,
-                     rowadd, residual)
+                     rowadd, residual, rowadd_ld, rowadd_step, rowadd_step_stride)
     dsc.w, dsc.wmeta, dsc.wscale = pw.packed.data_ptr(), pw.wmeta.data_ptr(), pw.wscale.data_ptr()
     dsc.bias = None if pw.bias is None else pw.bias.data_ptr()
     dsc.aq = aq
@@ -207,7 +285,8 @@ def conv2d_w4a8(xq: torch.Tensor, pw: PackedW4, aq: QSel, stride: int = 1, pad: 
 
 def conv2d_f16(x: torch.Tensor, pf: PackedF16, stride: int = 1, pad: Tuple[int, int, int, int] = (0, 0, 0, 0),
                up2x: bool = False, rowadd: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
-               out: Optional[torch.Tensor] = None, y_coff: int = 0) -> torch.Tensor:
+               out: Optional[torch.Tensor] = None, y_coff: int = 0, rowadd_ld=None, rowadd_step=None,
+               rowadd_step_stride: int = 0) -> torch.Tensor:
     """x: fp32 NHWC.  Un-quantised layers (f16 MFMA, fp32 accumulate)."""
     d = _dev(x)
     _chk(x, torch.float32, "x")
@@ -215,10 +294,11 @@ def conv2d_f16(x: torch.Tensor, pf: PackedF16, stride: int = 1, pad: Tuple[int, 
     if cin != pf.cin:
         raise TfmqError(f"conv2d_f16: Cin mismatch {cin} vs {pf.cin}")
     Ho, Wo = out_hw(H, W, pf.kh, pf.kw, stride, pad[0], pad[1], pad[2], pad[3], up2x)
-    y = out if out is not None else torch.empty(B, Ho, Wo, pf.cout, dtype=torch.float32, device=x.device)
+    y = out if out is not None else _alloc(B, Ho, Wo, pf.cout, dtype=torch.float32, device=x.device)
     dsc = _conv_desc(x, B, H, W, cin, pf.cout, pf.kh, pf.kw, stride, pad[0], pad[1], Ho, Wo, up2x, y, y.shape[-1], y_coff,
-                     rowadd, residual)
+                     rowadd, residual, rowadd_ld, rowadd_step, rowadd_step_stride)
     dsc.w = pf.w16.data_ptr()
+    dsc.wscale = None if pf.wscale is None else pf.wscale.data_ptr()
     dsc.bias = None if pf.bias is None else pf.bias.data_ptr()
     dsc.aq = QSel(None, None, 0, 0)
     handle(d).call("conv2d_f16", C.byref(dsc), _stream(d))
@@ -229,7 +309,7 @@ def conv2d_f16(x: torch.Tensor, pf: PackedF16, stride: int = 1, pad: Tuple[int, 
 def timestep_embedding(t: torch.Tensor, dim: int, ldm_order: bool = False) -> torch.Tensor:
     d = _dev(t)
     _chk(t, torch.float32, "t")
-    emb = torch.empty(t.numel(), dim, dtype=torch.float32, device=t.device)
+    emb = _alloc(t.numel(), dim, dtype=torch.float32, device=t.device)
     handle(d).call("timestep_embedding", _p(t), t.numel(), dim, int(ldm_order), _p(emb), _stream(d))
     return emb
 
@@ -238,7 +318,7 @@ def linear_small_f32(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tens
     d = _dev(x)
     m, k = x.shape
     n = w.shape[0]
-    y = torch.empty(m, n, dtype=torch.float32, device=x.device)
+    y = _alloc(m, n, dtype=torch.float32, device=x.device)
     handle(d).call("linear_small_f32", _p(x), _p(w), _p(bias), _p(y), m, n, k, int(silu_in), _stream(d))
     return y
 
@@ -246,7 +326,7 @@ def linear_small_f32(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tens
 def linear_small_w4(x: torch.Tensor, pw: PackedW4, aq: QSel, silu_in: bool = False) -> torch.Tensor:
     d = _dev(x)
     m, k = x.shape
-    y = torch.empty(m, pw.cout, dtype=torch.float32, device=x.device)
+    y = _alloc(m, pw.cout, dtype=torch.float32, device=x.device)
     handle(d).call("linear_small_w4", _p(x), _p(pw.packed), _p(pw.wmeta), _p(pw.wscale), _p(pw.bias), aq, _p(y), m, pw.cout,
                    k, int(silu_in), _stream(d))
     return y
@@ -270,15 +350,15 @@ def groupnorm(x1: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: fl
     yq = yf = xcat = None
     if aq is not None and aq.qtable:
         g.aq = aq
-        yq = torch.empty(shape, dtype=torch.int8, device=x1.device)
+        yq = _alloc(shape, dtype=torch.int8, device=x1.device)
         g.yq = yq.data_ptr()
     else:
         g.aq = QSel(None, None, 0, 0)
     if want_f32 or yq is None:
-        yf = torch.empty(shape, dtype=torch.float32, device=x1.device)
+        yf = _alloc(shape, dtype=torch.float32, device=x1.device)
         g.yf = yf.data_ptr()
     if want_cat:
-        xcat = torch.empty(shape, dtype=torch.float32, device=x1.device)
+        xcat = _alloc(shape, dtype=torch.float32, device=x1.device)
         g.xcat = xcat.data_ptr()
     handle(d).call("groupnorm", C.byref(g), _stream(d))
     return yq, yf, xcat
@@ -296,11 +376,11 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int, sca
     for t in (q, k, v):
         if t.dtype != torch.float32 or t.stride(-1) != 1 or t.stride(0) != t.shape[1] * t.stride(1):
             raise TfmqError("attention: q/k/v must be fp32 [B,T,C] with unit channel stride and dense batch/token strides")
-    out = torch.empty(B, Tq, Cq, dtype=torch.float32, device=q.device) if want_f32 else None
+    out = _alloc(B, Tq, Cq, dtype=torch.float32, device=q.device) if want_f32 else None
     yq = None
     sel = QSel(None, None, 0, 0)
     if aq is not None and aq.qtable:
-        yq = torch.empty(B, Tq, Cq, dtype=torch.int8, device=q.device)
+        yq = _alloc(B, Tq, Cq, dtype=torch.int8, device=q.device)
         sel = aq
     handle(d_).call("attention", _p(q), _p(k), _p(v), q.stride(1), k.stride(1), v.stride(1), _p(out), Cq, _p(yq), sel, B,
                     heads, Tq, Tk, dh, float(scale), _stream(d_))
@@ -308,10 +388,11 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int, sca
 
 
 # ------------------------------------------------------------------------------ K11
-def ddim_update(x, eps, coef, step=None, noise=None, want_x0=False):
+def ddim_update(x, eps, coef, step=None, noise=None, want_x0=False, out=None):
+    """out=x is allowed (the update is elementwise)."""
     d = _dev(x)
-    xn = torch.empty_like(x)
-    x0 = torch.empty_like(x) if want_x0 else None
+    xn = out if out is not None else _alloc_like(x)
+    x0 = _alloc_like(x) if want_x0 else None
     handle(d).call("ddim_update", _p(x), _p(eps), _p(noise), _p(xn), _p(x0), x.numel(), _p(coef), _p(step), _stream(d))
     return (xn, x0) if want_x0 else xn
 
@@ -325,7 +406,7 @@ def nchw_to_nhwc(x: torch.Tensor) -> torch.Tensor:
     d = _dev(x)
     _chk(x, torch.float32, "x")
     B, Cc, H, W = x.shape
-    y = torch.empty(B, H, W, Cc, dtype=torch.float32, device=x.device)
+    y = _alloc(B, H, W, Cc, dtype=torch.float32, device=x.device)
     handle(d).call("nchw_to_nhwc", _p(x), _p(y), B, Cc, H * W, _stream(d))
     return y
 
@@ -334,7 +415,7 @@ def nhwc_to_nchw(x: torch.Tensor) -> torch.Tensor:
     d = _dev(x)
     _chk(x, torch.float32, "x")
     B, H, W, Cc = x.shape
-    y = torch.empty(B, Cc, H, W, dtype=torch.float32, device=x.device)
+    y = _alloc(B, Cc, H, W, dtype=torch.float32, device=x.device)
     handle(d).call("nhwc_to_nchw", _p(x), _p(y), B, Cc, H * W, _stream(d))
     return y
 
@@ -343,7 +424,7 @@ def nhwc_to_nchw(x: torch.Tensor) -> torch.Tensor:
 def adaround_init(w: torch.Tensor, delta: torch.Tensor) -> torch.Tensor:
     d = _dev(w)
     rows = delta.numel()
-    alpha = torch.empty_like(w)
+    alpha = _alloc_like(w)
     handle(d).call("adaround_init", _p(w), _p(delta.reshape(-1).contiguous()), _p(alpha), rows, w.numel() // rows, _stream(d))
     return alpha
 
@@ -351,7 +432,7 @@ def adaround_init(w: torch.Tensor, delta: torch.Tensor) -> torch.Tensor:
 def adaround_soft_fwd(w, alpha, delta, zp, level: int) -> torch.Tensor:
     d = _dev(w)
     rows = delta.numel()
-    w_hat = torch.empty_like(w)
+    w_hat = _alloc_like(w)
     handle(d).call("adaround_soft_fwd", _p(w), _p(alpha), _p(delta.reshape(-1).contiguous()), _p(zp.reshape(-1).contiguous()),
                    _p(w_hat), rows, w.numel() // rows, level, _stream(d))
     return w_hat
@@ -369,6 +450,6 @@ def adaround_bwd_adam(w, alpha, delta, zp, g_what, m, v, level: int, w_reg: floa
 def recon_loss(pred, tgt, denom: int, want_grad: bool = True):
     d = _dev(pred)
     loss = torch.zeros(1, dtype=torch.float32, device=pred.device)
-    g = torch.empty_like(pred) if want_grad else None
+    g = _alloc_like(pred) if want_grad else None
     handle(d).call("recon_loss", _p(pred), _p(tgt), _p(g), pred.numel(), int(denom), _p(loss), _stream(d))
     return loss, g
