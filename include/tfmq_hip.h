@@ -184,6 +184,8 @@ int tfmq_attention(tfmq_handle h, const float* q, const float* k, const float* v
 int tfmq_ddim_update(tfmq_handle h, const float* x, const float* eps, const float* noise_or_null, float* x_next,
                      float* x0_or_null, size_t n, const float* coef, const int32_t* step, void* stream);
 int tfmq_step_advance(tfmq_handle h, int32_t* step, int delta, void* stream);
+/* y = x*sigmoid(x)  (nonlinearity, ddim/models/diffusion.py:27-29) */
+int tfmq_silu(tfmq_handle h, const float* x, float* y, size_t n, void* stream);
 int tfmq_nchw_to_nhwc(tfmq_handle h, const float* x, float* y, int B, int C, int HW, void* stream);
 int tfmq_nhwc_to_nchw(tfmq_handle h, const float* x, float* y, int B, int C, int HW, void* stream);
 

@@ -79,6 +79,7 @@ _SIGS = {
                                c_int, c_int, c_int, c_int, c_int, c_float, c_void_p]),
     "tfmq_ddim_update": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p]),
     "tfmq_step_advance": (c_int, [c_void_p, c_void_p, c_int, c_void_p]),
+    "tfmq_silu": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "tfmq_nchw_to_nhwc": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "tfmq_nhwc_to_nchw": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "tfmq_adaround_init": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_size_t, c_void_p]),
@@ -110,6 +111,10 @@ def load() -> C.CDLL:
         raise TfmqError(
             f"{LIB_PATH} is missing: build it with `python tfmq-dm_amd/build.py` (or __graft_entry__.build()). "
             "There is no CPU fallback for the TFMQ hot path.")
+    # torch owns the device memory and streams handed to the kernels, so both must share ONE HIP
+    # runtime: import torch first so libtfmq_hip.so binds to the libamdhip64 torch already loaded
+    # (loading ours first pulls a second runtime from /opt/rocm and tfmq_create then sees no device).
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in _SIGS.items():
         fn = getattr(lib, name)  # AttributeError if the library does not export a declared symbol

@@ -90,6 +90,22 @@ extern "C" int tfmq_nhwc_to_nchw(tfmq_handle h, const float* x, float* y, int B,
   return TFMQ_OK;
 }
 
+// y = x*sigmoid(x) (nonlinearity, ddim/models/diffusion.py:27-29): only used standalone when the
+// activation calibration has to observe the SiLU'd embedding before it is quantised.
+__global__ __launch_bounds__(256) void k_silu(const float* __restrict__ x, float* __restrict__ y, size_t n) {
+  const size_t stride = static_cast<size_t>(gridDim.x) * blockDim.x;
+  for (size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) y[i] = silu_f(x[i]);
+}
+extern "C" int tfmq_silu(tfmq_handle h, const float* x, float* y, size_t n, void* stream) {
+  TFMQ_CHECK_ARG(h, h && x && y, "silu: null pointer");
+  if (n == 0) return TFMQ_OK;
+  int blocks = ceil_div(static_cast<long>(n), 256);
+  if (blocks > h->cu_count * 8) blocks = h->cu_count * 8;
+  hipLaunchKernelGGL(k_silu, dim3(blocks), dim3(256), 0, as_stream(stream), x, y, n);
+  TFMQ_LAUNCH_CHECK(h);
+  return TFMQ_OK;
+}
+
 // ------------------------------------------------------------------------------ K7
 __global__ void k_timestep_embedding(const float* __restrict__ t, int m, int dim, int ldm_order, float* __restrict__ emb) {
   const int half = dim / 2;

@@ -1,0 +1,143 @@
+"""DDIM sampling loop of the pixel-space path.
+
+`generalized_steps` keeps the reference's signature and return value
+(ddim/functions/denoising.py:10-41) for drop-in use; `GraphDdimSampler` is the MI355X-native
+form of the same loop: the whole step (UNet forward on the HIP engine, DDIM update, step counter)
+is captured once into a hipGraph and replayed per step -- no per-step `load_state_dict`
+(denoising.py:26-29), no host<->device copies of x (:23,32,38), no Python in the timed loop.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from .. import ops
+from .._lib import TfmqError, handle
+
+
+def linear_betas(beta_start: float = 1e-4, beta_end: float = 0.02, n: int = 1000) -> torch.Tensor:
+    """get_beta_schedule('linear') -> float32 (ddim/runners/diffusion.py:46-49,83)."""
+    return torch.from_numpy(np.linspace(beta_start, beta_end, n, dtype=np.float64)).float()
+
+
+def step_sequence(skip_type: str, timesteps: int, num_timesteps: int = 1000) -> List[int]:
+    """sample_image (ddim/runners/diffusion.py:437-447)."""
+    if skip_type == "uniform":
+        return list(range(0, num_timesteps, num_timesteps // timesteps))
+    if skip_type == "quad":
+        return [int(s) for s in list(np.linspace(0, np.sqrt(num_timesteps * 0.8), timesteps) ** 2)]
+    raise NotImplementedError(skip_type)
+
+
+def alpha_bar(betas: torch.Tensor, t: torch.Tensor) -> torch.Tensor:
+    """compute_alpha (ddim/functions/denoising.py:4-7) on the host: schedule constants."""
+    b = torch.cat([torch.zeros(1), betas.cpu()], dim=0)
+    return (1 - b).cumprod(dim=0).index_select(0, t.long() + 1)
+
+
+def coef_table(seq: Sequence[int], betas: torch.Tensor, eta: float = 0.0) -> torch.Tensor:
+    """Row k (k-th executed step): {sqrt(1-a_t), sqrt(a_t), sqrt(a_next), c1, c2, t, 0, 0}, every
+    entry produced by the same fp32 tensor ops the reference applies per step (denoising.py:21-37)."""
+    seq = list(seq)
+    seq_next = [-1] + seq[:-1]
+    rows = []
+    for i, j in zip(reversed(seq), reversed(seq_next)):
+        at = alpha_bar(betas, torch.tensor([i]))
+        an = alpha_bar(betas, torch.tensor([j]))
+        c1 = eta * ((1 - at / an) * (1 - an) / (1 - at)).sqrt()
+        c2 = ((1 - an) - c1 ** 2).sqrt()
+        rows.append(torch.cat([(1 - at).sqrt(), at.sqrt(), an.sqrt(), c1.reshape(1).float(), c2, torch.tensor([float(i)]),
+                               torch.zeros(2)]))
+    return torch.stack(rows).float().contiguous()
+
+
+def generalized_steps(x, seq, model, b, **kwargs):
+    """Drop-in for ddim/functions/denoising.py:10-41 on device tensors (NCHW).  `model(xt, t)`
+    returns eps; `kwargs`: eta, untill_fake_t, tot/cali_ckpt (per-step act_k via model.load_state_dict)."""
+    if not x.is_cuda:
+        raise TfmqError("generalized_steps: tensors must live on the MI355X (no CPU fallback)")
+    with torch.no_grad():
+        n = x.size(0)
+        seq = list(seq)
+        coef = coef_table(seq, b, kwargs.get("eta", 0)).to(x.device)
+        xs, x0_preds = [x], []
+        t = xt = None
+        for cnt, i in enumerate(reversed(seq)):
+            t = torch.full((n,), float(i), device=x.device)
+            xt = xs[-1]
+            if "untill_fake_t" in kwargs and cnt == kwargs["untill_fake_t"] - 1:
+                break
+            if kwargs.get("tot") is not None:
+                model.load_state_dict(kwargs["cali_ckpt"][f"act_{cnt}"], strict=False)
+            et = model(xt, t)
+            noise = torch.randn_like(xt) if kwargs.get("eta", 0) else None
+            xn, x0 = ops.ddim_update(xt.contiguous(), et.contiguous(), coef[cnt:cnt + 1].contiguous(), noise=noise, want_x0=True)
+            x0_preds.append(x0)
+            xs.append(xn)
+    return xs, x0_preds, xt, t
+
+
+class GraphDdimSampler:
+    """DDIM loop over a prepared DdimUNetEngine, one hipGraph replay per step."""
+
+    def __init__(self, engine, seq: Sequence[int], betas: torch.Tensor, batch: int, eta: float = 0.0):
+        if eta != 0.0:
+            raise TfmqError("GraphDdimSampler: eta != 0 needs a device RNG stream (not wired yet); use generalized_steps")
+        self.eng, self.seq, self.batch = engine, list(seq), batch
+        self.dev = engine.dev
+        self.n_steps = len(self.seq)
+        self.coef = coef_table(self.seq, betas, eta).to(self.dev)
+        if engine.step is None:
+            raise TfmqError("GraphDdimSampler: engine.prepare() needs a device step counter")
+        self.step = engine.step
+        engine.build_tib_table([float(i) for i in reversed(self.seq)])
+        cfg = engine.cfg
+        self.x = torch.empty(batch, cfg["resolution"], cfg["resolution"], cfg.get("in_channels", 3), device=self.dev)
+        self.stream = torch.cuda.Stream(self.dev)
+        self.arena = ops.Arena()
+        self.h = handle(self.dev.index or 0)
+        self.gid = None
+
+    def _step_body(self):
+        eps = self.eng.forward(self.x, None)
+        ops.ddim_update(self.x, eps, self.coef, self.step, out=self.x)
+        ops.step_advance(self.step, 1)
+
+    def capture(self):
+        sp = C.c_void_p(self.stream.cuda_stream)
+        with torch.cuda.stream(self.stream):
+            self.step.zero_()
+            with ops.use_arena(self.arena):   # warm-up pass: allocates every intermediate once
+                self._step_body()
+            self.stream.synchronize()
+            with ops.use_arena(self.arena):   # replay the allocation log under capture
+                self.h.call("graph_begin", sp)
+                self._step_body()
+                gid = C.c_int()
+                self.h.call("graph_end", sp, C.byref(gid))
+            self.gid = gid.value
+        return self
+
+    def sample_nhwc(self, x_T: torch.Tensor, steps: Optional[int] = None) -> torch.Tensor:
+        """x_T: [B,H,W,C] fp32 on the device -> x_0 (same layout, a view of the sampler's buffer)."""
+        if self.gid is None:
+            self.capture()
+        sp = C.c_void_p(self.stream.cuda_stream)
+        with torch.cuda.stream(self.stream):
+            self.x.copy_(x_T, non_blocking=True)
+            self.step.zero_()
+            for _ in range(self.n_steps if steps is None else steps):
+                self.h.call("graph_launch", self.gid, sp)
+        return self.x
+
+    def sample(self, x_T_nchw: torch.Tensor) -> torch.Tensor:
+        with torch.cuda.stream(self.stream):
+            xin = ops.nchw_to_nhwc(x_T_nchw.contiguous())
+        out = self.sample_nhwc(xin)
+        with torch.cuda.stream(self.stream):
+            y = ops.nhwc_to_nchw(out)
+        self.stream.synchronize()
+        return y

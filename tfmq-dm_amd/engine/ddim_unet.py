@@ -71,6 +71,10 @@ class DdimUNetEngine:
         self.tib_table = None
         self.tib_off: Dict[str, int] = {}
         self.prepared = False
+        # activation calibration (Finite-Set Calibration, quant/calibration.py:108-152)
+        self.calib = None          # None | ("init", k) | ("running", k)
+        self.act_state = None      # [n_q, 2] EMA {x_min, x_max} (quant_layer.py:229-244)
+        self._qp_scratch = None
 
     # ------------------------------------------------------------------ weights
     def _conv_names(self):
@@ -128,6 +132,7 @@ class DdimUNetEngine:
                                       torch.cat([l.p.wscale for l in ls]), torch.cat([l.p.bias for l in ls]),
                                       3 * ls[0].p.cout, ls[0].p.cin, 1, 1)
                     self.fused_qkv[p] = _Layer("w4a8", pk, ls[0].aq)
+                    self.fused_qkv[p].sibling_qids = tuple(ids[1:])
             elif all(l.kind in ("fp", "w4") for l in ls) and len({l.kind for l in ls}) == 1:
                 pf = ls[0].p
                 ws = None if pf.wscale is None else torch.cat([l.p.wscale for l in ls])
@@ -137,12 +142,51 @@ class DdimUNetEngine:
         self.tib_table = None
         self.prepared = True
 
+    # ------------------------------------------------------------------ activation calibration
+    def set_calibration(self, mode: Optional[str], k: int = 0):
+        """mode 'init': every live activation quantizer is (re)initialised on the tensor it sees with
+        the MSE scaler, in execution order, upstream layers already quantised (lazy init of
+        UniformAffineQuantizer.forward, quant_layer.py:211-221, as driven by calibration.py:113-127).
+        mode 'running': EMA min/max update then MINMAX (act_momentum_update, quant_layer.py:229-244).
+        Results land in qtable[k]."""
+        if mode is None:
+            self.calib = None
+            return
+        if self.qtable is None:
+            raise TfmqError("set_calibration: prepare() was not given a qtable")
+        if self.act_state is None:
+            self.act_state = torch.zeros(self.qtable.shape[1], 2, dtype=torch.float32, device=self.dev)
+            self._qp_scratch = torch.zeros(1, 2, dtype=torch.float32, device=self.dev)
+        self.calib = (mode, int(k))
+        if self.step is not None:
+            self.step.fill_(int(k))
+
+    def _observe(self, aq, x, siblings=()):
+        mode, k = self.calib
+        qid = aq.qid
+        if mode == "init":
+            qp = ops.mse_search(x, 1, 256)
+            self.qtable[k, qid].copy_(qp[0])
+            ops.act_range_update(ops.minmax(x), self.act_state[qid:qid + 1], self._qp_scratch, 0.95, 256, init=True)
+        elif mode == "init_minmax":  # Scaler.MINMAX init (aq_params of the non-calibrating drivers)
+            ops.act_range_update(ops.minmax(x), self.act_state[qid:qid + 1], self.qtable[k, qid], 0.95, 256, init=True)
+        else:
+            ops.act_range_update(ops.minmax(x), self.act_state[qid:qid + 1], self.qtable[k, qid], 0.95, 256, init=False)
+        for s in siblings:  # sibling quantizers see the identical tensor (SURVEY §3.5)
+            self.qtable[k, s].copy_(self.qtable[k, qid])
+            self.act_state[s].copy_(self.act_state[qid])
+
     # ------------------------------------------------------------------ temporal information block
     def _linear(self, name, x, silu_in):
         ent = self.lin[name]
         if ent[0] == "fp":
             return ops.linear_small_f32(x, ent[1], ent[2], silu_in=silu_in)
-        return ops.linear_small_w4(x, ent[1], ent[3] if ent[3] is not None else ops.qsel(None), silu_in=silu_in)
+        aq = ent[3]
+        if aq is not None and self.calib is not None:
+            xs = ops.silu(x) if silu_in else x
+            self._observe(aq, xs)
+            return ops.linear_small_w4(xs, ent[1], aq, silu_in=False)
+        return ops.linear_small_w4(x, ent[1], aq if aq is not None else ops.qsel(None), silu_in=silu_in)
 
     def tib(self, t: torch.Tensor) -> List[torch.Tensor]:
         """QuantTemporalInformationBlockDDIM.forward (quant/quant_block.py:52-64): t [m] fp32 ->
@@ -176,6 +220,11 @@ class DdimUNetEngine:
     # ------------------------------------------------------------------ blocks
     def _gn(self, name, x1, x2, silu, layer: Optional[_Layer], want_cat=False):
         aq = layer.aq if (layer is not None and layer.kind == "w4a8") else None
+        if aq is not None and self.calib is not None:
+            _, yf, xcat = ops.groupnorm(x1, self.sd[name + ".weight"], self.sd[name + ".bias"], 1e-6, silu, None, x2=x2,
+                                        want_f32=True, want_cat=want_cat)
+            self._observe(aq, yf, getattr(layer, "sibling_qids", ()))
+            return ops.quantize_act(yf, aq), xcat
         yq, yf, xcat = ops.groupnorm(x1, self.sd[name + ".weight"], self.sd[name + ".bias"], 1e-6, silu, aq, x2=x2,
                                      want_cat=want_cat)
         return (yq if aq is not None else yf), xcat
@@ -213,6 +262,10 @@ class DdimUNetEngine:
                 l.run(cache[key], out=qkv, y_coff=i * Cc)
         qkv = qkv.reshape(B, H * W, 3 * Cc)
         aq = po.aq if po.kind == "w4a8" else None
+        if aq is not None and self.calib is not None:
+            out, _ = ops.attention(qkv[..., :Cc], qkv[..., Cc:2 * Cc], qkv[..., 2 * Cc:], 1, float(int(Cc) ** (-0.5)))
+            self._observe(aq, out)
+            return po.run(ops.quantize_act(out, aq).reshape(B, H, W, Cc), residual=x)
         out, oq = ops.attention(qkv[..., :Cc], qkv[..., Cc:2 * Cc], qkv[..., 2 * Cc:], 1, float(int(Cc) ** (-0.5)), aq,
                                 want_f32=aq is None)
         a = (oq if aq is not None else out).reshape(B, H, W, Cc)
@@ -283,6 +336,8 @@ class DdimUNetEngine:
                     tap(f"up.{i}.attn.{j}", hin, h)
             if i != 0:
                 up = L[f"up.{i}.upsample.conv"]
+                if up.kind == "w4a8" and self.calib is not None:
+                    self._observe(up.aq, h)
                 hq = ops.quantize_act(h, up.aq) if up.kind == "w4a8" else h
                 h = up.run(hq, pad=(1, 1, 1, 1), up2x=True)
                 res *= 2

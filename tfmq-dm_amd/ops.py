@@ -239,6 +239,35 @@ def pack_w_f16(w: torch.Tensor, bias: Optional[torch.Tensor] = None, delta: Opti
 
 
 # ------------------------------------------------------------------------------ K5 / K6
+_conv_prof = None  # list collecting (start_event, stop_event, algorithmic_ops, kind) per conv launch
+
+
+def set_conv_profile(rec):
+    """bench.py roofline leg: bracket every conv launch with HIP events on its launch stream."""
+    global _conv_prof
+    _conv_prof = rec
+
+
+def event_elapsed_ms(e0: int, e1: int, device: int = 0) -> float:
+    ms = C.c_float()
+    handle(device).call("event_elapsed_ms", e0, e1, C.byref(ms))
+    return float(ms.value)
+
+
+def _profiled_conv(name, kind, d, dsc, nops):
+    h = handle(d)
+    if _conv_prof is None:
+        h.call(name, C.byref(dsc), _stream(d))
+        return
+    e0, e1 = C.c_int(), C.c_int()
+    h.call("event_create", C.byref(e0))
+    h.call("event_create", C.byref(e1))
+    h.call("event_record", e0.value, _stream(d))
+    h.call(name, C.byref(dsc), _stream(d))
+    h.call("event_record", e1.value, _stream(d))
+    _conv_prof.append((e0.value, e1.value, nops, kind))
+
+
 def _conv_desc(x, B, H, W, cin, cout, kh, kw, stride, pad_t, pad_l, Ho, Wo, up2x, y, ldy, y_coff, rowadd, residual,
                rowadd_ld=None, rowadd_step=None, rowadd_step_stride=0):
     dsc = ConvDesc()
@@ -279,7 +308,7 @@ def conv2d_w4a8(xq: torch.Tensor, pw: PackedW4, aq: QSel, stride: int = 1, pad: 
     dsc.w, dsc.wmeta, dsc.wscale = pw.packed.data_ptr(), pw.wmeta.data_ptr(), pw.wscale.data_ptr()
     dsc.bias = None if pw.bias is None else pw.bias.data_ptr()
     dsc.aq = aq
-    handle(d).call("conv2d_w4a8", C.byref(dsc), _stream(d))
+    _profiled_conv("conv2d_w4a8", "w4a8", d, dsc, 2.0 * B * Ho * Wo * pw.cout * pw.kh * pw.kw * cin)
     return y
 
 
@@ -301,7 +330,7 @@ def conv2d_f16(x: torch.Tensor, pf: PackedF16, stride: int = 1, pad: Tuple[int, 
     dsc.wscale = None if pf.wscale is None else pf.wscale.data_ptr()
     dsc.bias = None if pf.bias is None else pf.bias.data_ptr()
     dsc.aq = QSel(None, None, 0, 0)
-    handle(d).call("conv2d_f16", C.byref(dsc), _stream(d))
+    _profiled_conv("conv2d_f16", "f16", d, dsc, 2.0 * B * Ho * Wo * pf.cout * pf.kh * pf.kw * cin)
     return y
 
 
@@ -395,6 +424,14 @@ def ddim_update(x, eps, coef, step=None, noise=None, want_x0=False, out=None):
     x0 = _alloc_like(x) if want_x0 else None
     handle(d).call("ddim_update", _p(x), _p(eps), _p(noise), _p(xn), _p(x0), x.numel(), _p(coef), _p(step), _stream(d))
     return (xn, x0) if want_x0 else xn
+
+
+def silu(x: torch.Tensor) -> torch.Tensor:
+    d = _dev(x)
+    _chk(x, torch.float32, "x")
+    y = _alloc_like(x)
+    handle(d).call("silu", _p(x), _p(y), x.numel(), _stream(d))
+    return y
 
 
 def step_advance(step: torch.Tensor, delta: int = 1):
