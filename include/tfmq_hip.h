@@ -193,9 +193,10 @@ int tfmq_nhwc_to_nchw(tfmq_handle h, const float* x, float* y, int B, int C, int
 /* alpha = -log(1.2/(w/delta - floor(w/delta) + 0.1) - 1)   (init_alpha :31-38); delta per row */
 int tfmq_adaround_init(tfmq_handle h, const float* w, const float* delta, float* alpha, size_t rows, size_t cols,
                        void* stream);
-/* soft forward (:40-41,51,59-60,67-69): w_hat = delta*(clamp(floor(w/delta)+h(alpha)+zp,0,L-1)-zp) */
+/* soft forward (:40-41,51,59-60,67-69): w_hat = delta*(clamp(floor(w/delta)+h(alpha)+zp,0,L-1)-zp);
+ * hard != 0 uses the inference-time rounding h = [alpha >= 0] (:63) instead of the soft target */
 int tfmq_adaround_soft_fwd(tfmq_handle h, const float* w, const float* alpha, const float* delta, const float* zp,
-                           float* w_hat, size_t rows, size_t cols, int level, void* stream);
+                           float* w_hat, size_t rows, size_t cols, int level, int hard, void* stream);
 /* backward of the soft forward + rounding regulariser, fused with one Adam step
  * (torch.optim.Adam defaults lr=1e-3, betas .9/.999, eps 1e-8; reconstruction.py:42):
  *   g = g_what * delta * [0<floor+h+zp<L-1] * h'(alpha) + w_reg * d/dalpha (1-|2h-1|^b)
@@ -208,6 +209,35 @@ int tfmq_adaround_bwd_adam(tfmq_handle h, const float* w, float* alpha, const fl
  * (lp_loss, quant_layer.py:152-153); also writes g = dL/dpred.  loss: one device float. */
 int tfmq_recon_loss(tfmq_handle h, const float* pred, const float* tgt, float* g_or_null, size_t n, size_t denom,
                     float* loss, void* stream);
+
+/* ---- K15: block-reconstruction forward/backward pieces (replace autograd through `block(*cur_inputs)`,
+ * quant/reconstruction.py:69-71,190-192,295-297).  Exact fp32: the soft AdaRound targets are
+ * non-integer, so this path is floating point by construction. ------------------------------ */
+/* batched strided GEMM: C[z] (M x N, row stride scm) = alpha * A[z] B[z] (+bias[n]) (+rowadd) (+residual), or C += ...
+ * A(m,k) = A[m*sam + k*sak], B(k,n) = B[k*sbk + n*sbn]; rowadd[(m / rows_per_img)*rowadd_ld + n] */
+int tfmq_gemm_f32(tfmq_handle h, const float* A, const float* B, float* C, int M, int N, int K, long sam, long sak,
+                  long sbk, long sbn, long scm, int batch, long bsa, long bsb, long bsc, float alpha, const float* bias,
+                  const float* rowadd, int rows_per_img, int rowadd_ld, const float* residual, int accumulate,
+                  void* stream);
+/* col[(b,ho,wo)][(kh,kw,c)] <- x NHWC (zero padded); col2im is its adjoint (gather form, deterministic) */
+int tfmq_im2col(tfmq_handle h, const float* x, float* col, int B, int H, int W, int C, int KH, int KW, int stride,
+                int pad_t, int pad_l, int Ho, int Wo, void* stream);
+int tfmq_col2im(tfmq_handle h, const float* dcol, float* dx, int B, int H, int W, int C, int KH, int KW, int stride,
+                int pad_t, int pad_l, int Ho, int Wo, void* stream);
+/* weights OIHW <-> [cout][(kh,kw,cin)] (dir 0: to the GEMM layout, 1: back) */
+int tfmq_w_relayout(tfmq_handle h, const float* src, float* dst, int cout, int cin, int kh, int kw, int dir, void* stream);
+int tfmq_silu_bwd(tfmq_handle h, const float* x, const float* gy, float* gx, size_t n, void* stream);
+/* backward of GroupNorm(+SiLU) w.r.t. its input (x: the un-normalised NHWC input, gy: dL/d output) */
+int tfmq_groupnorm_bwd(tfmq_handle h, const float* x, const float* gy, const float* gamma, const float* beta, float* gx,
+                       int B, int HW, int C, int groups, float eps, int silu, void* stream);
+/* P = softmax(scale*S) per row; dS = scale * P * (dP - sum(dP*P)) */
+int tfmq_softmax_rows(tfmq_handle h, const float* S, float* P, long rows, int cols, float scale, void* stream);
+int tfmq_softmax_bwd_rows(tfmq_handle h, const float* P, const float* dP, float* dS, long rows, int cols, float scale,
+                          void* stream);
+/* nearest-neighbour x2 (F.interpolate(scale_factor=2, mode="nearest"), ddim/models/diffusion.py:47-48) */
+int tfmq_upsample2x(tfmq_handle h, const float* x, float* y, int B, int H, int W, int C, void* stream);
+/* y += a*x */
+int tfmq_axpy(tfmq_handle h, float* y, const float* x, float a, size_t n, void* stream);
 
 /* ---- stream-capture helpers: a sampler step is captured once into a hipGraph and replayed */
 int tfmq_graph_begin(tfmq_handle h, void* stream);

@@ -83,10 +83,23 @@ _SIGS = {
     "tfmq_nchw_to_nhwc": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "tfmq_nhwc_to_nchw": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "tfmq_adaround_init": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_size_t, c_void_p]),
-    "tfmq_adaround_soft_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_size_t, c_int, c_void_p]),
+    "tfmq_adaround_soft_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_size_t, c_int, c_int, c_void_p]),
     "tfmq_adaround_bwd_adam": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_size_t,
                                        c_int, c_float, c_float, c_float, c_int, c_void_p, c_void_p]),
     "tfmq_recon_loss": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_size_t, c_void_p, c_void_p]),
+    "tfmq_gemm_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, C.c_long, C.c_long, C.c_long, C.c_long,
+                              C.c_long, c_int, C.c_long, C.c_long, C.c_long, c_float, c_void_p, c_void_p, c_int, c_int, c_void_p,
+                              c_int, c_void_p]),
+    "tfmq_im2col": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 11 + [c_void_p]),
+    "tfmq_col2im": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 11 + [c_void_p]),
+    "tfmq_w_relayout": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "tfmq_silu_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "tfmq_groupnorm_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float,
+                                   c_int, c_void_p]),
+    "tfmq_softmax_rows": (c_int, [c_void_p, c_void_p, c_void_p, C.c_long, c_int, c_float, c_void_p]),
+    "tfmq_softmax_bwd_rows": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, C.c_long, c_int, c_float, c_void_p]),
+    "tfmq_axpy": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_size_t, c_void_p]),
+    "tfmq_upsample2x": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "tfmq_graph_begin": (c_int, [c_void_p, c_void_p]),
     "tfmq_graph_end": (c_int, [c_void_p, c_void_p, C.POINTER(c_int)]),
     "tfmq_graph_launch": (c_int, [c_void_p, c_int, c_void_p]),

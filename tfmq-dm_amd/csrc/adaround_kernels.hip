@@ -34,13 +34,14 @@ extern "C" int tfmq_adaround_init(tfmq_handle h, const float* w, const float* de
 __global__ __launch_bounds__(256) void k_adaround_soft_fwd(const float* __restrict__ w, const float* __restrict__ alpha,
                                                            const float* __restrict__ delta, const float* __restrict__ zp,
                                                            float* __restrict__ w_hat, size_t rows, size_t cols,
-                                                           float lmax) {
+                                                           float lmax, int hard) {
   const size_t n = rows * cols, stride = static_cast<size_t>(gridDim.x) * blockDim.x;
   for (size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) {
     const size_t r = i / cols;
     const float d = delta[r], z = zp[r];
     float hsoft = sigmoid_f(alpha[i]) * ADA_ZETA_M_GAMMA + ADA_GAMMA;
     hsoft = fminf(fmaxf(hsoft, 0.0f), 1.0f);
+    if (hard) hsoft = alpha[i] >= 0.0f ? 1.0f : 0.0f;  // inference-time rounding (adaptive_rounding.py:63)
     float q = floorf(w[i] / d) + hsoft;
     q = fminf(fmaxf(q + z, 0.0f), lmax);
     w_hat[i] = d * (q - z);
@@ -48,12 +49,13 @@ __global__ __launch_bounds__(256) void k_adaround_soft_fwd(const float* __restri
 }
 
 extern "C" int tfmq_adaround_soft_fwd(tfmq_handle h, const float* w, const float* alpha, const float* delta,
-                                      const float* zp, float* w_hat, size_t rows, size_t cols, int level, void* stream) {
+                                      const float* zp, float* w_hat, size_t rows, size_t cols, int level, int hard,
+                                      void* stream) {
   TFMQ_CHECK_ARG(h, h && w && alpha && delta && zp && w_hat && rows > 0 && cols > 0, "adaround_soft_fwd: bad argument");
   int blocks = ceil_div(static_cast<long>(rows * cols), 256);
   if (blocks > h->cu_count * 8) blocks = h->cu_count * 8;
   hipLaunchKernelGGL(k_adaround_soft_fwd, dim3(blocks), dim3(256), 0, as_stream(stream), w, alpha, delta, zp, w_hat,
-                     rows, cols, static_cast<float>(level - 1));
+                     rows, cols, static_cast<float>(level - 1), hard);
   TFMQ_LAUNCH_CHECK(h);
   return TFMQ_OK;
 }

@@ -58,7 +58,15 @@ __global__ __launch_bounds__(256) void k_conv_igemm(ConvP p) {
   const tfmq_conv_desc& d = p.d;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid / WAVES_N, wn = wid % WAVES_N;
-  const int tile_n = blockIdx.x % p.tiles_n, tile_m = blockIdx.x / p.tiles_n;
+  // XCD-aware tile order (T1): the dispatcher places block b on XCD b % 8; give each XCD a contiguous
+  // range of tiles so the 3x3 taps / neighbouring rows of one image hit that XCD's private L2.
+  // Bijective for any grid size; placement is a speed matter only.
+  int bid = blockIdx.x;
+  {
+    const int nb = gridDim.x, xcd = bid & 7, q = nb >> 3, r = nb & 7;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  const int tile_n = bid % p.tiles_n, tile_m = bid / p.tiles_n;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
 
   float2 aqp = make_float2(1.0f, 0.0f);

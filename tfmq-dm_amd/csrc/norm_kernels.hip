@@ -1,17 +1,22 @@
 // K8: GroupNorm (+SiLU) (+8-bit quantise), reading a *virtual* channel concat of two NHWC
 // tensors.  Replaces Normalize -> nonlinearity -> aqtizer (ddim/models/diffusion.py:27-33,
-// 117-118,123-124; quant/quant_layer.py:223-226): 1 statistics read + 1 apply read of fp32,
-// 1 write of int8, instead of the reference's ~10 elementwise passes.
+// 117-118,123-124; quant/quant_layer.py:223-226): ONE read of fp32 and one write of int8,
+// instead of the reference's ~10 elementwise passes.
 //
-// One block = one image x one chunk of whole groups spanning ~32 channels (128-byte rows of
-// the NHWC tensor).  Statistics are accumulated in double per thread and combined in a fixed
-// order (deterministic).  HBM-bound: algorithmic bytes = 4 B read (+4 B re-read, normally an
-// L2/MALL hit) + 1 B written per element.
+// One block = one image x one chunk of whole groups spanning ~32 channels (128-byte rows of the
+// NHWC tensor).  When the chunk fits (pixels/iteration x R iterations), every thread keeps its
+// elements in registers between the statistics pass and the apply pass, so HBM sees each input
+// element exactly once: algorithmic bytes = 4 B read + 1 B written per element.  Larger groups
+// (SD 64x64) fall back to a second read (normally an L2 / Infinity-Cache hit).
+// Statistics: fp32 partial sums per thread (<= 128 values), combined in double in a fixed order
+// (deterministic run to run).
 #include "common.hpp"
 
 struct GnP {
   tfmq_gn_desc d;
   int C, cpg, gpb, cw;  // channels, channels/group, groups/block, chunk width = gpb*cpg
+  int tpp, ppi;         // threads per pixel, pixels per iteration
+  int lpg;              // lanes cooperating on one group's reduction (power of two <= 64)
 };
 
 template <int V>
@@ -31,53 +36,130 @@ __device__ __forceinline__ void gn_load(const GnP& p, size_t pix, int c, float (
 }
 
 template <int V>
+__device__ __forceinline__ void gn_apply_store(const GnP& p, size_t o, const float (&v)[V], const float (&ga)[V],
+                                               const float (&gb)[V], bool quant, float2 qp) {
+  const tfmq_gn_desc& d = p.d;
+  if (d.xcat_or_null) {
+#pragma unroll
+    for (int i = 0; i < V; ++i) d.xcat_or_null[o + i] = v[i];
+  }
+  float y[V];
+#pragma unroll
+  for (int i = 0; i < V; ++i) {
+    y[i] = ga[i] * v[i] + gb[i];
+    if (d.silu) y[i] = silu_f(y[i]);
+  }
+  if (quant) {
+    signed char q[V];
+#pragma unroll
+    for (int i = 0; i < V; ++i)
+      q[i] = static_cast<signed char>(static_cast<int>(quant_index_f(y[i], qp.x, qp.y, 255.0f)) - 128);
+    if constexpr (V == 4) {
+      *reinterpret_cast<char4*>(d.yq + o) = make_char4(q[0], q[1], q[2], q[3]);
+    } else if constexpr (V == 2) {
+      *reinterpret_cast<char2*>(d.yq + o) = make_char2(q[0], q[1]);
+    } else {
+      d.yq[o] = q[0];
+    }
+  }
+  if (d.yf) {
+#pragma unroll
+    for (int i = 0; i < V; ++i) d.yf[o + i] = y[i];
+  }
+}
+
+// R > 0: register-cached single-read path (HW <= R * ppi);  R == 0: re-read path.
+template <int V, int R>
 __global__ __launch_bounds__(256) void k_groupnorm(GnP p) {
   const tfmq_gn_desc& d = p.d;
   __shared__ double s_part[256][2];
   __shared__ float s_stat[64][2];  // mean, rstd per group of this block
   const int b = blockIdx.y;
   const int c_base = blockIdx.x * p.cw;
-  const int tpp = p.cw / V;           // threads per pixel
-  const int ppi = 256 / tpp;          // pixels per iteration
+  const int tpp = p.tpp, ppi = p.ppi;
   const int t = threadIdx.x;
   const bool active = t < tpp * ppi;
   const int c_off = (t % tpp) * V;    // channel offset inside the chunk
   const int p_off = t / tpp;
   const int g_rel = c_off / p.cpg;    // V divides cpg => all V channels share the group
   const size_t pix0 = static_cast<size_t>(b) * d.HW;
+  constexpr int RR = R > 0 ? R : 1;
+  float cache[RR][V];
 
-  // ---- pass 1: sum and sum of squares (double)
-  double s = 0.0, ss = 0.0;
+  // ---- pass 1: sum and sum of squares
+  float s = 0.0f, ss = 0.0f;
   if (active) {
-    for (int px = p_off; px < d.HW; px += ppi) {
-      float v[V];
-      gn_load<V>(p, pix0 + px, c_base + c_off, v);
+    if constexpr (R > 0) {
+      // issue every load first (clamped address, no predicate) so they are all in flight together
 #pragma unroll
-      for (int i = 0; i < V; ++i) {
-        const double x = static_cast<double>(v[i]);
-        s += x;
-        ss += x * x;
+      for (int r = 0; r < R; ++r) {
+        const int px = p_off + r * ppi;
+        gn_load<V>(p, pix0 + (px < d.HW ? px : d.HW - 1), c_base + c_off, cache[r]);
       }
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const float m = (p_off + r * ppi) < d.HW ? 1.0f : 0.0f;
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+          s += m * cache[r][i];
+          ss += m * (cache[r][i] * cache[r][i]);
+        }
+      }
+    } else {
+      double ds = 0.0, dss = 0.0;
+      for (int px0 = p_off; px0 < d.HW; px0 += ppi * 32) {  // fp32 runs of <= 32 pixels, double across runs
+        float fs = 0.0f, fss = 0.0f;
+        for (int px = px0; px < d.HW && px < px0 + ppi * 32; px += ppi) {
+          float v[V];
+          gn_load<V>(p, pix0 + px, c_base + c_off, v);
+#pragma unroll
+          for (int i = 0; i < V; ++i) {
+            fs += v[i];
+            fss += v[i] * v[i];
+          }
+        }
+        ds += fs;
+        dss += fss;
+      }
+      s_part[t][0] = ds;
+      s_part[t][1] = dss;
     }
   }
-  s_part[t][0] = s;
-  s_part[t][1] = ss;
+  if constexpr (R > 0) {
+    s_part[t][0] = active ? static_cast<double>(s) : 0.0;
+    s_part[t][1] = active ? static_cast<double>(ss) : 0.0;
+  } else {
+    if (!active) {
+      s_part[t][0] = 0.0;
+      s_part[t][1] = 0.0;
+    }
+  }
   __syncthreads();
-  if (t < p.gpb) {
+  // ---- fixed-order reduction: lpg lanes per group, each sums a strided subset, then xor-shuffle
+  {
+    const int g = t / p.lpg, l = t % p.lpg;
     double a = 0.0, aa = 0.0;
-    const int nact = tpp * ppi;
-    for (int j = 0; j < nact; ++j) {
-      if (((j % tpp) * V) / p.cpg == t) {
-        a += s_part[j][0];
-        aa += s_part[j][1];
+    if (g < p.gpb) {
+      const int nact = tpp * ppi;
+      for (int j = l; j < nact; j += p.lpg) {
+        if (((j % tpp) * V) / p.cpg == g) {
+          a += s_part[j][0];
+          aa += s_part[j][1];
+        }
       }
     }
-    const double n = static_cast<double>(d.HW) * p.cpg;
-    const double mean = a / n;
-    double var = aa / n - mean * mean;
-    if (var < 0.0) var = 0.0;
-    s_stat[t][0] = static_cast<float>(mean);
-    s_stat[t][1] = static_cast<float>(1.0 / sqrt(var + static_cast<double>(d.eps)));
+    for (int o = p.lpg >> 1; o > 0; o >>= 1) {
+      a += __shfl_xor(a, o, 64);
+      aa += __shfl_xor(aa, o, 64);
+    }
+    if (g < p.gpb && l == 0) {
+      const double n = static_cast<double>(d.HW) * p.cpg;
+      const double mean = a / n;
+      double var = aa / n - mean * mean;
+      if (var < 0.0) var = 0.0;
+      s_stat[g][0] = static_cast<float>(mean);
+      s_stat[g][1] = static_cast<float>(1.0 / sqrt(var + static_cast<double>(d.eps)));
+    }
   }
   __syncthreads();
   if (!active) return;
@@ -94,37 +176,27 @@ __global__ __launch_bounds__(256) void k_groupnorm(GnP p) {
   float2 qp = make_float2(1.0f, 0.0f);
   const bool quant = d.aq.qtable != nullptr;
   if (quant) qp = load_qparam(d.aq);
-  for (int px = p_off; px < d.HW; px += ppi) {
-    float v[V];
-    gn_load<V>(p, pix0 + px, c_base + c_off, v);
-    const size_t o = (pix0 + px) * p.C + c_base + c_off;
-    if (d.xcat_or_null) {
+  if constexpr (R > 0) {
 #pragma unroll
-      for (int i = 0; i < V; ++i) d.xcat_or_null[o + i] = v[i];
+    for (int r = 0; r < R; ++r) {
+      const int px = p_off + r * ppi;
+      if (px < d.HW) gn_apply_store<V>(p, (pix0 + px) * p.C + c_base + c_off, cache[r], ga, gb, quant, qp);
     }
-    float y[V];
-#pragma unroll
-    for (int i = 0; i < V; ++i) {
-      y[i] = ga[i] * v[i] + gb[i];
-      if (d.silu) y[i] = silu_f(y[i]);
-    }
-    if (quant) {
-      signed char q[V];
-#pragma unroll
-      for (int i = 0; i < V; ++i) q[i] = static_cast<signed char>(static_cast<int>(quant_index_f(y[i], qp.x, qp.y, 255.0f)) - 128);
-      if constexpr (V == 4) {
-        *reinterpret_cast<char4*>(d.yq + o) = make_char4(q[0], q[1], q[2], q[3]);
-      } else if constexpr (V == 2) {
-        *reinterpret_cast<char2*>(d.yq + o) = make_char2(q[0], q[1]);
-      } else {
-        d.yq[o] = q[0];
-      }
-    }
-    if (d.yf) {
-#pragma unroll
-      for (int i = 0; i < V; ++i) d.yf[o + i] = y[i];
+  } else {
+    for (int px = p_off; px < d.HW; px += ppi) {
+      float v[V];
+      gn_load<V>(p, pix0 + px, c_base + c_off, v);
+      gn_apply_store<V>(p, (pix0 + px) * p.C + c_base + c_off, v, ga, gb, quant, qp);
     }
   }
+}
+
+template <int V>
+static void launch_gn(const GnP& p, dim3 grid, hipStream_t st) {
+  const int iters = (p.d.HW + p.ppi - 1) / p.ppi;
+  if (iters <= 8) hipLaunchKernelGGL((k_groupnorm<V, 8>), grid, dim3(256), 0, st, p);
+  else if (iters <= 32) hipLaunchKernelGGL((k_groupnorm<V, 32>), grid, dim3(256), 0, st, p);
+  else hipLaunchKernelGGL((k_groupnorm<V, 0>), grid, dim3(256), 0, st, p);
 }
 
 extern "C" int tfmq_groupnorm(tfmq_handle h, const tfmq_gn_desc* dd, void* stream) {
@@ -132,7 +204,7 @@ extern "C" int tfmq_groupnorm(tfmq_handle h, const tfmq_gn_desc* dd, void* strea
   const tfmq_gn_desc& d = *dd;
   TFMQ_CHECK_ARG(h, d.x1 && d.gamma && d.beta && (d.C2 == 0 || d.x2), "groupnorm: null operand");
   TFMQ_CHECK_ARG(h, (d.aq.qtable && d.yq) || d.yf, "groupnorm: no output requested");
-  TFMQ_CHECK_ARG(h, d.B > 0 && d.HW > 0 && d.C1 > 0 && d.C2 >= 0 && d.groups > 0, "groupnorm: bad shape");
+  TFMQ_CHECK_ARG(h, d.B > 0 && d.HW > 0 && d.C1 > 0 && d.C2 >= 0 && d.groups > 0 && d.groups <= 64, "groupnorm: bad shape");
   GnP p;
   p.d = d;
   p.C = d.C1 + d.C2;
@@ -140,18 +212,22 @@ extern "C" int tfmq_groupnorm(tfmq_handle h, const tfmq_gn_desc* dd, void* strea
   p.cpg = p.C / d.groups;
   int gpb = 32 / p.cpg;
   if (gpb < 1) gpb = 1;
-  while (gpb > 1 && (d.groups % gpb != 0 || gpb > 64)) --gpb;
-  // keep the chunk width <= 256 threads' worth even for very wide groups
+  while (gpb > 1 && d.groups % gpb != 0) --gpb;
   p.gpb = gpb;
   p.cw = gpb * p.cpg;
   int V = 1;
   if (p.cpg % 4 == 0 && d.C1 % 4 == 0 && p.cw / 4 <= 256) V = 4;
   else if (p.cpg % 2 == 0 && d.C1 % 2 == 0 && p.cw / 2 <= 256) V = 2;
   TFMQ_CHECK_ARG(h, p.cw / V <= 256, "groupnorm: group too wide (channels per group > 1024)");
+  p.tpp = p.cw / V;
+  p.ppi = 256 / p.tpp;
+  int lpg = 64;
+  while (lpg * gpb > 256) lpg >>= 1;
+  p.lpg = lpg;
   dim3 grid(d.groups / gpb, d.B);
-  if (V == 4) hipLaunchKernelGGL(k_groupnorm<4>, grid, dim3(256), 0, as_stream(stream), p);
-  else if (V == 2) hipLaunchKernelGGL(k_groupnorm<2>, grid, dim3(256), 0, as_stream(stream), p);
-  else hipLaunchKernelGGL(k_groupnorm<1>, grid, dim3(256), 0, as_stream(stream), p);
+  if (V == 4) launch_gn<4>(p, grid, as_stream(stream));
+  else if (V == 2) launch_gn<2>(p, grid, as_stream(stream));
+  else launch_gn<1>(p, grid, as_stream(stream));
   TFMQ_LAUNCH_CHECK(h);
   return TFMQ_OK;
 }

@@ -1,0 +1,384 @@
+// K15: building blocks of the block-reconstruction forward/backward (quant/reconstruction.py:
+// `out_quant = block(*cur_inputs); err.backward()`), hand-written instead of autograd.
+// The AdaRound soft targets make the weights non-integer, so this path is floating point by
+// construction (SURVEY §7 hard part 1); it runs in exact fp32 (FMA GEMM) so the loss curve can be
+// compared with the reference's fp32 training.  Batch 32 units: the convolution is lowered to
+// im2col + GEMM (the 9x activation blow-up is irrelevant next to 288 GB of HBM), which gives
+// forward, weight gradient and input gradient from ONE strided-GEMM kernel:
+//   y    = col(x) W^T (+bias +temb row +residual)       gemm(A=col,  B=W^T)
+//   dW   = dY^T col(x)                                   gemm(A=dY^T, B=col)
+//   dcol = dY W ; dx = col2im(dcol)                      gemm(A=dY,   B=W) + gather
+#include "common.hpp"
+
+// ------------------------------------------------------------------ strided batched GEMM (fp32)
+struct GemmP {
+  const float* A; const float* B; float* C;
+  int M, N, K;
+  long sam, sak, sbk, sbn, scm;      // element strides: A(m,k)=A[m*sam+k*sak], B(k,n)=B[k*sbk+n*sbn], C(m,n)=C[m*scm+n]
+  long bsa, bsb, bsc;                // batch strides
+  float alpha;
+  const float* bias;                 // [N] or null
+  const float* rowadd;               // rowadd[(m / rows_per_img) * rowadd_ld + n] or null
+  int rows_per_img, rowadd_ld;
+  const float* residual;             // same layout as C, or null
+  int accumulate;                    // C += result
+};
+
+#define GT 64
+#define GK 16
+__global__ __launch_bounds__(256) void k_gemm_f32(GemmP p) {
+  __shared__ float As[GK][GT + 4];
+  __shared__ float Bs[GK][GT + 4];
+  const int bz = blockIdx.z;
+  const float* A = p.A + bz * p.bsa;
+  const float* B = p.B + bz * p.bsb;
+  float* C = p.C + bz * p.bsc;
+  const int m0 = blockIdx.y * GT, n0 = blockIdx.x * GT;
+  const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;  // 16 x 16 threads, 4x4 outputs each
+  float acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = 0.0f;
+  const bool a_kfast = p.sak == 1, b_nfast = p.sbn == 1;
+  for (int k0 = 0; k0 < p.K; k0 += GK) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int e = tid + i * 256;
+      int m, k;
+      if (a_kfast) { k = e & 15; m = e >> 4; } else { m = e & 63; k = e >> 6; }
+      const int gm = m0 + m, gk = k0 + k;
+      As[k][m] = (gm < p.M && gk < p.K) ? A[gm * p.sam + gk * p.sak] : 0.0f;
+      int n, kb;
+      if (b_nfast) { n = e & 63; kb = e >> 6; } else { kb = e & 15; n = e >> 4; }
+      const int gn = n0 + n, gkb = k0 + kb;
+      Bs[kb][n] = (gn < p.N && gkb < p.K) ? B[gkb * p.sbk + gn * p.sbn] : 0.0f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < GK; ++k) {
+      float a[4], b[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a[i] = As[k][ty * 4 + i];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) b[j] = Bs[k][tx * 4 + j];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(a[i], b[j], acc[i][j]);
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = m0 + ty * 4 + i;
+    if (m >= p.M) continue;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = n0 + tx * 4 + j;
+      if (n >= p.N) continue;
+      float v = p.alpha * acc[i][j];
+      if (p.bias) v += p.bias[n];
+      if (p.rowadd) v += p.rowadd[static_cast<long>(m / p.rows_per_img) * p.rowadd_ld + n];
+      if (p.residual) v += p.residual[bz * p.bsc + m * p.scm + n];
+      float* c = C + m * p.scm + n;
+      *c = p.accumulate ? *c + v : v;
+    }
+  }
+}
+
+extern "C" int tfmq_gemm_f32(tfmq_handle h, const float* A, const float* B, float* C, int M, int N, int K, long sam,
+                             long sak, long sbk, long sbn, long scm, int batch, long bsa, long bsb, long bsc, float alpha,
+                             const float* bias, const float* rowadd, int rows_per_img, int rowadd_ld,
+                             const float* residual, int accumulate, void* stream) {
+  TFMQ_CHECK_ARG(h, h && A && B && C && M > 0 && N > 0 && K > 0 && batch > 0 && batch < 65536, "gemm_f32: bad argument");
+  TFMQ_CHECK_ARG(h, !rowadd || rows_per_img > 0, "gemm_f32: rowadd needs rows_per_img");
+  GemmP p{A, B, C, M, N, K, sam, sak, sbk, sbn, scm, bsa, bsb, bsc, alpha, bias, rowadd, rows_per_img, rowadd_ld, residual,
+          accumulate};
+  dim3 grid((N + GT - 1) / GT, (M + GT - 1) / GT, batch);
+  hipLaunchKernelGGL(k_gemm_f32, grid, dim3(256), 0, as_stream(stream), p);
+  TFMQ_LAUNCH_CHECK(h);
+  return TFMQ_OK;
+}
+
+// ------------------------------------------------------------------ im2col / col2im (NHWC, zero pad)
+// col[(b,ho,wo)][(kh,kw,c)] = x[b][ho*s+kh-pt][wo*s+kw-pl][c]   (0 outside)
+__global__ __launch_bounds__(256) void k_im2col(const float* __restrict__ x, float* __restrict__ col, int B, int H, int W,
+                                                int Cc, int KH, int KW, int stride, int pt, int pl, int Ho, int Wo) {
+  const long total = static_cast<long>(B) * Ho * Wo * KH * KW * Cc;
+  for (long i = static_cast<long>(blockIdx.x) * blockDim.x + threadIdx.x; i < total;
+       i += static_cast<long>(gridDim.x) * blockDim.x) {
+    const int c = i % Cc;
+    long r = i / Cc;
+    const int kw = r % KW; r /= KW;
+    const int kh = r % KH; r /= KH;
+    const int wo = r % Wo; r /= Wo;
+    const int ho = r % Ho;
+    const int b = r / Ho;
+    const int hi = ho * stride + kh - pt, wi = wo * stride + kw - pl;
+    col[i] = (hi >= 0 && hi < H && wi >= 0 && wi < W) ? x[((static_cast<long>(b) * H + hi) * W + wi) * Cc + c] : 0.0f;
+  }
+}
+
+extern "C" int tfmq_im2col(tfmq_handle h, const float* x, float* col, int B, int H, int W, int C, int KH, int KW,
+                           int stride, int pad_t, int pad_l, int Ho, int Wo, void* stream) {
+  TFMQ_CHECK_ARG(h, h && x && col && B > 0 && H > 0 && W > 0 && C > 0 && KH > 0 && KW > 0 && stride > 0 && Ho > 0 && Wo > 0,
+                 "im2col: bad argument");
+  const long total = static_cast<long>(B) * Ho * Wo * KH * KW * C;
+  int blocks = ceil_div(total, 256);
+  if (blocks > h->cu_count * 16) blocks = h->cu_count * 16;
+  hipLaunchKernelGGL(k_im2col, dim3(blocks), dim3(256), 0, as_stream(stream), x, col, B, H, W, C, KH, KW, stride, pad_t,
+                     pad_l, Ho, Wo);
+  TFMQ_LAUNCH_CHECK(h);
+  return TFMQ_OK;
+}
+
+// dx[b][hi][wi][c] = sum over taps of dcol at the output pixel that read (hi,wi) through that tap (gather: deterministic)
+__global__ __launch_bounds__(256) void k_col2im(const float* __restrict__ dcol, float* __restrict__ dx, int B, int H, int W,
+                                                int Cc, int KH, int KW, int stride, int pt, int pl, int Ho, int Wo) {
+  const long total = static_cast<long>(B) * H * W * Cc;
+  for (long i = static_cast<long>(blockIdx.x) * blockDim.x + threadIdx.x; i < total;
+       i += static_cast<long>(gridDim.x) * blockDim.x) {
+    const int c = i % Cc;
+    long r = i / Cc;
+    const int wi = r % W; r /= W;
+    const int hi = r % H;
+    const int b = r / H;
+    float s = 0.0f;
+    for (int kh = 0; kh < KH; ++kh) {
+      const int hn = hi + pt - kh;
+      if (hn < 0 || hn % stride) continue;
+      const int ho = hn / stride;
+      if (ho >= Ho) continue;
+      for (int kw = 0; kw < KW; ++kw) {
+        const int wn = wi + pl - kw;
+        if (wn < 0 || wn % stride) continue;
+        const int wo = wn / stride;
+        if (wo >= Wo) continue;
+        s += dcol[(((static_cast<long>(b) * Ho + ho) * Wo + wo) * KH * KW + kh * KW + kw) * Cc + c];
+      }
+    }
+    dx[i] = s;
+  }
+}
+
+extern "C" int tfmq_col2im(tfmq_handle h, const float* dcol, float* dx, int B, int H, int W, int C, int KH, int KW,
+                           int stride, int pad_t, int pad_l, int Ho, int Wo, void* stream) {
+  TFMQ_CHECK_ARG(h, h && dcol && dx && B > 0 && H > 0 && W > 0 && C > 0, "col2im: bad argument");
+  const long total = static_cast<long>(B) * H * W * C;
+  int blocks = ceil_div(total, 256);
+  if (blocks > h->cu_count * 16) blocks = h->cu_count * 16;
+  hipLaunchKernelGGL(k_col2im, dim3(blocks), dim3(256), 0, as_stream(stream), dcol, dx, B, H, W, C, KH, KW, stride, pad_t,
+                     pad_l, Ho, Wo);
+  TFMQ_LAUNCH_CHECK(h);
+  return TFMQ_OK;
+}
+
+// OIHW [co][ci][kh][kw] <-> GEMM layout [co][(kh,kw,ci)]  (dir=0: to GEMM layout, dir=1: back)
+__global__ void k_w_relayout(const float* __restrict__ src, float* __restrict__ dst, int cout, int cin, int khw, int dir) {
+  const long total = static_cast<long>(cout) * cin * khw;
+  for (long i = static_cast<long>(blockIdx.x) * blockDim.x + threadIdx.x; i < total;
+       i += static_cast<long>(gridDim.x) * blockDim.x) {
+    const int ci = i % cin;
+    const int tap = (i / cin) % khw;
+    const int co = i / (static_cast<long>(cin) * khw);
+    const long oihw = (static_cast<long>(co) * cin + ci) * khw + tap;
+    if (dir == 0) dst[i] = src[oihw]; else dst[oihw] = src[i];
+  }
+}
+
+extern "C" int tfmq_w_relayout(tfmq_handle h, const float* src, float* dst, int cout, int cin, int kh, int kw, int dir,
+                               void* stream) {
+  TFMQ_CHECK_ARG(h, h && src && dst && cout > 0 && cin > 0 && kh > 0 && kw > 0, "w_relayout: bad argument");
+  const long total = static_cast<long>(cout) * cin * kh * kw;
+  hipLaunchKernelGGL(k_w_relayout, dim3(ceil_div(total, 256)), dim3(256), 0, as_stream(stream), src, dst, cout, cin, kh * kw,
+                     dir);
+  TFMQ_LAUNCH_CHECK(h);
+  return TFMQ_OK;
+}
+
+// ------------------------------------------------------------------ SiLU backward: gx = gy * d/dx (x sigmoid(x))
+__global__ __launch_bounds__(256) void k_silu_bwd(const float* __restrict__ x, const float* __restrict__ gy,
+                                                  float* __restrict__ gx, size_t n) {
+  const size_t stride = static_cast<size_t>(gridDim.x) * blockDim.x;
+  for (size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const float v = x[i];
+    const float s = 1.0f / (1.0f + expf(-v));
+    gx[i] = gy[i] * (s * (1.0f + v * (1.0f - s)));
+  }
+}
+
+extern "C" int tfmq_silu_bwd(tfmq_handle h, const float* x, const float* gy, float* gx, size_t n, void* stream) {
+  TFMQ_CHECK_ARG(h, h && x && gy && gx, "silu_bwd: null pointer");
+  if (n == 0) return TFMQ_OK;
+  int blocks = ceil_div(static_cast<long>(n), 256);
+  if (blocks > h->cu_count * 8) blocks = h->cu_count * 8;
+  hipLaunchKernelGGL(k_silu_bwd, dim3(blocks), dim3(256), 0, as_stream(stream), x, gy, gx, n);
+  TFMQ_LAUNCH_CHECK(h);
+  return TFMQ_OK;
+}
+
+// ------------------------------------------------------------------ GroupNorm(+SiLU) backward w.r.t. the input
+// y = silu?(gamma*xhat + beta), xhat = (x-mean)*rstd per (image, group).  Given gy = dL/dy:
+//   gh = gy * silu'(h)   (or gy);   gxh = gh*gamma;   gx = rstd*(gxh - mean_g(gxh) - xhat*mean_g(gxh*xhat))
+// one block per (image, group); three reads of the (small, batch-32) group.
+__global__ __launch_bounds__(256) void k_groupnorm_bwd(const float* __restrict__ x, const float* __restrict__ gy,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       float* __restrict__ gx, int HW, int Cc, int cpg, float eps,
+                                                       int silu) {
+  __shared__ double red[4][2];
+  const int b = blockIdx.y, g = blockIdx.x;
+  const long base = static_cast<long>(b) * HW * Cc + g * cpg;
+  const int n = HW * cpg;
+  auto block_sum2 = [&](double a, double c, double& oa, double& oc) {
+    a = wave_reduce_sum_d(a);
+    c = wave_reduce_sum_d(c);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6][0] = a; red[threadIdx.x >> 6][1] = c; }
+    __syncthreads();
+    oa = red[0][0] + red[1][0] + red[2][0] + red[3][0];
+    oc = red[0][1] + red[1][1] + red[2][1] + red[3][1];
+  };
+  double s = 0.0, ss = 0.0;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const float v = x[base + static_cast<long>(i / cpg) * Cc + (i % cpg)];
+    s += v; ss += static_cast<double>(v) * v;
+  }
+  double S, SS;
+  block_sum2(s, ss, S, SS);
+  const double mean_d = S / n;
+  double var = SS / n - mean_d * mean_d;
+  if (var < 0.0) var = 0.0;
+  const float mean = static_cast<float>(mean_d), rstd = static_cast<float>(1.0 / sqrt(var + static_cast<double>(eps)));
+  double a1 = 0.0, a2 = 0.0;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const int c = i % cpg;
+    const long o = base + static_cast<long>(i / cpg) * Cc + c;
+    const float xh = (x[o] - mean) * rstd;
+    float gh = gy[o];
+    if (silu) {
+      const float hval = gamma[g * cpg + c] * xh + beta[g * cpg + c];
+      const float sg = 1.0f / (1.0f + expf(-hval));
+      gh *= sg * (1.0f + hval * (1.0f - sg));
+    }
+    const float gxh = gh * gamma[g * cpg + c];
+    a1 += gxh; a2 += static_cast<double>(gxh) * xh;
+  }
+  double A1, A2;
+  block_sum2(a1, a2, A1, A2);
+  const float m1 = static_cast<float>(A1 / n), m2 = static_cast<float>(A2 / n);
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const int c = i % cpg;
+    const long o = base + static_cast<long>(i / cpg) * Cc + c;
+    const float xh = (x[o] - mean) * rstd;
+    float gh = gy[o];
+    if (silu) {
+      const float hval = gamma[g * cpg + c] * xh + beta[g * cpg + c];
+      const float sg = 1.0f / (1.0f + expf(-hval));
+      gh *= sg * (1.0f + hval * (1.0f - sg));
+    }
+    const float gxh = gh * gamma[g * cpg + c];
+    gx[o] = rstd * (gxh - m1 - xh * m2);
+  }
+}
+
+extern "C" int tfmq_groupnorm_bwd(tfmq_handle h, const float* x, const float* gy, const float* gamma, const float* beta,
+                                  float* gx, int B, int HW, int C, int groups, float eps, int silu, void* stream) {
+  TFMQ_CHECK_ARG(h, h && x && gy && gamma && beta && gx && B > 0 && HW > 0 && C > 0 && groups > 0 && C % groups == 0 && B < 65536,
+                 "groupnorm_bwd: bad argument");
+  hipLaunchKernelGGL(k_groupnorm_bwd, dim3(groups, B), dim3(256), 0, as_stream(stream), x, gy, gamma, beta, gx, HW, C,
+                     C / groups, eps, silu);
+  TFMQ_LAUNCH_CHECK(h);
+  return TFMQ_OK;
+}
+
+// ------------------------------------------------------------------ row softmax forward / backward (materialised attention)
+// P[r][:] = softmax(scale * S[r][:]);  dS = scale * P * (dP - sum(dP*P))
+__global__ __launch_bounds__(256) void k_softmax_rows(const float* __restrict__ S, float* __restrict__ P, int cols, float scale) {
+  __shared__ float red[4];
+  const long r = blockIdx.x;
+  const float* s = S + r * cols;
+  float mx = -INFINITY;
+  for (int i = threadIdx.x; i < cols; i += 256) mx = fmaxf(mx, s[i] * scale);
+  mx = wave_reduce_max(mx);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  __syncthreads();
+  float sum = 0.0f;
+  for (int i = threadIdx.x; i < cols; i += 256) sum += expf(s[i] * scale - mx);
+  sum = wave_reduce_sum(sum);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = sum;
+  __syncthreads();
+  sum = red[0] + red[1] + red[2] + red[3];
+  for (int i = threadIdx.x; i < cols; i += 256) P[r * cols + i] = expf(s[i] * scale - mx) / sum;
+}
+
+__global__ __launch_bounds__(256) void k_softmax_bwd_rows(const float* __restrict__ P, const float* __restrict__ dP,
+                                                          float* __restrict__ dS, int cols, float scale) {
+  __shared__ float red[4];
+  const long r = blockIdx.x;
+  float dot = 0.0f;
+  for (int i = threadIdx.x; i < cols; i += 256) dot += P[r * cols + i] * dP[r * cols + i];
+  dot = wave_reduce_sum(dot);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = dot;
+  __syncthreads();
+  dot = red[0] + red[1] + red[2] + red[3];
+  for (int i = threadIdx.x; i < cols; i += 256) dS[r * cols + i] = scale * P[r * cols + i] * (dP[r * cols + i] - dot);
+}
+
+extern "C" int tfmq_softmax_rows(tfmq_handle h, const float* S, float* P, long rows, int cols, float scale, void* stream) {
+  TFMQ_CHECK_ARG(h, h && S && P && rows > 0 && cols > 0 && rows < 2147483647L, "softmax_rows: bad argument");
+  hipLaunchKernelGGL(k_softmax_rows, dim3(static_cast<unsigned>(rows)), dim3(256), 0, as_stream(stream), S, P, cols, scale);
+  TFMQ_LAUNCH_CHECK(h);
+  return TFMQ_OK;
+}
+
+extern "C" int tfmq_softmax_bwd_rows(tfmq_handle h, const float* P, const float* dP, float* dS, long rows, int cols,
+                                     float scale, void* stream) {
+  TFMQ_CHECK_ARG(h, h && P && dP && dS && rows > 0 && cols > 0 && rows < 2147483647L, "softmax_bwd_rows: bad argument");
+  hipLaunchKernelGGL(k_softmax_bwd_rows, dim3(static_cast<unsigned>(rows)), dim3(256), 0, as_stream(stream), P, dP, dS, cols,
+                     scale);
+  TFMQ_LAUNCH_CHECK(h);
+  return TFMQ_OK;
+}
+
+// ------------------------------------------------------------------ nearest 2x upsample (materialised only for the
+// reconstruction cache of `upsample.conv` units; sampling fuses it into the conv's addressing)
+__global__ __launch_bounds__(256) void k_upsample2x(const float* __restrict__ x, float* __restrict__ y, int B, int H, int W,
+                                                    int Cc) {
+  const long total = static_cast<long>(B) * 2 * H * 2 * W * Cc;
+  for (long i = static_cast<long>(blockIdx.x) * blockDim.x + threadIdx.x; i < total;
+       i += static_cast<long>(gridDim.x) * blockDim.x) {
+    const int c = i % Cc;
+    long r = i / Cc;
+    const int wo = r % (2 * W); r /= 2 * W;
+    const int ho = r % (2 * H);
+    const int b = r / (2 * H);
+    y[i] = x[((static_cast<long>(b) * H + (ho >> 1)) * W + (wo >> 1)) * Cc + c];
+  }
+}
+extern "C" int tfmq_upsample2x(tfmq_handle h, const float* x, float* y, int B, int H, int W, int C, void* stream) {
+  TFMQ_CHECK_ARG(h, h && x && y && B > 0 && H > 0 && W > 0 && C > 0, "upsample2x: bad argument");
+  const long total = static_cast<long>(B) * 4 * H * W * C;
+  int blocks = ceil_div(total, 256);
+  if (blocks > h->cu_count * 16) blocks = h->cu_count * 16;
+  hipLaunchKernelGGL(k_upsample2x, dim3(blocks), dim3(256), 0, as_stream(stream), x, y, B, H, W, C);
+  TFMQ_LAUNCH_CHECK(h);
+  return TFMQ_OK;
+}
+
+// ------------------------------------------------------------------ flat gradient buffer helpers (K16: one all-reduce per iteration)
+__global__ void k_scale_add(float* __restrict__ y, const float* __restrict__ x, float a, size_t n) {
+  const size_t stride = static_cast<size_t>(gridDim.x) * blockDim.x;
+  for (size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) y[i] += a * x[i];
+}
+extern "C" int tfmq_axpy(tfmq_handle h, float* y, const float* x, float a, size_t n, void* stream) {
+  TFMQ_CHECK_ARG(h, h && x && y, "axpy: null pointer");
+  if (n == 0) return TFMQ_OK;
+  int blocks = ceil_div(static_cast<long>(n), 256);
+  if (blocks > h->cu_count * 8) blocks = h->cu_count * 8;
+  hipLaunchKernelGGL(k_scale_add, dim3(blocks), dim3(256), 0, as_stream(stream), y, x, a, n);
+  TFMQ_LAUNCH_CHECK(h);
+  return TFMQ_OK;
+}

@@ -1,0 +1,60 @@
+"""Stand-alone execution of one quantised block (a reconstruction unit) on the HIP kernels: what
+`block(*inputs)` means for QuantResnetBlock / QuantAttnBlock / the DDIM TIB outside a whole-model
+plan (quant/data_utill.py hooks, block_reconstruction's forward).  NCHW in / NCHW out."""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from .. import ops
+from .ddim_unet import DdimUNetEngine, LayerQ
+
+
+def _collect(block: nn.Module, prefix: str = "blk"):
+    """Module tree of one block -> (sd, wq) in the engine's naming, honouring each QuantLayer's
+    current use_wq / use_aq / disable_aq flags; per-layer activation parameters go to a 1-row table."""
+    from ..quant.quant_layer import QuantLayer
+    sd, wq, rows = {}, {}, []
+    for n, mod in block.named_modules():
+        full = f"{prefix}.{n}" if n else prefix
+        if isinstance(mod, QuantLayer):
+            if mod.use_wq:
+                d, z, a = mod.weight_quant_state()
+                sd[full + ".weight"] = mod.w.detach()
+                if mod.b is not None:
+                    sd[full + ".bias"] = mod.b.detach()
+                qid = None
+                if mod.use_aq and not mod.disable_aq and mod.aqtizer.delta is not None:
+                    qid = len(rows)
+                    rows.append([float(mod.aqtizer.delta), float(mod.aqtizer.zero_point)])
+                wq[full] = LayerQ(d, z, a, qid)
+            else:
+                sd[full + ".weight"] = mod.original_w
+                if mod.original_b is not None:
+                    sd[full + ".bias"] = mod.original_b
+        elif isinstance(mod, (nn.Conv2d, nn.Linear, nn.GroupNorm)):
+            for pn, p in mod.named_parameters(recurse=False):
+                sd[f"{full}.{pn}"] = p.detach()
+    return sd, wq, rows
+
+
+def _engine_for(block: nn.Module, device):
+    sd, wq, rows = _collect(block)
+    eng = DdimUNetEngine(sd, {}, device)
+    qtable = torch.tensor([rows], dtype=torch.float32, device=device) if rows else None
+    eng.prepare(wq, qtable, None)
+    return eng
+
+
+def run_resnet_block(block, x: torch.Tensor, temb: torch.Tensor) -> torch.Tensor:
+    """QuantResnetBlock.forward (reference quant/quant_block.py:415-444)."""
+    eng = _engine_for(block, x.device)
+    proj = eng._linear("blk.temb_proj", temb.float().contiguous(), True)
+    y = eng._resblock("blk", ops.nchw_to_nhwc(x.float().contiguous()), None, dict(rowadd=proj))
+    return ops.nhwc_to_nchw(y)
+
+
+def run_attn_block(block, x: torch.Tensor) -> torch.Tensor:
+    """QuantAttnBlock.forward (reference quant/quant_block.py:474-505) with un-quantised QK^T / PV."""
+    eng = _engine_for(block, x.device)
+    return ops.nhwc_to_nchw(eng._attnblock("blk", ops.nchw_to_nhwc(x.float().contiguous())))

@@ -63,7 +63,8 @@ class DdimUNetEngine:
         if self.dev.type != "cuda":
             raise TfmqError("DdimUNetEngine needs an MI355X device: the HIP kernels are the only implementation")
         self.sd = {k: v.detach().to(self.dev, torch.float32).contiguous() for k, v in sd.items()}
-        self.res_names = ddim_resblock_names(cfg)
+        self.res_names = ddim_resblock_names(cfg) if "ch_mult" in self.cfg else []
+        self.calib_mask = None     # None = observe every live quantizer, else a set of qids
         self.layers: Dict[str, _Layer] = {}
         self.lin: Dict[str, tuple] = {}
         self.qtable = None
@@ -109,7 +110,7 @@ class DdimUNetEngine:
                 a = None if q.alpha is None else q.alpha.to(self.dev).contiguous()
                 self.layers[n] = _Layer("w4a8", ops.pack_w4(w, q.delta.to(self.dev), q.zp.to(self.dev), a, b), aq)
         # linears of the temporal-information block
-        for n in ["temb.dense.0", "temb.dense.1"] + [r + ".temb_proj" for r in self.res_names]:
+        for n in [k[:-7] for k in sd if k.endswith(".weight") and sd[k].dim() == 2]:
             w, b = sd[n + ".weight"], sd.get(n + ".bias")
             q = wq.get(n)
             if q is None:
@@ -164,6 +165,8 @@ class DdimUNetEngine:
     def _observe(self, aq, x, siblings=()):
         mode, k = self.calib
         qid = aq.qid
+        if self.calib_mask is not None and qid not in self.calib_mask:
+            return
         if mode == "init":
             qp = ops.mse_search(x, 1, 256)
             self.qtable[k, qid].copy_(qp[0])
@@ -194,6 +197,7 @@ class DdimUNetEngine:
         emb = ops.timestep_embedding(t, self.cfg["ch"])
         h = self._linear("temb.dense.0", emb, False)
         temb = self._linear("temb.dense.1", h, True)
+        self._last_temb = temb
         return [self._linear(r + ".temb_proj", temb, True) for r in self.res_names]
 
     def build_tib_table(self, t_values: Sequence[float]):
@@ -281,6 +285,8 @@ class DdimUNetEngine:
         nlev, nres = len(cfg["ch_mult"]), cfg["num_res_blocks"]
         if t is not None:
             projs = dict(zip(self.res_names, self.tib(t)))
+            if taps is not None:
+                taps["__temb__"] = self._last_temb
 
             def rowadd(p):
                 return dict(rowadd=projs[p])
@@ -339,7 +345,10 @@ class DdimUNetEngine:
                 if up.kind == "w4a8" and self.calib is not None:
                     self._observe(up.aq, h)
                 hq = ops.quantize_act(h, up.aq) if up.kind == "w4a8" else h
+                hlow = h
                 h = up.run(hq, pad=(1, 1, 1, 1), up2x=True)
+                if taps is not None:  # layer unit: its input is the up-sampled tensor (Upsample.forward)
+                    taps[f"up.{i}.upsample.conv"] = (ops.upsample2x(hlow), h)
                 res *= 2
         h, _ = self._gn("norm_out", h, None, True, None)
         return L["conv_out"].run(h, pad=(1, 1, 1, 1))

@@ -1,0 +1,238 @@
+"""Reconstruction units: hand-written forward / backward of one quantised unit w.r.t. the AdaRound
+`alpha` of its layers (K12-K15), replacing autograd through `block(*cur_inputs)` + torch.optim.Adam
+(reference quant/reconstruction.py:63-78,182-198,290-303).
+
+Every unit exposes
+    iterate(idx, count) -> (total_loss, rec_loss, round_loss)
+running one Adam iteration on the mini-batch `idx` of its cached inputs/targets:
+    soft weights (K12) -> unit forward (exact fp32 GEMMs over im2col) -> lp_loss (K13) -> unit
+    backward to dL/dW_hat -> [all-reduce SUM across ranks, K16] -> alpha gradient + rounding
+    regulariser + Adam (K12/K14 fused).
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Sequence
+
+import torch
+
+from .. import ops
+
+
+def temp_decay(count: int, t_max: int, warmup: float, start_b: float = 20.0, end_b: float = 2.0) -> float:
+    """LinearTempDecay (reference quant/reconstruction_util.py:176-198; linear, not cosine)."""
+    start = warmup * t_max
+    if count < start:
+        return start_b
+    rel = (count - start) / (t_max - start)
+    return end_b + (start_b - end_b) * max(0.0, 1.0 - rel)
+
+
+class AdaLayer:
+    """One layer whose rounding is being learned: w (OIHW / [out,in]), frozen delta/zp, alpha + Adam state."""
+
+    def __init__(self, w: torch.Tensor, delta: torch.Tensor, zp: torch.Tensor, bias: Optional[torch.Tensor], level: int = 16,
+                 alpha: Optional[torch.Tensor] = None):
+        self.w = w.detach().float().contiguous()
+        self.cout = w.shape[0]
+        self.cin = w.shape[1]
+        self.kh, self.kw = (w.shape[2], w.shape[3]) if w.dim() == 4 else (1, 1)
+        self.delta = delta.detach().reshape(-1).float().contiguous()
+        self.zp = zp.detach().reshape(-1).float().contiguous()
+        self.bias = None if bias is None else bias.detach().float().contiguous()
+        self.level = level
+        self.alpha = ops.adaround_init(self.w, self.delta) if alpha is None else alpha.detach().float().contiguous().clone()
+        self.m = torch.zeros_like(self.alpha)
+        self.v = torch.zeros_like(self.alpha)
+
+    def soft_weight_gemm(self) -> torch.Tensor:
+        """w_hat in the GEMM layout [cout, kh*kw*cin] (adaptive_rounding.py soft branch)."""
+        w_hat = ops.adaround_soft_fwd(self.w, self.alpha, self.delta, self.zp, self.level)
+        if self.kh * self.kw == 1:
+            return w_hat.reshape(self.cout, self.cin)
+        return ops.w_relayout(w_hat, self.cout, self.cin, self.kh, self.kw, to_gemm=True)
+
+    def grad_to_oihw(self, g_gemm: torch.Tensor) -> torch.Tensor:
+        if self.kh * self.kw == 1:
+            return g_gemm.reshape(self.w.shape)
+        return ops.w_relayout(g_gemm, self.cout, self.cin, self.kh, self.kw, to_gemm=False)
+
+    def step(self, g_what: torch.Tensor, w_reg: float, b_temp: float, lr: float, t: int, round_loss: torch.Tensor):
+        ops.adaround_bwd_adam(self.w, self.alpha, self.delta, self.zp, g_what.contiguous(), self.m, self.v, self.level,
+                              w_reg, b_temp, lr, t, round_loss)
+
+
+class _Unit:
+    """Shared iteration driver.  Sub-classes implement _forward_backward(idx) -> (rec_loss_tensor,
+    [g_what per AdaLayer, OIHW])."""
+
+    def __init__(self, layers: Sequence[AdaLayer], iters: int, w: float = 0.01, warmup: float = 0.2, lr: float = 1e-3,
+                 world_size: int = 1, allreduce=None):
+        self.layers = list(layers)
+        self.iters, self.w_reg, self.warmup, self.lr = iters, w, warmup, lr
+        self.world_size, self.allreduce = world_size, allreduce
+        self.count = 0
+        dev = self.layers[0].w.device
+        self._rl = torch.zeros(1, dtype=torch.float32, device=dev)
+        self._flat = None
+
+    def iterate(self, idx: torch.Tensor):
+        self.count += 1
+        rec, grads = self._forward_backward(idx)
+        if self.world_size > 1 and self.allreduce is not None:
+            # one flattened fp32 buffer per iteration instead of one all-reduce per tensor
+            # (reference reconstruction.py:193-195); the rounding regulariser is computed identically on
+            # every rank and is therefore summed world_size times by the reference's grad all-reduce.
+            if self._flat is None:
+                self._flat = torch.empty(sum(g.numel() for g in grads), dtype=torch.float32, device=grads[0].device)
+            off = 0
+            for g in grads:
+                self._flat[off:off + g.numel()].copy_(g.reshape(-1))
+                off += g.numel()
+            self.allreduce(self._flat)
+            off, red = 0, []
+            for g in grads:
+                red.append(self._flat[off:off + g.numel()].view_as(g))
+                off += g.numel()
+            grads = red
+        b = temp_decay(self.count, self.iters, self.warmup)
+        reg_on = self.count >= self.iters * self.warmup
+        self._rl.zero_()
+        w_eff = self.w_reg * (self.world_size if (self.world_size > 1 and self.allreduce is not None) else 1)
+        for layer, g in zip(self.layers, grads):
+            layer.step(g, w_eff, b if reg_on else 0.0, self.lr, self.count, self._rl)
+        return rec, self._rl
+
+    def losses(self, rec, rl):
+        r, q = float(rec), float(rl) / (self.world_size if (self.world_size > 1 and self.allreduce is not None) else 1)
+        return r + q, r, q
+
+
+def _conv_fwd(x, layer: AdaLayer, w_gemm, pad, rowadd=None, residual=None):
+    """x NHWC -> (y NHWC, col) via im2col + exact fp32 GEMM."""
+    B, H, W, _ = x.shape
+    if layer.kh * layer.kw == 1:
+        col = x.reshape(B * H * W, layer.cin)
+    else:
+        col = ops.im2col(x, layer.kh, layer.kw, 1, pad)
+    y = ops.gemm(col, w_gemm, trans_b=True, bias=layer.bias, rowadd=rowadd, rows_per_img=H * W,
+                 residual=None if residual is None else residual.reshape(B * H * W, -1))
+    return y.reshape(B, H, W, layer.cout), col
+
+
+class LayerUnit(_Unit):
+    """Single QuantLayer (layer_reconstruction, reference :13-82); x: the layer's (already up-sampled) input."""
+
+    def __init__(self, layer: AdaLayer, x: torch.Tensor, y: torch.Tensor, pad=(1, 1, 1, 1), **kw):
+        super().__init__([layer], **kw)
+        self.x, self.y, self.pad = x, y, pad
+
+    def _forward_backward(self, idx):
+        L = self.layers[0]
+        x, y = self.x.index_select(0, idx), self.y.index_select(0, idx)
+        wg = L.soft_weight_gemm()
+        out, col = _conv_fwd(x, L, wg, self.pad)
+        loss, g = ops.recon_loss(out, y, denom=out.numel() // out.shape[-1])
+        gw = ops.gemm(g.reshape(-1, L.cout), col, trans_a=True)
+        return loss, [L.grad_to_oihw(gw)]
+
+
+class ResnetUnit(_Unit):
+    """QuantResnetBlock (reference quant/quant_block.py:415-444): AdaRound on conv1, conv2; temb_proj is
+    `quant_emb` (owned by the TIB unit) and nin_shortcut is FP, both constant here."""
+
+    def __init__(self, conv1: AdaLayer, conv2: AdaLayer, gn1, gn2, shortcut, x, proj, y, **kw):
+        super().__init__([conv1, conv2], **kw)
+        self.gn1, self.gn2 = gn1, gn2      # (gamma, beta)
+        self.shortcut = shortcut           # None or (w [cout, cin] fp32, bias)
+        self.x, self.proj, self.y = x, proj, y
+
+    def _forward_backward(self, idx):
+        c1l, c2l = self.layers
+        x, proj, y = self.x.index_select(0, idx), self.proj.index_select(0, idx), self.y.index_select(0, idx)
+        B, H, W, cin = x.shape
+        w1, w2 = c1l.soft_weight_gemm(), c2l.soft_weight_gemm()
+        _, a1, _ = ops.groupnorm(x, self.gn1[0], self.gn1[1], 1e-6, True, want_f32=True)
+        c1, col1 = _conv_fwd(a1, c1l, w1, (1, 1, 1, 1), rowadd=proj)
+        _, a2, _ = ops.groupnorm(c1, self.gn2[0], self.gn2[1], 1e-6, True, want_f32=True)
+        if self.shortcut is not None:
+            sc = ops.gemm(x.reshape(B * H * W, cin), self.shortcut[0], trans_b=True, bias=self.shortcut[1]).reshape(B, H, W, -1)
+        else:
+            sc = x
+        out, col2 = _conv_fwd(a2, c2l, w2, (1, 1, 1, 1), residual=sc)
+        loss, g = ops.recon_loss(out, y, denom=B * H * W)
+        g2 = g.reshape(B * H * W, c2l.cout)
+        gw2 = ops.gemm(g2, col2, trans_a=True)
+        dcol2 = ops.gemm(g2, w2)
+        g_a2 = ops.col2im(dcol2, (B, H, W, c2l.cin), 3, 3, 1, (1, 1, 1, 1))
+        g_c1 = ops.groupnorm_bwd(c1, g_a2, self.gn2[0], self.gn2[1], 1e-6, True)
+        gw1 = ops.gemm(g_c1.reshape(B * H * W, c1l.cout), col1, trans_a=True)
+        return loss, [c1l.grad_to_oihw(gw1), c2l.grad_to_oihw(gw2)]
+
+
+class AttnUnit(_Unit):
+    """QuantAttnBlock (reference quant/quant_block.py:474-505), single head, un-quantised matmuls."""
+
+    def __init__(self, q: AdaLayer, k: AdaLayer, v: AdaLayer, po: AdaLayer, gn, x, y, **kw):
+        super().__init__([q, k, v, po], **kw)
+        self.gn, self.x, self.y = gn, x, y
+
+    def _forward_backward(self, idx):
+        ql, kl, vl, pl = self.layers
+        x, y = self.x.index_select(0, idx), self.y.index_select(0, idx)
+        B, H, W, Cc = x.shape
+        T = H * W
+        scale = float(int(Cc) ** (-0.5))
+        wq, wk, wv, wp = (l.soft_weight_gemm() for l in self.layers)
+        _, hn, _ = ops.groupnorm(x, self.gn[0], self.gn[1], 1e-6, False, want_f32=True)
+        hf = hn.reshape(B * T, Cc)
+        q = ops.gemm(hf, wq, trans_b=True, bias=ql.bias).reshape(B, T, Cc)
+        k = ops.gemm(hf, wk, trans_b=True, bias=kl.bias).reshape(B, T, Cc)
+        v = ops.gemm(hf, wv, trans_b=True, bias=vl.bias).reshape(B, T, Cc)
+        S = ops.gemm(q, k, trans_b=True)                        # [B,T,T]
+        P = ops.softmax_rows(S, scale)
+        o = ops.gemm(P, v)                                      # [B,T,C]
+        out = ops.gemm(o.reshape(B * T, Cc), wp, trans_b=True, bias=pl.bias, residual=x.reshape(B * T, Cc)).reshape(B, H, W, Cc)
+        loss, g = ops.recon_loss(out, y, denom=B * T)
+        g2 = g.reshape(B * T, Cc)
+        gwp = ops.gemm(g2, o.reshape(B * T, Cc), trans_a=True)
+        g_o = ops.gemm(g2, wp).reshape(B, T, Cc)
+        dV = ops.gemm(P, g_o, trans_a=True)
+        dP = ops.gemm(g_o, v, trans_b=True)
+        dS = ops.softmax_bwd_rows(P, dP, scale)
+        dQ = ops.gemm(dS, k)
+        dK = ops.gemm(dS, q, trans_a=True)
+        gwq = ops.gemm(dQ.reshape(B * T, Cc), hf, trans_a=True)
+        gwk = ops.gemm(dK.reshape(B * T, Cc), hf, trans_a=True)
+        gwv = ops.gemm(dV.reshape(B * T, Cc), hf, trans_a=True)
+        return loss, [g.reshape(l.w.shape) for g, l in zip((gwq, gwk, gwv, gwp), self.layers)]
+
+
+class TibUnit(_Unit):
+    """Temporal-information block (TIAR, reference quant/reconstruction.py:212-318 with
+    LossFuncTimeEmbedding :94-173): dense.1 and every temb projection learn their rounding against
+    the FP projections; dense.0 is FP (ignore_recon).  s0 = silu(dense0(emb(t))) is constant."""
+
+    def __init__(self, dense1: AdaLayer, projs: Sequence[AdaLayer], s0: torch.Tensor, targets: Sequence[torch.Tensor], **kw):
+        super().__init__([dense1] + list(projs), **kw)
+        self.s0, self.targets = s0, list(targets)
+
+    def _forward_backward(self, idx):
+        d1, projs = self.layers[0], self.layers[1:]
+        s0 = self.s0.index_select(0, idx)
+        m = s0.shape[0]
+        w1 = d1.soft_weight_gemm()
+        temb = ops.gemm(s0, w1, trans_b=True, bias=d1.bias)
+        s1 = ops.silu(temb)
+        total = torch.zeros(1, dtype=torch.float32, device=s0.device)
+        g_s1 = None
+        grads = [None]
+        for pl, tgt in zip(projs, self.targets):
+            wp = pl.soft_weight_gemm()
+            out = ops.gemm(s1, wp, trans_b=True, bias=pl.bias)
+            loss, g = ops.recon_loss(out, tgt.index_select(0, idx), denom=m)
+            ops.axpy(total, loss, 1.0)
+            grads.append(ops.gemm(g, s1, trans_a=True).reshape(pl.w.shape))
+            g_s1 = ops.gemm(g, wp, out=g_s1, accumulate=g_s1 is not None)
+        g_temb = ops.silu_bwd(temb, g_s1)
+        grads[0] = ops.gemm(g_temb, s0, trans_a=True).reshape(d1.w.shape)
+        return total, grads

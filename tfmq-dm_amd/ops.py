@@ -466,12 +466,12 @@ def adaround_init(w: torch.Tensor, delta: torch.Tensor) -> torch.Tensor:
     return alpha
 
 
-def adaround_soft_fwd(w, alpha, delta, zp, level: int) -> torch.Tensor:
+def adaround_soft_fwd(w, alpha, delta, zp, level: int, hard: bool = False) -> torch.Tensor:
     d = _dev(w)
     rows = delta.numel()
     w_hat = _alloc_like(w)
     handle(d).call("adaround_soft_fwd", _p(w), _p(alpha), _p(delta.reshape(-1).contiguous()), _p(zp.reshape(-1).contiguous()),
-                   _p(w_hat), rows, w.numel() // rows, level, _stream(d))
+                   _p(w_hat), rows, w.numel() // rows, level, int(hard), _stream(d))
     return w_hat
 
 
@@ -482,6 +482,103 @@ def adaround_bwd_adam(w, alpha, delta, zp, g_what, m, v, level: int, w_reg: floa
     handle(d).call("adaround_bwd_adam", _p(w), _p(alpha), _p(delta.reshape(-1).contiguous()), _p(zp.reshape(-1).contiguous()),
                    _p(g_what), _p(m), _p(v), rows, w.numel() // rows, level, float(w_reg), float(b_temp), float(lr), int(t),
                    _p(round_loss), _stream(d))
+
+
+# ------------------------------------------------------------------------------ K15 (reconstruction fwd/bwd pieces)
+def gemm(A: torch.Tensor, B: torch.Tensor, trans_a: bool = False, trans_b: bool = False, alpha: float = 1.0,
+         bias=None, rowadd=None, rows_per_img: int = 1, residual=None, out=None, accumulate: bool = False) -> torch.Tensor:
+    """C = alpha * op(A) @ op(B) (+bias[n]) (+rowadd[m // rows_per_img]) (+residual); A,B: contiguous fp32
+    2-D or batched 3-D; exact fp32 FMA accumulation."""
+    d = _dev(A)
+    _chk(A, torch.float32, "A")
+    _chk(B, torch.float32, "B")
+    batched = A.dim() == 3
+    a2, b2 = (A.shape[-2], A.shape[-1]), (B.shape[-2], B.shape[-1])
+    M, K = (a2[1], a2[0]) if trans_a else a2
+    Kb, N = (b2[1], b2[0]) if trans_b else b2
+    if K != Kb:
+        raise TfmqError(f"gemm: inner dims differ ({K} vs {Kb})")
+    nb = A.shape[0] if batched else 1
+    sam, sak = (1, a2[1]) if trans_a else (a2[1], 1)
+    sbk, sbn = (1, b2[1]) if trans_b else (b2[1], 1)
+    shape = (nb, M, N) if batched else (M, N)
+    Cm = out if out is not None else _alloc(shape, dtype=torch.float32, device=A.device)
+    handle(d).call("gemm_f32", _p(A), _p(B), _p(Cm), M, N, K, sam, sak, sbk, sbn, N, nb, a2[0] * a2[1] if batched else 0,
+                   (b2[0] * b2[1] if B.dim() == 3 else 0), M * N if batched else 0, float(alpha), _p(bias), _p(rowadd),
+                   int(rows_per_img), 0 if rowadd is None else rowadd.shape[-1], _p(residual), int(accumulate), _stream(d))
+    return Cm
+
+
+def im2col(x: torch.Tensor, kh: int, kw: int, stride: int = 1, pad=(0, 0, 0, 0)) -> torch.Tensor:
+    d = _dev(x)
+    _chk(x, torch.float32, "x")
+    B, H, W, Cc = x.shape
+    Ho, Wo = out_hw(H, W, kh, kw, stride, pad[0], pad[1], pad[2], pad[3])
+    col = _alloc(B * Ho * Wo, kh * kw * Cc, dtype=torch.float32, device=x.device)
+    handle(d).call("im2col", _p(x), _p(col), B, H, W, Cc, kh, kw, stride, pad[0], pad[1], Ho, Wo, _stream(d))
+    return col
+
+
+def col2im(dcol: torch.Tensor, shape, kh: int, kw: int, stride: int = 1, pad=(0, 0, 0, 0)) -> torch.Tensor:
+    d = _dev(dcol)
+    B, H, W, Cc = shape
+    Ho, Wo = out_hw(H, W, kh, kw, stride, pad[0], pad[1], pad[2], pad[3])
+    dx = _alloc(B, H, W, Cc, dtype=torch.float32, device=dcol.device)
+    handle(d).call("col2im", _p(dcol), _p(dx), B, H, W, Cc, kh, kw, stride, pad[0], pad[1], Ho, Wo, _stream(d))
+    return dx
+
+
+def w_relayout(w: torch.Tensor, cout: int, cin: int, kh: int, kw: int, to_gemm: bool) -> torch.Tensor:
+    """OIHW <-> [cout, kh*kw*cin] (the im2col column order)."""
+    d = _dev(w)
+    out = _alloc((cout, kh * kw * cin) if to_gemm else (cout, cin, kh, kw), dtype=torch.float32, device=w.device)
+    handle(d).call("w_relayout", _p(w), _p(out), cout, cin, kh, kw, 0 if to_gemm else 1, _stream(d))
+    return out
+
+
+def silu_bwd(x: torch.Tensor, gy: torch.Tensor) -> torch.Tensor:
+    d = _dev(x)
+    gx = _alloc_like(x)
+    handle(d).call("silu_bwd", _p(x), _p(gy), _p(gx), x.numel(), _stream(d))
+    return gx
+
+
+def groupnorm_bwd(x: torch.Tensor, gy: torch.Tensor, gamma, beta, eps: float, silu: bool, groups: int = 32) -> torch.Tensor:
+    d = _dev(x)
+    B, Cc = x.shape[0], x.shape[-1]
+    gx = _alloc_like(x)
+    handle(d).call("groupnorm_bwd", _p(x), _p(gy), _p(gamma), _p(beta), _p(gx), B, x.numel() // (B * Cc), Cc, groups, float(eps),
+                   int(silu), _stream(d))
+    return gx
+
+
+def softmax_rows(S: torch.Tensor, scale: float) -> torch.Tensor:
+    d = _dev(S)
+    P = _alloc_like(S)
+    handle(d).call("softmax_rows", _p(S), _p(P), S.numel() // S.shape[-1], S.shape[-1], float(scale), _stream(d))
+    return P
+
+
+def softmax_bwd_rows(P: torch.Tensor, dP: torch.Tensor, scale: float) -> torch.Tensor:
+    d = _dev(P)
+    dS = _alloc_like(P)
+    handle(d).call("softmax_bwd_rows", _p(P), _p(dP), _p(dS), P.numel() // P.shape[-1], P.shape[-1], float(scale), _stream(d))
+    return dS
+
+
+def upsample2x(x: torch.Tensor) -> torch.Tensor:
+    d = _dev(x)
+    _chk(x, torch.float32, "x")
+    B, H, W, Cc = x.shape
+    y = _alloc(B, 2 * H, 2 * W, Cc, dtype=torch.float32, device=x.device)
+    handle(d).call("upsample2x", _p(x), _p(y), B, H, W, Cc, _stream(d))
+    return y
+
+
+def axpy(y: torch.Tensor, x: torch.Tensor, a: float = 1.0):
+    d = _dev(y)
+    handle(d).call("axpy", _p(y), _p(x), float(a), y.numel(), _stream(d))
+    return y
 
 
 def recon_loss(pred, tgt, denom: int, want_grad: bool = True):

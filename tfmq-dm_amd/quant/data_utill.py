@@ -1,0 +1,66 @@
+"""Reconstruction data capture (reference quant/data_utill.py): the FP output of a unit and its
+input under the already-quantised upstream (asymmetric reconstruction, A7).
+
+The reference registers a forward hook on the unit and aborts the forward with an exception; here the
+engine plan exposes every unit's input/output as taps of one forward pass, so a capture is two engine
+runs per calibration batch (FP for the target, weight-quantised for the input)."""
+from __future__ import annotations
+
+import logging
+from typing import Tuple, Union
+
+import torch
+
+from tfmq_dm_amd import ops
+
+logger = logging.getLogger(__name__)
+
+
+class StopForwardException(Exception):
+    """Kept for API compatibility (the engine does not need to abort a forward)."""
+
+
+def unit_name(model, unit) -> str:
+    for n, m in model.model.named_modules():
+        if m is unit:
+            return n
+    raise KeyError("unit is not a sub-module of the quantised model")
+
+
+def save_inout(model, layer, cali_data: Tuple[torch.Tensor], asym: bool = False, use_act: bool = False,
+               batch_size: int = 128, keep_gpu: bool = True):
+    """-> (cached_inputs: tuple of NHWC tensors, cached_output NHWC).  For a ResnetBlock unit the inputs are
+    (x, temb); for an attention block / single layer (x,).  Everything stays on the device (288 GB HBM;
+    the reference spills to host RAM for the largest units, calibration.py:62-67)."""
+    from .quant_block import QuantResnetBlock
+    name = unit_name(model, layer)
+    dev = next(model.model.parameters()).device
+    xs, ts = cali_data[0], cali_data[1]
+    ins, outs, tembs = [], [], []
+    # target: FP model
+    model.set_quant_state(False, False)
+    eng_fp = model.engine(dev)
+    # input: upstream with quantised weights (hard rounding of the units already reconstructed)
+    for i in range(0, xs.size(0), batch_size):
+        x = ops.nchw_to_nhwc(xs[i:i + batch_size].to(dev).float().contiguous())
+        t = ts[i:i + batch_size].to(dev).float().contiguous()
+        taps = {}
+        model.set_quant_state(False, False)
+        model.engine(dev).forward(x, t, taps=taps)
+        outs.append(taps[name][1])
+        if asym:
+            taps = {}
+            model.set_quant_state(True, use_act)
+            model.engine(dev).forward(x, t, taps=taps)
+        tin = taps[name][0]
+        if isinstance(tin, tuple):       # (h, skip): concatenated input of an up-path ResnetBlock
+            tin = torch.cat(tin, dim=-1)
+        ins.append(tin)
+        if isinstance(layer, QuantResnetBlock):
+            tembs.append(taps["__temb__"])
+    model.set_quant_state(False, False)
+    layer.set_quant_state(True, use_act)
+    cached_out = torch.cat(outs)
+    cached_in = (torch.cat(ins),) + ((torch.cat(tembs),) if tembs else ())
+    logger.info(f"input shapes: {[tuple(c.shape) for c in cached_in]} output shape: {tuple(cached_out.shape)}")
+    return cached_in, cached_out

@@ -1,0 +1,255 @@
+"""Quantisation primitives of the reference's quant/quant_layer.py on the HIP kernels.
+
+Same public names and call signatures (`minmax`, `mse`, `Scaler`, `lp_loss`,
+`UniformAffineQuantizer`, `QuantLayer`, `QMODE`, `StraightThrough`); every tensor operation is a
+launch through the C ABI (K1-K6).  CPU tensors are refused: there is no CPU fallback.
+"""
+from __future__ import annotations
+
+from enum import Enum
+from typing import List, Optional, Union
+
+import torch
+import torch.nn as nn
+
+from tfmq_dm_amd import ops
+from tfmq_dm_amd._lib import TfmqError
+
+
+class StraightThrough(nn.Module):
+    def forward(self, x):
+        return x
+
+
+def _scalar(qp: torch.Tensor, i: int) -> torch.Tensor:
+    return qp[0, i].clone()
+
+
+def minmax(x: torch.Tensor, symmetric: bool = False, level: int = 256, always_zero: bool = False):
+    """MINMAX scaler (reference quant_layer.py:20-35) -> (delta, zero_point) 0-dim device tensors."""
+    if symmetric:
+        raise NotImplementedError("symmetric quantisation is never selected by the TFMQ drivers")
+    qp = ops.minmax_to_qparam(ops.minmax(x.detach().contiguous().float(), 1), level, always_zero)
+    return _scalar(qp, 0), _scalar(qp, 1)
+
+
+def mse(x: torch.Tensor, symmetric: bool = False, level: int = 256, always_zero: bool = False):
+    """MSE scaler: 80 shrink candidates, L2.4 loss, first strict minimum (reference :38-64)."""
+    if symmetric:
+        raise NotImplementedError("symmetric quantisation is never selected by the TFMQ drivers")
+    qp = ops.mse_search(x.detach().contiguous().float(), 1, level, always_zero)
+    return _scalar(qp, 0), _scalar(qp, 1)
+
+
+def _unsupported(name):
+    def fn(*a, **k):
+        raise NotImplementedError(f"Scaler.{name} is selectable in the reference but never chosen by its drivers; "
+                                  "not on the MI355X hot path (SURVEY §8f-4)")
+    fn.__name__ = name.lower()
+    return fn
+
+
+class Scaler:
+    """Namespace of scaler functions (the reference's Enum of plain functions is just that)."""
+    MINMAX = staticmethod(minmax)
+    MSE = staticmethod(mse)
+    KL = staticmethod(_unsupported("KL"))
+    HIST = staticmethod(_unsupported("HIST"))
+
+
+REDUCTION = Enum("REDUCTION", ("NONE", "ALL"))
+QMODE = Enum("QMODE", ("QDIFF", "NORMAL", "PTQD"))
+
+
+def lp_loss(pred: torch.Tensor, tgt: torch.Tensor, p: float = 2.0, reduction: REDUCTION = REDUCTION.NONE) -> torch.Tensor:
+    """|pred-tgt|^p summed over dim 1, mean over the rest (reference :146-156); p = 2 on device."""
+    if p != 2.0 or reduction != REDUCTION.NONE:
+        raise NotImplementedError("lp_loss: the reconstruction path uses p=2, REDUCTION.NONE")
+    denom = pred.numel() // pred.shape[1]
+    loss, _ = ops.recon_loss(pred.contiguous(), tgt.contiguous(), denom, want_grad=False)
+    return loss[0]
+
+
+def _scaler_kind(fn) -> str:
+    name = getattr(fn, "__name__", str(fn))
+    if name not in ("mse", "minmax"):
+        fn()  # raises the NotImplementedError of the unsupported scalers
+    return name
+
+
+class UniformAffineQuantizer(nn.Module):
+    """Asymmetric uniform quantizer with lazy initialisation (reference :163-253)."""
+
+    def __init__(self, bits: int = 8, symmetric: bool = False, channel_wise: bool = False, scaler=Scaler.MINMAX,
+                 leaf_param: bool = False, always_zero: bool = False, quant_emb: bool = False) -> None:
+        super().__init__()
+        if symmetric:
+            raise NotImplementedError("symmetric quantisation is never selected by the TFMQ drivers")
+        self.level = 2 ** bits
+        self.symmetric = symmetric
+        self.channel_wise = channel_wise
+        self.scaler = scaler
+        self.leaf_param = leaf_param
+        if leaf_param:
+            self.x_min, self.x_max = None, None
+        self.running_stat = False
+        self.always_zero = always_zero
+        self.delta = None
+        self.zero_point = None
+        self.init = False
+        self.quant_emb = quant_emb
+
+    def _init_quantization_param(self, x: torch.Tensor, channel_wise: bool = False):
+        kind = _scaler_kind(self.scaler)
+        x = x.detach().contiguous().float()
+        rows = x.shape[0] if channel_wise else 1
+        if kind == "mse":
+            qp = ops.mse_search(x, rows, self.level, self.always_zero)
+        else:
+            qp = ops.minmax_to_qparam(ops.minmax(x, rows), self.level, self.always_zero)
+        if channel_wise:
+            shape = (-1,) + (1,) * (x.dim() - 1)
+            return qp[:, 0].clone().view(shape), qp[:, 1].clone().view(shape)
+        if self.leaf_param:
+            mm = ops.minmax(x, 1)
+            self.x_min, self.x_max = mm[0, 0].clone(), mm[0, 1].clone()
+        return _scalar(qp, 0), _scalar(qp, 1)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if not self.init:
+            self.delta, self.zero_point = self._init_quantization_param(x, self.channel_wise)
+            if self.leaf_param:
+                self.delta = nn.Parameter(self.delta)
+            self.init = True
+        if self.running_stat:
+            self.act_momentum_update(x)
+        zp = self.zero_point if torch.is_tensor(self.zero_point) else torch.tensor(float(self.zero_point), device=x.device)
+        return ops.fake_quant(x.detach().contiguous().float(), self.delta.detach(), zp.detach(), self.level)
+
+    def act_momentum_update(self, x: torch.Tensor, act_range_momentum: float = 0.95) -> None:
+        assert self.init and self.leaf_param
+        state = torch.stack([self.x_min, self.x_max]).reshape(1, 2).contiguous()
+        qp = torch.empty(1, 2, device=x.device)
+        ops.act_range_update(ops.minmax(x.detach().contiguous().float(), 1), state, qp, act_range_momentum, self.level, init=False)
+        self.x_min, self.x_max = state[0, 0].clone(), state[0, 1].clone()
+        self.zero_point = qp[0, 1].clone()
+        self.delta = nn.Parameter(qp[0, 0].clone())
+
+    def bitwidth_refactor(self, bits: int = 8) -> None:
+        self.level = 2 ** bits
+
+    def extra_repr(self) -> str:
+        return (f"level={self.level}, symmetric={self.symmetric}, channel_wise={self.channel_wise}, "
+                f"scaler={getattr(self.scaler, '__name__', self.scaler)}, leaf_param={self.leaf_param}")
+
+
+class QuantLayer(nn.Module):
+    """Conv2d / Linear wrapper (reference :259-355).  `forward` is the eager per-layer device path
+    (NCHW / [..., C] in and out, like the reference); whole-model execution goes through the fused
+    engine plan that QuantModel builds from these objects."""
+
+    QMAP = {nn.Conv2d: "conv2d", nn.Linear: "linear"}
+
+    def __init__(self, layer: Union[nn.Conv2d, nn.Linear], wq_params: dict = {}, aq_params: dict = {},
+                 disable_aq: bool = False, aq_mode: List[int] = [QMODE.QDIFF.value], quant_emb: bool = False) -> None:
+        super().__init__()
+        if type(layer) not in self.QMAP:
+            raise TfmqError(f"QuantLayer: unsupported layer type {type(layer).__name__}")
+        self.wq_params, self.aq_params = wq_params, aq_params
+        self.kind = self.QMAP[type(layer)]
+        self.fwd_kwargs = {}
+        if isinstance(layer, nn.Conv2d):
+            if layer.groups != 1 or tuple(layer.dilation) != (1, 1):
+                raise TfmqError("QuantLayer: grouped / dilated convolutions are not on the TFMQ hot path")
+            self.fwd_kwargs = dict(stride=layer.stride, padding=layer.padding, dilation=layer.dilation, groups=layer.groups)
+        self.w = layer.weight
+        self.original_w = self.w.data.clone()
+        self.b = None
+        self.original_b = None
+        if layer.bias is not None:
+            self.b = layer.bias
+            self.original_b = self.b.data.clone()
+        self.use_wq = False
+        self.use_aq = False
+        self.disable_aq = disable_aq
+        self.aq_mode = aq_mode
+        self.quant_emb = quant_emb
+        self.wq_params["quant_emb"] = quant_emb
+        self.wqtizer = UniformAffineQuantizer(**self.wq_params)
+        self.aqtizer = UniformAffineQuantizer(**self.aq_params)
+        self.split = 0
+        self.act_func = StraightThrough()
+        self.ignore_recon = False
+        self.extra_repr = layer.extra_repr
+        self._packed = None  # (key, packed weights)
+
+    # -- quantizer state as the engine sees it ------------------------------------------------
+    def weight_quant_state(self):
+        """(delta, zero_point, alpha|None) of the weight quantizer, initialising it lazily exactly
+        like `self.wqtizer(self.w)` would (reference :330-333)."""
+        q = self.wqtizer
+        if isinstance(q, UniformAffineQuantizer):
+            if not q.init:
+                q.delta, q.zero_point = q._init_quantization_param(self.w.data, q.channel_wise)
+                q.init = True
+            return q.delta.detach(), q.zero_point.detach(), None
+        return q.delta.detach(), q.zero_point.detach(), q.alpha.detach()  # AdaRoundQuantizer (hard rounding)
+
+    def _pack(self, mode: str):
+        key = (mode, self.w.data_ptr(), id(self.wqtizer), getattr(self.wqtizer, "_version_", 0))
+        if self._packed is not None and self._packed[0] == key:
+            return self._packed[1]
+        dev = self.w.device
+        b = None if self.b is None else (self.b if mode != "fp" else self.original_b.to(dev)).detach().float().contiguous()
+        if mode == "fp":
+            pk = ops.pack_w_f16(self.original_w.to(dev).float().contiguous(), b)
+        else:
+            d, z, a = self.weight_quant_state()
+            w = self.w.detach().float().contiguous()
+            a = None if a is None else a.float().contiguous()
+            pk = ops.pack_w4(w, d, z, a, b) if mode == "w4a8" else ops.pack_w_f16(w, b, d, z, a, self.wqtizer.level)
+        self._packed = (key, pk)
+        return pk
+
+    def forward(self, x: torch.Tensor, split: int = 0) -> torch.Tensor:
+        if split != 0 and self.split == 0:
+            self.split = split  # QDIFF split bookkeeping only: shortcuts are never QuantLayers
+        if not x.is_cuda:
+            raise TfmqError("QuantLayer.forward: CPU tensor (the HIP kernels are the only implementation)")
+        quant_act = self.use_aq and not self.disable_aq
+        mode = "fp" if not self.use_wq else ("w4a8" if quant_act else "w4")
+        x = x.float()
+        if quant_act and not self.use_wq:
+            x = self.aqtizer(x)  # act-only fake quant then FP weights (never used by the drivers)
+        if self.kind == "conv2d":
+            xn = ops.nchw_to_nhwc(x.contiguous())
+            ph, pw_ = self.fwd_kwargs["padding"]
+            stride = self.fwd_kwargs["stride"][0]
+            pad = (ph, pw_, ph, pw_)
+            shape_out = None
+        else:
+            shape_out = x.shape[:-1]
+            xn = x.reshape(-1, 1, 1, x.shape[-1]).contiguous()
+            stride, pad = 1, (0, 0, 0, 0)
+        pk = self._pack(mode)
+        if mode == "w4a8":
+            if not self.aqtizer.init:
+                self.aqtizer(xn)  # lazy init on this tensor (mse / minmax), reference :211-221
+            elif self.aqtizer.running_stat:
+                self.aqtizer.act_momentum_update(xn)
+            zp = self.aqtizer.zero_point
+            zp = zp.detach() if torch.is_tensor(zp) else torch.tensor(float(zp), device=x.device)
+            qt = torch.stack([self.aqtizer.delta.detach().reshape(()), zp.reshape(())]).reshape(1, 1, 2).contiguous()
+            sel = ops.qsel(qt)
+            y = ops.conv2d_w4a8(ops.quantize_act(xn, sel), pk, sel, stride=stride, pad=pad)
+        else:
+            y = ops.conv2d_f16(xn, pk, stride=stride, pad=pad)
+        y = ops.nhwc_to_nchw(y) if self.kind == "conv2d" else y.reshape(tuple(shape_out) + (y.shape[-1],))
+        return self.act_func(y)
+
+    def set_quant_state(self, use_wq: bool = False, use_aq: bool = False) -> None:
+        self.use_wq = use_wq if not self.ignore_recon else False
+        self.use_aq = use_aq if not self.ignore_recon else False
+
+    def set_running_stat(self, running_stat: bool) -> None:
+        self.aqtizer.running_stat = running_stat

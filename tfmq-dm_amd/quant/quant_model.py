@@ -1,0 +1,244 @@
+"""QuantModel (reference quant/quant_model.py): module-tree rewrite + lowering to the HIP engine.
+
+Same constructor, state toggles and state-dict layout as the reference.  `forward` does not walk
+the module tree: it lowers the tree once into a `DdimUNetEngine` plan (re-lowered only when the
+quantisation state changes) and runs that on the device.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional
+
+import torch
+import torch.nn as nn
+
+from tfmq_dm_amd import ops
+from tfmq_dm_amd._lib import TfmqError
+from .adaptive_rounding import AdaRoundQuantizer
+from .quant_block import (BaseQuantBlock, QuantAttentionBlock, QuantAttnBlock, QuantBasicTransformerBlock, QuantQKMatMul,
+                          QuantResBlock, QuantResnetBlock, QuantSMVMatMul, QuantTemporalInformationBlock,
+                          QuantTemporalInformationBlockDDIM, b2qb)
+from .quant_layer import QMODE, QuantLayer, StraightThrough, UniformAffineQuantizer
+
+
+class QuantModel(nn.Module):
+
+    def __init__(self, model: nn.Module, wq_params: dict = {}, aq_params: dict = {}, cali: bool = True, **kwargs) -> None:
+        super().__init__()
+        self.model = model
+        self.softmax_a_bit = kwargs.get("softmax_a_bit", 8)
+        self.in_channels = model.in_channels
+        if hasattr(model, "image_size"):
+            self.image_size = model.image_size
+        self.B = b2qb(aq_params["leaf_param"])
+        self.quant_module(self.model, wq_params, aq_params, aq_mode=kwargs.get("aq_mode", [QMODE.NORMAL.value]), prev_name=None)
+        self.quant_block(self.model, wq_params, aq_params)
+        if cali:
+            self.get_tib(self.model, wq_params, aq_params)
+        self._plan = None          # current (engine, act_names, qtable)
+        self._plans = {}           # state key -> plan (FP / weight-only / w4a8 plans coexist during calibration)
+        self._act_table = None     # [G, n_q, 2] FSC table installed by set_act_table()
+        self._act_step = None
+
+    # ------------------------------------------------------------------ tree rewrite (reference :31-84)
+    def get_tib(self, module: nn.Module, wq_params: dict = {}, aq_params: dict = {}):
+        for name, child in module.named_children():
+            if name == "temb":
+                self.tib = QuantTemporalInformationBlockDDIM(child, aq_params, self.model.ch)
+            elif name == "time_embed":
+                self.tib = QuantTemporalInformationBlock(child, aq_params, self.model.model_channels, None)
+            elif isinstance(child, QuantResBlock):
+                self.tib.add_emb_layer(child.emb_layers)
+            elif isinstance(child, QuantResnetBlock):
+                self.tib.add_temb_proj(child.temb_proj)
+            else:
+                self.get_tib(child, wq_params, aq_params)
+
+    def quant_module(self, module: nn.Module, wq_params: dict = {}, aq_params: dict = {},
+                     aq_mode: List[int] = [QMODE.NORMAL.value], prev_name: str = None) -> None:
+        """Every Conv2d / Linear becomes a QuantLayer except shortcut / skip convs, down-sample
+        convs and `op` (reference :57-58, "refer to PTQD"); temb / emb projections are `quant_emb`."""
+        for name, child in module.named_children():
+            quantisable = isinstance(child, (nn.Conv2d, nn.Linear)) and not isinstance(child, nn.Conv1d)
+            excluded = ("skip" in name or "op" in name or "shortcut" in name or (prev_name == "downsample" and name == "conv"))
+            if quantisable and not excluded:
+                is_emb = (prev_name is not None and "emb_layers" in prev_name and "1" in name) or "temb_proj" in name
+                setattr(module, name, QuantLayer(child, dict(wq_params), dict(aq_params), aq_mode=aq_mode, quant_emb=bool(is_emb)))
+            elif isinstance(child, StraightThrough):
+                continue
+            else:
+                self.quant_module(child, wq_params, aq_params, aq_mode=aq_mode, prev_name=name)
+
+    def quant_block(self, module: nn.Module, wq_params: dict = {}, aq_params: dict = {}) -> None:
+        for name, child in module.named_children():
+            cls = self.B.get(child.__class__.__name__)
+            if cls is None:
+                self.quant_block(child, wq_params, aq_params)
+            elif cls in (QuantBasicTransformerBlock, QuantAttnBlock):
+                setattr(module, name, cls(child, aq_params, softmax_a_bit=self.softmax_a_bit))
+            elif cls in (QuantResnetBlock, QuantAttentionBlock, QuantResBlock):
+                setattr(module, name, cls(child, aq_params))
+            elif cls is QuantSMVMatMul:
+                setattr(module, name, cls(aq_params, softmax_a_bit=self.softmax_a_bit))
+            elif cls is QuantQKMatMul:
+                setattr(module, name, cls(aq_params))
+
+    # ------------------------------------------------------------------ state toggles
+    def quant_layers(self) -> List[QuantLayer]:
+        return [m for m in self.model.modules() if isinstance(m, QuantLayer)]
+
+    def named_quant_layers(self):
+        return [(n, m) for n, m in self.model.named_modules() if isinstance(m, QuantLayer)]
+
+    def set_quant_state(self, use_wq: bool = False, use_aq: bool = False) -> None:
+        for m in self.model.modules():
+            if isinstance(m, (BaseQuantBlock, QuantLayer)):
+                m.set_quant_state(use_wq=use_wq, use_aq=use_aq)
+
+    def disable_out_quantization(self) -> None:
+        """First / last layers (reference :103-120): [0], [2], [-1] stay FP and leave reconstruction;
+        [1], [3] keep 4-bit weights but FP activations."""
+        m = self.quant_layers()
+        for i in (0, 2, -1):
+            m[i].use_wq = False
+            m[i].disable_aq = True
+            m[i].ignore_recon = True
+        m[1].disable_aq = True
+        m[3].disable_aq = True
+
+    def set_grad_ckpt(self, grad_ckpt: bool) -> None:
+        for module in self.model.modules():
+            if hasattr(module, "checkpoint") and module.__class__.__name__ in ("QuantBasicTransformerBlock", "BasicTransformerBlock"):
+                module.checkpoint = grad_ckpt
+
+    def synchorize_activation_statistics(self):
+        """all-average of every initialised activation delta (reference :127-132; zero-points are not
+        synchronised there either)."""
+        import linklink.dist_helper as dist
+        for module in self.modules():
+            if isinstance(module, QuantLayer) and module.aqtizer.delta is not None:
+                dist.allaverage(module.aqtizer.delta)
+
+    def set_running_stat(self, running_stat: bool = False) -> None:
+        for m in self.model.modules():
+            if isinstance(m, QuantAttnBlock):
+                for q in (m.aqtizer_q, m.aqtizer_k, m.aqtizer_v, m.aqtizer_w):
+                    q.running_stat = running_stat
+            elif isinstance(m, QuantLayer):
+                m.set_running_stat(running_stat)
+
+    # ------------------------------------------------------------------ lowering
+    def _state_key(self):
+        key = []
+        for n, l in self.named_quant_layers():
+            key.append((n, l.use_wq, l.use_aq and not l.disable_aq, id(l.wqtizer), getattr(l.wqtizer, "_version_", 0),
+                        l.w.data_ptr(), l.w._version))
+        return tuple(key)
+
+    def invalidate(self):
+        self._plans.clear()
+        self._plan = None
+
+    def act_layer_names(self) -> List[str]:
+        return [n for n, l in self.named_quant_layers() if l.use_aq and not l.disable_aq]
+
+    def _lower(self, device):
+        from tfmq_dm_amd.engine import DdimUNetEngine, LayerQ
+        if self.model.__class__.__name__ != "Model" or not hasattr(self.model, "temb"):
+            raise TfmqError(f"QuantModel: no engine plan for {self.model.__class__.__name__} yet "
+                            "(DDPM UNet is supported; LDM/SD UNetModel is the next row)")
+        sd, wq = {}, {}
+        act_names = self.act_layer_names()
+        qid = {n: i for i, n in enumerate(act_names)}
+        for n, mod in self.model.named_modules():
+            if isinstance(mod, QuantLayer):
+                if mod.use_wq:
+                    d, z, a = mod.weight_quant_state()
+                    sd[n + ".weight"] = mod.w.detach()
+                    if mod.b is not None:
+                        sd[n + ".bias"] = mod.b.detach()
+                    wq[n] = LayerQ(d, z, a, qid.get(n))
+                else:
+                    sd[n + ".weight"] = mod.original_w
+                    if mod.original_b is not None:
+                        sd[n + ".bias"] = mod.original_b
+            elif isinstance(mod, (nn.Conv2d, nn.Linear, nn.GroupNorm)):
+                for pn, p in mod.named_parameters(recurse=False):
+                    sd[f"{n}.{pn}"] = p.detach()
+        eng = DdimUNetEngine(sd, self.model.engine_cfg(), device)
+        n_steps = 1 if self._act_table is None else self._act_table.shape[0]
+        qtable = torch.zeros(n_steps, max(len(act_names), 1), 2, dtype=torch.float32, device=device)
+        if self._act_step is None:
+            self._act_step = torch.zeros(1, dtype=torch.int32, device=device)
+        eng.prepare(wq, qtable if act_names else None, self._act_step if act_names else None)
+        self._plan = (eng, act_names, qtable)
+        self._sync_act_params()
+        return eng
+
+    def _sync_act_params(self):
+        """Module quantizer state (aqtizer.delta / zero_point) -> row(s) of the device table."""
+        eng, act_names, qtable = self._plan
+        if not act_names:
+            return
+        if self._act_table is not None:
+            qtable.copy_(self._act_table)
+            return
+        layers = dict(self.named_quant_layers())
+        rows = []
+        for n in act_names:
+            q = layers[n].aqtizer
+            if q.delta is None:
+                rows.append([0.0, 0.0])      # not initialised yet: calibration mode fills it
+            else:
+                zp = q.zero_point
+                rows.append([float(q.delta), float(zp)])
+        qtable[0].copy_(torch.tensor(rows, dtype=torch.float32))
+
+    def engine(self, device=None):
+        device = device or next(self.model.parameters()).device
+        key = (self._state_key(), str(torch.device(device)))
+        plan = self._plans.get(key)
+        if plan is None:
+            if len(self._plans) >= 4:
+                self._plans.clear()
+            self._lower(device)
+            self._plans[key] = self._plan
+        else:
+            self._plan = plan
+        return self._plan[0]
+
+    def set_act_table(self, cali_ckpt: Optional[dict]):
+        """Install the whole Finite-Set-Calibration table {act_0..act_{G-1}} on the device, replacing
+        the per-step `load_state_dict(act_k)` of the reference's sampling loop."""
+        if cali_ckpt is None:
+            self._act_table = None
+        else:
+            names = self.act_layer_names()
+            G = len([k for k in cali_ckpt if k.startswith("act_")])
+            tab = torch.zeros(G, len(names), 2)
+            for g in range(G):
+                act = cali_ckpt[f"act_{g}"]
+                for i, n in enumerate(names):
+                    tab[g, i, 0] = float(act[f"model.{n}.aqtizer.delta"])
+                    tab[g, i, 1] = float(act[f"model.{n}.aqtizer.zero_point"])
+            self._act_table = tab.to(next(self.model.parameters()).device)
+        self.invalidate()
+
+    def load_state_dict(self, state_dict, strict: bool = True):
+        """`model.load_state_dict(act_k, strict=False)` (ddim/functions/denoising.py:26-29) keeps
+        working: the module state is updated as in torch and the device table row is refreshed."""
+        out = super().load_state_dict(state_dict, strict=strict)
+        if self._plan is not None and self._act_table is None and any("aqtizer" in k for k in state_dict):
+            self._sync_act_params()
+        if any((".w" in k or "alpha" in k or "wqtizer" in k) for k in state_dict):
+            self.invalidate()
+        return out
+
+    def forward(self, x: torch.Tensor, timestep=None, context: torch.Tensor = None) -> torch.Tensor:
+        if context is not None:
+            raise TfmqError("QuantModel.forward: context-conditioned (LDM/SD) models are the next row")
+        if not x.is_cuda:
+            raise TfmqError("QuantModel.forward: CPU tensor (the HIP kernels are the only implementation)")
+        eng = self.engine(x.device)
+        t = timestep if torch.is_tensor(timestep) else torch.full((x.shape[0],), float(timestep), device=x.device)
+        eps = eng.forward(ops.nchw_to_nhwc(x.float().contiguous()), t.float().contiguous().to(x.device))
+        return ops.nhwc_to_nchw(eps)

@@ -1,0 +1,170 @@
+"""layer_ / block_ / tib_reconstruction with the reference's signatures
+(quant/reconstruction.py:13-29,86-102,212-226), executed by engine.recon units on the device.
+
+Per unit: wrap the unit's weight quantizers in AdaRoundQuantizer (soft targets), cache the unit's
+inputs / FP targets for the calibration set (save_inout), run `iters` Adam iterations on random
+mini-batches -- same RNG calls as the reference (`torch.randperm(n)[:batch_size]` per iteration) -- with
+one SUM all-reduce of the flattened gradient buffer per iteration when `multi_gpu`, then switch the
+quantizers to hard rounding.
+"""
+from __future__ import annotations
+
+import logging
+from typing import Tuple
+
+import torch
+
+from tfmq_dm_amd import ops
+from tfmq_dm_amd._lib import TfmqError
+from tfmq_dm_amd.engine import recon as R
+from .adaptive_rounding import AdaRoundQuantizer, RMODE
+from .data_utill import save_inout
+from .quant_block import BaseQuantBlock, QuantAttnBlock, QuantResnetBlock, QuantTemporalInformationBlockDDIM
+from .quant_layer import QuantLayer, StraightThrough
+from .reconstruction_util import RLOSS, LossFunc, LossFuncTimeEmbedding
+
+logger = logging.getLogger(__name__)
+
+
+def _dist_kw(multi_gpu: bool):
+    if not multi_gpu:
+        return dict(world_size=1, allreduce=None)
+    import linklink as link
+    return dict(world_size=link.get_world_size(), allreduce=link.allreduce)
+
+
+def _to_adaround(layer: QuantLayer) -> AdaRoundQuantizer:
+    """module.wqtizer = AdaRoundQuantizer(uaqtizer=..., w=original_w) with soft targets on."""
+    d, z, _ = layer.weight_quant_state()
+    if not isinstance(layer.wqtizer, AdaRoundQuantizer):
+        layer.wqtizer = AdaRoundQuantizer(uaqtizer=layer.wqtizer, rmode=RMODE.LEARNED_HARD_SIGMOID,
+                                          w=layer.original_w.data.to(layer.w.device))
+    layer.wqtizer.soft_tgt = True
+    return layer.wqtizer
+
+
+def _ada_layer(layer: QuantLayer) -> R.AdaLayer:
+    q = _to_adaround(layer)
+    return R.AdaLayer(layer.w.data, q.delta, q.zero_point, None if layer.b is None else layer.b.data, q.level, alpha=q.alpha.data)
+
+
+def _commit(layer: QuantLayer, ada: R.AdaLayer):
+    """Write the learned alpha back into the module (state-dict key `...wqtizer.alpha`) and harden."""
+    q = layer.wqtizer
+    q.alpha.data.copy_(ada.alpha)
+    q.soft_tgt = False
+    q._version_ += 1
+
+
+def _run(unit: R._Unit, n: int, batch_size: int, iters: int, loss_func: LossFunc, device, rank0=True):
+    for _ in range(iters):
+        idx = torch.randperm(n)[:batch_size].to(device)       # same host RNG stream as the reference
+        b, active = loss_func.tick()
+        rec, rl = unit.iterate(idx)
+        if loss_func.count % 2000 == 0:
+            tot, r, q = unit.losses(rec, rl)
+            loss_func.log(tot, r, q, b, rank0)
+
+
+def layer_reconstruction(model, layer: QuantLayer, cali_data: Tuple[torch.Tensor], batch_size: int = 128,
+                         iters: int = 20000, w: float = 0.001, opt_mode: RLOSS = RLOSS.MSE, asym: bool = False,
+                         include_act_func: bool = True, b_range: tuple = (20, 2), warmup: float = 0.0,
+                         use_aq: bool = False, lr: float = 4e-5, p: float = 2.0, multi_gpu: bool = False,
+                         keep_gpu=True) -> None:
+    if use_aq:
+        raise NotImplementedError("delta-learning reconstruction (use_aq=True) is never requested by the drivers (SURVEY §8f-3)")
+    model.set_quant_state(use_wq=False, use_aq=False)
+    layer.set_quant_state(use_wq=True, use_aq=use_aq)
+    ada = _ada_layer(layer)
+    loss_func = LossFunc(o=layer, round_loss=RLOSS.RELAXATION, w=w, max_count=iters, rec_loss=opt_mode, b_range=b_range,
+                         decay_start=0.0, warmup=warmup, p=p)
+    cached_inputs, cached_outputs = save_inout(model, layer, cali_data, asym, use_aq, batch_size, keep_gpu)
+    ph, pw = layer.fwd_kwargs.get("padding", (0, 0))
+    unit = R.LayerUnit(ada, cached_inputs[0], cached_outputs, pad=(ph, pw, ph, pw), iters=iters, w=w, warmup=warmup,
+                       **_dist_kw(multi_gpu))
+    _run(unit, cached_inputs[0].size(0), batch_size, iters, loss_func, cached_outputs.device)
+    _commit(layer, ada)
+    model.invalidate()
+
+
+def block_reconstruction(model, block: BaseQuantBlock, cali_data: torch.Tensor, batch_size: int = 32,
+                         iters: int = 20000, w: float = 0.01, opt_mode: RLOSS = RLOSS.MSE, asym: bool = False,
+                         include_act_func: bool = True, b_range: tuple = (20, 2), warmup: float = 0.0,
+                         use_aq: bool = False, lr: float = 4e-5, p: float = 2.0, multi_gpu: bool = True,
+                         keep_gpu=True) -> None:
+    if use_aq:
+        raise NotImplementedError("delta-learning reconstruction (use_aq=True) is never requested by the drivers (SURVEY §8f-3)")
+    model.set_quant_state(use_wq=False, use_aq=False)
+    block.set_quant_state(use_wq=True, use_aq=use_aq)
+    loss_func = LossFunc(o=block, round_loss=RLOSS.RELAXATION, w=w, max_count=iters, rec_loss=opt_mode, b_range=b_range,
+                         decay_start=0.0, warmup=warmup, p=p)
+    dev = next(block.parameters()).device
+    kw = dict(iters=iters, w=w, warmup=warmup, **_dist_kw(multi_gpu))
+    if isinstance(block, QuantResnetBlock):
+        adas = {"conv1": _ada_layer(block.conv1), "conv2": _ada_layer(block.conv2)}   # temb_proj is quant_emb: excluded
+        cached_inputs, cached_outputs = save_inout(model, block, cali_data, asym, use_aq, batch_size, keep_gpu)
+        x, temb = cached_inputs
+        # frozen temb projection under the block's quant state (hard-rounded by the TIB unit)
+        tp = block.temb_proj
+        d, z, a = tp.weight_quant_state()
+        pk = ops.pack_w4(tp.w.data.float().contiguous(), d, z, None if a is None else a.contiguous(), tp.b.data)
+        proj = ops.linear_small_w4(temb.contiguous(), pk, ops.qsel(None), silu_in=True)
+        sc = None
+        if hasattr(block, "nin_shortcut"):
+            ns = block.nin_shortcut
+            sc = (ns.weight.data.reshape(ns.weight.shape[0], -1).float().contiguous(), ns.bias.data.float().contiguous())
+        unit = R.ResnetUnit(adas["conv1"], adas["conv2"],
+                            (block.norm1.weight.data.float(), block.norm1.bias.data.float()),
+                            (block.norm2.weight.data.float(), block.norm2.bias.data.float()), sc, x, proj, cached_outputs, **kw)
+        layers = [(block.conv1, adas["conv1"]), (block.conv2, adas["conv2"])]
+    elif isinstance(block, QuantAttnBlock):
+        names = ("q", "k", "v", "proj_out")
+        adas = {n: _ada_layer(getattr(block, n)) for n in names}
+        cached_inputs, cached_outputs = save_inout(model, block, cali_data, asym, use_aq, batch_size, keep_gpu)
+        unit = R.AttnUnit(adas["q"], adas["k"], adas["v"], adas["proj_out"],
+                          (block.norm.weight.data.float(), block.norm.bias.data.float()), cached_inputs[0], cached_outputs, **kw)
+        layers = [(getattr(block, n), adas[n]) for n in names]
+    else:
+        raise TfmqError(f"block_reconstruction: no reconstruction unit for {type(block).__name__} yet")
+    _run(unit, cached_inputs[0].size(0), batch_size, iters, loss_func, dev)
+    for layer, ada in layers:
+        _commit(layer, ada)
+    model.invalidate()
+
+
+def tib_reconstruction(block: BaseQuantBlock, cali_data: torch.Tensor, batch_size: int = 32, iters: int = 20000,
+                       w: float = 0.01, opt_mode: RLOSS = RLOSS.MSE, asym: bool = False, include_act_func: bool = True,
+                       b_range: tuple = (20, 2), warmup: float = 0.0, use_aq: bool = False, lr: float = 4e-5,
+                       p: float = 2.0, multi_gpu: bool = True, keep_gpu=True) -> None:
+    """Temporal-information-aware reconstruction (TIAR).  Gradients of FP-kept layers (temb.dense.0:
+    alpha.grad is None in the reference, which then crashes in its multi-GPU loop) are
+    simply absent from the all-reduced buffer."""
+    if use_aq:
+        raise NotImplementedError("delta-learning reconstruction (use_aq=True) is never requested by the drivers")
+    if not isinstance(block, QuantTemporalInformationBlockDDIM):
+        raise TfmqError("tib_reconstruction: only the DDPM-UNet TIB is built so far")
+    assert opt_mode == RLOSS.MSE
+    from tfmq_dm_amd.engine.tib import tib_forward_ddim
+    dev = next(block.parameters()).device
+    ts = cali_data[1].to(dev).float().contiguous()
+    # FP targets (save_inout(block, block, ...): the TIB is its own model there)
+    block.set_quant_state(False, False)
+    targets = list(tib_forward_ddim(block, ts))
+    block.set_quant_state(use_wq=True, use_aq=use_aq)
+    d0, d1 = block.temb.dense[0], block.temb.dense[1]
+    # every QuantLayer of the TIB is wrapped (state-dict parity), dense.0 stays FP (ignore_recon)
+    _to_adaround(d0)
+    ada1 = _ada_layer(d1)
+    adap = [_ada_layer(pj) for pj in block.temb_projs]
+    emb = ops.timestep_embedding(ts, block.ch)
+    h0 = ops.linear_small_f32(emb, d0.original_w.to(dev).float().contiguous(),
+                              None if d0.original_b is None else d0.original_b.to(dev).float().contiguous())
+    s0 = ops.silu(h0)
+    loss_func = LossFuncTimeEmbedding(o=block, round_loss=RLOSS.RELAXATION, w=w, max_count=iters, rec_loss=opt_mode,
+                                      b_range=b_range, decay_start=0.0, warmup=warmup, p=p)
+    unit = R.TibUnit(ada1, adap, s0, targets, iters=iters, w=w, warmup=warmup, **_dist_kw(multi_gpu))
+    _run(unit, ts.size(0), batch_size, iters, loss_func, dev)
+    d0.wqtizer.soft_tgt = False
+    _commit(d1, ada1)
+    for pj, a in zip(block.temb_projs, adap):
+        _commit(pj, a)
