@@ -13,11 +13,13 @@ from .ddim_unet import DdimUNetEngine, LayerQ
 def _collect(block: nn.Module, prefix: str = "blk"):
     """Module tree of one block -> (sd, wq) in the engine's naming, honouring each QuantLayer's
     current use_wq / use_aq / disable_aq flags; per-layer activation parameters go to a 1-row table."""
-    from ..quant.quant_layer import QuantLayer
+    # duck-typed: the mirror may be imported as `quant.*` (drop-in) or `tfmq_dm_amd.quant.*`
+    def is_quant_layer(m):
+        return hasattr(m, "wqtizer") and hasattr(m, "original_w") and hasattr(m, "weight_quant_state")
     sd, wq, rows = {}, {}, []
     for n, mod in block.named_modules():
         full = f"{prefix}.{n}" if n else prefix
-        if isinstance(mod, QuantLayer):
+        if is_quant_layer(mod):
             if mod.use_wq:
                 d, z, a = mod.weight_quant_state()
                 sd[full + ".weight"] = mod.w.detach()
