@@ -1,0 +1,70 @@
+"""N>1 path on CPU (gloo, world_size 2): calibration-set sharding (reference calibration.py:269-282,
+fixture F10), the SUM all-reduce of a unit's flattened gradient buffer and the all-average of the
+activation deltas (linklink shim), checked against a single-process emulation of the same shards."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_shard_for_rank_matches_reference_indices(golden):
+    sys.path.insert(0, os.path.join(ROOT, "tfmq-dm_amd"))
+    from quant.calibration import shard_for_rank
+    g = golden("f10_shards")
+    for I, W in ((256, 8), (512, 8), (256, 4), (16, 2)):
+        data = torch.arange(I * 3)
+        for r in range(W):
+            (sh,) = shard_for_rank((data,), I, W, r)
+            assert sh.tolist() == list(g[f"I{I}_W{W}_r{r}"])
+        # the shards of all ranks partition every timestep group
+        allidx = torch.cat([shard_for_rank((data,), I, W, r)[0] for r in range(W)])
+        assert sorted(allidx.tolist()) == list(range(I * 3))
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tfmq-dm_amd"))
+    import linklink as link
+    import linklink.dist_helper as dh
+    from quant.calibration import shard_for_rank
+    link.init_process_group(backend="gloo", init_method=f"tcp://127.0.0.1:{port}", world_size=world, rank=rank)
+    assert link.get_world_size() == world and link.get_rank() == rank
+    g = torch.Generator().manual_seed(0)
+    data = torch.randn(3 * 16, 5, generator=g)            # 3 timestep groups of 16 samples
+    (mine,) = shard_for_rank((data,), 16, world, rank)
+    # per-rank "gradient" of two tensors, flattened into one buffer, ONE all-reduce (K16)
+    w1, w2 = torch.randn(5, 4, generator=g), torch.randn(5, 3, generator=g)
+    g1, g2 = mine.t() @ (mine @ w1), mine.t() @ (mine @ w2)
+    flat = torch.cat([g1.reshape(-1), g2.reshape(-1)])
+    link.allreduce(flat)
+    # activation delta all-average
+    delta = torch.tensor([float(rank + 1)])
+    dh.allaverage(delta)
+    torch.save({"flat": flat, "delta": delta, "n": mine.shape[0]}, os.path.join(out_dir, f"r{rank}.pt"))
+    link.barrier()
+
+
+def test_gloo_world2_allreduce_matches_single_process_emulation(tmp_path):
+    world, port = 2, 29000 + (os.getpid() % 2000)
+    mp.start_processes(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True, start_method="spawn")
+    sys.path.insert(0, os.path.join(ROOT, "tfmq-dm_amd"))
+    from quant.calibration import shard_for_rank
+    g = torch.Generator().manual_seed(0)
+    data = torch.randn(3 * 16, 5, generator=g)
+    w1, w2 = torch.randn(5, 4, generator=g), torch.randn(5, 3, generator=g)
+    ref = torch.zeros(5 * 4 + 5 * 3)
+    for r in range(world):   # single-process emulation: loop over the same shards, sum the gradients
+        (sh,) = shard_for_rank((data,), 16, world, r)
+        ref += torch.cat([(sh.t() @ (sh @ w1)).reshape(-1), (sh.t() @ (sh @ w2)).reshape(-1)])
+    for r in range(world):
+        res = torch.load(os.path.join(str(tmp_path), f"r{r}.pt"))
+        assert res["n"] == 24
+        np.testing.assert_allclose(res["flat"].numpy(), ref.numpy(), rtol=1e-5, atol=1e-5)
+        assert abs(float(res["delta"]) - 1.5) < 1e-6       # (1 + 2) / 2
