@@ -134,6 +134,10 @@ typedef struct tfmq_conv_desc {
   float* y;                      /* fp32 NHWC [B][Ho][Wo][ldy]  (written at channel offset y_coff) */
   int32_t ldy, y_coff;           /* output row stride in floats (>= Cout) and channel offset: lets q/k/v or a
                                     concat target share one buffer */
+  float* stats;                  /* optional [ceil(M/stats_seg)][Cout][2]: per-channel {sum, sum of squares} of every
+                                    stats_seg consecutive output pixels, for the GroupNorm that consumes y (K8) */
+  int32_t stats_seg;             /* 16, 32, 64 or 128; must divide Ho*Wo */
+  int32_t reserved_;
 } tfmq_conv_desc;
 int tfmq_conv2d_w4a8(tfmq_handle h, const tfmq_conv_desc* d, void* stream);
 int tfmq_conv2d_f16(tfmq_handle h, const tfmq_conv_desc* d, void* stream);
@@ -169,6 +173,11 @@ typedef struct tfmq_gn_desc {
   float* xcat_or_null;     /* optional: also materialise the fp32 concat (input of the FP nin_shortcut) */
 } tfmq_gn_desc;
 int tfmq_groupnorm(tfmq_handle h, const tfmq_gn_desc* d, void* stream);
+/* same result when the producing conv(s) already emitted the statistics (tfmq_conv_desc.stats, segment size
+ * `seg`): a tiny finalize kernel + ONE coalesced elementwise pass (4 B read, 1 B written per element).
+ * stats2 pairs with d->x2 (channel concat).  ws: 2 * B * (C1+C2) floats. */
+int tfmq_groupnorm_from_stats(tfmq_handle h, const tfmq_gn_desc* d, const float* stats1, const float* stats2, int seg,
+                              float* ws, void* stream);
 
 /* ---- K10: attention core on un-quantised q,k,v (QuantAttnBlock.forward quant_block.py:483-500:
  * bmm, *c^-1/2, softmax, bmm; attention quantizers are never enabled) ---- */

@@ -37,6 +37,7 @@ class ConvDesc(C.Structure):
         ("rowadd", c_void_p), ("rowadd_step", c_void_p), ("rowadd_ld", C.c_int32), ("rowadd_step_stride", C.c_int32),
         ("residual", c_void_p), ("y", c_void_p),
         ("ldy", C.c_int32), ("y_coff", C.c_int32),
+        ("stats", c_void_p), ("stats_seg", C.c_int32), ("reserved_", C.c_int32),
     ]
 
 
@@ -75,6 +76,7 @@ _SIGS = {
     "tfmq_linear_small_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "tfmq_linear_small_w4": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, QSel, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "tfmq_groupnorm": (c_int, [c_void_p, C.POINTER(GnDesc), c_void_p]),
+    "tfmq_groupnorm_from_stats": (c_int, [c_void_p, C.POINTER(GnDesc), c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     "tfmq_attention": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p, QSel,
                                c_int, c_int, c_int, c_int, c_int, c_float, c_void_p]),
     "tfmq_ddim_update": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p]),

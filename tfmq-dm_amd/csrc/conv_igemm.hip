@@ -50,10 +50,16 @@ __global__ __launch_bounds__(256) void k_conv_igemm(ConvP p) {
   static_assert(WAVES_M * WAVES_N == 4, "4 waves");
   static_assert(BM * SLOTS % 256 == 0, "A items");
 
-  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * (BM + BN) * 64 + BM * 4];
+  // LDS: main loop 2 x (A tile + B tile); the epilogue re-uses the same bytes for its output staging
+  // tile + statistics partials; the per-row activation sums live behind both.
+  constexpr int EPI_PR = (BN == 128) ? 64 : BM;
+  constexpr int LDS_MAIN = 2 * (BM + BN) * 64;
+  constexpr int LDS_EPI = EPI_PR * (BN + 4) * 4 + (256 / (BN / 4)) * BN * 8 + BN * 8;
+  constexpr int LDS_BODY = LDS_MAIN > LDS_EPI ? LDS_MAIN : LDS_EPI;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BODY + BM * 4];
   auto ldsA = [&](int buf) -> unsigned char* { return lds + buf * ((BM + BN) * 64); };
   auto ldsB = [&](int buf) -> unsigned char* { return lds + buf * ((BM + BN) * 64) + BM * 64; };
-  int* ldsS = reinterpret_cast<int*>(lds + 2 * (BM + BN) * 64);
+  int* ldsS = reinterpret_cast<int*>(lds + LDS_BODY);
 
   const tfmq_conv_desc& d = p.d;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -254,39 +260,144 @@ __global__ __launch_bounds__(256) void k_conv_igemm(ConvP p) {
     __syncthreads();
   }
 
-  // ---- epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+  // ---- epilogue.  The accumulators (C/D layout of the 32x32 MFMA: col = lane&31,
+  // row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)) are dequantised in registers, staged through LDS one
+  // PR-row pass at a time, and leave the CU as whole rows: every lane moves 16 B (float4) of the
+  // temb row, the residual and the output, so the fp32 traffic of the epilogue is fully coalesced
+  // (per-lane 4-byte strided accesses made this phase 2.5x slower than the MFMA loop).  The same
+  // pass produces the per-channel sum / sum-of-squares of every SEG-row segment for the GroupNorm
+  // that consumes this tensor, so that GroupNorm never has to re-read it for statistics.
+  constexpr int PR = (BN == 128) ? 64 : BM;       // rows per pass
+  constexpr int LDO = BN + 4;                      // padded LDS row (floats)
+  constexpr int TPR = BN / 4;                      // threads per output row (float4 each)
+  constexpr int NTR = 256 / TPR;                   // thread-rows
+  constexpr int RPT = PR / NTR;                    // consecutive rows per thread
+  static_assert(RPT >= 1 && RPT <= 16, "rows per thread");
+  float* ldsO = reinterpret_cast<float*>(lds);                      // [PR][LDO]
+  float2* ldsP = reinterpret_cast<float2*>(lds + PR * LDO * 4);     // [NTR][BN] partial (sum, sumsq)
+  float2* ldsG = ldsP + NTR * BN;                                   // [BN] running segment sums
   const int hw = d.Ho * d.Wo;
   const float* rowadd = d.rowadd;
   if (rowadd && d.rowadd_step) rowadd += static_cast<size_t>(*d.rowadd_step) * d.rowadd_step_stride;
+  const bool vec_ok = ((d.Cout | d.ldy | d.y_coff) & 3) == 0 && (!d.rowadd || (d.rowadd_ld & 3) == 0);
+  const int seg = d.stats ? d.stats_seg : 0;
+  const int tr = tid / TPR, c4 = (tid % TPR) * 4;
+  if (seg) {
+    for (int o = tid; o < BN; o += 256) ldsG[o] = make_float2(0.0f, 0.0f);
+  }
+
+  float sc_[WN_TILES], bias_[WN_TILES];
+  int zw_[WN_TILES], corr_[WN_TILES];
 #pragma unroll
   for (int j = 0; j < WN_TILES; ++j) {
     const int n = n0 + (wn * WN_TILES + j) * 32 + (lane & 31);
-    if (n >= d.Cout) continue;
-    float sc = (!INT8 && d.wscale) ? d.wscale[n] : 1.0f, bias = d.bias ? d.bias[n] : 0.0f;
-    int zw = 0, corr = 0;
+    const bool nok = n < d.Cout;
+    sc_[j] = (!INT8 && d.wscale && nok) ? d.wscale[n] : 1.0f;
+    bias_[j] = (d.bias && nok) ? d.bias[n] : 0.0f;
+    zw_[j] = 0;
+    corr_[j] = 0;
     if constexpr (INT8) {
-      const int4 wmv = reinterpret_cast<const int4*>(d.wmeta)[n];
-      zw = wmv.x;
-      corr = (128 - za) * (wmv.y - p.Ktot * zw);
-      sc = aqp.x * d.wscale[n];
+      if (nok) {
+        const int4 wmv = reinterpret_cast<const int4*>(d.wmeta)[n];
+        zw_[j] = wmv.x;
+        corr_[j] = (128 - za) * (wmv.y - p.Ktot * zw_[j]);
+        sc_[j] = aqp.x * d.wscale[n];
+      }
     }
+  }
+
+  for (int pass = 0; pass < BM / PR; ++pass) {
+    __syncthreads();  // previous pass fully consumed (also orders ldsS / main-loop LDS reads before the overwrite)
+    // phase 1: registers -> LDS
 #pragma unroll
     for (int i = 0; i < WM_TILES; ++i) {
+      const int tile_row0 = (wm * WM_TILES + i) * 32;
+      if (tile_row0 / PR != pass) continue;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = (wm * WM_TILES + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        const int m = m0 + row;
-        if (m >= p.M) continue;
-        float v;
-        if constexpr (INT8) {
-          const int t = acc[i][j][r] - zw * ldsS[row] + corr;
-          v = sc * static_cast<float>(t) + bias;
-        } else {
-          v = d.wscale ? sc * acc[i][j][r] + bias : acc[i][j][r] + bias;
+      for (int j = 0; j < WN_TILES; ++j) {
+        const int col = (wn * WN_TILES + j) * 32 + (lane & 31);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = tile_row0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+          float v;
+          if constexpr (INT8) {
+            const int t = acc[i][j][r] - zw_[j] * ldsS[row] + corr_[j];
+            v = sc_[j] * static_cast<float>(t) + bias_[j];
+          } else {
+            v = d.wscale ? sc_[j] * acc[i][j][r] + bias_[j] : acc[i][j][r] + bias_[j];
+          }
+          ldsO[(row - pass * PR) * LDO + col] = v;
         }
-        if (d.rowadd) v += rowadd[static_cast<size_t>(m / hw) * d.rowadd_ld + n];
-        if (d.residual) v += d.residual[static_cast<size_t>(m) * d.Cout + n];
-        d.y[static_cast<size_t>(m) * d.ldy + d.y_coff + n] = v;
+      }
+    }
+    __syncthreads();
+    // phase 2: whole rows out, + temb row + residual, + statistics
+    float4 ps = make_float4(0.f, 0.f, 0.f, 0.f), pss = ps;
+#pragma unroll
+    for (int k = 0; k < RPT; ++k) {
+      const int prow = tr * RPT + k;
+      const int m = m0 + pass * PR + prow;
+      const int n = n0 + c4;
+      if (m >= p.M || n >= d.Cout) continue;
+      float4 v = *reinterpret_cast<const float4*>(ldsO + prow * LDO + c4);
+      if (vec_ok) {
+        if (rowadd) {
+          const float4 a = *reinterpret_cast<const float4*>(rowadd + static_cast<size_t>(m / hw) * d.rowadd_ld + n);
+          v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
+        }
+        if (d.residual) {
+          const float4 a = *reinterpret_cast<const float4*>(d.residual + static_cast<size_t>(m) * d.Cout + n);
+          v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
+        }
+        *reinterpret_cast<float4*>(d.y + static_cast<size_t>(m) * d.ldy + d.y_coff + n) = v;
+      } else {
+        float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          if (n + q >= d.Cout) { e[q] = 0.0f; continue; }
+          if (rowadd) e[q] += rowadd[static_cast<size_t>(m / hw) * d.rowadd_ld + n + q];
+          if (d.residual) e[q] += d.residual[static_cast<size_t>(m) * d.Cout + n + q];
+          d.y[static_cast<size_t>(m) * d.ldy + d.y_coff + n + q] = e[q];
+        }
+        v = make_float4(e[0], e[1], e[2], e[3]);
+      }
+      ps.x += v.x; ps.y += v.y; ps.z += v.z; ps.w += v.w;
+      pss.x += v.x * v.x; pss.y += v.y * v.y; pss.z += v.z * v.z; pss.w += v.w * v.w;
+    }
+    if (seg) {
+      float2* pp = ldsP + tr * BN + c4;
+      pp[0] = make_float2(ps.x, pss.x);
+      pp[1] = make_float2(ps.y, pss.y);
+      pp[2] = make_float2(ps.z, pss.z);
+      pp[3] = make_float2(ps.w, pss.w);
+      __syncthreads();
+      // fixed-order reduction over the thread-rows of each segment
+      const int nseg_pass = seg < PR ? PR / seg : 1;
+      const int tr_per_seg = NTR / nseg_pass;
+      for (int o = tid; o < nseg_pass * BN; o += 256) {
+        const int sidx = o / BN, col = o % BN;
+        float2 a = make_float2(0.0f, 0.0f);
+        for (int q = 0; q < tr_per_seg; ++q) {
+          const float2 b = ldsP[(sidx * tr_per_seg + q) * BN + col];
+          a.x += b.x;
+          a.y += b.y;
+        }
+        const int row0 = m0 + pass * PR + sidx * (seg < PR ? seg : PR);
+        const int n = n0 + col;
+        if (seg <= PR) {
+          if (row0 < p.M && n < d.Cout) reinterpret_cast<float2*>(d.stats)[static_cast<size_t>(row0 / seg) * d.Cout + n] = a;
+        } else {  // segment spans several passes: accumulate, write after its last pass
+          float2 g = ldsG[col];
+          g.x += a.x;
+          g.y += a.y;
+          const bool last = ((pass + 1) * PR) % seg == 0;
+          if (last) {
+            const int srow0 = m0 + (pass + 1) * PR - seg;
+            if (srow0 < p.M && n < d.Cout) reinterpret_cast<float2*>(d.stats)[static_cast<size_t>(srow0 / seg) * d.Cout + n] = g;
+            g = make_float2(0.0f, 0.0f);
+          }
+          ldsG[col] = g;
+        }
       }
     }
   }
@@ -300,6 +411,9 @@ static int launch_conv(tfmq_handle h, const tfmq_conv_desc* dd, void* stream) {
   TFMQ_CHECK_ARG(h, d.B > 0 && d.H > 0 && d.W > 0 && d.Cin > 0 && d.Cout > 0 && d.KH > 0 && d.KW > 0 && d.stride > 0,
                  "conv: bad geometry");
   TFMQ_CHECK_ARG(h, d.Ho > 0 && d.Wo > 0 && d.ldy >= d.Cout + d.y_coff, "conv: bad output geometry");
+  TFMQ_CHECK_ARG(h, !d.stats || ((d.stats_seg == 16 || d.stats_seg == 32 || d.stats_seg == 64 || d.stats_seg == 128) &&
+                                 (d.Ho * d.Wo) % d.stats_seg == 0),
+                 "conv: stats_seg must be 16/32/64/128 and divide Ho*Wo");
   ConvP p;
   p.d = d;
   p.M = d.B * d.Ho * d.Wo;

@@ -199,6 +199,131 @@ static void launch_gn(const GnP& p, dim3 grid, hipStream_t st) {
   else hipLaunchKernelGGL((k_groupnorm<V, 0>), grid, dim3(256), 0, st, p);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Split form: the producing conv's epilogue already wrote per-channel {sum, sumsq} of every `seg`
+// output pixels (tfmq_conv_desc.stats).  k_gn_finalize folds them into a per-(image, channel) affine
+// y = A*x + Bb (A = rstd*gamma, Bb = beta - A*mean); k_gn_apply is then a pure, fully coalesced
+// elementwise pass: 4 B read + 1 B written per element, nothing else.
+__global__ __launch_bounds__(256) void k_gn_finalize(const float2* __restrict__ st1, int C1, const float2* __restrict__ st2,
+                                                     int C2, int HW, int seg, int groups, float eps,
+                                                     const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                     float* __restrict__ A, float* __restrict__ Bb) {
+  __shared__ float s_mean[64], s_rstd[64];
+  const int b = blockIdx.x, Cc = C1 + C2, cpg = Cc / groups, nseg = HW / seg;
+  if (threadIdx.x < groups) {
+    const int g = threadIdx.x;
+    double s = 0.0, ss = 0.0;
+    for (int sgi = 0; sgi < nseg; ++sgi) {
+      const size_t row = static_cast<size_t>(b) * nseg + sgi;
+      for (int c = g * cpg; c < (g + 1) * cpg; ++c) {
+        const float2 v = c < C1 ? st1[row * C1 + c] : st2[row * C2 + (c - C1)];
+        s += v.x;
+        ss += v.y;
+      }
+    }
+    const double n = static_cast<double>(HW) * cpg;
+    const double mean = s / n;
+    double var = ss / n - mean * mean;
+    if (var < 0.0) var = 0.0;
+    s_mean[g] = static_cast<float>(mean);
+    s_rstd[g] = static_cast<float>(1.0 / sqrt(var + static_cast<double>(eps)));
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < Cc; c += 256) {
+    const int g = c / cpg;
+    const float a = s_rstd[g] * gamma[c];
+    A[static_cast<size_t>(b) * Cc + c] = a;
+    Bb[static_cast<size_t>(b) * Cc + c] = beta[c] - a * s_mean[g];
+  }
+}
+
+template <int V>
+__global__ __launch_bounds__(256) void k_gn_apply(tfmq_gn_desc d, const float* __restrict__ A, const float* __restrict__ Bb) {
+  const int Cc = d.C1 + d.C2;
+  const int cv = Cc / V;
+  const size_t total = static_cast<size_t>(d.B) * d.HW * cv;
+  const bool quant = d.aq.qtable != nullptr;
+  float2 qp = make_float2(1.0f, 0.0f);
+  if (quant) qp = load_qparam(d.aq);
+  for (size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < total;
+       i += static_cast<size_t>(gridDim.x) * blockDim.x) {
+    const size_t pix = i / cv;
+    const int c = static_cast<int>(i - pix * cv) * V;
+    const int b = static_cast<int>(pix / d.HW);
+    const float* src = c < d.C1 ? d.x1 + pix * d.C1 + c : d.x2 + pix * d.C2 + (c - d.C1);
+    float v[V], a[V], bb[V], y[V];
+    if constexpr (V == 4) {
+      const float4 t = *reinterpret_cast<const float4*>(src);
+      const float4 ta = *reinterpret_cast<const float4*>(A + static_cast<size_t>(b) * Cc + c);
+      const float4 tb = *reinterpret_cast<const float4*>(Bb + static_cast<size_t>(b) * Cc + c);
+      v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+      a[0] = ta.x; a[1] = ta.y; a[2] = ta.z; a[3] = ta.w;
+      bb[0] = tb.x; bb[1] = tb.y; bb[2] = tb.z; bb[3] = tb.w;
+    } else {
+#pragma unroll
+      for (int q = 0; q < V; ++q) {
+        v[q] = src[q];
+        a[q] = A[static_cast<size_t>(b) * Cc + c + q];
+        bb[q] = Bb[static_cast<size_t>(b) * Cc + c + q];
+      }
+    }
+    const size_t o = pix * Cc + c;
+#pragma unroll
+    for (int q = 0; q < V; ++q) {
+      y[q] = a[q] * v[q] + bb[q];
+      if (d.silu) y[q] = silu_f(y[q]);
+    }
+    if (d.xcat_or_null) {
+      if constexpr (V == 4) *reinterpret_cast<float4*>(d.xcat_or_null + o) = make_float4(v[0], v[1], v[2], v[3]);
+      else
+#pragma unroll
+        for (int q = 0; q < V; ++q) d.xcat_or_null[o + q] = v[q];
+    }
+    if (quant) {
+      signed char qq[V];
+#pragma unroll
+      for (int q = 0; q < V; ++q)
+        qq[q] = static_cast<signed char>(static_cast<int>(quant_index_f(y[q], qp.x, qp.y, 255.0f)) - 128);
+      if constexpr (V == 4) *reinterpret_cast<char4*>(d.yq + o) = make_char4(qq[0], qq[1], qq[2], qq[3]);
+      else
+#pragma unroll
+        for (int q = 0; q < V; ++q) d.yq[o + q] = qq[q];
+    }
+    if (d.yf) {
+      if constexpr (V == 4) *reinterpret_cast<float4*>(d.yf + o) = make_float4(y[0], y[1], y[2], y[3]);
+      else
+#pragma unroll
+        for (int q = 0; q < V; ++q) d.yf[o + q] = y[q];
+    }
+  }
+}
+
+extern "C" int tfmq_groupnorm_from_stats(tfmq_handle h, const tfmq_gn_desc* dd, const float* stats1, const float* stats2,
+                                         int seg, float* ws, void* stream) {
+  TFMQ_CHECK_ARG(h, h && dd && stats1 && ws, "groupnorm_from_stats: null pointer");
+  const tfmq_gn_desc& d = *dd;
+  TFMQ_CHECK_ARG(h, d.x1 && d.gamma && d.beta && (d.C2 == 0 || (d.x2 && stats2)), "groupnorm_from_stats: null operand");
+  TFMQ_CHECK_ARG(h, (d.aq.qtable && d.yq) || d.yf, "groupnorm_from_stats: no output requested");
+  TFMQ_CHECK_ARG(h, d.B > 0 && d.HW > 0 && d.groups > 0 && d.groups <= 64 && (d.C1 + d.C2) % d.groups == 0,
+                 "groupnorm_from_stats: bad shape");
+  TFMQ_CHECK_ARG(h, seg > 0 && d.HW % seg == 0, "groupnorm_from_stats: seg must divide HW");
+  const int Cc = d.C1 + d.C2;
+  float* A = ws;
+  float* Bb = ws + static_cast<size_t>(d.B) * Cc;
+  hipLaunchKernelGGL(k_gn_finalize, dim3(d.B), dim3(256), 0, as_stream(stream), reinterpret_cast<const float2*>(stats1), d.C1,
+                     reinterpret_cast<const float2*>(stats2), d.C2, d.HW, seg, d.groups, d.eps, d.gamma, d.beta, A, Bb);
+  TFMQ_LAUNCH_CHECK(h);
+  const bool v4 = (d.C1 % 4 == 0) && (d.C2 % 4 == 0);
+  const size_t total = static_cast<size_t>(d.B) * d.HW * (v4 ? Cc / 4 : Cc);
+  int blocks = ceil_div(static_cast<long>(total), 256 * 4);
+  if (blocks > h->cu_count * 16) blocks = h->cu_count * 16;
+  if (blocks < 1) blocks = 1;
+  if (v4) hipLaunchKernelGGL(k_gn_apply<4>, dim3(blocks), dim3(256), 0, as_stream(stream), d, A, Bb);
+  else hipLaunchKernelGGL(k_gn_apply<1>, dim3(blocks), dim3(256), 0, as_stream(stream), d, A, Bb);
+  TFMQ_LAUNCH_CHECK(h);
+  return TFMQ_OK;
+}
+
 extern "C" int tfmq_groupnorm(tfmq_handle h, const tfmq_gn_desc* dd, void* stream) {
   TFMQ_CHECK_ARG(h, h && dd, "groupnorm: null pointer");
   const tfmq_gn_desc& d = *dd;

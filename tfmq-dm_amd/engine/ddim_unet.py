@@ -40,6 +40,7 @@ class _Layer:
         self.kind, self.p, self.aq = kind, packed, aq
 
     def run(self, x, **kw):
+        kw.setdefault("want_stats", True)   # conv-epilogue GroupNorm statistics (K8 split form)
         if self.kind == "w4a8":
             return ops.conv2d_w4a8(x, self.p, self.aq, **kw)
         return ops.conv2d_f16(x, self.p, **kw)
@@ -263,7 +264,7 @@ class DdimUNetEngine:
                 key = (l.kind == "w4a8", l.aq.qid if l.aq is not None else -1)
                 if key not in cache:
                     cache[key], _ = self._gn(p + ".norm", x, None, False, l)
-                l.run(cache[key], out=qkv, y_coff=i * Cc)
+                l.run(cache[key], out=qkv, y_coff=i * Cc, want_stats=False)
         qkv = qkv.reshape(B, H * W, 3 * Cc)
         aq = po.aq if po.kind == "w4a8" else None
         if aq is not None and self.calib is not None:

@@ -254,6 +254,26 @@ def event_elapsed_ms(e0: int, e1: int, device: int = 0) -> float:
     return float(ms.value)
 
 
+def stats_segment(hw: int) -> int:
+    """Segment size of the conv-epilogue GroupNorm statistics for an image of `hw` pixels (0 = unsupported)."""
+    for s in (128, 64, 32, 16):
+        if hw % s == 0:
+            return s
+    return 0
+
+
+def _attach_stats(dsc, y: torch.Tensor, B: int, hw: int, cout: int, want_stats: bool):
+    """Allocate the statistics buffer of a conv output and remember it on the tensor object."""
+    if not want_stats:
+        return
+    seg = stats_segment(hw)
+    if seg == 0 or y.shape[-1] != cout:
+        return
+    st = _alloc(B * hw // seg, cout, 2, dtype=torch.float32, device=y.device)
+    dsc.stats, dsc.stats_seg = st.data_ptr(), seg
+    y._tfmq_stats = (st, seg)
+
+
 def _profiled_conv(name, kind, d, dsc, nops):
     h = handle(d)
     if _conv_prof is None:
@@ -294,7 +314,7 @@ def out_hw(H, W, kh, kw, stride, pad_t, pad_l, pad_b, pad_r, up2x=False):
 def conv2d_w4a8(xq: torch.Tensor, pw: PackedW4, aq: QSel, stride: int = 1, pad: Tuple[int, int, int, int] = (0, 0, 0, 0),
                 up2x: bool = False, rowadd: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
                 out: Optional[torch.Tensor] = None, y_coff: int = 0, rowadd_ld=None, rowadd_step=None,
-                rowadd_step_stride: int = 0) -> torch.Tensor:
+                rowadd_step_stride: int = 0, want_stats: bool = False) -> torch.Tensor:
     """xq: int8 NHWC [B,H,W,Cin] (bin-128).  pad = (top, left, bottom, right).  -> fp32 NHWC."""
     d = _dev(xq)
     _chk(xq, torch.int8, "xq")
@@ -308,6 +328,7 @@ def conv2d_w4a8(xq: torch.Tensor, pw: PackedW4, aq: QSel, stride: int = 1, pad: 
     dsc.w, dsc.wmeta, dsc.wscale = pw.packed.data_ptr(), pw.wmeta.data_ptr(), pw.wscale.data_ptr()
     dsc.bias = None if pw.bias is None else pw.bias.data_ptr()
     dsc.aq = aq
+    _attach_stats(dsc, y, B, Ho * Wo, pw.cout, want_stats and y_coff == 0)
     _profiled_conv("conv2d_w4a8", "w4a8", d, dsc, 2.0 * B * Ho * Wo * pw.cout * pw.kh * pw.kw * cin)
     return y
 
@@ -315,7 +336,7 @@ def conv2d_w4a8(xq: torch.Tensor, pw: PackedW4, aq: QSel, stride: int = 1, pad: 
 def conv2d_f16(x: torch.Tensor, pf: PackedF16, stride: int = 1, pad: Tuple[int, int, int, int] = (0, 0, 0, 0),
                up2x: bool = False, rowadd: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
                out: Optional[torch.Tensor] = None, y_coff: int = 0, rowadd_ld=None, rowadd_step=None,
-               rowadd_step_stride: int = 0) -> torch.Tensor:
+               rowadd_step_stride: int = 0, want_stats: bool = False) -> torch.Tensor:
     """x: fp32 NHWC.  Un-quantised layers (f16 MFMA, fp32 accumulate)."""
     d = _dev(x)
     _chk(x, torch.float32, "x")
@@ -330,6 +351,7 @@ def conv2d_f16(x: torch.Tensor, pf: PackedF16, stride: int = 1, pad: Tuple[int, 
     dsc.wscale = None if pf.wscale is None else pf.wscale.data_ptr()
     dsc.bias = None if pf.bias is None else pf.bias.data_ptr()
     dsc.aq = QSel(None, None, 0, 0)
+    _attach_stats(dsc, y, B, Ho * Wo, pf.cout, want_stats and y_coff == 0)
     _profiled_conv("conv2d_f16", "f16", d, dsc, 2.0 * B * Ho * Wo * pf.cout * pf.kh * pf.kw * cin)
     return y
 
@@ -389,7 +411,14 @@ def groupnorm(x1: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: fl
     if want_cat:
         xcat = _alloc(shape, dtype=torch.float32, device=x1.device)
         g.xcat = xcat.data_ptr()
-    handle(d).call("groupnorm", C.byref(g), _stream(d))
+    st1 = getattr(x1, "_tfmq_stats", None)
+    st2 = getattr(x2, "_tfmq_stats", None) if x2 is not None else None
+    if st1 is not None and (x2 is None or (st2 is not None and st2[1] == st1[1])) and HW % st1[1] == 0:
+        ws = _alloc(2 * B * (C1 + C2), dtype=torch.float32, device=x1.device)
+        handle(d).call("groupnorm_from_stats", C.byref(g), _p(st1[0]), None if st2 is None else _p(st2[0]), st1[1], _p(ws),
+                       _stream(d))
+    else:
+        handle(d).call("groupnorm", C.byref(g), _stream(d))
     return yq, yf, xcat
 
 
