@@ -92,8 +92,11 @@ int tfmq_mse_search(tfmq_handle h, const float* x, size_t rows, size_t cols, con
  * adaptive_rounding.py:51-69) ------------------------------------------------------------ */
 /* w: [cout][cin][kh][kw] fp32 (PyTorch OIHW; Linear = kh=kw=1).  alpha NULL => nearest
  * rounding, else hard AdaRound (floor + [alpha>=0]).  delta/zp: [cout].
- * packed: [cout][K/2] bytes, K = kh*kw*cin ordered (kh,kw,cin) to match NHWC activations;
- *   each 32-bit word holds 8 consecutive k: byte i = q[k+i] | q[k+4+i] << 4  (i=0..3).
+ * packed: ceil32(cout) * K/2 bytes, K = kh*kw*cin ordered (kh,kw,cin) to match NHWC activations;
+ *   each 32-bit word holds 8 consecutive k: byte i = q[k+i] | q[k+4+i] << 4  (i=0..3);
+ *   words are stored tile-major: 32-row blocks of output channels, inside a block one K-step
+ *   (ck = 64 or 32 input channels) of all 32 rows is contiguous, so the GEMM loader reads whole
+ *   128-byte lines: word(n, g) = ((n/32 * K/ck + g/(ck/8)) * 32 + n%32) * (ck/8) + g%(ck/8).
  * wmeta: [cout][4] int32 = {zp, rowsum_q = sum_k q, 0, 0}.  cin must be a multiple of 8. */
 int tfmq_pack_w4(tfmq_handle h, const float* w, const float* alpha_or_null, const float* delta, const float* zp,
                  int cout, int cin, int kh, int kw, uint8_t* packed, int32_t* wmeta, void* stream);

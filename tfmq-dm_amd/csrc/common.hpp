@@ -85,3 +85,16 @@ __device__ __forceinline__ float wave_reduce_max(float v) {
 __device__ __forceinline__ float silu_f(float x) { return x * (1.0f / (1.0f + expf(-x))); }
 
 static inline int ceil_div(long a, long b) { return static_cast<int>((a + b - 1) / b); }
+
+// ---------------------------------------------------------------- packed int4 weight layout
+// "Tile-major": output channels are grouped in blocks of 32 rows; inside a block the bytes of one
+// K-step (ck input channels of one tap = ck/8 32-bit words per row) of all 32 rows are contiguous,
+// so the implicit-GEMM loader reads whole 128-byte lines and uses every byte of them
+// (row-major [cout][K/2] made every K-step touch a quarter of 128 different lines).
+//   word(n, g) = ((n/32 * nsteps + g/wps) * 32 + n%32) * wps + g%wps,   wps = ck/8, nsteps = K/ck
+// ck = 64 if cin % 64 == 0, else 32 if cin % 32 == 0, else 8 (plain row-major; GEMV / tests only).
+__host__ __device__ inline int w4_ck(int cin) { return (cin % 64 == 0) ? 64 : ((cin % 32 == 0) ? 32 : 8); }
+__host__ __device__ inline size_t w4_word_index(int n, int g, int K, int ck) {
+  const int wps = ck / 8, nsteps = K / ck;
+  return ((static_cast<size_t>(n / 32) * nsteps + g / wps) * 32 + (n % 32)) * wps + (g % wps);
+}

@@ -36,7 +36,7 @@ struct ConvP {
 
 __device__ __forceinline__ int swz(int row, int slot) { return row * 64 + ((slot ^ ((row >> 2) & 3)) << 4); }
 
-template <bool INT8, int CK8, int WAVES_M, int WAVES_N, int WM_TILES, int WN_TILES>
+template <bool INT8, bool FAST, int CK8, int WAVES_M, int WAVES_N, int WM_TILES, int WN_TILES>
 __global__ __launch_bounds__(256) void k_conv_igemm(ConvP p) {
   constexpr int BM = WAVES_M * WM_TILES * 32;
   constexpr int BN = WAVES_N * WN_TILES * 32;
@@ -44,15 +44,15 @@ __global__ __launch_bounds__(256) void k_conv_igemm(ConvP p) {
   constexpr int SLOTS = INT8 ? CK8 / 16 : 4;    // 16-byte slots used per 64-byte LDS row
   constexpr int KSUB = INT8 ? CK8 / 32 : 2;     // MFMA k-sub-steps per K-step
   constexpr int BPR = INT8 ? CK8 / 32 : 4;      // 16-byte global items per B row
-  constexpr int A_ITEMS = BM * SLOTS / 256;     // 16-byte LDS items per thread (A)
+  constexpr int A_TOTAL = BM * SLOTS;
+  constexpr int A_ITEMS = (A_TOTAL + 255) / 256;  // 16-byte LDS items per thread (A)
   constexpr int B_TOTAL = BN * BPR;
   constexpr int B_ITEMS = (B_TOTAL + 255) / 256;
   static_assert(WAVES_M * WAVES_N == 4, "4 waves");
-  static_assert(BM * SLOTS % 256 == 0, "A items");
 
   // LDS: main loop 2 x (A tile + B tile); the epilogue re-uses the same bytes for its output staging
   // tile + statistics partials; the per-row activation sums live behind both.
-  constexpr int EPI_PR = (BN == 128) ? 64 : BM;
+  constexpr int EPI_PR = (BN == 128) ? 64 : BM;   // keep in sync with PR in the epilogue
   constexpr int LDS_MAIN = 2 * (BM + BN) * 64;
   constexpr int LDS_EPI = EPI_PR * (BN + 4) * 4 + (256 / (BN / 4)) * BN * 8 + BN * 8;
   constexpr int LDS_BODY = LDS_MAIN > LDS_EPI ? LDS_MAIN : LDS_EPI;
@@ -87,14 +87,15 @@ __global__ __launch_bounds__(256) void k_conv_igemm(ConvP p) {
 
   // ---- per-thread A rows (fixed for the whole K loop)
   int a_row[A_ITEMS], a_slot[A_ITEMS], a_b[A_ITEMS], a_ho[A_ITEMS], a_wo[A_ITEMS];
-  bool a_ok[A_ITEMS];
+  bool a_ok[A_ITEMS], a_in[A_ITEMS];
 #pragma unroll
   for (int it = 0; it < A_ITEMS; ++it) {
     const int item = tid + it * 256;
     a_row[it] = item / SLOTS;
     a_slot[it] = item % SLOTS;
+    a_in[it] = item < A_TOTAL;
     const int m = m0 + a_row[it];
-    a_ok[it] = m < p.M;
+    a_ok[it] = a_in[it] && m < p.M;
     const int mm = a_ok[it] ? m : 0;
     const int hw = d.Ho * d.Wo;
     a_b[it] = mm / hw;
@@ -106,13 +107,82 @@ __global__ __launch_bounds__(256) void k_conv_igemm(ConvP p) {
 #pragma unroll
   for (int it = 0; it < A_ITEMS; ++it) a_sum[it] = 0;
 
-  uint4 a_reg[A_ITEMS];
-  uint4 b_reg[B_ITEMS];
+  // two register sets: the global loads of K-step s+2 are issued while step s is being multiplied
+  // (prefetch distance 2: each load has two full K-steps to land before it is staged into LDS)
+  uint4 a_reg0[A_ITEMS], a_reg1[A_ITEMS];
+  uint4 b_reg0[B_ITEMS], b_reg1[B_ITEMS];
 
-  auto load_step = [&](int s) {
+  // Fast addressing (stride 1, no fused upsample, whole K-steps): everything that depends on the thread
+  // is computed ONCE -- a base pointer per staged item and a bit mask of the taps that fall inside the
+  // image -- and a K-step only adds a wave-uniform (scalar) offset.  The generic path below recomputes
+  // pixel coordinates with 64-bit multiplies every step (VALU-bound: ~1.3k issue cycles per K-step).
+  const unsigned char* a_base[A_ITEMS];
+  unsigned a_mask[A_ITEMS];
+  const unsigned char* b_base[B_ITEMS];
+  bool b_ok[B_ITEMS];
+  if constexpr (FAST) {
+    constexpr int ESZ = INT8 ? 1 : 4;  // bytes per input element
+#pragma unroll
+    for (int it = 0; it < A_ITEMS; ++it) {
+      const size_t pix = (static_cast<size_t>(a_b[it]) * d.H + a_ho[it]) * d.W + a_wo[it];
+      a_base[it] = static_cast<const unsigned char*>(d.x) + (pix * d.Cin + a_slot[it] * (INT8 ? 16 : 8)) * ESZ;
+      unsigned mask = 0;
+      for (int t = 0; t < d.KH * d.KW; ++t) {
+        const int hi = a_ho[it] + t / d.KW - d.pad_t, wi = a_wo[it] + t % d.KW - d.pad_l;
+        if (a_ok[it] && hi >= 0 && hi < d.H && wi >= 0 && wi < d.W) mask |= 1u << t;
+      }
+      a_mask[it] = mask;
+    }
+#pragma unroll
+    for (int it = 0; it < B_ITEMS; ++it) {
+      const int item = tid + it * 256;
+      const int n = n0 + item / BPR;
+      b_ok[it] = item < B_TOTAL && n < d.Cout;
+      const int nn = b_ok[it] ? n : 0;
+      if constexpr (INT8)
+        b_base[it] = static_cast<const unsigned char*>(d.w) +
+                     ((static_cast<size_t>(nn / 32) * p.nsteps) * 32 + (nn % 32)) * (CK / 2) + (item % BPR) * 16;
+      else
+        b_base[it] = static_cast<const unsigned char*>(d.w) +
+                     (static_cast<size_t>(nn) * (d.KH * d.KW) * p.cin_pad + (item & 3) * 8) * 2;
+    }
+  }
+
+  auto load_step = [&](int s, uint4 (&ar)[A_ITEMS], uint4 (&br)[B_ITEMS]) {
     const int tap = s / p.chunks;
     const int c0 = (s - tap * p.chunks) * CK;
     const int kh = tap / d.KW, kw = tap - kh * d.KW;
+    if constexpr (FAST) {
+      // wave-uniform byte offsets of this K-step
+      const long a_off = (static_cast<long>((kh - d.pad_t) * d.W + (kw - d.pad_l)) * d.Cin + c0) * (INT8 ? 1 : 4);
+      const long b_off = static_cast<long>(s) * (INT8 ? 16 * CK : 64);  // int4: 32 rows x CK/2 bytes per K-step (tile-major)
+#pragma unroll
+      for (int it = 0; it < A_ITEMS; ++it) {
+        const bool ok = (a_mask[it] >> tap) & 1u;
+        if constexpr (INT8) {
+          uint4 v = make_uint4(pad_word, pad_word, pad_word, pad_word);
+          if (ok) v = *reinterpret_cast<const uint4*>(a_base[it] + a_off);
+          ar[it] = v;
+        } else {
+          float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
+          if (ok) {
+            v0 = *reinterpret_cast<const float4*>(a_base[it] + a_off);
+            v1 = *reinterpret_cast<const float4*>(a_base[it] + a_off + 16);
+          }
+          v8h hv = {static_cast<_Float16>(v0.x), static_cast<_Float16>(v0.y), static_cast<_Float16>(v0.z),
+                    static_cast<_Float16>(v0.w), static_cast<_Float16>(v1.x), static_cast<_Float16>(v1.y),
+                    static_cast<_Float16>(v1.z), static_cast<_Float16>(v1.w)};
+          ar[it] = *reinterpret_cast<uint4*>(&hv);
+        }
+      }
+#pragma unroll
+      for (int it = 0; it < B_ITEMS; ++it) {
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (b_ok[it]) v = *reinterpret_cast<const uint4*>(b_base[it] + b_off);
+        br[it] = v;
+      }
+      return;
+    }
     // ---- A
 #pragma unroll
     for (int it = 0; it < A_ITEMS; ++it) {
@@ -127,7 +197,7 @@ __global__ __launch_bounds__(256) void k_conv_igemm(ConvP p) {
       if constexpr (INT8) {
         uint4 v = make_uint4(pad_word, pad_word, pad_word, pad_word);
         if (ok) v = *reinterpret_cast<const uint4*>(static_cast<const int8_t*>(d.x) + pix * d.Cin + c0 + a_slot[it] * 16);
-        a_reg[it] = v;
+        ar[it] = v;
       } else {
         const int c = c0 + a_slot[it] * 8;
         float f[8];
@@ -149,7 +219,7 @@ __global__ __launch_bounds__(256) void k_conv_igemm(ConvP p) {
         v8h hv;
 #pragma unroll
         for (int j = 0; j < 8; ++j) hv[j] = static_cast<_Float16>(f[j]);
-        a_reg[it] = *reinterpret_cast<uint4*>(&hv);
+        ar[it] = *reinterpret_cast<uint4*>(&hv);
       }
     }
     // ---- B
@@ -161,8 +231,9 @@ __global__ __launch_bounds__(256) void k_conv_igemm(ConvP p) {
         if constexpr (INT8) {
           const int n = n0 + item / BPR;
           if (n < d.Cout)
-            v = *reinterpret_cast<const uint4*>(static_cast<const uint8_t*>(d.w) + static_cast<size_t>(n) * (p.Ktot >> 1) +
-                                                ((tap * d.Cin + c0) >> 1) + (item % BPR) * 16);
+            v = *reinterpret_cast<const uint4*>(static_cast<const uint8_t*>(d.w) +
+                                                ((static_cast<size_t>(n / 32) * p.nsteps + s) * 32 + (n % 32)) * (CK / 2) +
+                                                (item % BPR) * 16);
         } else {
           const int n = n0 + (item >> 2);
           if (n < d.Cout)
@@ -170,20 +241,20 @@ __global__ __launch_bounds__(256) void k_conv_igemm(ConvP p) {
                                                 (static_cast<size_t>(n) * (d.KH * d.KW) + tap) * p.cin_pad + c0 + (item & 3) * 8);
         }
       }
-      b_reg[it] = v;
+      br[it] = v;
     }
   };
 
-  auto store_step = [&](int buf) {
+  auto store_step = [&](int buf, uint4 (&ar)[A_ITEMS], uint4 (&br)[B_ITEMS]) {
 #pragma unroll
     for (int it = 0; it < A_ITEMS; ++it) {
-      *reinterpret_cast<uint4*>(ldsA(buf) + swz(a_row[it], a_slot[it])) = a_reg[it];
+      if (a_in[it]) *reinterpret_cast<uint4*>(ldsA(buf) + swz(a_row[it], a_slot[it])) = ar[it];
       if constexpr (INT8) {
         int s = a_sum[it];
-        s = __builtin_amdgcn_sdot4(static_cast<int>(a_reg[it].x), 0x01010101, s, false);
-        s = __builtin_amdgcn_sdot4(static_cast<int>(a_reg[it].y), 0x01010101, s, false);
-        s = __builtin_amdgcn_sdot4(static_cast<int>(a_reg[it].z), 0x01010101, s, false);
-        s = __builtin_amdgcn_sdot4(static_cast<int>(a_reg[it].w), 0x01010101, s, false);
+        s = __builtin_amdgcn_sdot4(static_cast<int>(ar[it].x), 0x01010101, s, false);
+        s = __builtin_amdgcn_sdot4(static_cast<int>(ar[it].y), 0x01010101, s, false);
+        s = __builtin_amdgcn_sdot4(static_cast<int>(ar[it].z), 0x01010101, s, false);
+        s = __builtin_amdgcn_sdot4(static_cast<int>(ar[it].w), 0x01010101, s, false);
         a_sum[it] = s;
       }
     }
@@ -193,7 +264,7 @@ __global__ __launch_bounds__(256) void k_conv_igemm(ConvP p) {
       if (item < B_TOTAL) {
         if constexpr (INT8) {
           const int row = item / BPR, half = item % BPR;
-          const uint4 v = b_reg[it];
+          const uint4 v = br[it];
           uint4 lo, hi;  // word j of the packed 16 B holds k = 8j..8j+7
           lo.x = v.x & 0x0f0f0f0fu; lo.y = (v.x >> 4) & 0x0f0f0f0fu;
           lo.z = v.y & 0x0f0f0f0fu; lo.w = (v.y >> 4) & 0x0f0f0f0fu;
@@ -202,7 +273,7 @@ __global__ __launch_bounds__(256) void k_conv_igemm(ConvP p) {
           *reinterpret_cast<uint4*>(ldsB(buf) + swz(row, half * 2)) = lo;
           *reinterpret_cast<uint4*>(ldsB(buf) + swz(row, half * 2 + 1)) = hi;
         } else {
-          *reinterpret_cast<uint4*>(ldsB(buf) + swz(item >> 2, item & 3)) = b_reg[it];
+          *reinterpret_cast<uint4*>(ldsB(buf) + swz(item >> 2, item & 3)) = br[it];
         }
       }
     }
@@ -217,34 +288,43 @@ __global__ __launch_bounds__(256) void k_conv_igemm(ConvP p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0;
 
-  load_step(0);
-  for (int s = 0; s < p.nsteps; ++s) {
-    const int buf = s & 1;
-    store_step(buf);
-    __syncthreads();
-    if (s + 1 < p.nsteps) load_step(s + 1);
+  auto compute = [&](int buf) {
 #pragma unroll
     for (int ks = 0; ks < KSUB; ++ks) {
-      uint4 af[WM_TILES], bf[WN_TILES];
-      const int kslot = ks * 2 + (lane >> 5);
-#pragma unroll
-      for (int i = 0; i < WM_TILES; ++i)
-        af[i] = *reinterpret_cast<const uint4*>(ldsA(buf) + swz((wm * WM_TILES + i) * 32 + (lane & 31), kslot));
-#pragma unroll
-      for (int j = 0; j < WN_TILES; ++j)
-        bf[j] = *reinterpret_cast<const uint4*>(ldsB(buf) + swz((wn * WN_TILES + j) * 32 + (lane & 31), kslot));
-#pragma unroll
-      for (int i = 0; i < WM_TILES; ++i)
-#pragma unroll
-        for (int j = 0; j < WN_TILES; ++j) {
-          if constexpr (INT8) {
-            acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(*reinterpret_cast<v4i*>(&af[i]),
-                                                              *reinterpret_cast<v4i*>(&bf[j]), acc[i][j], 0, 0, 0);
-          } else {
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<v8h*>(&af[i]),
-                                                               *reinterpret_cast<v8h*>(&bf[j]), acc[i][j], 0, 0, 0);
+        uint4 af[WM_TILES], bf[WN_TILES];
+        const int kslot = ks * 2 + (lane >> 5);
+  #pragma unroll
+        for (int i = 0; i < WM_TILES; ++i)
+          af[i] = *reinterpret_cast<const uint4*>(ldsA(buf) + swz((wm * WM_TILES + i) * 32 + (lane & 31), kslot));
+  #pragma unroll
+        for (int j = 0; j < WN_TILES; ++j)
+          bf[j] = *reinterpret_cast<const uint4*>(ldsB(buf) + swz((wn * WN_TILES + j) * 32 + (lane & 31), kslot));
+  #pragma unroll
+        for (int i = 0; i < WM_TILES; ++i)
+  #pragma unroll
+          for (int j = 0; j < WN_TILES; ++j) {
+            if constexpr (INT8) {
+              acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(*reinterpret_cast<v4i*>(&af[i]),
+                                                                *reinterpret_cast<v4i*>(&bf[j]), acc[i][j], 0, 0, 0);
+            } else {
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<v8h*>(&af[i]),
+                                                                 *reinterpret_cast<v8h*>(&bf[j]), acc[i][j], 0, 0, 0);
+            }
           }
-        }
+      }
+  };
+  load_step(0, a_reg0, b_reg0);
+  if (p.nsteps > 1) load_step(1, a_reg1, b_reg1);
+  for (int s = 0; s < p.nsteps; s += 2) {
+    store_step(0, a_reg0, b_reg0);
+    __syncthreads();
+    if (s + 2 < p.nsteps) load_step(s + 2, a_reg0, b_reg0);
+    compute(0);
+    if (s + 1 < p.nsteps) {
+      store_step(1, a_reg1, b_reg1);
+      __syncthreads();
+      if (s + 3 < p.nsteps) load_step(s + 3, a_reg1, b_reg1);
+      compute(1);
     }
   }
 
@@ -255,7 +335,7 @@ __global__ __launch_bounds__(256) void k_conv_igemm(ConvP p) {
       int s = a_sum[it];
       s += __shfl_xor(s, 1, 64);
       if constexpr (SLOTS == 4) s += __shfl_xor(s, 2, 64);
-      if (a_slot[it] == 0) ldsS[a_row[it]] = s;
+      if (a_slot[it] == 0 && a_in[it]) ldsS[a_row[it]] = s;
     }
     __syncthreads();
   }
@@ -431,18 +511,30 @@ static int launch_conv(tfmq_handle h, const tfmq_conv_desc* dd, void* stream) {
   }
   p.nsteps = d.KH * d.KW * p.chunks;
   const bool narrow = d.Cout <= 32;
-  const int BM = 128, BN = narrow ? 32 : 128;
+  // small-M layers (4x4 / 8x8 feature maps): 128x128 tiles leave most of the 256 CUs idle -> 64x64 tiles
+  // (a statistics segment must not span tiles, so 128-pixel segments keep the 128-row tile)
+  const bool small = !narrow && !(d.stats && d.stats_seg > 64) &&
+                     static_cast<long>((p.M + 127) / 128) * ((d.Cout + 127) / 128) < 2L * h->cu_count;
+  const int BM = small ? 64 : 128, BN = narrow ? 32 : (small ? 64 : 128);
   p.tiles_n = (d.Cout + BN - 1) / BN;
   const int tiles_m = (p.M + BM - 1) / BM;
   dim3 grid(static_cast<unsigned>(p.tiles_n) * tiles_m);
   const bool k32 = INT8 && (d.Cin % 64 != 0);
+  // fast addressing: stride 1, no fused upsample, whole K-steps, <= 32 taps, 16-byte aligned rows
+  const bool fast = d.stride == 1 && !d.up2x && d.KH * d.KW <= 32 && (INT8 ? true : d.Cin % 32 == 0);
+  hipStream_t st = as_stream(stream);
+#define TFMQ_LAUNCH(F, CK, A, B_, C_, D_) hipLaunchKernelGGL((k_conv_igemm<INT8, F, CK, A, B_, C_, D_>), grid, dim3(256), 0, st, p)
   if (narrow) {
-    if (k32) hipLaunchKernelGGL((k_conv_igemm<INT8, 32, 4, 1, 1, 1>), grid, dim3(256), 0, as_stream(stream), p);
-    else hipLaunchKernelGGL((k_conv_igemm<INT8, 64, 4, 1, 1, 1>), grid, dim3(256), 0, as_stream(stream), p);
+    if (k32) { if (fast) TFMQ_LAUNCH(true, 32, 4, 1, 1, 1); else TFMQ_LAUNCH(false, 32, 4, 1, 1, 1); }
+    else { if (fast) TFMQ_LAUNCH(true, 64, 4, 1, 1, 1); else TFMQ_LAUNCH(false, 64, 4, 1, 1, 1); }
+  } else if (small) {
+    if (k32) { if (fast) TFMQ_LAUNCH(true, 32, 2, 2, 1, 1); else TFMQ_LAUNCH(false, 32, 2, 2, 1, 1); }
+    else { if (fast) TFMQ_LAUNCH(true, 64, 2, 2, 1, 1); else TFMQ_LAUNCH(false, 64, 2, 2, 1, 1); }
   } else {
-    if (k32) hipLaunchKernelGGL((k_conv_igemm<INT8, 32, 2, 2, 2, 2>), grid, dim3(256), 0, as_stream(stream), p);
-    else hipLaunchKernelGGL((k_conv_igemm<INT8, 64, 2, 2, 2, 2>), grid, dim3(256), 0, as_stream(stream), p);
+    if (k32) { if (fast) TFMQ_LAUNCH(true, 32, 2, 2, 2, 2); else TFMQ_LAUNCH(false, 32, 2, 2, 2, 2); }
+    else { if (fast) TFMQ_LAUNCH(true, 64, 2, 2, 2, 2); else TFMQ_LAUNCH(false, 64, 2, 2, 2, 2); }
   }
+#undef TFMQ_LAUNCH
   TFMQ_LAUNCH_CHECK(h);
   return TFMQ_OK;
 }

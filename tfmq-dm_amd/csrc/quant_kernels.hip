@@ -356,7 +356,7 @@ __global__ __launch_bounds__(256) void k_pack_w4(const float* __restrict__ w, co
       sum += static_cast<int>(qi);
       word |= qi << ((i & 3) * 8 + (i >> 2) * 4);
     }
-    packed[static_cast<size_t>(co) * (K / 8) + g] = word;
+    packed[w4_word_index(co, g, K, w4_ck(cin))] = word;
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
@@ -392,7 +392,7 @@ __global__ void k_unpack_w4(const uint32_t* __restrict__ packed, int cout, int c
        g += static_cast<size_t>(gridDim.x) * blockDim.x) {
     const int co = g / (K / 8), k0 = (g % (K / 8)) * 8;
     const int tap = k0 / cin, ci0 = k0 - tap * cin;
-    const uint32_t word = packed[g];
+    const uint32_t word = packed[w4_word_index(co, static_cast<int>(g % (K / 8)), K, w4_ck(cin))];
     for (int i = 0; i < 8; ++i) {
       const uint32_t qi = (word >> ((i & 3) * 8 + (i >> 2) * 4)) & 15u;
       idx[static_cast<size_t>(co) * K + static_cast<size_t>(ci0 + i) * khw + tap] = static_cast<uint8_t>(qi);

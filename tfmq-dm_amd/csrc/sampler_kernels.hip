@@ -207,9 +207,9 @@ __global__ __launch_bounds__(256) void k_linear_small_w4(const float* __restrict
     facc[r] = 0.0f;
     iacc[r] = 0;
   }
-  const uint32_t* wr = wp + static_cast<size_t>(wave) * (k / 8);
+  const int ck = w4_ck(k);
   for (int g = lane; g < k / 8; g += 64) {
-    const uint32_t word = wr[g];
+    const uint32_t word = wp[w4_word_index(wave, g, k, ck)];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const int qw = static_cast<int>((word >> ((i & 3) * 8 + (i >> 2) * 4)) & 15u) - zw;

@@ -201,7 +201,8 @@ def pack_w4(w: torch.Tensor, delta: torch.Tensor, zp: torch.Tensor, alpha: Optio
         raise TfmqError("pack_w4: |weight zero-point| > 255 is not supported by the int32 epilogue")
     if alpha is not None:
         _chk(alpha, torch.float32, "alpha")
-    packed = _alloc(cout, kh * kw * cin // 2, dtype=torch.uint8, device=w.device)
+    # tile-major layout (csrc/common.hpp w4_word_index): rows padded to a multiple of 32 output channels
+    packed = torch.zeros((cout + 31) // 32 * 32, kh * kw * cin // 2, dtype=torch.uint8, device=w.device)
     wmeta = _alloc(cout, 4, dtype=torch.int32, device=w.device)
     handle(d).call("pack_w4", _p(w), _p(alpha), _p(dl), _p(z), cout, cin, kh, kw, _p(packed), _p(wmeta), _stream(d))
     return PackedW4(packed, wmeta, dl, None if bias is None else bias.contiguous().float(), cout, cin, kh, kw)
