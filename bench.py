@@ -78,14 +78,15 @@ def conv_roofline(eng, x, n_fwd=3):
         stream.synchronize()
     finally:
         ops.set_conv_profile(None)
-    tot_ops, tot_ms, n = 0.0, 0.0, 0
-    for (e0, e1, nops, kind) in rec:
+    tot_ops, tot_ms, tot_bytes, n = 0.0, 0.0, 0.0, 0
+    for (e0, e1, nops, kind, nbytes) in rec:
         if kind != "w4a8":
             continue
         tot_ops += nops
+        tot_bytes += nbytes
         tot_ms += ops.event_elapsed_ms(e0, e1)
         n += 1
-    return tot_ops, tot_ms, n
+    return tot_ops, tot_ms, n, tot_bytes
 
 
 def cpu_baseline(cfg, sd, wq, names, qtable, seq, betas, batch=8, steps=4):
@@ -174,11 +175,22 @@ def main():
         # ---- roofline of the dominant kernel (HIP events around every launch, launch stream)
         with torch.cuda.stream(sampler.stream):
             eng.step.zero_()
-            tot_ops, tot_ms, n_launch = conv_roofline(eng, sampler.x)
+            tot_ops, tot_ms, n_launch, tot_bytes = conv_roofline(eng, sampler.x)
+        traffic, traffic_src = None, None
+        tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
+        if os.path.exists(tpath):   # PMC bytes (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 passes) of the same kernel
+            tj = json.load(open(tpath))["kernels"]
+            ks = [v for k, v in tj.items() if k.startswith("void k_conv_igemm<true")]
+            if ks:
+                traffic = sum(v["hbm_bytes_per_launch"] * v["launches"] for v in ks) / sum(v["launches"] for v in ks)
+                traffic_src = "profiles/r01_traffic.json (rocprofv3 --pmc, eager forwards of the same workload)"
         achieved = tot_ops / (tot_ms * 1e-3) / 1e12 if tot_ms > 0 else 0.0
         roof = {"bound": "mfma", "kernel": "k_conv_igemm<int8> (w4a8 implicit-GEMM conv / linear)",
                 "achieved": round(achieved, 2), "peak": INT8_PEAK_TOPS, "unit": "TOP/s",
-                "frac": round(achieved / INT8_PEAK_TOPS, 4), "traffic": None,
+                "frac": round(achieved / INT8_PEAK_TOPS, 4), "traffic": traffic, "traffic_unit": "bytes/launch (PMC)",
+                "traffic_source": traffic_src,
+                "algorithmic_bytes_per_launch": round(tot_bytes / max(n_launch, 1)),
+                "hbm_achieved_TBps": round(tot_bytes / (tot_ms * 1e-3) / 1e12, 3) if tot_ms > 0 else None,
                 "launches_timed": n_launch, "avg_launch_us": round(tot_ms * 1e3 / max(n_launch, 1), 2),
                 "algorithmic_ops_per_forward": tot_ops / 3.0}
         cpu = None

@@ -275,7 +275,7 @@ def _attach_stats(dsc, y: torch.Tensor, B: int, hw: int, cout: int, want_stats: 
     y._tfmq_stats = (st, seg)
 
 
-def _profiled_conv(name, kind, d, dsc, nops):
+def _profiled_conv(name, kind, d, dsc, nops, nbytes=0.0):
     h = handle(d)
     if _conv_prof is None:
         h.call(name, C.byref(dsc), _stream(d))
@@ -286,7 +286,7 @@ def _profiled_conv(name, kind, d, dsc, nops):
     h.call("event_record", e0.value, _stream(d))
     h.call(name, C.byref(dsc), _stream(d))
     h.call("event_record", e1.value, _stream(d))
-    _conv_prof.append((e0.value, e1.value, nops, kind))
+    _conv_prof.append((e0.value, e1.value, nops, kind, nbytes))
 
 
 def _conv_desc(x, B, H, W, cin, cout, kh, kw, stride, pad_t, pad_l, Ho, Wo, up2x, y, ldy, y_coff, rowadd, residual,
@@ -330,7 +330,9 @@ def conv2d_w4a8(xq: torch.Tensor, pw: PackedW4, aq: QSel, stride: int = 1, pad: 
     dsc.bias = None if pw.bias is None else pw.bias.data_ptr()
     dsc.aq = aq
     _attach_stats(dsc, y, B, Ho * Wo, pw.cout, want_stats and y_coff == 0)
-    _profiled_conv("conv2d_w4a8", "w4a8", d, dsc, 2.0 * B * Ho * Wo * pw.cout * pw.kh * pw.kw * cin)
+    # algorithmic HBM bytes: int8 input once + packed int4 weights + fp32 output (+ fp32 residual)
+    nbytes = B * H * W * cin + pw.cout * pw.kh * pw.kw * cin / 2 + 4.0 * B * Ho * Wo * pw.cout * (2 if residual is not None else 1)
+    _profiled_conv("conv2d_w4a8", "w4a8", d, dsc, 2.0 * B * Ho * Wo * pw.cout * pw.kh * pw.kw * cin, nbytes)
     return y
 
 
@@ -353,7 +355,8 @@ def conv2d_f16(x: torch.Tensor, pf: PackedF16, stride: int = 1, pad: Tuple[int, 
     dsc.bias = None if pf.bias is None else pf.bias.data_ptr()
     dsc.aq = QSel(None, None, 0, 0)
     _attach_stats(dsc, y, B, Ho * Wo, pf.cout, want_stats and y_coff == 0)
-    _profiled_conv("conv2d_f16", "f16", d, dsc, 2.0 * B * Ho * Wo * pf.cout * pf.kh * pf.kw * cin)
+    nbytes = 4.0 * B * H * W * cin + 2.0 * pf.cout * pf.kh * pf.kw * cin + 4.0 * B * Ho * Wo * pf.cout * (2 if residual is not None else 1)
+    _profiled_conv("conv2d_f16", "f16", d, dsc, 2.0 * B * Ho * Wo * pf.cout * pf.kh * pf.kw * cin, nbytes)
     return y
 
 
