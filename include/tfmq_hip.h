@@ -182,6 +182,14 @@ int tfmq_groupnorm(tfmq_handle h, const tfmq_gn_desc* d, void* stream);
 int tfmq_groupnorm_from_stats(tfmq_handle h, const tfmq_gn_desc* d, const float* stats1, const float* stats2, int seg,
                               float* ws, void* stream);
 
+/* ---- K9: LayerNorm (+quantise) and GEGLU (+quantise) of the SpatialTransformer blocks
+ * (nn.LayerNorm ldm/modules/attention.py:203-205 eps 1e-5; GEGLU :37-44 exact erf GELU) ------------ */
+/* x: [rows][C] fp32; writes int8 (bin-128) to yq when aq.qtable != NULL and/or fp32 to yf */
+int tfmq_layernorm(tfmq_handle h, const float* x, const float* gamma, const float* beta, float eps, long rows, int C,
+                   tfmq_qsel aq, int8_t* yq, float* yf, void* stream);
+/* hin: [rows][2*inner] (output of ff.net.0.proj): y = hin[:, :inner] * gelu(hin[:, inner:]) */
+int tfmq_geglu(tfmq_handle h, const float* hin, long rows, int inner, tfmq_qsel aq, int8_t* yq, float* yf, void* stream);
+
 /* ---- K10: attention core on un-quantised q,k,v (QuantAttnBlock.forward quant_block.py:483-500:
  * bmm, *c^-1/2, softmax, bmm; attention quantizers are never enabled) ---- */
 /* q,k,v: fp32, token t of batch b head hd at ptr[(b*T + t)*ld + hd*d ...]; out likewise (ldo).
@@ -195,6 +203,11 @@ int tfmq_attention(tfmq_handle h, const float* q, const float* k, const float* v
  * x_next = sqrt(a_next)*x0 + c1*z + c2*eps with x0 = (x - eps*sqrt(1-a_t))/sqrt(a_t). */
 int tfmq_ddim_update(tfmq_handle h, const float* x, const float* eps, const float* noise_or_null, float* x_next,
                      float* x0_or_null, size_t n, const float* coef, const int32_t* step, void* stream);
+/* latent DDIM step with classifier-free guidance (p_sample_ddim, ldm/models/diffusion/ddim.py:181-211):
+ * e = eps_u + scale*(eps_c - eps_u), then the DDIM update with the same coef row layout */
+int tfmq_ddim_update_cfg(tfmq_handle h, const float* x, const float* eps_u, const float* eps_c, float scale,
+                         const float* noise_or_null, float* x_next, float* x0_or_null, size_t n, const float* coef,
+                         const int32_t* step, void* stream);
 int tfmq_step_advance(tfmq_handle h, int32_t* step, int delta, void* stream);
 /* y = x*sigmoid(x)  (nonlinearity, ddim/models/diffusion.py:27-29) */
 int tfmq_silu(tfmq_handle h, const float* x, float* y, size_t n, void* stream);

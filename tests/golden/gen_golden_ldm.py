@@ -1,0 +1,112 @@
+"""Golden vectors for the latent-diffusion (Stable-Diffusion-style) UNet path, produced by the reference.
+
+    python tests/golden/gen_golden_ldm.py
+
+Tiny SpatialTransformer UNet (model_channels 32, mult [1,2], 2 heads, context 64): FP / w4 / w4a8 eps,
+quantizer tables, and a 4-step DDIM trajectory with classifier-free guidance run by the reference's own
+DDIMSampler over a minimal stand-in for LatentDiffusion (schedule buffers + apply_model)."""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import _refharness as H  # noqa: E402
+
+torch = H.install()
+from gen_golden import quant_tables, save, sd_arrays  # noqa: E402
+from quant.quant_layer import QMODE, Scaler  # noqa: E402
+from quant.quant_model import QuantModel  # noqa: E402
+
+UNET_KW = dict(image_size=8, in_channels=4, model_channels=32, out_channels=4, num_res_blocks=1,
+               attention_resolutions=[1, 2], channel_mult=[1, 2], num_heads=2, use_spatial_transformer=True,
+               transformer_depth=1, context_dim=64, legacy=False)
+
+
+def build():
+    from ldm.modules.diffusionmodules.openaimodel import UNetModel
+    torch.manual_seed(21)
+    m = UNetModel(**UNET_KW).eval()
+    H.rerandomize_zero_params(m, seed=9)
+    return m
+
+
+class FakeLDM:
+    """What DDIMSampler needs from LatentDiffusion (ddpm.py:117-169 register_schedule, :891-900 apply_model)."""
+
+    def __init__(self, unet, linear_start=0.00085, linear_end=0.012, n=1000):
+        from ldm.modules.diffusionmodules.util import make_beta_schedule
+        betas = make_beta_schedule("linear", n, linear_start=linear_start, linear_end=linear_end)
+        alphas_cumprod = np.cumprod(1.0 - betas, axis=0)
+        alphas_cumprod_prev = np.append(1.0, alphas_cumprod[:-1])
+        self.num_timesteps = n
+        self.betas = torch.tensor(betas, dtype=torch.float32)
+        self.alphas_cumprod = torch.tensor(alphas_cumprod, dtype=torch.float32)
+        self.alphas_cumprod_prev = torch.tensor(alphas_cumprod_prev, dtype=torch.float32)
+        self.device = torch.device("cpu")
+        self.unet = unet
+
+    def apply_model(self, x, t, c):
+        return self.unet(x, t, c)
+
+
+def main():
+    from ldm.models.diffusion.ddim import DDIMSampler
+    from ldm.modules.diffusionmodules.util import make_ddim_sampling_parameters, make_ddim_timesteps, timestep_embedding
+    m = build()
+    out = sd_arrays(m)
+    g = torch.Generator().manual_seed(1111)
+    x = torch.randn(2, 4, 8, 8, generator=g)
+    t = torch.tensor([981, 21])
+    ctx = torch.randn(2, 5, 64, generator=g)
+    out.update(x=x, t=t, ctx=ctx)
+    with torch.no_grad():
+        out["eps_fp"] = m(x, t, ctx)
+    out["temb_32"] = timestep_embedding(torch.tensor([0, 1, 21, 981]), 32)
+    wq = {"bits": 4, "channel_wise": True, "scaler": Scaler.MSE}
+    aq = {"bits": 8, "channel_wise": False, "scaler": Scaler.MSE, "leaf_param": True}
+    qnn = QuantModel(m, wq, aq, aq_mode=[QMODE.NORMAL.value, QMODE.QDIFF.value]).eval()
+    from quant.quant_layer import QuantLayer
+    out["quant_layer_names"] = np.array([n for n, mod in qnn.model.named_modules() if isinstance(mod, QuantLayer)])
+    qnn.set_quant_state(True, False)
+    with torch.no_grad():
+        _ = qnn(x, t, ctx)
+    qnn.disable_out_quantization()
+    with torch.no_grad():
+        out["eps_w4"] = qnn(x, t, ctx)
+        out["tib_w4"] = torch.cat(qnn.tib(x, t), dim=1)
+    qnn.set_quant_state(True, True)
+    with torch.no_grad():
+        _ = qnn(x, t, ctx)
+        out["eps_w4a8"] = qnn(x, t, ctx)
+    out.update(quant_tables(qnn))
+    # schedules
+    ldm = FakeLDM(qnn)
+    out["alphas_cumprod"] = ldm.alphas_cumprod
+    for S in (4, 20, 50):
+        ts = make_ddim_timesteps("uniform", S, 1000, verbose=False)
+        sig, al, alp = make_ddim_sampling_parameters(ldm.alphas_cumprod.cpu(), ts, 0.0, verbose=False)
+        out[f"ddim_ts_{S}"] = ts
+        out[f"ddim_alphas_{S}"] = np.asarray(al, dtype=np.float64)
+        out[f"ddim_alphas_prev_{S}"] = np.asarray(alp, dtype=np.float64)
+    # 4-step DDIM with CFG 7.5 through the reference sampler (w4a8, fixed act table)
+    sampler = DDIMSampler(ldm)
+    x_T = torch.randn(2, 4, 8, 8, generator=g)
+    uc = torch.randn(2, 5, 64, generator=g)
+    out["traj_xT"], out["traj_uc"] = x_T, uc
+    inter = []
+    samples, _ = sampler.sample(S=4, conditioning=ctx, batch_size=2, shape=[4, 8, 8], verbose=False,
+                                unconditional_guidance_scale=7.5, unconditional_conditioning=uc, eta=0.0, x_T=x_T,
+                                img_callback=lambda px0, i: inter.append(px0.clone()), log_every_t=1)
+    out["traj_w4a8_final"] = samples
+    out["traj_w4a8_predx0"] = torch.stack(inter)
+    qnn.set_quant_state(False, False)
+    samples, _ = sampler.sample(S=4, conditioning=ctx, batch_size=2, shape=[4, 8, 8], verbose=False,
+                                unconditional_guidance_scale=7.5, unconditional_conditioning=uc, eta=0.0, x_T=x_T)
+    out["traj_fp_final"] = samples
+    save("f11_ldm_tiny", **out)
+
+
+if __name__ == "__main__":
+    main()

@@ -77,9 +77,13 @@ _SIGS = {
     "tfmq_linear_small_w4": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, QSel, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "tfmq_groupnorm": (c_int, [c_void_p, C.POINTER(GnDesc), c_void_p]),
     "tfmq_groupnorm_from_stats": (c_int, [c_void_p, C.POINTER(GnDesc), c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
+    "tfmq_layernorm": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, C.c_long, c_int, QSel, c_void_p, c_void_p, c_void_p]),
+    "tfmq_geglu": (c_int, [c_void_p, c_void_p, C.c_long, c_int, QSel, c_void_p, c_void_p, c_void_p]),
     "tfmq_attention": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p, QSel,
                                c_int, c_int, c_int, c_int, c_int, c_float, c_void_p]),
     "tfmq_ddim_update": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p]),
+    "tfmq_ddim_update_cfg": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_size_t,
+                                     c_void_p, c_void_p, c_void_p]),
     "tfmq_step_advance": (c_int, [c_void_p, c_void_p, c_int, c_void_p]),
     "tfmq_silu": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "tfmq_nchw_to_nhwc": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),

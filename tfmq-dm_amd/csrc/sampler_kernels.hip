@@ -35,6 +35,42 @@ extern "C" int tfmq_ddim_update(tfmq_handle h, const float* x, const float* eps,
   return TFMQ_OK;
 }
 
+// latent DDIM step with classifier-free guidance (p_sample_ddim, ldm/models/diffusion/ddim.py:181-211):
+//   e = e_u + s (e_c - e_u);  x0 = (x - sqrt(1-a_t) e)/sqrt(a_t);  x' = sqrt(a_prev) x0 + sqrt(1-a_prev-sig^2) e + sig z
+// (same coef row layout as k_ddim_update; note the reference adds dir_xt before the noise here)
+__global__ __launch_bounds__(256) void k_ddim_update_cfg(const float* __restrict__ x, const float* __restrict__ eps_u,
+                                                         const float* __restrict__ eps_c, float scale,
+                                                         const float* __restrict__ z, float* __restrict__ xn,
+                                                         float* __restrict__ x0o, size_t n,
+                                                         const float* __restrict__ coef, const int32_t* __restrict__ step) {
+  const float* c = coef + static_cast<size_t>(step ? *step : 0) * 8;
+  const float s1m = c[0], sa = c[1], san = c[2], c1 = c[3], c2 = c[4];
+  const size_t stride = static_cast<size_t>(gridDim.x) * blockDim.x;
+  for (size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const float eu = eps_u[i];
+    const float e = eu + scale * (eps_c[i] - eu);
+    const float x0 = (x[i] - s1m * e) / sa;
+    if (x0o) x0o[i] = x0;
+    float r = san * x0;
+    r = r + c2 * e;
+    r = r + c1 * (z ? z[i] : 0.0f);
+    xn[i] = r;
+  }
+}
+
+extern "C" int tfmq_ddim_update_cfg(tfmq_handle h, const float* x, const float* eps_u, const float* eps_c, float scale,
+                                    const float* noise, float* x_next, float* x0, size_t n, const float* coef,
+                                    const int32_t* step, void* stream) {
+  TFMQ_CHECK_ARG(h, h && x && eps_u && eps_c && x_next && coef, "ddim_update_cfg: null pointer");
+  if (n == 0) return TFMQ_OK;
+  int blocks = ceil_div(static_cast<long>(n), 256);
+  if (blocks > h->cu_count * 8) blocks = h->cu_count * 8;
+  hipLaunchKernelGGL(k_ddim_update_cfg, dim3(blocks), dim3(256), 0, as_stream(stream), x, eps_u, eps_c, scale, noise, x_next,
+                     x0, n, coef, step);
+  TFMQ_LAUNCH_CHECK(h);
+  return TFMQ_OK;
+}
+
 __global__ void k_step_advance(int32_t* step, int delta) {
   if (threadIdx.x == 0 && blockIdx.x == 0) *step += delta;
 }

@@ -195,11 +195,19 @@ class DdimUNetEngine:
     def tib(self, t: torch.Tensor) -> List[torch.Tensor]:
         """QuantTemporalInformationBlockDDIM.forward (quant/quant_block.py:52-64): t [m] fp32 ->
         list of the per-ResnetBlock projections [m, Cout_i]."""
-        emb = ops.timestep_embedding(t, self.cfg["ch"])
-        h = self._linear("temb.dense.0", emb, False)
-        temb = self._linear("temb.dense.1", h, True)
+        d0, d1, projs, dim, ldm = self.tib_layout()
+        emb = ops.timestep_embedding(t, dim, ldm_order=ldm)
+        h = self._linear(d0, emb, False)
+        temb = self._linear(d1, h, True)
         self._last_temb = temb
-        return [self._linear(r + ".temb_proj", temb, True) for r in self.res_names]
+        return [self._linear(n, temb, True) for n in projs]
+
+    def tib_layout(self):
+        """(dense0, dense1, [projection layer names], embedding dim, ldm sin/cos order)"""
+        return "temb.dense.0", "temb.dense.1", [r + ".temb_proj" for r in self.res_names], self.cfg["ch"], False
+
+    def tib_widths(self):
+        return [self.sd[n + ".weight"].shape[0] for n in self.tib_layout()[2]]
 
     def build_tib_table(self, t_values: Sequence[float]):
         """The TIB depends only on the step: evaluate it once per sampling step (with that
@@ -215,22 +223,22 @@ class DdimUNetEngine:
             rows.append(torch.cat(self.tib(t), dim=1))
         self.tib_table = torch.cat(rows, dim=0).contiguous()
         off = 0
-        for r in self.res_names:
+        for r, wdt in zip(self.res_names, self.tib_widths()):
             self.tib_off[r] = off
-            off += self.sd[r + ".temb_proj.weight"].shape[0]
+            off += wdt
         if self.step is not None:
             self.step.zero_()
         return self.tib_table
 
     # ------------------------------------------------------------------ blocks
-    def _gn(self, name, x1, x2, silu, layer: Optional[_Layer], want_cat=False):
+    def _gn(self, name, x1, x2, silu, layer: Optional[_Layer], want_cat=False, eps=1e-6):
         aq = layer.aq if (layer is not None and layer.kind == "w4a8") else None
         if aq is not None and self.calib is not None:
-            _, yf, xcat = ops.groupnorm(x1, self.sd[name + ".weight"], self.sd[name + ".bias"], 1e-6, silu, None, x2=x2,
+            _, yf, xcat = ops.groupnorm(x1, self.sd[name + ".weight"], self.sd[name + ".bias"], eps, silu, None, x2=x2,
                                         want_f32=True, want_cat=want_cat)
             self._observe(aq, yf, getattr(layer, "sibling_qids", ()))
             return ops.quantize_act(yf, aq), xcat
-        yq, yf, xcat = ops.groupnorm(x1, self.sd[name + ".weight"], self.sd[name + ".bias"], 1e-6, silu, aq, x2=x2,
+        yq, yf, xcat = ops.groupnorm(x1, self.sd[name + ".weight"], self.sd[name + ".bias"], eps, silu, aq, x2=x2,
                                      want_cat=want_cat)
         return (yq if aq is not None else yf), xcat
 

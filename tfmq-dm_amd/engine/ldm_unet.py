@@ -1,0 +1,254 @@
+"""Latent-diffusion UNet with SpatialTransformer blocks (Stable Diffusion v1 family) lowered to the HIP
+kernels.  Dataflow of `UNetModel.forward` (ldm/modules/diffusionmodules/openaimodel.py:744-780) with
+`QuantResBlock` / `QuantBasicTransformerBlock` / `cross_attn_forward` (quant/quant_block.py:178-299):
+
+  ResBlock            GN32(1e-5)+SiLU+quant -> conv3x3 (+emb row) -> GN+SiLU+quant -> conv3x3 (+skip / 1x1 FP skip)
+  SpatialTransformer  GN(1e-6)+quant -> proj_in 1x1 -> tokens -> transformer block -> quant -> proj_out 1x1 (+x)
+  transformer block   LN+quant -> fused q|k|v GEMM -> flash attention (8 heads) -> quant -> to_out (+x)
+                      LN+quant -> to_q ; context -> quant -> fused k|v GEMM -> cross attention -> to_out (+x)
+                      LN+quant -> ff.net.0.proj -> GEGLU+quant -> ff.net.2 (+x)
+Token tensors [B,T,C] are NHWC images with W = 1, so every Linear over tokens is the same implicit-GEMM
+kernel as the 1x1 convs.  Attention matmuls stay un-quantised (their quantizers are never enabled,
+SURVEY §0 fact 2)."""
+from __future__ import annotations
+
+from typing import Dict, List, Optional
+
+import torch
+
+from .. import ops
+from .._lib import TfmqError
+from .ddim_unet import DdimUNetEngine, LayerQ, _Layer
+
+
+def _n_children(sd, prefix):
+    idx = set()
+    for k in sd:
+        if k.startswith(prefix + "."):
+            head = k[len(prefix) + 1:].split(".")[0]
+            if head.isdigit():
+                idx.add(int(head))
+    return len(idx)
+
+
+def ldm_resblock_paths(sd) -> List[str]:
+    out = []
+    for grp in ("input_blocks", "middle_block", "output_blocks"):
+        if grp == "middle_block":
+            out += [f"{grp}.{j}" for j in range(_n_children(sd, grp)) if f"{grp}.{j}.in_layers.0.weight" in sd]
+            continue
+        for i in range(_n_children(sd, grp)):
+            out += [f"{grp}.{i}.{j}" for j in range(_n_children(sd, f"{grp}.{i}")) if f"{grp}.{i}.{j}.in_layers.0.weight" in sd]
+    return out
+
+
+class LdmUNetEngine(DdimUNetEngine):
+    """cfg: model_channels, num_heads (head dim = channels // num_heads), in_channels."""
+
+    def __init__(self, sd: Dict[str, torch.Tensor], cfg: dict, device="cuda:0"):
+        # token Linears become 1x1 convs (same GEMM kernel); the TIB Linears stay small GEMVs
+        sd2 = {}
+        for k, v in sd.items():
+            if k.endswith(".weight") and v.dim() == 2 and not (k.startswith("time_embed") or ".emb_layers." in k):
+                v = v.reshape(v.shape[0], v.shape[1], 1, 1)
+            sd2[k] = v
+        super().__init__(sd2, dict(cfg), device)
+        self.res_names = ldm_resblock_paths(self.sd)
+
+    def tib_layout(self):
+        return ("time_embed.0", "time_embed.2", [r + ".emb_layers.1" for r in self.res_names],
+                self.cfg["model_channels"], True)
+
+    # ------------------------------------------------------------------ prepare: add fused k|v of the cross attention
+    def prepare(self, wq=None, qtable=None, step=None):
+        super().prepare(wq, qtable, step)
+        wq = wq or {}
+        self.fused_kv: Dict[str, _Layer] = {}
+        # self-attention q|k|v: the base class fuses names ending in ".q"; here the layers are to_q/to_k/to_v
+        for n in list(self.layers):
+            if not n.endswith(".to_q"):
+                continue
+            p = n[:-5]
+            names3 = [p + s for s in (".to_q", ".to_k", ".to_v")]
+            ls = [self.layers[x] for x in names3]
+            if p.endswith("attn1"):
+                f = self._fuse(ls, [wq.get(x) for x in names3])
+                if f is not None:
+                    self.fused_qkv[p] = f
+            else:
+                f = self._fuse(ls[1:], [wq.get(x) for x in names3[1:]])
+                if f is not None:
+                    self.fused_kv[p] = f
+
+    def _fuse(self, ls, qs):
+        kinds = {l.kind for l in ls}
+        if len(kinds) != 1:
+            return None
+        if ls[0].kind == "w4a8":
+            ids = [q.qid for q in qs]
+            if not all(bool(torch.equal(self.qtable[:, ids[0]], self.qtable[:, i])) for i in ids[1:]):
+                return None
+            bias = None if ls[0].p.bias is None else torch.cat([l.p.bias for l in ls])
+            pk = ops.PackedW4(torch.cat([l.p.packed for l in ls]), torch.cat([l.p.wmeta for l in ls]),
+                              torch.cat([l.p.wscale for l in ls]), bias, sum(l.p.cout for l in ls), ls[0].p.cin, 1, 1)
+            f = _Layer("w4a8", pk, ls[0].aq)
+            f.sibling_qids = tuple(ids[1:])
+            return f
+        pf = ls[0].p
+        ws = None if pf.wscale is None else torch.cat([l.p.wscale for l in ls])
+        bias = None if pf.bias is None else torch.cat([l.p.bias for l in ls])
+        return _Layer(ls[0].kind, ops.PackedF16(torch.cat([l.p.w16 for l in ls]), bias, sum(l.p.cout for l in ls), pf.cin, 1, 1, ws), None)
+
+    # ------------------------------------------------------------------ helpers
+    def _quant_in(self, layer: _Layer, x: torch.Tensor, siblings=()):
+        """fp32 tensor -> what `layer` consumes (int8 under its activation quantizer, or fp32)."""
+        if layer.kind != "w4a8":
+            return x
+        if self.calib is not None:
+            self._observe(layer.aq, x, siblings)
+        return ops.quantize_act(x, layer.aq)
+
+    def _ln(self, name, x, layer: _Layer):
+        g, b = self.sd[name + ".weight"], self.sd[name + ".bias"]
+        if layer.kind == "w4a8" and self.calib is None:
+            return ops.layernorm(x, g, b, 1e-5, layer.aq)[0]
+        yf = ops.layernorm(x, g, b, 1e-5, None)[1]
+        return self._quant_in(layer, yf, getattr(layer, "sibling_qids", ()))
+
+    def _tok(self, layer: _Layer, x, **kw):
+        """Linear over tokens: x [B,T,C] (int8 or fp32) -> fp32 [B,T,N]."""
+        B, T, Cc = x.shape
+        kw.setdefault("want_stats", False)
+        if "residual" in kw and kw["residual"] is not None:
+            kw["residual"] = kw["residual"].reshape(B, T, 1, -1)
+        y = layer.run(x.reshape(B, T, 1, Cc), **kw)
+        return y.reshape(B, T, -1)
+
+    # ------------------------------------------------------------------ blocks
+    def _res(self, p, x1, x2, rowadd_kw):
+        L = self.layers
+        cin, cout = L[p + ".in_layers.2"], L[p + ".out_layers.3"]
+        has_skip = (p + ".skip_connection") in L
+        if x2 is not None and not has_skip:
+            raise TfmqError(f"{p}: concatenated input without skip_connection")
+        h, xcat = self._gn(p + ".in_layers.0", x1, x2, True, cin, want_cat=has_skip and x2 is not None, eps=1e-5)
+        h = cin.run(h, pad=(1, 1, 1, 1), **rowadd_kw)
+        h, _ = self._gn(p + ".out_layers.0", h, None, True, cout, eps=1e-5)
+        sc = L[p + ".skip_connection"].run(xcat if x2 is not None else x1, want_stats=False) if has_skip else x1
+        return cout.run(h, pad=(1, 1, 1, 1), residual=sc)
+
+    def _attention(self, p, xq_src, ctx, x_res, self_attn: bool):
+        """one CrossAttention + residual; xq_src: LN output already in to_q's input form."""
+        L = self.layers
+        heads = self.cfg["num_heads"]
+        to_out = L[p + ".to_out.0"]
+        if self_attn and p in self.fused_qkv:
+            qkv = self._tok(self.fused_qkv[p], xq_src)
+            Cc = qkv.shape[-1] // 3
+            q, k, v = qkv[..., :Cc], qkv[..., Cc:2 * Cc], qkv[..., 2 * Cc:]
+        else:
+            q = self._tok(L[p + ".to_q"], xq_src)
+            Cc = q.shape[-1]
+            if self_attn:
+                k = self._tok(L[p + ".to_k"], xq_src)
+                v = self._tok(L[p + ".to_v"], xq_src)
+            elif p in self.fused_kv:
+                f = self.fused_kv[p]
+                kv = self._tok(f, self._quant_in(f, ctx, getattr(f, "sibling_qids", ())))
+                k, v = kv[..., :Cc], kv[..., Cc:]
+            else:
+                k = self._tok(L[p + ".to_k"], self._quant_in(L[p + ".to_k"], ctx))
+                v = self._tok(L[p + ".to_v"], self._quant_in(L[p + ".to_v"], ctx))
+        d = Cc // heads
+        aq = to_out.aq if to_out.kind == "w4a8" else None
+        if aq is not None and self.calib is None:
+            _, o = ops.attention(q, k, v, heads, float(d ** -0.5), aq, want_f32=False)
+        else:
+            o, _ = ops.attention(q, k, v, heads, float(d ** -0.5))
+            o = self._quant_in(to_out, o)
+        return self._tok(to_out, o, residual=x_res)
+
+    def _tblock(self, p, x, ctx):
+        L = self.layers
+        q1 = self.fused_qkv.get(p + ".attn1", L[p + ".attn1.to_q"])
+        x = self._attention(p + ".attn1", self._ln(p + ".norm1", x, q1), None, x, True)
+        x = self._attention(p + ".attn2", self._ln(p + ".norm2", x, L[p + ".attn2.to_q"]), ctx, x, False)
+        ff0, ff2 = L[p + ".ff.net.0.proj"], L[p + ".ff.net.2"]
+        h = self._tok(ff0, self._ln(p + ".norm3", x, ff0))
+        if ff2.kind == "w4a8" and self.calib is None:
+            g = ops.geglu(h, ff2.aq)[0]
+        else:
+            g = self._quant_in(ff2, ops.geglu(h, None)[1])
+        return self._tok(ff2, g, residual=x)
+
+    def _st(self, p, x, ctx):
+        L = self.layers
+        B, H, W, Cc = x.shape
+        pin, pout = L[p + ".proj_in"], L[p + ".proj_out"]
+        h, _ = self._gn(p + ".norm", x, None, False, pin, eps=1e-6)
+        h = pin.run(h, want_stats=False)
+        tok = h.reshape(B, H * W, h.shape[-1])
+        for i in range(_n_children(self.sd, p + ".transformer_blocks")):
+            tok = self._tblock(f"{p}.transformer_blocks.{i}", tok, ctx)
+        h = self._quant_in(pout, tok.reshape(B, H, W, -1))
+        return pout.run(h, residual=x)
+
+    def _seq(self, p, h, skip, ctx, rowadd, taps):
+        L = self.layers
+        for j in range(_n_children(self.sd, p)):
+            q = f"{p}.{j}"
+            hin = h
+            if (q + ".in_layers.0.weight") in self.sd:
+                h = self._res(q, h, skip if j == 0 else None, rowadd(q))
+                if taps is not None:
+                    taps[q] = ((hin, skip) if (j == 0 and skip is not None) else hin, h)
+            elif (q + ".transformer_blocks.0.norm1.weight") in self.sd:
+                h = self._st(q, h, ctx)
+                if taps is not None:
+                    taps[q] = (hin, h)
+            elif (q + ".op") in L:
+                h = L[q + ".op"].run(h, stride=2, pad=(1, 1, 1, 1))
+            elif (q + ".conv") in L:
+                up = L[q + ".conv"]
+                h = up.run(self._quant_in(up, h), pad=(1, 1, 1, 1), up2x=True)
+            elif q in L:
+                h = L[q].run(h, pad=(1, 1, 1, 1))
+            else:
+                raise TfmqError(f"LdmUNetEngine: unknown child {q}")
+        return h
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, x: torch.Tensor, t: Optional[torch.Tensor] = None, context: Optional[torch.Tensor] = None,
+                taps: Optional[dict] = None) -> torch.Tensor:
+        """x: fp32 NHWC latents [B,H,W,C]; t: [B] timesteps (or None -> per-step TIB table); context: fp32 [B,L,D]."""
+        if not self.prepared:
+            raise TfmqError("LdmUNetEngine.forward before prepare()")
+        if context is None:
+            raise TfmqError("LdmUNetEngine: SpatialTransformer UNets need a context tensor")
+        L = self.layers
+        if t is not None:
+            projs = dict(zip(self.res_names, self.tib(t)))
+            if taps is not None:
+                taps["__temb__"] = self._last_temb
+
+            def rowadd(p):
+                return dict(rowadd=projs[p])
+        else:
+            if self.tib_table is None:
+                raise TfmqError("forward(t=None) needs build_tib_table() first")
+
+            def rowadd(p):
+                o = self.tib_off[p]
+                return dict(rowadd=self.tib_table[0, o:], rowadd_ld=0, rowadd_step=self.step,
+                            rowadd_step_stride=self.tib_table.shape[1])
+        ctx = context.contiguous()
+        hs = []
+        h = x
+        for i in range(_n_children(self.sd, "input_blocks")):
+            h = self._seq(f"input_blocks.{i}", h, None, ctx, rowadd, taps)
+            hs.append(h)
+        h = self._seq("middle_block", h, None, ctx, rowadd, taps)
+        for i in range(_n_children(self.sd, "output_blocks")):
+            h = self._seq(f"output_blocks.{i}", h, hs.pop(), ctx, rowadd, taps)
+        h, _ = self._gn("out.0", h, None, True, None, eps=1e-5)
+        return L["out.2"].run(h, pad=(1, 1, 1, 1), want_stats=False)

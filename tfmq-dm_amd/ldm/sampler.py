@@ -1,0 +1,104 @@
+"""Latent DDIM sampling with classifier-free guidance on the HIP engine.
+
+Host side = schedule constants exactly as the reference builds them (make_beta_schedule /
+register_schedule ldm/models/diffusion/ddpm.py:117-131, make_ddim_timesteps /
+make_ddim_sampling_parameters ldm/modules/diffusionmodules/util.py:46-74); device side = one hipGraph
+replay per step: duplicate the latent for the (uncond, cond) halves, UNet forward on the batch-2B plan with
+the step's Finite-Set activation table (k = t_max - (t-1)//tot == step counter), CFG combine +
+DDIM update in one kernel, step counter increment (DDIMSampler.ddim_sampling / p_sample_ddim,
+ldm/models/diffusion/ddim.py:118-212)."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import numpy as np
+import torch
+
+from .. import ops
+from .._lib import TfmqError, handle
+
+
+def alphas_cumprod_linear(linear_start: float = 0.00085, linear_end: float = 0.012, n: int = 1000) -> torch.Tensor:
+    betas = (torch.linspace(linear_start ** 0.5, linear_end ** 0.5, n, dtype=torch.float64) ** 2).numpy()
+    return torch.tensor(np.cumprod(1.0 - betas, axis=0), dtype=torch.float32)
+
+
+def ddim_timesteps(S: int, n: int = 1000) -> np.ndarray:
+    return np.asarray(list(range(0, n, n // S))) + 1
+
+
+def ddim_coef_table(alphas_cumprod: torch.Tensor, S: int, eta: float = 0.0) -> torch.Tensor:
+    """Row i (i-th executed step) = {sqrt(1-a_t), sqrt(a_t), sqrt(a_prev), sigma, sqrt(1-a_prev-sigma^2), t, 0, 0}
+    with the fp32 tensor arithmetic of p_sample_ddim."""
+    ts = ddim_timesteps(S, alphas_cumprod.shape[0])
+    a = alphas_cumprod[ts]
+    a_prev = torch.tensor([float(alphas_cumprod[0])] + alphas_cumprod[ts[:-1]].tolist(), dtype=torch.float32)
+    sig = eta * torch.sqrt((1 - a_prev) / (1 - a) * (1 - a / a_prev))
+    rows = []
+    for i, step in enumerate(np.flip(ts)):
+        idx = S - i - 1
+        a_t, ap, sg = a[idx].reshape(1), a_prev[idx].reshape(1), sig[idx].reshape(1).float()
+        rows.append(torch.cat([torch.sqrt(1.0 - a[idx]).reshape(1), a_t.sqrt(), ap.sqrt(), sg, (1.0 - ap - sg ** 2).sqrt(),
+                               torch.tensor([float(step)]), torch.zeros(2)]))
+    return torch.stack(rows).float().contiguous()
+
+
+class GraphLatentDdimSampler:
+    def __init__(self, engine, S: int, batch: int, latent_shape, context_shape, scale: float = 7.5,
+                 alphas_cumprod: Optional[torch.Tensor] = None, eta: float = 0.0):
+        if eta != 0.0:
+            raise TfmqError("GraphLatentDdimSampler: eta != 0 needs a device RNG stream (not wired yet)")
+        self.eng, self.S, self.batch, self.scale = engine, S, batch, float(scale)
+        self.dev = engine.dev
+        ac = alphas_cumprod if alphas_cumprod is not None else alphas_cumprod_linear()
+        self.coef = ddim_coef_table(ac, S, eta).to(self.dev)
+        if engine.step is None:
+            raise TfmqError("GraphLatentDdimSampler: engine.prepare() needs a device step counter")
+        self.step = engine.step
+        engine.build_tib_table([float(t) for t in np.flip(ddim_timesteps(S, ac.shape[0]))])
+        Cc, H, W = latent_shape
+        self.x = torch.empty(batch, H, W, Cc, device=self.dev)
+        self.x2 = torch.empty(2 * batch, H, W, Cc, device=self.dev)
+        self.ctx2 = torch.empty((2 * batch,) + tuple(context_shape), device=self.dev)
+        self.stream = torch.cuda.Stream(self.dev)
+        self.arena = ops.Arena()
+        self.h = handle(self.dev.index or 0)
+        self.gid = None
+
+    def _step_body(self):
+        B = self.batch
+        self.x2[:B].copy_(self.x)
+        self.x2[B:].copy_(self.x)
+        eps2 = self.eng.forward(self.x2, None, self.ctx2)
+        ops.ddim_update_cfg(self.x, eps2[:B], eps2[B:], self.scale, self.coef, self.step, out=self.x)
+        ops.step_advance(self.step, 1)
+
+    def capture(self):
+        sp = C.c_void_p(self.stream.cuda_stream)
+        with torch.cuda.stream(self.stream):
+            self.step.zero_()
+            with ops.use_arena(self.arena):
+                self._step_body()
+            self.stream.synchronize()
+            with ops.use_arena(self.arena):
+                self.h.call("graph_begin", sp)
+                self._step_body()
+                gid = C.c_int()
+                self.h.call("graph_end", sp, C.byref(gid))
+            self.gid = gid.value
+        return self
+
+    def sample_nhwc(self, x_T: torch.Tensor, cond: torch.Tensor, uncond: torch.Tensor, steps: Optional[int] = None):
+        """x_T [B,H,W,C]; cond/uncond [B,L,D] (CLIP / class embeddings: glue, computed elsewhere)."""
+        if self.gid is None:
+            self.capture()
+        sp = C.c_void_p(self.stream.cuda_stream)
+        with torch.cuda.stream(self.stream):
+            self.x.copy_(x_T, non_blocking=True)
+            self.ctx2[:self.batch].copy_(uncond, non_blocking=True)   # c_in = cat[uc, c]  (ddim.py:183)
+            self.ctx2[self.batch:].copy_(cond, non_blocking=True)
+            self.step.zero_()
+            for _ in range(self.S if steps is None else steps):
+                self.h.call("graph_launch", self.gid, sp)
+        return self.x

@@ -426,6 +426,36 @@ def groupnorm(x1: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: fl
     return yq, yf, xcat
 
 
+# ------------------------------------------------------------------------------ K9
+def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float = 1e-5, aq: Optional[QSel] = None,
+              want_f32: bool = False):
+    """x: fp32 [..., C] tokens.  Returns (yq int8 | None, yf fp32 | None)."""
+    d = _dev(x)
+    _chk(x, torch.float32, "x")
+    Cc = x.shape[-1]
+    rows = x.numel() // Cc
+    quant = aq is not None and bool(aq.qtable)
+    yq = _alloc(x.shape, dtype=torch.int8, device=x.device) if quant else None
+    yf = _alloc_like(x) if (want_f32 or not quant) else None
+    handle(d).call("layernorm", _p(x), _p(gamma), _p(beta), float(eps), rows, Cc, aq if quant else QSel(None, None, 0, 0),
+                   _p(yq), _p(yf), _stream(d))
+    return yq, yf
+
+
+def geglu(hin: torch.Tensor, aq: Optional[QSel] = None, want_f32: bool = False):
+    """hin: fp32 [..., 2*inner] -> x * gelu(gate) as (int8 | None, fp32 | None) of shape [..., inner]."""
+    d = _dev(hin)
+    _chk(hin, torch.float32, "hin")
+    inner = hin.shape[-1] // 2
+    rows = hin.numel() // hin.shape[-1]
+    shape = tuple(hin.shape[:-1]) + (inner,)
+    quant = aq is not None and bool(aq.qtable)
+    yq = _alloc(shape, dtype=torch.int8, device=hin.device) if quant else None
+    yf = _alloc(shape, dtype=torch.float32, device=hin.device) if (want_f32 or not quant) else None
+    handle(d).call("geglu", _p(hin), rows, inner, aq if quant else QSel(None, None, 0, 0), _p(yq), _p(yf), _stream(d))
+    return yq, yf
+
+
 # ------------------------------------------------------------------------------ K10
 def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int, scale: float, aq: Optional[QSel] = None,
               want_f32: bool = True):
@@ -456,6 +486,16 @@ def ddim_update(x, eps, coef, step=None, noise=None, want_x0=False, out=None):
     xn = out if out is not None else _alloc_like(x)
     x0 = _alloc_like(x) if want_x0 else None
     handle(d).call("ddim_update", _p(x), _p(eps), _p(noise), _p(xn), _p(x0), x.numel(), _p(coef), _p(step), _stream(d))
+    return (xn, x0) if want_x0 else xn
+
+
+def ddim_update_cfg(x, eps_u, eps_c, scale: float, coef, step=None, noise=None, want_x0=False, out=None):
+    """Classifier-free-guidance combine + DDIM update in one pass (out=x allowed)."""
+    d = _dev(x)
+    xn = out if out is not None else _alloc_like(x)
+    x0 = _alloc_like(x) if want_x0 else None
+    handle(d).call("ddim_update_cfg", _p(x), _p(eps_u), _p(eps_c), float(scale), _p(noise), _p(xn), _p(x0), x.numel(), _p(coef),
+                   _p(step), _stream(d))
     return (xn, x0) if want_x0 else xn
 
 
