@@ -1,21 +1,27 @@
 #!/usr/bin/env python
 """Headline benchmark of the TFMQ-DM hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--workload sd|cifar]
     (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...)
 
-Workload (BASELINE.json configs[1]): DDIM CIFAR-10 w4a8 -- DDPM UNet (35.7 M params, 32x32x3),
-DDIM-100 'quad' schedule, eta = 0, 256-image batch per GPU, one Finite-Set-Calibration activation
-table per step, synthetic N(0,1) latents and random-init weights (no checkpoints offline).
-One "step" = one full 100-step sampling of one 256-image batch on every rank (UNet evals + DDIM
-updates only, the timing region of sample_diffusion_ldm.py:127-150).  Sampling shards with no
-exchange (images are independent): weak scaling, value = total images / max-over-ranks time.
+Workloads
+  sd     (default; BASELINE.json's metric config, configs[3]): Stable Diffusion v1-4 UNet (859.5 M params),
+         w4a8, DDIM-50 eta 0, classifier-free guidance 7.5 (UNet batch = 2 x images), 64x64x4 latents,
+         77x768 context, one Finite-Set-Calibration activation table per step.  One "step" = one full
+         50-step sampling of `--batch` images on every rank.
+  cifar  (configs[1]): DDPM UNet 35.7 M, 32x32x3, DDIM-100 quad, 256-image batch per GPU.
+Synthetic data in both cases (no checkpoints / datasets offline): N(0,1) latents and context, random-init
+weights with the reference's initialisers (zero parameters re-drawn N(0, 0.02^2)), per-channel MSE weight scales
+computed on the device, synthetic FSC tables (MINMAX of the actual activations at every step).
+Timing region = UNet evaluations + sampler updates only (sample_diffusion_ldm.py:127-150); text encoder and
+VAE are glue and excluded.  Sampling shards with no exchange: weak scaling, value = total images / max time.
 
 The JSON line also carries
-  roofline    : the dominant kernel (w4a8 implicit-GEMM conv, int8 MFMA) -- algorithmic int8 ops of
-                every launch of one UNet forward / its HIP-event-measured duration, vs 5 POP/s dense.
-  cpu_baseline: the CPU oracle (torch-CPU restatement of the reference's fake-quant path) timed on
-                this box's host cores on a bounded sample of the same workload.
+  roofline    : dominant kernel = the w4a8 implicit-GEMM (int8 MFMA): algorithmic int8 ops of every launch of
+                UNet forwards / their HIP-event-measured durations (launch stream), vs the 5 POP/s dense int8
+                peak; `traffic` = PMC HBM bytes per launch from profiles/ (rocprofv3, separate passes).
+  cpu_baseline: the CPU oracle (torch-CPU restatement of the reference's fake-quant path) on this box's host
+                cores, bounded sample of the same workload.
 """
 import argparse
 import json
@@ -31,6 +37,7 @@ sys.path.insert(0, ROOT)
 INT8_PEAK_TOPS = 5000.0  # dense int8 MFMA peak of MI355X (2x the 2.5 PF bf16 dense peak, MI355X_MICROARCH.md)
 
 
+# ------------------------------------------------------------------------------------------------ cifar
 def build_quantized_engine(dev, batch, n_steps, seed=1234, log=lambda *a: None):
     import tfmq_dm_amd.ddim.models as M
     from tfmq_dm_amd.ddim.sampler import linear_betas, step_sequence
@@ -50,31 +57,165 @@ def build_quantized_engine(dev, batch, n_steps, seed=1234, log=lambda *a: None):
     step = torch.zeros(1, dtype=torch.int32, device=dev)
     eng = DdimUNetEngine(sd, cfg, dev)
     eng.prepare(wq, qtable, step)
-    # synthetic Finite-Set Calibration: one group of N(0,1) latents per sampling step, MINMAX scaler
-    # (what the reference's running-stat pass ends with), at the benchmark batch so that every conv
-    # launch of the process has the shapes of the timed region (keeps rocprof averages comparable).
-    calib_batch = batch
+    # synthetic Finite-Set Calibration at the benchmark batch (every conv launch of the process then has the
+    # shapes of the timed region, which keeps rocprof per-kernel averages comparable with the live ones)
     t0 = time.time()
     g = torch.Generator(device="cpu").manual_seed(seed + 1)
     groups = []
     for i in reversed(seq):
-        x = torch.randn(calib_batch, cfg["resolution"], cfg["resolution"], 3, generator=g).to(dev)
-        groups.append((x, torch.full((calib_batch,), float(i), device=dev)))
-    Q.calibrate_activations(eng, groups, running_stat=False, init_batch=calib_batch, scaler="minmax")
+        x = torch.randn(batch, cfg["resolution"], cfg["resolution"], 3, generator=g).to(dev)
+        groups.append((x, torch.full((batch,), float(i), device=dev)))
+    Q.calibrate_activations(eng, groups, running_stat=False, init_batch=batch, scaler="minmax")
     torch.cuda.synchronize()
-    log(f"synthetic activation calibration ({n_steps} groups x {calib_batch}, minmax): {time.time() - t0:.2f}s")
+    log(f"synthetic activation calibration ({n_steps} groups x {batch}, minmax): {time.time() - t0:.2f}s")
     return eng, cfg, sd, wq, names, seq, linear_betas()
 
 
-def conv_roofline(eng, x, n_fwd=3):
-    """Per-launch HIP-event timing (on the launch stream) of every w4a8 conv launch of a UNet forward."""
+def setup_cifar(args, dev, rank, log):
+    from tfmq_dm_amd.ddim.sampler import GraphDdimSampler
+    batch = args.batch or 256
+    n_steps = args.ddim_steps or 100
+    eng, cfg, sd, wq, names, seq, betas = build_quantized_engine(dev, batch, n_steps, log=log)
+    sampler = GraphDdimSampler(eng, seq, betas, batch).capture()
+    log(f"captured DDIM step graph; activations arena {sampler.arena.nbytes() / 2**30:.2f} GiB")
+    g = torch.Generator(device="cpu").manual_seed(1234 + rank)
+    x_T = torch.randn(batch, cfg["resolution"], cfg["resolution"], 3, generator=g).to(dev)
+
+    def run():
+        sampler.sample_nhwc(x_T)
+
+    def fwd():
+        eng.forward(sampler.x, None)
+
+    def cpu():
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import tfmq_oracle as O
+        qt = eng.qtable.cpu()
+        sdc = {k: v.cpu() for k, v in sd.items()}
+        wqc = {n: {"delta": q.delta.cpu(), "zp": q.zp.cpu(), "alpha": None} for n, q in wq.items()}
+        cb, cs = 8, 4
+        x = torch.randn(cb, 3, cfg["resolution"], cfg["resolution"])
+
+        def model_fn(xt, t, cnt):
+            aq = {n: (qt[cnt, i, 0], qt[cnt, i, 1]) for i, n in enumerate(names)}
+            return O.ddim_unet_forward(sdc, dict(cfg), xt, t, O.QuantSpec(wq=wqc, aq=aq))
+        with torch.no_grad():
+            t0 = time.time()
+            O.generalized_steps(x, seq, model_fn, betas, until=cs + 1)
+            dt = time.time() - t0
+        return 1.0 / (dt / cs * len(seq) / cb), f"{cb} images x {cs} of the {len(seq)} DDIM steps = {dt:.1f}s, extrapolated to the full schedule"
+
+    info = dict(batch=batch, sync=sampler.stream.synchronize, finite=lambda: bool(torch.isfinite(sampler.x).all().item()),
+                stream=sampler.stream, step=eng.step,
+                workload=("DDIM CIFAR-10 w4a8 on MI355X: DDPM UNet 35.7M, 32x32x3, DDIM-100 quad eta=0, "
+                          f"{batch}-image batch per GPU (BASELINE.json configs[1])"),
+                extra={"batch_per_gpu": batch, "ddim_steps": len(seq), "unet_evals_per_step": len(seq)})
+    return run, fwd, cpu, info
+
+
+# ------------------------------------------------------------------------------------------------ stable diffusion
+def setup_sd(args, dev, rank, log):
+    import numpy as np
+    import tfmq_dm_amd.ldm.unet as U
+    import tfmq_dm_amd.ops as ops
+    from tfmq_dm_amd.ddim.models import random_init
+    from tfmq_dm_amd.engine import LayerQ, LdmUNetEngine
+    from tfmq_dm_amd.ldm.sampler import GraphLatentDdimSampler, alphas_cumprod_linear, ddim_timesteps
+
+    batch = args.batch or 8
+    S = args.ddim_steps or 50
+    scale = 7.5
+    t0 = time.time()
+    torch.manual_seed(40)
+    model = random_init(U.UNetModel(**U.SD_V1_UNET), 40)
+    cfg = model.engine_cfg()
+    sd = {k: v.detach() for k, v in model.state_dict().items()}
+    log(f"SD v1 UNet random init ({sum(v.numel() for v in sd.values()) / 1e6:.1f} M params): {time.time() - t0:.1f}s")
+    # QuantLayers in module order = every Conv2d / Linear except skip_connection / op (quant_model.py:57-58)
+    qnames = [k[:-7] for k in sd if k.endswith(".weight") and sd[k].dim() in (2, 4) and "skip_connection" not in k
+              and not k.endswith(".op.weight")]
+    fp = {qnames[0], qnames[2], qnames[-1]}
+    no_act = fp | {qnames[1], qnames[3]}
+    t0 = time.time()
+    wq = {}
+    for n in qnames:
+        if n in fp:
+            continue
+        w = sd[n + ".weight"].to(dev, torch.float32).contiguous()
+        qp = ops.mse_search(w, w.shape[0], 16)
+        wq[n] = LayerQ(qp[:, 0].contiguous(), qp[:, 1].contiguous(), None, None)
+    torch.cuda.synchronize()
+    log(f"weight-scale search (mse, per channel, {len(wq)} layers): {time.time() - t0:.2f}s")
+    act_names = [n for n in qnames if n not in no_act]
+    for i, n in enumerate(act_names):
+        wq[n].qid = i
+    qtable = torch.zeros(S, len(act_names), 2, device=dev)
+    step = torch.zeros(1, dtype=torch.int32, device=dev)
+    eng = LdmUNetEngine(sd, cfg, dev)
+    eng.prepare(wq, qtable, step)
+    # synthetic FSC: MINMAX of the activations at every step, on UNet batch 2 x batch
+    t0 = time.time()
+    g = torch.Generator(device="cpu").manual_seed(41 + rank)
+    ctx = torch.randn(2 * batch, 77, 768, generator=g).to(dev)
+    ts = np.flip(ddim_timesteps(S))
+    for k, tv in enumerate(ts):
+        eng.set_calibration("init_minmax", k)
+        x = torch.randn(2 * batch, 64, 64, 4, generator=g).to(dev)
+        eng.forward(x, torch.full((2 * batch,), float(tv), device=dev), ctx)
+    eng.set_calibration(None)
+    eng.prepare(wq, eng.qtable, step)   # re-evaluate the sibling-quantizer fusion with the calibrated table
+    torch.cuda.synchronize()
+    log(f"synthetic activation calibration ({S} groups x {2 * batch}, minmax): {time.time() - t0:.2f}s")
+    sampler = GraphLatentDdimSampler(eng, S, batch, (4, 64, 64), (77, 768), scale=scale,
+                                     alphas_cumprod=alphas_cumprod_linear()).capture()
+    log(f"captured CFG-DDIM step graph; activations arena {sampler.arena.nbytes() / 2**30:.2f} GiB")
+    x_T = torch.randn(batch, 64, 64, 4, generator=g).to(dev)
+    cond, uncond = ctx[batch:].contiguous(), ctx[:batch].contiguous()
+
+    def run():
+        sampler.sample_nhwc(x_T, cond, uncond)
+
+    def fwd():
+        eng.forward(sampler.x2, None, sampler.ctx2)
+
+    def cpu():
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import tfmq_oracle as O
+        qt = eng.qtable.cpu()
+        sdc = {k: v.cpu() for k, v in sd.items()}
+
+        def shp(n, v):
+            return v.cpu().reshape((-1,) + (1,) * (sdc[n + ".weight"].dim() - 1))
+        wqc = {n: {"delta": shp(n, q.delta), "zp": shp(n, q.zp), "alpha": None} for n, q in wq.items()}
+        cs = 1
+        xc = torch.randn(1, 4, 64, 64)
+        c1, u1 = torch.randn(1, 77, 768), torch.randn(1, 77, 768)
+        tsn, _, _ = O.ldm_ddim_schedule(O.ldm_alphas_cumprod(), S)
+        with torch.no_grad():
+            t0 = time.time()
+            for i, stp in enumerate(list(np.flip(tsn))[:cs]):
+                t = torch.full((2,), int(stp), dtype=torch.long)
+                aq = {n: (qt[i, j, 0], qt[i, j, 1]) for j, n in enumerate(act_names)}
+                O.ldm_unet_forward(sdc, dict(cfg), torch.cat([xc] * 2), t, torch.cat([u1, c1]), O.QuantSpec(wq=wqc, aq=aq))
+            dt = time.time() - t0
+        return 1.0 / (dt / cs * S), f"1 image (UNet batch 2, CFG) x {cs} of the {S} DDIM steps = {dt:.1f}s, extrapolated to the full schedule"
+
+    info = dict(batch=batch, sync=sampler.stream.synchronize, finite=lambda: bool(torch.isfinite(sampler.x).all().item()),
+                stream=sampler.stream, step=eng.step,
+                workload=("Stable Diffusion v1-4 UNet (859.5M) w4a8 on MI355X: 64x64x4 latents (512x512 images), DDIM-50 eta=0, "
+                          f"CFG 7.5 (UNet batch 2x{batch}), 77x768 context, {batch} images per GPU (BASELINE.json configs[3] = the metric's config)"),
+                extra={"batch_per_gpu": batch, "ddim_steps": S, "unet_evals_per_step": S, "unet_batch": 2 * batch, "guidance_scale": scale})
+    return run, fwd, cpu, info
+
+
+def conv_roofline(fwd, stream, n_fwd=2):
+    """Per-launch HIP-event timing (on the launch stream) of every w4a8 GEMM launch of UNet forwards."""
     import tfmq_dm_amd.ops as ops
     rec = []
     ops.set_conv_profile(rec)
-    stream = torch.cuda.current_stream()
     try:
         for _ in range(n_fwd):
-            eng.forward(x, None)
+            fwd()
         stream.synchronize()
     finally:
         ops.set_conv_profile(None)
@@ -86,39 +227,17 @@ def conv_roofline(eng, x, n_fwd=3):
         tot_bytes += nbytes
         tot_ms += ops.event_elapsed_ms(e0, e1)
         n += 1
-    return tot_ops, tot_ms, n, tot_bytes
-
-
-def cpu_baseline(cfg, sd, wq, names, qtable, seq, betas, batch=8, steps=4):
-    """Oracle (torch-CPU fake-quant UNet + DDIM update) on a bounded sample: `batch` images x `steps`
-    of the 100 DDIM steps; images/s extrapolated to the full 100-step schedule."""
-    sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    import tfmq_oracle as O
-    qt = qtable.cpu()
-    sdc = {k: v.cpu() for k, v in sd.items()}
-    wqc = {n: {"delta": q.delta.cpu(), "zp": q.zp.cpu(), "alpha": None} for n, q in wq.items()}
-    ocfg = dict(cfg)
-    x = torch.randn(batch, 3, cfg["resolution"], cfg["resolution"])
-
-    def model_fn(xt, t, cnt):
-        aq = {n: (qt[cnt, i, 0], qt[cnt, i, 1]) for i, n in enumerate(names)}
-        return O.ddim_unet_forward(sdc, ocfg, xt, t, O.QuantSpec(wq=wqc, aq=aq))
-
-    with torch.no_grad():
-        t0 = time.time()
-        O.generalized_steps(x, seq, model_fn, betas, until=steps + 1)
-        dt = time.time() - t0
-    per_image_full = dt / steps * len(seq) / batch
-    return 1.0 / per_image_full, dt
+    return tot_ops, tot_ms, n, tot_bytes, n_fwd
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=256)
-    ap.add_argument("--ddim-steps", type=int, default=100)
+    ap.add_argument("--workload", choices=["sd", "cifar"], default="sd")
+    ap.add_argument("--batch", type=int, default=0, help="images per GPU (default 8 for sd, 256 for cifar)")
+    ap.add_argument("--ddim-steps", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -139,12 +258,7 @@ def main():
         if rank == 0:
             print("[bench]", *a, file=sys.stderr, flush=True)
 
-    from tfmq_dm_amd.ddim.sampler import GraphDdimSampler
-    eng, cfg, sd, wq, names, seq, betas = build_quantized_engine(dev, args.batch, args.ddim_steps, log=log)
-    sampler = GraphDdimSampler(eng, seq, betas, args.batch).capture()
-    log(f"captured DDIM step graph; activations arena {sampler.arena.nbytes() / 2**30:.2f} GiB")
-    g = torch.Generator(device="cpu").manual_seed(1234 + rank)
-    x_T = torch.randn(args.batch, cfg["resolution"], cfg["resolution"], 3, generator=g).to(dev)
+    run, fwd, cpu, info = (setup_sd if args.workload == "sd" else setup_cifar)(args, dev, rank, log)
 
     def barrier():
         torch.cuda.synchronize()
@@ -153,63 +267,59 @@ def main():
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        sampler.sample_nhwc(x_T)
+        run()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        sampler.sample_nhwc(x_T)
-    sampler.stream.synchronize()
+        run()
+    info["sync"]()
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
-    x0 = sampler.x
-    finite = bool(torch.isfinite(x0).all().item())
+    finite = info["finite"]()
 
-    out = None
     if rank == 0:
-        images = args.batch * world * args.steps
+        images = info["batch"] * world * args.steps
         value = images / dt
-        # ---- roofline of the dominant kernel (HIP events around every launch, launch stream)
-        with torch.cuda.stream(sampler.stream):
-            eng.step.zero_()
-            tot_ops, tot_ms, n_launch, tot_bytes = conv_roofline(eng, sampler.x)
+        with torch.cuda.stream(info["stream"]):
+            info["step"].zero_()
+            tot_ops, tot_ms, n_launch, tot_bytes, n_fwd = conv_roofline(fwd, info["stream"])
+        achieved = tot_ops / (tot_ms * 1e-3) / 1e12 if tot_ms > 0 else 0.0
         traffic, traffic_src = None, None
-        tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
-        if os.path.exists(tpath):   # PMC bytes (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 passes) of the same kernel
+        tpath = os.path.join(ROOT, "profiles", f"r01_traffic_{args.workload}.json")
+        if os.path.exists(tpath):
             tj = json.load(open(tpath))["kernels"]
             ks = [v for k, v in tj.items() if k.startswith("void k_conv_igemm<true")]
             if ks:
                 traffic = sum(v["hbm_bytes_per_launch"] * v["launches"] for v in ks) / sum(v["launches"] for v in ks)
-                traffic_src = "profiles/r01_traffic.json (rocprofv3 --pmc, eager forwards of the same workload)"
-        achieved = tot_ops / (tot_ms * 1e-3) / 1e12 if tot_ms > 0 else 0.0
-        roof = {"bound": "mfma", "kernel": "k_conv_igemm<int8> (w4a8 implicit-GEMM conv / linear)",
+                traffic_src = (f"profiles/r01_traffic_{args.workload}.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, "
+                               "separate passes, eager forwards of the same workload)")
+        roof = {"bound": "mfma", "kernel": "k_conv_igemm<int8,...> (w4a8 implicit-GEMM conv / linear, all tile variants)",
                 "achieved": round(achieved, 2), "peak": INT8_PEAK_TOPS, "unit": "TOP/s",
                 "frac": round(achieved / INT8_PEAK_TOPS, 4), "traffic": traffic, "traffic_unit": "bytes/launch (PMC)",
                 "traffic_source": traffic_src,
                 "algorithmic_bytes_per_launch": round(tot_bytes / max(n_launch, 1)),
                 "hbm_achieved_TBps": round(tot_bytes / (tot_ms * 1e-3) / 1e12, 3) if tot_ms > 0 else None,
                 "launches_timed": n_launch, "avg_launch_us": round(tot_ms * 1e3 / max(n_launch, 1), 2),
-                "algorithmic_ops_per_forward": tot_ops / 3.0}
-        cpu = None
+                "algorithmic_ops_per_forward": tot_ops / n_fwd}
+        cpu_b = None
         if world == 1 and not args.no_cpu_baseline:
-            v, secs = cpu_baseline(cfg, sd, wq, names, eng.qtable, seq, betas)
-            cpu = {"value": round(v, 4), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
-                   "sample": f"oracle (torch-CPU fake-quant UNet, same weights/act tables): 8 images x 4 of the "
-                             f"{len(seq)} DDIM steps = {secs:.1f}s, extrapolated to the full schedule"}
+            v, sample = cpu()
+            cpu_b = {"value": round(v, 5), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+                     "sample": "oracle (torch-CPU fake-quant UNet, same weights / act tables): " + sample}
+        cfgd = {"workload": info["workload"], "parallelism": f"replicas x{world} (no data-path collective)"}
+        cfgd.update(info["extra"])
         out = {
-            "metric": "DDIM images/sec, w4a8 (headline metric of BASELINE.json on its configs[1] workload)",
-            "value": round(value, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "metric": "DDIM-50 images/sec, w4a8 SD-v1-4" if args.workload == "sd" else "DDIM-100 images/sec, w4a8 CIFAR-10 DDPM",
+            "value": round(value, 3), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "int8 (u8 act bins x int4 weights, int32 accumulate; f16 for the un-quantised layers/attention)",
-            "data": "synthetic: N(0,1) latents, random-init weights (zero params re-drawn N(0,0.02^2)), synthetic FSC tables",
-            "config": {"workload": "DDIM CIFAR-10 w4a8 on MI355X: DDPM UNet 35.7M, 32x32x3, DDIM-100 quad eta=0, "
-                                   f"{args.batch}-image batch per GPU (BASELINE.json configs[1])",
-                       "batch_per_gpu": args.batch, "ddim_steps": len(seq), "unet_evals_per_step": len(seq),
-                       "parallelism": f"replicas x{world} (no data-path collective)"},
-            "finite": finite, "roofline": roof, "cpu_baseline": cpu,
+            "vs_baseline": None,
+            "dtype": "int8 (u8 activation bins x int4 weights, int32 accumulate; f16 MFMA for un-quantised layers / attention, fp32 residual stream)",
+            "data": "synthetic: N(0,1) latents / context, random-init weights (zero params re-drawn N(0,0.02^2)), synthetic FSC tables",
+            "config": cfgd, "finite": finite, "roofline": roof, "cpu_baseline": cpu_b,
         }
         print(json.dumps(out), flush=True)
     if dist is not None:
