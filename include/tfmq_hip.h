@@ -102,6 +102,11 @@ int tfmq_pack_w4(tfmq_handle h, const float* w, const float* alpha_or_null, cons
                  int cout, int cin, int kh, int kw, uint8_t* packed, int32_t* wmeta, void* stream);
 /* inverse (tests): idx[cout][cin][kh][kw] u8 */
 int tfmq_unpack_w4(tfmq_handle h, const uint8_t* packed, int cout, int cin, int kh, int kw, uint8_t* idx, void* stream);
+/* packed int4 -> the conv kernels' int8 operand: byte (n,k) = q_w - z_w, tile-major
+ * [cout_pad32/32][K/ck][32][ck] (ck = 64 if cin % 64 == 0 else 32; cin % 32 == 0 required); w8 holds
+ * cout_pad32 * kh*kw*cin bytes.  This is what tfmq_conv_desc.w points at for tfmq_conv2d_w4a8. */
+int tfmq_expand_w4(tfmq_handle h, const uint8_t* packed, const int32_t* wmeta, int cout, int cin, int kh, int kw,
+                   int8_t* w8, void* stream);
 /* fp16 weights for the un-quantised convs, reordered to [cout][kh][kw][cin_pad],
  * cin_pad = cin rounded up to a multiple of 32 (zero filled).  With delta/zp (and optional
  * alpha) non-NULL the stored value is the integer grid coordinate q - zp (exact in f16) of the
@@ -121,7 +126,7 @@ typedef struct tfmq_conv_desc {
                                     stored input size, the conv sees 2H x 2W */
   /* operands */
   const void* x;                 /* int8 (w4a8) or fp32 (f16 path) NHWC */
-  const void* w;                 /* packed int4 (tfmq_pack_w4) or fp16 (tfmq_pack_w_f16) */
+  const void* w;                 /* w4a8: int8 (q_w - z_w) tiles (tfmq_expand_w4); f16 path: fp16 (tfmq_pack_w_f16) */
   const int32_t* wmeta;          /* [Cout][4] from tfmq_pack_w4 (w4a8 only) */
   const float* wscale;           /* [Cout] delta_w.  w4a8: required.  f16 path: optional per-channel output scale
                                     (weight-only layers store the integer grid q-z exactly in f16) */

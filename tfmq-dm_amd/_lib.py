@@ -69,6 +69,7 @@ _SIGS = {
     "tfmq_mse_search": (c_int, [c_void_p, c_void_p, c_size_t, c_size_t, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "tfmq_pack_w4": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "tfmq_unpack_w4": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "tfmq_expand_w4": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "tfmq_pack_w_f16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "tfmq_conv2d_w4a8": (c_int, [c_void_p, C.POINTER(ConvDesc), c_void_p]),
     "tfmq_conv2d_f16": (c_int, [c_void_p, C.POINTER(ConvDesc), c_void_p]),

@@ -16,6 +16,9 @@ struct tfmq_ctx {
   std::string err;
   std::vector<hipGraphExec_t> graphs;
   std::vector<hipEvent_t> events;
+  // 256 rows x 64 bytes, row v filled with byte v: source of "real zero" activations (bin za-128) for the
+  // padded taps of the LDS-DMA convolution, whose loads cannot substitute a value in registers.
+  unsigned char* pad_table = nullptr;
 };
 
 #define TFMQ_CHECK_ARG(h, cond, msg)          \

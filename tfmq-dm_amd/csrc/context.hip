@@ -16,6 +16,16 @@ extern "C" int tfmq_create(int device, tfmq_handle* out) {
   c->cu_count = p.multiProcessorCount > 0 ? p.multiProcessorCount : 256;
   c->clock_khz = p.clockRate;
   c->hbm_bytes = p.totalGlobalMem;
+  {
+    std::vector<unsigned char> host(256 * 64);
+    for (int v = 0; v < 256; ++v)
+      for (int i = 0; i < 64; ++i) host[v * 64 + i] = static_cast<unsigned char>(v);
+    if (hipMalloc(reinterpret_cast<void**>(&c->pad_table), host.size()) != hipSuccess ||
+        hipMemcpy(c->pad_table, host.data(), host.size(), hipMemcpyHostToDevice) != hipSuccess) {
+      delete c;
+      return TFMQ_ERR_HIP;
+    }
+  }
   *out = c;
   return TFMQ_OK;
 }
@@ -26,6 +36,7 @@ extern "C" int tfmq_destroy(tfmq_handle h) {
     if (g) (void)hipGraphExecDestroy(g);
   for (auto e : h->events)
     if (e) (void)hipEventDestroy(e);
+  if (h->pad_table) (void)hipFree(h->pad_table);
   delete h;
   return TFMQ_OK;
 }

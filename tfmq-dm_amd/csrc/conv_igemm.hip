@@ -1,8 +1,8 @@
 // K5/K6: Conv2d / Linear as implicit GEMM on the gfx950 matrix cores.
 //
-//   w4a8 path : A = int8 NHWC activations (bin-128), B = packed int4 weights unpacked to
-//               int8 while staging, v_mfma_i32_32x32x32_i8, exact int32 accumulation.
-//               y = da*dw[c] * ( sum a'.q_w - zw[c]*sum_k a' + (128-za)*(sum_k q_w - K*zw[c]) ) + b[c]
+//   w4a8 path : A = int8 NHWC activations (bin-128), B = int8 (q_w - z_w) expanded once from the packed int4
+//               weights (tfmq_expand_w4), v_mfma_i32_32x32x32_i8, exact int32 accumulation.
+//               y = da*dw[c] * ( sum a'.(q_w - z_w) + (128-za) * sum_k (q_w - z_w) ) + b[c]
 //               which equals the reference's F.conv2d on the two fake-quantised operands
 //               (quant/quant_layer.py:318-338) up to fp32 rounding of the final scale.
 //               Zero padding must be a *real* zero => padded taps carry a' = za-128.
@@ -13,8 +13,14 @@
 // GEMM view: M = B*Ho*Wo output pixels, N = Cout, K = KH*KW*Cin ordered (kh,kw,cin) so a
 // K-step is 64 contiguous bytes of one input pixel.  256 threads = 4 waves; LDS rows are
 // 64 bytes (64 int8 or 32 f16) with a 16-byte-slot XOR swizzle so ds_read_b128 fragment
-// reads and ds_write_b128 staging writes are bank-conflict free.  Register-prefetched,
-// double-buffered LDS, one barrier per K-step.
+// reads are bank-conflict free.
+//
+// Two main loops share one epilogue:
+//   k_conv_dma   (w4a8, Cin % 64 == 0, <= 9 taps): both operands travel global -> LDS by LDS-DMA
+//                (global_load_lds_dwordx4), three LDS stages, loads of K-step s+2 in flight while step s is
+//                multiplied, counted vmcnt + one raw s_barrier per K-step, no staging registers, no ds_write,
+//                ~20 VALU instructions per K-step.
+//   k_conv_igemm (f16 layers; w4a8 shapes the DMA loop does not take): register-prefetched, double-buffered.
 #include "common.hpp"
 #include <type_traits>
 
@@ -32,327 +38,53 @@ struct ConvP {
   int cin_pad;  // f16 path: padded Cin of the weight layout
   int Hv, Wv;   // virtual input size (2H,2W when up2x)
   int tiles_n;
+  int cout_pad;                    // w4a8: rows of the expanded weight operand (multiple of 32)
+  const unsigned char* pad_table;  // 256 x 64 B, row v = byte v (tfmq_ctx::pad_table)
 };
+
+// Workgroup barrier that only waits for LDS traffic.  __syncthreads() also drains vmcnt(0), i.e. it would wait for
+// the global prefetch loads of the NEXT K-steps at every barrier.
+#define LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 
 __device__ __forceinline__ int swz(int row, int slot) { return row * 64 + ((slot ^ ((row >> 2) & 3)) << 4); }
 
-template <bool INT8, bool FAST, int CK8, int WAVES_M, int WAVES_N, int WM_TILES, int WN_TILES>
-__global__ __launch_bounds__(256) void k_conv_igemm(ConvP p) {
+// One LDS-DMA wave instruction: lane l moves 16 bytes from its own global pointer to LDS byte lds_dst + 16*l
+// (the destination is wave-uniform base + lane*16; M0 carries the base and is restored afterwards).
+__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(gsrc), "s"(lds_dst)
+               : "memory");
+}
+
+template <int BM, int BN>
+__host__ __device__ constexpr int epi_lds_bytes() {
+  constexpr int PR = (BN == 128) ? 64 : BM;
+  return PR * (BN + 4) * 4 + (256 / (BN / 4)) * BN * 8 + BN * 8;
+}
+
+// ---- epilogue.  The accumulators (C/D layout of the 32x32 MFMA: col = lane&31,
+// row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)) are dequantised in registers, staged through LDS one
+// PR-row pass at a time, and leave the CU as whole rows: every lane moves 16 B (float4) of the
+// temb row, the residual and the output, so the fp32 traffic of the epilogue is fully coalesced
+// (per-lane 4-byte strided accesses made this phase 2.5x slower than the MFMA loop).  The same
+// pass produces the per-channel sum / sum-of-squares of every SEG-row segment for the GroupNorm
+// that consumes this tensor, so that GroupNorm never has to re-read it for statistics.
+template <bool INT8, int WAVES_M, int WAVES_N, int WM_TILES, int WN_TILES, typename ACC>
+__device__ __forceinline__ void conv_epilogue(const ConvP& p, unsigned char* lds, ACC (&acc)[WM_TILES][WN_TILES],
+                                              int m0, int n0, float2 aqp, int za) {
   constexpr int BM = WAVES_M * WM_TILES * 32;
   constexpr int BN = WAVES_N * WN_TILES * 32;
-  constexpr int CK = INT8 ? CK8 : 32;           // channels per K-step (CK8 = 64 or 32 int8 channels)
-  constexpr int SLOTS = INT8 ? CK8 / 16 : 4;    // 16-byte slots used per 64-byte LDS row
-  constexpr int KSUB = INT8 ? CK8 / 32 : 2;     // MFMA k-sub-steps per K-step
-  constexpr int BPR = INT8 ? CK8 / 32 : 4;      // 16-byte global items per B row
-  constexpr int A_TOTAL = BM * SLOTS;
-  constexpr int A_ITEMS = (A_TOTAL + 255) / 256;  // 16-byte LDS items per thread (A)
-  constexpr int B_TOTAL = BN * BPR;
-  constexpr int B_ITEMS = (B_TOTAL + 255) / 256;
-  static_assert(WAVES_M * WAVES_N == 4, "4 waves");
-
-  // LDS: main loop 2 x (A tile + B tile); the epilogue re-uses the same bytes for its output staging
-  // tile + statistics partials; the per-row activation sums live behind both.
-  constexpr int EPI_PR = (BN == 128) ? 64 : BM;   // keep in sync with PR in the epilogue
-  constexpr int LDS_MAIN = 2 * (BM + BN) * 64;
-  constexpr int LDS_EPI = EPI_PR * (BN + 4) * 4 + (256 / (BN / 4)) * BN * 8 + BN * 8;
-  constexpr int LDS_BODY = LDS_MAIN > LDS_EPI ? LDS_MAIN : LDS_EPI;
-  __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BODY + BM * 4];
-  auto ldsA = [&](int buf) -> unsigned char* { return lds + buf * ((BM + BN) * 64); };
-  auto ldsB = [&](int buf) -> unsigned char* { return lds + buf * ((BM + BN) * 64) + BM * 64; };
-  int* ldsS = reinterpret_cast<int*>(lds + LDS_BODY);
-
-  const tfmq_conv_desc& d = p.d;
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int wm = wid / WAVES_N, wn = wid % WAVES_N;
-  // XCD-aware tile order (T1): the dispatcher places block b on XCD b % 8; give each XCD a contiguous
-  // range of tiles so the 3x3 taps / neighbouring rows of one image hit that XCD's private L2.
-  // Bijective for any grid size; placement is a speed matter only.
-  int bid = blockIdx.x;
-  {
-    const int nb = gridDim.x, xcd = bid & 7, q = nb >> 3, r = nb & 7;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-  }
-  const int tile_n = bid % p.tiles_n, tile_m = bid / p.tiles_n;
-  const int m0 = tile_m * BM, n0 = tile_n * BN;
-
-  float2 aqp = make_float2(1.0f, 0.0f);
-  int za = 0;
-  unsigned pad_word = 0;
-  if constexpr (INT8) {
-    aqp = load_qparam(d.aq);
-    za = static_cast<int>(aqp.y);
-    const unsigned pb = static_cast<unsigned>(za - 128) & 0xffu;  // real zero == bin za
-    pad_word = pb * 0x01010101u;
-  }
-
-  // ---- per-thread A rows (fixed for the whole K loop)
-  int a_row[A_ITEMS], a_slot[A_ITEMS], a_b[A_ITEMS], a_ho[A_ITEMS], a_wo[A_ITEMS];
-  bool a_ok[A_ITEMS], a_in[A_ITEMS];
-#pragma unroll
-  for (int it = 0; it < A_ITEMS; ++it) {
-    const int item = tid + it * 256;
-    a_row[it] = item / SLOTS;
-    a_slot[it] = item % SLOTS;
-    a_in[it] = item < A_TOTAL;
-    const int m = m0 + a_row[it];
-    a_ok[it] = a_in[it] && m < p.M;
-    const int mm = a_ok[it] ? m : 0;
-    const int hw = d.Ho * d.Wo;
-    a_b[it] = mm / hw;
-    const int r = mm - a_b[it] * hw;
-    a_ho[it] = r / d.Wo;
-    a_wo[it] = r - a_ho[it] * d.Wo;
-  }
-  int a_sum[A_ITEMS];
-#pragma unroll
-  for (int it = 0; it < A_ITEMS; ++it) a_sum[it] = 0;
-
-  // two register sets: the global loads of K-step s+2 are issued while step s is being multiplied
-  // (prefetch distance 2: each load has two full K-steps to land before it is staged into LDS)
-  uint4 a_reg0[A_ITEMS], a_reg1[A_ITEMS];
-  uint4 b_reg0[B_ITEMS], b_reg1[B_ITEMS];
-
-  // Fast addressing (stride 1, no fused upsample, whole K-steps): everything that depends on the thread
-  // is computed ONCE -- a base pointer per staged item and a bit mask of the taps that fall inside the
-  // image -- and a K-step only adds a wave-uniform (scalar) offset.  The generic path below recomputes
-  // pixel coordinates with 64-bit multiplies every step (VALU-bound: ~1.3k issue cycles per K-step).
-  const unsigned char* a_base[A_ITEMS];
-  unsigned a_mask[A_ITEMS];
-  const unsigned char* b_base[B_ITEMS];
-  bool b_ok[B_ITEMS];
-  if constexpr (FAST) {
-    constexpr int ESZ = INT8 ? 1 : 4;  // bytes per input element
-#pragma unroll
-    for (int it = 0; it < A_ITEMS; ++it) {
-      const size_t pix = (static_cast<size_t>(a_b[it]) * d.H + a_ho[it]) * d.W + a_wo[it];
-      a_base[it] = static_cast<const unsigned char*>(d.x) + (pix * d.Cin + a_slot[it] * (INT8 ? 16 : 8)) * ESZ;
-      unsigned mask = 0;
-      for (int t = 0; t < d.KH * d.KW; ++t) {
-        const int hi = a_ho[it] + t / d.KW - d.pad_t, wi = a_wo[it] + t % d.KW - d.pad_l;
-        if (a_ok[it] && hi >= 0 && hi < d.H && wi >= 0 && wi < d.W) mask |= 1u << t;
-      }
-      a_mask[it] = mask;
-    }
-#pragma unroll
-    for (int it = 0; it < B_ITEMS; ++it) {
-      const int item = tid + it * 256;
-      const int n = n0 + item / BPR;
-      b_ok[it] = item < B_TOTAL && n < d.Cout;
-      const int nn = b_ok[it] ? n : 0;
-      if constexpr (INT8)
-        b_base[it] = static_cast<const unsigned char*>(d.w) +
-                     ((static_cast<size_t>(nn / 32) * p.nsteps) * 32 + (nn % 32)) * (CK / 2) + (item % BPR) * 16;
-      else
-        b_base[it] = static_cast<const unsigned char*>(d.w) +
-                     (static_cast<size_t>(nn) * (d.KH * d.KW) * p.cin_pad + (item & 3) * 8) * 2;
-    }
-  }
-
-  auto load_step = [&](int s, uint4 (&ar)[A_ITEMS], uint4 (&br)[B_ITEMS]) {
-    const int tap = s / p.chunks;
-    const int c0 = (s - tap * p.chunks) * CK;
-    const int kh = tap / d.KW, kw = tap - kh * d.KW;
-    if constexpr (FAST) {
-      // wave-uniform byte offsets of this K-step
-      const long a_off = (static_cast<long>((kh - d.pad_t) * d.W + (kw - d.pad_l)) * d.Cin + c0) * (INT8 ? 1 : 4);
-      const long b_off = static_cast<long>(s) * (INT8 ? 16 * CK : 64);  // int4: 32 rows x CK/2 bytes per K-step (tile-major)
-#pragma unroll
-      for (int it = 0; it < A_ITEMS; ++it) {
-        const bool ok = (a_mask[it] >> tap) & 1u;
-        if constexpr (INT8) {
-          uint4 v = make_uint4(pad_word, pad_word, pad_word, pad_word);
-          if (ok) v = *reinterpret_cast<const uint4*>(a_base[it] + a_off);
-          ar[it] = v;
-        } else {
-          float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
-          if (ok) {
-            v0 = *reinterpret_cast<const float4*>(a_base[it] + a_off);
-            v1 = *reinterpret_cast<const float4*>(a_base[it] + a_off + 16);
-          }
-          v8h hv = {static_cast<_Float16>(v0.x), static_cast<_Float16>(v0.y), static_cast<_Float16>(v0.z),
-                    static_cast<_Float16>(v0.w), static_cast<_Float16>(v1.x), static_cast<_Float16>(v1.y),
-                    static_cast<_Float16>(v1.z), static_cast<_Float16>(v1.w)};
-          ar[it] = *reinterpret_cast<uint4*>(&hv);
-        }
-      }
-#pragma unroll
-      for (int it = 0; it < B_ITEMS; ++it) {
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (b_ok[it]) v = *reinterpret_cast<const uint4*>(b_base[it] + b_off);
-        br[it] = v;
-      }
-      return;
-    }
-    // ---- A
-#pragma unroll
-    for (int it = 0; it < A_ITEMS; ++it) {
-      int hi = a_ho[it] * d.stride + kh - d.pad_t;
-      int wi = a_wo[it] * d.stride + kw - d.pad_l;
-      const bool ok = a_ok[it] && hi >= 0 && hi < p.Hv && wi >= 0 && wi < p.Wv;
-      if (d.up2x) {
-        hi >>= 1;
-        wi >>= 1;
-      }
-      const size_t pix = (static_cast<size_t>(a_b[it]) * d.H + hi) * d.W + wi;
-      if constexpr (INT8) {
-        uint4 v = make_uint4(pad_word, pad_word, pad_word, pad_word);
-        if (ok) v = *reinterpret_cast<const uint4*>(static_cast<const int8_t*>(d.x) + pix * d.Cin + c0 + a_slot[it] * 16);
-        ar[it] = v;
-      } else {
-        const int c = c0 + a_slot[it] * 8;
-        float f[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) f[j] = 0.0f;
-        if (ok) {
-          const float* src = static_cast<const float*>(d.x) + pix * d.Cin + c;
-          if ((d.Cin & 3) == 0 && c + 8 <= d.Cin) {
-            const float4 v0 = *reinterpret_cast<const float4*>(src);
-            const float4 v1 = *reinterpret_cast<const float4*>(src + 4);
-            f[0] = v0.x; f[1] = v0.y; f[2] = v0.z; f[3] = v0.w;
-            f[4] = v1.x; f[5] = v1.y; f[6] = v1.z; f[7] = v1.w;
-          } else {
-#pragma unroll
-            for (int j = 0; j < 8; ++j)
-              if (c + j < d.Cin) f[j] = src[j];
-          }
-        }
-        v8h hv;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) hv[j] = static_cast<_Float16>(f[j]);
-        ar[it] = *reinterpret_cast<uint4*>(&hv);
-      }
-    }
-    // ---- B
-#pragma unroll
-    for (int it = 0; it < B_ITEMS; ++it) {
-      const int item = tid + it * 256;
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (item < B_TOTAL) {
-        if constexpr (INT8) {
-          const int n = n0 + item / BPR;
-          if (n < d.Cout)
-            v = *reinterpret_cast<const uint4*>(static_cast<const uint8_t*>(d.w) +
-                                                ((static_cast<size_t>(n / 32) * p.nsteps + s) * 32 + (n % 32)) * (CK / 2) +
-                                                (item % BPR) * 16);
-        } else {
-          const int n = n0 + (item >> 2);
-          if (n < d.Cout)
-            v = *reinterpret_cast<const uint4*>(static_cast<const __half*>(d.w) +
-                                                (static_cast<size_t>(n) * (d.KH * d.KW) + tap) * p.cin_pad + c0 + (item & 3) * 8);
-        }
-      }
-      br[it] = v;
-    }
-  };
-
-  auto store_step = [&](int buf, uint4 (&ar)[A_ITEMS], uint4 (&br)[B_ITEMS]) {
-#pragma unroll
-    for (int it = 0; it < A_ITEMS; ++it) {
-      if (a_in[it]) *reinterpret_cast<uint4*>(ldsA(buf) + swz(a_row[it], a_slot[it])) = ar[it];
-      if constexpr (INT8) {
-        int s = a_sum[it];
-        s = __builtin_amdgcn_sdot4(static_cast<int>(ar[it].x), 0x01010101, s, false);
-        s = __builtin_amdgcn_sdot4(static_cast<int>(ar[it].y), 0x01010101, s, false);
-        s = __builtin_amdgcn_sdot4(static_cast<int>(ar[it].z), 0x01010101, s, false);
-        s = __builtin_amdgcn_sdot4(static_cast<int>(ar[it].w), 0x01010101, s, false);
-        a_sum[it] = s;
-      }
-    }
-#pragma unroll
-    for (int it = 0; it < B_ITEMS; ++it) {
-      const int item = tid + it * 256;
-      if (item < B_TOTAL) {
-        if constexpr (INT8) {
-          const int row = item / BPR, half = item % BPR;
-          const uint4 v = br[it];
-          uint4 lo, hi;  // word j of the packed 16 B holds k = 8j..8j+7
-          lo.x = v.x & 0x0f0f0f0fu; lo.y = (v.x >> 4) & 0x0f0f0f0fu;
-          lo.z = v.y & 0x0f0f0f0fu; lo.w = (v.y >> 4) & 0x0f0f0f0fu;
-          hi.x = v.z & 0x0f0f0f0fu; hi.y = (v.z >> 4) & 0x0f0f0f0fu;
-          hi.z = v.w & 0x0f0f0f0fu; hi.w = (v.w >> 4) & 0x0f0f0f0fu;
-          *reinterpret_cast<uint4*>(ldsB(buf) + swz(row, half * 2)) = lo;
-          *reinterpret_cast<uint4*>(ldsB(buf) + swz(row, half * 2 + 1)) = hi;
-        } else {
-          *reinterpret_cast<uint4*>(ldsB(buf) + swz(item >> 2, item & 3)) = br[it];
-        }
-      }
-    }
-  };
-
-  using acc_t = typename std::conditional<INT8, v16i, v16f>::type;
-  acc_t acc[WM_TILES][WN_TILES];
-#pragma unroll
-  for (int i = 0; i < WM_TILES; ++i)
-#pragma unroll
-    for (int j = 0; j < WN_TILES; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0;
-
-  auto compute = [&](int buf) {
-#pragma unroll
-    for (int ks = 0; ks < KSUB; ++ks) {
-        uint4 af[WM_TILES], bf[WN_TILES];
-        const int kslot = ks * 2 + (lane >> 5);
-  #pragma unroll
-        for (int i = 0; i < WM_TILES; ++i)
-          af[i] = *reinterpret_cast<const uint4*>(ldsA(buf) + swz((wm * WM_TILES + i) * 32 + (lane & 31), kslot));
-  #pragma unroll
-        for (int j = 0; j < WN_TILES; ++j)
-          bf[j] = *reinterpret_cast<const uint4*>(ldsB(buf) + swz((wn * WN_TILES + j) * 32 + (lane & 31), kslot));
-  #pragma unroll
-        for (int i = 0; i < WM_TILES; ++i)
-  #pragma unroll
-          for (int j = 0; j < WN_TILES; ++j) {
-            if constexpr (INT8) {
-              acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(*reinterpret_cast<v4i*>(&af[i]),
-                                                                *reinterpret_cast<v4i*>(&bf[j]), acc[i][j], 0, 0, 0);
-            } else {
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<v8h*>(&af[i]),
-                                                                 *reinterpret_cast<v8h*>(&bf[j]), acc[i][j], 0, 0, 0);
-            }
-          }
-      }
-  };
-  load_step(0, a_reg0, b_reg0);
-  if (p.nsteps > 1) load_step(1, a_reg1, b_reg1);
-  for (int s = 0; s < p.nsteps; s += 2) {
-    store_step(0, a_reg0, b_reg0);
-    __syncthreads();
-    if (s + 2 < p.nsteps) load_step(s + 2, a_reg0, b_reg0);
-    compute(0);
-    if (s + 1 < p.nsteps) {
-      store_step(1, a_reg1, b_reg1);
-      __syncthreads();
-      if (s + 3 < p.nsteps) load_step(s + 3, a_reg1, b_reg1);
-      compute(1);
-    }
-  }
-
-  // ---- per-row activation sums (w4a8): 4 adjacent lanes share a row
-  if constexpr (INT8) {
-#pragma unroll
-    for (int it = 0; it < A_ITEMS; ++it) {
-      int s = a_sum[it];
-      s += __shfl_xor(s, 1, 64);
-      if constexpr (SLOTS == 4) s += __shfl_xor(s, 2, 64);
-      if (a_slot[it] == 0 && a_in[it]) ldsS[a_row[it]] = s;
-    }
-    __syncthreads();
-  }
-
-  // ---- epilogue.  The accumulators (C/D layout of the 32x32 MFMA: col = lane&31,
-  // row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)) are dequantised in registers, staged through LDS one
-  // PR-row pass at a time, and leave the CU as whole rows: every lane moves 16 B (float4) of the
-  // temb row, the residual and the output, so the fp32 traffic of the epilogue is fully coalesced
-  // (per-lane 4-byte strided accesses made this phase 2.5x slower than the MFMA loop).  The same
-  // pass produces the per-channel sum / sum-of-squares of every SEG-row segment for the GroupNorm
-  // that consumes this tensor, so that GroupNorm never has to re-read it for statistics.
   constexpr int PR = (BN == 128) ? 64 : BM;       // rows per pass
   constexpr int LDO = BN + 4;                      // padded LDS row (floats)
   constexpr int TPR = BN / 4;                      // threads per output row (float4 each)
   constexpr int NTR = 256 / TPR;                   // thread-rows
   constexpr int RPT = PR / NTR;                    // consecutive rows per thread
   static_assert(RPT >= 1 && RPT <= 16, "rows per thread");
+  const tfmq_conv_desc& d = p.d;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid / WAVES_N, wn = wid % WAVES_N;
   float* ldsO = reinterpret_cast<float*>(lds);                      // [PR][LDO]
   float2* ldsP = reinterpret_cast<float2*>(lds + PR * LDO * 4);     // [NTR][BN] partial (sum, sumsq)
   float2* ldsG = ldsP + NTR * BN;                                   // [BN] running segment sums
@@ -362,32 +94,30 @@ __global__ __launch_bounds__(256) void k_conv_igemm(ConvP p) {
   const bool vec_ok = ((d.Cout | d.ldy | d.y_coff) & 3) == 0 && (!d.rowadd || (d.rowadd_ld & 3) == 0);
   const int seg = d.stats ? d.stats_seg : 0;
   const int tr = tid / TPR, c4 = (tid % TPR) * 4;
-  if (seg) {
-    for (int o = tid; o < BN; o += 256) ldsG[o] = make_float2(0.0f, 0.0f);
-  }
 
   float sc_[WN_TILES], bias_[WN_TILES];
-  int zw_[WN_TILES], corr_[WN_TILES];
+  int corr_[WN_TILES];
 #pragma unroll
   for (int j = 0; j < WN_TILES; ++j) {
     const int n = n0 + (wn * WN_TILES + j) * 32 + (lane & 31);
     const bool nok = n < d.Cout;
     sc_[j] = (!INT8 && d.wscale && nok) ? d.wscale[n] : 1.0f;
     bias_[j] = (d.bias && nok) ? d.bias[n] : 0.0f;
-    zw_[j] = 0;
     corr_[j] = 0;
     if constexpr (INT8) {
       if (nok) {
         const int4 wmv = reinterpret_cast<const int4*>(d.wmeta)[n];
-        zw_[j] = wmv.x;
-        corr_[j] = (128 - za) * (wmv.y - p.Ktot * zw_[j]);
+        corr_[j] = (128 - za) * (wmv.y - p.Ktot * wmv.x);
         sc_[j] = aqp.x * d.wscale[n];
       }
     }
   }
 
   for (int pass = 0; pass < BM / PR; ++pass) {
-    __syncthreads();  // previous pass fully consumed (also orders ldsS / main-loop LDS reads before the overwrite)
+    __syncthreads();  // previous pass fully consumed (also orders the main loop's LDS reads before the overwrite)
+    if (seg && pass == 0) {
+      for (int o = tid; o < BN; o += 256) ldsG[o] = make_float2(0.0f, 0.0f);
+    }
     // phase 1: registers -> LDS
 #pragma unroll
     for (int i = 0; i < WM_TILES; ++i) {
@@ -401,8 +131,7 @@ __global__ __launch_bounds__(256) void k_conv_igemm(ConvP p) {
           const int row = tile_row0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
           float v;
           if constexpr (INT8) {
-            const int t = acc[i][j][r] - zw_[j] * ldsS[row] + corr_[j];
-            v = sc_[j] * static_cast<float>(t) + bias_[j];
+            v = sc_[j] * static_cast<float>(acc[i][j][r] + corr_[j]) + bias_[j];
           } else {
             v = d.wscale ? sc_[j] * acc[i][j][r] + bias_[j] : acc[i][j][r] + bias_[j];
           }
@@ -483,6 +212,428 @@ __global__ __launch_bounds__(256) void k_conv_igemm(ConvP p) {
   }
 }
 
+// XCD-aware tile order (T1): the dispatcher places block b on XCD b % 8; give each XCD a contiguous
+// range of tiles so the 3x3 taps / neighbouring rows of one image hit that XCD's private L2.
+// Bijective for any grid size; placement is a speed matter only.
+__device__ __forceinline__ int xcd_tile_id() {
+  const int bid = blockIdx.x, nb = gridDim.x, xcd = bid & 7, q = nb >> 3, r = nb & 7;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+}
+
+// ================================================================================================
+// w4a8 main path: LDS-DMA pipeline
+// ================================================================================================
+template <int WAVES_M, int WAVES_N, int WM_TILES, int WN_TILES>
+__global__ __launch_bounds__(256, 3) void k_conv_dma(ConvP p) {
+  constexpr int BM = WAVES_M * WM_TILES * 32;
+  constexpr int BN = WAVES_N * WN_TILES * 32;
+  constexpr int STAGE = (BM + BN) * 64;          // bytes of one K-step: A tile then B tile, 64-byte rows
+  constexpr int NST = 3;                          // stages: multiply s, s+1 landed/landing, s+2 landing
+  constexpr int A_CH = BM / 64;                   // 1-KiB (16-row) DMA pieces per wave
+  constexpr int B_CH = BN >= 64 ? BN / 64 : 1;    // (BN = 32: two pieces, waves 2/3 repeat them)
+  constexpr int NLOAD = A_CH + B_CH;              // DMA instructions per wave per K-step
+  constexpr int MAXT = 9;
+  constexpr int LDS_MAIN = NST * STAGE;
+  constexpr int LDS_EPI = epi_lds_bytes<BM, BN>();
+  constexpr int LDS_BODY = LDS_MAIN > LDS_EPI ? LDS_MAIN : LDS_EPI;
+  static_assert(WAVES_M * WAVES_N == 4, "4 waves");
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[LDS_BODY + MAXT * BM * 4];
+  int* tab = reinterpret_cast<int*>(lds + LDS_BODY);  // [tap][row] byte offset of the input pixel, -1 = padding
+
+  const tfmq_conv_desc& d = p.d;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wid / WAVES_N, wn = wid % WAVES_N;
+  const int bid = xcd_tile_id();
+  const int tile_n = bid % p.tiles_n, tile_m = bid / p.tiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+  const float2 aqp = load_qparam(d.aq);
+  const int za = static_cast<int>(aqp.y);
+  // real zero == bin za  ->  stored byte za-128; its 64-byte row in the pad table feeds the padded taps
+  const unsigned char* padp = p.pad_table + (static_cast<unsigned>(za - 128) & 0xffu) * 64;
+
+  // ---- pixel offset table (any stride / padding / fused 2x upsample)
+  {
+    const int taps = d.KH * d.KW, hw = d.Ho * d.Wo;
+    for (int idx = tid; idx < taps * BM; idx += 256) {
+      const int tap = idx / BM, row = idx - tap * BM;
+      const int m = m0 + row;
+      int off = -1;
+      if (m < p.M) {
+        const int b = m / hw, r = m - b * hw;
+        const int ho = r / d.Wo, wo = r - ho * d.Wo;
+        const int kh = tap / d.KW, kw = tap - kh * d.KW;
+        int hi = ho * d.stride + kh - d.pad_t, wi = wo * d.stride + kw - d.pad_l;
+        if (hi >= 0 && hi < p.Hv && wi >= 0 && wi < p.Wv) {
+          if (d.up2x) {
+            hi >>= 1;
+            wi >>= 1;
+          }
+          off = ((b * d.H + hi) * d.W + wi) * d.Cin;  // < 2^31, checked by the launcher
+        }
+      }
+      tab[idx] = off;
+    }
+  }
+
+  // ---- per-thread DMA sources.  Lane l of a piece lands on LDS row l/4, physical slot l%4, so it must fetch
+  // logical slot (l%4) ^ swizzle(row): the swizzle lives on the SOURCE address and on the fragment reads.
+  const unsigned lds0 = static_cast<unsigned>(reinterpret_cast<uintptr_t>(lds));
+  const unsigned char* xb = static_cast<const unsigned char*>(d.x);
+  int a_row[A_CH], a_col[A_CH], a_off[A_CH];
+  unsigned a_dst[A_CH], b_dst[B_CH];
+  const unsigned char* b_ptr[B_CH];
+#pragma unroll
+  for (int it = 0; it < A_CH; ++it) {
+    const int piece = wid * A_CH + it;
+    a_row[it] = piece * 16 + (lane >> 2);
+    a_col[it] = ((lane & 3) ^ ((a_row[it] >> 2) & 3)) * 16;
+    a_dst[it] = __builtin_amdgcn_readfirstlane(piece * 1024);
+    a_off[it] = -1;
+  }
+#pragma unroll
+  for (int it = 0; it < B_CH; ++it) {
+    const int piece = BN >= 64 ? wid * B_CH + it : (wid & 1);
+    const int row = piece * 16 + (lane >> 2);
+    int n = n0 + row;
+    n = n < p.cout_pad ? n : p.cout_pad - 1;
+    b_ptr[it] = static_cast<const unsigned char*>(d.w) +
+                (static_cast<size_t>(n / 32) * p.nsteps * 32 + (n % 32)) * 64 + ((lane & 3) ^ ((row >> 2) & 3)) * 16;
+    b_dst[it] = __builtin_amdgcn_readfirstlane(BM * 64 + piece * 1024);
+  }
+  __syncthreads();  // tab visible
+
+  int i_tap = 0, i_chunk = 0;
+  auto issue = [&](int s, int stage) {
+    if (i_chunk == 0) {
+#pragma unroll
+      for (int it = 0; it < A_CH; ++it) a_off[it] = tab[i_tap * BM + a_row[it]];
+    }
+    const int c0 = i_chunk * 64;
+    const unsigned sbase = lds0 + stage * STAGE;
+#pragma unroll
+    for (int it = 0; it < A_CH; ++it) {
+      const unsigned char* src = a_off[it] >= 0 ? xb + static_cast<size_t>(static_cast<unsigned>(a_off[it])) + c0 + a_col[it]
+                                                : padp + a_col[it];
+      glds16(src, sbase + a_dst[it]);
+    }
+#pragma unroll
+    for (int it = 0; it < B_CH; ++it) glds16(b_ptr[it] + static_cast<size_t>(s) * 2048, sbase + b_dst[it]);
+    if (++i_chunk == p.chunks) {
+      i_chunk = 0;
+      ++i_tap;
+    }
+  };
+
+  v16i acc[WM_TILES][WN_TILES];
+#pragma unroll
+  for (int i = 0; i < WM_TILES; ++i)
+#pragma unroll
+    for (int j = 0; j < WN_TILES; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0;
+
+  auto compute = [&](int stage) {
+    const unsigned char* sa = lds + stage * STAGE;
+    const unsigned char* sb = sa + BM * 64;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      v4i af[WM_TILES], bf[WN_TILES];
+      const int kslot = ks * 2 + (lane >> 5);
+#pragma unroll
+      for (int i = 0; i < WM_TILES; ++i)
+        af[i] = *reinterpret_cast<const v4i*>(sa + swz((wm * WM_TILES + i) * 32 + (lane & 31), kslot));
+#pragma unroll
+      for (int j = 0; j < WN_TILES; ++j)
+        bf[j] = *reinterpret_cast<const v4i*>(sb + swz((wn * WN_TILES + j) * 32 + (lane & 31), kslot));
+#pragma unroll
+      for (int i = 0; i < WM_TILES; ++i)
+#pragma unroll
+        for (int j = 0; j < WN_TILES; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[i], bf[j], acc[i][j], 0, 0, 0);
+    }
+  };
+
+  issue(0, 0);
+  if (p.nsteps > 1) issue(1, 1);
+  int st_c = 0, st_i = 2;
+  for (int s = 0; s < p.nsteps; ++s) {
+    // this wave's pieces of K-step s have landed (those of s+1 may still be in flight) ...
+    if (s + 1 < p.nsteps)
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLOAD) : "memory");
+    else
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // ... and after the barrier every wave's have, and nobody still reads the stage refilled below
+    asm volatile("s_barrier" ::: "memory");
+    if (s + 2 < p.nsteps) issue(s + 2, st_i);
+    compute(st_c);
+    st_c = st_c == NST - 1 ? 0 : st_c + 1;
+    st_i = st_i == NST - 1 ? 0 : st_i + 1;
+  }
+
+  conv_epilogue<true, WAVES_M, WAVES_N, WM_TILES, WN_TILES>(p, lds, acc, m0, n0, aqp, za);
+}
+
+// ================================================================================================
+// generic path: f16 layers, and w4a8 shapes outside the DMA loop's domain
+// ================================================================================================
+template <bool INT8, bool FAST, int CK8, int WAVES_M, int WAVES_N, int WM_TILES, int WN_TILES>
+__global__ __launch_bounds__(256, 3) void k_conv_igemm(ConvP p) {
+  constexpr int BM = WAVES_M * WM_TILES * 32;
+  constexpr int BN = WAVES_N * WN_TILES * 32;
+  constexpr int CK = INT8 ? CK8 : 32;           // channels per K-step (CK8 = 64 or 32 int8 channels)
+  constexpr int SLOTS = INT8 ? CK8 / 16 : 4;    // 16-byte slots used per 64-byte LDS row
+  constexpr int KSUB = INT8 ? CK8 / 32 : 2;     // MFMA k-sub-steps per K-step
+  constexpr int A_TOTAL = BM * SLOTS;
+  constexpr int A_ITEMS = (A_TOTAL + 255) / 256;  // 16-byte LDS items per thread (A)
+  constexpr int B_TOTAL = BN * SLOTS;
+  constexpr int B_ITEMS = (B_TOTAL + 255) / 256;
+  static_assert(WAVES_M * WAVES_N == 4, "4 waves");
+
+  // LDS: main loop 2 x (A tile + B tile); the epilogue re-uses the same bytes for its output staging
+  // tile + statistics partials.
+  constexpr int LDS_MAIN = 2 * (BM + BN) * 64;
+  constexpr int LDS_EPI = epi_lds_bytes<BM, BN>();
+  constexpr int LDS_BODY = LDS_MAIN > LDS_EPI ? LDS_MAIN : LDS_EPI;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BODY];
+  auto ldsA = [&](int buf) -> unsigned char* { return lds + buf * ((BM + BN) * 64); };
+  auto ldsB = [&](int buf) -> unsigned char* { return lds + buf * ((BM + BN) * 64) + BM * 64; };
+
+  const tfmq_conv_desc& d = p.d;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid / WAVES_N, wn = wid % WAVES_N;
+  const int bid = xcd_tile_id();
+  const int tile_n = bid % p.tiles_n, tile_m = bid / p.tiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+  float2 aqp = make_float2(1.0f, 0.0f);
+  int za = 0;
+  unsigned pad_word = 0;
+  if constexpr (INT8) {
+    aqp = load_qparam(d.aq);
+    za = static_cast<int>(aqp.y);
+    const unsigned pb = static_cast<unsigned>(za - 128) & 0xffu;  // real zero == bin za
+    pad_word = pb * 0x01010101u;
+  }
+
+  // ---- per-thread A rows (fixed for the whole K loop)
+  int a_row[A_ITEMS], a_slot[A_ITEMS], a_b[A_ITEMS], a_ho[A_ITEMS], a_wo[A_ITEMS];
+  bool a_ok[A_ITEMS], a_in[A_ITEMS];
+#pragma unroll
+  for (int it = 0; it < A_ITEMS; ++it) {
+    const int item = tid + it * 256;
+    a_row[it] = item / SLOTS;
+    a_slot[it] = item % SLOTS;
+    a_in[it] = item < A_TOTAL;
+    const int m = m0 + a_row[it];
+    a_ok[it] = a_in[it] && m < p.M;
+    const int mm = a_ok[it] ? m : 0;
+    const int hw = d.Ho * d.Wo;
+    a_b[it] = mm / hw;
+    const int r = mm - a_b[it] * hw;
+    a_ho[it] = r / d.Wo;
+    a_wo[it] = r - a_ho[it] * d.Wo;
+  }
+
+  // two register sets: the global loads of K-step s+2 are issued while step s is being multiplied
+  uint4 a_reg0[A_ITEMS], a_reg1[A_ITEMS];
+  uint4 b_reg0[B_ITEMS], b_reg1[B_ITEMS];
+
+  // Fast addressing (stride 1, no fused upsample, whole K-steps): everything that depends on the thread
+  // is computed ONCE -- a base pointer per staged item and a bit mask of the taps that fall inside the
+  // image -- and a K-step only adds a wave-uniform (scalar) offset.
+  const unsigned char* a_base[A_ITEMS];
+  unsigned a_mask[A_ITEMS];
+  const unsigned char* b_base[B_ITEMS];
+  bool b_ok[B_ITEMS];
+  if constexpr (FAST) {
+    constexpr int ESZ = INT8 ? 1 : 4;  // bytes per input element
+#pragma unroll
+    for (int it = 0; it < A_ITEMS; ++it) {
+      const size_t pix = (static_cast<size_t>(a_b[it]) * d.H + a_ho[it]) * d.W + a_wo[it];
+      a_base[it] = static_cast<const unsigned char*>(d.x) + (pix * d.Cin + a_slot[it] * (INT8 ? 16 : 8)) * ESZ;
+      unsigned mask = 0;
+      for (int t = 0; t < d.KH * d.KW; ++t) {
+        const int hi = a_ho[it] + t / d.KW - d.pad_t, wi = a_wo[it] + t % d.KW - d.pad_l;
+        if (a_ok[it] && hi >= 0 && hi < d.H && wi >= 0 && wi < d.W) mask |= 1u << t;
+      }
+      a_mask[it] = mask;
+    }
+#pragma unroll
+    for (int it = 0; it < B_ITEMS; ++it) {
+      const int item = tid + it * 256;
+      const int n = n0 + item / SLOTS;
+      b_ok[it] = item < B_TOTAL && n < d.Cout;
+      const int nn = b_ok[it] ? n : 0;
+      if constexpr (INT8)
+        b_base[it] = static_cast<const unsigned char*>(d.w) +
+                     ((static_cast<size_t>(nn / 32) * p.nsteps) * 32 + (nn % 32)) * CK + (item % SLOTS) * 16;
+      else
+        b_base[it] = static_cast<const unsigned char*>(d.w) +
+                     (static_cast<size_t>(nn) * (d.KH * d.KW) * p.cin_pad + (item & 3) * 8) * 2;
+    }
+  }
+
+  auto load_step = [&](int s, uint4 (&ar)[A_ITEMS], uint4 (&br)[B_ITEMS]) {
+    const int tap = s / p.chunks;
+    const int c0 = (s - tap * p.chunks) * CK;
+    const int kh = tap / d.KW, kw = tap - kh * d.KW;
+    if constexpr (FAST) {
+      // wave-uniform byte offsets of this K-step
+      const long a_off = (static_cast<long>((kh - d.pad_t) * d.W + (kw - d.pad_l)) * d.Cin + c0) * (INT8 ? 1 : 4);
+      const long b_off = static_cast<long>(s) * (INT8 ? 32 * CK : 64);  // int8: 32 rows x CK bytes per K-step (tile-major)
+#pragma unroll
+      for (int it = 0; it < A_ITEMS; ++it) {
+        const bool ok = (a_mask[it] >> tap) & 1u;
+        if constexpr (INT8) {
+          uint4 v = make_uint4(pad_word, pad_word, pad_word, pad_word);
+          if (ok) v = *reinterpret_cast<const uint4*>(a_base[it] + a_off);
+          ar[it] = v;
+        } else {
+          float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
+          if (ok) {
+            v0 = *reinterpret_cast<const float4*>(a_base[it] + a_off);
+            v1 = *reinterpret_cast<const float4*>(a_base[it] + a_off + 16);
+          }
+          v8h hv = {static_cast<_Float16>(v0.x), static_cast<_Float16>(v0.y), static_cast<_Float16>(v0.z),
+                    static_cast<_Float16>(v0.w), static_cast<_Float16>(v1.x), static_cast<_Float16>(v1.y),
+                    static_cast<_Float16>(v1.z), static_cast<_Float16>(v1.w)};
+          ar[it] = *reinterpret_cast<uint4*>(&hv);
+        }
+      }
+#pragma unroll
+      for (int it = 0; it < B_ITEMS; ++it) {
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (b_ok[it]) v = *reinterpret_cast<const uint4*>(b_base[it] + b_off);
+        br[it] = v;
+      }
+      return;
+    }
+    // ---- A
+#pragma unroll
+    for (int it = 0; it < A_ITEMS; ++it) {
+      int hi = a_ho[it] * d.stride + kh - d.pad_t;
+      int wi = a_wo[it] * d.stride + kw - d.pad_l;
+      const bool ok = a_ok[it] && hi >= 0 && hi < p.Hv && wi >= 0 && wi < p.Wv;
+      if (d.up2x) {
+        hi >>= 1;
+        wi >>= 1;
+      }
+      const size_t pix = (static_cast<size_t>(a_b[it]) * d.H + hi) * d.W + wi;
+      if constexpr (INT8) {
+        uint4 v = make_uint4(pad_word, pad_word, pad_word, pad_word);
+        if (ok) v = *reinterpret_cast<const uint4*>(static_cast<const int8_t*>(d.x) + pix * d.Cin + c0 + a_slot[it] * 16);
+        ar[it] = v;
+      } else {
+        const int c = c0 + a_slot[it] * 8;
+        float f[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f[j] = 0.0f;
+        if (ok) {
+          const float* src = static_cast<const float*>(d.x) + pix * d.Cin + c;
+          if ((d.Cin & 3) == 0 && c + 8 <= d.Cin) {
+            const float4 v0 = *reinterpret_cast<const float4*>(src);
+            const float4 v1 = *reinterpret_cast<const float4*>(src + 4);
+            f[0] = v0.x; f[1] = v0.y; f[2] = v0.z; f[3] = v0.w;
+            f[4] = v1.x; f[5] = v1.y; f[6] = v1.z; f[7] = v1.w;
+          } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+              if (c + j < d.Cin) f[j] = src[j];
+          }
+        }
+        v8h hv;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) hv[j] = static_cast<_Float16>(f[j]);
+        ar[it] = *reinterpret_cast<uint4*>(&hv);
+      }
+    }
+    // ---- B
+#pragma unroll
+    for (int it = 0; it < B_ITEMS; ++it) {
+      const int item = tid + it * 256;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (item < B_TOTAL) {
+        const int n = n0 + item / SLOTS;
+        if (n < d.Cout) {
+          if constexpr (INT8)
+            v = *reinterpret_cast<const uint4*>(static_cast<const uint8_t*>(d.w) +
+                                                ((static_cast<size_t>(n / 32) * p.nsteps + s) * 32 + (n % 32)) * CK +
+                                                (item % SLOTS) * 16);
+          else
+            v = *reinterpret_cast<const uint4*>(static_cast<const __half*>(d.w) +
+                                                (static_cast<size_t>(n) * (d.KH * d.KW) + tap) * p.cin_pad + c0 + (item & 3) * 8);
+        }
+      }
+      br[it] = v;
+    }
+  };
+
+  auto store_step = [&](int buf, uint4 (&ar)[A_ITEMS], uint4 (&br)[B_ITEMS]) {
+#pragma unroll
+    for (int it = 0; it < A_ITEMS; ++it)
+      if (a_in[it]) *reinterpret_cast<uint4*>(ldsA(buf) + swz(a_row[it], a_slot[it])) = ar[it];
+#pragma unroll
+    for (int it = 0; it < B_ITEMS; ++it) {
+      const int item = tid + it * 256;
+      if (item < B_TOTAL) *reinterpret_cast<uint4*>(ldsB(buf) + swz(item / SLOTS, item % SLOTS)) = br[it];
+    }
+  };
+
+  using acc_t = typename std::conditional<INT8, v16i, v16f>::type;
+  acc_t acc[WM_TILES][WN_TILES];
+#pragma unroll
+  for (int i = 0; i < WM_TILES; ++i)
+#pragma unroll
+    for (int j = 0; j < WN_TILES; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0;
+
+  auto compute = [&](int buf) {
+#pragma unroll
+    for (int ks = 0; ks < KSUB; ++ks) {
+      uint4 af[WM_TILES], bf[WN_TILES];
+      const int kslot = ks * 2 + (lane >> 5);
+#pragma unroll
+      for (int i = 0; i < WM_TILES; ++i)
+        af[i] = *reinterpret_cast<const uint4*>(ldsA(buf) + swz((wm * WM_TILES + i) * 32 + (lane & 31), kslot));
+#pragma unroll
+      for (int j = 0; j < WN_TILES; ++j)
+        bf[j] = *reinterpret_cast<const uint4*>(ldsB(buf) + swz((wn * WN_TILES + j) * 32 + (lane & 31), kslot));
+#pragma unroll
+      for (int i = 0; i < WM_TILES; ++i)
+#pragma unroll
+        for (int j = 0; j < WN_TILES; ++j) {
+          if constexpr (INT8) {
+            acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(*reinterpret_cast<v4i*>(&af[i]),
+                                                              *reinterpret_cast<v4i*>(&bf[j]), acc[i][j], 0, 0, 0);
+          } else {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<v8h*>(&af[i]),
+                                                               *reinterpret_cast<v8h*>(&bf[j]), acc[i][j], 0, 0, 0);
+          }
+        }
+    }
+  };
+
+  load_step(0, a_reg0, b_reg0);
+  if (p.nsteps > 1) load_step(1, a_reg1, b_reg1);
+  for (int s = 0; s < p.nsteps; s += 2) {
+    store_step(0, a_reg0, b_reg0);
+    LDS_BARRIER();
+    if (s + 2 < p.nsteps) load_step(s + 2, a_reg0, b_reg0);
+    compute(0);
+    if (s + 1 < p.nsteps) {
+      store_step(1, a_reg1, b_reg1);
+      LDS_BARRIER();
+      if (s + 3 < p.nsteps) load_step(s + 3, a_reg1, b_reg1);
+      compute(1);
+    }
+  }
+
+  conv_epilogue<INT8, WAVES_M, WAVES_N, WM_TILES, WN_TILES>(p, lds, acc, m0, n0, aqp, za);
+}
+
 template <bool INT8>
 static int launch_conv(tfmq_handle h, const tfmq_conv_desc* dd, void* stream) {
   TFMQ_CHECK_ARG(h, h && dd, "conv: null pointer");
@@ -500,6 +651,8 @@ static int launch_conv(tfmq_handle h, const tfmq_conv_desc* dd, void* stream) {
   p.Hv = d.up2x ? 2 * d.H : d.H;
   p.Wv = d.up2x ? 2 * d.W : d.W;
   p.Ktot = d.KH * d.KW * d.Cin;
+  p.cout_pad = (d.Cout + 31) / 32 * 32;
+  p.pad_table = h->pad_table;
   if (INT8) {
     TFMQ_CHECK_ARG(h, d.Cin % 32 == 0, "conv_w4a8: Cin must be a multiple of 32");
     TFMQ_CHECK_ARG(h, d.wmeta && d.wscale && d.aq.qtable, "conv_w4a8: wmeta/wscale/aq required");
@@ -519,22 +672,31 @@ static int launch_conv(tfmq_handle h, const tfmq_conv_desc* dd, void* stream) {
   p.tiles_n = (d.Cout + BN - 1) / BN;
   const int tiles_m = (p.M + BM - 1) / BM;
   dim3 grid(static_cast<unsigned>(p.tiles_n) * tiles_m);
-  const bool k32 = INT8 && (d.Cin % 64 != 0);
-  // fast addressing: stride 1, no fused upsample, whole K-steps, <= 32 taps, 16-byte aligned rows
-  const bool fast = d.stride == 1 && !d.up2x && d.KH * d.KW <= 32 && (INT8 ? true : d.Cin % 32 == 0);
   hipStream_t st = as_stream(stream);
-#define TFMQ_LAUNCH(F, CK, A, B_, C_, D_) hipLaunchKernelGGL((k_conv_igemm<INT8, F, CK, A, B_, C_, D_>), grid, dim3(256), 0, st, p)
-  if (narrow) {
-    if (k32) { if (fast) TFMQ_LAUNCH(true, 32, 4, 1, 1, 1); else TFMQ_LAUNCH(false, 32, 4, 1, 1, 1); }
-    else { if (fast) TFMQ_LAUNCH(true, 64, 4, 1, 1, 1); else TFMQ_LAUNCH(false, 64, 4, 1, 1, 1); }
-  } else if (small) {
-    if (k32) { if (fast) TFMQ_LAUNCH(true, 32, 2, 2, 1, 1); else TFMQ_LAUNCH(false, 32, 2, 2, 1, 1); }
-    else { if (fast) TFMQ_LAUNCH(true, 64, 2, 2, 1, 1); else TFMQ_LAUNCH(false, 64, 2, 2, 1, 1); }
-  } else {
-    if (k32) { if (fast) TFMQ_LAUNCH(true, 32, 2, 2, 2, 2); else TFMQ_LAUNCH(false, 32, 2, 2, 2, 2); }
-    else { if (fast) TFMQ_LAUNCH(true, 64, 2, 2, 2, 2); else TFMQ_LAUNCH(false, 64, 2, 2, 2, 2); }
-  }
+  if constexpr (INT8) {
+    const bool dma = d.Cin % 64 == 0 && d.KH * d.KW <= 9 &&
+                     static_cast<size_t>(d.B) * d.H * d.W * d.Cin < (static_cast<size_t>(1) << 31);
+    if (dma) {
+      if (narrow) hipLaunchKernelGGL((k_conv_dma<4, 1, 1, 1>), grid, dim3(256), 0, st, p);
+      else if (small) hipLaunchKernelGGL((k_conv_dma<2, 2, 1, 1>), grid, dim3(256), 0, st, p);
+      else hipLaunchKernelGGL((k_conv_dma<2, 2, 2, 2>), grid, dim3(256), 0, st, p);
+    } else {
+#define TFMQ_LAUNCH(CK, A, B_, C_, D_) hipLaunchKernelGGL((k_conv_igemm<true, false, CK, A, B_, C_, D_>), grid, dim3(256), 0, st, p)
+      const bool k32 = d.Cin % 64 != 0;
+      if (narrow) { if (k32) TFMQ_LAUNCH(32, 4, 1, 1, 1); else TFMQ_LAUNCH(64, 4, 1, 1, 1); }
+      else if (small) { if (k32) TFMQ_LAUNCH(32, 2, 2, 1, 1); else TFMQ_LAUNCH(64, 2, 2, 1, 1); }
+      else { if (k32) TFMQ_LAUNCH(32, 2, 2, 2, 2); else TFMQ_LAUNCH(64, 2, 2, 2, 2); }
 #undef TFMQ_LAUNCH
+    }
+  } else {
+    // fast addressing: stride 1, no fused upsample, whole K-steps, <= 32 taps, 16-byte aligned rows
+    const bool fast = d.stride == 1 && !d.up2x && d.KH * d.KW <= 32 && d.Cin % 32 == 0;
+#define TFMQ_LAUNCH(F, A, B_, C_, D_) hipLaunchKernelGGL((k_conv_igemm<false, F, 64, A, B_, C_, D_>), grid, dim3(256), 0, st, p)
+    if (narrow) { if (fast) TFMQ_LAUNCH(true, 4, 1, 1, 1); else TFMQ_LAUNCH(false, 4, 1, 1, 1); }
+    else if (small) { if (fast) TFMQ_LAUNCH(true, 2, 2, 1, 1); else TFMQ_LAUNCH(false, 2, 2, 1, 1); }
+    else { if (fast) TFMQ_LAUNCH(true, 2, 2, 2, 2); else TFMQ_LAUNCH(false, 2, 2, 2, 2); }
+#undef TFMQ_LAUNCH
+  }
   TFMQ_LAUNCH_CHECK(h);
   return TFMQ_OK;
 }

@@ -410,6 +410,46 @@ extern "C" int tfmq_unpack_w4(tfmq_handle h, const uint8_t* packed, int cout, in
   return TFMQ_OK;
 }
 
+// Packed int4 (at-rest format) -> MFMA-ready int8 operand: byte (n, k) = q_w - z_w in [-15, 15], tile-major
+//   byte(n, k) = ((n/32 * nsteps + k/ck) * 32 + n%32) * ck + k%ck,   ck = w4_ck(cin), nsteps = K/ck
+// so one K-step of 32 output channels is one contiguous 32*ck-byte block the conv kernel DMAs straight into
+// LDS.  Folding z_w into the operand removes the per-row activation sums from the GEMM
+// (sum a'(q_w - z_w) needs no -z_w*sum a' correction).  Rows cout..cout_pad32 are zero.
+__global__ void k_expand_w4(const uint32_t* __restrict__ packed, const int32_t* __restrict__ wmeta, int cout,
+                            int cout_pad, int K, int ck, int8_t* __restrict__ w8) {
+  const size_t total = static_cast<size_t>(cout_pad) * (K / 8);
+  const int nsteps = K / ck;
+  for (size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < total;
+       i += static_cast<size_t>(gridDim.x) * blockDim.x) {
+    const int n = static_cast<int>(i / (K / 8)), g = static_cast<int>(i % (K / 8));
+    const int k0 = g * 8;
+    int8_t o[8];
+    if (n < cout) {
+      const uint32_t word = packed[w4_word_index(n, g, K, ck)];
+      const int z = wmeta[4 * n];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = static_cast<int8_t>(static_cast<int>((word >> ((j & 3) * 8 + (j >> 2) * 4)) & 15u) - z);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = 0;
+    }
+    const size_t dst = ((static_cast<size_t>(n / 32) * nsteps + k0 / ck) * 32 + (n % 32)) * ck + (k0 % ck);
+    *reinterpret_cast<uint2*>(w8 + dst) = *reinterpret_cast<const uint2*>(o);
+  }
+}
+
+extern "C" int tfmq_expand_w4(tfmq_handle h, const uint8_t* packed, const int32_t* wmeta, int cout, int cin, int kh,
+                              int kw, int8_t* w8, void* stream) {
+  TFMQ_CHECK_ARG(h, h && packed && wmeta && w8, "expand_w4: null pointer");
+  TFMQ_CHECK_ARG(h, cout > 0 && cin > 0 && kh > 0 && kw > 0 && cin % 32 == 0, "expand_w4: cin must be a multiple of 32");
+  const int K = kh * kw * cin, cout_pad = (cout + 31) / 32 * 32;
+  const size_t total = static_cast<size_t>(cout_pad) * (K / 8);
+  hipLaunchKernelGGL(k_expand_w4, dim3(ceil_div(total, 256)), dim3(256), 0, as_stream(stream),
+                     reinterpret_cast<const uint32_t*>(packed), wmeta, cout, cout_pad, K, w4_ck(cin), w8);
+  TFMQ_LAUNCH_CHECK(h);
+  return TFMQ_OK;
+}
+
 __global__ void k_pack_w_f16(const float* __restrict__ w, const float* __restrict__ alpha,
                              const float* __restrict__ delta, const float* __restrict__ zp, float lmax, int cout,
                              int cin, int cin_pad, int khw, __half* __restrict__ out) {

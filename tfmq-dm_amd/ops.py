@@ -178,11 +178,20 @@ def mse_search(x: torch.Tensor, rows: int, level: int, always_zero: bool = False
 
 # ------------------------------------------------------------------------------ K4
 class PackedW4:
-    """int4 weights of one QuantLayer, resident on the device."""
+    """int4 weights of one QuantLayer, resident on the device.
+
+    packed : at-rest format, two weights per byte (tfmq_pack_w4)
+    w8     : the conv/linear kernels' operand, int8 (q_w - z_w) tiles expanded once from `packed`
+             (tfmq_expand_w4); None when cin % 32 != 0 (only the small GEMV reads such layers)."""
 
     def __init__(self, packed, wmeta, wscale, bias, cout, cin, kh, kw):
         self.packed, self.wmeta, self.wscale, self.bias = packed, wmeta, wscale, bias
         self.cout, self.cin, self.kh, self.kw = cout, cin, kh, kw
+        self.w8 = None
+        if cin % 32 == 0:
+            d = _dev(packed)
+            self.w8 = torch.empty((cout + 31) // 32 * 32 * kh * kw * cin, dtype=torch.int8, device=packed.device)
+            handle(d).call("expand_w4", _p(packed), _p(wmeta), cout, cin, kh, kw, _p(self.w8), _stream(d))
 
 
 def pack_w4(w: torch.Tensor, delta: torch.Tensor, zp: torch.Tensor, alpha: Optional[torch.Tensor] = None,
@@ -197,8 +206,8 @@ def pack_w4(w: torch.Tensor, delta: torch.Tensor, zp: torch.Tensor, alpha: Optio
     z = zp.reshape(-1).contiguous().float()
     if dl.numel() != cout or z.numel() != cout:
         raise TfmqError("pack_w4: delta/zp must have one entry per output channel")
-    if float(z.abs().max()) > 255:
-        raise TfmqError("pack_w4: |weight zero-point| > 255 is not supported by the int32 epilogue")
+    if float(z.max()) > 127 or float(z.min()) < -112:
+        raise TfmqError("pack_w4: weight zero-point outside [-112, 127] (q - z must fit int8)")
     if alpha is not None:
         _chk(alpha, torch.float32, "alpha")
     # tile-major layout (csrc/common.hpp w4_word_index): rows padded to a multiple of 32 output channels
@@ -326,7 +335,9 @@ def conv2d_w4a8(xq: torch.Tensor, pw: PackedW4, aq: QSel, stride: int = 1, pad: 
     y = out if out is not None else _alloc(B, Ho, Wo, pw.cout, dtype=torch.float32, device=xq.device)
     dsc = _conv_desc(xq, B, H, W, cin, pw.cout, pw.kh, pw.kw, stride, pad[0], pad[1], Ho, Wo, up2x, y, y.shape[-1], y_coff,
                      rowadd, residual, rowadd_ld, rowadd_step, rowadd_step_stride)
-    dsc.w, dsc.wmeta, dsc.wscale = pw.packed.data_ptr(), pw.wmeta.data_ptr(), pw.wscale.data_ptr()
+    if pw.w8 is None:
+        raise TfmqError("conv2d_w4a8: Cin must be a multiple of 32")
+    dsc.w, dsc.wmeta, dsc.wscale = pw.w8.data_ptr(), pw.wmeta.data_ptr(), pw.wscale.data_ptr()
     dsc.bias = None if pw.bias is None else pw.bias.data_ptr()
     dsc.aq = aq
     _attach_stats(dsc, y, B, Ho * Wo, pw.cout, want_stats and y_coff == 0)
