@@ -145,8 +145,21 @@ typedef struct tfmq_conv_desc {
   float* stats;                  /* optional [ceil(M/stats_seg)][Cout][2]: per-channel {sum, sum of squares} of every
                                     stats_seg consecutive output pixels, for the GroupNorm that consumes y (K8) */
   int32_t stats_seg;             /* 16, 32, 64 or 128; must divide Ho*Wo */
-  int32_t reserved_;
+  int32_t out_mode;              /* TFMQ_OUT_F32 (0): y as above.
+                                    TFMQ_OUT_F16: y is an fp16 buffer (ldy / y_coff in halves): operands of the
+                                      f16 attention kernel (q/k/v projections), rounded once exactly as that kernel
+                                      would on load.
+                                    TFMQ_OUT_GEGLU_Q8 (w4a8, Linear only): the layer is GEGLU's projection
+                                      (ldm/modules/attention.py:52-59) with its 2*inner output channels interleaved
+                                      per 128-column tile as [64 value | 64 gate] (packed row p holds original row
+                                      (p/128)*64 + p%64 (+ inner when p%128 >= 64)); the epilogue
+                                      writes yq[m][c] = quant_oq(value * gelu(gate)) - 128, int8 [M][Cout/2],
+                                      i.e. the next QuantLayer's input (quant_layer.py:312-313), and y is unused.
+                                    rowadd / residual / stats are only defined for TFMQ_OUT_F32. */
+  tfmq_qsel oq;                  /* TFMQ_OUT_GEGLU_Q8: activation quantizer of the consumer */
+  int8_t* yq;                    /* TFMQ_OUT_GEGLU_Q8: int8 output */
 } tfmq_conv_desc;
+enum { TFMQ_OUT_F32 = 0, TFMQ_OUT_F16 = 1, TFMQ_OUT_GEGLU_Q8 = 2 };
 int tfmq_conv2d_w4a8(tfmq_handle h, const tfmq_conv_desc* d, void* stream);
 int tfmq_conv2d_f16(tfmq_handle h, const tfmq_conv_desc* d, void* stream);
 

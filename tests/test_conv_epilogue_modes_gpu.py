@@ -1,0 +1,77 @@
+"""Fused output modes of the w4a8 GEMM epilogue (include/tfmq_hip.h: tfmq_conv_desc.out_mode).
+
+TFMQ_OUT_F16       the fp32 result rounded once to fp16 -- bit-identical to casting the fp32 output.
+TFMQ_OUT_GEGLU_Q8  GEGLU (ldm/modules/attention.py:52-59: x, gate = proj(x).chunk(2); x * gelu(gate)) followed by
+                   the next QuantLayer's 8-bit activation quantizer (quant_layer.py:223-226), checked bit-exactly
+                   against the unfused kernels and against the oracle's arithmetic.
+"""
+import os
+import sys
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "oracle"))
+import tfmq_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def ops():
+    import tfmq_dm_amd.ops as ops
+    return ops
+
+
+def qtab(delta, zp):
+    return torch.tensor([[float(delta), float(zp)]], dtype=torch.float32, device=DEV)
+
+
+def _setup(ops, B, T, cin, cout, seed):
+    gen = torch.Generator().manual_seed(seed)
+    x = torch.randn(B, T, 1, cin, generator=gen) * 1.3 - 0.2
+    w = torch.randn(cout, cin, 1, 1, generator=gen) * (2.0 / cin ** 0.5)
+    b = torch.randn(cout, generator=gen) * 0.2
+    wd, wz = O.init_channelwise(w, 16, "minmax")
+    ad, az = O.minmax(x, 256)
+    sel = ops.qsel(qtab(ad, az))
+    xq = ops.quantize_act(x.to(DEV), sel)
+    return x, w, b, wd, wz, ad, az, sel, xq
+
+
+@pytest.mark.parametrize("B,T,cin,cout", [(2, 256, 128, 384), (1, 77, 64, 200), (3, 64, 320, 64)])
+def test_f16_output_is_the_rounded_fp32_output(ops, B, T, cin, cout):
+    x, w, b, wd, wz, ad, az, sel, xq = _setup(ops, B, T, cin, cout, 5 + cout)
+    pw = ops.pack_w4(w.to(DEV), wd.to(DEV), wz.to(DEV), bias=b.to(DEV))
+    y32 = ops.conv2d_w4a8(xq, pw, sel)
+    y16 = ops.conv2d_w4a8(xq, pw, sel, out_f16=True)
+    assert y16.dtype == torch.float16 and y16.shape == y32.shape
+    assert torch.equal(y16, y32.half())
+
+
+@pytest.mark.parametrize("B,T,cin,inner", [(2, 200, 128, 256), (1, 64, 320, 1280), (2, 77, 64, 64)])
+def test_geglu_epilogue_bit_exact(ops, B, T, cin, inner):
+    x, w, b, wd, wz, ad, az, sel, xq = _setup(ops, B, T, cin, 2 * inner, 11 + inner)
+    pw = ops.pack_w4(w.to(DEV), wd.to(DEV), wz.to(DEV), bias=b.to(DEV))
+    h = ops.conv2d_w4a8(xq, pw, sel)                                   # fp32 [B,T,1,2*inner]
+    # consumer quantizer from the unfused fp32 GEGLU output
+    gf = ops.geglu(h.reshape(B, T, 2 * inner), None)[1]
+    od, oz = O.minmax(gf.cpu(), 256)
+    osel = ops.qsel(qtab(od, oz))
+    want = ops.geglu(h.reshape(B, T, 2 * inner), osel)[0]
+    perm = ops.geglu_perm(inner)
+    pwp = ops.pack_w4(w[perm].contiguous().to(DEV), wd.reshape(-1)[perm].contiguous().to(DEV),
+                      wz.reshape(-1)[perm].contiguous().to(DEV), bias=b[perm].contiguous().to(DEV))
+    got = ops.conv2d_w4a8(xq, pwp, sel, geglu_oq=osel)
+    assert got.dtype == torch.int8 and got.shape == (B, T, 1, inner)
+    assert torch.equal(got.reshape(B, T, inner), want)
+    # and against the oracle's arithmetic on the same fake-quantised operands (bins may differ only where the
+    # fp32 GEMM rounding moves a value across a bin edge)
+    ref_h = F.conv2d(O.fake_quant(x.permute(0, 3, 1, 2), ad, az, 256), O.fake_quant(w, wd, wz, 16), b)
+    ref_h = ref_h.permute(0, 2, 3, 1).reshape(B, T, 2 * inner)
+    a, g = ref_h.chunk(2, dim=-1)
+    ref_bins = O.quant_index(a * F.gelu(g), od, oz, 256)
+    diff = (got.reshape(B, T, inner).cpu().float() + 128 - ref_bins).abs()
+    assert diff.max() <= 1 and (diff > 0).float().mean() < 2e-3

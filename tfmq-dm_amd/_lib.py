@@ -37,7 +37,8 @@ class ConvDesc(C.Structure):
         ("rowadd", c_void_p), ("rowadd_step", c_void_p), ("rowadd_ld", C.c_int32), ("rowadd_step_stride", C.c_int32),
         ("residual", c_void_p), ("y", c_void_p),
         ("ldy", C.c_int32), ("y_coff", C.c_int32),
-        ("stats", c_void_p), ("stats_seg", C.c_int32), ("reserved_", C.c_int32),
+        ("stats", c_void_p), ("stats_seg", C.c_int32), ("out_mode", C.c_int32),
+        ("oq", QSel), ("yq", c_void_p),
     ]
 
 

@@ -140,6 +140,59 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, unsigned char* lds
       }
     }
     __syncthreads();
+    if constexpr (INT8 && BN == 128) {
+      if (d.out_mode == TFMQ_OUT_GEGLU_Q8) {
+        // tile columns [0,64) = value, [64,128) = gate of the same 64 output channels:
+        // yq = quant(value * gelu(gate)), gelu exact (erf), the arithmetic of k_geglu
+        const float2 oqp = load_qparam(d.oq);
+        const int inner = d.Cout >> 1, rg = tid >> 4, g4 = (tid & 15) * 4;
+#pragma unroll
+        for (int k = 0; k < PR / 16; ++k) {
+          const int prow = rg + 16 * k;
+          const int m = m0 + pass * PR + prow;
+          if (m >= p.M) continue;
+          const float4 a = *reinterpret_cast<const float4*>(ldsO + prow * LDO + g4);
+          const float4 g = *reinterpret_cast<const float4*>(ldsO + prow * LDO + 64 + g4);
+          float4 y;
+          y.x = a.x * (0.5f * g.x * (1.0f + erff(g.x * 0.70710678118654752440f)));
+          y.y = a.y * (0.5f * g.y * (1.0f + erff(g.y * 0.70710678118654752440f)));
+          y.z = a.z * (0.5f * g.z * (1.0f + erff(g.z * 0.70710678118654752440f)));
+          y.w = a.w * (0.5f * g.w * (1.0f + erff(g.w * 0.70710678118654752440f)));
+          char4 q;
+          q.x = static_cast<signed char>(static_cast<int>(quant_index_f(y.x, oqp.x, oqp.y, 255.0f)) - 128);
+          q.y = static_cast<signed char>(static_cast<int>(quant_index_f(y.y, oqp.x, oqp.y, 255.0f)) - 128);
+          q.z = static_cast<signed char>(static_cast<int>(quant_index_f(y.z, oqp.x, oqp.y, 255.0f)) - 128);
+          q.w = static_cast<signed char>(static_cast<int>(quant_index_f(y.w, oqp.x, oqp.y, 255.0f)) - 128);
+          *reinterpret_cast<char4*>(d.yq + static_cast<size_t>(m) * inner + (n0 >> 1) + g4) = q;
+        }
+        continue;
+      }
+    }
+    if (d.out_mode == TFMQ_OUT_F16) {
+      __half* yh = reinterpret_cast<__half*>(d.y);
+#pragma unroll
+      for (int k = 0; k < RPT; ++k) {
+        const int prow = tr * RPT + k;
+        const int m = m0 + pass * PR + prow;
+        const int n = n0 + c4;
+        if (m >= p.M || n >= d.Cout) continue;
+        const float4 v = *reinterpret_cast<const float4*>(ldsO + prow * LDO + c4);
+        __half* dst = yh + static_cast<size_t>(m) * d.ldy + d.y_coff + n;
+        if (vec_ok) {
+          const __half2 lo = __floats2half2_rn(v.x, v.y), hi = __floats2half2_rn(v.z, v.w);
+          uint2 u;
+          u.x = *reinterpret_cast<const unsigned*>(&lo);
+          u.y = *reinterpret_cast<const unsigned*>(&hi);
+          *reinterpret_cast<uint2*>(dst) = u;
+        } else {
+          const float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            if (n + q < d.Cout) dst[q] = __float2half_rn(e[q]);
+        }
+      }
+      continue;
+    }
     // phase 2: whole rows out, + temb row + residual, + statistics
     float4 ps = make_float4(0.f, 0.f, 0.f, 0.f), pss = ps;
 #pragma unroll
@@ -638,10 +691,16 @@ template <bool INT8>
 static int launch_conv(tfmq_handle h, const tfmq_conv_desc* dd, void* stream) {
   TFMQ_CHECK_ARG(h, h && dd, "conv: null pointer");
   const tfmq_conv_desc& d = *dd;
-  TFMQ_CHECK_ARG(h, d.x && d.w && d.y, "conv: null operand");
+  TFMQ_CHECK_ARG(h, d.x && d.w && (d.y || d.out_mode == TFMQ_OUT_GEGLU_Q8), "conv: null operand");
   TFMQ_CHECK_ARG(h, d.B > 0 && d.H > 0 && d.W > 0 && d.Cin > 0 && d.Cout > 0 && d.KH > 0 && d.KW > 0 && d.stride > 0,
                  "conv: bad geometry");
   TFMQ_CHECK_ARG(h, d.Ho > 0 && d.Wo > 0 && d.ldy >= d.Cout + d.y_coff, "conv: bad output geometry");
+  TFMQ_CHECK_ARG(h, d.out_mode == TFMQ_OUT_F32 || (!d.rowadd && !d.residual && !d.stats),
+                 "conv: rowadd / residual / stats need out_mode F32");
+  TFMQ_CHECK_ARG(h, d.out_mode != TFMQ_OUT_GEGLU_Q8 ||
+                        (INT8 && d.yq && d.oq.qtable && d.KH == 1 && d.KW == 1 && d.Cout % 128 == 0 && d.Cout / 2 % 4 == 0),
+                 "conv: GEGLU epilogue needs a w4a8 Linear with Cout % 128 == 0, yq and oq");
+  TFMQ_CHECK_ARG(h, d.out_mode >= 0 && d.out_mode <= 2, "conv: bad out_mode");
   TFMQ_CHECK_ARG(h, !d.stats || ((d.stats_seg == 16 || d.stats_seg == 32 || d.stats_seg == 64 || d.stats_seg == 128) &&
                                  (d.Ho * d.Wo) % d.stats_seg == 0),
                  "conv: stats_seg must be 16/32/64/128 and divide Ho*Wo");
@@ -663,10 +722,11 @@ static int launch_conv(tfmq_handle h, const tfmq_conv_desc* dd, void* stream) {
     p.cin_pad = p.chunks * 32;
   }
   p.nsteps = d.KH * d.KW * p.chunks;
+  const bool geglu = d.out_mode == TFMQ_OUT_GEGLU_Q8;  // epilogue pairs columns inside one 128-wide tile
   const bool narrow = d.Cout <= 32;
   // small-M layers (4x4 / 8x8 feature maps): 128x128 tiles leave most of the 256 CUs idle -> 64x64 tiles
   // (a statistics segment must not span tiles, so 128-pixel segments keep the 128-row tile)
-  const bool small = !narrow && !(d.stats && d.stats_seg > 64) &&
+  const bool small = !narrow && !geglu && !(d.stats && d.stats_seg > 64) &&
                      static_cast<long>((p.M + 127) / 128) * ((d.Cout + 127) / 128) < 2L * h->cu_count;
   const int BM = small ? 64 : 128, BN = narrow ? 32 : (small ? 64 : 128);
   p.tiles_n = (d.Cout + BN - 1) / BN;

@@ -80,6 +80,26 @@ class LdmUNetEngine(DdimUNetEngine):
                 if f is not None:
                     self.fused_kv[p] = f
 
+        # GEGLU projection with the value/gate rows interleaved per 128-column tile: the GEMM epilogue applies
+        # value * gelu(gate) and the consumer's 8-bit quantizer, the [B,T,2*inner] fp32 tensor never reaches HBM
+        self.geglu_fused: Dict[str, ops.PackedW4] = {}
+        for n in list(self.layers):
+            if not n.endswith(".ff.net.0.proj"):
+                continue
+            l0, l2 = self.layers[n], self.layers.get(n[:-len("0.proj")] + "2")
+            q = wq.get(n)
+            if l0.kind != "w4a8" or l2 is None or l2.kind != "w4a8" or q is None:
+                continue
+            w, b = self.sd[n + ".weight"], self.sd.get(n + ".bias")
+            inner = w.shape[0] // 2
+            if inner % 64:
+                continue
+            perm = ops.geglu_perm(inner, self.dev)
+            a = None if q.alpha is None else q.alpha.to(self.dev)[perm].contiguous()
+            self.geglu_fused[n] = ops.pack_w4(w[perm].contiguous(), q.delta.to(self.dev).reshape(-1)[perm].contiguous(),
+                                              q.zp.to(self.dev).reshape(-1)[perm].contiguous(), a,
+                                              None if b is None else b[perm].contiguous())
+
     def _fuse(self, ls, qs):
         kinds = {l.kind for l in ls}
         if len(kinds) != 1:
@@ -174,6 +194,12 @@ class LdmUNetEngine(DdimUNetEngine):
         x = self._attention(p + ".attn1", self._ln(p + ".norm1", x, q1), None, x, True)
         x = self._attention(p + ".attn2", self._ln(p + ".norm2", x, L[p + ".attn2.to_q"]), ctx, x, False)
         ff0, ff2 = L[p + ".ff.net.0.proj"], L[p + ".ff.net.2"]
+        gp = self.geglu_fused.get(p + ".ff.net.0.proj")
+        if gp is not None and self.calib is None:
+            xq = self._ln(p + ".norm3", x, ff0)
+            B, T, Cc = xq.shape
+            g = ops.conv2d_w4a8(xq.reshape(B, T, 1, Cc), gp, ff0.aq, geglu_oq=ff2.aq).reshape(B, T, -1)
+            return self._tok(ff2, g, residual=x)
         h = self._tok(ff0, self._ln(p + ".norm3", x, ff0))
         if ff2.kind == "w4a8" and self.calib is None:
             g = ops.geglu(h, ff2.aq)[0]

@@ -321,28 +321,56 @@ def out_hw(H, W, kh, kw, stride, pad_t, pad_l, pad_b, pad_r, up2x=False):
     return (H + pad_t + pad_b - kh) // stride + 1, (W + pad_l + pad_r - kw) // stride + 1
 
 
+def geglu_perm(inner: int, device=None) -> torch.Tensor:
+    """Row order of a GEGLU projection [2*inner, K] for the fused epilogue (TFMQ_OUT_GEGLU_Q8): every 128-row
+    group holds 64 value rows followed by the 64 gate rows of the same output channels."""
+    if inner % 64:
+        raise TfmqError("geglu_perm: inner must be a multiple of 64")
+    p = torch.arange(2 * inner, device=device)
+    return (p // 128) * 64 + p % 64 + (p % 128 >= 64) * inner
+
+
 def conv2d_w4a8(xq: torch.Tensor, pw: PackedW4, aq: QSel, stride: int = 1, pad: Tuple[int, int, int, int] = (0, 0, 0, 0),
                 up2x: bool = False, rowadd: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
                 out: Optional[torch.Tensor] = None, y_coff: int = 0, rowadd_ld=None, rowadd_step=None,
-                rowadd_step_stride: int = 0, want_stats: bool = False) -> torch.Tensor:
-    """xq: int8 NHWC [B,H,W,Cin] (bin-128).  pad = (top, left, bottom, right).  -> fp32 NHWC."""
+                rowadd_step_stride: int = 0, want_stats: bool = False, out_f16: bool = False,
+                geglu_oq: Optional[QSel] = None) -> torch.Tensor:
+    """xq: int8 NHWC [B,H,W,Cin] (bin-128).  pad = (top, left, bottom, right).  -> fp32 NHWC.
+    out_f16: fp16 output (operands of the attention kernel).  geglu_oq: `pw` is a geglu_perm-ordered GEGLU projection;
+    returns int8 [B,Ho,Wo,Cout/2] = quant_geglu_oq(value * gelu(gate)) - 128."""
     d = _dev(xq)
     _chk(xq, torch.int8, "xq")
     B, H, W, cin = xq.shape
     if cin != pw.cin:
         raise TfmqError(f"conv2d_w4a8: Cin mismatch {cin} vs {pw.cin}")
     Ho, Wo = out_hw(H, W, pw.kh, pw.kw, stride, pad[0], pad[1], pad[2], pad[3], up2x)
-    y = out if out is not None else _alloc(B, Ho, Wo, pw.cout, dtype=torch.float32, device=xq.device)
-    dsc = _conv_desc(xq, B, H, W, cin, pw.cout, pw.kh, pw.kw, stride, pad[0], pad[1], Ho, Wo, up2x, y, y.shape[-1], y_coff,
+    if geglu_oq is not None:
+        if out is not None or rowadd is not None or residual is not None or want_stats or out_f16:
+            raise TfmqError("conv2d_w4a8: the GEGLU epilogue takes no other epilogue option")
+        y = _alloc(B, Ho, Wo, pw.cout // 2, dtype=torch.int8, device=xq.device)
+        ldy = pw.cout
+    else:
+        y = out if out is not None else _alloc(B, Ho, Wo, pw.cout, dtype=torch.float16 if out_f16 else torch.float32,
+                                               device=xq.device)
+        _chk(y, torch.float16 if out_f16 else torch.float32, "out")
+        ldy = y.shape[-1]
+    dsc = _conv_desc(xq, B, H, W, cin, pw.cout, pw.kh, pw.kw, stride, pad[0], pad[1], Ho, Wo, up2x, y, ldy, y_coff,
                      rowadd, residual, rowadd_ld, rowadd_step, rowadd_step_stride)
     if pw.w8 is None:
         raise TfmqError("conv2d_w4a8: Cin must be a multiple of 32")
     dsc.w, dsc.wmeta, dsc.wscale = pw.w8.data_ptr(), pw.wmeta.data_ptr(), pw.wscale.data_ptr()
     dsc.bias = None if pw.bias is None else pw.bias.data_ptr()
     dsc.aq = aq
-    _attach_stats(dsc, y, B, Ho * Wo, pw.cout, want_stats and y_coff == 0)
-    # algorithmic HBM bytes: int8 input once + packed int4 weights + fp32 output (+ fp32 residual)
-    nbytes = B * H * W * cin + pw.cout * pw.kh * pw.kw * cin / 2 + 4.0 * B * Ho * Wo * pw.cout * (2 if residual is not None else 1)
+    osz = 4.0
+    if geglu_oq is not None:
+        dsc.out_mode, dsc.oq, dsc.yq, dsc.y = 2, geglu_oq, y.data_ptr(), None
+        osz = 0.5
+    elif out_f16:
+        dsc.out_mode = 1
+        osz = 2.0
+    _attach_stats(dsc, y, B, Ho * Wo, pw.cout, want_stats and y_coff == 0 and dsc.out_mode == 0)
+    # algorithmic HBM bytes: int8 input once + int8 weight operand + output (+ fp32 residual)
+    nbytes = B * H * W * cin + pw.cout * pw.kh * pw.kw * cin + B * Ho * Wo * pw.cout * (osz + (4.0 if residual is not None else 0.0))
     _profiled_conv("conv2d_w4a8", "w4a8", d, dsc, 2.0 * B * Ho * Wo * pw.cout * pw.kh * pw.kw * cin, nbytes)
     return y
 
