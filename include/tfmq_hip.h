@@ -158,6 +158,11 @@ typedef struct tfmq_conv_desc {
                                     rowadd / residual / stats are only defined for TFMQ_OUT_F32. */
   tfmq_qsel oq;                  /* TFMQ_OUT_GEGLU_Q8: activation quantizer of the consumer */
   int8_t* yq;                    /* TFMQ_OUT_GEGLU_Q8: int8 output */
+  uint16_t* yt;                  /* TFMQ_OUT_F16, optional: output channels n >= t_col0 are written TRANSPOSED,
+                                    fp16 yt[b][n - t_col0][t], t = ho*Wo + wo (instead of into y): the V^T operand of
+                                    tfmq_attention_f16 straight from the fused q|k|v projection */
+  int32_t t_col0;                /* multiple of 128; Ho*Wo % 4 == 0 required */
+  int32_t pad0_;
 } tfmq_conv_desc;
 enum { TFMQ_OUT_F32 = 0, TFMQ_OUT_F16 = 1, TFMQ_OUT_GEGLU_Q8 = 2 };
 int tfmq_conv2d_w4a8(tfmq_handle h, const tfmq_conv_desc* d, void* stream);
@@ -215,6 +220,11 @@ int tfmq_geglu(tfmq_handle h, const float* hin, long rows, int inner, tfmq_qsel 
 int tfmq_attention(tfmq_handle h, const float* q, const float* k, const float* v, int ldq, int ldk, int ldv,
                    float* out, int ldo, int8_t* yq, tfmq_qsel aq, int B, int heads, int Tq, int Tk, int d,
                    float scale, void* stream);
+/* Same operation on fp16 operands written by the projection GEMM (TFMQ_OUT_F16): q,k as above (ld in halves),
+ * vt = V transposed, fp16 [B][heads*d][Tk] (tfmq_conv_desc.yt).  d % 8 == 0, d <= 160, Tk % 8 == 0. */
+int tfmq_attention_f16(tfmq_handle h, const uint16_t* q, const uint16_t* k, const uint16_t* vt, int ldq, int ldk,
+                       float* out, int ldo, int8_t* yq, tfmq_qsel aq, int B, int heads, int Tq, int Tk, int d,
+                       float scale, void* stream);
 
 /* ---- K11: sampler elementwise (generalized_steps, ddim/functions/denoising.py:31-37) ----- */
 /* coef: device [n_steps][4] = {sqrt(1-a_t), 1/sqrt(a_t)... see DESIGN.md}; step: device scalar.

@@ -1,0 +1,34 @@
+import sys, os
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+import tfmq_dm_amd.ops as ops
+DEV = "cuda:0"
+def timeit(fn, n=10):
+    fn(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n): fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1)/n
+qt = torch.tensor([[0.05, 120.0]], device=DEV); sel = ops.qsel(qt)
+cases = [(16,4096,1,320,2560,1,"geglu"), (16,4096,1,320,2560,1,"f32"), (16,4096,1,320,320,1,"res"), (16,4096,1,320,960,1,"qkv"),
+         (16,64,64,320,320,3,"res"), (16,4096,1,1280,320,1,"res")]
+for (B,H,W,cin,cout,k,mode) in cases:
+    x = (torch.randn(B,H,W,cin, device=DEV)*40).clamp(-128,127).to(torch.int8)
+    w = torch.randn(cout,cin,k,k, device=DEV)*0.02
+    qp = ops.minmax_to_qparam(ops.minmax(w, cout), 16)
+    pw = ops.pack_w4(w, qp[:,0].contiguous(), qp[:,1].contiguous(), bias=torch.zeros(cout, device=DEV))
+    pad = (k//2,)*4
+    res = torch.randn(B,H,W,cout, device=DEV) if mode == "res" else None
+    if mode == "geglu": fn = lambda: ops.conv2d_w4a8(x, pw, sel, geglu_oq=sel)
+    elif mode == "qkv": fn = lambda: ops.conv2d_w4a8(x, pw, sel, out_f16=True, t_col0=640)
+    else:
+        y = ops.conv2d_w4a8(x, pw, sel, pad=pad, residual=res)
+        fn = lambda: ops.conv2d_w4a8(x, pw, sel, pad=pad, residual=res, out=y)
+    os.environ.pop("TFMQ_PHASE_PRINT", None)
+    ms = timeit(fn)
+    print((B,H,W,cin,cout,k,mode), f"{ms*1e3:.1f} us", flush=True)
+    os.environ["TFMQ_PHASE_PRINT"] = "1"
+    fn(); torch.cuda.synchronize()
+    os.environ.pop("TFMQ_PHASE_PRINT", None)

@@ -1,0 +1,84 @@
+"""fp16-operand attention (tfmq_attention_f16) and the projection GEMM's transposed fp16 output that feeds it.
+
+Reference semantics: QuantAttnBlock / cross_attn_forward (quant/quant_block.py:285-299, 483-500): softmax(q k^T * scale) v
+on un-quantised operands.  Bar 3e-3 max-normalised, as for tfmq_attention: q, k, v and P are rounded to f16 for the
+MFMA (fp32 accumulation).
+"""
+import os
+import sys
+
+import pytest
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "oracle"))
+import tfmq_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def ops():
+    import tfmq_dm_amd.ops as ops
+    return ops
+
+
+def qtab(delta, zp):
+    return torch.tensor([[float(delta), float(zp)]], dtype=torch.float32, device=DEV)
+
+
+def maxnorm(a, b):
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-12))
+
+
+@pytest.mark.parametrize("B,heads,Tq,Tk,d", [(2, 8, 256, 256, 40), (1, 2, 200, 200, 64), (2, 1, 130, 136, 160),
+                                             (1, 4, 64, 72, 32), (1, 2, 128, 1000, 80), (2, 1, 256, 256, 128)])
+def test_attention_f16_vs_fp32(ops, B, heads, Tq, Tk, d):
+    gen = torch.Generator().manual_seed(Tq + d)
+    C = heads * d
+    q = torch.randn(B, Tq, C, generator=gen)
+    k = torch.randn(B, Tk, C, generator=gen)
+    v = torch.randn(B, Tk, C, generator=gen)
+    scale = d ** -0.5
+    qh = q.reshape(B, Tq, heads, d).permute(0, 2, 1, 3)
+    kh = k.reshape(B, Tk, heads, d).permute(0, 2, 1, 3)
+    vh = v.reshape(B, Tk, heads, d).permute(0, 2, 1, 3)
+    ref = torch.softmax(qh @ kh.transpose(-1, -2) * scale, -1) @ vh
+    ref = ref.permute(0, 2, 1, 3).reshape(B, Tq, C)
+    ad, az = O.minmax(ref, 256)
+    assert ops.attention_f16_ok(d, Tk)
+    vt = v.transpose(1, 2).contiguous().half().to(DEV)
+    out, yq = ops.attention_f16(q.half().to(DEV), k.half().to(DEV), vt, heads, scale, ops.qsel(qtab(ad, az)))
+    assert maxnorm(out.cpu(), ref) <= 3e-3
+    assert torch.equal(yq.cpu().float() + 128, O.quant_index(out.cpu(), ad, az, 256))
+    # agrees with the fp32-operand kernel to the rounding of exp2 / accumulation order
+    out32, _ = ops.attention(q.to(DEV), k.to(DEV), v.to(DEV), heads, scale)
+    assert maxnorm(out.cpu(), out32.cpu()) <= 2e-3
+    # q | k column slices of one fused buffer
+    if Tq == Tk:
+        qk = torch.cat([q, k], -1).half().to(DEV)
+        out2, _ = ops.attention_f16(qk[..., :C], qk[..., C:], vt, heads, scale)
+        assert torch.equal(out2, out)
+
+
+@pytest.mark.parametrize("B,T,cin,C", [(2, 256, 128, 128), (1, 64, 64, 320), (2, 100, 320, 64)])
+def test_fused_qkv_gemm_writes_v_transposed(ops, B, T, cin, C):
+    gen = torch.Generator().manual_seed(C + T)
+    x = torch.randn(B, T, 1, cin, generator=gen)
+    w = torch.randn(3 * C, cin, 1, 1, generator=gen) * (2.0 / cin ** 0.5)
+    b = torch.randn(3 * C, generator=gen) * 0.1
+    wd, wz = O.init_channelwise(w, 16, "minmax")
+    ad, az = O.minmax(x, 256)
+    sel = ops.qsel(qtab(ad, az))
+    xq = ops.quantize_act(x.to(DEV), sel)
+    pw = ops.pack_w4(w.to(DEV), wd.to(DEV), wz.to(DEV), bias=b.to(DEV))
+    y32 = ops.conv2d_w4a8(xq, pw, sel).reshape(B, T, 3 * C)
+    if (2 * C) % 128:
+        with pytest.raises(Exception):
+            ops.conv2d_w4a8(xq, pw, sel, out_f16=True, t_col0=2 * C)
+        return
+    y16, yt = ops.conv2d_w4a8(xq, pw, sel, out_f16=True, t_col0=2 * C)
+    y16 = y16.reshape(B, T, 3 * C)
+    assert torch.equal(y16[..., :2 * C], y32[..., :2 * C].half())
+    assert yt.shape == (B, C, T)
+    assert torch.equal(yt, y32[..., 2 * C:].half().transpose(1, 2))

@@ -38,7 +38,7 @@ class ConvDesc(C.Structure):
         ("residual", c_void_p), ("y", c_void_p),
         ("ldy", C.c_int32), ("y_coff", C.c_int32),
         ("stats", c_void_p), ("stats_seg", C.c_int32), ("out_mode", C.c_int32),
-        ("oq", QSel), ("yq", c_void_p),
+        ("oq", QSel), ("yq", c_void_p), ("yt", c_void_p), ("t_col0", C.c_int32), ("pad0_", C.c_int32),
     ]
 
 
@@ -83,6 +83,7 @@ _SIGS = {
     "tfmq_geglu": (c_int, [c_void_p, c_void_p, C.c_long, c_int, QSel, c_void_p, c_void_p, c_void_p]),
     "tfmq_attention": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p, QSel,
                                c_int, c_int, c_int, c_int, c_int, c_float, c_void_p]),
+    "tfmq_attention_f16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, QSel, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p]),
     "tfmq_ddim_update": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p]),
     "tfmq_ddim_update_cfg": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_size_t,
                                      c_void_p, c_void_p, c_void_p]),

@@ -18,7 +18,10 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "libtfmq_hip.so")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
-         "-Wall", "-Wno-unused-function"]
+         "-Wall", "-Wno-unused-function"] + os.environ.get("TFMQ_EXTRA_HIPCC_FLAGS", "").split()
+# Per-file additions.  VGPR-form MFMA: the softmax works on the score accumulators with VALU instructions, and with
+# the accumulators in AGPRs every key tile paid 64 v_accvgpr_read/write (a quarter of the kernel's VALU time).
+FILE_FLAGS = {"attention_f16.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
 
 
 def _hipcc():
@@ -30,7 +33,7 @@ def _hipcc():
 
 def _digest(path, extra):
     h = hashlib.sha1()
-    h.update(" ".join(FLAGS).encode())
+    h.update(" ".join(FLAGS + FILE_FLAGS.get(os.path.basename(path), [])).encode())
     for p in [path] + extra:
         with open(p, "rb") as f:
             h.update(f.read())
@@ -56,7 +59,7 @@ def build(force=False, verbose=True):
 
     def compile_one(job):
         src, obj, stamp, dig = job
-        cmd = [hipcc] + FLAGS + ["-c", src, "-o", obj]
+        cmd = [hipcc] + FLAGS + FILE_FLAGS.get(os.path.basename(src), []) + ["-c", src, "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("hipcc failed for %s:\n%s\n%s" % (src, r.stdout, r.stderr))

@@ -1,0 +1,277 @@
+// K10 (main path): fused softmax(Q K^T * scale) V with fp16 operands written by the projection GEMM's epilogue
+// (TFMQ_OUT_F16: q, k row-major [B][T][ld]; v TRANSPOSED [B][heads*d][Tk], tfmq_conv_desc.yt).  Same mathematics
+// and the same MFMA operand roles as k_attention (attention.hip); what changes is how the tiles travel:
+//
+//   * no conversion and no transposition in the kernel: K rows and V^T rows are copied as 16-byte pieces;
+//   * Q fragments live in registers for the whole kernel (no LDS for Q);
+//   * 64-key tiles, double-buffered LDS, ONE barrier per tile; the global loads of tile t+1 are issued before
+//     the MFMAs of tile t and written to the other buffer after them (register staging split);
+//   * key k of a 32-key sub-tile is stored at LDS row swap_bits_2_3(k): the S^T accumulator registers of a lane
+//     then hold 8 CONSECUTIVE keys per 16-key MFMA step, so the V^T fragment is one ds_read_b128;
+//   * exp2 with the softmax scale folded in, running-max rescale of O skipped when no lane's max moved.
+#include "common.hpp"
+#include <type_traits>
+
+typedef float v16f __attribute__((ext_vector_type(16)));
+typedef _Float16 v8h __attribute__((ext_vector_type(8)));
+
+struct AttnHP {
+  const __half *q, *k, *vt;
+  int ldq, ldk;
+  float* out;
+  int ldo;
+  int8_t* yq;
+  tfmq_qsel aq;
+  int B, heads, Tq, Tk, d;
+  float scale;
+};
+
+// NKS = k-steps of the score MFMA (16 channels each), NT = 32-column output tiles: compile-time, so that the MFMA
+// chains stay straight-line code (run-time trip counts made the compiler shuttle the accumulators between
+// AGPRs and VGPRs: ~900 moves per key tile).  d <= 16*NKS, d <= 32*NT; the LDS padding is zero.
+template <int NKS, int NT>
+__global__ __launch_bounds__(256) void k_attention_h(AttnHP p) {
+  constexpr int DPAD = NT * 32;
+  static_assert(NKS <= 2 * NT, "score k-steps must fit the padded row");
+  constexpr int KROW = DPAD * 2 + 16;    // bytes per K row in LDS (odd number of 16-byte slots: conflict-free)
+  constexpr int VROW = 64 * 2 + 16;      // bytes per V^T row (64 keys)
+  constexpr int KBUF = 64 * KROW, VBUF = DPAD * VROW;
+  constexpr int KPT = (64 * (DPAD / 8) + 255) / 256;   // 16-byte pieces per thread, K tile (upper bound)
+  constexpr int VPT = (DPAD * 8 + 255) / 256;          // ... V^T tile
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* sK = smem;                 // [2][64][KROW]
+  unsigned char* sV = smem + 2 * KBUF;      // [2][DPAD][VROW]
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int j = lane & 31, hh = lane >> 5;
+  const int b = blockIdx.y / p.heads, hd = blockIdx.y % p.heads;
+  const int q0 = blockIdx.x * 128;
+  const int d = p.d, dp8 = d >> 3;          // pieces per K row
+
+  // zero both buffers once: the pad pieces (halves d..16*nks of a K row, V^T rows d..32*nt) are never staged
+  for (int i = tid; i < (2 * KBUF + 2 * VBUF) / 16; i += 256) reinterpret_cast<uint4*>(smem)[i] = make_uint4(0, 0, 0, 0);
+
+  // ---- Q fragments (B operand of S^T = K Q^T): lane (query j, half hh) holds d-range ks*16 + hh*8 .. +7
+  v8h qf[NKS];
+  {
+    const int qrow = q0 + wid * 32 + j;
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+      uint4 v = make_uint4(0, 0, 0, 0);
+      const int c = ks * 16 + hh * 8;
+      if (qrow < p.Tq && c < d)
+        v = *reinterpret_cast<const uint4*>(p.q + (static_cast<size_t>(b) * p.Tq + qrow) * p.ldq + hd * d + c);
+      qf[ks] = *reinterpret_cast<v8h*>(&v);
+    }
+    // Pin the arrival of the (conditional) Q loads HERE.  Otherwise the compiler's wait-count bookkeeping carries
+    // "Q may still be in flight" into the key loop and puts s_waitcnt vmcnt(0) in front of every score MFMA,
+    // which also drains the K/V prefetch of the next tile that was issued just before.
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) asm volatile("" : "+v"(qf[ks]));
+  }
+
+  const __half* kbase = p.k + static_cast<size_t>(b) * p.Tk * p.ldk + hd * d;
+  const __half* vbase = p.vt + (static_cast<size_t>(b) * p.heads + hd) * d * p.Tk;
+  // ---- staging plan of this thread (the same for every key tile): global offset, LDS offset, first key
+  const int kpieces = 64 * dp8, vpieces = d * 8;
+  int k_go[KPT], k_lo[KPT], k_key[KPT], v_go[VPT], v_lo[VPT], v_key[VPT];
+#pragma unroll
+  for (int it = 0; it < KPT; ++it) {
+    const int idx = tid + it * 256;
+    const int key = idx / dp8, pc = idx - key * dp8;
+    const int row = (key & 0x33) | ((key & 4) << 1) | ((key & 8) >> 1);   // swap bits 2 and 3
+    k_key[it] = idx < kpieces ? key : (1 << 30);    // never valid
+    k_go[it] = key * p.ldk + pc * 8;
+    k_lo[it] = row * KROW + pc * 16;
+  }
+#pragma unroll
+  for (int it = 0; it < VPT; ++it) {
+    const int idx = tid + it * 256;
+    const int dc = idx >> 3, kp = idx & 7;
+    v_key[it] = idx < vpieces ? kp * 8 : (1 << 30);
+    v_go[it] = dc * p.Tk + kp * 8;
+    v_lo[it] = dc * VROW + kp * 16;
+  }
+  uint4 kreg[KPT], vreg[VPT];
+  auto load_tile = [&](int kt) {
+    const int left = p.Tk - kt * 64;   // keys left from the start of this tile
+    const __half* kb = kbase + static_cast<size_t>(kt) * 64 * p.ldk;
+    const __half* vb = vbase + kt * 64;
+#pragma unroll
+    for (int it = 0; it < KPT; ++it) {
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (k_key[it] < left) v = *reinterpret_cast<const uint4*>(kb + k_go[it]);
+      kreg[it] = v;
+    }
+#pragma unroll
+    for (int it = 0; it < VPT; ++it) {
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (v_key[it] < left) v = *reinterpret_cast<const uint4*>(vb + v_go[it]);
+      vreg[it] = v;
+    }
+  };
+  auto store_tile = [&](int buf) {
+#pragma unroll
+    for (int it = 0; it < KPT; ++it)
+      if (k_key[it] < 64) *reinterpret_cast<uint4*>(sK + buf * KBUF + k_lo[it]) = kreg[it];
+#pragma unroll
+    for (int it = 0; it < VPT; ++it)
+      if (v_key[it] < 64) *reinterpret_cast<uint4*>(sV + buf * VBUF + v_lo[it]) = vreg[it];
+  };
+
+  float m_run = -INFINITY, l_run = 0.0f;
+  v16f o[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[t][r] = 0.0f;
+  const float c2 = p.scale * 1.44269504088896340736f;   // exp(x*scale) = exp2(x*c2)
+
+  // one 64-key tile: scores, online softmax, O += P V.  MASK (compile time) = the ragged last tile.
+  auto tile = [&](int kt, int buf, auto mask_tag) {
+    constexpr bool MASK = decltype(mask_tag)::value;
+    const unsigned char* bK = sK + buf * KBUF;
+    const unsigned char* bV = sV + buf * VBUF;
+    // ---- S^T = K Q^T for the two 32-key sub-tiles
+    v16f s[2];
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[sub][r] = 0.0f;
+#pragma unroll
+      for (int ks = 0; ks < NKS; ++ks) {
+        const v8h a = *reinterpret_cast<const v8h*>(bK + (sub * 32 + j) * KROW + (ks * 16 + hh * 8) * 2);
+        s[sub] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, qf[ks], s[sub], 0, 0, 0);
+      }
+    }
+    // register r of sub-tile sub holds key kt*64 + sub*32 + 16*(r>>3) + 8*hh + (r&7)
+    if constexpr (MASK) {
+#pragma unroll
+      for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = kt * 64 + sub * 32 + 16 * (r >> 3) + 8 * hh + (r & 7);
+          if (key >= p.Tk) s[sub][r] = -INFINITY;
+        }
+    }
+    // ---- online softmax over this lane's 32 keys (+ partner lane^32)
+    float mx = s[0][0];
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[sub][r]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx);
+    const float mc = m_new * c2;
+    float rs = 0.0f;
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        s[sub][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[sub][r], c2, -mc));
+        rs += s[sub][r];
+      }
+    rs += __shfl_xor(rs, 32, 64);
+    if (__builtin_amdgcn_ballot_w64(m_new > m_run) != 0) {   // some query's running max moved: rescale
+      const float alpha = __builtin_amdgcn_exp2f(m_run * c2 - mc);
+      l_run *= alpha;
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[t][r] *= alpha;
+      m_run = m_new;
+    }
+    l_run += rs;
+    // ---- O^T += V^T P^T : 4 MFMA k-steps of 16 keys
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      v8h bp;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) bp[e] = static_cast<_Float16>(s[u >> 1][8 * (u & 1) + e]);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const v8h a = *reinterpret_cast<const v8h*>(bV + (t * 32 + j) * VROW + (16 * u + 8 * hh) * 2);
+        o[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bp, o[t], 0, 0, 0);
+      }
+    }
+  };
+
+  const int ntiles = (p.Tk + 63) / 64;
+  const int nfull = p.Tk / 64;       // tiles without a ragged tail
+  load_tile(0);
+  __syncthreads();   // zero fill done
+  store_tile(0);
+  __syncthreads();
+  for (int kt = 0; kt < nfull; ++kt) {
+    if (kt + 1 < ntiles) load_tile(kt + 1);
+    tile(kt, kt & 1, std::false_type{});
+    if (kt + 1 < ntiles) store_tile((kt & 1) ^ 1);
+    __syncthreads();
+  }
+  if (nfull < ntiles) tile(nfull, nfull & 1, std::true_type{});
+
+  // ---- normalise and store: lane (query j, half hh) owns dcols t*32 + (r&3) + 8*(r>>2) + 4*hh
+  const int qg = q0 + wid * 32 + j;
+  if (qg >= p.Tq) return;
+  const float inv = 1.0f / l_run;
+  const bool quant = p.yq != nullptr;
+  float2 qp = make_float2(1.0f, 0.0f);
+  if (quant) qp = load_qparam(p.aq);
+  const size_t tok = static_cast<size_t>(b) * p.Tq + qg;
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int dc = t * 32 + 8 * g + 4 * hh;
+      if (dc >= d) continue;
+      float4 v = make_float4(o[t][4 * g] * inv, o[t][4 * g + 1] * inv, o[t][4 * g + 2] * inv, o[t][4 * g + 3] * inv);
+      if (p.out) *reinterpret_cast<float4*>(p.out + tok * p.ldo + hd * d + dc) = v;
+      if (quant) {
+        char4 c;
+        c.x = static_cast<signed char>(static_cast<int>(quant_index_f(v.x, qp.x, qp.y, 255.0f)) - 128);
+        c.y = static_cast<signed char>(static_cast<int>(quant_index_f(v.y, qp.x, qp.y, 255.0f)) - 128);
+        c.z = static_cast<signed char>(static_cast<int>(quant_index_f(v.z, qp.x, qp.y, 255.0f)) - 128);
+        c.w = static_cast<signed char>(static_cast<int>(quant_index_f(v.w, qp.x, qp.y, 255.0f)) - 128);
+        *reinterpret_cast<char4*>(p.yq + tok * (static_cast<size_t>(p.heads) * d) + hd * d + dc) = c;
+      }
+    }
+  }
+}
+
+template <int NKS, int NT>
+static int launch_attn_h(tfmq_handle h, const AttnHP& p, void* stream) {
+  constexpr int DPAD = NT * 32;
+  constexpr size_t smem = 2 * (64 * (DPAD * 2 + 16) + static_cast<size_t>(DPAD) * (64 * 2 + 16));
+  static bool configured = false;
+  if (!configured) {
+    TFMQ_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_attention_h<NKS, NT>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(smem)));
+    configured = true;
+  }
+  dim3 grid((p.Tq + 127) / 128, p.B * p.heads);
+  hipLaunchKernelGGL((k_attention_h<NKS, NT>), grid, dim3(256), smem, as_stream(stream), p);
+  TFMQ_LAUNCH_CHECK(h);
+  return TFMQ_OK;
+}
+
+extern "C" int tfmq_attention_f16(tfmq_handle h, const uint16_t* q, const uint16_t* k, const uint16_t* vt, int ldq, int ldk,
+                                  float* out, int ldo, int8_t* yq, tfmq_qsel aq, int B, int heads, int Tq, int Tk, int d,
+                                  float scale, void* stream) {
+  TFMQ_CHECK_ARG(h, h && q && k && vt && (out || yq), "attention_f16: null pointer");
+  TFMQ_CHECK_ARG(h, B > 0 && heads > 0 && Tq > 0 && Tk > 0 && d > 0, "attention_f16: bad shape");
+  TFMQ_CHECK_ARG(h, d % 8 == 0 && ldq % 8 == 0 && ldk % 8 == 0 && Tk % 8 == 0 && (!out || ldo % 4 == 0),
+                 "attention_f16: head dim, leading dims and Tk must be multiples of 8");
+  TFMQ_CHECK_ARG(h, !yq || aq.qtable, "attention_f16: quantised output needs a qparam");
+  TFMQ_CHECK_ARG(h, static_cast<long>(B) * heads < 65536, "attention_f16: B*heads must be < 65536");
+  AttnHP p{reinterpret_cast<const __half*>(q), reinterpret_cast<const __half*>(k), reinterpret_cast<const __half*>(vt),
+           ldq, ldk, out, ldo, yq, aq, B, heads, Tq, Tk, d, scale};
+  if (d <= 32) return launch_attn_h<2, 1>(h, p, stream);
+  if (d <= 48) return launch_attn_h<3, 2>(h, p, stream);     // SD v1 at 64x64: d = 40
+  if (d <= 64) return launch_attn_h<4, 2>(h, p, stream);
+  if (d <= 80) return launch_attn_h<5, 3>(h, p, stream);     // SD v1 at 32x32
+  if (d <= 96) return launch_attn_h<6, 3>(h, p, stream);
+  if (d <= 128) return launch_attn_h<8, 4>(h, p, stream);
+  if (d <= 160) return launch_attn_h<10, 5>(h, p, stream);   // SD v1 at 16x16 / 8x8
+  if (h) h->err = "attention_f16: head dim > 160 not supported (use tfmq_attention)";
+  return TFMQ_ERR_UNSUPPORTED;
+}

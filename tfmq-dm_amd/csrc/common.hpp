@@ -87,6 +87,24 @@ __device__ __forceinline__ float wave_reduce_max(float v) {
 
 __device__ __forceinline__ float silu_f(float x) { return x * (1.0f / (1.0f + expf(-x))); }
 
+// erf to |error| <= 1.5e-7 absolute (Abramowitz & Stegun 7.1.26) plus a few fp32 roundings: 5 fma, one v_rcp, one
+// v_exp.  The library erff (two divergent branches, ~140 issued instructions per call) made the GEGLU arithmetic --
+// 84 M evaluations for one SD feed-forward -- cost more than the GEMM that feeds it.  GEGLU's product
+// a * 0.5 g (1 + erf(g/sqrt 2)) is reproduced to ~1e-7 of its range: far below one 8-bit activation bin.
+__device__ __forceinline__ float erf_fast_f(float x) {
+  const float ax = fabsf(x);
+  const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(0.3275911f, ax, 1.0f));
+  float pl = __builtin_fmaf(1.061405429f, t, -1.453152027f);
+  pl = __builtin_fmaf(pl, t, 1.421413741f);
+  pl = __builtin_fmaf(pl, t, -0.284496736f);
+  pl = __builtin_fmaf(pl, t, 0.254829592f);
+  pl *= t;
+  const float e = __builtin_amdgcn_exp2f(-1.44269504088896340736f * ax * ax);
+  return copysignf(__builtin_fmaf(-pl, e, 1.0f), x);
+}
+// gelu(g) = 0.5 g (1 + erf(g / sqrt 2))   (F.gelu default, "none" approximation)
+__device__ __forceinline__ float gelu_f(float g) { return 0.5f * g * (1.0f + erf_fast_f(g * 0.70710678118654752440f)); }
+
 static inline int ceil_div(long a, long b) { return static_cast<int>((a + b - 1) / b); }
 
 // ---------------------------------------------------------------- packed int4 weight layout

@@ -23,6 +23,10 @@
 //   k_conv_igemm (f16 layers; w4a8 shapes the DMA loop does not take): register-prefetched, double-buffered.
 #include "common.hpp"
 #include <type_traits>
+#ifdef TFMQ_PHASE_TIMERS
+#include <cstdio>
+#include <cstdlib>
+#endif
 
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
@@ -40,7 +44,18 @@ struct ConvP {
   int tiles_n;
   int cout_pad;                    // w4a8: rows of the expanded weight operand (multiple of 32)
   const unsigned char* pad_table;  // 256 x 64 B, row v = byte v (tfmq_ctx::pad_table)
+#ifdef TFMQ_PHASE_TIMERS
+  unsigned long long* dbg;         // [blocks][4] shader-clock stamps: start, loop start, loop end, end
+#endif
 };
+
+// Diagnostics build (TFMQ_EXTRA_HIPCC_FLAGS=-DTFMQ_PHASE_TIMERS python tfmq-dm_amd/build.py): every w4a8 DMA launch
+// is followed by a device sync and prints the mean cycles a block spends in prologue / K loop / epilogue.
+#ifdef TFMQ_PHASE_TIMERS
+#define TFMQ_MARK(i) do { if (p.dbg && threadIdx.x == 0) p.dbg[blockIdx.x * 4 + (i)] = clock64(); } while (0)
+#else
+#define TFMQ_MARK(i) do { } while (0)
+#endif
 
 // Workgroup barrier that only waits for LDS traffic.  __syncthreads() also drains vmcnt(0), i.e. it would wait for
 // the global prefetch loads of the NEXT K-steps at every barrier.
@@ -94,6 +109,10 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, unsigned char* lds
   const bool vec_ok = ((d.Cout | d.ldy | d.y_coff) & 3) == 0 && (!d.rowadd || (d.rowadd_ld & 3) == 0);
   const int seg = d.stats ? d.stats_seg : 0;
   const int tr = tid / TPR, c4 = (tid % TPR) * 4;
+  // tiles of the transposed output region (V^T for the attention kernel) stage with an odd row pitch so the
+  // column-wise LDS reads of their store pass are (at most 2-way) conflict free
+  const bool transposed = d.out_mode == TFMQ_OUT_F16 && d.yt && n0 >= d.t_col0;
+  const int ldo = transposed ? BN + 1 : LDO;
 
   float sc_[WN_TILES], bias_[WN_TILES];
   int corr_[WN_TILES];
@@ -135,7 +154,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, unsigned char* lds
           } else {
             v = d.wscale ? sc_[j] * acc[i][j][r] + bias_[j] : acc[i][j][r] + bias_[j];
           }
-          ldsO[(row - pass * PR) * LDO + col] = v;
+          ldsO[(row - pass * PR) * ldo + col] = v;
         }
       }
     }
@@ -154,10 +173,10 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, unsigned char* lds
           const float4 a = *reinterpret_cast<const float4*>(ldsO + prow * LDO + g4);
           const float4 g = *reinterpret_cast<const float4*>(ldsO + prow * LDO + 64 + g4);
           float4 y;
-          y.x = a.x * (0.5f * g.x * (1.0f + erff(g.x * 0.70710678118654752440f)));
-          y.y = a.y * (0.5f * g.y * (1.0f + erff(g.y * 0.70710678118654752440f)));
-          y.z = a.z * (0.5f * g.z * (1.0f + erff(g.z * 0.70710678118654752440f)));
-          y.w = a.w * (0.5f * g.w * (1.0f + erff(g.w * 0.70710678118654752440f)));
+          y.x = a.x * gelu_f(g.x);
+          y.y = a.y * gelu_f(g.y);
+          y.z = a.z * gelu_f(g.z);
+          y.w = a.w * gelu_f(g.w);
           char4 q;
           q.x = static_cast<signed char>(static_cast<int>(quant_index_f(y.x, oqp.x, oqp.y, 255.0f)) - 128);
           q.y = static_cast<signed char>(static_cast<int>(quant_index_f(y.y, oqp.x, oqp.y, 255.0f)) - 128);
@@ -167,6 +186,27 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, unsigned char* lds
         }
         continue;
       }
+    }
+    if (transposed) {
+      // yt[b][n - t_col0][t]: a thread takes 4 consecutive pixels of one channel -> one 8-byte store; the PR/4
+      // threads of a channel write PR*2 contiguous bytes
+      constexpr int TPC = PR / 4, CPI = 256 / TPC;
+      const int cv = d.Cout - d.t_col0;
+      const int rg = tid % TPC;
+#pragma unroll
+      for (int it = 0; it < BN / CPI; ++it) {
+        const int col = it * CPI + tid / TPC;
+        const int m = m0 + pass * PR + 4 * rg, n = n0 + col;
+        if (m >= p.M || n >= d.Cout) continue;
+        const float* src = ldsO + (4 * rg) * ldo + col;
+        const __half2 lo = __floats2half2_rn(src[0], src[ldo]), hi = __floats2half2_rn(src[2 * ldo], src[3 * ldo]);
+        uint2 u;
+        u.x = *reinterpret_cast<const unsigned*>(&lo);
+        u.y = *reinterpret_cast<const unsigned*>(&hi);
+        const int b = m / hw, t = m - b * hw;
+        *reinterpret_cast<uint2*>(reinterpret_cast<__half*>(d.yt) + (static_cast<size_t>(b) * cv + (n - d.t_col0)) * hw + t) = u;
+      }
+      continue;
     }
     if (d.out_mode == TFMQ_OUT_F16) {
       __half* yh = reinterpret_cast<__half*>(d.y);
@@ -292,6 +332,7 @@ __global__ __launch_bounds__(256, 3) void k_conv_dma(ConvP p) {
   static_assert(WAVES_M * WAVES_N == 4, "4 waves");
   __shared__ __attribute__((aligned(1024))) unsigned char lds[LDS_BODY + MAXT * BM * 4];
   int* tab = reinterpret_cast<int*>(lds + LDS_BODY);  // [tap][row] byte offset of the input pixel, -1 = padding
+  TFMQ_MARK(0);
 
   const tfmq_conv_desc& d = p.d;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -408,6 +449,7 @@ __global__ __launch_bounds__(256, 3) void k_conv_dma(ConvP p) {
     }
   };
 
+  TFMQ_MARK(1);
   issue(0, 0);
   if (p.nsteps > 1) issue(1, 1);
   int st_c = 0, st_i = 2;
@@ -425,7 +467,9 @@ __global__ __launch_bounds__(256, 3) void k_conv_dma(ConvP p) {
     st_i = st_i == NST - 1 ? 0 : st_i + 1;
   }
 
+  TFMQ_MARK(2);
   conv_epilogue<true, WAVES_M, WAVES_N, WM_TILES, WN_TILES>(p, lds, acc, m0, n0, aqp, za);
+  TFMQ_MARK(3);
 }
 
 // ================================================================================================
@@ -701,6 +745,9 @@ static int launch_conv(tfmq_handle h, const tfmq_conv_desc* dd, void* stream) {
                         (INT8 && d.yq && d.oq.qtable && d.KH == 1 && d.KW == 1 && d.Cout % 128 == 0 && d.Cout / 2 % 4 == 0),
                  "conv: GEGLU epilogue needs a w4a8 Linear with Cout % 128 == 0, yq and oq");
   TFMQ_CHECK_ARG(h, d.out_mode >= 0 && d.out_mode <= 2, "conv: bad out_mode");
+  TFMQ_CHECK_ARG(h, !d.yt || (d.out_mode == TFMQ_OUT_F16 && d.t_col0 >= 0 && d.t_col0 % 128 == 0 && d.t_col0 < d.Cout &&
+                              (d.Ho * d.Wo) % 4 == 0),
+                 "conv: transposed region needs out_mode F16, t_col0 % 128 == 0 and Ho*Wo % 4 == 0");
   TFMQ_CHECK_ARG(h, !d.stats || ((d.stats_seg == 16 || d.stats_seg == 32 || d.stats_seg == 64 || d.stats_seg == 128) &&
                                  (d.Ho * d.Wo) % d.stats_seg == 0),
                  "conv: stats_seg must be 16/32/64/128 and divide Ho*Wo");
@@ -737,9 +784,33 @@ static int launch_conv(tfmq_handle h, const tfmq_conv_desc* dd, void* stream) {
     const bool dma = d.Cin % 64 == 0 && d.KH * d.KW <= 9 &&
                      static_cast<size_t>(d.B) * d.H * d.W * d.Cin < (static_cast<size_t>(1) << 31);
     if (dma) {
+#ifdef TFMQ_PHASE_TIMERS
+      static unsigned long long* dbuf = nullptr;
+      const size_t dwords = static_cast<size_t>(grid.x) * 4;
+      if (!dbuf) (void)hipMalloc(reinterpret_cast<void**>(&dbuf), sizeof(unsigned long long) * 4 * (1u << 20));
+      p.dbg = grid.x <= (1u << 20) ? dbuf : nullptr;
+#endif
       if (narrow) hipLaunchKernelGGL((k_conv_dma<4, 1, 1, 1>), grid, dim3(256), 0, st, p);
       else if (small) hipLaunchKernelGGL((k_conv_dma<2, 2, 1, 1>), grid, dim3(256), 0, st, p);
       else hipLaunchKernelGGL((k_conv_dma<2, 2, 2, 2>), grid, dim3(256), 0, st, p);
+#ifdef TFMQ_PHASE_TIMERS
+      if (p.dbg && getenv("TFMQ_PHASE_PRINT")) {
+        (void)hipStreamSynchronize(st);
+        std::vector<unsigned long long> hbuf(dwords);
+        (void)hipMemcpy(hbuf.data(), dbuf, dwords * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+        double a = 0, b = 0, c = 0;
+        unsigned long long lo = ~0ull, hi = 0;
+        for (unsigned i = 0; i < grid.x; ++i) {
+          a += double(hbuf[i * 4 + 1] - hbuf[i * 4]);
+          b += double(hbuf[i * 4 + 2] - hbuf[i * 4 + 1]);
+          c += double(hbuf[i * 4 + 3] - hbuf[i * 4 + 2]);
+          lo = hbuf[i * 4] < lo ? hbuf[i * 4] : lo;
+          hi = hbuf[i * 4 + 3] > hi ? hbuf[i * 4 + 3] : hi;
+        }
+        fprintf(stderr, "[conv_dma %dx%dx%d Cin%d Cout%d k%d mode%d] blocks %u nsteps %d: prologue %.0f  loop %.0f  epilogue %.0f  ticks/block; span %llu ticks\n",
+                d.B, d.H, d.W, d.Cin, d.Cout, d.KH, d.out_mode, grid.x, p.nsteps, a / grid.x, b / grid.x, c / grid.x, hi - lo);
+      }
+#endif
     } else {
 #define TFMQ_LAUNCH(CK, A, B_, C_, D_) hipLaunchKernelGGL((k_conv_igemm<true, false, CK, A, B_, C_, D_>), grid, dim3(256), 0, st, p)
       const bool k32 = d.Cin % 64 != 0;

@@ -88,10 +88,10 @@ __global__ __launch_bounds__(256) void k_geglu(const float* __restrict__ hin, lo
     const float4 a = *reinterpret_cast<const float4*>(hin + m * 2 * I + c);
     const float4 g = *reinterpret_cast<const float4*>(hin + m * 2 * I + I + c);
     float4 y;
-    y.x = a.x * (0.5f * g.x * (1.0f + erff(g.x * 0.70710678118654752440f)));
-    y.y = a.y * (0.5f * g.y * (1.0f + erff(g.y * 0.70710678118654752440f)));
-    y.z = a.z * (0.5f * g.z * (1.0f + erff(g.z * 0.70710678118654752440f)));
-    y.w = a.w * (0.5f * g.w * (1.0f + erff(g.w * 0.70710678118654752440f)));
+    y.x = a.x * gelu_f(g.x);
+    y.y = a.y * gelu_f(g.y);
+    y.z = a.z * gelu_f(g.z);
+    y.w = a.w * gelu_f(g.w);
     if (yf) *reinterpret_cast<float4*>(yf + m * I + c) = y;
     if (quant) {
       char4 q;

@@ -162,6 +162,23 @@ class LdmUNetEngine(DdimUNetEngine):
         L = self.layers
         heads = self.cfg["num_heads"]
         to_out = L[p + ".to_out.0"]
+        f = self.fused_qkv.get(p) if self_attn else None
+        if f is not None and f.kind == "w4a8":
+            # main path: the projection GEMM writes q | k as fp16 rows and v as fp16 V^T, the attention kernel
+            # copies them tile by tile (no fp32 round trip, no conversion, no transposition)
+            B, T, Cin = xq_src.shape
+            Cc = f.p.cout // 3
+            d = Cc // heads
+            if ops.attention_f16_ok(d, T) and (2 * Cc) % 128 == 0 and T % 4 == 0:
+                y16, vt = ops.conv2d_w4a8(xq_src.reshape(B, T, 1, Cin), f.p, f.aq, out_f16=True, t_col0=2 * Cc)
+                y16 = y16.reshape(B, T, 3 * Cc)
+                aq = to_out.aq if to_out.kind == "w4a8" else None
+                if aq is not None and self.calib is None:
+                    _, o = ops.attention_f16(y16[..., :Cc], y16[..., Cc:2 * Cc], vt, heads, float(d ** -0.5), aq, want_f32=False)
+                else:
+                    o, _ = ops.attention_f16(y16[..., :Cc], y16[..., Cc:2 * Cc], vt, heads, float(d ** -0.5))
+                    o = self._quant_in(to_out, o)
+                return self._tok(to_out, o, residual=x_res)
         if self_attn and p in self.fused_qkv:
             qkv = self._tok(self.fused_qkv[p], xq_src)
             Cc = qkv.shape[-1] // 3

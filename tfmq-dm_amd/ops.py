@@ -334,10 +334,12 @@ def conv2d_w4a8(xq: torch.Tensor, pw: PackedW4, aq: QSel, stride: int = 1, pad: 
                 up2x: bool = False, rowadd: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
                 out: Optional[torch.Tensor] = None, y_coff: int = 0, rowadd_ld=None, rowadd_step=None,
                 rowadd_step_stride: int = 0, want_stats: bool = False, out_f16: bool = False,
-                geglu_oq: Optional[QSel] = None) -> torch.Tensor:
+                geglu_oq: Optional[QSel] = None, t_col0: Optional[int] = None):
     """xq: int8 NHWC [B,H,W,Cin] (bin-128).  pad = (top, left, bottom, right).  -> fp32 NHWC.
     out_f16: fp16 output (operands of the attention kernel).  geglu_oq: `pw` is a geglu_perm-ordered GEGLU projection;
-    returns int8 [B,Ho,Wo,Cout/2] = quant_geglu_oq(value * gelu(gate)) - 128."""
+    returns int8 [B,Ho,Wo,Cout/2] = quant_geglu_oq(value * gelu(gate)) - 128.
+    t_col0 (with out_f16): channels >= t_col0 go TRANSPOSED into a second fp16 tensor [B, Cout - t_col0, Ho*Wo]
+    (the V^T operand of attention_f16); returns (y, yt), y's channels >= t_col0 are left unwritten."""
     d = _dev(xq)
     _chk(xq, torch.int8, "xq")
     B, H, W, cin = xq.shape
@@ -368,11 +370,17 @@ def conv2d_w4a8(xq: torch.Tensor, pw: PackedW4, aq: QSel, stride: int = 1, pad: 
     elif out_f16:
         dsc.out_mode = 1
         osz = 2.0
+    yt = None
+    if t_col0 is not None:
+        if not out_f16 or t_col0 % 128 or not 0 <= t_col0 < pw.cout or (Ho * Wo) % 4:
+            raise TfmqError("conv2d_w4a8: t_col0 needs out_f16, t_col0 % 128 == 0 and Ho*Wo % 4 == 0")
+        yt = _alloc(B, pw.cout - t_col0, Ho * Wo, dtype=torch.float16, device=xq.device)
+        dsc.yt, dsc.t_col0 = yt.data_ptr(), int(t_col0)
     _attach_stats(dsc, y, B, Ho * Wo, pw.cout, want_stats and y_coff == 0 and dsc.out_mode == 0)
     # algorithmic HBM bytes: int8 input once + int8 weight operand + output (+ fp32 residual)
     nbytes = B * H * W * cin + pw.cout * pw.kh * pw.kw * cin + B * Ho * Wo * pw.cout * (osz + (4.0 if residual is not None else 0.0))
     _profiled_conv("conv2d_w4a8", "w4a8", d, dsc, 2.0 * B * Ho * Wo * pw.cout * pw.kh * pw.kw * cin, nbytes)
-    return y
+    return y if yt is None else (y, yt)
 
 
 def conv2d_f16(x: torch.Tensor, pf: PackedF16, stride: int = 1, pad: Tuple[int, int, int, int] = (0, 0, 0, 0),
@@ -514,6 +522,34 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int, sca
         yq = _alloc(B, Tq, Cq, dtype=torch.int8, device=q.device)
         sel = aq
     handle(d_).call("attention", _p(q), _p(k), _p(v), q.stride(1), k.stride(1), v.stride(1), _p(out), Cq, _p(yq), sel, B,
+                    heads, Tq, Tk, dh, float(scale), _stream(d_))
+    return out, yq
+
+
+def attention_f16_ok(d: int, Tk: int) -> bool:
+    return d % 8 == 0 and d <= 160 and Tk % 8 == 0
+
+
+def attention_f16(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, heads: int, scale: float,
+                  aq: Optional[QSel] = None, want_f32: bool = True):
+    """q, k: fp16 [B,T,*] views with unit channel stride (column slices of the fused projection's fp16 output);
+    vt: fp16 [B, heads*d, Tk] (conv2d_w4a8(..., out_f16=True, t_col0=...)).  Returns (out fp32 | None, yq int8 | None)."""
+    d_ = _dev(q)
+    B, Tq, Cq = q.shape
+    Tk = k.shape[1]
+    dh = Cq // heads
+    for t in (q, k):
+        if t.dtype != torch.float16 or t.stride(-1) != 1 or t.stride(0) != t.shape[1] * t.stride(1):
+            raise TfmqError("attention_f16: q/k must be fp16 [B,T,C] with unit channel stride and dense batch/token strides")
+    if vt.dtype != torch.float16 or not vt.is_contiguous() or tuple(vt.shape) != (B, Cq, Tk):
+        raise TfmqError("attention_f16: vt must be contiguous fp16 [B, heads*d, Tk]")
+    out = _alloc(B, Tq, Cq, dtype=torch.float32, device=q.device) if want_f32 else None
+    yq = None
+    sel = QSel(None, None, 0, 0)
+    if aq is not None and aq.qtable:
+        yq = _alloc(B, Tq, Cq, dtype=torch.int8, device=q.device)
+        sel = aq
+    handle(d_).call("attention_f16", _p(q), _p(k), _p(vt), q.stride(1), k.stride(1), _p(out), Cq, _p(yq), sel, B,
                     heads, Tq, Tk, dh, float(scale), _stream(d_))
     return out, yq
 
