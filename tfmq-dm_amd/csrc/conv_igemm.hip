@@ -137,27 +137,33 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, unsigned char* lds
     if (seg && pass == 0) {
       for (int o = tid; o < BN; o += 256) ldsG[o] = make_float2(0.0f, 0.0f);
     }
-    // phase 1: registers -> LDS
+    // phase 1: registers -> LDS (row pitch a compile-time constant on either path: the 64 store offsets fold
+    // into ds_write immediates)
+    auto phase1 = [&](auto pitch_tag) {
+      constexpr int PITCH = decltype(pitch_tag)::value;
 #pragma unroll
-    for (int i = 0; i < WM_TILES; ++i) {
-      const int tile_row0 = (wm * WM_TILES + i) * 32;
-      if (tile_row0 / PR != pass) continue;
+      for (int i = 0; i < WM_TILES; ++i) {
+        const int tile_row0 = (wm * WM_TILES + i) * 32;
+        if (tile_row0 / PR != pass) continue;
 #pragma unroll
-      for (int j = 0; j < WN_TILES; ++j) {
-        const int col = (wn * WN_TILES + j) * 32 + (lane & 31);
+        for (int j = 0; j < WN_TILES; ++j) {
+          const int col = (wn * WN_TILES + j) * 32 + (lane & 31);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = tile_row0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-          float v;
-          if constexpr (INT8) {
-            v = sc_[j] * static_cast<float>(acc[i][j][r] + corr_[j]) + bias_[j];
-          } else {
-            v = d.wscale ? sc_[j] * acc[i][j][r] + bias_[j] : acc[i][j][r] + bias_[j];
+          for (int r = 0; r < 16; ++r) {
+            const int row = tile_row0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            float v;
+            if constexpr (INT8) {
+              v = sc_[j] * static_cast<float>(acc[i][j][r] + corr_[j]) + bias_[j];
+            } else {
+              v = d.wscale ? sc_[j] * acc[i][j][r] + bias_[j] : acc[i][j][r] + bias_[j];
+            }
+            ldsO[(row - pass * PR) * PITCH + col] = v;
           }
-          ldsO[(row - pass * PR) * ldo + col] = v;
         }
       }
-    }
+    };
+    if (transposed) phase1(std::integral_constant<int, BN + 1>{});
+    else phase1(std::integral_constant<int, LDO>{});
     __syncthreads();
     if constexpr (INT8 && BN == 128) {
       if (d.out_mode == TFMQ_OUT_GEGLU_Q8) {

@@ -208,32 +208,35 @@ __global__ __launch_bounds__(256) void k_gn_finalize(const float2* __restrict__ 
                                                      int C2, int HW, int seg, int groups, float eps,
                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
                                                      float* __restrict__ A, float* __restrict__ Bb) {
-  __shared__ float s_mean[64], s_rstd[64];
+  // block = (image, 8 groups); 32 lanes per group stride over its nseg x cpg partial sums, double accumulation,
+  // fixed-order butterfly -> deterministic
   const int b = blockIdx.x, Cc = C1 + C2, cpg = Cc / groups, nseg = HW / seg;
-  if (threadIdx.x < groups) {
-    const int g = threadIdx.x;
-    double s = 0.0, ss = 0.0;
-    for (int sgi = 0; sgi < nseg; ++sgi) {
-      const size_t row = static_cast<size_t>(b) * nseg + sgi;
-      for (int c = g * cpg; c < (g + 1) * cpg; ++c) {
-        const float2 v = c < C1 ? st1[row * C1 + c] : st2[row * C2 + (c - C1)];
-        s += v.x;
-        ss += v.y;
-      }
-    }
-    const double n = static_cast<double>(HW) * cpg;
-    const double mean = s / n;
-    double var = ss / n - mean * mean;
-    if (var < 0.0) var = 0.0;
-    s_mean[g] = static_cast<float>(mean);
-    s_rstd[g] = static_cast<float>(1.0 / sqrt(var + static_cast<double>(eps)));
+  const int g = blockIdx.y * 8 + (threadIdx.x >> 5), l = threadIdx.x & 31;
+  if (g >= groups) return;
+  double s = 0.0, ss = 0.0;
+  const int items = nseg * cpg;
+  for (int i = l; i < items; i += 32) {
+    const int sgi = i / cpg, c = g * cpg + (i - sgi * cpg);
+    const size_t row = static_cast<size_t>(b) * nseg + sgi;
+    const float2 v = c < C1 ? st1[row * C1 + c] : st2[row * C2 + (c - C1)];
+    s += v.x;
+    ss += v.y;
   }
-  __syncthreads();
-  for (int c = threadIdx.x; c < Cc; c += 256) {
-    const int g = c / cpg;
-    const float a = s_rstd[g] * gamma[c];
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) {
+    s += __shfl_xor(s, o, 64);
+    ss += __shfl_xor(ss, o, 64);
+  }
+  const double n = static_cast<double>(HW) * cpg;
+  const double mean = s / n;
+  double var = ss / n - mean * mean;
+  if (var < 0.0) var = 0.0;
+  const float meanf = static_cast<float>(mean);
+  const float rstd = static_cast<float>(1.0 / sqrt(var + static_cast<double>(eps)));
+  for (int c = g * cpg + l; c < (g + 1) * cpg; c += 32) {
+    const float a = rstd * gamma[c];
     A[static_cast<size_t>(b) * Cc + c] = a;
-    Bb[static_cast<size_t>(b) * Cc + c] = beta[c] - a * s_mean[g];
+    Bb[static_cast<size_t>(b) * Cc + c] = beta[c] - a * meanf;
   }
 }
 
@@ -310,7 +313,7 @@ extern "C" int tfmq_groupnorm_from_stats(tfmq_handle h, const tfmq_gn_desc* dd, 
   const int Cc = d.C1 + d.C2;
   float* A = ws;
   float* Bb = ws + static_cast<size_t>(d.B) * Cc;
-  hipLaunchKernelGGL(k_gn_finalize, dim3(d.B), dim3(256), 0, as_stream(stream), reinterpret_cast<const float2*>(stats1), d.C1,
+  hipLaunchKernelGGL(k_gn_finalize, dim3(d.B, (d.groups + 7) / 8), dim3(256), 0, as_stream(stream), reinterpret_cast<const float2*>(stats1), d.C1,
                      reinterpret_cast<const float2*>(stats2), d.C2, d.HW, seg, d.groups, d.eps, d.gamma, d.beta, A, Bb);
   TFMQ_LAUNCH_CHECK(h);
   const bool v4 = (d.C1 % 4 == 0) && (d.C2 % 4 == 0);
