@@ -272,6 +272,11 @@ int tfmq_gemm_f32(tfmq_handle h, const float* A, const float* B, float* C, int M
                   long sbk, long sbn, long scm, int batch, long bsa, long bsb, long bsc, float alpha, const float* bias,
                   const float* rowadd, int rows_per_img, int rowadd_ld, const float* residual, int accumulate,
                   void* stream);
+/* LayerNorm / GEGLU backward w.r.t. their inputs (BasicTransformerBlock units, ldm/modules/attention.py:196-215):
+ * gx = d LN(x; gamma)/dx applied to gy, rows tokens of C channels;  dh = d(h[:, :I] * gelu(h[:, I:]))/dh applied to dy */
+int tfmq_layernorm_bwd(tfmq_handle h, const float* x, const float* gy, const float* gamma, float eps, long rows, int C,
+                       float* gx, void* stream);
+int tfmq_geglu_bwd(tfmq_handle h, const float* hin, const float* dy, long rows, int inner, float* dh, void* stream);
 /* col[(b,ho,wo)][(kh,kw,c)] <- x NHWC (zero padded); col2im is its adjoint (gather form, deterministic) */
 int tfmq_im2col(tfmq_handle h, const float* x, float* col, int B, int H, int W, int C, int KH, int KW, int stride,
                 int pad_t, int pad_l, int Ho, int Wo, void* stream);

@@ -108,5 +108,67 @@ def main():
     save("f11_ldm_tiny", **out)
 
 
+def f12():
+    """Tiny end-to-end LDM calibration by the reference's own cali_model (weight init -> TIAR on the LDM TIB ->
+    layer / ResBlock / BasicTransformerBlock reconstruction -> Finite-Set activation calibration), plus the
+    load_cali_model round trip.  SD-style UNet as above."""
+    import tempfile
+    import quant.reconstruction as _rec
+    from quant.calibration import cali_model, load_cali_model
+    from quant.reconstruction_util import RLOSS
+    # torch 2.10 CPU segfaults in the backward of a block whose cached input is channels-last-strided (the output of
+    # the stride-2 `op` conv).  Same values, contiguous memory: harness-side workaround, the reference is untouched.
+    _orig_save_inout = _rec.save_inout
+
+    def _contig_save_inout(*a, **k):
+        ci, co = _orig_save_inout(*a, **k)
+        return tuple(c.contiguous() for c in ci), (co.contiguous() if torch.is_tensor(co) else co)
+    _rec.save_inout = _contig_save_inout
+    m = build()
+    out = sd_arrays(m)
+    g = torch.Generator().manual_seed(1212)
+    G, I = 3, 16
+    xs = torch.randn(G * I, 4, 8, 8, generator=g)
+    ts = torch.cat([torch.full((I,), float(t)) for t in (901, 501, 101)])
+    cs = torch.randn(G * I, 5, 64, generator=g)
+    out["cali_x"], out["cali_t"], out["cali_c"] = xs, ts, cs
+    wq = {"bits": 4, "channel_wise": True, "scaler": Scaler.MSE}
+    aq = {"bits": 8, "channel_wise": False, "scaler": Scaler.MSE, "leaf_param": True}
+    qnn = QuantModel(m, wq, aq, aq_mode=[QMODE.NORMAL.value, QMODE.QDIFF.value]).eval()
+    qnn.set_grad_ckpt(False)
+    torch.manual_seed(5)
+    np.random.seed(5)
+    path = os.path.join(tempfile.mkdtemp(), "c.pth")
+    cali_model(qnn, (xs, ts, cs), (xs, ts, cs), use_aq=True, path=path, running_stat=True, interval=I,
+               iters=10, batch_size=8, w=0.01, asym=True, warmup=0.2, opt_mode=RLOSS.MSE, multi_gpu=False)
+    ck = torch.load(path, map_location="cpu")
+    keys = sorted(ck["weight"].keys())
+    out["weight_keys"] = np.array(keys)
+    for k in keys:
+        out["ck/weight/" + k] = ck["weight"][k]
+    for gi in range(G):
+        ak = sorted(ck[f"act_{gi}"].keys())
+        if gi == 0:
+            out["act_keys"] = np.array(ak)
+        out[f"ck/act_{gi}/delta"] = torch.stack([ck[f"act_{gi}"][k].reshape(()) for k in ak if k.endswith("delta")])
+        out[f"ck/act_{gi}/zp"] = torch.stack([ck[f"act_{gi}"][k].reshape(()) for k in ak if k.endswith("zero_point")])
+    m2 = build()
+    qnn2 = QuantModel(m2, wq, aq, cali=False, aq_mode=[QMODE.NORMAL.value, QMODE.QDIFF.value]).eval()
+    init = (torch.randn(1, 4, 8, 8, generator=g), torch.randint(0, 1000, (1,), generator=g), torch.randn(1, 5, 64, generator=g))
+    load_cali_model(qnn2, init, use_aq=True, path=path)
+    qnn2.load_state_dict(ck["act_1"], strict=False)
+    xe = torch.randn(2, 4, 8, 8, generator=g)
+    te = torch.tensor([501.0, 501.0])
+    ce = torch.randn(2, 5, 64, generator=g)
+    with torch.no_grad():
+        out["reload_x"], out["reload_t"], out["reload_c"] = xe, te, ce
+        out["reload_eps_act1"] = qnn2(xe, te, ce)
+    save("f12_ldm_cali_tiny", **out)
+
+
 if __name__ == "__main__":
-    main()
+    which = sys.argv[1:] or ["f11", "f12"]
+    if "f11" in which:
+        main()
+    if "f12" in which:
+        f12()

@@ -382,3 +382,85 @@ extern "C" int tfmq_axpy(tfmq_handle h, float* y, const float* x, float a, size_
   TFMQ_LAUNCH_CHECK(h);
   return TFMQ_OK;
 }
+
+// ------------------------------------------------------------------ LayerNorm backward w.r.t. the input
+// y = gamma*xhat + beta, xhat = (x-mean)*rstd over the C channels of a token.  Given gy:
+//   gxh = gy*gamma;  gx = rstd*(gxh - mean(gxh) - xhat*mean(gxh*xhat)).  One block per token, double sums.
+__global__ __launch_bounds__(256) void k_layernorm_bwd(const float* __restrict__ x, const float* __restrict__ gy,
+                                                       const float* __restrict__ gamma, float* __restrict__ gx, int Cc,
+                                                       float eps) {
+  __shared__ double red[4][2];
+  const long base = static_cast<long>(blockIdx.x) * Cc;
+  auto block_sum2 = [&](double a, double c, double& oa, double& oc) {
+    a = wave_reduce_sum_d(a);
+    c = wave_reduce_sum_d(c);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6][0] = a; red[threadIdx.x >> 6][1] = c; }
+    __syncthreads();
+    oa = red[0][0] + red[1][0] + red[2][0] + red[3][0];
+    oc = red[0][1] + red[1][1] + red[2][1] + red[3][1];
+  };
+  double s = 0.0, ss = 0.0;
+  for (int c = threadIdx.x; c < Cc; c += 256) {
+    const double v = x[base + c];
+    s += v;
+    ss += v * v;
+  }
+  double S, SS;
+  block_sum2(s, ss, S, SS);
+  const double mean = S / Cc;
+  double var = SS / Cc - mean * mean;
+  if (var < 0.0) var = 0.0;
+  const float meanf = static_cast<float>(mean), rstd = static_cast<float>(1.0 / sqrt(var + static_cast<double>(eps)));
+  double a = 0.0, b = 0.0;
+  for (int c = threadIdx.x; c < Cc; c += 256) {
+    const float xh = (x[base + c] - meanf) * rstd;
+    const float g = gy[base + c] * gamma[c];
+    a += g;
+    b += static_cast<double>(g) * xh;
+  }
+  double A, Bq;
+  block_sum2(a, b, A, Bq);
+  const float ma = static_cast<float>(A / Cc), mb = static_cast<float>(Bq / Cc);
+  for (int c = threadIdx.x; c < Cc; c += 256) {
+    const float xh = (x[base + c] - meanf) * rstd;
+    const float g = gy[base + c] * gamma[c];
+    gx[base + c] = rstd * (g - ma - xh * mb);
+  }
+}
+
+extern "C" int tfmq_layernorm_bwd(tfmq_handle h, const float* x, const float* gy, const float* gamma, float eps, long rows,
+                                  int C, float* gx, void* stream) {
+  TFMQ_CHECK_ARG(h, h && x && gy && gamma && gx && rows > 0 && C > 0, "layernorm_bwd: bad argument");
+  hipLaunchKernelGGL(k_layernorm_bwd, dim3(static_cast<unsigned>(rows)), dim3(256), 0, as_stream(stream), x, gy, gamma, gx, C, eps);
+  TFMQ_LAUNCH_CHECK(h);
+  return TFMQ_OK;
+}
+
+// ------------------------------------------------------------------ GEGLU backward
+// y[m][i] = a*gelu(g), a = h[m][i], g = h[m][I+i]:  dh[m][i] = dy*gelu(g);  dh[m][I+i] = dy*a*gelu'(g),
+// gelu'(g) = Phi(g) + g*phi(g).
+__global__ __launch_bounds__(256) void k_geglu_bwd(const float* __restrict__ hin, const float* __restrict__ dy,
+                                                   float* __restrict__ dh, long rows, int I) {
+  const long total = rows * I;
+  for (long i = static_cast<long>(blockIdx.x) * blockDim.x + threadIdx.x; i < total;
+       i += static_cast<long>(gridDim.x) * blockDim.x) {
+    const long m = i / I;
+    const int c = static_cast<int>(i - m * I);
+    const float a = hin[m * 2 * I + c], g = hin[m * 2 * I + I + c], d = dy[i];
+    const float Phi = 0.5f * (1.0f + erf_fast_f(g * 0.70710678118654752440f));
+    const float phi = 0.39894228040143267794f * expf(-0.5f * g * g);
+    dh[m * 2 * I + c] = d * (g * Phi);
+    dh[m * 2 * I + I + c] = d * a * (Phi + g * phi);
+  }
+}
+
+extern "C" int tfmq_geglu_bwd(tfmq_handle h, const float* hin, const float* dy, long rows, int inner, float* dh,
+                              void* stream) {
+  TFMQ_CHECK_ARG(h, h && hin && dy && dh && rows > 0 && inner > 0, "geglu_bwd: bad argument");
+  int blocks = ceil_div(rows * inner, 256);
+  if (blocks > h->cu_count * 8) blocks = h->cu_count * 8;
+  hipLaunchKernelGGL(k_geglu_bwd, dim3(blocks), dim3(256), 0, as_stream(stream), hin, dy, dh, rows, inner);
+  TFMQ_LAUNCH_CHECK(h);
+  return TFMQ_OK;
+}

@@ -34,7 +34,7 @@ def _collect(block: nn.Module, prefix: str = "blk"):
                 sd[full + ".weight"] = mod.original_w
                 if mod.original_b is not None:
                     sd[full + ".bias"] = mod.original_b
-        elif isinstance(mod, (nn.Conv2d, nn.Linear, nn.GroupNorm)):
+        elif isinstance(mod, (nn.Conv2d, nn.Linear, nn.GroupNorm, nn.LayerNorm)):
             for pn, p in mod.named_parameters(recurse=False):
                 sd[f"{full}.{pn}"] = p.detach()
     return sd, wq, rows
@@ -60,3 +60,26 @@ def run_attn_block(block, x: torch.Tensor) -> torch.Tensor:
     """QuantAttnBlock.forward (reference quant/quant_block.py:474-505) with un-quantised QK^T / PV."""
     eng = _engine_for(block, x.device)
     return ops.nhwc_to_nchw(eng._attnblock("blk", ops.nchw_to_nhwc(x.float().contiguous())))
+
+
+def _ldm_engine_for(block: nn.Module, device, cfg):
+    from .ldm_unet import LdmUNetEngine
+    sd, wq, rows = _collect(block)
+    eng = LdmUNetEngine(sd, cfg, device)
+    qtable = torch.tensor([rows], dtype=torch.float32, device=device) if rows else None
+    eng.prepare(wq, qtable, None)
+    return eng
+
+
+def run_res_block(block, x: torch.Tensor, emb: torch.Tensor) -> torch.Tensor:
+    """QuantResBlock.forward (reference quant/quant_block.py:153-206): x NCHW, emb [B, emb_channels]."""
+    eng = _ldm_engine_for(block, x.device, {})
+    proj = eng._linear("blk.emb_layers.1", emb.float().contiguous(), True)
+    y = eng._res("blk", ops.nchw_to_nhwc(x.float().contiguous()), None, dict(rowadd=proj))
+    return ops.nhwc_to_nchw(y)
+
+
+def run_transformer_block(block, x: torch.Tensor, context: torch.Tensor) -> torch.Tensor:
+    """QuantBasicTransformerBlock.forward (reference quant/quant_block.py:286-299): x [B,T,C] tokens, context [B,L,D]."""
+    eng = _ldm_engine_for(block, x.device, dict(num_heads=block.attn1.heads))
+    return eng._tblock("blk", x.float().contiguous(), context.float().contiguous())

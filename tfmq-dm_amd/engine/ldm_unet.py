@@ -224,16 +224,29 @@ class LdmUNetEngine(DdimUNetEngine):
             g = self._quant_in(ff2, ops.geglu(h, None)[1])
         return self._tok(ff2, g, residual=x)
 
-    def _st(self, p, x, ctx):
+    def _st(self, p, x, ctx, taps=None):
+        """taps (reconstruction data capture): every QuantLayer / QuantBasicTransformerBlock of the SpatialTransformer is a
+        reconstruction unit of its own (recon_model walks norm, proj_in, transformer_blocks, proj_out)."""
         L = self.layers
         B, H, W, Cc = x.shape
         pin, pout = L[p + ".proj_in"], L[p + ".proj_out"]
-        h, _ = self._gn(p + ".norm", x, None, False, pin, eps=1e-6)
-        h = pin.run(h, want_stats=False)
+        h_in, _ = self._gn(p + ".norm", x, None, False, pin, eps=1e-6)
+        h = pin.run(h_in, want_stats=False)
+        if taps is not None:
+            taps[p + ".proj_in"] = (h_in, h)
         tok = h.reshape(B, H * W, h.shape[-1])
         for i in range(_n_children(self.sd, p + ".transformer_blocks")):
-            tok = self._tblock(f"{p}.transformer_blocks.{i}", tok, ctx)
+            name = f"{p}.transformer_blocks.{i}"
+            tin = tok
+            tok = self._tblock(name, tok, ctx)
+            if taps is not None:
+                taps[name] = ((tin, ctx), tok)
         h = self._quant_in(pout, tok.reshape(B, H, W, -1))
+        if taps is not None:
+            o = pout.run(h, want_stats=False)            # the layer's own output, without the fused residual
+            taps[p + ".proj_out"] = (h, o.clone())
+            ops.axpy(o, x, 1.0)
+            return o
         return pout.run(h, residual=x)
 
     def _seq(self, p, h, skip, ctx, rowadd, taps):
@@ -246,14 +259,17 @@ class LdmUNetEngine(DdimUNetEngine):
                 if taps is not None:
                     taps[q] = ((hin, skip) if (j == 0 and skip is not None) else hin, h)
             elif (q + ".transformer_blocks.0.norm1.weight") in self.sd:
-                h = self._st(q, h, ctx)
+                h = self._st(q, h, ctx, taps)
                 if taps is not None:
                     taps[q] = (hin, h)
             elif (q + ".op") in L:
                 h = L[q + ".op"].run(h, stride=2, pad=(1, 1, 1, 1))
             elif (q + ".conv") in L:
                 up = L[q + ".conv"]
-                h = up.run(self._quant_in(up, h), pad=(1, 1, 1, 1), up2x=True)
+                hq = self._quant_in(up, h)
+                h = up.run(hq, pad=(1, 1, 1, 1), up2x=True)
+                if taps is not None and hq.dtype == torch.float32:
+                    taps[q + ".conv"] = (ops.upsample2x(hq), h)
             elif q in L:
                 h = L[q].run(h, pad=(1, 1, 1, 1))
             else:

@@ -140,8 +140,12 @@ class ResnetUnit(_Unit):
     """QuantResnetBlock (reference quant/quant_block.py:415-444): AdaRound on conv1, conv2; temb_proj is
     `quant_emb` (owned by the TIB unit) and nin_shortcut is FP, both constant here."""
 
-    def __init__(self, conv1: AdaLayer, conv2: AdaLayer, gn1, gn2, shortcut, x, proj, y, **kw):
+    def __init__(self, conv1: AdaLayer, conv2: AdaLayer, gn1, gn2, shortcut, x, proj, y, eps: float = 1e-6, **kw):
+        """eps: 1e-6 for the DDPM UNet's Normalize, 1e-5 for the LDM ResBlock's GroupNorm32 (QuantResBlock, reference
+        quant/quant_block.py:131-206: same dataflow with emb_layers in place of temb_proj, skip_connection in place of
+        nin_shortcut)."""
         super().__init__([conv1, conv2], **kw)
+        self.eps = eps
         self.gn1, self.gn2 = gn1, gn2      # (gamma, beta)
         self.shortcut = shortcut           # None or (w [cout, cin] fp32, bias)
         self.x, self.proj, self.y = x, proj, y
@@ -151,9 +155,9 @@ class ResnetUnit(_Unit):
         x, proj, y = self.x.index_select(0, idx), self.proj.index_select(0, idx), self.y.index_select(0, idx)
         B, H, W, cin = x.shape
         w1, w2 = c1l.soft_weight_gemm(), c2l.soft_weight_gemm()
-        _, a1, _ = ops.groupnorm(x, self.gn1[0], self.gn1[1], 1e-6, True, want_f32=True)
+        _, a1, _ = ops.groupnorm(x, self.gn1[0], self.gn1[1], self.eps, True, want_f32=True)
         c1, col1 = _conv_fwd(a1, c1l, w1, (1, 1, 1, 1), rowadd=proj)
-        _, a2, _ = ops.groupnorm(c1, self.gn2[0], self.gn2[1], 1e-6, True, want_f32=True)
+        _, a2, _ = ops.groupnorm(c1, self.gn2[0], self.gn2[1], self.eps, True, want_f32=True)
         if self.shortcut is not None:
             sc = ops.gemm(x.reshape(B * H * W, cin), self.shortcut[0], trans_b=True, bias=self.shortcut[1]).reshape(B, H, W, -1)
         else:
@@ -164,7 +168,7 @@ class ResnetUnit(_Unit):
         gw2 = ops.gemm(g2, col2, trans_a=True)
         dcol2 = ops.gemm(g2, w2)
         g_a2 = ops.col2im(dcol2, (B, H, W, c2l.cin), 3, 3, 1, (1, 1, 1, 1))
-        g_c1 = ops.groupnorm_bwd(c1, g_a2, self.gn2[0], self.gn2[1], 1e-6, True)
+        g_c1 = ops.groupnorm_bwd(c1, g_a2, self.gn2[0], self.gn2[1], self.eps, True)
         gw1 = ops.gemm(g_c1.reshape(B * H * W, c1l.cout), col1, trans_a=True)
         return loss, [c1l.grad_to_oihw(gw1), c2l.grad_to_oihw(gw2)]
 
@@ -205,6 +209,109 @@ class AttnUnit(_Unit):
         gwk = ops.gemm(dK.reshape(B * T, Cc), hf, trans_a=True)
         gwv = ops.gemm(dV.reshape(B * T, Cc), hf, trans_a=True)
         return loss, [g.reshape(l.w.shape) for g, l in zip((gwq, gwk, gwv, gwp), self.layers)]
+
+
+class TransformerUnit(_Unit):
+    """QuantBasicTransformerBlock (reference quant/quant_block.py:254-299 with cross_attn_forward :208-251): self-attention,
+    cross-attention on `context`, GEGLU feed-forward, pre-LayerNorm residuals; multi-head, un-quantised matmuls.
+    Layers in module order: attn1.{to_q,to_k,to_v,to_out.0}, ff.net.0.proj, ff.net.2, attn2.{to_q,to_k,to_v,to_out.0}.
+    The heads stay packed in the channel dimension ([B,T,heads*d]); per-head GEMMs address them by stride."""
+
+    def __init__(self, layers: Sequence[AdaLayer], norms, heads: int, x: torch.Tensor, ctx: torch.Tensor, y: torch.Tensor, **kw):
+        super().__init__(layers, **kw)
+        assert len(layers) == 10
+        self.norms, self.heads = norms, heads      # norms: 3 x (gamma, beta)
+        self.x, self.ctx, self.y = x, ctx, y
+
+    # ---- multi-head attention on packed heads
+    def _attn_fwd(self, q, k, v):
+        """q [B,T,C], k/v [B,L,C] -> (o [B,T,C], P [B,heads,T,L])"""
+        B, T, Cc = q.shape
+        L, H = k.shape[1], self.heads
+        d = Cc // H
+        S = torch.empty(B, H, T, L, dtype=torch.float32, device=q.device)
+        for h in range(H):
+            ops.gemm_strided(q, h * d, Cc, 1, T * Cc, k, h * d, 1, Cc, L * Cc, S, h * T * L, L, H * T * L, T, L, d, B)
+        P = ops.softmax_rows(S, float(d ** -0.5))
+        o = torch.empty(B, T, Cc, dtype=torch.float32, device=q.device)
+        for h in range(H):
+            ops.gemm_strided(P, h * T * L, L, 1, H * T * L, v, h * d, Cc, 1, L * Cc, o, h * d, Cc, T * Cc, T, d, L, B)
+        return o, P
+
+    def _attn_bwd(self, g_o, q, k, v, P):
+        """-> dQ [B,T,C], dK [B,L,C], dV [B,L,C]"""
+        B, T, Cc = q.shape
+        L, H = k.shape[1], self.heads
+        d = Cc // H
+        dV, dK, dQ = torch.empty_like(v), torch.empty_like(k), torch.empty_like(q)
+        dP = torch.empty_like(P)
+        for h in range(H):
+            # dV_h = P_h^T g_o_h ; dP_h = g_o_h V_h^T
+            ops.gemm_strided(P, h * T * L, 1, L, H * T * L, g_o, h * d, Cc, 1, T * Cc, dV, h * d, Cc, L * Cc, L, d, T, B)
+            ops.gemm_strided(g_o, h * d, Cc, 1, T * Cc, v, h * d, 1, Cc, L * Cc, dP, h * T * L, L, H * T * L, T, L, d, B)
+        dS = ops.softmax_bwd_rows(P, dP, float(d ** -0.5))
+        for h in range(H):
+            # dQ_h = dS_h K_h ; dK_h = dS_h^T Q_h
+            ops.gemm_strided(dS, h * T * L, L, 1, H * T * L, k, h * d, Cc, 1, L * Cc, dQ, h * d, Cc, T * Cc, T, d, L, B)
+            ops.gemm_strided(dS, h * T * L, 1, L, H * T * L, q, h * d, Cc, 1, T * Cc, dK, h * d, Cc, L * Cc, L, d, T, B)
+        return dQ, dK, dV
+
+    def _forward_backward(self, idx):
+        (q1l, k1l, v1l, o1l, f0l, f2l, q2l, k2l, v2l, o2l) = self.layers
+        x, ctx, y = self.x.index_select(0, idx), self.ctx.index_select(0, idx), self.y.index_select(0, idx)
+        B, T, Cc = x.shape
+        L, Dc = ctx.shape[1], ctx.shape[2]
+        W = [l.soft_weight_gemm() for l in self.layers]
+        (wq1, wk1, wv1, wo1, wf0, wf2, wq2, wk2, wv2, wo2) = W
+        (g1, b1), (g2, b2), (g3, b3) = self.norms
+        x2d = x.reshape(B * T, Cc)
+        c2d = ctx.reshape(B * L, Dc)
+        # ---- forward
+        n1 = ops.layernorm(x, g1, b1, 1e-5, None)[1].reshape(B * T, Cc)
+        q1 = ops.gemm(n1, wq1, trans_b=True, bias=q1l.bias).reshape(B, T, Cc)
+        k1 = ops.gemm(n1, wk1, trans_b=True, bias=k1l.bias).reshape(B, T, Cc)
+        v1 = ops.gemm(n1, wv1, trans_b=True, bias=v1l.bias).reshape(B, T, Cc)
+        o1, P1 = self._attn_fwd(q1, k1, v1)
+        x1 = ops.gemm(o1.reshape(B * T, Cc), wo1, trans_b=True, bias=o1l.bias, residual=x2d)          # [B*T, C]
+        n2 = ops.layernorm(x1.reshape(B, T, Cc), g2, b2, 1e-5, None)[1].reshape(B * T, Cc)
+        q2 = ops.gemm(n2, wq2, trans_b=True, bias=q2l.bias).reshape(B, T, Cc)
+        k2 = ops.gemm(c2d, wk2, trans_b=True, bias=k2l.bias).reshape(B, L, Cc)
+        v2 = ops.gemm(c2d, wv2, trans_b=True, bias=v2l.bias).reshape(B, L, Cc)
+        o2, P2 = self._attn_fwd(q2, k2, v2)
+        x2 = ops.gemm(o2.reshape(B * T, Cc), wo2, trans_b=True, bias=o2l.bias, residual=x1)
+        n3 = ops.layernorm(x2.reshape(B, T, Cc), g3, b3, 1e-5, None)[1].reshape(B * T, Cc)
+        hcat = ops.gemm(n3, wf0, trans_b=True, bias=f0l.bias)                                        # [B*T, 2I]
+        gg = ops.geglu(hcat, None)[1]                                                                  # [B*T, I]
+        out = ops.gemm(gg, wf2, trans_b=True, bias=f2l.bias, residual=x2)
+        loss, g = ops.recon_loss(out.reshape(B, T, Cc), y, denom=B * T)
+        # ---- backward (weight gradients only; d/dx of the block input is not needed)
+        g_out = g.reshape(B * T, Cc)
+        gwf2 = ops.gemm(g_out, gg, trans_a=True)
+        d_gg = ops.gemm(g_out, wf2)
+        d_hcat = ops.geglu_bwd(hcat, d_gg)
+        gwf0 = ops.gemm(d_hcat, n3, trans_a=True)
+        d_n3 = ops.gemm(d_hcat, wf0)
+        d_x2 = ops.layernorm_bwd(x2.reshape(B, T, Cc), d_n3.reshape(B, T, Cc), g3, 1e-5).reshape(B * T, Cc)
+        ops.axpy(d_x2, g_out, 1.0)                                   # residual path of the feed-forward
+        # cross attention
+        gwo2 = ops.gemm(d_x2, o2.reshape(B * T, Cc), trans_a=True)
+        g_o2 = ops.gemm(d_x2, wo2).reshape(B, T, Cc)
+        dQ2, dK2, dV2 = self._attn_bwd(g_o2, q2, k2, v2, P2)
+        gwq2 = ops.gemm(dQ2.reshape(B * T, Cc), n2, trans_a=True)
+        gwk2 = ops.gemm(dK2.reshape(B * L, Cc), c2d, trans_a=True)
+        gwv2 = ops.gemm(dV2.reshape(B * L, Cc), c2d, trans_a=True)
+        d_n2 = ops.gemm(dQ2.reshape(B * T, Cc), wq2)
+        d_x1 = ops.layernorm_bwd(x1.reshape(B, T, Cc), d_n2.reshape(B, T, Cc), g2, 1e-5).reshape(B * T, Cc)
+        ops.axpy(d_x1, d_x2, 1.0)                                    # residual path of the cross attention
+        # self attention
+        gwo1 = ops.gemm(d_x1, o1.reshape(B * T, Cc), trans_a=True)
+        g_o1 = ops.gemm(d_x1, wo1).reshape(B, T, Cc)
+        dQ1, dK1, dV1 = self._attn_bwd(g_o1, q1, k1, v1, P1)
+        gwq1 = ops.gemm(dQ1.reshape(B * T, Cc), n1, trans_a=True)
+        gwk1 = ops.gemm(dK1.reshape(B * T, Cc), n1, trans_a=True)
+        gwv1 = ops.gemm(dV1.reshape(B * T, Cc), n1, trans_a=True)
+        grads = (gwq1, gwk1, gwv1, gwo1, gwf0, gwf2, gwq2, gwk2, gwv2, gwo2)
+        return loss, [gw.reshape(l.w.shape) for gw, l in zip(grads, self.layers)]
 
 
 class TibUnit(_Unit):

@@ -657,6 +657,42 @@ def gemm(A: torch.Tensor, B: torch.Tensor, trans_a: bool = False, trans_b: bool 
     return Cm
 
 
+def gemm_strided(A: torch.Tensor, a_off: int, sam: int, sak: int, bsa: int, B: torch.Tensor, b_off: int, sbk: int, sbn: int,
+                 bsb: int, Cm: torch.Tensor, c_off: int, scm: int, bsc: int, M: int, N: int, K: int, batch: int = 1,
+                 alpha: float = 1.0, accumulate: bool = False) -> torch.Tensor:
+    """C[z](m,n) (+)= alpha * sum_k A[z](m,k) B[z](k,n) on views of fp32 tensors described by element offsets and strides:
+    A(z,m,k) = A.flat[a_off + z*bsa + m*sam + k*sak], likewise B(k,n) and C(m,n) (row stride scm, unit column stride).
+    Lets the multi-head attention of a reconstruction unit run on the [B,T,heads*d] layout without permutes."""
+    d = _dev(A)
+    for t in (A, B, Cm):
+        _chk(t, torch.float32, "gemm_strided operand")
+    handle(d).call("gemm_f32", A.data_ptr() + 4 * a_off, B.data_ptr() + 4 * b_off, Cm.data_ptr() + 4 * c_off, M, N, K,
+                   sam, sak, sbk, sbn, scm, batch, bsa, bsb, bsc, float(alpha), None, None, 1, 0, None, int(accumulate),
+                   _stream(d))
+    return Cm
+
+
+def layernorm_bwd(x: torch.Tensor, gy: torch.Tensor, gamma: torch.Tensor, eps: float = 1e-5) -> torch.Tensor:
+    d = _dev(x)
+    _chk(x, torch.float32, "x")
+    _chk(gy, torch.float32, "gy")
+    Cc = x.shape[-1]
+    gx = _alloc_like(x)
+    handle(d).call("layernorm_bwd", _p(x), _p(gy), _p(gamma), float(eps), x.numel() // Cc, Cc, _p(gx), _stream(d))
+    return gx
+
+
+def geglu_bwd(hin: torch.Tensor, dy: torch.Tensor) -> torch.Tensor:
+    """hin [..., 2*inner], dy [..., inner] -> d hin."""
+    d = _dev(hin)
+    _chk(hin, torch.float32, "hin")
+    _chk(dy, torch.float32, "dy")
+    inner = hin.shape[-1] // 2
+    dh = _alloc_like(hin)
+    handle(d).call("geglu_bwd", _p(hin), _p(dy), hin.numel() // (2 * inner), inner, _p(dh), _stream(d))
+    return dh
+
+
 def im2col(x: torch.Tensor, kh: int, kw: int, stride: int = 1, pad=(0, 0, 0, 0)) -> torch.Tensor:
     d = _dev(x)
     _chk(x, torch.float32, "x")

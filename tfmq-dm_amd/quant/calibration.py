@@ -83,19 +83,24 @@ def _calibrate_activations(qnn: QuantModel, a_cali_data, interval: int, running_
     for time in range(n_groups):
         tx = a_cali_data[0][time * interval:(time + 1) * interval]
         tt = a_cali_data[1][time * interval:(time + 1) * interval]
+        tc = a_cali_data[2][time * interval:(time + 1) * interval] if len(a_cali_data) > 2 else None
         n = tx.shape[0]
         batch_size = min(16, n)
+
+        def fwd(sel):
+            args = [ops.nchw_to_nhwc(tx[sel].to(dev).float().contiguous()), tt[sel].to(dev).float().contiguous()]
+            if tc is not None:       # context-conditioned UNet (Stable Diffusion: text-encoder output)
+                args.append(tc[sel].to(dev).float().contiguous())
+            eng.forward(*args)
         inds = np.random.choice(n, 16, replace=False)
-        xb = ops.nchw_to_nhwc(tx[inds].to(dev).float().contiguous())
         eng.set_calibration("init" if scaler == "mse" else "init_minmax", 0)
-        eng.forward(xb, tt[inds].to(dev).float().contiguous())
+        fwd(inds)
         if running_stat:
             inds = np.arange(n)
             np.random.shuffle(inds)
             eng.set_calibration("running", 0)
             for i in range(0, n, batch_size):
-                sel = inds[i:i + batch_size]
-                eng.forward(ops.nchw_to_nhwc(tx[sel].to(dev).float().contiguous()), tt[sel].to(dev).float().contiguous())
+                fwd(inds[i:i + batch_size])
         eng.set_calibration(None)
         if sync is not None:
             sync(eng.qtable[0, :, 0])            # all-average of the deltas only (quant_model.py:127-132)

@@ -29,38 +29,52 @@ def unit_name(model, unit) -> str:
 
 def save_inout(model, layer, cali_data: Tuple[torch.Tensor], asym: bool = False, use_act: bool = False,
                batch_size: int = 128, keep_gpu: bool = True):
-    """-> (cached_inputs: tuple of NHWC tensors, cached_output NHWC).  For a ResnetBlock unit the inputs are
-    (x, temb); for an attention block / single layer (x,).  Everything stays on the device (288 GB HBM;
-    the reference spills to host RAM for the largest units, calibration.py:62-67)."""
-    from .quant_block import QuantResnetBlock
+    """-> (cached_inputs: tuple of tensors, cached_output).  Unit inputs (reference DataSaverHook, :79-104):
+    ResnetBlock / ResBlock (x NHWC, temb | emb); BasicTransformerBlock (tokens [N,T,C], context [N,L,D]);
+    attention block / single layer (x,).  cali_data = (xs, ts) or (xs, ts, cs) for context-conditioned UNets.
+    Everything stays on the device (288 GB HBM; the reference spills to host RAM for the largest units,
+    calibration.py:62-67)."""
+    from .quant_block import QuantBasicTransformerBlock, QuantResBlock, QuantResnetBlock
     name = unit_name(model, layer)
     dev = next(model.model.parameters()).device
     xs, ts = cali_data[0], cali_data[1]
-    ins, outs, tembs = [], [], []
-    # target: FP model
-    model.set_quant_state(False, False)
-    eng_fp = model.engine(dev)
-    # input: upstream with quantised weights (hard rounding of the units already reconstructed)
+    cs = cali_data[2] if len(cali_data) > 2 else None
+    ins, outs, tembs, ctxs = [], [], [], []
+
+    def fwd(x, t, c, taps):
+        eng = model.engine(dev)
+        if c is None:
+            eng.forward(x, t, taps=taps)
+        else:
+            eng.forward(x, t, c, taps=taps)
+
     for i in range(0, xs.size(0), batch_size):
         x = ops.nchw_to_nhwc(xs[i:i + batch_size].to(dev).float().contiguous())
         t = ts[i:i + batch_size].to(dev).float().contiguous()
+        c = None if cs is None else cs[i:i + batch_size].to(dev).float().contiguous()
         taps = {}
-        model.set_quant_state(False, False)
-        model.engine(dev).forward(x, t, taps=taps)
+        model.set_quant_state(False, False)             # target: FP model
+        fwd(x, t, c, taps)
+        if name not in taps:
+            raise KeyError(f"save_inout: the engine exposes no tap for unit '{name}'")
         outs.append(taps[name][1])
-        if asym:
+        if asym:                                        # input: upstream with the already-quantised weights
             taps = {}
             model.set_quant_state(True, use_act)
-            model.engine(dev).forward(x, t, taps=taps)
+            fwd(x, t, c, taps)
         tin = taps[name][0]
-        if isinstance(tin, tuple):       # (h, skip): concatenated input of an up-path ResnetBlock
+        if isinstance(layer, QuantBasicTransformerBlock):
+            ins.append(tin[0])
+            ctxs.append(tin[1])
+            continue
+        if isinstance(tin, tuple):       # (h, skip): concatenated input of an up-path block
             tin = torch.cat(tin, dim=-1)
         ins.append(tin)
-        if isinstance(layer, QuantResnetBlock):
+        if isinstance(layer, (QuantResnetBlock, QuantResBlock)):
             tembs.append(taps["__temb__"])
     model.set_quant_state(False, False)
     layer.set_quant_state(True, use_act)
     cached_out = torch.cat(outs)
-    cached_in = (torch.cat(ins),) + ((torch.cat(tembs),) if tembs else ())
+    cached_in = (torch.cat(ins),) + ((torch.cat(tembs),) if tembs else ()) + ((torch.cat(ctxs),) if ctxs else ())
     logger.info(f"input shapes: {[tuple(c.shape) for c in cached_in]} output shape: {tuple(cached_out.shape)}")
     return cached_in, cached_out

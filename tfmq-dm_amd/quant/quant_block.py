@@ -6,10 +6,9 @@ Execution is not done module by module: QuantModel lowers the whole tree to an e
 block's own `forward` (used when a unit is evaluated in isolation, e.g. by save_inout or
 block_reconstruction) runs the corresponding fused engine routine.
 
-DDPM-UNet blocks (BASELINE configs 1-2) are implemented; the LDM / Stable-Diffusion blocks
-(QuantResBlock, QuantBasicTransformerBlock, QuantAttentionBlock, QuantQKMatMul, QuantSMVMatMul,
-QuantTemporalInformationBlock) are declared and raise until their engine plan lands (SURVEY §8
-rows U2/U3).
+DDPM-UNet blocks (BASELINE configs 1-2) and the SpatialTransformer-UNet blocks of Stable Diffusion
+(QuantResBlock, QuantBasicTransformerBlock, QuantTemporalInformationBlock; config 3) are implemented;
+QuantAttentionBlock / QuantQKMatMul / QuantSMVMatMul (AttentionBlock LDMs) are declared and raise.
 """
 from __future__ import annotations
 
@@ -105,21 +104,103 @@ class QuantAttnBlock(BaseQuantBlock):
         return run_attn_block(self, x)
 
 
+class QuantTemporalInformationBlock(BaseQuantBlock):
+    """TIB of the latent-diffusion UNets (reference :76-128): `time_embed` MLP + the `emb_layers` of every ResBlock,
+    optimised as one unit (TIAR).  The emb_layers stay owned by their ResBlocks (plain list, as in the reference)."""
+
+    def __init__(self, t_emb: nn.Sequential, aq_params: dict = {}, model_channels: int = None, num_classes: int = None) -> None:
+        super().__init__(aq_params)
+        self.t_emb = t_emb
+        self.emb_layers = []
+        self.label_emb_layer = None
+        self.model_channels = model_channels
+        self.num_classes = num_classes
+        if num_classes is not None:
+            raise TfmqError("QuantTemporalInformationBlock: class-conditional label embedding (cin256) is a next row")
+
+    def add_emb_layer(self, layer: nn.Sequential) -> None:
+        self.emb_layers.append(layer)
+
+    def add_label_emb_layer(self, layer: nn.Sequential) -> None:
+        self.label_emb = layer
+
+    def quant_layers(self):
+        own = [m for m in self.modules() if isinstance(m, QuantLayer)]
+        return own + [m for seq in self.emb_layers for m in seq.modules() if isinstance(m, QuantLayer)]
+
+    def forward(self, x: torch.Tensor, t: torch.Tensor, y: torch.Tensor = None) -> Tuple[torch.Tensor]:
+        from tfmq_dm_amd.engine.tib import tib_forward_ldm
+        return tib_forward_ldm(self, t)
+
+
+class QuantResBlock(BaseQuantBlock):
+    """reference :131-206 (the SD / LDM ResBlock: GN32 -> SiLU -> conv, + emb_layers(emb), GN32 -> SiLU -> conv,
+    + skip_connection).  up/down and scale-shift variants are not enabled by any BASELINE config."""
+
+    def __init__(self, res: nn.Module, aq_params: dict = {}) -> None:
+        super().__init__(aq_params)
+        self.channels, self.emb_channels, self.dropout = res.channels, res.emb_channels, res.dropout
+        self.out_channels, self.use_conv = res.out_channels, res.use_conv
+        self.use_checkpoint, self.use_scale_shift_norm = res.use_checkpoint, res.use_scale_shift_norm
+        self.in_layers = res.in_layers
+        self.updown = res.updown
+        self.h_upd, self.x_upd = res.h_upd, res.x_upd
+        self.emb_layers = res.emb_layers
+        self.out_layers = res.out_layers
+        self.skip_connection = res.skip_connection
+        if self.updown or self.use_scale_shift_norm:
+            raise TfmqError("QuantResBlock: resblock up/down and scale-shift norm are not used by the BASELINE configs")
+
+    def forward(self, x, emb=None, split: int = 0):
+        if emb is None:
+            x, emb = x
+        if split != 0:
+            raise TfmqError("QuantResBlock: split (QDIFF dual quantizers) is never enabled by the drivers (SURVEY §8f)")
+        from tfmq_dm_amd.engine.blocks import run_res_block
+        return run_res_block(self, x, emb)
+
+
+class QuantBasicTransformerBlock(BaseQuantBlock):
+    """reference :254-299.  attn1 (self), attn2 (cross, context), GEGLU feed-forward, pre-LayerNorm residuals.  The
+    q/k/v/softmax quantizers are created for state compatibility; `attn.use_aq` is never set by any driver."""
+
+    def __init__(self, tran: nn.Module, aq_params: dict = {}, softmax_a_bit: int = 8) -> None:
+        super().__init__(aq_params)
+        self.attn1, self.ff, self.attn2 = tran.attn1, tran.ff, tran.attn2
+        self.norm1, self.norm2, self.norm3 = tran.norm1, tran.norm2, tran.norm3
+        self.checkpoint = False
+        aq_w = dict(aq_params)
+        aq_w.update(bits=softmax_a_bit, symmetric=False, always_zero=True)
+        for attn in (self.attn1, self.attn2):
+            attn.aqtizer_q = UniformAffineQuantizer(**aq_params)
+            attn.aqtizer_k = UniformAffineQuantizer(**aq_params)
+            attn.aqtizer_v = UniformAffineQuantizer(**aq_params)
+        self.attn1.aqtizer_w = UniformAffineQuantizer(**aq_w)
+        self.attn2.aqtizer_w = UniformAffineQuantizer(**aq_w)
+        self.attn1.use_aq = False
+        self.attn2.use_aq = False
+
+    def forward(self, x: torch.Tensor, context: torch.Tensor = None) -> torch.Tensor:
+        if context is None:
+            raise TfmqError("QuantBasicTransformerBlock: context is required (reference asserts the same)")
+        if self.attn1.use_aq or self.attn2.use_aq:
+            raise NotImplementedError("int8 attention matmuls are a 'next' row (SURVEY §8f-3); no driver enables them")
+        from tfmq_dm_amd.engine.blocks import run_transformer_block
+        return run_transformer_block(self, x, context)
+
+
 def _ldm_block(name):
     class _Pending(BaseQuantBlock):
         def __init__(self, *a, **k):
-            raise TfmqError(f"{name}: the LDM / Stable-Diffusion engine plan is not built yet "
-                            "(BASELINE configs 3-5; DESIGN.md 'what comes next')")
+            raise TfmqError(f"{name}: only needed by the AttentionBlock (non-SpatialTransformer) LDMs, a next row "
+                            "(DESIGN.md 'what comes next')")
     _Pending.__name__ = name
     return _Pending
 
 
-QuantResBlock = _ldm_block("QuantResBlock")
-QuantBasicTransformerBlock = _ldm_block("QuantBasicTransformerBlock")
 QuantAttentionBlock = _ldm_block("QuantAttentionBlock")
 QuantQKMatMul = _ldm_block("QuantQKMatMul")
 QuantSMVMatMul = _ldm_block("QuantSMVMatMul")
-QuantTemporalInformationBlock = _ldm_block("QuantTemporalInformationBlock")
 
 
 def b2qb(use_aq: bool = False) -> Dict[str, type]:

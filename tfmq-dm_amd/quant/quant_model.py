@@ -123,6 +123,10 @@ class QuantModel(nn.Module):
             if isinstance(m, QuantAttnBlock):
                 for q in (m.aqtizer_q, m.aqtizer_k, m.aqtizer_v, m.aqtizer_w):
                     q.running_stat = running_stat
+            elif isinstance(m, QuantBasicTransformerBlock):
+                for attn in (m.attn1, m.attn2):
+                    for q in (attn.aqtizer_q, attn.aqtizer_k, attn.aqtizer_v, attn.aqtizer_w):
+                        q.running_stat = running_stat
             elif isinstance(m, QuantLayer):
                 m.set_running_stat(running_stat)
 
@@ -142,10 +146,13 @@ class QuantModel(nn.Module):
         return [n for n, l in self.named_quant_layers() if l.use_aq and not l.disable_aq]
 
     def _lower(self, device):
-        from tfmq_dm_amd.engine import DdimUNetEngine, LayerQ
-        if self.model.__class__.__name__ != "Model" or not hasattr(self.model, "temb"):
-            raise TfmqError(f"QuantModel: no engine plan for {self.model.__class__.__name__} yet "
-                            "(DDPM UNet is supported; LDM/SD UNetModel is the next row)")
+        from tfmq_dm_amd.engine import DdimUNetEngine, LayerQ, LdmUNetEngine
+        if self.model.__class__.__name__ == "Model" and hasattr(self.model, "temb"):
+            engine_cls = DdimUNetEngine          # DDPM pixel-space UNet (ddim/models/diffusion.py)
+        elif self.model.__class__.__name__ == "UNetModel" and hasattr(self.model, "time_embed"):
+            engine_cls = LdmUNetEngine           # SpatialTransformer UNet (openaimodel.py: SD v1 family)
+        else:
+            raise TfmqError(f"QuantModel: no engine plan for {self.model.__class__.__name__}")
         sd, wq = {}, {}
         act_names = self.act_layer_names()
         qid = {n: i for i, n in enumerate(act_names)}
@@ -161,10 +168,10 @@ class QuantModel(nn.Module):
                     sd[n + ".weight"] = mod.original_w
                     if mod.original_b is not None:
                         sd[n + ".bias"] = mod.original_b
-            elif isinstance(mod, (nn.Conv2d, nn.Linear, nn.GroupNorm)):
+            elif isinstance(mod, (nn.Conv2d, nn.Linear, nn.GroupNorm, nn.LayerNorm)):
                 for pn, p in mod.named_parameters(recurse=False):
                     sd[f"{n}.{pn}"] = p.detach()
-        eng = DdimUNetEngine(sd, self.model.engine_cfg(), device)
+        eng = engine_cls(sd, self.model.engine_cfg(), device)
         n_steps = 1 if self._act_table is None else self._act_table.shape[0]
         qtable = torch.zeros(n_steps, max(len(act_names), 1), 2, dtype=torch.float32, device=device)
         if self._act_step is None:
@@ -234,11 +241,13 @@ class QuantModel(nn.Module):
         return out
 
     def forward(self, x: torch.Tensor, timestep=None, context: torch.Tensor = None) -> torch.Tensor:
-        if context is not None:
-            raise TfmqError("QuantModel.forward: context-conditioned (LDM/SD) models are the next row")
         if not x.is_cuda:
             raise TfmqError("QuantModel.forward: CPU tensor (the HIP kernels are the only implementation)")
         eng = self.engine(x.device)
         t = timestep if torch.is_tensor(timestep) else torch.full((x.shape[0],), float(timestep), device=x.device)
-        eps = eng.forward(ops.nchw_to_nhwc(x.float().contiguous()), t.float().contiguous().to(x.device))
+        xin = ops.nchw_to_nhwc(x.float().contiguous())
+        if context is None:
+            eps = eng.forward(xin, t.float().contiguous().to(x.device))
+        else:
+            eps = eng.forward(xin, t.float().contiguous().to(x.device), context.float().contiguous().to(x.device))
         return ops.nhwc_to_nchw(eps)

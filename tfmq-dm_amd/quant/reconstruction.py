@@ -19,7 +19,8 @@ from tfmq_dm_amd._lib import TfmqError
 from tfmq_dm_amd.engine import recon as R
 from .adaptive_rounding import AdaRoundQuantizer, RMODE
 from .data_utill import save_inout
-from .quant_block import BaseQuantBlock, QuantAttnBlock, QuantResnetBlock, QuantTemporalInformationBlockDDIM
+from .quant_block import (BaseQuantBlock, QuantAttnBlock, QuantBasicTransformerBlock, QuantResBlock, QuantResnetBlock,
+                          QuantTemporalInformationBlock, QuantTemporalInformationBlockDDIM)
 from .quant_layer import QuantLayer, StraightThrough
 from .reconstruction_util import RLOSS, LossFunc, LossFuncTimeEmbedding
 
@@ -124,6 +125,32 @@ def block_reconstruction(model, block: BaseQuantBlock, cali_data: torch.Tensor, 
         unit = R.AttnUnit(adas["q"], adas["k"], adas["v"], adas["proj_out"],
                           (block.norm.weight.data.float(), block.norm.bias.data.float()), cached_inputs[0], cached_outputs, **kw)
         layers = [(getattr(block, n), adas[n]) for n in names]
+    elif isinstance(block, QuantResBlock):
+        conv1, conv2 = block.in_layers[2], block.out_layers[3]
+        adas = {"c1": _ada_layer(conv1), "c2": _ada_layer(conv2)}      # emb_layers.1 is quant_emb: excluded (TIB unit)
+        cached_inputs, cached_outputs = save_inout(model, block, cali_data, asym, use_aq, batch_size, keep_gpu)
+        x, emb = cached_inputs
+        ep = block.emb_layers[1]                                       # frozen under the block's quant state
+        d, z, a = ep.weight_quant_state()
+        pk = ops.pack_w4(ep.w.data.float().contiguous(), d, z, None if a is None else a.contiguous(), ep.b.data)
+        proj = ops.linear_small_w4(emb.contiguous(), pk, ops.qsel(None), silu_in=True)
+        sc = None
+        if isinstance(block.skip_connection, torch.nn.Conv2d):
+            ns = block.skip_connection
+            sc = (ns.weight.data.reshape(ns.weight.shape[0], -1).float().contiguous(), ns.bias.data.float().contiguous())
+        n1, n2 = block.in_layers[0], block.out_layers[0]
+        unit = R.ResnetUnit(adas["c1"], adas["c2"], (n1.weight.data.float(), n1.bias.data.float()),
+                            (n2.weight.data.float(), n2.bias.data.float()), sc, x, proj, cached_outputs, eps=n1.eps, **kw)
+        layers = [(conv1, adas["c1"]), (conv2, adas["c2"])]
+    elif isinstance(block, QuantBasicTransformerBlock):
+        mods = [block.attn1.to_q, block.attn1.to_k, block.attn1.to_v, block.attn1.to_out[0], block.ff.net[0].proj,
+                block.ff.net[2], block.attn2.to_q, block.attn2.to_k, block.attn2.to_v, block.attn2.to_out[0]]
+        adal = [_ada_layer(m) for m in mods]
+        cached_inputs, cached_outputs = save_inout(model, block, cali_data, asym, use_aq, batch_size, keep_gpu)
+        x, ctx = cached_inputs
+        norms = [(n.weight.data.float().contiguous(), n.bias.data.float().contiguous()) for n in (block.norm1, block.norm2, block.norm3)]
+        unit = R.TransformerUnit(adal, norms, block.attn1.heads, x, ctx, cached_outputs, **kw)
+        layers = list(zip(mods, adal))
     else:
         raise TfmqError(f"block_reconstruction: no reconstruction unit for {type(block).__name__} yet")
     _run(unit, cached_inputs[0].size(0), batch_size, iters, loss_func, dev)
@@ -141,22 +168,30 @@ def tib_reconstruction(block: BaseQuantBlock, cali_data: torch.Tensor, batch_siz
     simply absent from the all-reduced buffer."""
     if use_aq:
         raise NotImplementedError("delta-learning reconstruction (use_aq=True) is never requested by the drivers")
-    if not isinstance(block, QuantTemporalInformationBlockDDIM):
-        raise TfmqError("tib_reconstruction: only the DDPM-UNet TIB is built so far")
+    ldm = isinstance(block, QuantTemporalInformationBlock)
+    if not (ldm or isinstance(block, QuantTemporalInformationBlockDDIM)):
+        raise TfmqError(f"tib_reconstruction: not a temporal-information block: {type(block).__name__}")
     assert opt_mode == RLOSS.MSE
-    from tfmq_dm_amd.engine.tib import tib_forward_ddim
+    from tfmq_dm_amd.engine.tib import tib_forward_ddim, tib_forward_ldm
     dev = next(block.parameters()).device
     ts = cali_data[1].to(dev).float().contiguous()
+    fwd = tib_forward_ldm if ldm else tib_forward_ddim
     # FP targets (save_inout(block, block, ...): the TIB is its own model there)
     block.set_quant_state(False, False)
-    targets = list(tib_forward_ddim(block, ts))
+    targets = list(fwd(block, ts))
     block.set_quant_state(use_wq=True, use_aq=use_aq)
-    d0, d1 = block.temb.dense[0], block.temb.dense[1]
-    # every QuantLayer of the TIB is wrapped (state-dict parity), dense.0 stays FP (ignore_recon)
+    if ldm:      # time_embed = Linear, SiLU, Linear; emb_layers = SiLU, Linear (openaimodel.py:466-470,193-199)
+        d0, d1 = block.t_emb[0], block.t_emb[2]
+        projs = [seq[1] for seq in block.emb_layers]
+        emb = ops.timestep_embedding(ts, block.model_channels, ldm_order=True)
+    else:
+        d0, d1 = block.temb.dense[0], block.temb.dense[1]
+        projs = list(block.temb_projs)
+        emb = ops.timestep_embedding(ts, block.ch)
+    # every QuantLayer of the TIB is wrapped (state-dict parity), the first Linear stays FP (ignore_recon)
     _to_adaround(d0)
     ada1 = _ada_layer(d1)
-    adap = [_ada_layer(pj) for pj in block.temb_projs]
-    emb = ops.timestep_embedding(ts, block.ch)
+    adap = [_ada_layer(pj) for pj in projs]
     h0 = ops.linear_small_f32(emb, d0.original_w.to(dev).float().contiguous(),
                               None if d0.original_b is None else d0.original_b.to(dev).float().contiguous())
     s0 = ops.silu(h0)
@@ -166,5 +201,5 @@ def tib_reconstruction(block: BaseQuantBlock, cali_data: torch.Tensor, batch_siz
     _run(unit, ts.size(0), batch_size, iters, loss_func, dev)
     d0.wqtizer.soft_tgt = False
     _commit(d1, ada1)
-    for pj, a in zip(block.temb_projs, adap):
+    for pj, a in zip(projs, adap):
         _commit(pj, a)
