@@ -236,6 +236,14 @@ int tfmq_ddim_update(tfmq_handle h, const float* x, const float* eps, const floa
 int tfmq_ddim_update_cfg(tfmq_handle h, const float* x, const float* eps_u, const float* eps_c, float scale,
                          const float* noise_or_null, float* x_next, float* x0_or_null, size_t n, const float* coef,
                          const int32_t* step, void* stream);
+/* PLMS sampler pieces (ldm/models/diffusion/plms.py:179-242), in the reference's operation order:
+ * cfg_combine: out = eps_u + scale*(eps_c - eps_u);
+ * plms_combine: order 1 (e0+e1)/2 [e1 = eps at t_next]; 2 (3e0-e1)/2; 3 (23e0-16e1+5e2)/12; 4 (55e0-59e1+37e2-9e3)/24
+ * with e1..e3 the previous model outputs, newest first; the result feeds tfmq_ddim_update. */
+int tfmq_cfg_combine(tfmq_handle h, const float* eps_u, const float* eps_c, float scale, float* out, size_t n,
+                     void* stream);
+int tfmq_plms_combine(tfmq_handle h, int order, const float* e0, const float* e1, const float* e2_or_null,
+                      const float* e3_or_null, float* out, size_t n, void* stream);
 int tfmq_step_advance(tfmq_handle h, int32_t* step, int delta, void* stream);
 /* y = x*sigmoid(x)  (nonlinearity, ddim/models/diffusion.py:27-29) */
 int tfmq_silu(tfmq_handle h, const float* x, float* y, size_t n, void* stream);

@@ -105,6 +105,28 @@ def main():
     samples, _ = sampler.sample(S=4, conditioning=ctx, batch_size=2, shape=[4, 8, 8], verbose=False,
                                 unconditional_guidance_scale=7.5, unconditional_conditioning=uc, eta=0.0, x_T=x_T)
     out["traj_fp_final"] = samples
+    # PLMS (Adams-Bashforth 1-4, one extra model call on the first step), 6 steps, CFG 7.5: FP and w4a8, plus the
+    # `untill_fake_t` early stop used by the calibration-set generators
+    from ldm.models.diffusion.plms import PLMSSampler
+    psampler = PLMSSampler(ldm)
+    inter = []
+    samples, _ = psampler.sample(S=6, conditioning=ctx, batch_size=2, shape=[4, 8, 8], verbose=False,
+                                 unconditional_guidance_scale=7.5, unconditional_conditioning=uc, eta=0.0, x_T=x_T,
+                                 img_callback=lambda px0, i: inter.append(px0.clone()), log_every_t=1)
+    out["plms_fp_final"] = samples
+    out["plms_fp_predx0"] = torch.stack(inter)
+    samples, _ = psampler.sample(S=6, conditioning=ctx, batch_size=2, shape=[4, 8, 8], verbose=False,
+                                 unconditional_guidance_scale=7.5, unconditional_conditioning=uc, eta=0.0, x_T=x_T,
+                                 untill_fake_t=4)
+    out["plms_fp_until4"] = samples
+    samples, _ = sampler.sample(S=4, conditioning=ctx, batch_size=2, shape=[4, 8, 8], verbose=False,
+                                unconditional_guidance_scale=7.5, unconditional_conditioning=uc, eta=0.0, x_T=x_T,
+                                untill_fake_t=3)
+    out["traj_fp_until3"] = samples
+    qnn.set_quant_state(True, True)
+    samples, _ = psampler.sample(S=6, conditioning=ctx, batch_size=2, shape=[4, 8, 8], verbose=False,
+                                 unconditional_guidance_scale=7.5, unconditional_conditioning=uc, eta=0.0, x_T=x_T)
+    out["plms_w4a8_final"] = samples
     save("f11_ldm_tiny", **out)
 
 

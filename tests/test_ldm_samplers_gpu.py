@@ -1,0 +1,111 @@
+"""Drop-in latent samplers (DDIMSampler / PLMSSampler over LatentDiffusion.apply_model -> QuantModel -> HIP engine) against
+trajectories produced by the reference's own samplers on the tiny SD-style UNet (fixture F11), incl. classifier-free
+guidance, the `untill_fake_t` early stop, and the DiffusionWrapper's Finite-Set activation-group selection."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tfmq-dm_amd"))
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+from test_quant_mirror_ldm import T, tiny_qnn  # noqa: E402
+
+
+def rel_l2(a, b):
+    return float((a - b).norm() / b.norm())
+
+
+@pytest.fixture(scope="module")
+def ldm(golden):
+    from tfmq_dm_amd.ldm.ddpm import LatentDiffusion
+    g = golden("f11_ldm_tiny")
+    q = tiny_qnn(g, device=DEV)
+    q.set_quant_state(False, False)
+    m = LatentDiffusion(q).to(DEV)
+    assert np.array_equal(m.alphas_cumprod.cpu().numpy(), g["alphas_cumprod"])      # register_schedule, bit-exact
+    return g, q, m
+
+
+def test_ddim_dropin_fp(ldm):
+    from tfmq_dm_amd.ldm.ddim import DDIMSampler
+    g, q, m = ldm
+    ctx, uc, x_T = T(g["ctx"]).to(DEV), T(g["traj_uc"]).to(DEV), T(g["traj_xT"]).to(DEV)
+    s = DDIMSampler(m)
+    inter = []
+    out, im = s.sample(S=4, conditioning=ctx, batch_size=2, shape=[4, 8, 8], verbose=False, unconditional_guidance_scale=7.5,
+                       unconditional_conditioning=uc, eta=0.0, x_T=x_T, img_callback=lambda p, i: inter.append(p.clone()),
+                       log_every_t=1)
+    assert np.array_equal(s.ddim_timesteps, g["ddim_ts_4"])
+    assert rel_l2(out.cpu(), T(g["traj_fp_final"])) <= 2e-2          # f16 MFMA layers, CFG 7.5 amplifies eps error
+    assert len(inter) == 4 and len(im["x_inter"]) == 5
+    out3, _ = s.sample(S=4, conditioning=ctx, batch_size=2, shape=[4, 8, 8], verbose=False, unconditional_guidance_scale=7.5,
+                       unconditional_conditioning=uc, eta=0.0, x_T=x_T, untill_fake_t=3)
+    assert rel_l2(out3.cpu(), T(g["traj_fp_until3"])) <= 2e-2
+
+
+def test_plms_dropin_fp(ldm):
+    from tfmq_dm_amd.ldm.ddim import PLMSSampler
+    g, q, m = ldm
+    ctx, uc, x_T = T(g["ctx"]).to(DEV), T(g["traj_uc"]).to(DEV), T(g["traj_xT"]).to(DEV)
+    s = PLMSSampler(m)
+    inter = []
+    out, _ = s.sample(S=6, conditioning=ctx, batch_size=2, shape=[4, 8, 8], verbose=False, unconditional_guidance_scale=7.5,
+                      unconditional_conditioning=uc, eta=0.0, x_T=x_T, img_callback=lambda p, i: inter.append(p.clone()),
+                      log_every_t=1)
+    ref_px0 = T(g["plms_fp_predx0"])
+    assert len(inter) == ref_px0.shape[0] == 7                       # 1000 // 6 = 166 -> 7 executed steps
+    assert rel_l2(inter[0].cpu(), ref_px0[0]) <= 1e-2                # first step: pseudo improved Euler (2 model calls)
+    assert rel_l2(out.cpu(), T(g["plms_fp_final"])) <= 2e-2
+    out4, _ = s.sample(S=6, conditioning=ctx, batch_size=2, shape=[4, 8, 8], verbose=False, unconditional_guidance_scale=7.5,
+                       unconditional_conditioning=uc, eta=0.0, x_T=x_T, untill_fake_t=4)
+    assert rel_l2(out4.cpu(), T(g["plms_fp_until4"])) <= 2e-2
+    with pytest.raises(ValueError):
+        s.sample(S=6, conditioning=ctx, batch_size=2, shape=[4, 8, 8], eta=0.5, x_T=x_T)
+
+
+def test_plms_combine_kernels_bit_exact():
+    import tfmq_dm_amd.ops as ops
+    gen = torch.Generator().manual_seed(1)
+    e = [torch.randn(3, 4, 8, 8, generator=gen) for _ in range(4)]
+    d = [t.to(DEV) for t in e]
+    assert torch.equal(ops.plms_combine(1, d[0], d[1]).cpu(), (e[0] + e[1]) / 2)
+    assert torch.equal(ops.plms_combine(2, d[0], d[1]).cpu(), (3 * e[0] - e[1]) / 2)
+    assert torch.equal(ops.plms_combine(3, d[0], d[1], d[2]).cpu(), (23 * e[0] - 16 * e[1] + 5 * e[2]) / 12)
+    assert torch.equal(ops.plms_combine(4, d[0], d[1], d[2], d[3]).cpu(), (55 * e[0] - 59 * e[1] + 37 * e[2] - 9 * e[3]) / 24)
+    assert torch.equal(ops.cfg_combine(d[0], d[1], 7.5).cpu(), e[0] + 7.5 * (e[1] - e[0]))
+
+
+def test_wrapper_selects_activation_group(golden):
+    """DiffusionWrapper.{tot,t_max,ckpt} (txt2img.py): k = t_max - (t-1)//tot picks the act_k group; the device-table
+    path gives the same eps as the reference's load_state_dict path."""
+    from tfmq_dm_amd.ldm.ddpm import LatentDiffusion
+    from quant.calibration import load_cali_model
+    import tempfile
+    g = golden("f12_ldm_cali_tiny")
+    ck = {"weight": {str(k): T(g["ck/weight/" + str(k)]) for k in g["weight_keys"]}}
+    akeys = [str(k) for k in g["act_keys"]]
+    for gi in range(3):
+        d, z = T(g[f"ck/act_{gi}/delta"]), T(g[f"ck/act_{gi}/zp"])
+        dk = [k for k in akeys if k.endswith("delta")]
+        zk = [k for k in akeys if k.endswith("zero_point")]
+        ck[f"act_{gi}"] = {**{k: d[i] for i, k in enumerate(dk)}, **{k: z[i] for i, k in enumerate(zk)}}
+    path = os.path.join(tempfile.mkdtemp(), "c.pth")
+    torch.save(ck, path)
+    q = tiny_qnn(g, cali=False, device=DEV)
+    init = (torch.randn(1, 4, 8, 8), torch.randint(0, 1000, (1,)).float(), torch.randn(1, 5, 64))
+    load_cali_model(q, init, use_aq=True, path=path)
+    m = LatentDiffusion(q).to(DEV)
+    xe, ce = T(g["reload_x"]).to(DEV), T(g["reload_c"]).to(DEV)
+    te = torch.full((2,), 501, device=DEV, dtype=torch.long)
+    # three groups over 1000 steps: tot = 334, t_max = 2 -> t = 501 selects act_1
+    m.model.tot, m.model.t_max, m.model.ckpt = 334, 2, ck
+    eps = m.apply_model(xe, te, ce).cpu()
+    assert int(q._act_step.item()) == 1
+    ref = T(g["reload_eps_act1"])
+    assert rel_l2(eps, ref) <= 5e-2

@@ -289,3 +289,54 @@ extern "C" int tfmq_linear_small_w4(tfmq_handle h, const float* x, const uint8_t
   TFMQ_LAUNCH_CHECK(h);
   return TFMQ_OK;
 }
+
+// ------------------------------------------------------------------ PLMS (Adams-Bashforth) pieces
+// e = e_u + s (e_c - e_u)   (get_model_output, ldm/models/diffusion/plms.py:186-195; same operation order)
+__global__ __launch_bounds__(256) void k_cfg_combine(const float* __restrict__ eu, const float* __restrict__ ec, float s,
+                                                     float* __restrict__ out, size_t n) {
+  const size_t stride = static_cast<size_t>(gridDim.x) * blockDim.x;
+  for (size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride)
+    out[i] = eu[i] + s * (ec[i] - eu[i]);
+}
+
+extern "C" int tfmq_cfg_combine(tfmq_handle h, const float* eps_u, const float* eps_c, float scale, float* out, size_t n,
+                                void* stream) {
+  TFMQ_CHECK_ARG(h, h && eps_u && eps_c && out, "cfg_combine: null pointer");
+  if (n == 0) return TFMQ_OK;
+  int blocks = ceil_div(static_cast<long>(n), 256);
+  if (blocks > h->cu_count * 8) blocks = h->cu_count * 8;
+  hipLaunchKernelGGL(k_cfg_combine, dim3(blocks), dim3(256), 0, as_stream(stream), eps_u, eps_c, scale, out, n);
+  TFMQ_LAUNCH_CHECK(h);
+  return TFMQ_OK;
+}
+
+// e' of p_sample_plms (plms.py:224-240), evaluated in the reference's operation order:
+//   order 1: (e0 + e1) / 2                    e1 = model output at t_next (pseudo improved Euler)
+//   order 2: (3 e0 - e1) / 2                  e1, e2, e3 = previous outputs, newest first
+//   order 3: (23 e0 - 16 e1 + 5 e2) / 12
+//   order 4: (55 e0 - 59 e1 + 37 e2 - 9 e3) / 24
+__global__ __launch_bounds__(256) void k_plms_combine(int order, const float* __restrict__ e0, const float* __restrict__ e1,
+                                                      const float* __restrict__ e2, const float* __restrict__ e3,
+                                                      float* __restrict__ out, size_t n) {
+  const size_t stride = static_cast<size_t>(gridDim.x) * blockDim.x;
+  for (size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) {
+    float v;
+    if (order == 1) v = (e0[i] + e1[i]) / 2.0f;
+    else if (order == 2) v = (3.0f * e0[i] - e1[i]) / 2.0f;
+    else if (order == 3) v = (23.0f * e0[i] - 16.0f * e1[i] + 5.0f * e2[i]) / 12.0f;
+    else v = (55.0f * e0[i] - 59.0f * e1[i] + 37.0f * e2[i] - 9.0f * e3[i]) / 24.0f;
+    out[i] = v;
+  }
+}
+
+extern "C" int tfmq_plms_combine(tfmq_handle h, int order, const float* e0, const float* e1, const float* e2,
+                                 const float* e3, float* out, size_t n, void* stream) {
+  TFMQ_CHECK_ARG(h, h && e0 && out && order >= 1 && order <= 4, "plms_combine: bad argument");
+  TFMQ_CHECK_ARG(h, e1 && (order < 3 || e2) && (order < 4 || e3), "plms_combine: missing history");
+  if (n == 0) return TFMQ_OK;
+  int blocks = ceil_div(static_cast<long>(n), 256);
+  if (blocks > h->cu_count * 8) blocks = h->cu_count * 8;
+  hipLaunchKernelGGL(k_plms_combine, dim3(blocks), dim3(256), 0, as_stream(stream), order, e0, e1, e2, e3, out, n);
+  TFMQ_LAUNCH_CHECK(h);
+  return TFMQ_OK;
+}

@@ -36,8 +36,9 @@ def ddim_coef_table(alphas_cumprod: torch.Tensor, S: int, eta: float = 0.0) -> t
     a_prev = torch.tensor([float(alphas_cumprod[0])] + alphas_cumprod[ts[:-1]].tolist(), dtype=torch.float32)
     sig = eta * torch.sqrt((1 - a_prev) / (1 - a) * (1 - a / a_prev))
     rows = []
+    n = len(ts)          # S' = ceil(1000 / (1000 // S)) executed steps: S when S divides the schedule, else more
     for i, step in enumerate(np.flip(ts)):
-        idx = S - i - 1
+        idx = n - i - 1
         a_t, ap, sg = a[idx].reshape(1), a_prev[idx].reshape(1), sig[idx].reshape(1).float()
         rows.append(torch.cat([torch.sqrt(1.0 - a[idx]).reshape(1), a_t.sqrt(), ap.sqrt(), sg, (1.0 - ap - sg ** 2).sqrt(),
                                torch.tensor([float(step)]), torch.zeros(2)]))
@@ -99,6 +100,6 @@ class GraphLatentDdimSampler:
             self.ctx2[:self.batch].copy_(uncond, non_blocking=True)   # c_in = cat[uc, c]  (ddim.py:183)
             self.ctx2[self.batch:].copy_(cond, non_blocking=True)
             self.step.zero_()
-            for _ in range(self.S if steps is None else steps):
+            for _ in range(self.coef.shape[0] if steps is None else steps):
                 self.h.call("graph_launch", self.gid, sp)
         return self.x

@@ -564,6 +564,22 @@ def ddim_update(x, eps, coef, step=None, noise=None, want_x0=False, out=None):
     return (xn, x0) if want_x0 else xn
 
 
+def cfg_combine(eps_u: torch.Tensor, eps_c: torch.Tensor, scale: float, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """e_u + scale * (e_c - e_u), the classifier-free-guidance combine in the reference's operation order."""
+    d = _dev(eps_u)
+    o = out if out is not None else _alloc_like(eps_u)
+    handle(d).call("cfg_combine", _p(eps_u), _p(eps_c), float(scale), _p(o), eps_u.numel(), _stream(d))
+    return o
+
+
+def plms_combine(order: int, e0, e1, e2=None, e3=None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Adams-Bashforth eps combination of p_sample_plms (order 1 = pseudo improved Euler with e1 = eps at t_next)."""
+    d = _dev(e0)
+    o = out if out is not None else _alloc_like(e0)
+    handle(d).call("plms_combine", int(order), _p(e0), _p(e1), _p(e2), _p(e3), _p(o), e0.numel(), _stream(d))
+    return o
+
+
 def ddim_update_cfg(x, eps_u, eps_c, scale: float, coef, step=None, noise=None, want_x0=False, out=None):
     """Classifier-free-guidance combine + DDIM update in one pass (out=x allowed)."""
     d = _dev(x)

@@ -230,6 +230,17 @@ class QuantModel(nn.Module):
             self._act_table = tab.to(next(self.model.parameters()).device)
         self.invalidate()
 
+    def select_act_group(self, k: int):
+        """Finite-Set Calibration: use row k of the table installed by set_act_table() for the following forwards
+        (what `load_state_dict(ckpt['act_k'])` does in ddpm.py:1403-1405 / denoising.py:26-29, without the tree walk)."""
+        if self._act_table is None:
+            raise TfmqError("select_act_group: no activation table installed (set_act_table)")
+        if not 0 <= int(k) < self._act_table.shape[0]:
+            raise TfmqError(f"select_act_group: group {k} outside the table (0..{self._act_table.shape[0] - 1})")
+        if self._act_step is None:
+            self._act_step = torch.zeros(1, dtype=torch.int32, device=self._act_table.device)
+        self._act_step.fill_(int(k))
+
     def load_state_dict(self, state_dict, strict: bool = True):
         """`model.load_state_dict(act_k, strict=False)` (ddim/functions/denoising.py:26-29) keeps
         working: the module state is updated as in torch and the device table row is refreshed."""
