@@ -109,3 +109,32 @@ def test_wrapper_selects_activation_group(golden):
     assert int(q._act_step.item()) == 1
     ref = T(g["reload_eps_act1"])
     assert rel_l2(eps, ref) <= 5e-2
+
+
+def test_text_guided_calibration_set(ldm):
+    """generate_cali_text_guided_data (quant/data_generate.py:13-49): per c-th step and prompt, CFG-7.5 sampling from
+    fresh noise until that step; both the conditional and the unconditional context enter the set; timesteps follow
+    real_time = (T - t) * 1000 // T + 1."""
+    from quant.data_generate import generate_cali_text_guided_data
+    from tfmq_dm_amd.ldm.ddim import DDIMSampler, PLMSSampler
+    g, q, m = ldm
+    gen = torch.Generator().manual_seed(7)
+    table = {"": torch.randn(5, 64, generator=gen), "a": torch.randn(5, 64, generator=gen), "b": torch.randn(5, 64, generator=gen)}
+    m.get_learned_conditioning = lambda prompts: torch.stack([table[p] for p in prompts]).to(DEV)
+    T_, c_, bs = 4, 2, 2
+    for cls in (DDIMSampler, PLMSSampler):
+        torch.manual_seed(11)
+        xs, ts, cs = generate_cali_text_guided_data(m, cls(m), T_, c_, bs, ("a", "b"), [4, 8, 8])
+        n_t = T_ // c_
+        assert xs.shape == (n_t * 2 * 2 * bs, 4, 8, 8) and ts.shape == (n_t * 2 * 2 * bs,) and cs.shape == (n_t * 2 * 2 * bs, 5, 64)
+        assert ts.tolist() == [(T_ - t) * 1000 // T_ + 1 for t in (2, 4) for _ in range(2 * 2 * bs)]
+        assert torch.equal(cs[:bs].cpu(), table["a"].expand(bs, 5, 64)) and torch.equal(cs[bs:2 * bs].cpu(), table[""].expand(bs, 5, 64))
+        assert torch.equal(xs[:bs], xs[bs:2 * bs])                     # the same latent paired with c and with uc
+        # first entry == sampling until step 2 from the same noise
+        torch.manual_seed(11)
+        s = cls(m)
+        ref, _ = s.sample(S=T_, conditioning=m.get_learned_conditioning(bs * ["a"]), batch_size=bs, shape=[4, 8, 8], verbose=False,
+                          unconditional_guidance_scale=7.5, unconditional_conditioning=m.get_learned_conditioning(bs * [""]),
+                          untill_fake_t=2)
+        assert torch.equal(ref, xs[:bs])
+        assert torch.isfinite(xs).all()

@@ -22,13 +22,84 @@ def generate_cali_data_ddim(runnr, model, T: int, c: int, batch_size: int, shape
     return tuple(torch.cat([p[k] for p in tmp]) for k in range(2))
 
 
-def _ldm_only(name):
-    def fn(*a, **k):
-        raise TfmqError(f"{name}: latent-diffusion samplers are the next row (BASELINE configs 3-5)")
-    fn.__name__ = name
-    return fn
+def _real_time(T: int, t: int, ddpm_time_num: int = 1000) -> int:
+    """DDPM timestep the sampler would evaluate next after stopping at step t of T (reference :41-42,100-101)."""
+    return (T - t) * ddpm_time_num // T + 1
 
 
-generate_cali_data_ldm = _ldm_only("generate_cali_data_ldm")
-generate_cali_data_ldm_imagenet = _ldm_only("generate_cali_data_ldm_imagenet")
-generate_cali_text_guided_data = _ldm_only("generate_cali_text_guided_data")
+def _stack(tmp):
+    return tuple(torch.cat([p[k] for p in tmp]) for k in range(len(tmp[0])))
+
+
+def _is_ddim_like(sampler) -> bool:
+    from tfmq_dm_amd.ldm.ddim import DDIMSampler          # PLMSSampler derives from it
+    return isinstance(sampler, DDIMSampler) or sampler.__class__.__name__ in ("DDIMSampler", "PLMSSampler")
+
+
+def generate_cali_data_ldm(model, T: int, c: int, batch_size: int, shape: List[int], vanilla: bool = False,
+                           dpm: bool = False, plms: bool = False, eta: float = 0.0) -> Tuple[torch.Tensor]:
+    """reference :75-112 (unconditional LDMs): for every c-th step t, sample from fresh noise until step t with the
+    DDIM / PLMS sampler and keep (x_t, the DDPM timestep the next model call would see)."""
+    from tfmq_dm_amd.ldm.ddim import DDIMSampler, PLMSSampler
+    if vanilla:
+        raise NotImplementedError("Vanilla LDM is not implemented yet, because it needs 1000 steps to generate one sample.")
+    if dpm:
+        raise TfmqError("generate_cali_data_ldm: the DPM-Solver sampler is a next row (SURVEY §8f-1)")
+    sampler = PLMSSampler(model) if plms else DDIMSampler(model)
+    tmp = []
+    for t in range(1, T + 1):
+        if t % c == 0:
+            x_t, _ = sampler.sample(S=T, batch_size=batch_size, shape=shape, verbose=False, eta=eta, untill_fake_t=t)
+            t_t = torch.full((batch_size,), _real_time(T, t), device=sampler.model.betas.device, dtype=torch.long)
+            tmp.append((x_t, t_t))
+    return _stack(tmp)
+
+
+def generate_cali_data_ldm_imagenet(model, T: int, c: int, batch_size: int, shape: List[int], eta: float = 0.0,
+                                    scale: float = 3.0) -> Tuple[torch.Tensor]:
+    """reference :115-154 (class-conditional LDM, classifier-free guidance): 32 class labels x every c-th step; both the
+    conditional and the unconditional context of each sample enter the set.  `model` supplies the class embedder
+    (`get_learned_conditioning`, `cond_stage_key`, `ema_scope`): glue outside this package."""
+    from contextlib import nullcontext
+    from tfmq_dm_amd.ldm.ddim import DDIMSampler
+    sampler = DDIMSampler(model)
+    tmp = []
+    classes = [i for i in range(0, 1000, 1000 // 31)]
+    scope = model.ema_scope() if hasattr(model, "ema_scope") else nullcontext()
+    with torch.no_grad(), scope:
+        for i in range(1, T + 1):
+            if i % c == 0:
+                uc_t = model.get_learned_conditioning({model.cond_stage_key: torch.tensor(batch_size * [1000]).to(model.device)})
+                for class_label in classes:
+                    xc = torch.tensor(batch_size * [class_label])
+                    c_t = model.get_learned_conditioning({model.cond_stage_key: xc.to(model.device)})
+                    x_t, _ = sampler.sample(S=T, batch_size=batch_size, shape=shape, verbose=False, eta=eta,
+                                            unconditional_guidance_scale=scale, unconditional_conditioning=uc_t,
+                                            conditioning=c_t, untill_fake_t=i)
+                    t_t = torch.full((batch_size,), _real_time(T, i), device=sampler.model.betas.device, dtype=torch.long)
+                    tmp += [(x_t, t_t, c_t), (x_t, t_t, uc_t)]
+    return _stack(tmp)
+
+
+def generate_cali_text_guided_data(model, sampler, T: int, c: int, batch_size: int, prompts: Tuple[str], shape: List[int],
+                                   precision_scope=None) -> Tuple[torch.Tensor]:
+    """reference :13-49 (Stable Diffusion): for every c-th step and every prompt, CFG-7.5 sampling from fresh noise until
+    step t; (x_t, t, c) and (x_t, t, uc) both enter the set.  `model.get_learned_conditioning` is the text encoder
+    (glue outside this package); `precision_scope` is accepted for signature compatibility (the engine's precision is
+    fixed: int8 / f16 MFMA with fp32 accumulation)."""
+    tmp = []
+    if hasattr(model, "eval"):
+        model.eval()
+    with torch.no_grad():
+        for t in range(1, T + 1):
+            if t % c == 0:
+                for p in prompts:
+                    uc_t = model.get_learned_conditioning(batch_size * [""])
+                    c_t = model.get_learned_conditioning(batch_size * [p])
+                    x_t, t_t = sampler.sample(S=T, conditioning=c_t, batch_size=batch_size, shape=shape, verbose=False,
+                                              unconditional_guidance_scale=7.5, unconditional_conditioning=uc_t,
+                                              untill_fake_t=t)
+                    if _is_ddim_like(sampler):
+                        t_t = torch.full((batch_size,), _real_time(T, t), device=sampler.model.betas.device, dtype=torch.long)
+                    tmp += [(x_t, t_t, c_t), (x_t, t_t, uc_t)]
+    return _stack(tmp)
