@@ -188,8 +188,63 @@ def f12():
     save("f12_ldm_cali_tiny", **out)
 
 
+ATTN_UNET_KW = dict(image_size=8, in_channels=3, model_channels=32, out_channels=3, num_res_blocks=1,
+                    attention_resolutions=[1, 2], channel_mult=[1, 2], num_head_channels=16)
+
+
+def f13():
+    """Unconditional LDM family (CelebA-HQ / LSUN configs): UNetModel with plain AttentionBlocks (Conv1d qkv / proj_out,
+    QKVAttentionLegacy head layout), no context.  FP / w4 / w4a8 eps, quantizer tables, the tree-rewrite layer list
+    (QKMatMul / SMVMatMul seams become Quant*MatMul under leaf_param), a 4-step DDIM trajectory (eta 0)."""
+    from ldm.modules.diffusionmodules.openaimodel import UNetModel
+    from ldm.models.diffusion.ddim import DDIMSampler
+    from quant.quant_layer import QuantLayer
+    from quant.quant_block import BaseQuantBlock
+    torch.manual_seed(31)
+    m = UNetModel(**ATTN_UNET_KW).eval()
+    H.rerandomize_zero_params(m, seed=10)
+    out = sd_arrays(m)
+    g = torch.Generator().manual_seed(1313)
+    x = torch.randn(2, 3, 8, 8, generator=g)
+    t = torch.tensor([981, 21])
+    out.update(x=x, t=t)
+    with torch.no_grad():
+        out["eps_fp"] = m(x, t)
+    wq = {"bits": 4, "channel_wise": True, "scaler": Scaler.MSE}
+    aq = {"bits": 8, "channel_wise": False, "scaler": Scaler.MSE, "leaf_param": True}
+    qnn = QuantModel(m, wq, aq, aq_mode=[QMODE.NORMAL.value, QMODE.QDIFF.value]).eval()
+    out["quant_layer_names"] = np.array([n for n, mod in qnn.model.named_modules() if isinstance(mod, QuantLayer)])
+    out["quant_block_names"] = np.array([f"{n}:{type(mod).__name__}" for n, mod in qnn.model.named_modules()
+                                         if isinstance(mod, BaseQuantBlock)])
+    qnn.set_quant_state(True, False)
+    with torch.no_grad():
+        _ = qnn(x, t)
+    qnn.disable_out_quantization()
+    with torch.no_grad():
+        out["eps_w4"] = qnn(x, t)
+    qnn.set_quant_state(True, True)
+    with torch.no_grad():
+        _ = qnn(x, t)
+        out["eps_w4a8"] = qnn(x, t)
+    out.update(quant_tables(qnn))
+    ldm = FakeLDM(qnn, linear_start=0.0015, linear_end=0.0195)
+    ldm.apply_model = lambda xx, tt, cc: qnn(xx, tt)
+    sampler = DDIMSampler(ldm)
+    x_T = torch.randn(2, 3, 8, 8, generator=g)
+    out["traj_xT"] = x_T
+    samples, _ = sampler.sample(S=4, batch_size=2, shape=[3, 8, 8], verbose=False, eta=0.0, x_T=x_T)
+    out["traj_w4a8_final"] = samples
+    qnn.set_quant_state(False, False)
+    samples, _ = sampler.sample(S=4, batch_size=2, shape=[3, 8, 8], verbose=False, eta=0.0, x_T=x_T)
+    out["traj_fp_final"] = samples
+    out["alphas_cumprod"] = ldm.alphas_cumprod
+    save("f13_ldm_attnblock_tiny", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["f11", "f12"]
+    which = sys.argv[1:] or ["f11", "f12", "f13"]
+    if "f13" in which:
+        f13()
     if "f11" in which:
         main()
     if "f12" in which:

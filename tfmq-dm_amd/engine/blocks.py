@@ -34,7 +34,7 @@ def _collect(block: nn.Module, prefix: str = "blk"):
                 sd[full + ".weight"] = mod.original_w
                 if mod.original_b is not None:
                     sd[full + ".bias"] = mod.original_b
-        elif isinstance(mod, (nn.Conv2d, nn.Linear, nn.GroupNorm, nn.LayerNorm)):
+        elif isinstance(mod, (nn.Conv2d, nn.Conv1d, nn.Linear, nn.GroupNorm, nn.LayerNorm)):
             for pn, p in mod.named_parameters(recurse=False):
                 sd[f"{full}.{pn}"] = p.detach()
     return sd, wq, rows
@@ -83,3 +83,9 @@ def run_transformer_block(block, x: torch.Tensor, context: torch.Tensor) -> torc
     """QuantBasicTransformerBlock.forward (reference quant/quant_block.py:286-299): x [B,T,C] tokens, context [B,L,D]."""
     eng = _ldm_engine_for(block, x.device, dict(num_heads=block.attn1.heads))
     return eng._tblock("blk", x.float().contiguous(), context.float().contiguous())
+
+
+def run_attention_block(block, x: torch.Tensor) -> torch.Tensor:
+    """QuantAttentionBlock.forward (reference quant/quant_block.py:373-387): x NCHW."""
+    eng = _ldm_engine_for(block, x.device, dict(num_heads=block.num_heads))
+    return ops.nhwc_to_nchw(eng._attn_block("blk", ops.nchw_to_nhwc(x.float().contiguous())))

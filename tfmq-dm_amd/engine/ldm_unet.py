@@ -51,7 +51,21 @@ class LdmUNetEngine(DdimUNetEngine):
         for k, v in sd.items():
             if k.endswith(".weight") and v.dim() == 2 and not (k.startswith("time_embed") or ".emb_layers." in k):
                 v = v.reshape(v.shape[0], v.shape[1], 1, 1)
+            elif k.endswith(".weight") and v.dim() == 3:          # Conv1d of an AttentionBlock (kernel size 1)
+                v = v.reshape(v.shape[0], v.shape[1], 1, 1)
             sd2[k] = v
+        # AttentionBlock (QKVAttentionLegacy, openaimodel.py:372-405): the qkv projection's output channels are ordered
+        # (head, {q,k,v}, c).  Re-order its rows once to ({q,k,v}, head, c): q | k | v become column slices of one
+        # buffer, exactly the operand layout of the attention kernels.  Same mathematics.
+        for k in [k for k in sd2 if k.endswith(".qkv.weight")]:
+            Cc = sd2[k].shape[1]
+            nhc = cfg.get("num_head_channels", -1)
+            heads = cfg["num_heads"] if nhc in (-1, None) else Cc // nhc
+            d = Cc // heads
+            perm = torch.arange(3 * Cc).reshape(heads, 3, d).permute(1, 0, 2).reshape(-1).to(sd2[k].device)
+            sd2[k] = sd2[k][perm].contiguous()
+            if k[:-6] + "bias" in sd2:
+                sd2[k[:-6] + "bias"] = sd2[k[:-6] + "bias"][perm].contiguous()
         super().__init__(sd2, dict(cfg), device)
         self.res_names = ldm_resblock_paths(self.sd)
 
@@ -249,6 +263,20 @@ class LdmUNetEngine(DdimUNetEngine):
             return o
         return pout.run(h, residual=x)
 
+    def _attn_block(self, p, x):
+        """AttentionBlock._forward (openaimodel.py:317-326): un-quantised (Conv1d is not a QuantLayer type)."""
+        L = self.layers
+        B, H, W, Cc = x.shape
+        qkv_l, po = L[p + ".qkv"], L[p + ".proj_out"]
+        hn, _ = self._gn(p + ".norm", x, None, False, qkv_l, eps=1e-5)
+        qkv = qkv_l.run(hn, want_stats=False).reshape(B, H * W, 3 * Cc)
+        nhc = self.cfg.get("num_head_channels", -1)
+        heads = self.cfg["num_heads"] if nhc in (-1, None) else Cc // nhc
+        d = Cc // heads
+        # q*s . k*s with s = d^-1/4 (QKMatMul) == (q . k) * d^-1/2
+        o, _ = ops.attention(qkv[..., :Cc], qkv[..., Cc:2 * Cc], qkv[..., 2 * Cc:], heads, float(d ** -0.5))
+        return po.run(o.reshape(B, H, W, Cc), residual=x, want_stats=True)
+
     def _seq(self, p, h, skip, ctx, rowadd, taps):
         L = self.layers
         for j in range(_n_children(self.sd, p)):
@@ -260,6 +288,10 @@ class LdmUNetEngine(DdimUNetEngine):
                     taps[q] = ((hin, skip) if (j == 0 and skip is not None) else hin, h)
             elif (q + ".transformer_blocks.0.norm1.weight") in self.sd:
                 h = self._st(q, h, ctx, taps)
+                if taps is not None:
+                    taps[q] = (hin, h)
+            elif (q + ".qkv") in L:
+                h = self._attn_block(q, h)
                 if taps is not None:
                     taps[q] = (hin, h)
             elif (q + ".op") in L:
@@ -282,7 +314,7 @@ class LdmUNetEngine(DdimUNetEngine):
         """x: fp32 NHWC latents [B,H,W,C]; t: [B] timesteps (or None -> per-step TIB table); context: fp32 [B,L,D]."""
         if not self.prepared:
             raise TfmqError("LdmUNetEngine.forward before prepare()")
-        if context is None:
+        if context is None and any(k.endswith(".attn2.to_k.weight") for k in self.sd):
             raise TfmqError("LdmUNetEngine: SpatialTransformer UNets need a context tensor")
         L = self.layers
         if t is not None:
@@ -300,7 +332,7 @@ class LdmUNetEngine(DdimUNetEngine):
                 o = self.tib_off[p]
                 return dict(rowadd=self.tib_table[0, o:], rowadd_ld=0, rowadd_step=self.step,
                             rowadd_step_stride=self.tib_table.shape[1])
-        ctx = context.contiguous()
+        ctx = None if context is None else context.contiguous()
         hs = []
         h = x
         for i in range(_n_children(self.sd, "input_blocks")):

@@ -103,6 +103,47 @@ class SpatialTransformer(nn.Module):
         self.proj_out = nn.Conv2d(inner, in_channels, 1)
 
 
+class QKMatMul(nn.Module):
+    """Module seam of the reference (openaimodel.py:349-360): swapped for QuantQKMatMul by the tree rewrite."""
+
+    def __init__(self):
+        super().__init__()
+        self.scale = None
+
+
+class SMVMatMul(nn.Module):
+    pass
+
+
+class QKVAttentionLegacy(nn.Module):
+    """heads are split BEFORE q/k/v: channel (h, {q,k,v}, c) of the qkv projection (openaimodel.py:372-405)."""
+
+    def __init__(self, n_heads):
+        super().__init__()
+        self.n_heads = n_heads
+        self.qkv_matmul = QKMatMul()
+        self.smv_matmul = SMVMatMul()
+
+
+class AttentionBlock(nn.Module):
+    """Self-attention over the spatial positions (openaimodel.py:280-326): GroupNorm32 -> qkv Conv1d -> multi-head
+    attention -> proj_out Conv1d, + x.  Conv1d is not in QuantLayer.QMAP, so the block stays un-quantised."""
+
+    def __init__(self, channels, num_heads=1, num_head_channels=-1, use_checkpoint=False, use_new_attention_order=False):
+        super().__init__()
+        if use_new_attention_order:
+            raise TfmqError("AttentionBlock: use_new_attention_order is not set by any BASELINE config")
+        self.channels = channels
+        self.num_heads = num_heads if num_head_channels == -1 else channels // num_head_channels
+        if num_head_channels != -1 and channels % num_head_channels:
+            raise TfmqError(f"q,k,v channels {channels} is not divisible by num_head_channels {num_head_channels}")
+        self.use_checkpoint = use_checkpoint
+        self.norm = GroupNorm32(32, channels)
+        self.qkv = nn.Conv1d(channels, channels * 3, 1)
+        self.attention = QKVAttentionLegacy(self.num_heads)
+        self.proj_out = nn.Conv1d(channels, channels, 1)
+
+
 class UNetModel(nn.Module):
     """SpatialTransformer UNet (openaimodel.py:408-780), constructor arguments as in the YAML configs."""
 
@@ -111,13 +152,14 @@ class UNetModel(nn.Module):
                  num_heads=-1, num_head_channels=-1, use_spatial_transformer=True, transformer_depth=1, context_dim=None,
                  legacy=True, **unused):
         super().__init__()
-        if not use_spatial_transformer or context_dim is None:
-            raise TfmqError("only the SpatialTransformer (cross-attention) UNet is built so far (SD v1 / cin256 family)")
+        if use_spatial_transformer and context_dim is None:
+            raise TfmqError("UNetModel: the SpatialTransformer UNet needs context_dim")
         if num_classes is not None:
             raise TfmqError("class-conditional label embedding is not used by the SD config")
         self.image_size, self.in_channels, self.model_channels, self.out_channels = image_size, in_channels, model_channels, out_channels
         self.num_res_blocks, self.attention_resolutions, self.channel_mult = num_res_blocks, list(attention_resolutions), list(channel_mult)
         self.num_heads, self.num_head_channels, self.context_dim = num_heads, num_head_channels, context_dim
+        self.use_spatial_transformer = use_spatial_transformer
         ted = model_channels * 4
         self.time_embed = nn.Sequential(nn.Linear(model_channels, ted), nn.SiLU(), nn.Linear(ted, ted))
 
@@ -128,6 +170,11 @@ class UNetModel(nn.Module):
 
         def st(ch):
             nh, dh = heads_for(ch)
+            if not use_spatial_transformer:      # unconditional LDMs (CelebA-HQ, LSUN): plain AttentionBlock
+                return AttentionBlock(ch, use_checkpoint=use_checkpoint, num_heads=nh,
+                                      num_head_channels=num_head_channels if legacy else dh)
+            if legacy:
+                dh = ch // nh
             return SpatialTransformer(ch, nh, dh, depth=transformer_depth, context_dim=context_dim)
 
         self.input_blocks = nn.ModuleList([TimestepEmbedSequential(nn.Conv2d(in_channels, model_channels, 3, padding=1))])
@@ -162,7 +209,7 @@ class UNetModel(nn.Module):
 
     def engine_cfg(self) -> dict:
         return dict(model_channels=self.model_channels, num_heads=self.num_heads, in_channels=self.in_channels,
-                    out_channels=self.out_channels, context_dim=self.context_dim)
+                    out_channels=self.out_channels, context_dim=self.context_dim, num_head_channels=self.num_head_channels)
 
     def forward(self, x, timesteps=None, context=None, y=None, **kw):
         from .. import ops
@@ -173,7 +220,7 @@ class UNetModel(nn.Module):
             self._engine = LdmUNetEngine(self.state_dict(), self.engine_cfg(), x.device)
             self._engine.prepare()
         eps = self._engine.forward(ops.nchw_to_nhwc(x.float().contiguous()), timesteps.float().contiguous(),
-                                   context.float().contiguous())
+                                   None if context is None else context.float().contiguous())
         return ops.nhwc_to_nchw(eps)
 
 

@@ -7,8 +7,8 @@ block's own `forward` (used when a unit is evaluated in isolation, e.g. by save_
 block_reconstruction) runs the corresponding fused engine routine.
 
 DDPM-UNet blocks (BASELINE configs 1-2) and the SpatialTransformer-UNet blocks of Stable Diffusion
-(QuantResBlock, QuantBasicTransformerBlock, QuantTemporalInformationBlock; config 3) are implemented;
-QuantAttentionBlock / QuantQKMatMul / QuantSMVMatMul (AttentionBlock LDMs) are declared and raise.
+(QuantResBlock, QuantBasicTransformerBlock, QuantTemporalInformationBlock) and the AttentionBlock seams of the
+unconditional LDMs (QuantAttentionBlock, QuantQKMatMul, QuantSMVMatMul) are implemented.
 """
 from __future__ import annotations
 
@@ -189,18 +189,48 @@ class QuantBasicTransformerBlock(BaseQuantBlock):
         return run_transformer_block(self, x, context)
 
 
-def _ldm_block(name):
-    class _Pending(BaseQuantBlock):
-        def __init__(self, *a, **k):
-            raise TfmqError(f"{name}: only needed by the AttentionBlock (non-SpatialTransformer) LDMs, a next row "
-                            "(DESIGN.md 'what comes next')")
-    _Pending.__name__ = name
-    return _Pending
+class QuantQKMatMul(BaseQuantBlock):
+    """reference :303-328: the q.k^T seam of QKVAttentionLegacy.  Carries the (never enabled) q/k quantizers; holds no
+    QuantLayer, so block reconstruction returns immediately.  Executed inside the engine's attention kernel."""
+
+    def __init__(self, aq_params: dict = {}) -> None:
+        super().__init__(aq_params)
+        self.scale = None
+        self.use_aq = False
+        self.aqtizer_q = UniformAffineQuantizer(**aq_params)
+        self.aqtizer_k = UniformAffineQuantizer(**aq_params)
+
+    def forward(self, q, k):
+        raise TfmqError("QuantQKMatMul: the attention matmuls run inside the engine's attention kernel, not module by module")
 
 
-QuantAttentionBlock = _ldm_block("QuantAttentionBlock")
-QuantQKMatMul = _ldm_block("QuantQKMatMul")
-QuantSMVMatMul = _ldm_block("QuantSMVMatMul")
+class QuantSMVMatMul(BaseQuantBlock):
+    """reference :331-354: the softmax.v seam (8-bit `always_zero` softmax quantizer, never enabled)."""
+
+    def __init__(self, aq_params: dict = {}, softmax_a_bit: int = 8) -> None:
+        super().__init__(aq_params)
+        self.use_aq = False
+        self.aqtizer_v = UniformAffineQuantizer(**aq_params)
+        aq_w = dict(aq_params)
+        aq_w.update(bits=softmax_a_bit, symmetric=False, always_zero=True)
+        self.aqtizer_w = UniformAffineQuantizer(**aq_w)
+
+    def forward(self, weight, v):
+        raise TfmqError("QuantSMVMatMul: the attention matmuls run inside the engine's attention kernel, not module by module")
+
+
+class QuantAttentionBlock(BaseQuantBlock):
+    """reference :357-387 (weight-only runs, `leaf_param` False): re-hosts the AttentionBlock.  Its Conv1d projections
+    are not QuantLayers, so the block has nothing to reconstruct."""
+
+    def __init__(self, attn: nn.Module, aq_params: dict = {}) -> None:
+        super().__init__(aq_params)
+        self.channels, self.num_heads, self.use_checkpoint = attn.channels, attn.num_heads, attn.use_checkpoint
+        self.norm, self.qkv, self.attention, self.proj_out = attn.norm, attn.qkv, attn.attention, attn.proj_out
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        from tfmq_dm_amd.engine.blocks import run_attention_block
+        return run_attention_block(self, x)
 
 
 def b2qb(use_aq: bool = False) -> Dict[str, type]:

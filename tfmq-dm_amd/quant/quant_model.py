@@ -168,7 +168,7 @@ class QuantModel(nn.Module):
                     sd[n + ".weight"] = mod.original_w
                     if mod.original_b is not None:
                         sd[n + ".bias"] = mod.original_b
-            elif isinstance(mod, (nn.Conv2d, nn.Linear, nn.GroupNorm, nn.LayerNorm)):
+            elif isinstance(mod, (nn.Conv2d, nn.Conv1d, nn.Linear, nn.GroupNorm, nn.LayerNorm)):
                 for pn, p in mod.named_parameters(recurse=False):
                     sd[f"{n}.{pn}"] = p.detach()
         eng = engine_cls(sd, self.model.engine_cfg(), device)

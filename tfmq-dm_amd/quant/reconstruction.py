@@ -97,6 +97,8 @@ def block_reconstruction(model, block: BaseQuantBlock, cali_data: torch.Tensor, 
         raise NotImplementedError("delta-learning reconstruction (use_aq=True) is never requested by the drivers (SURVEY §8f-3)")
     model.set_quant_state(use_wq=False, use_aq=False)
     block.set_quant_state(use_wq=True, use_aq=use_aq)
+    if not any(isinstance(m, QuantLayer) and not m.quant_emb for m in block.modules()):
+        return      # QuantAttentionBlock / QuantQKMatMul / QuantSMVMatMul: nothing to optimise (reference :130-131)
     loss_func = LossFunc(o=block, round_loss=RLOSS.RELAXATION, w=w, max_count=iters, rec_loss=opt_mode, b_range=b_range,
                          decay_start=0.0, warmup=warmup, p=p)
     dev = next(block.parameters()).device
