@@ -24,6 +24,8 @@ struct GemmP {
   int accumulate;                    // C += result
 };
 
+int tfmq_gemm_f32_mfma_launch(const void* p, int M, int N, int batch, hipStream_t st);   // gemm_f32_mfma.hip (same GemmP)
+
 #define GT 64
 #define GK 16
 __global__ __launch_bounds__(256) void k_gemm_f32(GemmP p) {
@@ -95,6 +97,11 @@ extern "C" int tfmq_gemm_f32(tfmq_handle h, const float* A, const float* B, floa
   TFMQ_CHECK_ARG(h, !rowadd || rows_per_img > 0, "gemm_f32: rowadd needs rows_per_img");
   GemmP p{A, B, C, M, N, K, sam, sak, sbk, sbn, scm, bsa, bsb, bsc, alpha, bias, rowadd, rows_per_img, rowadd_ld, residual,
           accumulate};
+  if (M >= 96 && N >= 24 && K >= 8) {     // fp32 matrix cores (gemm_f32_mfma.hip); small problems keep the FMA tile
+    tfmq_gemm_f32_mfma_launch(&p, M, N, batch, as_stream(stream));
+    TFMQ_LAUNCH_CHECK(h);
+    return TFMQ_OK;
+  }
   dim3 grid((N + GT - 1) / GT, (M + GT - 1) / GT, batch);
   hipLaunchKernelGGL(k_gemm_f32, grid, dim3(256), 0, as_stream(stream), p);
   TFMQ_LAUNCH_CHECK(h);
