@@ -208,6 +208,56 @@ def setup_sd(args, dev, rank, log):
     return run, fwd, cpu, info
 
 
+def calibration_sample(dev):
+    """Second half of BASELINE.json's metric ("... + calibration wall-clock"): milliseconds per AdaRound iteration of
+    SD-v1-size reconstruction units (the reference's single-GPU SD setting: mini-batch 8), measured on a bounded sample
+    (3 timed iterations per unit, synthetic cached inputs), and the wall-clock those rates imply for the block
+    reconstructions of the whole UNet at the recipe's 20 000 iterations per unit (16 ResBlocks + 16 transformer blocks
+    with at least these sizes' cost classes; layer units, TIB and activation calibration are minutes and left out)."""
+    import tfmq_dm_amd.ops as ops
+    from tfmq_dm_amd.engine import recon as R
+    gen = torch.Generator().manual_seed(0)
+
+    def ada(cout, cin, k=1, bias=True):
+        shape = (cout, cin, k, k) if k > 1 else (cout, cin)
+        w = (torch.randn(*shape, generator=gen) * 0.05).to(dev)
+        qp = ops.minmax_to_qparam(ops.minmax(w.reshape(cout, -1).contiguous(), cout), 16)
+        return R.AdaLayer(w, qp[:, 0].contiguous(), qp[:, 1].contiguous(), torch.zeros(cout, device=dev) if bias else None)
+
+    def timeit(unit, bs, iters=3):
+        idx = torch.arange(bs, device=dev)
+        unit.iterate(idx)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            unit.iterate(idx)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / iters * 1e3
+    res = {}
+    hours = 0.0
+    # (channels, resolution, #ResBlocks, #transformer blocks) of SD v1: input + output path per level; middle at 8x8
+    for Cc, HW, n_res, n_tb in ((320, 64, 5, 5), (640, 32, 5, 5), (1280, 16, 5, 5), (1280, 8, 7, 1)):
+        N = 8
+        x = torch.randn(N, HW, HW, Cc, device=dev)
+        y = torch.randn(N, HW, HW, Cc, device=dev)
+        gn = (torch.ones(Cc, device=dev), torch.zeros(Cc, device=dev))
+        ru = R.ResnetUnit(ada(Cc, Cc, 3), ada(Cc, Cc, 3), gn, gn, None, x, torch.randn(N, Cc, device=dev), y, eps=1e-5, iters=100)
+        ms_r = timeit(ru, N)
+        layers = [ada(Cc, Cc, 1, False), ada(Cc, Cc, 1, False), ada(Cc, Cc, 1, False), ada(Cc, Cc), ada(8 * Cc, Cc), ada(Cc, 4 * Cc),
+                  ada(Cc, Cc, 1, False), ada(Cc, 768, 1, False), ada(Cc, 768, 1, False), ada(Cc, Cc)]
+        tu = R.TransformerUnit(layers, [gn, gn, gn], 8, x.reshape(N, HW * HW, Cc), torch.randn(N, 77, 768, device=dev),
+                               y.reshape(N, HW * HW, Cc), iters=100)
+        ms_t = timeit(tu, N)
+        res[f"resblock_{Cc}ch_{HW}x{HW}_ms_per_iter"] = round(ms_r, 2)
+        res[f"transformer_{Cc}ch_{HW}x{HW}_ms_per_iter"] = round(ms_t, 2)
+        hours += (n_res * ms_r + n_tb * ms_t) * 20000 / 3.6e6
+        del ru, tu, layers, x, y
+        torch.cuda.empty_cache()
+    res["projected_block_reconstruction_hours_1gpu"] = round(hours, 2)
+    res["recipe"] = "AdaRound block reconstruction, 20000 iterations/unit, mini-batch 8, fp32 MFMA GEMMs (K15)"
+    return res
+
+
 def conv_roofline(fwd, stream, n_fwd=2):
     """Per-launch HIP-event timing (on the launch stream) of every w4a8 GEMM launch of UNet forwards."""
     import tfmq_dm_amd.ops as ops
@@ -310,6 +360,9 @@ def main():
             v, sample = cpu()
             cpu_b = {"value": round(v, 5), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
                      "sample": "oracle (torch-CPU fake-quant UNet, same weights / act tables): " + sample}
+        cali = None
+        if world == 1 and args.workload == "sd" and not args.no_cpu_baseline:
+            cali = calibration_sample(dev)
         cfgd = {"workload": info["workload"], "parallelism": f"replicas x{world} (no data-path collective)"}
         cfgd.update(info["extra"])
         out = {
@@ -319,7 +372,7 @@ def main():
             "vs_baseline": None,
             "dtype": "int8 (u8 activation bins x int4 weights, int32 accumulate; f16 MFMA for un-quantised layers / attention, fp32 residual stream)",
             "data": "synthetic: N(0,1) latents / context, random-init weights (zero params re-drawn N(0,0.02^2)), synthetic FSC tables",
-            "config": cfgd, "finite": finite, "roofline": roof, "cpu_baseline": cpu_b,
+            "config": cfgd, "finite": finite, "roofline": roof, "cpu_baseline": cpu_b, "calibration": cali,
         }
         print(json.dumps(out), flush=True)
     if dist is not None:
