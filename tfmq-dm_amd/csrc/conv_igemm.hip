@@ -348,10 +348,8 @@ __global__ __launch_bounds__(256, 3) void k_conv_dma(ConvP p) {
   const int tile_n = bid % p.tiles_n, tile_m = bid / p.tiles_n;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
 
+  // two dependent global loads (step counter -> table row): issued first, consumed after the offset table is built
   const float2 aqp = load_qparam(d.aq);
-  const int za = static_cast<int>(aqp.y);
-  // real zero == bin za  ->  stored byte za-128; its 64-byte row in the pad table feeds the padded taps
-  const unsigned char* padp = p.pad_table + (static_cast<unsigned>(za - 128) & 0xffu) * 64;
 
   // ---- pixel offset table (any stride / padding / fused 2x upsample)
   {
@@ -403,6 +401,9 @@ __global__ __launch_bounds__(256, 3) void k_conv_dma(ConvP p) {
     b_dst[it] = __builtin_amdgcn_readfirstlane(BM * 64 + piece * 1024);
   }
   __syncthreads();  // tab visible
+  const int za = static_cast<int>(aqp.y);
+  // real zero == bin za  ->  stored byte za-128; its 64-byte row in the pad table feeds the padded taps
+  const unsigned char* padp = p.pad_table + (static_cast<unsigned>(za - 128) & 0xffu) * 64;
 
   int i_tap = 0, i_chunk = 0;
   auto issue = [&](int s, int stage) {
