@@ -162,7 +162,10 @@ typedef struct tfmq_conv_desc {
                                     fp16 yt[b][n - t_col0][t], t = ho*Wo + wo (instead of into y): the V^T operand of
                                     tfmq_attention_f16 straight from the fused q|k|v projection */
   int32_t t_col0;                /* multiple of 128; Ho*Wo % 4 == 0 required */
-  int32_t pad0_;
+  int32_t x_f16;                 /* tfmq_conv2d_f16 only: x is fp16 NHWC (written as fp16 by its producer, e.g.
+                                    tfmq_gn_desc.half_out): operands go global -> LDS by DMA like the w4a8 path.
+                                    Needs Cin % 32 == 0 and KH*KW <= 9; bit-identical to the fp32-input path, which
+                                    rounds x to fp16 while staging */
 } tfmq_conv_desc;
 enum { TFMQ_OUT_F32 = 0, TFMQ_OUT_F16 = 1, TFMQ_OUT_GEGLU_Q8 = 2 };
 int tfmq_conv2d_w4a8(tfmq_handle h, const tfmq_conv_desc* d, void* stream);
@@ -196,7 +199,10 @@ typedef struct tfmq_gn_desc {
   tfmq_qsel aq;            /* qtable!=NULL: write int8 (bin-128) to yq; else write fp32 to yf */
   int8_t* yq;
   float* yf;
-  float* xcat_or_null;     /* optional: also materialise the fp32 concat (input of the FP nin_shortcut) */
+  float* xcat_or_null;     /* optional: also materialise the concat (input of the FP nin_shortcut / skip_connection) */
+  int32_t half_out;        /* !=0: yf and xcat_or_null are fp16 buffers (consumers that round to fp16 anyway:
+                              tfmq_conv2d_f16 with x_f16) */
+  int32_t pad0_;
 } tfmq_gn_desc;
 int tfmq_groupnorm(tfmq_handle h, const tfmq_gn_desc* d, void* stream);
 /* same result when the producing conv(s) already emitted the statistics (tfmq_conv_desc.stats, segment size
@@ -245,6 +251,8 @@ int tfmq_cfg_combine(tfmq_handle h, const float* eps_u, const float* eps_c, floa
 int tfmq_plms_combine(tfmq_handle h, int order, const float* e0, const float* e1, const float* e2_or_null,
                       const float* e3_or_null, float* out, size_t n, void* stream);
 int tfmq_step_advance(tfmq_handle h, int32_t* step, int delta, void* stream);
+/* fp32 -> fp16 copy (round to nearest even): operand of tfmq_conv2d_f16 with x_f16 when the producer writes fp32 */
+int tfmq_f32_to_f16(tfmq_handle h, const float* x, uint16_t* y, size_t n, void* stream);
 /* y = x*sigmoid(x)  (nonlinearity, ddim/models/diffusion.py:27-29) */
 int tfmq_silu(tfmq_handle h, const float* x, float* y, size_t n, void* stream);
 int tfmq_nchw_to_nhwc(tfmq_handle h, const float* x, float* y, int B, int C, int HW, void* stream);

@@ -75,3 +75,51 @@ def test_geglu_epilogue_bit_exact(ops, B, T, cin, inner):
     ref_bins = O.quant_index(a * F.gelu(g), od, oz, 256)
     diff = (got.reshape(B, T, inner).cpu().float() + 128 - ref_bins).abs()
     assert diff.max() <= 1 and (diff > 0).float().mean() < 2e-3
+
+
+@pytest.mark.parametrize("B,H,W,cin,cout,k,stride,pad", [
+    (2, 16, 16, 128, 96, 1, 1, (0, 0, 0, 0)),       # skip_connection / nin_shortcut
+    (2, 17, 17, 64, 64, 3, 2, (1, 1, 1, 1)),        # Downsample.op: stride 2, ragged
+    (1, 8, 8, 320, 4, 3, 1, (1, 1, 1, 1)),          # out.2: narrow Cout
+    (3, 8, 8, 2560, 1280, 1, 1, (0, 0, 0, 0)),      # widest SD skip conv, 64x64 tiles
+])
+def test_f16_input_conv_is_bit_identical_to_fp32_input(ops, B, H, W, cin, cout, k, stride, pad):
+    """tfmq_conv_desc.x_f16: the un-quantised convs on fp16 activations (LDS-DMA pipeline) -- the fp32-input path rounds
+    its input to fp16 while staging, so both paths multiply the same operands in the same order."""
+    gen = torch.Generator().manual_seed(cin + cout)
+    x = torch.randn(B, H, W, cin, generator=gen).to(DEV)
+    w = torch.randn(cout, cin, k, k, generator=gen) * (1.0 / (cin * k * k) ** 0.5)
+    b = torch.randn(cout, generator=gen) * 0.1
+    pf = ops.pack_w_f16(w.to(DEV), b.to(DEV))
+    assert ops.f16_dma_ok(cin, k, k)
+    y32 = ops.conv2d_f16(x, pf, stride=stride, pad=pad)
+    xh = ops.to_half(x)
+    assert torch.equal(xh, x.half())
+    y16 = ops.conv2d_f16(xh, pf, stride=stride, pad=pad)
+    assert torch.equal(y16, y32)
+    res = torch.randn(y32.shape, generator=gen).to(DEV)
+    assert torch.equal(ops.conv2d_f16(xh, pf, stride=stride, pad=pad, residual=res), ops.conv2d_f16(x, pf, stride=stride, pad=pad, residual=res))
+
+
+def test_groupnorm_half_outputs(ops):
+    gen = torch.Generator().manual_seed(2)
+    x1 = torch.randn(2, 8, 8, 64, generator=gen).to(DEV)
+    x2 = torch.randn(2, 8, 8, 32, generator=gen).to(DEV)
+    gm, bt = torch.randn(96, generator=gen).to(DEV), torch.randn(96, generator=gen).to(DEV)
+    _, yf, xc = ops.groupnorm(x1, gm, bt, 1e-5, True, None, x2=x2, want_cat=True)
+    _, yh, xh = ops.groupnorm(x1, gm, bt, 1e-5, True, None, x2=x2, want_cat=True, half_out=True)
+    assert yh.dtype == torch.float16 and xh.dtype == torch.float16
+    assert torch.equal(yh, yf.half()) and torch.equal(xh, xc.half()) and torch.equal(xc, torch.cat([x1, x2], -1))
+    # split form (statistics from the producing conv's epilogue)
+    qt = torch.tensor([[0.05, 120.0]], device=DEV)
+    sel = ops.qsel(qt)
+    xq = (torch.randn(2, 8, 8, 64, generator=gen) * 30).clamp(-128, 127).to(torch.int8).to(DEV)
+    w = torch.randn(64, 64, 3, 3, generator=gen) * 0.05
+    qp = ops.minmax_to_qparam(ops.minmax(w.to(DEV), 64), 16)
+    pw = ops.pack_w4(w.to(DEV), qp[:, 0].contiguous(), qp[:, 1].contiguous(), bias=torch.zeros(64, device=DEV))
+    y = ops.conv2d_w4a8(xq, pw, sel, pad=(1, 1, 1, 1), want_stats=True)
+    assert getattr(y, "_tfmq_stats", None) is not None
+    g2, b2 = torch.randn(64, generator=gen).to(DEV), torch.randn(64, generator=gen).to(DEV)
+    yq_a, _, xc_a = ops.groupnorm(y, g2, b2, 1e-5, True, sel, want_cat=True)
+    yq_b, _, xc_b = ops.groupnorm(y, g2, b2, 1e-5, True, sel, want_cat=True, half_out=True)
+    assert torch.equal(yq_a, yq_b) and torch.equal(xc_b, xc_a.half())

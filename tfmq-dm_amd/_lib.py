@@ -38,7 +38,7 @@ class ConvDesc(C.Structure):
         ("residual", c_void_p), ("y", c_void_p),
         ("ldy", C.c_int32), ("y_coff", C.c_int32),
         ("stats", c_void_p), ("stats_seg", C.c_int32), ("out_mode", C.c_int32),
-        ("oq", QSel), ("yq", c_void_p), ("yt", c_void_p), ("t_col0", C.c_int32), ("pad0_", C.c_int32),
+        ("oq", QSel), ("yq", c_void_p), ("yt", c_void_p), ("t_col0", C.c_int32), ("x_f16", C.c_int32),
     ]
 
 
@@ -50,6 +50,7 @@ class GnDesc(C.Structure):
         ("eps", c_float), ("groups", C.c_int32), ("silu", C.c_int32),
         ("aq", QSel),
         ("yq", c_void_p), ("yf", c_void_p), ("xcat", c_void_p),
+        ("half_out", C.c_int32), ("pad0_", C.c_int32),
     ]
 
 
@@ -90,6 +91,7 @@ _SIGS = {
     "tfmq_ddim_update_cfg": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_size_t,
                                      c_void_p, c_void_p, c_void_p]),
     "tfmq_step_advance": (c_int, [c_void_p, c_void_p, c_int, c_void_p]),
+    "tfmq_f32_to_f16": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "tfmq_silu": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "tfmq_nchw_to_nhwc": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "tfmq_nhwc_to_nchw": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),

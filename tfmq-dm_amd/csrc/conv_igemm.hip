@@ -320,9 +320,11 @@ __device__ __forceinline__ int xcd_tile_id() {
 }
 
 // ================================================================================================
-// w4a8 main path: LDS-DMA pipeline
+// main path: LDS-DMA pipeline.  F16 = false: w4a8 (int8 operands, 64 channels per K-step, i8 MFMA);
+// F16 = true: un-quantised layers on fp16 operands (fp16 NHWC activations written by the producing kernel, 32
+// channels per K-step, f16 MFMA, fp32 accumulation) -- the same 64-byte rows, swizzle and pipeline.
 // ================================================================================================
-template <int WAVES_M, int WAVES_N, int WM_TILES, int WN_TILES>
+template <bool F16, int WAVES_M, int WAVES_N, int WM_TILES, int WN_TILES>
 __global__ __launch_bounds__(256, 3) void k_conv_dma(ConvP p) {
   constexpr int BM = WAVES_M * WM_TILES * 32;
   constexpr int BN = WAVES_N * WN_TILES * 32;
@@ -349,7 +351,8 @@ __global__ __launch_bounds__(256, 3) void k_conv_dma(ConvP p) {
   const int m0 = tile_m * BM, n0 = tile_n * BN;
 
   // two dependent global loads (step counter -> table row): issued first, consumed after the offset table is built
-  const float2 aqp = load_qparam(d.aq);
+  float2 aqp = make_float2(1.0f, 0.0f);
+  if constexpr (!F16) aqp = load_qparam(d.aq);
 
   // ---- pixel offset table (any stride / padding / fused 2x upsample)
   {
@@ -368,7 +371,7 @@ __global__ __launch_bounds__(256, 3) void k_conv_dma(ConvP p) {
             hi >>= 1;
             wi >>= 1;
           }
-          off = ((b * d.H + hi) * d.W + wi) * d.Cin;  // < 2^31, checked by the launcher
+          off = ((b * d.H + hi) * d.W + wi) * d.Cin * (F16 ? 2 : 1);  // bytes; < 2^31, checked by the launcher
         }
       }
       tab[idx] = off;
@@ -395,15 +398,22 @@ __global__ __launch_bounds__(256, 3) void k_conv_dma(ConvP p) {
     const int piece = BN >= 64 ? wid * B_CH + it : (wid & 1);
     const int row = piece * 16 + (lane >> 2);
     int n = n0 + row;
-    n = n < p.cout_pad ? n : p.cout_pad - 1;
-    b_ptr[it] = static_cast<const unsigned char*>(d.w) +
-                (static_cast<size_t>(n / 32) * p.nsteps * 32 + (n % 32)) * 64 + ((lane & 3) ^ ((row >> 2) & 3)) * 16;
+    if constexpr (F16) {       // fp16 weights [cout][tap][cin] row-major (tfmq_pack_w_f16; cin % 32 == 0 here)
+      n = n < d.Cout ? n : d.Cout - 1;
+      b_ptr[it] = static_cast<const unsigned char*>(d.w) + static_cast<size_t>(n) * (d.KH * d.KW) * p.cin_pad * 2 +
+                  ((lane & 3) ^ ((row >> 2) & 3)) * 16;
+    } else {
+      n = n < p.cout_pad ? n : p.cout_pad - 1;
+      b_ptr[it] = static_cast<const unsigned char*>(d.w) +
+                  (static_cast<size_t>(n / 32) * p.nsteps * 32 + (n % 32)) * 64 + ((lane & 3) ^ ((row >> 2) & 3)) * 16;
+    }
     b_dst[it] = __builtin_amdgcn_readfirstlane(BM * 64 + piece * 1024);
   }
   __syncthreads();  // tab visible
   const int za = static_cast<int>(aqp.y);
   // real zero == bin za  ->  stored byte za-128; its 64-byte row in the pad table feeds the padded taps
-  const unsigned char* padp = p.pad_table + (static_cast<unsigned>(za - 128) & 0xffu) * 64;
+  // (fp16 operands: row 0 = zeros)
+  const unsigned char* padp = p.pad_table + (F16 ? 0u : (static_cast<unsigned>(za - 128) & 0xffu)) * 64;
 
   int i_tap = 0, i_chunk = 0;
   auto issue = [&](int s, int stage) {
@@ -419,15 +429,17 @@ __global__ __launch_bounds__(256, 3) void k_conv_dma(ConvP p) {
                                                 : padp + a_col[it];
       glds16(src, sbase + a_dst[it]);
     }
+    const size_t b_off = F16 ? static_cast<size_t>(i_tap * p.cin_pad + i_chunk * 32) * 2 : static_cast<size_t>(s) * 2048;
 #pragma unroll
-    for (int it = 0; it < B_CH; ++it) glds16(b_ptr[it] + static_cast<size_t>(s) * 2048, sbase + b_dst[it]);
+    for (int it = 0; it < B_CH; ++it) glds16(b_ptr[it] + b_off, sbase + b_dst[it]);
     if (++i_chunk == p.chunks) {
       i_chunk = 0;
       ++i_tap;
     }
   };
 
-  v16i acc[WM_TILES][WN_TILES];
+  using acc_t = typename std::conditional<F16, v16f, v16i>::type;
+  acc_t acc[WM_TILES][WN_TILES];
 #pragma unroll
   for (int i = 0; i < WM_TILES; ++i)
 #pragma unroll
@@ -451,8 +463,13 @@ __global__ __launch_bounds__(256, 3) void k_conv_dma(ConvP p) {
 #pragma unroll
       for (int i = 0; i < WM_TILES; ++i)
 #pragma unroll
-        for (int j = 0; j < WN_TILES; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[i], bf[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < WN_TILES; ++j) {
+          if constexpr (F16)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<v8h*>(&af[i]), *reinterpret_cast<v8h*>(&bf[j]),
+                                                               acc[i][j], 0, 0, 0);
+          else
+            acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
     }
   };
 
@@ -475,7 +492,7 @@ __global__ __launch_bounds__(256, 3) void k_conv_dma(ConvP p) {
   }
 
   TFMQ_MARK(2);
-  conv_epilogue<true, WAVES_M, WAVES_N, WM_TILES, WN_TILES>(p, lds, acc, m0, n0, aqp, za);
+  conv_epilogue<!F16, WAVES_M, WAVES_N, WM_TILES, WN_TILES>(p, lds, acc, m0, n0, aqp, za);
   TFMQ_MARK(3);
 }
 
@@ -797,9 +814,9 @@ static int launch_conv(tfmq_handle h, const tfmq_conv_desc* dd, void* stream) {
       if (!dbuf) (void)hipMalloc(reinterpret_cast<void**>(&dbuf), sizeof(unsigned long long) * 4 * (1u << 20));
       p.dbg = grid.x <= (1u << 20) ? dbuf : nullptr;
 #endif
-      if (narrow) hipLaunchKernelGGL((k_conv_dma<4, 1, 1, 1>), grid, dim3(256), 0, st, p);
-      else if (small) hipLaunchKernelGGL((k_conv_dma<2, 2, 1, 1>), grid, dim3(256), 0, st, p);
-      else hipLaunchKernelGGL((k_conv_dma<2, 2, 2, 2>), grid, dim3(256), 0, st, p);
+      if (narrow) hipLaunchKernelGGL((k_conv_dma<false, 4, 1, 1, 1>), grid, dim3(256), 0, st, p);
+      else if (small) hipLaunchKernelGGL((k_conv_dma<false, 2, 2, 1, 1>), grid, dim3(256), 0, st, p);
+      else hipLaunchKernelGGL((k_conv_dma<false, 2, 2, 2, 2>), grid, dim3(256), 0, st, p);
 #ifdef TFMQ_PHASE_TIMERS
       if (p.dbg && getenv("TFMQ_PHASE_PRINT")) {
         (void)hipStreamSynchronize(st);
@@ -826,6 +843,14 @@ static int launch_conv(tfmq_handle h, const tfmq_conv_desc* dd, void* stream) {
       else { if (k32) TFMQ_LAUNCH(32, 2, 2, 2, 2); else TFMQ_LAUNCH(64, 2, 2, 2, 2); }
 #undef TFMQ_LAUNCH
     }
+  } else if (d.x_f16) {
+    // fp16 activations (written as fp16 by the producer): LDS-DMA pipeline, any stride / padding / upsample
+    TFMQ_CHECK_ARG(h, d.Cin % 32 == 0 && d.KH * d.KW <= 9 &&
+                          static_cast<size_t>(d.B) * d.H * d.W * d.Cin * 2 < (static_cast<size_t>(1) << 31),
+                   "conv_f16: fp16 input needs Cin % 32 == 0, <= 9 taps and < 2 GiB of input");
+    if (narrow) hipLaunchKernelGGL((k_conv_dma<true, 4, 1, 1, 1>), grid, dim3(256), 0, st, p);
+    else if (small) hipLaunchKernelGGL((k_conv_dma<true, 2, 2, 1, 1>), grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((k_conv_dma<true, 2, 2, 2, 2>), grid, dim3(256), 0, st, p);
   } else {
     // fast addressing: stride 1, no fused upsample, whole K-steps, <= 32 taps, 16-byte aligned rows
     const bool fast = d.stride == 1 && !d.up2x && d.KH * d.KW <= 32 && d.Cin % 32 == 0;

@@ -40,8 +40,14 @@ __device__ __forceinline__ void gn_apply_store(const GnP& p, size_t o, const flo
                                                const float (&gb)[V], bool quant, float2 qp) {
   const tfmq_gn_desc& d = p.d;
   if (d.xcat_or_null) {
+    if (d.half_out) {
+      __half* xh = reinterpret_cast<__half*>(d.xcat_or_null);
 #pragma unroll
-    for (int i = 0; i < V; ++i) d.xcat_or_null[o + i] = v[i];
+      for (int i = 0; i < V; ++i) xh[o + i] = __float2half_rn(v[i]);
+    } else {
+#pragma unroll
+      for (int i = 0; i < V; ++i) d.xcat_or_null[o + i] = v[i];
+    }
   }
   float y[V];
 #pragma unroll
@@ -63,8 +69,14 @@ __device__ __forceinline__ void gn_apply_store(const GnP& p, size_t o, const flo
     }
   }
   if (d.yf) {
+    if (d.half_out) {
+      __half* yh = reinterpret_cast<__half*>(d.yf);
 #pragma unroll
-    for (int i = 0; i < V; ++i) d.yf[o + i] = y[i];
+      for (int i = 0; i < V; ++i) yh[o + i] = __float2half_rn(y[i]);
+    } else {
+#pragma unroll
+      for (int i = 0; i < V; ++i) d.yf[o + i] = y[i];
+    }
   }
 }
 
@@ -277,7 +289,11 @@ __global__ __launch_bounds__(256) void k_gn_apply(tfmq_gn_desc d, const float* _
       if (d.silu) y[q] = silu_f(y[q]);
     }
     if (d.xcat_or_null) {
-      if constexpr (V == 4) *reinterpret_cast<float4*>(d.xcat_or_null + o) = make_float4(v[0], v[1], v[2], v[3]);
+      if (d.half_out) {
+        __half* xh = reinterpret_cast<__half*>(d.xcat_or_null);
+#pragma unroll
+        for (int q = 0; q < V; ++q) xh[o + q] = __float2half_rn(v[q]);
+      } else if constexpr (V == 4) *reinterpret_cast<float4*>(d.xcat_or_null + o) = make_float4(v[0], v[1], v[2], v[3]);
       else
 #pragma unroll
         for (int q = 0; q < V; ++q) d.xcat_or_null[o + q] = v[q];
@@ -293,7 +309,11 @@ __global__ __launch_bounds__(256) void k_gn_apply(tfmq_gn_desc d, const float* _
         for (int q = 0; q < V; ++q) d.yq[o + q] = qq[q];
     }
     if (d.yf) {
-      if constexpr (V == 4) *reinterpret_cast<float4*>(d.yf + o) = make_float4(y[0], y[1], y[2], y[3]);
+      if (d.half_out) {
+        __half* yh = reinterpret_cast<__half*>(d.yf);
+#pragma unroll
+        for (int q = 0; q < V; ++q) yh[o + q] = __float2half_rn(y[q]);
+      } else if constexpr (V == 4) *reinterpret_cast<float4*>(d.yf + o) = make_float4(y[0], y[1], y[2], y[3]);
       else
 #pragma unroll
         for (int q = 0; q < V; ++q) d.yf[o + q] = y[q];

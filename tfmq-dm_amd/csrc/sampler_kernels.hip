@@ -340,3 +340,29 @@ extern "C" int tfmq_plms_combine(tfmq_handle h, int order, const float* e0, cons
   TFMQ_LAUNCH_CHECK(h);
   return TFMQ_OK;
 }
+
+// ------------------------------------------------------------------ fp32 -> fp16 (round to nearest even)
+__global__ __launch_bounds__(256) void k_f32_to_f16(const float* __restrict__ x, __half* __restrict__ y, size_t n) {
+  const size_t stride = static_cast<size_t>(gridDim.x) * blockDim.x;
+  const size_t n4 = n / 4;
+  for (size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    const float4 v = reinterpret_cast<const float4*>(x)[i];
+    const __half2 lo = __floats2half2_rn(v.x, v.y), hi = __floats2half2_rn(v.z, v.w);
+    uint2 u;
+    u.x = *reinterpret_cast<const unsigned*>(&lo);
+    u.y = *reinterpret_cast<const unsigned*>(&hi);
+    reinterpret_cast<uint2*>(y)[i] = u;
+  }
+  for (size_t i = n4 * 4 + static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride)
+    y[i] = __float2half_rn(x[i]);
+}
+
+extern "C" int tfmq_f32_to_f16(tfmq_handle h, const float* x, uint16_t* y, size_t n, void* stream) {
+  TFMQ_CHECK_ARG(h, h && x && y, "f32_to_f16: null pointer");
+  if (n == 0) return TFMQ_OK;
+  int blocks = ceil_div(static_cast<long>(n / 4 + 1), 256);
+  if (blocks > h->cu_count * 16) blocks = h->cu_count * 16;
+  hipLaunchKernelGGL(k_f32_to_f16, dim3(blocks), dim3(256), 0, as_stream(stream), x, reinterpret_cast<__half*>(y), n);
+  TFMQ_LAUNCH_CHECK(h);
+  return TFMQ_OK;
+}

@@ -231,27 +231,36 @@ class DdimUNetEngine:
         return self.tib_table
 
     # ------------------------------------------------------------------ blocks
-    def _gn(self, name, x1, x2, silu, layer: Optional[_Layer], want_cat=False, eps=1e-6):
+    def _gn(self, name, x1, x2, silu, layer: Optional[_Layer], want_cat=False, eps=1e-6, half=False):
+        """half: the fp outputs of this GroupNorm (the concat copy for an un-quantised shortcut conv, or the normalised
+        tensor itself when its consumer is an un-quantised conv) may be written as fp16 -- those convs round their input
+        to fp16 anyway, so the result is bit-identical and the conv runs on the LDS-DMA path at half the bytes."""
         aq = layer.aq if (layer is not None and layer.kind == "w4a8") else None
         if aq is not None and self.calib is not None:
             _, yf, xcat = ops.groupnorm(x1, self.sd[name + ".weight"], self.sd[name + ".bias"], eps, silu, None, x2=x2,
                                         want_f32=True, want_cat=want_cat)
             self._observe(aq, yf, getattr(layer, "sibling_qids", ()))
             return ops.quantize_act(yf, aq), xcat
+        # a fp32 main output (weight-only / FP consumer that is a QuantLayer) stays fp32 unless the caller opted in
+        half = half and (aq is not None or layer is None)
         yq, yf, xcat = ops.groupnorm(x1, self.sd[name + ".weight"], self.sd[name + ".bias"], eps, silu, aq, x2=x2,
-                                     want_cat=want_cat)
+                                     want_cat=want_cat, half_out=half)
         return (yq if aq is not None else yf), xcat
+
+    def _fp_conv_half_ok(self, layer: _Layer) -> bool:
+        return layer.kind != "w4a8" and ops.f16_dma_ok(layer.p.cin, layer.p.kh, layer.p.kw)
 
     def _resblock(self, p, x1, x2, rowadd_kw):
         L = self.layers
         has_sc = (p + ".nin_shortcut") in L
         if x2 is not None and not has_sc:
             raise TfmqError(f"{p}: concatenated input without nin_shortcut is not a DDPM-UNet block")
-        h, xcat = self._gn(p + ".norm1", x1, x2, True, L[p + ".conv1"], want_cat=has_sc and x2 is not None)
+        half = has_sc and self._fp_conv_half_ok(L[p + ".nin_shortcut"])
+        h, xcat = self._gn(p + ".norm1", x1, x2, True, L[p + ".conv1"], want_cat=has_sc and (x2 is not None or half), half=half)
         h = L[p + ".conv1"].run(h, pad=(1, 1, 1, 1), **rowadd_kw)
         h, _ = self._gn(p + ".norm2", h, None, True, L[p + ".conv2"])
         if has_sc:
-            sc = L[p + ".nin_shortcut"].run(xcat if x2 is not None else x1)
+            sc = L[p + ".nin_shortcut"].run(xcat if xcat is not None else x1)
         else:
             sc = x1
         return L[p + ".conv2"].run(h, pad=(1, 1, 1, 1), residual=sc)
@@ -326,7 +335,8 @@ class DdimUNetEngine:
                 hs.append(h)
             if i != nlev - 1:
                 # Downsample (ddim/models/diffusion.py:65-72): pad (0,1,0,1), 3x3 stride 2, un-quantised
-                hs.append(L[f"down.{i}.downsample.conv"].run(hs[-1], stride=2, pad=(0, 0, 1, 1)))
+                dl = L[f"down.{i}.downsample.conv"]
+                hs.append(dl.run(ops.to_half(hs[-1]) if self._fp_conv_half_ok(dl) else hs[-1], stride=2, pad=(0, 0, 1, 1)))
                 res //= 2
         h = hs[-1]
         hin = h
@@ -359,5 +369,5 @@ class DdimUNetEngine:
                 if taps is not None:  # layer unit: its input is the up-sampled tensor (Upsample.forward)
                     taps[f"up.{i}.upsample.conv"] = (ops.upsample2x(hlow), h)
                 res *= 2
-        h, _ = self._gn("norm_out", h, None, True, None)
+        h, _ = self._gn("norm_out", h, None, True, None, half=self._fp_conv_half_ok(L["conv_out"]))
         return L["conv_out"].run(h, pad=(1, 1, 1, 1))

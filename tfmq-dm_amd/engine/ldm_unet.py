@@ -165,10 +165,12 @@ class LdmUNetEngine(DdimUNetEngine):
         has_skip = (p + ".skip_connection") in L
         if x2 is not None and not has_skip:
             raise TfmqError(f"{p}: concatenated input without skip_connection")
-        h, xcat = self._gn(p + ".in_layers.0", x1, x2, True, cin, want_cat=has_skip and x2 is not None, eps=1e-5)
+        half = has_skip and self._fp_conv_half_ok(L[p + ".skip_connection"])
+        h, xcat = self._gn(p + ".in_layers.0", x1, x2, True, cin, want_cat=has_skip and (x2 is not None or half), eps=1e-5,
+                           half=half)
         h = cin.run(h, pad=(1, 1, 1, 1), **rowadd_kw)
         h, _ = self._gn(p + ".out_layers.0", h, None, True, cout, eps=1e-5)
-        sc = L[p + ".skip_connection"].run(xcat if x2 is not None else x1, want_stats=False) if has_skip else x1
+        sc = L[p + ".skip_connection"].run(xcat if xcat is not None else x1, want_stats=False) if has_skip else x1
         return cout.run(h, pad=(1, 1, 1, 1), residual=sc)
 
     def _attention(self, p, xq_src, ctx, x_res, self_attn: bool):
@@ -295,7 +297,8 @@ class LdmUNetEngine(DdimUNetEngine):
                 if taps is not None:
                     taps[q] = (hin, h)
             elif (q + ".op") in L:
-                h = L[q + ".op"].run(h, stride=2, pad=(1, 1, 1, 1))
+                dl = L[q + ".op"]
+                h = dl.run(ops.to_half(h) if self._fp_conv_half_ok(dl) else h, stride=2, pad=(1, 1, 1, 1))
             elif (q + ".conv") in L:
                 up = L[q + ".conv"]
                 hq = self._quant_in(up, h)
@@ -341,5 +344,5 @@ class LdmUNetEngine(DdimUNetEngine):
         h = self._seq("middle_block", h, None, ctx, rowadd, taps)
         for i in range(_n_children(self.sd, "output_blocks")):
             h = self._seq(f"output_blocks.{i}", h, hs.pop(), ctx, rowadd, taps)
-        h, _ = self._gn("out.0", h, None, True, None, eps=1e-5)
+        h, _ = self._gn("out.0", h, None, True, None, eps=1e-5, half=self._fp_conv_half_ok(L["out.2"]))
         return L["out.2"].run(h, pad=(1, 1, 1, 1), want_stats=False)

@@ -387,9 +387,12 @@ def conv2d_f16(x: torch.Tensor, pf: PackedF16, stride: int = 1, pad: Tuple[int, 
                up2x: bool = False, rowadd: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
                out: Optional[torch.Tensor] = None, y_coff: int = 0, rowadd_ld=None, rowadd_step=None,
                rowadd_step_stride: int = 0, want_stats: bool = False) -> torch.Tensor:
-    """x: fp32 NHWC.  Un-quantised layers (f16 MFMA, fp32 accumulate)."""
+    """x: fp32 NHWC, or fp16 NHWC written as fp16 by its producer (groupnorm(half_out=True), to_half): the fp16 input
+    takes the LDS-DMA pipeline (Cin % 32 == 0, <= 9 taps).  Un-quantised layers (f16 MFMA, fp32 accumulate)."""
     d = _dev(x)
-    _chk(x, torch.float32, "x")
+    if x.dtype not in (torch.float32, torch.float16):
+        raise TfmqError("conv2d_f16: x must be fp32 or fp16")
+    _chk(x, x.dtype, "x")
     B, H, W, cin = x.shape
     if cin != pf.cin:
         raise TfmqError(f"conv2d_f16: Cin mismatch {cin} vs {pf.cin}")
@@ -401,9 +404,24 @@ def conv2d_f16(x: torch.Tensor, pf: PackedF16, stride: int = 1, pad: Tuple[int, 
     dsc.wscale = None if pf.wscale is None else pf.wscale.data_ptr()
     dsc.bias = None if pf.bias is None else pf.bias.data_ptr()
     dsc.aq = QSel(None, None, 0, 0)
+    dsc.x_f16 = int(x.dtype == torch.float16)
     _attach_stats(dsc, y, B, Ho * Wo, pf.cout, want_stats and y_coff == 0)
-    nbytes = 4.0 * B * H * W * cin + 2.0 * pf.cout * pf.kh * pf.kw * cin + 4.0 * B * Ho * Wo * pf.cout * (2 if residual is not None else 1)
+    nbytes = (2.0 if x.dtype == torch.float16 else 4.0) * B * H * W * cin + 2.0 * pf.cout * pf.kh * pf.kw * cin + 4.0 * B * Ho * Wo * pf.cout * (2 if residual is not None else 1)
     _profiled_conv("conv2d_f16", "f16", d, dsc, 2.0 * B * Ho * Wo * pf.cout * pf.kh * pf.kw * cin, nbytes)
+    return y
+
+
+def f16_dma_ok(cin: int, kh: int, kw: int) -> bool:
+    """conv2d_f16 takes fp16 activations (LDS-DMA path) for these layer shapes."""
+    return cin % 32 == 0 and kh * kw <= 9
+
+
+def to_half(x: torch.Tensor) -> torch.Tensor:
+    """fp32 -> fp16 copy (round to nearest even) for an un-quantised conv whose producer cannot write fp16 itself."""
+    d = _dev(x)
+    _chk(x, torch.float32, "x")
+    y = _alloc(x.shape, dtype=torch.float16, device=x.device)
+    handle(d).call("f32_to_f16", _p(x), _p(y), x.numel(), _stream(d))
     return y
 
 
@@ -436,8 +454,10 @@ def linear_small_w4(x: torch.Tensor, pw: PackedW4, aq: QSel, silu_in: bool = Fal
 
 # ------------------------------------------------------------------------------ K8
 def groupnorm(x1: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float, silu: bool, aq: Optional[QSel] = None,
-              x2: Optional[torch.Tensor] = None, groups: int = 32, want_f32: bool = False, want_cat: bool = False):
-    """x1 (and optional x2, concatenated on channels): fp32 NHWC.  Returns (yq int8 | None, yf | None, xcat | None)."""
+              x2: Optional[torch.Tensor] = None, groups: int = 32, want_f32: bool = False, want_cat: bool = False,
+              half_out: bool = False):
+    """x1 (and optional x2, concatenated on channels): fp32 NHWC.  Returns (yq int8 | None, yf | None, xcat | None).
+    half_out: yf / xcat are written as fp16 (operands of conv2d_f16's fp16-input path, which rounds to fp16 anyway)."""
     d = _dev(x1)
     _chk(x1, torch.float32, "x1")
     B = x1.shape[0]
@@ -456,11 +476,13 @@ def groupnorm(x1: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: fl
         g.yq = yq.data_ptr()
     else:
         g.aq = QSel(None, None, 0, 0)
+    odt = torch.float16 if half_out else torch.float32
+    g.half_out = int(half_out)
     if want_f32 or yq is None:
-        yf = _alloc(shape, dtype=torch.float32, device=x1.device)
+        yf = _alloc(shape, dtype=odt, device=x1.device)
         g.yf = yf.data_ptr()
     if want_cat:
-        xcat = _alloc(shape, dtype=torch.float32, device=x1.device)
+        xcat = _alloc(shape, dtype=odt, device=x1.device)
         g.xcat = xcat.data_ptr()
     st1 = getattr(x1, "_tfmq_stats", None)
     st2 = getattr(x2, "_tfmq_stats", None) if x2 is not None else None
