@@ -354,8 +354,10 @@ __global__ __launch_bounds__(256, 3) void k_conv_dma(ConvP p) {
   float2 aqp = make_float2(1.0f, 0.0f);
   if constexpr (!F16) aqp = load_qparam(d.aq);
 
-  // ---- pixel offset table (any stride / padding / fused 2x upsample)
-  {
+  // ---- pixel offset table (any stride / padding / fused 2x upsample).  A Linear / 1x1 stride-1 conv needs none:
+  // pixel m reads input pixel m (most launches of a transformer UNet: no table, no barrier in the prologue)
+  const bool pointwise = d.KH * d.KW == 1 && d.stride == 1 && !d.up2x && d.pad_t == 0 && d.pad_l == 0;
+  if (!pointwise) {
     const int taps = d.KH * d.KW, hw = d.Ho * d.Wo;
     for (int idx = tid; idx < taps * BM; idx += 256) {
       const int tap = idx / BM, row = idx - tap * BM;
@@ -391,7 +393,7 @@ __global__ __launch_bounds__(256, 3) void k_conv_dma(ConvP p) {
     a_row[it] = piece * 16 + (lane >> 2);
     a_col[it] = ((lane & 3) ^ ((a_row[it] >> 2) & 3)) * 16;
     a_dst[it] = __builtin_amdgcn_readfirstlane(piece * 1024);
-    a_off[it] = -1;
+    a_off[it] = (pointwise && m0 + a_row[it] < p.M) ? (m0 + a_row[it]) * d.Cin * (F16 ? 2 : 1) : -1;
   }
 #pragma unroll
   for (int it = 0; it < B_CH; ++it) {
@@ -409,7 +411,7 @@ __global__ __launch_bounds__(256, 3) void k_conv_dma(ConvP p) {
     }
     b_dst[it] = __builtin_amdgcn_readfirstlane(BM * 64 + piece * 1024);
   }
-  __syncthreads();  // tab visible
+  if (!pointwise) __syncthreads();  // tab visible
   const int za = static_cast<int>(aqp.y);
   // real zero == bin za  ->  stored byte za-128; its 64-byte row in the pad table feeds the padded taps
   // (fp16 operands: row 0 = zeros)
@@ -417,7 +419,7 @@ __global__ __launch_bounds__(256, 3) void k_conv_dma(ConvP p) {
 
   int i_tap = 0, i_chunk = 0;
   auto issue = [&](int s, int stage) {
-    if (i_chunk == 0) {
+    if (i_chunk == 0 && !pointwise) {
 #pragma unroll
       for (int it = 0; it < A_CH; ++it) a_off[it] = tab[i_tap * BM + a_row[it]];
     }
