@@ -155,9 +155,12 @@ typedef struct tfmq_conv_desc {
                                       (p/128)*64 + p%64 (+ inner when p%128 >= 64)); the epilogue
                                       writes yq[m][c] = quant_oq(value * gelu(gate)) - 128, int8 [M][Cout/2],
                                       i.e. the next QuantLayer's input (quant_layer.py:312-313), and y is unused.
-                                    rowadd / residual / stats are only defined for TFMQ_OUT_F32. */
-  tfmq_qsel oq;                  /* TFMQ_OUT_GEGLU_Q8: activation quantizer of the consumer */
-  int8_t* yq;                    /* TFMQ_OUT_GEGLU_Q8: int8 output */
+                                    TFMQ_OUT_Q8: yq[m][c] = quant_oq(conv + bias (+ rowadd) (+ residual)) - 128, int8
+                                      [M][Cout]: for an output whose ONLY consumer is the next QuantLayer's
+                                      activation quantizer (quant_layer.py:312-313); y is unused.
+                                    rowadd / residual are defined for TFMQ_OUT_F32 and TFMQ_OUT_Q8, stats for F32. */
+  tfmq_qsel oq;                  /* TFMQ_OUT_GEGLU_Q8 / TFMQ_OUT_Q8: activation quantizer of the consumer */
+  int8_t* yq;                    /* TFMQ_OUT_GEGLU_Q8 / TFMQ_OUT_Q8: int8 output */
   uint16_t* yt;                  /* TFMQ_OUT_F16, optional: output channels n >= t_col0 are written TRANSPOSED,
                                     fp16 yt[b][n - t_col0][t], t = ho*Wo + wo (instead of into y): the V^T operand of
                                     tfmq_attention_f16 straight from the fused q|k|v projection */
@@ -167,7 +170,7 @@ typedef struct tfmq_conv_desc {
                                     Needs Cin % 32 == 0 and KH*KW <= 9; bit-identical to the fp32-input path, which
                                     rounds x to fp16 while staging */
 } tfmq_conv_desc;
-enum { TFMQ_OUT_F32 = 0, TFMQ_OUT_F16 = 1, TFMQ_OUT_GEGLU_Q8 = 2 };
+enum { TFMQ_OUT_F32 = 0, TFMQ_OUT_F16 = 1, TFMQ_OUT_GEGLU_Q8 = 2, TFMQ_OUT_Q8 = 3 };
 int tfmq_conv2d_w4a8(tfmq_handle h, const tfmq_conv_desc* d, void* stream);
 int tfmq_conv2d_f16(tfmq_handle h, const tfmq_conv_desc* d, void* stream);
 

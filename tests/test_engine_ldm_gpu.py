@@ -79,6 +79,11 @@ def test_ldm_w4a8_and_cfg_ddim(env):
     r = rel_l2(eps, T(g["eps_w4a8"]))
     print("ldm w4a8 eps rel-L2:", r)
     assert r <= 3e-2
+    # the fused output modes (int8 straight from the epilogue of a GEMM whose only consumer is a quantizer, fused GEGLU,
+    # fp16 attention operands) change where a value is rounded to its bin, never the value: the un-fused forward that
+    # exposes every unit's tensors (taps) gives the same eps bit for bit
+    eps_taps = nchw(eng.forward(nhwc(x), t.to(DEV), ctx.to(DEV), taps={}))
+    assert torch.equal(eps_taps, eps)
     from tfmq_dm_amd.ldm.sampler import GraphLatentDdimSampler, alphas_cumprod_linear, ddim_coef_table
     ac = alphas_cumprod_linear()
     assert np.array_equal(ac.numpy(), g["alphas_cumprod"])

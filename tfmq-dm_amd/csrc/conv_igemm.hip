@@ -111,6 +111,9 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, unsigned char* lds
   const int tr = tid / TPR, c4 = (tid % TPR) * 4;
   // tiles of the transposed output region (V^T for the attention kernel) stage with an odd row pitch so the
   // column-wise LDS reads of their store pass are (at most 2-way) conflict free
+  const bool q8 = d.out_mode == TFMQ_OUT_Q8;
+  float2 oqp = make_float2(1.0f, 0.0f);
+  if (q8) oqp = load_qparam(d.oq);
   const bool transposed = d.out_mode == TFMQ_OUT_F16 && d.yt && n0 >= d.t_col0;
   const int ldo = transposed ? BN + 1 : LDO;
 
@@ -257,7 +260,16 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, unsigned char* lds
           const float4 a = *reinterpret_cast<const float4*>(d.residual + static_cast<size_t>(m) * d.Cout + n);
           v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
         }
-        *reinterpret_cast<float4*>(d.y + static_cast<size_t>(m) * d.ldy + d.y_coff + n) = v;
+        if (q8) {     // the only consumer is the next QuantLayer's activation quantizer: write its bins
+          char4 q;
+          q.x = static_cast<signed char>(static_cast<int>(quant_index_f(v.x, oqp.x, oqp.y, 255.0f)) - 128);
+          q.y = static_cast<signed char>(static_cast<int>(quant_index_f(v.y, oqp.x, oqp.y, 255.0f)) - 128);
+          q.z = static_cast<signed char>(static_cast<int>(quant_index_f(v.z, oqp.x, oqp.y, 255.0f)) - 128);
+          q.w = static_cast<signed char>(static_cast<int>(quant_index_f(v.w, oqp.x, oqp.y, 255.0f)) - 128);
+          *reinterpret_cast<char4*>(d.yq + static_cast<size_t>(m) * d.Cout + n) = q;
+        } else {
+          *reinterpret_cast<float4*>(d.y + static_cast<size_t>(m) * d.ldy + d.y_coff + n) = v;
+        }
       } else {
         float e[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
@@ -761,16 +773,19 @@ template <bool INT8>
 static int launch_conv(tfmq_handle h, const tfmq_conv_desc* dd, void* stream) {
   TFMQ_CHECK_ARG(h, h && dd, "conv: null pointer");
   const tfmq_conv_desc& d = *dd;
-  TFMQ_CHECK_ARG(h, d.x && d.w && (d.y || d.out_mode == TFMQ_OUT_GEGLU_Q8), "conv: null operand");
+  TFMQ_CHECK_ARG(h, d.x && d.w && (d.y || d.out_mode == TFMQ_OUT_GEGLU_Q8 || d.out_mode == TFMQ_OUT_Q8), "conv: null operand");
   TFMQ_CHECK_ARG(h, d.B > 0 && d.H > 0 && d.W > 0 && d.Cin > 0 && d.Cout > 0 && d.KH > 0 && d.KW > 0 && d.stride > 0,
                  "conv: bad geometry");
   TFMQ_CHECK_ARG(h, d.Ho > 0 && d.Wo > 0 && d.ldy >= d.Cout + d.y_coff, "conv: bad output geometry");
-  TFMQ_CHECK_ARG(h, d.out_mode == TFMQ_OUT_F32 || (!d.rowadd && !d.residual && !d.stats),
-                 "conv: rowadd / residual / stats need out_mode F32");
+  TFMQ_CHECK_ARG(h, d.out_mode == TFMQ_OUT_F32 || d.out_mode == TFMQ_OUT_Q8 || (!d.rowadd && !d.residual),
+                 "conv: rowadd / residual need out_mode F32 or Q8");
+  TFMQ_CHECK_ARG(h, d.out_mode == TFMQ_OUT_F32 || !d.stats, "conv: stats need out_mode F32");
+  TFMQ_CHECK_ARG(h, d.out_mode != TFMQ_OUT_Q8 || (d.yq && d.oq.qtable && d.Cout % 4 == 0 && (!d.rowadd || d.rowadd_ld % 4 == 0)),
+                 "conv: Q8 output needs yq, oq and Cout % 4 == 0");
   TFMQ_CHECK_ARG(h, d.out_mode != TFMQ_OUT_GEGLU_Q8 ||
                         (INT8 && d.yq && d.oq.qtable && d.KH == 1 && d.KW == 1 && d.Cout % 128 == 0 && d.Cout / 2 % 4 == 0),
                  "conv: GEGLU epilogue needs a w4a8 Linear with Cout % 128 == 0, yq and oq");
-  TFMQ_CHECK_ARG(h, d.out_mode >= 0 && d.out_mode <= 2, "conv: bad out_mode");
+  TFMQ_CHECK_ARG(h, d.out_mode >= 0 && d.out_mode <= 3, "conv: bad out_mode");
   TFMQ_CHECK_ARG(h, !d.yt || (d.out_mode == TFMQ_OUT_F16 && d.t_col0 >= 0 && d.t_col0 % 128 == 0 && d.t_col0 < d.Cout &&
                               (d.Ho * d.Wo) % 4 == 0),
                  "conv: transposed region needs out_mode F16, t_col0 % 128 == 0 and Ho*Wo % 4 == 0");

@@ -12,6 +12,7 @@ kernel as the 1x1 convs.  Attention matmuls stay un-quantised (their quantizers 
 SURVEY §0 fact 2)."""
 from __future__ import annotations
 
+import os
 from typing import Dict, List, Optional
 
 import torch
@@ -68,6 +69,7 @@ class LdmUNetEngine(DdimUNetEngine):
                 sd2[k[:-6] + "bias"] = sd2[k[:-6] + "bias"][perm].contiguous()
         super().__init__(sd2, dict(cfg), device)
         self.res_names = ldm_resblock_paths(self.sd)
+        self.fuse_q8 = os.environ.get("TFMQ_NO_Q8") is None
 
     def tib_layout(self):
         return ("time_embed.0", "time_embed.2", [r + ".emb_layers.1" for r in self.res_names],
@@ -159,7 +161,9 @@ class LdmUNetEngine(DdimUNetEngine):
         return y.reshape(B, T, -1)
 
     # ------------------------------------------------------------------ blocks
-    def _res(self, p, x1, x2, rowadd_kw):
+    def _res(self, p, x1, x2, rowadd_kw, out_aq=None):
+        """out_aq: the block's output is consumed only by that activation quantizer (an up-sampling conv follows): the
+        last conv's epilogue writes the int8 bins instead of fp32 (TFMQ_OUT_Q8)."""
         L = self.layers
         cin, cout = L[p + ".in_layers.2"], L[p + ".out_layers.3"]
         has_skip = (p + ".skip_connection") in L
@@ -171,6 +175,8 @@ class LdmUNetEngine(DdimUNetEngine):
         h = cin.run(h, pad=(1, 1, 1, 1), **rowadd_kw)
         h, _ = self._gn(p + ".out_layers.0", h, None, True, cout, eps=1e-5)
         sc = L[p + ".skip_connection"].run(xcat if xcat is not None else x1, want_stats=False) if has_skip else x1
+        if out_aq is not None and cout.kind == "w4a8":
+            return cout.run(h, pad=(1, 1, 1, 1), residual=sc, want_stats=False, out_q8=out_aq)
         return cout.run(h, pad=(1, 1, 1, 1), residual=sc)
 
     def _attention(self, p, xq_src, ctx, x_res, self_attn: bool):
@@ -221,7 +227,7 @@ class LdmUNetEngine(DdimUNetEngine):
             o = self._quant_in(to_out, o)
         return self._tok(to_out, o, residual=x_res)
 
-    def _tblock(self, p, x, ctx):
+    def _tblock(self, p, x, ctx, out_aq=None):
         L = self.layers
         q1 = self.fused_qkv.get(p + ".attn1", L[p + ".attn1.to_q"])
         x = self._attention(p + ".attn1", self._ln(p + ".norm1", x, q1), None, x, True)
@@ -232,6 +238,8 @@ class LdmUNetEngine(DdimUNetEngine):
             xq = self._ln(p + ".norm3", x, ff0)
             B, T, Cc = xq.shape
             g = ops.conv2d_w4a8(xq.reshape(B, T, 1, Cc), gp, ff0.aq, geglu_oq=ff2.aq).reshape(B, T, -1)
+            if out_aq is not None:      # tokens feed only proj_out's quantizer: int8 straight from the epilogue
+                return self._tok(ff2, g, residual=x, out_q8=out_aq)
             return self._tok(ff2, g, residual=x)
         h = self._tok(ff0, self._ln(p + ".norm3", x, ff0))
         if ff2.kind == "w4a8" and self.calib is None:
@@ -240,7 +248,7 @@ class LdmUNetEngine(DdimUNetEngine):
             g = self._quant_in(ff2, ops.geglu(h, None)[1])
         return self._tok(ff2, g, residual=x)
 
-    def _st(self, p, x, ctx, taps=None):
+    def _st(self, p, x, ctx, taps=None, out_aq=None):
         """taps (reconstruction data capture): every QuantLayer / QuantBasicTransformerBlock of the SpatialTransformer is a
         reconstruction unit of its own (recon_model walks norm, proj_in, transformer_blocks, proj_out)."""
         L = self.layers
@@ -251,18 +259,22 @@ class LdmUNetEngine(DdimUNetEngine):
         if taps is not None:
             taps[p + ".proj_in"] = (h_in, h)
         tok = h.reshape(B, H * W, h.shape[-1])
-        for i in range(_n_children(self.sd, p + ".transformer_blocks")):
+        nblk = _n_children(self.sd, p + ".transformer_blocks")
+        fuse_q = pout.kind == "w4a8" and self.calib is None and taps is None and self.fuse_q8
+        for i in range(nblk):
             name = f"{p}.transformer_blocks.{i}"
             tin = tok
-            tok = self._tblock(name, tok, ctx)
+            tok = self._tblock(name, tok, ctx, out_aq=pout.aq if (fuse_q and i == nblk - 1) else None)
             if taps is not None:
                 taps[name] = ((tin, ctx), tok)
-        h = self._quant_in(pout, tok.reshape(B, H, W, -1))
+        h = tok.reshape(B, H, W, -1) if tok.dtype == torch.int8 else self._quant_in(pout, tok.reshape(B, H, W, -1))
         if taps is not None:
             o = pout.run(h, want_stats=False)            # the layer's own output, without the fused residual
             taps[p + ".proj_out"] = (h, o.clone())
             ops.axpy(o, x, 1.0)
             return o
+        if out_aq is not None and pout.kind == "w4a8":
+            return pout.run(h, residual=x, want_stats=False, out_q8=out_aq)
         return pout.run(h, residual=x)
 
     def _attn_block(self, p, x):
@@ -281,15 +293,20 @@ class LdmUNetEngine(DdimUNetEngine):
 
     def _seq(self, p, h, skip, ctx, rowadd, taps):
         L = self.layers
-        for j in range(_n_children(self.sd, p)):
+        nchild = _n_children(self.sd, p)
+        for j in range(nchild):
             q = f"{p}.{j}"
             hin = h
+            # the next child is an up-sampling conv on 8-bit activations: this child's output feeds only its quantizer
+            nxt = L.get(f"{p}.{j + 1}.conv") if j + 1 < nchild else None
+            out_aq = nxt.aq if (nxt is not None and nxt.kind == "w4a8" and self.calib is None and taps is None
+                                and self.fuse_q8) else None
             if (q + ".in_layers.0.weight") in self.sd:
-                h = self._res(q, h, skip if j == 0 else None, rowadd(q))
+                h = self._res(q, h, skip if j == 0 else None, rowadd(q), out_aq=out_aq)
                 if taps is not None:
                     taps[q] = ((hin, skip) if (j == 0 and skip is not None) else hin, h)
             elif (q + ".transformer_blocks.0.norm1.weight") in self.sd:
-                h = self._st(q, h, ctx, taps)
+                h = self._st(q, h, ctx, taps, out_aq=out_aq)
                 if taps is not None:
                     taps[q] = (hin, h)
             elif (q + ".qkv") in L:
@@ -301,7 +318,7 @@ class LdmUNetEngine(DdimUNetEngine):
                 h = dl.run(ops.to_half(h) if self._fp_conv_half_ok(dl) else h, stride=2, pad=(1, 1, 1, 1))
             elif (q + ".conv") in L:
                 up = L[q + ".conv"]
-                hq = self._quant_in(up, h)
+                hq = h if h.dtype == torch.int8 else self._quant_in(up, h)
                 h = up.run(hq, pad=(1, 1, 1, 1), up2x=True)
                 if taps is not None and hq.dtype == torch.float32:
                     taps[q + ".conv"] = (ops.upsample2x(hq), h)

@@ -334,7 +334,7 @@ def conv2d_w4a8(xq: torch.Tensor, pw: PackedW4, aq: QSel, stride: int = 1, pad: 
                 up2x: bool = False, rowadd: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
                 out: Optional[torch.Tensor] = None, y_coff: int = 0, rowadd_ld=None, rowadd_step=None,
                 rowadd_step_stride: int = 0, want_stats: bool = False, out_f16: bool = False,
-                geglu_oq: Optional[QSel] = None, t_col0: Optional[int] = None):
+                geglu_oq: Optional[QSel] = None, t_col0: Optional[int] = None, out_q8: Optional[QSel] = None):
     """xq: int8 NHWC [B,H,W,Cin] (bin-128).  pad = (top, left, bottom, right).  -> fp32 NHWC.
     out_f16: fp16 output (operands of the attention kernel).  geglu_oq: `pw` is a geglu_perm-ordered GEGLU projection;
     returns int8 [B,Ho,Wo,Cout/2] = quant_geglu_oq(value * gelu(gate)) - 128.
@@ -347,9 +347,15 @@ def conv2d_w4a8(xq: torch.Tensor, pw: PackedW4, aq: QSel, stride: int = 1, pad: 
         raise TfmqError(f"conv2d_w4a8: Cin mismatch {cin} vs {pw.cin}")
     Ho, Wo = out_hw(H, W, pw.kh, pw.kw, stride, pad[0], pad[1], pad[2], pad[3], up2x)
     if geglu_oq is not None:
-        if out is not None or rowadd is not None or residual is not None or want_stats or out_f16:
+        if out is not None or rowadd is not None or residual is not None or want_stats or out_f16 or out_q8 is not None:
             raise TfmqError("conv2d_w4a8: the GEGLU epilogue takes no other epilogue option")
         y = _alloc(B, Ho, Wo, pw.cout // 2, dtype=torch.int8, device=xq.device)
+        ldy = pw.cout
+    elif out_q8 is not None:
+        # out_q8: the consumer's activation quantizer; returns its int8 input (bias / temb row / residual applied first)
+        if out is not None or want_stats or out_f16 or y_coff:
+            raise TfmqError("conv2d_w4a8: the int8 output mode takes no out / stats / fp16 / channel-offset option")
+        y = _alloc(B, Ho, Wo, pw.cout, dtype=torch.int8, device=xq.device)
         ldy = pw.cout
     else:
         y = out if out is not None else _alloc(B, Ho, Wo, pw.cout, dtype=torch.float16 if out_f16 else torch.float32,
@@ -367,6 +373,9 @@ def conv2d_w4a8(xq: torch.Tensor, pw: PackedW4, aq: QSel, stride: int = 1, pad: 
     if geglu_oq is not None:
         dsc.out_mode, dsc.oq, dsc.yq, dsc.y = 2, geglu_oq, y.data_ptr(), None
         osz = 0.5
+    elif out_q8 is not None:
+        dsc.out_mode, dsc.oq, dsc.yq, dsc.y = 3, out_q8, y.data_ptr(), None
+        osz = 1.0
     elif out_f16:
         dsc.out_mode = 1
         osz = 2.0
