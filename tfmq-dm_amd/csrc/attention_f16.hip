@@ -29,7 +29,10 @@ struct AttnHP {
 // NKS = k-steps of the score MFMA (16 channels each), NT = 32-column output tiles: compile-time, so that the MFMA
 // chains stay straight-line code (run-time trip counts made the compiler shuttle the accumulators between
 // AGPRs and VGPRs: ~900 moves per key tile).  d <= 16*NKS, d <= 32*NT; the LDS padding is zero.
-template <int NKS, int NT>
+// ONES_ROW = d when 32*NT > d (else -1): V^T row d (a padding row of the last output tile) is set to 1.0 once, so the
+// PV MFMA accumulates the softmax denominator sum_k P[q][k] in output row d -- rescaled with O for free -- and the
+// 32 adds + one cross-lane exchange per key tile disappear from the VALU-bound softmax.
+template <int NKS, int NT, int ONES_ROW>
 __global__ __launch_bounds__(256) void k_attention_h(AttnHP p) {
   constexpr int DPAD = NT * 32;
   static_assert(NKS <= 2 * NT, "score k-steps must fit the padded row");
@@ -179,9 +182,9 @@ __global__ __launch_bounds__(256) void k_attention_h(AttnHP p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         s[sub][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[sub][r], c2, -mc));
-        rs += s[sub][r];
+        if constexpr (ONES_ROW < 0) rs += s[sub][r];
       }
-    rs += __shfl_xor(rs, 32, 64);
+    if constexpr (ONES_ROW < 0) rs += __shfl_xor(rs, 32, 64);
     if (__builtin_amdgcn_ballot_w64(m_new > m_run) != 0) {   // some query's running max moved: rescale
       const float alpha = __builtin_amdgcn_exp2f(m_run * c2 - mc);
       l_run *= alpha;
@@ -210,6 +213,12 @@ __global__ __launch_bounds__(256) void k_attention_h(AttnHP p) {
   const int nfull = p.Tk / 64;       // tiles without a ragged tail
   load_tile(0);
   __syncthreads();   // zero fill done
+  if constexpr (ONES_ROW >= 0) {
+    if (tid < 16) {
+      const uint4 ones = make_uint4(0x3C003C00u, 0x3C003C00u, 0x3C003C00u, 0x3C003C00u);   // 8 x fp16 1.0
+      *reinterpret_cast<uint4*>(sV + (tid >> 3) * VBUF + ONES_ROW * VROW + (tid & 7) * 16) = ones;
+    }
+  }
   store_tile(0);
   __syncthreads();
   for (int kt = 0; kt < nfull; ++kt) {
@@ -223,6 +232,12 @@ __global__ __launch_bounds__(256) void k_attention_h(AttnHP p) {
   // ---- normalise and store: lane (query j, half hh) owns dcols t*32 + (r&3) + 8*(r>>2) + 4*hh
   const int qg = q0 + wid * 32 + j;
   if (qg >= p.Tq) return;
+  if constexpr (ONES_ROW >= 0) {     // the denominator sits in output row ONES_ROW: lanes of half hh_one, register r_one
+    constexpr int lr = ONES_ROW % 32, hh_one = (lr >> 2) & 1, r_one = (lr & 3) + 4 * (lr >> 3);
+    const float mine = o[ONES_ROW / 32][r_one];
+    const float other = __shfl_xor(mine, 32, 64);
+    l_run = hh == hh_one ? mine : other;
+  }
   const float inv = 1.0f / l_run;
   const bool quant = p.yq != nullptr;
   float2 qp = make_float2(1.0f, 0.0f);
@@ -248,18 +263,18 @@ __global__ __launch_bounds__(256) void k_attention_h(AttnHP p) {
   }
 }
 
-template <int NKS, int NT>
+template <int NKS, int NT, int ONES_ROW = -1>
 static int launch_attn_h(tfmq_handle h, const AttnHP& p, void* stream) {
   constexpr int DPAD = NT * 32;
   constexpr size_t smem = 2 * (64 * (DPAD * 2 + 16) + static_cast<size_t>(DPAD) * (64 * 2 + 16));
   static bool configured = false;
   if (!configured) {
-    TFMQ_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_attention_h<NKS, NT>),
+    TFMQ_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_attention_h<NKS, NT, ONES_ROW>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(smem)));
     configured = true;
   }
   dim3 grid(static_cast<unsigned>((p.Tq + 127) / 128) * p.B * p.heads);
-  hipLaunchKernelGGL((k_attention_h<NKS, NT>), grid, dim3(256), smem, as_stream(stream), p);
+  hipLaunchKernelGGL((k_attention_h<NKS, NT, ONES_ROW>), grid, dim3(256), smem, as_stream(stream), p);
   TFMQ_LAUNCH_CHECK(h);
   return TFMQ_OK;
 }
@@ -275,9 +290,11 @@ extern "C" int tfmq_attention_f16(tfmq_handle h, const uint16_t* q, const uint16
   AttnHP p{reinterpret_cast<const __half*>(q), reinterpret_cast<const __half*>(k), reinterpret_cast<const __half*>(vt),
            ldq, ldk, out, ldo, yq, aq, B, heads, Tq, Tk, d, scale};
   if (d <= 32) return launch_attn_h<2, 1>(h, p, stream);
-  if (d <= 48) return launch_attn_h<3, 2>(h, p, stream);     // SD v1 at 64x64: d = 40
+  if (d == 40) return launch_attn_h<3, 2, 40>(h, p, stream);  // SD v1 at 64x64
+  if (d <= 48) return launch_attn_h<3, 2>(h, p, stream);
   if (d <= 64) return launch_attn_h<4, 2>(h, p, stream);
-  if (d <= 80) return launch_attn_h<5, 3>(h, p, stream);     // SD v1 at 32x32
+  if (d == 80) return launch_attn_h<5, 3, 80>(h, p, stream);  // SD v1 at 32x32
+  if (d <= 80) return launch_attn_h<5, 3>(h, p, stream);
   if (d <= 96) return launch_attn_h<6, 3>(h, p, stream);
   if (d <= 128) return launch_attn_h<8, 4>(h, p, stream);
   if (d <= 160) return launch_attn_h<10, 5>(h, p, stream);   // SD v1 at 16x16 / 8x8
