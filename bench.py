@@ -342,12 +342,12 @@ def main():
         tpath = os.path.join(ROOT, "profiles", f"r01_traffic_{args.workload}.json")
         if os.path.exists(tpath):
             tj = json.load(open(tpath))["kernels"]
-            ks = [v for k, v in tj.items() if k.startswith("void k_conv_dma") or k.startswith("void k_conv_igemm<true")]
+            ks = [v for k, v in tj.items() if k.startswith("void k_conv_dma<false") or k.startswith("void k_conv_igemm<true")]
             if ks:
                 traffic = sum(v["hbm_bytes_per_launch"] * v["launches"] for v in ks) / sum(v["launches"] for v in ks)
                 traffic_src = (f"profiles/r01_traffic_{args.workload}.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, "
                                "separate passes, eager forwards of the same workload)")
-        roof = {"bound": "mfma", "kernel": "k_conv_dma<...> (w4a8 implicit-GEMM conv / linear, LDS-DMA pipeline, all tile variants)",
+        roof = {"bound": "mfma", "kernel": "k_conv_dma<false,...> (w4a8 implicit-GEMM conv / linear, LDS-DMA pipeline, all tile variants)",
                 "achieved": round(achieved, 2), "peak": INT8_PEAK_TOPS, "unit": "TOP/s",
                 "frac": round(achieved / INT8_PEAK_TOPS, 4), "traffic": traffic, "traffic_unit": "bytes/launch (PMC)",
                 "traffic_source": traffic_src,
