@@ -82,3 +82,27 @@ def test_fused_qkv_gemm_writes_v_transposed(ops, B, T, cin, C):
     assert torch.equal(y16[..., :2 * C], y32[..., :2 * C].half())
     assert yt.shape == (B, C, T)
     assert torch.equal(yt, y32[..., 2 * C:].half().transpose(1, 2))
+
+
+@pytest.mark.parametrize("B,heads,Tq,Tk,d", [(2, 1, 256, 256, 384), (1, 1, 64, 1, 960), (2, 2, 100, 77, 320)])
+def test_attention_wide_heads(ops, B, heads, Tq, Tk, d):
+    """cin256-style attention (one head of 384..960 channels; cross attention over ONE class token): head dims above the
+    flash kernels' limit take the three-launch exact-fp32 path.  Bar 1e-5 max-normalised (fp32 throughout)."""
+    gen = torch.Generator().manual_seed(Tq + d)
+    C = heads * d
+    q = torch.randn(B, Tq, C, generator=gen)
+    k = torch.randn(B, Tk, C, generator=gen)
+    v = torch.randn(B, Tk, C, generator=gen)
+    scale = d ** -0.5
+    qh = q.reshape(B, Tq, heads, d).permute(0, 2, 1, 3)
+    kh = k.reshape(B, Tk, heads, d).permute(0, 2, 1, 3)
+    vh = v.reshape(B, Tk, heads, d).permute(0, 2, 1, 3)
+    ref = (torch.softmax(qh @ kh.transpose(-1, -2) * scale, -1) @ vh).permute(0, 2, 1, 3).reshape(B, Tq, C)
+    ad, az = O.minmax(ref, 256)
+    out, yq = ops.attention(q.to(DEV), k.to(DEV), v.to(DEV), heads, scale, ops.qsel(qtab(ad, az)))
+    assert maxnorm(out.cpu(), ref) <= 1e-5
+    assert torch.equal(yq.cpu().float() + 128, O.quant_index(out.cpu(), ad, az, 256))
+    if Tq == Tk:      # column slices of a fused q|k|v buffer
+        qkv = torch.cat([q, k, v], -1).to(DEV)
+        out2, _ = ops.attention(qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:], heads, scale)
+        assert torch.equal(out2, out)

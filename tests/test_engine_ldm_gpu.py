@@ -121,3 +121,27 @@ def test_layernorm_geglu_kernels(env):
     yq, yf = ops.geglu(h.to(DEV), ops.qsel(qt), want_f32=True)
     assert float((yf.cpu() - ref).abs().max() / ref.abs().max()) <= 1e-5
     assert torch.equal(yq.cpu().float() + 128, O.quant_index(yf.cpu(), ad, az, 256))
+
+
+def test_single_wide_head_unet_vs_oracle():
+    """cin256-style configuration (num_heads = 1 -> one attention head as wide as the level, cross attention over ONE
+    context token): engine vs the CPU oracle on a random-init UNet, FP path.  Head dim 288 > 256 takes the exact-fp32
+    three-launch attention."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from tfmq_dm_amd.ddim.models import random_init
+    from tfmq_dm_amd.engine import LdmUNetEngine
+    from tfmq_dm_amd.ldm.unet import UNetModel
+    kw = dict(image_size=8, in_channels=3, model_channels=288, out_channels=3, num_res_blocks=1, attention_resolutions=[1],
+              channel_mult=[1], num_heads=1, use_spatial_transformer=True, transformer_depth=1, context_dim=32)
+    m = random_init(UNetModel(**kw), 77)
+    sd = {k: v.detach() for k, v in m.state_dict().items()}
+    cfg = m.engine_cfg()
+    gen = torch.Generator().manual_seed(5)
+    x, t, ctx = torch.randn(2, 3, 8, 8, generator=gen), torch.tensor([900.0, 17.0]), torch.randn(2, 1, 32, generator=gen)
+    eng = LdmUNetEngine(sd, cfg, DEV)
+    eng.prepare()
+    eps = nchw(eng.forward(nhwc(x), t.to(DEV), ctx.to(DEV)))
+    with torch.no_grad():
+        ref = O.ldm_unet_forward(sd, dict(cfg), x, t.long(), ctx, O.QuantSpec(wq={}, aq={}))
+    assert float((eps - ref).abs().max() / ref.abs().max()) <= 1e-2

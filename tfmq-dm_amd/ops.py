@@ -546,6 +546,8 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int, sca
     for t in (q, k, v):
         if t.dtype != torch.float32 or t.stride(-1) != 1 or t.stride(0) != t.shape[1] * t.stride(1):
             raise TfmqError("attention: q/k/v must be fp32 [B,T,C] with unit channel stride and dense batch/token strides")
+    if dh > 256:
+        return _attention_wide(q, k, v, heads, scale, aq, want_f32)
     out = _alloc(B, Tq, Cq, dtype=torch.float32, device=q.device) if want_f32 else None
     yq = None
     sel = QSel(None, None, 0, 0)
@@ -555,6 +557,28 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int, sca
     handle(d_).call("attention", _p(q), _p(k), _p(v), q.stride(1), k.stride(1), v.stride(1), _p(out), Cq, _p(yq), sel, B,
                     heads, Tq, Tk, dh, float(scale), _stream(d_))
     return out, yq
+
+
+def _attention_wide(q, k, v, heads: int, scale: float, aq: Optional[QSel], want_f32: bool):
+    """Head dims beyond the flash kernels' register budget (cin256: ONE head of 384 / 576 / 960 channels over <= 1024
+    tokens): scores, softmax and P.V as three exact-fp32 launches (strided MFMA GEMM, row softmax) -- the score matrix of
+    these shapes is a few MB."""
+    B, Tq, Cq = q.shape
+    Tk, d = k.shape[1], Cq // heads
+    lq, lk, lv = q.stride(1), k.stride(1), v.stride(1)
+    S = _alloc(B, heads, Tq, Tk, dtype=torch.float32, device=q.device)
+    for h in range(heads):
+        gemm_strided(q, h * d, lq, 1, Tq * lq, k, h * d, 1, lk, Tk * lk,
+                     S, h * Tq * Tk, Tk, heads * Tq * Tk, Tq, Tk, d, B)
+    P = softmax_rows(S, float(scale))
+    out = _alloc(B, Tq, Cq, dtype=torch.float32, device=q.device)
+    for h in range(heads):
+        gemm_strided(P, h * Tq * Tk, Tk, 1, heads * Tq * Tk, v, h * d, lv, 1, Tk * lv,
+                     out, h * d, Cq, Tq * Cq, Tq, d, Tk, B)
+    yq = None
+    if aq is not None and aq.qtable:
+        yq = quantize_act(out, aq)
+    return (out if want_f32 else None), yq
 
 
 def attention_f16_ok(d: int, Tk: int) -> bool:
@@ -711,8 +735,9 @@ def gemm_strided(A: torch.Tensor, a_off: int, sam: int, sak: int, bsa: int, B: t
     A(z,m,k) = A.flat[a_off + z*bsa + m*sam + k*sak], likewise B(k,n) and C(m,n) (row stride scm, unit column stride).
     Lets the multi-head attention of a reconstruction unit run on the [B,T,heads*d] layout without permutes."""
     d = _dev(A)
-    for t in (A, B, Cm):
-        _chk(t, torch.float32, "gemm_strided operand")
+    for t in (A, B, Cm):       # views are welcome: the strides are given explicitly
+        if not t.is_cuda or t.dtype != torch.float32:
+            raise TfmqError("gemm_strided: operands must be fp32 device tensors")
     handle(d).call("gemm_f32", A.data_ptr() + 4 * a_off, B.data_ptr() + 4 * b_off, Cm.data_ptr() + 4 * c_off, M, N, K,
                    sam, sak, sbk, sbn, scm, batch, bsa, bsb, bsc, float(alpha), None, None, 1, 0, None, int(accumulate),
                    _stream(d))
