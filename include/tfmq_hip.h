@@ -253,6 +253,11 @@ int tfmq_cfg_combine(tfmq_handle h, const float* eps_u, const float* eps_c, floa
                      void* stream);
 int tfmq_plms_combine(tfmq_handle h, int order, const float* e0, const float* e1, const float* e2_or_null,
                       const float* e3_or_null, float* out, size_t n, void* stream);
+/* DPM-Solver++ multistep (order <= 2, data prediction; ldm/models/diffusion/dpm_solver/dpm_solver.py:386-399,504-549,
+ * 755-810): x0 = (x - sigma*eps)/alpha;  x_t = c_x x - c_m m0 [- c_d (inv_r0 (m0 - m1))] */
+int tfmq_dpm_x0(tfmq_handle h, const float* x, const float* eps, float sigma, float alpha, float* out, size_t n, void* stream);
+int tfmq_dpm_update(tfmq_handle h, int order, const float* x, const float* m0, const float* m1_or_null, float c_x, float c_m,
+                    float c_d, float inv_r0, float* out, size_t n, void* stream);
 int tfmq_step_advance(tfmq_handle h, int32_t* step, int delta, void* stream);
 /* fp32 -> fp16 copy (round to nearest even): operand of tfmq_conv2d_f16 with x_f16 when the producer writes fp32 */
 int tfmq_f32_to_f16(tfmq_handle h, const float* x, uint16_t* y, size_t n, void* stream);

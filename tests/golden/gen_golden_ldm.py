@@ -123,6 +123,18 @@ def main():
                                 unconditional_guidance_scale=7.5, unconditional_conditioning=uc, eta=0.0, x_T=x_T,
                                 untill_fake_t=3)
     out["traj_fp_until3"] = samples
+    # DPM-Solver++ (multistep order 2, data prediction, CFG) through the reference's DPMSolverSampler, FP model
+    for name in ("ldm.models.diffusion.dpm_solver", "ldm.models.diffusion.dpm_solver.sampler"):
+        sys.modules.pop(name, None)       # the harness stubs these (annotation-only imports elsewhere); use the real ones
+    from ldm.models.diffusion.dpm_solver.sampler import DPMSolverSampler
+    dsampler = DPMSolverSampler(ldm)
+    samples, vt = dsampler.sample(S=6, conditioning=ctx, batch_size=2, shape=[4, 8, 8], verbose=False,
+                                  unconditional_guidance_scale=7.5, unconditional_conditioning=uc, eta=0.0, x_T=x_T)
+    out["dpm_fp_final"], out["dpm_fp_vect"] = samples, vt
+    samples, vt = dsampler.sample(S=6, conditioning=ctx, batch_size=2, shape=[4, 8, 8], verbose=False,
+                                  unconditional_guidance_scale=7.5, unconditional_conditioning=uc, eta=0.0, x_T=x_T,
+                                  untill_fake_t=3)
+    out["dpm_fp_until3"], out["dpm_fp_until3_vect"] = samples, vt
     qnn.set_quant_state(True, True)
     samples, _ = psampler.sample(S=6, conditioning=ctx, batch_size=2, shape=[4, 8, 8], verbose=False,
                                  unconditional_guidance_scale=7.5, unconditional_conditioning=uc, eta=0.0, x_T=x_T)

@@ -138,3 +138,40 @@ def test_text_guided_calibration_set(ldm):
                           untill_fake_t=2)
         assert torch.equal(ref, xs[:bs])
         assert torch.isfinite(xs).all()
+
+
+def test_dpm_solver_dropin_fp(ldm):
+    """DPMSolverSampler (DPM-Solver++ multistep order 2, data prediction, CFG 7.5) vs the reference's sampler on the FP
+    model, full trajectory and the `untill_fake_t` early stop; returned time labels are the reference's continuous t."""
+    from tfmq_dm_amd.ldm.dpm_solver import DPMSolverSampler, NoiseScheduleVP
+    g, q, m = ldm
+    ctx, uc, x_T = T(g["ctx"]).to(DEV), T(g["traj_uc"]).to(DEV), T(g["traj_xT"]).to(DEV)
+    s = DPMSolverSampler(m)
+    out, vt = s.sample(S=6, conditioning=ctx, batch_size=2, shape=[4, 8, 8], verbose=False, unconditional_guidance_scale=7.5,
+                       unconditional_conditioning=uc, eta=0.0, x_T=x_T)
+    assert rel_l2(out.cpu(), T(g["dpm_fp_final"])) <= 2e-2
+    np.testing.assert_allclose(vt.cpu().numpy(), g["dpm_fp_vect"], rtol=1e-6)
+    out3, vt3 = s.sample(S=6, conditioning=ctx, batch_size=2, shape=[4, 8, 8], verbose=False, unconditional_guidance_scale=7.5,
+                         unconditional_conditioning=uc, eta=0.0, x_T=x_T, untill_fake_t=3)
+    assert rel_l2(out3.cpu(), T(g["dpm_fp_until3"])) <= 2e-2
+    np.testing.assert_allclose(vt3.cpu().numpy(), g["dpm_fp_until3_vect"], rtol=1e-6)
+    # schedule: alpha^2 + sigma^2 = 1 and lambda = log(alpha / sigma), at the knots alpha = sqrt(alphas_cumprod)
+    ns = NoiseScheduleVP("discrete", alphas_cumprod=m.alphas_cumprod)
+    t = torch.tensor([0.001, 0.5, 1.0])
+    a, sg = ns.marginal_alpha(t), ns.marginal_std(t)
+    assert torch.allclose(a * a + sg * sg, torch.ones(3), atol=1e-6)
+    ac = m.alphas_cumprod.cpu()
+    assert torch.allclose(a, torch.stack([ac[0], ac[499], ac[999]]).sqrt(), rtol=1e-5)
+
+
+def test_dpm_kernels_bit_exact():
+    import tfmq_dm_amd.ops as ops
+    gen = torch.Generator().manual_seed(3)
+    x, m0, m1 = (torch.randn(2, 4, 8, 8, generator=gen) for _ in range(3))
+    sg, al, cx, cm, ir = 0.73, 0.41, 0.9, -0.37, 1.7
+    f = lambda v: torch.tensor(v, dtype=torch.float32)
+    assert torch.equal(ops.dpm_x0(x.to(DEV), m0.to(DEV), sg, al).cpu(), (x - f(sg) * m0) / f(al))
+    assert torch.equal(ops.dpm_update(1, x.to(DEV), m0.to(DEV), None, cx, cm).cpu(), f(cx) * x - f(cm) * m0)
+    cd = float(0.5 * f(cm))
+    want = f(cx) * x - f(cm) * m0 - f(cd) * (f(ir) * (m0 - m1))
+    assert torch.equal(ops.dpm_update(2, x.to(DEV), m0.to(DEV), m1.to(DEV), cx, cm, cd, ir).cpu(), want)

@@ -366,3 +366,49 @@ extern "C" int tfmq_f32_to_f16(tfmq_handle h, const float* x, uint16_t* y, size_
   TFMQ_LAUNCH_CHECK(h);
   return TFMQ_OK;
 }
+
+// ------------------------------------------------------------------ DPM-Solver++ (multistep, data prediction) pieces
+// x0 = (x - sigma_t * eps) / alpha_t          (DPM_Solver.data_prediction_fn, dpm_solver.py:386-399)
+__global__ __launch_bounds__(256) void k_dpm_x0(const float* __restrict__ x, const float* __restrict__ eps, float sigma,
+                                                float alpha, float* __restrict__ out, size_t n) {
+  const size_t stride = static_cast<size_t>(gridDim.x) * blockDim.x;
+  for (size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride)
+    out[i] = (x[i] - sigma * eps[i]) / alpha;
+}
+
+extern "C" int tfmq_dpm_x0(tfmq_handle h, const float* x, const float* eps, float sigma, float alpha, float* out, size_t n,
+                           void* stream) {
+  TFMQ_CHECK_ARG(h, h && x && eps && out, "dpm_x0: null pointer");
+  if (n == 0) return TFMQ_OK;
+  int blocks = ceil_div(static_cast<long>(n), 256);
+  if (blocks > h->cu_count * 8) blocks = h->cu_count * 8;
+  hipLaunchKernelGGL(k_dpm_x0, dim3(blocks), dim3(256), 0, as_stream(stream), x, eps, sigma, alpha, out, n);
+  TFMQ_LAUNCH_CHECK(h);
+  return TFMQ_OK;
+}
+
+// order 1: x_t = c_x x - c_m m0                                      (dpm_solver_first_update, :504-549)
+// order 2: x_t = c_x x - c_m m0 - c_d (inv_r0 (m0 - m1))            (multistep_dpm_solver_second_update, :755-810)
+// with c_x = sigma_t/sigma_s, c_m = alpha_t (e^{-h} - 1), c_d = 0.5 c_m, m0 / m1 = newest / previous data prediction
+__global__ __launch_bounds__(256) void k_dpm_update(int order, const float* __restrict__ x, const float* __restrict__ m0,
+                                                    const float* __restrict__ m1, float c_x, float c_m, float c_d, float inv_r0,
+                                                    float* __restrict__ out, size_t n) {
+  const size_t stride = static_cast<size_t>(gridDim.x) * blockDim.x;
+  for (size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) {
+    float v = c_x * x[i] - c_m * m0[i];
+    if (order == 2) v = v - c_d * (inv_r0 * (m0[i] - m1[i]));
+    out[i] = v;
+  }
+}
+
+extern "C" int tfmq_dpm_update(tfmq_handle h, int order, const float* x, const float* m0, const float* m1_or_null, float c_x,
+                               float c_m, float c_d, float inv_r0, float* out, size_t n, void* stream) {
+  TFMQ_CHECK_ARG(h, h && x && m0 && out && (order == 1 || (order == 2 && m1_or_null)), "dpm_update: bad argument");
+  if (n == 0) return TFMQ_OK;
+  int blocks = ceil_div(static_cast<long>(n), 256);
+  if (blocks > h->cu_count * 8) blocks = h->cu_count * 8;
+  hipLaunchKernelGGL(k_dpm_update, dim3(blocks), dim3(256), 0, as_stream(stream), order, x, m0, m1_or_null, c_x, c_m, c_d,
+                     inv_r0, out, n);
+  TFMQ_LAUNCH_CHECK(h);
+  return TFMQ_OK;
+}

@@ -28,7 +28,7 @@ class DiffusionWrapper(nn.Module):
 
     def forward(self, x, t, c_concat: list = None, c_crossattn: list = None):
         if hasattr(self, "tot"):
-            k = int(self.t_max - (int(t[0].item()) - 1) // self.tot)
+            k = int(self.t_max - (float(t[0].item()) - 1) // self.tot)     # t may be fractional (DPM-Solver)
             dm = self.diffusion_model
             if hasattr(dm, "set_act_table"):
                 if self._table_of is not self.ckpt:

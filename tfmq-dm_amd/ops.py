@@ -619,6 +619,21 @@ def ddim_update(x, eps, coef, step=None, noise=None, want_x0=False, out=None):
     return (xn, x0) if want_x0 else xn
 
 
+def dpm_x0(x: torch.Tensor, eps: torch.Tensor, sigma: float, alpha: float) -> torch.Tensor:
+    d = _dev(x)
+    o = _alloc_like(x)
+    handle(d).call("dpm_x0", _p(x), _p(eps), float(sigma), float(alpha), _p(o), x.numel(), _stream(d))
+    return o
+
+
+def dpm_update(order: int, x, m0, m1, c_x: float, c_m: float, c_d: float = 0.0, inv_r0: float = 0.0) -> torch.Tensor:
+    d = _dev(x)
+    o = _alloc_like(x)
+    handle(d).call("dpm_update", int(order), _p(x), _p(m0), _p(m1), float(c_x), float(c_m), float(c_d), float(inv_r0), _p(o),
+                   x.numel(), _stream(d))
+    return o
+
+
 def cfg_combine(eps_u: torch.Tensor, eps_c: torch.Tensor, scale: float, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """e_u + scale * (e_c - e_u), the classifier-free-guidance combine in the reference's operation order."""
     d = _dev(eps_u)

@@ -43,14 +43,14 @@ def generate_cali_data_ldm(model, T: int, c: int, batch_size: int, shape: List[i
     from tfmq_dm_amd.ldm.ddim import DDIMSampler, PLMSSampler
     if vanilla:
         raise NotImplementedError("Vanilla LDM is not implemented yet, because it needs 1000 steps to generate one sample.")
-    if dpm:
-        raise TfmqError("generate_cali_data_ldm: the DPM-Solver sampler is a next row (SURVEY §8f-1)")
-    sampler = PLMSSampler(model) if plms else DDIMSampler(model)
+    from tfmq_dm_amd.ldm.dpm_solver import DPMSolverSampler
+    sampler = DPMSolverSampler(model) if dpm else (PLMSSampler(model) if plms else DDIMSampler(model))
     tmp = []
     for t in range(1, T + 1):
         if t % c == 0:
-            x_t, _ = sampler.sample(S=T, batch_size=batch_size, shape=shape, verbose=False, eta=eta, untill_fake_t=t)
-            t_t = torch.full((batch_size,), _real_time(T, t), device=sampler.model.betas.device, dtype=torch.long)
+            x_t, t_t = sampler.sample(S=T, batch_size=batch_size, shape=shape, verbose=False, eta=eta, untill_fake_t=t)
+            if _is_ddim_like(sampler):       # DPM-Solver returns its own (continuous) time labels
+                t_t = torch.full((batch_size,), _real_time(T, t), device=sampler.model.betas.device, dtype=torch.long)
             tmp.append((x_t, t_t))
     return _stack(tmp)
 
