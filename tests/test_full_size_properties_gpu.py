@@ -1,0 +1,76 @@
+"""Size-independent properties at BASELINE.json's full sizes (Stable Diffusion v1 UNet, 859.5 M parameters, 64x64x4 latents,
+77x768 context, w4a8 with a Finite-Set table) -- the oracle cannot run these sizes in seconds, so the checks are structural:
+
+  * batch independence: eps of sample i does not depend on what else is in the batch (every kernel reduces per output
+    element / per image / per (batch, head) in a fixed order) -- bit-exact;
+  * run-to-run determinism -- bit-exact;
+  * the fused forward (int8 / fp16 epilogue modes, fused GEGLU) equals the un-fused forward that exposes every unit's
+    tensors -- bit-exact;
+  * the Finite-Set table is honoured: a different step row gives a different eps, the same row the same eps;
+  * quantizer idempotence at size: quantising the de-quantised tensor returns the same bins.
+"""
+import argparse
+import os
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def sd():
+    import bench
+    args = argparse.Namespace(batch=1, ddim_steps=2)
+    run, fwd, cpu, info = bench.setup_sd(args, torch.device(DEV), 0, lambda *a: None)
+    eng = fwd.__closure__ and None
+    return run, fwd, info
+
+
+def _engine_of(fwd):
+    for c in fwd.__closure__:
+        v = c.cell_contents
+        if hasattr(v, "forward") and hasattr(v, "qtable"):
+            return v
+    raise RuntimeError("engine not found")
+
+
+def test_sd_full_size_properties(sd):
+    run, fwd, info = sd
+    eng = _engine_of(fwd)
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(2, 64, 64, 4, generator=g).to(DEV)
+    ctx = torch.randn(2, 77, 768, generator=g).to(DEV)
+    t = torch.tensor([981.0, 981.0], device=DEV)
+    with torch.cuda.stream(info["stream"]):
+        info["step"].zero_()
+        e2 = eng.forward(x, t, ctx).clone()
+        e2b = eng.forward(x, t, ctx).clone()
+        ea = eng.forward(x[:1].contiguous(), t[:1], ctx[:1].contiguous()).clone()
+        eb = eng.forward(x[1:].contiguous(), t[1:], ctx[1:].contiguous()).clone()
+        e_taps = eng.forward(x, t, ctx, taps={}).clone()
+        info["step"].fill_(1)
+        e_step1 = eng.forward(x, t, ctx).clone()
+        info["step"].zero_()
+        info["stream"].synchronize()
+    assert torch.isfinite(e2).all()
+    assert torch.equal(e2, e2b)                                   # deterministic
+    assert torch.equal(e2[:1], ea) and torch.equal(e2[1:], eb)    # batch independent
+    assert torch.equal(e2, e_taps)                                # fused == un-fused
+    assert not torch.equal(e2, e_step1)                           # the step's activation table is used
+
+
+def test_quantizer_idempotent_at_size():
+    import tfmq_dm_amd.ops as ops
+    g = torch.Generator().manual_seed(1)
+    x = (torch.randn(16, 64, 64, 320, generator=g) * 3).to(DEV)
+    qt = torch.tensor([[0.0471, 113.0]], device=DEV)
+    sel = ops.qsel(qt)
+    q1 = ops.quantize_act(x, sel)
+    deq = (q1.float() + 128.0 - 113.0) * 0.0471
+    assert torch.equal(ops.quantize_act(deq, sel), q1)

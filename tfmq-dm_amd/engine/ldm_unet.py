@@ -269,10 +269,9 @@ class LdmUNetEngine(DdimUNetEngine):
                 taps[name] = ((tin, ctx), tok)
         h = tok.reshape(B, H, W, -1) if tok.dtype == torch.int8 else self._quant_in(pout, tok.reshape(B, H, W, -1))
         if taps is not None:
-            o = pout.run(h, want_stats=False)            # the layer's own output, without the fused residual
-            taps[p + ".proj_out"] = (h, o.clone())
-            ops.axpy(o, x, 1.0)
-            return o
+            # the layer's own output (its reconstruction target) excludes the residual; the data path stays the fused
+            # launch, so a tapped forward is bit-identical to the sampling forward
+            taps[p + ".proj_out"] = (h, pout.run(h, want_stats=False))
         if out_aq is not None and pout.kind == "w4a8":
             return pout.run(h, residual=x, want_stats=False, out_q8=out_aq)
         return pout.run(h, residual=x)
