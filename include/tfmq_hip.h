@@ -230,10 +230,12 @@ int tfmq_attention(tfmq_handle h, const float* q, const float* k, const float* v
                    float* out, int ldo, int8_t* yq, tfmq_qsel aq, int B, int heads, int Tq, int Tk, int d,
                    float scale, void* stream);
 /* Same operation on fp16 operands written by the projection GEMM (TFMQ_OUT_F16): q,k as above (ld in halves),
- * vt = V transposed, fp16 [B][heads*d][Tk] (tfmq_conv_desc.yt).  d % 8 == 0, d <= 160, Tk % 8 == 0. */
+ * vt = V transposed, fp16 [B][heads*d][Tk_stride] (tfmq_conv_desc.yt).  Tk_stride >= Tk keys per batch item are
+ * present in memory (k: [B][Tk_stride][ldk]); keys >= Tk are masked (a 77-token context is stored padded to 80).
+ * d % 8 == 0, d <= 160, Tk_stride % 8 == 0. */
 int tfmq_attention_f16(tfmq_handle h, const uint16_t* q, const uint16_t* k, const uint16_t* vt, int ldq, int ldk,
-                       float* out, int ldo, int8_t* yq, tfmq_qsel aq, int B, int heads, int Tq, int Tk, int d,
-                       float scale, void* stream);
+                       float* out, int ldo, int8_t* yq, tfmq_qsel aq, int B, int heads, int Tq, int Tk, int Tk_stride,
+                       int d, float scale, void* stream);
 
 /* ---- K11: sampler elementwise (generalized_steps, ddim/functions/denoising.py:31-37) ----- */
 /* coef: device [n_steps][4] = {sqrt(1-a_t), 1/sqrt(a_t)... see DESIGN.md}; step: device scalar.

@@ -106,3 +106,28 @@ def test_attention_wide_heads(ops, B, heads, Tq, Tk, d):
         qkv = torch.cat([q, k, v], -1).to(DEV)
         out2, _ = ops.attention(qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:], heads, scale)
         assert torch.equal(out2, out)
+
+
+def test_attention_f16_padded_keys(ops):
+    """Keys stored padded to a multiple of 8 (77 CLIP tokens -> 80 rows): the padding is masked, the result equals the
+    fp32-operand kernel on the un-padded operands to the f16 tolerance."""
+    gen = torch.Generator().manual_seed(77)
+    B, heads, Tq, Tk, d = 2, 8, 256, 77, 40
+    C = heads * d
+    q = torch.randn(B, Tq, C, generator=gen)
+    k = torch.randn(B, Tk, C, generator=gen)
+    v = torch.randn(B, Tk, C, generator=gen)
+    scale = d ** -0.5
+    qh = q.reshape(B, Tq, heads, d).permute(0, 2, 1, 3)
+    kh = k.reshape(B, Tk, heads, d).permute(0, 2, 1, 3)
+    vh = v.reshape(B, Tk, heads, d).permute(0, 2, 1, 3)
+    ref = (torch.softmax(qh @ kh.transpose(-1, -2) * scale, -1) @ vh).permute(0, 2, 1, 3).reshape(B, Tq, C)
+    kp = torch.zeros(B, 80, C)
+    kp[:, :Tk] = k
+    kp[:, Tk:] = 50.0            # poison: would dominate the softmax if the padding were not masked
+    vp = torch.zeros(B, 80, C)
+    vp[:, :Tk] = v
+    vp[:, Tk:] = 1e4
+    out, _ = ops.attention_f16(q.half().to(DEV), kp.half().to(DEV), vp.transpose(1, 2).contiguous().half().to(DEV), heads, scale,
+                               n_keys=Tk)
+    assert maxnorm(out.cpu(), ref) <= 3e-3

@@ -84,7 +84,7 @@ _SIGS = {
     "tfmq_geglu": (c_int, [c_void_p, c_void_p, C.c_long, c_int, QSel, c_void_p, c_void_p, c_void_p]),
     "tfmq_attention": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p, QSel,
                                c_int, c_int, c_int, c_int, c_int, c_float, c_void_p]),
-    "tfmq_attention_f16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, QSel, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p]),
+    "tfmq_attention_f16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, QSel, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p]),
     "tfmq_ddim_update": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p]),
     "tfmq_dpm_x0": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_float, c_void_p, c_size_t, c_void_p]),
     "tfmq_dpm_update": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_float, c_float, c_float, c_float, c_void_p, c_size_t, c_void_p]),

@@ -22,7 +22,7 @@ struct AttnHP {
   int ldo;
   int8_t* yq;
   tfmq_qsel aq;
-  int B, heads, Tq, Tk, d;
+  int B, heads, Tq, Tk, Tks, d;   // Tks: keys per batch item in memory (K rows, V^T row length), >= Tk, % 8 == 0
   float scale;
 };
 
@@ -83,8 +83,8 @@ __global__ __launch_bounds__(256) void k_attention_h(AttnHP p) {
     for (int ks = 0; ks < NKS; ++ks) asm volatile("" : "+v"(qf[ks]));
   }
 
-  const __half* kbase = p.k + static_cast<size_t>(b) * p.Tk * p.ldk + hd * d;
-  const __half* vbase = p.vt + (static_cast<size_t>(b) * p.heads + hd) * d * p.Tk;
+  const __half* kbase = p.k + static_cast<size_t>(b) * p.Tks * p.ldk + hd * d;
+  const __half* vbase = p.vt + (static_cast<size_t>(b) * p.heads + hd) * d * p.Tks;
   // ---- staging plan of this thread (the same for every key tile): global offset, LDS offset, first key
   const int kpieces = 64 * dp8, vpieces = d * 8;
   int k_go[KPT], k_lo[KPT], k_key[KPT], v_go[VPT], v_lo[VPT], v_key[VPT];
@@ -102,7 +102,7 @@ __global__ __launch_bounds__(256) void k_attention_h(AttnHP p) {
     const int idx = tid + it * 256;
     const int dc = idx >> 3, kp = idx & 7;
     v_key[it] = idx < vpieces ? kp * 8 : (1 << 30);
-    v_go[it] = dc * p.Tk + kp * 8;
+    v_go[it] = dc * p.Tks + kp * 8;
     v_lo[it] = dc * VROW + kp * 16;
   }
   uint4 kreg[KPT], vreg[VPT];
@@ -280,15 +280,15 @@ static int launch_attn_h(tfmq_handle h, const AttnHP& p, void* stream) {
 }
 
 extern "C" int tfmq_attention_f16(tfmq_handle h, const uint16_t* q, const uint16_t* k, const uint16_t* vt, int ldq, int ldk,
-                                  float* out, int ldo, int8_t* yq, tfmq_qsel aq, int B, int heads, int Tq, int Tk, int d,
-                                  float scale, void* stream) {
+                                  float* out, int ldo, int8_t* yq, tfmq_qsel aq, int B, int heads, int Tq, int Tk,
+                                  int Tk_stride, int d, float scale, void* stream) {
   TFMQ_CHECK_ARG(h, h && q && k && vt && (out || yq), "attention_f16: null pointer");
   TFMQ_CHECK_ARG(h, B > 0 && heads > 0 && Tq > 0 && Tk > 0 && d > 0, "attention_f16: bad shape");
-  TFMQ_CHECK_ARG(h, d % 8 == 0 && ldq % 8 == 0 && ldk % 8 == 0 && Tk % 8 == 0 && (!out || ldo % 4 == 0),
-                 "attention_f16: head dim, leading dims and Tk must be multiples of 8");
+  TFMQ_CHECK_ARG(h, d % 8 == 0 && ldq % 8 == 0 && ldk % 8 == 0 && Tk_stride % 8 == 0 && Tk_stride >= Tk && (!out || ldo % 4 == 0),
+                 "attention_f16: head dim, leading dims and Tk_stride must be multiples of 8, Tk_stride >= Tk");
   TFMQ_CHECK_ARG(h, !yq || aq.qtable, "attention_f16: quantised output needs a qparam");
   AttnHP p{reinterpret_cast<const __half*>(q), reinterpret_cast<const __half*>(k), reinterpret_cast<const __half*>(vt),
-           ldq, ldk, out, ldo, yq, aq, B, heads, Tq, Tk, d, scale};
+           ldq, ldk, out, ldo, yq, aq, B, heads, Tq, Tk, Tk_stride, d, scale};
   if (d <= 32) return launch_attn_h<2, 1>(h, p, stream);
   if (d == 40) return launch_attn_h<3, 2, 40>(h, p, stream);  // SD v1 at 64x64
   if (d <= 48) return launch_attn_h<3, 2>(h, p, stream);

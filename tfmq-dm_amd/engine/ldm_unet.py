@@ -69,6 +69,7 @@ class LdmUNetEngine(DdimUNetEngine):
                 sd2[k[:-6] + "bias"] = sd2[k[:-6] + "bias"][perm].contiguous()
         super().__init__(sd2, dict(cfg), device)
         self.res_names = ldm_resblock_paths(self.sd)
+        self._ctx_pad = None
         self.fuse_q8 = os.environ.get("TFMQ_NO_Q8") is None
 
     def tib_layout(self):
@@ -200,6 +201,26 @@ class LdmUNetEngine(DdimUNetEngine):
                 else:
                     o, _ = ops.attention_f16(y16[..., :Cc], y16[..., Cc:2 * Cc], vt, heads, float(d ** -0.5))
                     o = self._quant_in(to_out, o)
+                return self._tok(to_out, o, residual=x_res)
+        if (not self_attn) and self.calib is None and self._ctx_pad is not None:
+            # cross attention on fp16 operands: the context is stored padded to a multiple of 8 tokens (padding masked
+            # in the kernel), to_q writes fp16 rows, to_k fp16 rows, to_v its fp16 transpose
+            lq, lk, lv = L[p + ".to_q"], L[p + ".to_k"], L[p + ".to_v"]
+            cpad, n_ctx = self._ctx_pad
+            B, T, Cin = xq_src.shape
+            Cc = lq.p.cout
+            d = Cc // heads
+            if lq.kind == lk.kind == lv.kind == "w4a8" and ops.attention_f16_ok(d, cpad.shape[1]):
+                Bc, Lp, Dc = cpad.shape
+                q16 = ops.conv2d_w4a8(xq_src.reshape(B, T, 1, Cin), lq.p, lq.aq, out_f16=True).reshape(B, T, Cc)
+                k16 = ops.conv2d_w4a8(ops.quantize_act(cpad, lk.aq).reshape(Bc, Lp, 1, Dc), lk.p, lk.aq, out_f16=True)
+                _, vt = ops.conv2d_w4a8(ops.quantize_act(cpad, lv.aq).reshape(Bc, Lp, 1, Dc), lv.p, lv.aq, out_f16=True, t_col0=0)
+                aq = to_out.aq if to_out.kind == "w4a8" else None
+                if aq is not None:
+                    _, o = ops.attention_f16(q16, k16.reshape(Bc, Lp, Cc), vt, heads, float(d ** -0.5), aq, want_f32=False,
+                                             n_keys=n_ctx)
+                else:
+                    o, _ = ops.attention_f16(q16, k16.reshape(Bc, Lp, Cc), vt, heads, float(d ** -0.5), n_keys=n_ctx)
                 return self._tok(to_out, o, residual=x_res)
         if self_attn and p in self.fused_qkv:
             qkv = self._tok(self.fused_qkv[p], xq_src)
@@ -352,6 +373,16 @@ class LdmUNetEngine(DdimUNetEngine):
                 return dict(rowadd=self.tib_table[0, o:], rowadd_ld=0, rowadd_step=self.step,
                             rowadd_step_stride=self.tib_table.shape[1])
         ctx = None if context is None else context.contiguous()
+        self._ctx_pad = None
+        if ctx is not None and self.calib is None:
+            Bc, Lc, Dc = ctx.shape
+            Lp = (Lc + 7) // 8 * 8
+            cpad = ctx
+            if Lp != Lc:      # e.g. 77 CLIP tokens -> 80 rows; the 3 zero rows are masked keys in the attention kernel
+                cpad = ops._alloc(Bc, Lp, Dc, dtype=torch.float32, device=ctx.device)
+                cpad.zero_()
+                cpad[:, :Lc].copy_(ctx)
+            self._ctx_pad = (cpad, Lc)
         hs = []
         h = x
         for i in range(_n_children(self.sd, "input_blocks")):

@@ -582,21 +582,24 @@ def _attention_wide(q, k, v, heads: int, scale: float, aq: Optional[QSel], want_
 
 
 def attention_f16_ok(d: int, Tk: int) -> bool:
+    """Tk = keys per batch item as stored (a multiple of 8; fewer may be valid, see attention_f16(n_keys=...))."""
     return d % 8 == 0 and d <= 160 and Tk % 8 == 0
 
 
 def attention_f16(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, heads: int, scale: float,
-                  aq: Optional[QSel] = None, want_f32: bool = True):
+                  aq: Optional[QSel] = None, want_f32: bool = True, n_keys: Optional[int] = None):
     """q, k: fp16 [B,T,*] views with unit channel stride (column slices of the fused projection's fp16 output);
-    vt: fp16 [B, heads*d, Tk] (conv2d_w4a8(..., out_f16=True, t_col0=...)).  Returns (out fp32 | None, yq int8 | None)."""
+    vt: fp16 [B, heads*d, Tk] (conv2d_w4a8(..., out_f16=True, t_col0=...)).  n_keys: only the first n_keys of the Tk
+    stored keys are real (context padded to a multiple of 8).  Returns (out fp32 | None, yq int8 | None)."""
     d_ = _dev(q)
     B, Tq, Cq = q.shape
-    Tk = k.shape[1]
+    Tks = k.shape[1]
+    Tk = Tks if n_keys is None else int(n_keys)
     dh = Cq // heads
     for t in (q, k):
         if t.dtype != torch.float16 or t.stride(-1) != 1 or t.stride(0) != t.shape[1] * t.stride(1):
             raise TfmqError("attention_f16: q/k must be fp16 [B,T,C] with unit channel stride and dense batch/token strides")
-    if vt.dtype != torch.float16 or not vt.is_contiguous() or tuple(vt.shape) != (B, Cq, Tk):
+    if vt.dtype != torch.float16 or not vt.is_contiguous() or tuple(vt.shape) != (B, Cq, Tks) or not 0 < Tk <= Tks:
         raise TfmqError("attention_f16: vt must be contiguous fp16 [B, heads*d, Tk]")
     out = _alloc(B, Tq, Cq, dtype=torch.float32, device=q.device) if want_f32 else None
     yq = None
@@ -605,7 +608,7 @@ def attention_f16(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, heads: int
         yq = _alloc(B, Tq, Cq, dtype=torch.int8, device=q.device)
         sel = aq
     handle(d_).call("attention_f16", _p(q), _p(k), _p(vt), q.stride(1), k.stride(1), _p(out), Cq, _p(yq), sel, B,
-                    heads, Tq, Tk, dh, float(scale), _stream(d_))
+                    heads, Tq, Tk, Tks, dh, float(scale), _stream(d_))
     return out, yq
 
 
