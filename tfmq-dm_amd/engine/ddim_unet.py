@@ -19,6 +19,8 @@ Layer modes (QuantLayer.forward, quant/quant_layer.py:306-340):
 """
 from __future__ import annotations
 
+import os
+
 from typing import Dict, List, Optional, Sequence
 
 import torch
@@ -231,7 +233,7 @@ class DdimUNetEngine:
         return self.tib_table
 
     # ------------------------------------------------------------------ blocks
-    def _gn(self, name, x1, x2, silu, layer: Optional[_Layer], want_cat=False, eps=1e-6, half=False):
+    def _gn(self, name, x1, x2, silu, layer: Optional[_Layer], want_cat=False, eps=1e-6, half=False, half_main=False):
         """half: the fp outputs of this GroupNorm (the concat copy for an un-quantised shortcut conv, or the normalised
         tensor itself when its consumer is an un-quantised conv) may be written as fp16 -- those convs round their input
         to fp16 anyway, so the result is bit-identical and the conv runs on the LDS-DMA path at half the bytes."""
@@ -241,8 +243,12 @@ class DdimUNetEngine:
                                         want_f32=True, want_cat=want_cat)
             self._observe(aq, yf, getattr(layer, "sibling_qids", ()))
             return ops.quantize_act(yf, aq), xcat
-        # a fp32 main output (weight-only / FP consumer that is a QuantLayer) stays fp32 unless the caller opted in
-        half = half and (aq is not None or layer is None)
+        # half: fp16 for the concat copy (and for the main output when there is no consumer layer, e.g. conv_out's
+        # input); half_main: the main output feeds an un-quantised / weight-only conv directly, which takes fp16 too.
+        # One flag covers both outputs of the kernel, so they must agree.
+        if aq is None and layer is not None:
+            main_ok = half_main and self._fp_conv_half_ok(layer)
+            half = main_ok and (half or not want_cat)
         yq, yf, xcat = ops.groupnorm(x1, self.sd[name + ".weight"], self.sd[name + ".bias"], eps, silu, aq, x2=x2,
                                      want_cat=want_cat, half_out=half)
         return (yq if aq is not None else yf), xcat
@@ -256,9 +262,10 @@ class DdimUNetEngine:
         if x2 is not None and not has_sc:
             raise TfmqError(f"{p}: concatenated input without nin_shortcut is not a DDPM-UNet block")
         half = has_sc and self._fp_conv_half_ok(L[p + ".nin_shortcut"])
-        h, xcat = self._gn(p + ".norm1", x1, x2, True, L[p + ".conv1"], want_cat=has_sc and (x2 is not None or half), half=half)
+        h, xcat = self._gn(p + ".norm1", x1, x2, True, L[p + ".conv1"], want_cat=has_sc and (x2 is not None or half), half=half,
+                           half_main=True)
         h = L[p + ".conv1"].run(h, pad=(1, 1, 1, 1), **rowadd_kw)
-        h, _ = self._gn(p + ".norm2", h, None, True, L[p + ".conv2"])
+        h, _ = self._gn(p + ".norm2", h, None, True, L[p + ".conv2"], half_main=True)
         if has_sc:
             sc = L[p + ".nin_shortcut"].run(xcat if xcat is not None else x1)
         else:

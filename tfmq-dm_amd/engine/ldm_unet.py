@@ -172,9 +172,9 @@ class LdmUNetEngine(DdimUNetEngine):
             raise TfmqError(f"{p}: concatenated input without skip_connection")
         half = has_skip and self._fp_conv_half_ok(L[p + ".skip_connection"])
         h, xcat = self._gn(p + ".in_layers.0", x1, x2, True, cin, want_cat=has_skip and (x2 is not None or half), eps=1e-5,
-                           half=half)
+                           half=half, half_main=True)
         h = cin.run(h, pad=(1, 1, 1, 1), **rowadd_kw)
-        h, _ = self._gn(p + ".out_layers.0", h, None, True, cout, eps=1e-5)
+        h, _ = self._gn(p + ".out_layers.0", h, None, True, cout, eps=1e-5, half_main=True)
         sc = L[p + ".skip_connection"].run(xcat if xcat is not None else x1, want_stats=False) if has_skip else x1
         if out_aq is not None and cout.kind == "w4a8":
             return cout.run(h, pad=(1, 1, 1, 1), residual=sc, want_stats=False, out_q8=out_aq)
