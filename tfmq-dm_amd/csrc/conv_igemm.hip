@@ -23,9 +23,9 @@
 //   k_conv_igemm (f16 layers; w4a8 shapes the DMA loop does not take): register-prefetched, double-buffered.
 #include "common.hpp"
 #include <type_traits>
+#include <cstdlib>
 #ifdef TFMQ_PHASE_TIMERS
 #include <cstdio>
-#include <cstdlib>
 #endif
 
 typedef int v4i __attribute__((ext_vector_type(4)));
@@ -86,7 +86,7 @@ __host__ __device__ constexpr int epi_lds_bytes() {
 // (per-lane 4-byte strided accesses made this phase 2.5x slower than the MFMA loop).  The same
 // pass produces the per-channel sum / sum-of-squares of every SEG-row segment for the GroupNorm
 // that consumes this tensor, so that GroupNorm never has to re-read it for statistics.
-template <bool INT8, int WAVES_M, int WAVES_N, int WM_TILES, int WN_TILES, typename ACC>
+template <bool INT8, int WAVES_M, int WAVES_N, int WM_TILES, int WN_TILES, bool RES_PRE = false, typename ACC>
 __device__ __forceinline__ void conv_epilogue(const ConvP& p, unsigned char* lds, ACC (&acc)[WM_TILES][WN_TILES],
                                               int m0, int n0, float2 aqp, int za) {
   constexpr int BM = WAVES_M * WM_TILES * 32;
@@ -135,7 +135,20 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, unsigned char* lds
     }
   }
 
+  // the residual rows of a pass are requested before its accumulators are staged, so their latency (HBM: these
+  // layers run at the fp32-activation roofline) overlaps the staging and the barrier instead of following them
+  // (RES_PRE kernels are launched only for vectorisable fp32 / Q8 outputs with a residual; a separate instantiation,
+  // because the 32 extra live registers cost the other output modes spills)
   for (int pass = 0; pass < BM / PR; ++pass) {
+    float4 rpre[RES_PRE ? RPT : 1];
+    if constexpr (RES_PRE) {
+#pragma unroll
+      for (int k = 0; k < RPT; ++k) {
+        const int m = m0 + pass * PR + tr * RPT + k, n = n0 + c4;
+        rpre[k] = (m < p.M && n < d.Cout) ? *reinterpret_cast<const float4*>(d.residual + static_cast<size_t>(m) * d.Cout + n)
+                                          : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
     __syncthreads();  // previous pass fully consumed (also orders the main loop's LDS reads before the overwrite)
     if (seg && pass == 0) {
       for (int o = tid; o < BN; o += 256) ldsG[o] = make_float2(0.0f, 0.0f);
@@ -257,7 +270,9 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, unsigned char* lds
           v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
         }
         if (d.residual) {
-          const float4 a = *reinterpret_cast<const float4*>(d.residual + static_cast<size_t>(m) * d.Cout + n);
+          float4 a;
+          if constexpr (RES_PRE) a = rpre[k];
+          else a = *reinterpret_cast<const float4*>(d.residual + static_cast<size_t>(m) * d.Cout + n);
           v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
         }
         if (q8) {     // the only consumer is the next QuantLayer's activation quantizer: write its bins
@@ -336,8 +351,8 @@ __device__ __forceinline__ int xcd_tile_id() {
 // F16 = true: un-quantised layers on fp16 operands (fp16 NHWC activations written by the producing kernel, 32
 // channels per K-step, f16 MFMA, fp32 accumulation) -- the same 64-byte rows, swizzle and pipeline.
 // ================================================================================================
-template <bool F16, int WAVES_M, int WAVES_N, int WM_TILES, int WN_TILES>
-__global__ __launch_bounds__(256, 3) void k_conv_dma(ConvP p) {
+template <bool F16, int WAVES_M, int WAVES_N, int WM_TILES, int WN_TILES, bool RES_PRE = false>
+__global__ __launch_bounds__(256, (WM_TILES * WN_TILES > 4) ? 2 : 3) void k_conv_dma(ConvP p) {
   constexpr int BM = WAVES_M * WM_TILES * 32;
   constexpr int BN = WAVES_N * WN_TILES * 32;
   constexpr int STAGE = (BM + BN) * 64;          // bytes of one K-step: A tile then B tile, 64-byte rows
@@ -349,8 +364,12 @@ __global__ __launch_bounds__(256, 3) void k_conv_dma(ConvP p) {
   constexpr int LDS_MAIN = NST * STAGE;
   constexpr int LDS_EPI = epi_lds_bytes<BM, BN>();
   constexpr int LDS_BODY = LDS_MAIN > LDS_EPI ? LDS_MAIN : LDS_EPI;
+  // 256-row tiles (stride 1, no fused upsample -- the launcher's rule): the offset table shrinks to {offset of the
+  // window origin, bit mask of in-image taps} per row, so two workgroups (2 x 80 KiB) still share a CU
+  constexpr bool COMPACT = BM > 128;
+  constexpr int TAB_BYTES = COMPACT ? BM * 8 : MAXT * BM * 4;
   static_assert(WAVES_M * WAVES_N == 4, "4 waves");
-  __shared__ __attribute__((aligned(1024))) unsigned char lds[LDS_BODY + MAXT * BM * 4];
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[LDS_BODY + TAB_BYTES];
   int* tab = reinterpret_cast<int*>(lds + LDS_BODY);  // [tap][row] byte offset of the input pixel, -1 = padding
   TFMQ_MARK(0);
 
@@ -369,7 +388,23 @@ __global__ __launch_bounds__(256, 3) void k_conv_dma(ConvP p) {
   // ---- pixel offset table (any stride / padding / fused 2x upsample).  A Linear / 1x1 stride-1 conv needs none:
   // pixel m reads input pixel m (most launches of a transformer UNet: no table, no barrier in the prologue)
   const bool pointwise = d.KH * d.KW == 1 && d.stride == 1 && !d.up2x && d.pad_t == 0 && d.pad_l == 0;
-  if (!pointwise) {
+  if (!pointwise && COMPACT) {
+    const int taps = d.KH * d.KW, hw = d.Ho * d.Wo;
+    for (int row = tid; row < BM; row += 256) {
+      const int m = m0 + row;
+      int base = 0, mask = 0;
+      if (m < p.M) {
+        const int b = m / hw, r = m - b * hw;
+        const int ho = r / d.Wo, wo = r - ho * d.Wo;
+        base = ((b * d.H + ho - d.pad_t) * d.W + wo - d.pad_l) * d.Cin * (F16 ? 2 : 1);
+        for (int tap = 0; tap < taps; ++tap) {
+          const int hi = ho + tap / d.KW - d.pad_t, wi = wo + tap % d.KW - d.pad_l;
+          mask |= (hi >= 0 && hi < d.H && wi >= 0 && wi < d.W) ? (1 << tap) : 0;
+        }
+      }
+      reinterpret_cast<int2*>(tab)[row] = make_int2(base, mask);
+    }
+  } else if (!pointwise) {
     const int taps = d.KH * d.KW, hw = d.Ho * d.Wo;
     for (int idx = tid; idx < taps * BM; idx += 256) {
       const int tap = idx / BM, row = idx - tap * BM;
@@ -432,8 +467,17 @@ __global__ __launch_bounds__(256, 3) void k_conv_dma(ConvP p) {
   int i_tap = 0, i_chunk = 0;
   auto issue = [&](int s, int stage) {
     if (i_chunk == 0 && !pointwise) {
+      if constexpr (COMPACT) {
+        const int tapoff = ((i_tap / d.KW) * d.W + (i_tap % d.KW)) * d.Cin * (F16 ? 2 : 1);
 #pragma unroll
-      for (int it = 0; it < A_CH; ++it) a_off[it] = tab[i_tap * BM + a_row[it]];
+        for (int it = 0; it < A_CH; ++it) {
+          const int2 e = reinterpret_cast<const int2*>(tab)[a_row[it]];
+          a_off[it] = ((e.y >> i_tap) & 1) ? e.x + tapoff : -1;
+        }
+      } else {
+#pragma unroll
+        for (int it = 0; it < A_CH; ++it) a_off[it] = tab[i_tap * BM + a_row[it]];
+      }
     }
     const int c0 = i_chunk * 64;
     const unsigned sbase = lds0 + stage * STAGE;
@@ -506,7 +550,7 @@ __global__ __launch_bounds__(256, 3) void k_conv_dma(ConvP p) {
   }
 
   TFMQ_MARK(2);
-  conv_epilogue<!F16, WAVES_M, WAVES_N, WM_TILES, WN_TILES>(p, lds, acc, m0, n0, aqp, za);
+  conv_epilogue<!F16, WAVES_M, WAVES_N, WM_TILES, WN_TILES, RES_PRE>(p, lds, acc, m0, n0, aqp, za);
   TFMQ_MARK(3);
 }
 
@@ -816,7 +860,14 @@ static int launch_conv(tfmq_handle h, const tfmq_conv_desc* dd, void* stream) {
   // (a statistics segment must not span tiles, so 128-pixel segments keep the 128-row tile)
   const bool small = !narrow && !geglu && !(d.stats && d.stats_seg > 64) &&
                      static_cast<long>((p.M + 127) / 128) * ((d.Cout + 127) / 128) < 2L * h->cu_count;
-  const int BM = small ? 64 : 128, BN = narrow ? 32 : (small ? 64 : 128);
+  // large-M layers: 256 x 128 tiles move a quarter fewer L2 -> LDS bytes per MFMA (the K loop is bound by that path)
+  const bool dma8 = INT8 && d.Cin % 64 == 0 && d.KH * d.KW <= 9 &&
+                    static_cast<size_t>(d.B) * d.H * d.W * d.Cin < (static_cast<size_t>(1) << 31);
+  // (measured: pays for the fp16-output token Linears -- q/k/v projections, -16 % -- whose epilogue is light; layers
+  // with the fp32 residual epilogue lose more from 2 instead of 3 resident workgroups than the K loop gains)
+  const bool big = dma8 && !narrow && !small && d.stride == 1 && !d.up2x && d.out_mode == TFMQ_OUT_F16 &&
+                   static_cast<long>((p.M + 127) / 128) * ((d.Cout + 127) / 128) >= 4L * h->cu_count;
+  const int BM = big ? 256 : (small ? 64 : 128), BN = narrow ? 32 : (small ? 64 : 128);
   p.tiles_n = (d.Cout + BN - 1) / BN;
   const int tiles_m = (p.M + BM - 1) / BM;
   dim3 grid(static_cast<unsigned>(p.tiles_n) * tiles_m);
@@ -831,8 +882,13 @@ static int launch_conv(tfmq_handle h, const tfmq_conv_desc* dd, void* stream) {
       if (!dbuf) (void)hipMalloc(reinterpret_cast<void**>(&dbuf), sizeof(unsigned long long) * 4 * (1u << 20));
       p.dbg = grid.x <= (1u << 20) ? dbuf : nullptr;
 #endif
+      // residual rows prefetched ahead of the staging (see conv_epilogue): the epilogue's vector path only
+      const bool res_pre = d.residual && (d.out_mode == TFMQ_OUT_F32 || d.out_mode == TFMQ_OUT_Q8) &&
+                           ((d.Cout | d.ldy | d.y_coff) & 3) == 0 && (!d.rowadd || (d.rowadd_ld & 3) == 0);
       if (narrow) hipLaunchKernelGGL((k_conv_dma<false, 4, 1, 1, 1>), grid, dim3(256), 0, st, p);
       else if (small) hipLaunchKernelGGL((k_conv_dma<false, 2, 2, 1, 1>), grid, dim3(256), 0, st, p);
+      else if (big) hipLaunchKernelGGL((k_conv_dma<false, 2, 2, 4, 2>), grid, dim3(256), 0, st, p);
+      else if (res_pre) hipLaunchKernelGGL((k_conv_dma<false, 2, 2, 2, 2, true>), grid, dim3(256), 0, st, p);
       else hipLaunchKernelGGL((k_conv_dma<false, 2, 2, 2, 2>), grid, dim3(256), 0, st, p);
 #ifdef TFMQ_PHASE_TIMERS
       if (p.dbg && getenv("TFMQ_PHASE_PRINT")) {
