@@ -12,11 +12,12 @@ def timeit(fn, n=10):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1)/n
 qt = torch.tensor([[0.05, 120.0]], device=DEV); sel = ops.qsel(qt)
-cases = [(32,4096,1,320,2560,1,"geglu"), (32,4096,1,320,320,1,"res"), (32,4096,1,320,960,1,"qkv"),
-         (32,4096,1,1280,320,1,"res"), (32,1024,1,640,5120,1,"geglu"), (32,1024,1,640,640,1,"res"), (32,1024,1,2560,640,1,"res"),
-         (32,256,1,1280,10240,1,"geglu"), (32,256,1,5120,1280,1,"res"), (32,256,1,1280,1280,1,"res"),
-         (32,64,64,320,320,3,"res"), (32,32,32,640,640,3,"res"), (32,16,16,1280,1280,3,"res"), (32,8,8,1280,1280,3,"res"),
-         (32,16,16,2560,1280,3,"f32")]
+cases = [(32,4096,1,320,2560,1,"geglu"), (32,4096,1,1280,320,1,"res"), (32,1024,1,2560,640,1,"res"), (32,256,1,5120,1280,1,"res"),
+         (32,64,64,320,320,3,"res"), (32,32,32,640,640,3,"res"), (32,16,16,1280,1280,3,"res"), (32,16,16,2560,1280,3,"f32")]
+if os.environ.get("PHASE_CASES") == "all":
+    cases += [(32,4096,1,320,320,1,"res"), (32,4096,1,320,960,1,"qkv"), (32,1024,1,640,5120,1,"geglu"), (32,1024,1,640,640,1,"res"),
+              (32,256,1,1280,10240,1,"geglu"), (32,256,1,1280,1280,1,"res"), (32,8,8,1280,1280,3,"res")]
+if os.environ.get("PHASE_NO_GEGLU"): cases = [c for c in cases if c[6] != "geglu"]
 for (B,H,W,cin,cout,k,mode) in cases:
     x = (torch.randn(B,H,W,cin, device=DEV)*40).clamp(-128,127).to(torch.int8)
     w = torch.randn(cout,cin,k,k, device=DEV)*0.02

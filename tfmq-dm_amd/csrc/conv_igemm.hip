@@ -543,8 +543,16 @@ __global__ __launch_bounds__(256, (WM_TILES * WN_TILES > 4) ? 2 : 3) void k_conv
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     // ... and after the barrier every wave's have, and nobody still reads the stage refilled below
     asm volatile("s_barrier" ::: "memory");
+    // diagnostics builds (-DTFMQ_DBG_NO_DMA / -DTFMQ_DBG_NO_MFMA, results are garbage): the K loop without its
+    // L2 -> LDS traffic, or without its fragment reads and MFMAs -- DESIGN.md section 4 quotes both
+#ifdef TFMQ_DBG_NO_DMA
+    if (s + 2 < p.nsteps && s < 1) issue(s + 2, st_i);
+#else
     if (s + 2 < p.nsteps) issue(s + 2, st_i);
+#endif
+#ifndef TFMQ_DBG_NO_MFMA
     compute(st_c);
+#endif
     st_c = st_c == NST - 1 ? 0 : st_c + 1;
     st_i = st_i == NST - 1 ? 0 : st_i + 1;
   }
