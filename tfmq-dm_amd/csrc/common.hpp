@@ -19,6 +19,25 @@ struct tfmq_ctx {
   // 256 rows x 64 bytes, row v filled with byte v: source of "real zero" activations (bin za-128) for the
   // padded taps of the LDS-DMA convolution, whose loads cannot substitute a value in registers.
   unsigned char* pad_table = nullptr;
+  // grow-only scratch of the split-K reconstruction GEMM (partial sums); used in stream order by one stream at a time
+  float* gemm_ws = nullptr;
+  size_t gemm_ws_bytes = 0;
+};
+
+// strided fp32 GEMM of the reconstruction units (recon_kernels.hip, gemm_f32_mfma.hip)
+struct GemmP {
+  const float* A; const float* B; float* C;
+  int M, N, K;
+  long sam, sak, sbk, sbn, scm;      // element strides: A(m,k)=A[m*sam+k*sak], B(k,n)=B[k*sbk+n*sbn], C(m,n)=C[m*scm+n]
+  long bsa, bsb, bsc;                // batch strides
+  float alpha;
+  const float* bias;                 // [N] or null
+  const float* rowadd;               // rowadd[(m / rows_per_img) * rowadd_ld + n] or null
+  int rows_per_img, rowadd_ld;
+  const float* residual;             // same layout as C, or null
+  int accumulate;                    // C += result
+  int ksplit, kchunk;                // split-K: blockIdx.z = batch * ksplit + split, split covers K range [split*kchunk, +kchunk)
+  float* partial;                    // [ksplit][batch][M][N] raw partial sums (ksplit > 1)
 };
 
 #define TFMQ_CHECK_ARG(h, cond, msg)          \

@@ -37,6 +37,7 @@ extern "C" int tfmq_destroy(tfmq_handle h) {
   for (auto e : h->events)
     if (e) (void)hipEventDestroy(e);
   if (h->pad_table) (void)hipFree(h->pad_table);
+  if (h->gemm_ws) (void)hipFree(h->gemm_ws);
   delete h;
   return TFMQ_OK;
 }

@@ -10,18 +10,6 @@
 
 typedef float v16f __attribute__((ext_vector_type(16)));
 
-struct GemmP {
-  const float* A; const float* B; float* C;
-  int M, N, K;
-  long sam, sak, sbk, sbn, scm;
-  long bsa, bsb, bsc;
-  float alpha;
-  const float* bias;
-  const float* rowadd;
-  int rows_per_img, rowadd_ld;
-  const float* residual;
-  int accumulate;
-};
 
 // One operand tile [R rows][16 k] -> LDS [16][R + 4].  (rs, ks) = element strides of the row / k index.
 template <int R>
@@ -89,7 +77,15 @@ __global__ __launch_bounds__(256) void k_gemm_f32_mfma(GemmP p) {
   static_assert(WAVES_M * WAVES_N == 4, "4 waves");
   __shared__ __attribute__((aligned(16))) float sA[2][16 * (BM + 4)];
   __shared__ __attribute__((aligned(16))) float sB[2][16 * (BN + 4)];
-  const int bz = blockIdx.z;
+  // split-K (skinny outputs with a long reduction: weight gradients dW = X^T dY, K = B*T): blockIdx.z also carries the
+  // K slice; slices write raw partial tiles, k_gemm_splitk_reduce adds them in slice order (deterministic)
+  int bz = blockIdx.z, kb = 0, ke = p.K;
+  if (p.ksplit > 1) {
+    const int sp = bz % p.ksplit;
+    bz /= p.ksplit;
+    kb = sp * p.kchunk;
+    ke = kb + p.kchunk < p.K ? kb + p.kchunk : p.K;
+  }
   const float* A = p.A + bz * p.bsa;
   const float* B = p.B + bz * p.bsb;
   float* C = p.C + bz * p.bsc;
@@ -111,17 +107,17 @@ __global__ __launch_bounds__(256) void k_gemm_f32_mfma(GemmP p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-  const int nk = (p.K + 15) / 16;
-  la.load(A, p.sam, p.sak, m0, 0, p.M, p.K);
-  lb.load(B, p.sbn, p.sbk, n0, 0, p.N, p.K);
+  const int nk = (ke - kb + 15) / 16;
+  la.load(A, p.sam, p.sak, m0, kb, p.M, ke);
+  lb.load(B, p.sbn, p.sbk, n0, kb, p.N, ke);
   la.store(sA[0]);
   lb.store(sB[0]);
   __syncthreads();
   for (int s = 0; s < nk; ++s) {
     const int buf = s & 1;
     if (s + 1 < nk) {
-      la.load(A, p.sam, p.sak, m0, (s + 1) * 16, p.M, p.K);
-      lb.load(B, p.sbn, p.sbk, n0, (s + 1) * 16, p.N, p.K);
+      la.load(A, p.sam, p.sak, m0, kb + (s + 1) * 16, p.M, ke);
+      lb.load(B, p.sbn, p.sbk, n0, kb + (s + 1) * 16, p.N, ke);
     }
     const float* a_l = sA[buf] + (wm * WM_TILES * 32) + l32;
     const float* b_l = sB[buf] + (wn * WN_TILES * 32) + l32;
@@ -156,6 +152,11 @@ __global__ __launch_bounds__(256) void k_gemm_f32_mfma(GemmP p) {
       for (int r = 0; r < 16; ++r) {
         const int m = m0 + (wm * WM_TILES + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
         if (m >= p.M) continue;
+        if (p.ksplit > 1) {
+          p.partial[(static_cast<size_t>(blockIdx.z % p.ksplit) * gridDim.z / p.ksplit + bz) * p.M * p.N +
+                    static_cast<size_t>(m) * p.N + n] = acc[i][j][r];
+          continue;
+        }
         float v = p.alpha * acc[i][j][r];
         if (p.bias) v += bv;
         if (p.rowadd) v += p.rowadd[static_cast<long>(m / p.rows_per_img) * p.rowadd_ld + n];
@@ -166,15 +167,61 @@ __global__ __launch_bounds__(256) void k_gemm_f32_mfma(GemmP p) {
     }
 }
 
-// called from tfmq_gemm_f32 (recon_kernels.hip) when the problem is large enough for 128-row tiles
-int tfmq_gemm_f32_mfma_launch(const void* pp, int M, int N, int batch, hipStream_t st) {
-  const GemmP& p = *static_cast<const GemmP*>(pp);
-  if (N > 64) {
-    dim3 grid((N + 127) / 128, (M + 127) / 128, batch);
-    hipLaunchKernelGGL((k_gemm_f32_mfma<2, 2, 2, 2>), grid, dim3(256), 0, st, p);
-  } else {
-    dim3 grid((N + 63) / 64, (M + 127) / 128, batch);
-    hipLaunchKernelGGL((k_gemm_f32_mfma<4, 1, 1, 2>), grid, dim3(256), 0, st, p);
+// C(bz, m, n) = alpha * sum_s partial[s][bz][m][n]  (+ bias / rowadd / residual, accumulate) -- the epilogue of the slices
+__global__ void k_gemm_splitk_reduce(GemmP p, int batch) {
+  const size_t per = static_cast<size_t>(p.M) * p.N, total = per * batch;
+  for (size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < total;
+       i += static_cast<size_t>(gridDim.x) * blockDim.x) {
+    const int bz = static_cast<int>(i / per);
+    const size_t r = i - static_cast<size_t>(bz) * per;
+    const int m = static_cast<int>(r / p.N), n = static_cast<int>(r - static_cast<size_t>(m) * p.N);
+    float a = 0.0f;
+    for (int sp = 0; sp < p.ksplit; ++sp) a += p.partial[static_cast<size_t>(sp) * total + i];
+    float v = p.alpha * a;
+    if (p.bias) v += p.bias[n];
+    if (p.rowadd) v += p.rowadd[static_cast<long>(m / p.rows_per_img) * p.rowadd_ld + n];
+    if (p.residual) v += p.residual[bz * p.bsc + m * p.scm + n];
+    float* c = p.C + bz * p.bsc + m * p.scm + n;
+    *c = p.accumulate ? *c + v : v;
   }
-  return 0;
+}
+
+// called from tfmq_gemm_f32 (recon_kernels.hip) when the problem is large enough for 128-row tiles
+int tfmq_gemm_f32_mfma_launch(tfmq_handle h, GemmP& p, int batch, hipStream_t st) {
+  const int M = p.M, N = p.N;
+  const int BN = N > 64 ? 128 : 64;
+  const long tiles = static_cast<long>((N + BN - 1) / BN) * ((M + 127) / 128) * batch;
+  // fewer tiles than CUs and a long reduction: slice K so that ~2 blocks per CU exist, >= 256 elements per slice
+  int ks = 1;
+  if (tiles < h->cu_count && p.K >= 1024) {
+    ks = static_cast<int>((2L * h->cu_count + tiles - 1) / tiles);
+    if (ks > p.K / 256) ks = p.K / 256;
+    if (ks > 64) ks = 64;
+    if (static_cast<long>(batch) * ks > 65535) ks = 65535 / batch;
+  }
+  if (ks > 1) {
+    p.kchunk = ((p.K + ks - 1) / ks + 15) / 16 * 16;
+    ks = (p.K + p.kchunk - 1) / p.kchunk;
+    const size_t need = static_cast<size_t>(ks) * batch * M * N * sizeof(float);
+    if (need > h->gemm_ws_bytes) {
+      if (h->gemm_ws) (void)hipFree(h->gemm_ws);   // stream-ordered users of the old block have been enqueued: hipFree syncs
+      h->gemm_ws = nullptr;
+      h->gemm_ws_bytes = 0;
+      if (hipMalloc(reinterpret_cast<void**>(&h->gemm_ws), need) != hipSuccess) {
+        h->err = "gemm_f32: split-K workspace allocation failed";
+        return TFMQ_ERR_HIP;
+      }
+      h->gemm_ws_bytes = need;
+    }
+    p.ksplit = ks;
+    p.partial = h->gemm_ws;
+  }
+  dim3 grid((N + BN - 1) / BN, (M + 127) / 128, batch * (ks > 1 ? ks : 1));
+  if (BN == 128) hipLaunchKernelGGL((k_gemm_f32_mfma<2, 2, 2, 2>), grid, dim3(256), 0, st, p);
+  else hipLaunchKernelGGL((k_gemm_f32_mfma<4, 1, 1, 2>), grid, dim3(256), 0, st, p);
+  if (ks > 1) {
+    const size_t total = static_cast<size_t>(M) * N * batch;
+    hipLaunchKernelGGL(k_gemm_splitk_reduce, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0, st, p, batch);
+  }
+  return TFMQ_OK;
 }

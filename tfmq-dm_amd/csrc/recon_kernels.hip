@@ -11,20 +11,8 @@
 #include "common.hpp"
 
 // ------------------------------------------------------------------ strided batched GEMM (fp32)
-struct GemmP {
-  const float* A; const float* B; float* C;
-  int M, N, K;
-  long sam, sak, sbk, sbn, scm;      // element strides: A(m,k)=A[m*sam+k*sak], B(k,n)=B[k*sbk+n*sbn], C(m,n)=C[m*scm+n]
-  long bsa, bsb, bsc;                // batch strides
-  float alpha;
-  const float* bias;                 // [N] or null
-  const float* rowadd;               // rowadd[(m / rows_per_img) * rowadd_ld + n] or null
-  int rows_per_img, rowadd_ld;
-  const float* residual;             // same layout as C, or null
-  int accumulate;                    // C += result
-};
 
-int tfmq_gemm_f32_mfma_launch(const void* p, int M, int N, int batch, hipStream_t st);   // gemm_f32_mfma.hip (same GemmP)
+int tfmq_gemm_f32_mfma_launch(tfmq_handle h, GemmP& p, int batch, hipStream_t st);   // gemm_f32_mfma.hip
 
 #define GT 64
 #define GK 16
@@ -96,9 +84,12 @@ extern "C" int tfmq_gemm_f32(tfmq_handle h, const float* A, const float* B, floa
   TFMQ_CHECK_ARG(h, h && A && B && C && M > 0 && N > 0 && K > 0 && batch > 0 && batch < 65536, "gemm_f32: bad argument");
   TFMQ_CHECK_ARG(h, !rowadd || rows_per_img > 0, "gemm_f32: rowadd needs rows_per_img");
   GemmP p{A, B, C, M, N, K, sam, sak, sbk, sbn, scm, bsa, bsb, bsc, alpha, bias, rowadd, rows_per_img, rowadd_ld, residual,
-          accumulate};
-  if (M >= 96 && N >= 24 && K >= 8) {     // fp32 matrix cores (gemm_f32_mfma.hip); small problems keep the FMA tile
-    tfmq_gemm_f32_mfma_launch(&p, M, N, batch, as_stream(stream));
+          accumulate, 1, 0, nullptr};
+  // fp32 matrix cores (gemm_f32_mfma.hip); small problems keep the FMA tile.  Skinny outputs with a long reduction
+  // (the context-side gradients of cross attention: 77 x 40, K = 4096) also go there: split-K fills the chip
+  if ((M >= 96 && N >= 24 && K >= 8) || (M >= 32 && N >= 24 && K >= 1024)) {
+    const int rc = tfmq_gemm_f32_mfma_launch(h, p, batch, as_stream(stream));
+    if (rc != TFMQ_OK) return rc;
     TFMQ_LAUNCH_CHECK(h);
     return TFMQ_OK;
   }
