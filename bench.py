@@ -258,6 +258,67 @@ def calibration_sample(dev):
     return res
 
 
+def sd_first_stage_state(gen):
+    """Random-init state dict of the SD v1 KL-f8 first stage's decode side (ch 128, mult 1-2-4-4, 2 res blocks)."""
+    sd = {}
+
+    def conv(name, co, ci, k):
+        sd[name + ".weight"] = torch.randn(co, ci, k, k, generator=gen) * (1.0 / (ci * k * k) ** 0.5)
+        sd[name + ".bias"] = torch.randn(co, generator=gen) * 0.02
+
+    def norm(name, c):
+        sd[name + ".weight"] = 1.0 + 0.1 * torch.randn(c, generator=gen)
+        sd[name + ".bias"] = 0.05 * torch.randn(c, generator=gen)
+
+    def res(p, ci, co):
+        norm(p + ".norm1", ci); conv(p + ".conv1", co, ci, 3); norm(p + ".norm2", co); conv(p + ".conv2", co, co, 3)
+        if ci != co:
+            conv(p + ".nin_shortcut", co, ci, 1)
+
+    ch, mult = 128, (1, 2, 4, 4)
+    conv("post_quant_conv", 4, 4, 1)
+    bi = ch * mult[-1]
+    conv("decoder.conv_in", bi, 4, 3)
+    res("decoder.mid.block_1", bi, bi)
+    norm("decoder.mid.attn_1.norm", bi)
+    for nm in ("q", "k", "v", "proj_out"):
+        conv("decoder.mid.attn_1." + nm, bi, bi, 1)
+    res("decoder.mid.block_2", bi, bi)
+    for i in reversed(range(4)):
+        bo = ch * mult[i]
+        for j in range(3):
+            res(f"decoder.up.{i}.block.{j}", bi, bo)
+            bi = bo
+        if i != 0:
+            conv(f"decoder.up.{i}.upsample.conv", bi, bi, 3)
+    norm("decoder.norm_out", bi)
+    conv("decoder.conv_out", 3, bi, 3)
+    return sd, dict(ch=ch, ch_mult=mult, num_res_blocks=2, resolution=256, attn_resolutions=[])
+
+
+def first_stage_sample(dev, n_img=4):
+    """Outside the metric's timed region (sample_diffusion_ldm.py:127-150 times the sampler loop only) and reported
+    separately: decode of 64x64x4 latents to 512x512x3 images on the HIP first-stage decoder."""
+    from tfmq_dm_amd.engine.vae_decoder import VaeDecoderEngine
+    gen = torch.Generator().manual_seed(11)
+    sd, cfg = sd_first_stage_state(gen)
+    eng = VaeDecoderEngine(sd, cfg, dev)
+    z = (torch.randn(n_img, 64, 64, 4, generator=gen) * 0.9).to(dev)
+    eng.forward(z, scale_factor=0.18215)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(2):
+        y = eng.forward(z, scale_factor=0.18215)
+    torch.cuda.synchronize(dev)
+    ms = (time.perf_counter() - t0) / 2 / n_img * 1e3
+    res = {"ms_per_image": round(ms, 2), "images_per_s": round(1e3 / ms, 1), "tflops": round(2.5145 / ms * 1e3, 1), "batch": n_img,
+           "finite": bool(torch.isfinite(y).all()),
+           "config": "SD v1 KL-f8 decoder (49.5 M params, 2.51 TFLOP/image), fp16-operand MFMA convs, exact-fp32 512-channel mid attention"}
+    del eng, y, z
+    torch.cuda.empty_cache()
+    return res
+
+
 def conv_roofline(fwd, stream, n_fwd=2):
     """Per-launch HIP-event timing (on the launch stream) of every w4a8 GEMM launch of UNet forwards."""
     import tfmq_dm_amd.ops as ops
@@ -363,6 +424,7 @@ def main():
         cali = None
         if world == 1 and args.workload == "sd" and not args.no_cpu_baseline:
             cali = calibration_sample(dev)
+            cali["first_stage_decode"] = first_stage_sample(dev)
         cfgd = {"workload": info["workload"], "parallelism": f"replicas x{world} (no data-path collective)"}
         cfgd.update(info["extra"])
         out = {

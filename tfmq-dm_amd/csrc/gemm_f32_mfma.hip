@@ -190,7 +190,9 @@ __global__ void k_gemm_splitk_reduce(GemmP p, int batch) {
 int tfmq_gemm_f32_mfma_launch(tfmq_handle h, GemmP& p, int batch, hipStream_t st) {
   const int M = p.M, N = p.N;
   const int BN = N > 64 ? 128 : 64;
-  const long tiles = static_cast<long>((N + BN - 1) / BN) * ((M + 127) / 128) * batch;
+  // tiles of ONE batch item: the slicing (hence the summation order) must not depend on how many items share the
+  // launch -- results stay bit-identical whatever else is in the batch
+  const long tiles = static_cast<long>((N + BN - 1) / BN) * ((M + 127) / 128);
   // fewer tiles than CUs and a long reduction: slice K so that ~2 blocks per CU exist, >= 256 elements per slice
   int ks = 1;
   if (tiles < h->cu_count && p.K >= 1024) {

@@ -61,6 +61,21 @@ class LatentDiffusion(nn.Module):
     def device(self):
         return self.betas.device
 
+    def decode_first_stage(self, z, predict_cids: bool = False, force_not_quantize: bool = False):
+        """reference :694-708: z / scale_factor, then first_stage_model.decode.  Needs `first_stage_model` (e.g.
+        ldm.autoencoder.FirstStageDecoder) and `scale_factor` attributes set by the driver, as the reference's
+        instantiate_first_stage / checkpoint loading does."""
+        if not hasattr(self, "first_stage_model"):
+            raise TfmqError("decode_first_stage: no first_stage_model attached")
+        if predict_cids:
+            raise TfmqError("decode_first_stage: predict_cids is not used by the BASELINE configs")
+        sf = float(getattr(self, "scale_factor", 1.0))
+        fs = self.first_stage_model
+        if hasattr(fs, "engine"):       # scale on the device inside the engine's first kernel chain
+            y = fs.engine.forward(z.permute(0, 2, 3, 1).contiguous().float(), scale_factor=sf)
+            return y.permute(0, 3, 1, 2)
+        return fs.decode(1.0 / sf * z)
+
     def apply_model(self, x_noisy, t, cond, return_ids: bool = False):
         if self.model.conditioning_key is None:
             return self.model(x_noisy, t)
