@@ -169,8 +169,15 @@ typedef struct tfmq_conv_desc {
                                     tfmq_gn_desc.half_out): operands go global -> LDS by DMA like the w4a8 path.
                                     Needs Cin % 32 == 0 and KH*KW <= 9; bit-identical to the fp32-input path, which
                                     rounds x to fp16 while staging */
+  int32_t tile;                  /* TFMQ_TILE_AUTO (0): the library's rule picks the tile shape.  TFMQ_TILE_128 / _64 / _256 / _128x64:
+                                    128x128, 64x64, 256x128 or 128x64 output tiles -- the result does not depend on the choice
+                                    (int32 sums are exact; the f16 path accumulates each output in the same K order);
+                                    a shape the launch is not eligible for falls back to the rule.  Lets a host time
+                                    the variants per layer shape once and pin the fastest (ops.set_conv_autotune) */
+  int32_t pad1_;
 } tfmq_conv_desc;
 enum { TFMQ_OUT_F32 = 0, TFMQ_OUT_F16 = 1, TFMQ_OUT_GEGLU_Q8 = 2, TFMQ_OUT_Q8 = 3 };
+enum { TFMQ_TILE_AUTO = 0, TFMQ_TILE_128 = 1, TFMQ_TILE_64 = 2, TFMQ_TILE_256 = 3, TFMQ_TILE_128x64 = 4 };
 int tfmq_conv2d_w4a8(tfmq_handle h, const tfmq_conv_desc* d, void* stream);
 int tfmq_conv2d_f16(tfmq_handle h, const tfmq_conv_desc* d, void* stream);
 

@@ -123,3 +123,53 @@ def test_groupnorm_half_outputs(ops):
     yq_a, _, xc_a = ops.groupnorm(y, g2, b2, 1e-5, True, sel, want_cat=True)
     yq_b, _, xc_b = ops.groupnorm(y, g2, b2, 1e-5, True, sel, want_cat=True, half_out=True)
     assert torch.equal(yq_a, yq_b) and torch.equal(xc_b, xc_a.half())
+
+
+# ---- tile shape hint (tfmq_conv_desc.tile) and the measured per-shape selection (ops.set_conv_autotune): the result
+# must not depend on the tile shape
+@pytest.mark.parametrize("k,res,mode", [(3, True, "f32"), (1, False, "f16"), (1, True, "q8")])
+def test_tile_variants_are_bit_identical(ops, k, res, mode):
+    B, H, W, cin, cout = 4, 32, 32, 128, 384
+    g = torch.Generator().manual_seed(7 + k)
+    x = torch.randn(B, H, W, cin, generator=g) * 1.3 - 0.2
+    w = torch.randn(cout, cin, k, k, generator=g) * (2.0 / (cin * k * k) ** 0.5)
+    b = torch.randn(cout, generator=g) * 0.2
+    wd, wz = O.init_channelwise(w, 16, "minmax")
+    ad, az = O.minmax(x, 256)
+    sel = ops.qsel(qtab(ad, az))
+    oq = ops.qsel(qtab(0.03, 117.0))
+    xq = ops.quantize_act(x.to(DEV), sel)
+    pw = ops.pack_w4(w.to(DEV), wd.to(DEV), wz.to(DEV), bias=b.to(DEV))
+    r = torch.randn(B, H, W, cout, generator=g).to(DEV) if res else None
+    kw = dict(pad=(k // 2,) * 4, residual=r)
+    if mode == "f16":
+        kw["out_f16"] = True
+    elif mode == "q8":
+        kw["out_q8"] = oq
+    else:
+        kw["want_stats"] = True
+    outs = []
+    for tile in (1, 2, 3, 4):
+        ops.set_conv_autotune({})
+        try:
+            import tfmq_dm_amd.ops as _o
+            orig = _o._tune_conv
+            _o._tune_conv = lambda h, name, kind, d, dsc, t=tile: t
+            y = ops.conv2d_w4a8(xq, pw, sel, **kw)
+            outs.append((y.clone(), y._tfmq_stats[0].clone() if mode == "f32" else None))
+        finally:
+            _o._tune_conv = orig
+            ops.set_conv_autotune(None)
+    for y, st in outs[1:]:
+        assert torch.equal(y, outs[0][0])
+        if st is not None:   # statistics: per-segment sums in a fixed order inside a tile; segments of 64 here
+            assert torch.equal(st, outs[0][1])
+    # the measured selection fills its cache with one of the eligible variants and returns the same result
+    cache = {}
+    ops.set_conv_autotune(cache)
+    try:
+        y = ops.conv2d_w4a8(xq, pw, sel, **kw)
+    finally:
+        ops.set_conv_autotune(None)
+    assert len(cache) == 1 and list(cache.values())[0] in (1, 2, 3, 4)
+    assert torch.equal(y, outs[0][0])

@@ -38,7 +38,7 @@ class ConvDesc(C.Structure):
         ("residual", c_void_p), ("y", c_void_p),
         ("ldy", C.c_int32), ("y_coff", C.c_int32),
         ("stats", c_void_p), ("stats_seg", C.c_int32), ("out_mode", C.c_int32),
-        ("oq", QSel), ("yq", c_void_p), ("yt", c_void_p), ("t_col0", C.c_int32), ("x_f16", C.c_int32),
+        ("oq", QSel), ("yq", c_void_p), ("yt", c_void_p), ("t_col0", C.c_int32), ("x_f16", C.c_int32), ("tile", C.c_int32), ("pad1_", C.c_int32),
     ]
 
 

@@ -866,16 +866,28 @@ static int launch_conv(tfmq_handle h, const tfmq_conv_desc* dd, void* stream) {
   const bool narrow = d.Cout <= 32;
   // small-M layers (4x4 / 8x8 feature maps): 128x128 tiles leave most of the 256 CUs idle -> 64x64 tiles
   // (a statistics segment must not span tiles, so 128-pixel segments keep the 128-row tile)
-  const bool small = !narrow && !geglu && !(d.stats && d.stats_seg > 64) &&
-                     static_cast<long>((p.M + 127) / 128) * ((d.Cout + 127) / 128) < 2L * h->cu_count;
+  const bool small_ok = !narrow && !geglu && !(d.stats && d.stats_seg > 64);
   // large-M layers: 256 x 128 tiles move a quarter fewer L2 -> LDS bytes per MFMA (the K loop is bound by that path)
   const bool dma8 = INT8 && d.Cin % 64 == 0 && d.KH * d.KW <= 9 &&
                     static_cast<size_t>(d.B) * d.H * d.W * d.Cin < (static_cast<size_t>(1) << 31);
-  // (measured: pays for the fp16-output token Linears -- q/k/v projections, -16 % -- whose epilogue is light; layers
-  // with the fp32 residual epilogue lose more from 2 instead of 3 resident workgroups than the K loop gains)
-  const bool big = dma8 && !narrow && !small && d.stride == 1 && !d.up2x && d.out_mode == TFMQ_OUT_F16 &&
-                   static_cast<long>((p.M + 127) / 128) * ((d.Cout + 127) / 128) >= 4L * h->cu_count;
-  const int BM = big ? 256 : (small ? 64 : 128), BN = narrow ? 32 : (small ? 64 : 128);
+  const bool big_ok = dma8 && !narrow && d.stride == 1 && !d.up2x;
+  const long tiles128 = static_cast<long>((p.M + 127) / 128) * ((d.Cout + 127) / 128);
+  bool small, big;
+  const bool half_n = d.tile == TFMQ_TILE_128x64 && dma8 && small_ok;     // 128 x 64: no column waste for Cout = 64 (2k+1)
+  if (half_n) {
+    small = big = false;
+  } else if (d.tile == TFMQ_TILE_128 || (d.tile == TFMQ_TILE_64 && small_ok) || (d.tile == TFMQ_TILE_256 && big_ok)) {
+    // the caller measured the variants for this launch (ops.set_conv_autotune) -- tile quantisation against
+    // 256 CUs x 2..5 resident blocks is not something a closed-form rule gets right for every batch size
+    small = d.tile == TFMQ_TILE_64;
+    big = d.tile == TFMQ_TILE_256;
+  } else {
+    small = small_ok && tiles128 < 2L * h->cu_count;
+    // (measured: pays for the fp16-output token Linears -- q/k/v projections, -16 % -- whose epilogue is light; layers
+    // with the fp32 residual epilogue lose more from 2 instead of 3 resident workgroups than the K loop gains)
+    big = big_ok && !small && d.out_mode == TFMQ_OUT_F16 && tiles128 >= 4L * h->cu_count;
+  }
+  const int BM = big ? 256 : (small ? 64 : 128), BN = narrow ? 32 : ((small || half_n) ? 64 : 128);
   p.tiles_n = (d.Cout + BN - 1) / BN;
   const int tiles_m = (p.M + BM - 1) / BM;
   dim3 grid(static_cast<unsigned>(p.tiles_n) * tiles_m);
@@ -894,6 +906,9 @@ static int launch_conv(tfmq_handle h, const tfmq_conv_desc* dd, void* stream) {
       const bool res_pre = d.residual && (d.out_mode == TFMQ_OUT_F32 || d.out_mode == TFMQ_OUT_Q8) &&
                            ((d.Cout | d.ldy | d.y_coff) & 3) == 0 && (!d.rowadd || (d.rowadd_ld & 3) == 0);
       if (narrow) hipLaunchKernelGGL((k_conv_dma<false, 4, 1, 1, 1>), grid, dim3(256), 0, st, p);
+      else if (half_n && res_pre) hipLaunchKernelGGL((k_conv_dma<false, 2, 2, 2, 1, true>), grid, dim3(256), 0, st, p);
+      else if (half_n) hipLaunchKernelGGL((k_conv_dma<false, 2, 2, 2, 1>), grid, dim3(256), 0, st, p);
+      else if (small && res_pre) hipLaunchKernelGGL((k_conv_dma<false, 2, 2, 1, 1, true>), grid, dim3(256), 0, st, p);
       else if (small) hipLaunchKernelGGL((k_conv_dma<false, 2, 2, 1, 1>), grid, dim3(256), 0, st, p);
       else if (big) hipLaunchKernelGGL((k_conv_dma<false, 2, 2, 4, 2>), grid, dim3(256), 0, st, p);
       else if (res_pre) hipLaunchKernelGGL((k_conv_dma<false, 2, 2, 2, 2, true>), grid, dim3(256), 0, st, p);

@@ -10,6 +10,7 @@ ldm/models/diffusion/ddim.py:118-212)."""
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Optional
 
 import numpy as np
@@ -79,15 +80,29 @@ class GraphLatentDdimSampler:
         sp = C.c_void_p(self.stream.cuda_stream)
         with torch.cuda.stream(self.stream):
             self.step.zero_()
-            with ops.use_arena(self.arena):
-                self._step_body()
-            self.stream.synchronize()
-            with ops.use_arena(self.arena):
-                self.h.call("graph_begin", sp)
-                self._step_body()
-                gid = C.c_int()
-                self.h.call("graph_end", sp, C.byref(gid))
+            # the warm-up pass allocates every intermediate once and times the tile variants of every conv / linear shape
+            # (ops.set_conv_autotune); the captured pass replays the allocation log and pins the winners
+            self.tiles = getattr(self, "tiles", {})
+            ops.set_conv_autotune(self.tiles)
+            try:
+                with ops.use_arena(self.arena):
+                    self._step_body()
+                self.stream.synchronize()
+                with ops.use_arena(self.arena):
+                    self.h.call("graph_begin", sp)
+                    self._step_body()
+                    gid = C.c_int()
+                    self.h.call("graph_end", sp, C.byref(gid))
+            finally:
+                ops.set_conv_autotune(None)
             self.gid = gid.value
+            if os.environ.get("TFMQ_TUNE_REPORT"):
+                import collections, sys
+                print("[tfmq] tile selection:", dict(collections.Counter(ops._TILE_NAMES.get(v, "rule") for v in self.tiles.values())),
+                      file=sys.stderr)
+                if os.environ["TFMQ_TUNE_REPORT"] == "2":
+                    for k, v in self.tiles.items():
+                        print("   ", k, ops._TILE_NAMES.get(v, "rule"), file=sys.stderr)
         return self
 
     def sample_nhwc(self, x_T: torch.Tensor, cond: torch.Tensor, uncond: torch.Tensor, steps: Optional[int] = None):

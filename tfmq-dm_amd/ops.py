@@ -7,6 +7,7 @@ current stream.  There is no CPU path: a CPU tensor raises TfmqError.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Optional, Tuple
 
 import torch
@@ -284,8 +285,60 @@ def _attach_stats(dsc, y: torch.Tensor, B: int, hw: int, cout: int, want_stats: 
     y._tfmq_stats = (st, seg)
 
 
+# ---- per-shape tile selection by measurement.  Which of the 128x128 / 64x64 / 256x128 tile kernels is fastest for a
+# launch depends on how its tile count divides over 256 CUs x 2..5 resident blocks, i.e. on the batch size; with
+# autotuning on, the first launch of every distinct shape times the eligible variants (3 launches each, HIP events on
+# the launch stream; a conv is idempotent, so re-running it is harmless) and later launches -- in particular the ones
+# captured into the sampler's hipGraph -- use the winner.  The result does not depend on the tile shape.
+_AUTOTUNE = None      # None = off, else {shape key: tile id}
+_TILE_NAMES = {1: "128x128", 2: "64x64", 3: "256x128", 4: "128x64"}
+
+
+def set_conv_autotune(cache) -> None:
+    """cache: a dict to fill / reuse (shape key -> tile id), or None to switch the selection back to the library's rule."""
+    global _AUTOTUNE
+    _AUTOTUNE = None if os.environ.get("TFMQ_CONV_AUTOTUNE", "1") == "0" else cache   # env switch: A/B runs
+
+
+def conv_autotune_report():
+    return {} if _AUTOTUNE is None else {k: _TILE_NAMES.get(v, "auto") for k, v in _AUTOTUNE.items()}
+
+
+def _tune_conv(h, name, kind, d, dsc):
+    key = (kind, dsc.B, dsc.H, dsc.W, dsc.Cin, dsc.Cout, dsc.KH, dsc.stride, dsc.up2x, dsc.out_mode, bool(dsc.residual),
+           bool(dsc.stats), dsc.stats_seg, dsc.x_f16, bool(dsc.yt))
+    t = _AUTOTUNE.get(key)
+    if t is not None:
+        return t
+    if torch.cuda.is_current_stream_capturing() or dsc.Cout <= 32 or (dsc.residual and dsc.residual in (dsc.y, dsc.yq)):
+        return 0                      # cannot time inside a capture / nothing to choose / not idempotent
+    cands = [1, 2]
+    if kind == "w4a8" and dsc.Cin % 64 == 0:
+        cands.append(4)
+        if dsc.stride == 1 and not dsc.up2x:
+            cands.append(3)
+    best, best_ms = 0, None
+    e0, e1 = C.c_int(), C.c_int()
+    h.call("event_create", C.byref(e0))
+    h.call("event_create", C.byref(e1))
+    for t in cands:
+        dsc.tile = t
+        h.call(name, C.byref(dsc), _stream(d))          # warm (instruction cache, clocks)
+        h.call("event_record", e0.value, _stream(d))
+        for _ in range(3):
+            h.call(name, C.byref(dsc), _stream(d))
+        h.call("event_record", e1.value, _stream(d))
+        ms = event_elapsed_ms(e0.value, e1.value)        # synchronises on e1
+        if best_ms is None or ms < best_ms:
+            best, best_ms = t, ms
+    _AUTOTUNE[key] = best
+    return best
+
+
 def _profiled_conv(name, kind, d, dsc, nops, nbytes=0.0):
     h = handle(d)
+    if _AUTOTUNE is not None:
+        dsc.tile = _tune_conv(h, name, kind, d, dsc)
     if _conv_prof is None:
         h.call(name, C.byref(dsc), _stream(d))
         return
