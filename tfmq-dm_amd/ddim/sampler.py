@@ -113,7 +113,9 @@ class GraphDdimSampler:
             self.step.zero_()
             # the warm-up pass allocates every intermediate once and times the tile variants of every conv / linear shape
             # (ops.set_conv_autotune); the captured pass replays the allocation log and pins the winners
-            self.tiles = getattr(self, "tiles", {})
+            if not hasattr(self.eng, "tiles"):
+                self.eng.tiles = {}
+            self.tiles = self.eng.tiles          # one cache per engine: eager forwards and the captured graph agree
             ops.set_conv_autotune(self.tiles)
             try:
                 with ops.use_arena(self.arena):

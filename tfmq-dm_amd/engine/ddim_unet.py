@@ -301,7 +301,15 @@ class DdimUNetEngine:
         return po.run(a, residual=x)
 
     # ------------------------------------------------------------------ forward
-    def forward(self, x: torch.Tensor, t: Optional[torch.Tensor] = None, taps: Optional[dict] = None) -> torch.Tensor:
+    def forward(self, *a, **k):
+        """See _forward.  Outside activation calibration the conv tile shapes are measured once per shape
+        (ops.autotuned) and reused -- the output does not depend on them."""
+        if not hasattr(self, "tiles"):
+            self.tiles = {}
+        with ops.autotuned(self.tiles if self.calib is None else None):
+            return self._forward(*a, **k)
+
+    def _forward(self, x: torch.Tensor, t: Optional[torch.Tensor] = None, taps: Optional[dict] = None) -> torch.Tensor:
         """x: fp32 NHWC [B,H,W,C].  t: [B] fp32 timesteps, or None to use the per-step TIB table
         (build_tib_table) indexed by the device step counter."""
         if not self.prepared:

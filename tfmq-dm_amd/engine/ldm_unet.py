@@ -349,7 +349,15 @@ class LdmUNetEngine(DdimUNetEngine):
         return h
 
     # ------------------------------------------------------------------ forward
-    def forward(self, x: torch.Tensor, t: Optional[torch.Tensor] = None, context: Optional[torch.Tensor] = None,
+    def forward(self, *a, **k):
+        """See _forward.  Outside activation calibration the conv / linear tile shapes are measured once per shape
+        (ops.autotuned) and reused -- the output does not depend on them."""
+        if not hasattr(self, "tiles"):
+            self.tiles = {}
+        with ops.autotuned(self.tiles if self.calib is None else None):
+            return self._forward(*a, **k)
+
+    def _forward(self, x: torch.Tensor, t: Optional[torch.Tensor] = None, context: Optional[torch.Tensor] = None,
                 taps: Optional[dict] = None) -> torch.Tensor:
         """x: fp32 NHWC latents [B,H,W,C]; t: [B] timesteps (or None -> per-step TIB table); context: fp32 [B,L,D]."""
         if not self.prepared:

@@ -35,7 +35,7 @@ class VaeDecoderEngine(DdimUNetEngine):
         self.res_names = []
         self.prepare()       # every layer FP
 
-    def forward(self, z: torch.Tensor, scale_factor: float = 1.0, pre_end: bool = False, **_) -> torch.Tensor:
+    def _forward(self, z: torch.Tensor, scale_factor: float = 1.0, pre_end: bool = False, **_) -> torch.Tensor:
         """z: fp32 NHWC latents [B,h,w,zc] -> fp32 NHWC image [B, h*2^(levels-1), w*2^(levels-1), out_ch]."""
         cfg, L = self.cfg, self.layers
         nlev, nres = len(cfg["ch_mult"]), cfg["num_res_blocks"]

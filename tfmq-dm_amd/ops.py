@@ -300,6 +300,25 @@ def set_conv_autotune(cache) -> None:
     _AUTOTUNE = None if os.environ.get("TFMQ_CONV_AUTOTUNE", "1") == "0" else cache   # env switch: A/B runs
 
 
+class autotuned:
+    """Context manager used by the engines' forward(): measure / reuse tile shapes in `cache` unless a caller (a graph
+    sampler's capture) already installed its own cache."""
+
+    def __init__(self, cache):
+        self.cache, self.mine = cache, False
+
+    def __enter__(self):
+        if _AUTOTUNE is None and self.cache is not None:
+            set_conv_autotune(self.cache)
+            self.mine = _AUTOTUNE is not None
+        return self
+
+    def __exit__(self, *exc):
+        if self.mine:
+            set_conv_autotune(None)
+        return False
+
+
 def conv_autotune_report():
     return {} if _AUTOTUNE is None else {k: _TILE_NAMES.get(v, "auto") for k, v in _AUTOTUNE.items()}
 
