@@ -18,36 +18,72 @@ NULL = None
 
 
 class Arena:
-    """Replayable allocation log.  The first pass through a plan allocates (torch caching
-    allocator) and records every tensor; later passes hand out the same tensors in the same
-    order, so (a) the sequence of launches is legal inside a HIP stream capture (no hipMalloc)
-    and (b) the pointers baked into the captured hipGraph stay owned by the plan."""
+    """Replayable allocation log with liveness-based reuse.  The first pass through a plan records, for every
+    allocation, a block of device memory and the view handed out; later passes hand out the same views in the same
+    order, so (a) the sequence of launches is legal inside a HIP stream capture (no hipMalloc) and (b) the pointers
+    baked into the captured hipGraph stay owned by the plan.
 
-    def __init__(self):
-        self.tensors = []
+    Reuse: a block whose storage is referenced by nobody but the arena (torch's storage use count back at its
+    base-only value: every view of it, and every view of those views, has been dropped by the plan) is dead in
+    program order and is handed out again for a later allocation of that size -- everything runs on one stream, so
+    the later writer is ordered after the earlier readers.  An SD UNet forward at batch 40 then needs a few GiB
+    instead of one block per intermediate (24.7 GiB)."""
+
+    def __init__(self, reuse: bool = True):
+        self.blocks = []          # uint8 base tensors
+        self.log = []             # (block index, shape, dtype)
         self.cursor = 0
         self.frozen = False
+        self.reuse = reuse
+        self._by_size = {}        # nbytes -> [block indices]
 
     def rewind(self):
         self.cursor = 0
-        self.frozen = len(self.tensors) > 0
+        self.frozen = len(self.log) > 0
+
+    @staticmethod
+    def _uses(base) -> int:
+        return torch._C._storage_Use_Count(base.untyped_storage()._cdata)
+
+    def _view(self, bi, shape, dtype):
+        n = 1
+        for s_ in shape:
+            n *= s_
+        nb = n * torch.empty(0, dtype=dtype).element_size()
+        return self.blocks[bi][:nb].view(dtype).view(shape)
 
     def take(self, shape, dtype, device):
         shape = tuple(int(s) for s in (shape if isinstance(shape, (tuple, list, torch.Size)) else (shape,)))
         if self.frozen:
-            if self.cursor >= len(self.tensors):
+            if self.cursor >= len(self.log):
                 raise TfmqError("Arena: replay allocates more tensors than the recorded pass")
-            t = self.tensors[self.cursor]
-            if tuple(t.shape) != shape or t.dtype != dtype:
-                raise TfmqError(f"Arena: replay mismatch at #{self.cursor}: {tuple(t.shape)}/{t.dtype} vs {shape}/{dtype}")
+            bi, shp, dt = self.log[self.cursor]
+            if shp != shape or dt != dtype:
+                raise TfmqError(f"Arena: replay mismatch at #{self.cursor}: {shp}/{dt} vs {shape}/{dtype}")
         else:
-            t = torch.empty(shape, dtype=dtype, device=device)
-            self.tensors.append(t)
+            n = 1
+            for s_ in shape:
+                n *= s_
+            need = max(256, (n * torch.empty(0, dtype=dtype).element_size() + 255) // 256 * 256)
+            bi = None
+            if self.reuse:
+                for cand in self._by_size.get(need, ()):
+                    if self._uses(self.blocks[cand]) == self._base_uses:
+                        bi = cand
+                        break
+            if bi is None:
+                base = torch.empty(need, dtype=torch.uint8, device=device)
+                if not self.blocks:
+                    self._base_uses = self._uses(base)      # use count of a block nobody but the arena refers to
+                self.blocks.append(base)
+                bi = len(self.blocks) - 1
+                self._by_size.setdefault(need, []).append(bi)
+            self.log.append((bi, shape, dtype))
         self.cursor += 1
-        return t
+        return self._view(bi, shape, dtype)
 
     def nbytes(self):
-        return sum(t.numel() * t.element_size() for t in self.tensors)
+        return sum(b.numel() for b in self.blocks)
 
 
 _arena: Optional[Arena] = None
