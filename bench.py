@@ -122,7 +122,7 @@ def setup_sd(args, dev, rank, log):
     from tfmq_dm_amd.engine import LayerQ, LdmUNetEngine
     from tfmq_dm_amd.ldm.sampler import GraphLatentDdimSampler, alphas_cumprod_linear, ddim_timesteps
 
-    batch = args.batch or 20
+    batch = args.batch or 64
     S = args.ddim_steps or 50
     scale = 7.5
     t0 = time.time()
@@ -347,7 +347,7 @@ def main():
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", choices=["sd", "cifar"], default="sd")
-    ap.add_argument("--batch", type=int, default=0, help="images per GPU (default 20 for sd, 256 for cifar)")
+    ap.add_argument("--batch", type=int, default=0, help="images per GPU (default 64 for sd, 256 for cifar)")
     ap.add_argument("--ddim-steps", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()

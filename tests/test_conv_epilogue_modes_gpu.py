@@ -127,9 +127,11 @@ def test_groupnorm_half_outputs(ops):
 
 # ---- tile shape hint (tfmq_conv_desc.tile) and the measured per-shape selection (ops.set_conv_autotune): the result
 # must not depend on the tile shape
-@pytest.mark.parametrize("k,res,mode", [(3, True, "f32"), (1, False, "f16"), (1, True, "q8")])
-def test_tile_variants_are_bit_identical(ops, k, res, mode):
-    B, H, W, cin, cout = 4, 32, 32, 128, 384
+@pytest.mark.parametrize("k,res,mode,B,H", [(3, True, "f32", 4, 32), (1, False, "f16", 4, 32), (1, True, "q8", 4, 32),
+                                              (3, True, "f32", 64, 8), (3, False, "f32", 256, 4), (1, True, "f32", 16, 16)])
+def test_tile_variants_are_bit_identical(ops, k, res, mode, B, H):
+    # (8x8, 4x4, 16x16 maps: GroupNorm statistics segments of 64, 16, 128 pixels -- one summation order for every tile)
+    W, cin, cout = H, 128, 384
     g = torch.Generator().manual_seed(7 + k)
     x = torch.randn(B, H, W, cin, generator=g) * 1.3 - 0.2
     w = torch.randn(cout, cin, k, k, generator=g) * (2.0 / (cin * k * k) ** 0.5)

@@ -65,6 +65,26 @@ def test_sd_full_size_properties(sd):
     assert not torch.equal(e2, e_step1)                           # the step's activation table is used
 
 
+def test_sd_batch_independent_across_tile_choices(sd):
+    """The tile shape of every conv / linear is measured per shape (hence per batch size) -- the GroupNorm statistics
+    of the conv epilogue are summed in one canonical order, so a UNet-batch-12 forward still equals two batch-6
+    forwards bit for bit although the two sizes run different tile kernels."""
+    run, fwd, info = sd
+    eng = _engine_of(fwd)
+    g = torch.Generator().manual_seed(10)
+    x = torch.randn(12, 64, 64, 4, generator=g).to(DEV)
+    ctx = torch.randn(12, 77, 768, generator=g).to(DEV)
+    t = torch.full((12,), 501.0, device=DEV)
+    with torch.cuda.stream(info["stream"]):
+        info["step"].zero_()
+        e = eng.forward(x, t, ctx).clone()
+        a = eng.forward(x[:6].contiguous(), t[:6], ctx[:6].contiguous()).clone()
+        b = eng.forward(x[6:].contiguous(), t[6:], ctx[6:].contiguous()).clone()
+        info["stream"].synchronize()
+    assert len({v for k, v in eng.tiles.items() if k[1] == 12}) > 1      # several tile shapes in use
+    assert torch.equal(e[:6], a) and torch.equal(e[6:], b)
+
+
 def test_quantizer_idempotent_at_size():
     import tfmq_dm_amd.ops as ops
     g = torch.Generator().manual_seed(1)

@@ -120,7 +120,9 @@ def test_ldm_blocks_run_in_isolation(golden):
     res = q.model.input_blocks[3][0]
     hin, hout = taps["input_blocks.3.0"]
     y = res(ops.nhwc_to_nchw(hin), taps["__temb__"])
-    assert float((ops.nchw_to_nhwc(y) - hout).abs().max() / hout.abs().max()) <= 1e-5
+    # (the isolated block computes its GroupNorm statistics in the GroupNorm kernel, the engine in the producing conv's
+    # epilogue: two fp32 summation orders)
+    assert float((ops.nchw_to_nhwc(y) - hout).abs().max() / hout.abs().max()) <= 3e-5
     tb = q.model.input_blocks[1][1].transformer_blocks[0]
     tin, tout = taps["input_blocks.1.1.transformer_blocks.0"]
     y = tb(tin[0], tin[1])

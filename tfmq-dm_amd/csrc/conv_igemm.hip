@@ -256,7 +256,14 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, unsigned char* lds
       continue;
     }
     // phase 2: whole rows out, + temb row + residual, + statistics
-    float4 ps = make_float4(0.f, 0.f, 0.f, 0.f), pss = ps;
+    // Statistics are summed in ONE order whatever the tile shape (the shape is picked per batch size, the result must
+    // not depend on it): a segment = its 8-row groups added in row order, an 8-row group = (rows 0..3 added in
+    // order) + (rows 4..7 added in order).
+    constexpr int G4 = RPT / 4;
+    static_assert(RPT == 4 || RPT == 8, "rows per thread: one or two 4-row groups");
+    float4 ps[G4], pss[G4];
+#pragma unroll
+    for (int gi = 0; gi < G4; ++gi) ps[gi] = pss[gi] = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int k = 0; k < RPT; ++k) {
       const int prow = tr * RPT + k;
@@ -296,42 +303,51 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, unsigned char* lds
         }
         v = make_float4(e[0], e[1], e[2], e[3]);
       }
-      ps.x += v.x; ps.y += v.y; ps.z += v.z; ps.w += v.w;
-      pss.x += v.x * v.x; pss.y += v.y * v.y; pss.z += v.z * v.z; pss.w += v.w * v.w;
+      ps[k >> 2].x += v.x; ps[k >> 2].y += v.y; ps[k >> 2].z += v.z; ps[k >> 2].w += v.w;
+      pss[k >> 2].x += v.x * v.x; pss[k >> 2].y += v.y * v.y; pss[k >> 2].z += v.z * v.z; pss[k >> 2].w += v.w * v.w;
     }
     if (seg) {
-      float2* pp = ldsP + tr * BN + c4;
-      pp[0] = make_float2(ps.x, pss.x);
-      pp[1] = make_float2(ps.y, pss.y);
-      pp[2] = make_float2(ps.z, pss.z);
-      pp[3] = make_float2(ps.w, pss.w);
+      float4 s = ps[0], ss = pss[0];
+      if constexpr (G4 == 2) {
+        s.x += ps[1].x; s.y += ps[1].y; s.z += ps[1].z; s.w += ps[1].w;
+        ss.x += pss[1].x; ss.y += pss[1].y; ss.z += pss[1].z; ss.w += pss[1].w;
+      }
+      float2* pp = ldsP + tr * BN + c4;     // one partial per thread-row: 8 rows (RPT 8) or 4 rows (RPT 4)
+      pp[0] = make_float2(s.x, ss.x);
+      pp[1] = make_float2(s.y, ss.y);
+      pp[2] = make_float2(s.z, ss.z);
+      pp[3] = make_float2(s.w, ss.w);
       __syncthreads();
-      // fixed-order reduction over the thread-rows of each segment
-      const int nseg_pass = seg < PR ? PR / seg : 1;
-      const int tr_per_seg = NTR / nseg_pass;
+      constexpr int PPG = 8 / RPT;          // stored partials per 8-row group
+      const int rows_seg = seg < PR ? seg : PR;
+      const int nseg_pass = PR / rows_seg, g8 = rows_seg / 8;
       for (int o = tid; o < nseg_pass * BN; o += 256) {
         const int sidx = o / BN, col = o % BN;
-        float2 a = make_float2(0.0f, 0.0f);
-        for (int q = 0; q < tr_per_seg; ++q) {
-          const float2 b = ldsP[(sidx * tr_per_seg + q) * BN + col];
+        // a segment spanning several passes keeps adding its groups to the running sum, in the same order
+        float2 a = seg <= PR ? make_float2(0.0f, 0.0f) : ldsG[col];
+        for (int q = 0; q < g8; ++q) {
+          const int base = (sidx * g8 + q) * PPG;
+          float2 b = ldsP[base * BN + col];
+          if constexpr (PPG == 2) {
+            const float2 b2 = ldsP[(base + 1) * BN + col];
+            b.x += b2.x;
+            b.y += b2.y;
+          }
           a.x += b.x;
           a.y += b.y;
         }
-        const int row0 = m0 + pass * PR + sidx * (seg < PR ? seg : PR);
         const int n = n0 + col;
         if (seg <= PR) {
+          const int row0 = m0 + pass * PR + sidx * seg;
           if (row0 < p.M && n < d.Cout) reinterpret_cast<float2*>(d.stats)[static_cast<size_t>(row0 / seg) * d.Cout + n] = a;
-        } else {  // segment spans several passes: accumulate, write after its last pass
-          float2 g = ldsG[col];
-          g.x += a.x;
-          g.y += a.y;
+        } else {  // write after the segment's last pass
           const bool last = ((pass + 1) * PR) % seg == 0;
           if (last) {
             const int srow0 = m0 + (pass + 1) * PR - seg;
-            if (srow0 < p.M && n < d.Cout) reinterpret_cast<float2*>(d.stats)[static_cast<size_t>(srow0 / seg) * d.Cout + n] = g;
-            g = make_float2(0.0f, 0.0f);
+            if (srow0 < p.M && n < d.Cout) reinterpret_cast<float2*>(d.stats)[static_cast<size_t>(srow0 / seg) * d.Cout + n] = a;
+            a = make_float2(0.0f, 0.0f);
           }
-          ldsG[col] = g;
+          ldsG[col] = a;
         }
       }
     }

@@ -146,8 +146,11 @@ class GraphDdimSampler:
         with torch.cuda.stream(self.stream):
             self.x.copy_(x_T, non_blocking=True)
             self.step.zero_()
-            for _ in range(self.n_steps if steps is None else steps):
+            sync_every = int(os.environ.get("TFMQ_GRAPH_SYNC_EVERY", "16"))   # bounded host run-ahead (ldm/sampler.py)
+            for i in range(self.n_steps if steps is None else steps):
                 self.h.call("graph_launch", self.gid, sp)
+                if sync_every and (i + 1) % sync_every == 0:
+                    self.stream.synchronize()
         return self.x
 
     def sample(self, x_T_nchw: torch.Tensor) -> torch.Tensor:

@@ -117,6 +117,11 @@ class GraphLatentDdimSampler:
             self.ctx2[:self.batch].copy_(uncond, non_blocking=True)   # c_in = cat[uc, c]  (ddim.py:183)
             self.ctx2[self.batch:].copy_(cond, non_blocking=True)
             self.step.zero_()
-            for _ in range(self.coef.shape[0] if steps is None else steps):
+            # at most 8 step graphs (~10 k kernel dispatches) are enqueued ahead of the GPU: an unbounded run-ahead of
+            # the host buys nothing and overflows rocprofv3's dispatch records at large batches
+            sync_every = int(os.environ.get("TFMQ_GRAPH_SYNC_EVERY", "8"))
+            for i in range(self.coef.shape[0] if steps is None else steps):
                 self.h.call("graph_launch", self.gid, sp)
+                if sync_every and (i + 1) % sync_every == 0:
+                    self.stream.synchronize()
         return self.x
