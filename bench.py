@@ -200,8 +200,22 @@ def setup_sd(args, dev, rank, log):
             dt = time.time() - t0
         return 1.0 / (dt / cs * S), f"1 image (UNet batch 2, CFG) x {cs} of the {S} DDIM steps = {dt:.1f}s, extrapolated to the full schedule"
 
+    def plms():
+        """The README's SD recipe samples with PLMS (S + 1 UNet calls): reported beside the metric, one
+        sampling after a warm one, on the same engine, tables and inputs."""
+        from tfmq_dm_amd.ldm.sampler import GraphLatentPlmsSampler
+        ps = GraphLatentPlmsSampler(eng, S, batch, (4, 64, 64), (77, 768), scale=scale, alphas_cumprod=alphas_cumprod_linear()).capture()
+        ps.sample_nhwc(x_T, cond, uncond)
+        ps.stream.synchronize()
+        t0 = time.perf_counter()
+        out = ps.sample_nhwc(x_T, cond, uncond)
+        ps.stream.synchronize()
+        dt = time.perf_counter() - t0
+        return {"images_per_s": round(batch / dt, 3), "unet_evals": S + 1, "finite": bool(torch.isfinite(out).all().item()),
+                "sampler": "PLMS-50 (Adams-Bashforth 1-4), CFG 7.5, four captured step graphs"}
+
     info = dict(batch=batch, sync=sampler.stream.synchronize, finite=lambda: bool(torch.isfinite(sampler.x).all().item()),
-                stream=sampler.stream, step=eng.step,
+                stream=sampler.stream, step=eng.step, plms=plms,
                 workload=("Stable Diffusion v1-4 UNet (859.5M) w4a8 on MI355X: 64x64x4 latents (512x512 images), DDIM-50 eta=0, "
                           f"CFG 7.5 (UNet batch 2x{batch}), 77x768 context, {batch} images per GPU (BASELINE.json configs[3] = the metric's config)"),
                 extra={"batch_per_gpu": batch, "ddim_steps": S, "unet_evals_per_step": S, "unet_batch": 2 * batch, "guidance_scale": scale})
@@ -425,6 +439,7 @@ def main():
         if world == 1 and args.workload == "sd" and not args.no_cpu_baseline:
             cali = calibration_sample(dev)
             cali["first_stage_decode"] = first_stage_sample(dev)
+            cali["plms"] = info["plms"]()
         cfgd = {"workload": info["workload"], "parallelism": f"replicas x{world} (no data-path collective)"}
         cfgd.update(info["extra"])
         out = {

@@ -145,3 +145,58 @@ def test_single_wide_head_unet_vs_oracle():
     with torch.no_grad():
         ref = O.ldm_unet_forward(sd, dict(cfg), x, t.long(), ctx, O.QuantSpec(wq={}, aq={}))
     assert float((eps - ref).abs().max() / ref.abs().max()) <= 1e-2
+
+
+def test_graph_plms_sampler_matches_the_eager_recurrence(env):
+    """GraphLatentPlmsSampler (four captured graphs, history ring, step counter) against the PLMS recurrence of
+    p_sample_plms (ldm/models/diffusion/plms.py:179-242) spelled out with the same kernels and eager engine forwards:
+    bit-exact, including the extra UNet call of the first step at t_next with step 1's activation group."""
+    g, sd, Engine, LayerQ = env
+    from tfmq_dm_amd import ops
+    from tfmq_dm_amd.ldm.sampler import GraphLatentPlmsSampler, alphas_cumprod_linear
+    ctx, uc, x_T = T(g["ctx"]).to(DEV), T(g["traj_uc"]).to(DEV), nhwc(T(g["traj_xT"])).to(DEV)
+    wq, qtable = layerq(g, LayerQ, True)
+    S = 6                                           # 1000 // 6 = 166 -> 7 executed steps
+    step = torch.zeros(1, dtype=torch.int32, device=DEV)
+    n_exec = 7
+    qt = torch.stack([qtable[0] * torch.tensor([1.0 + 0.01 * k, 1.0]) for k in range(n_exec)]).contiguous()   # a table per step
+    eng = Engine(sd, CFG, DEV)
+    eng.prepare(wq, qt.to(DEV), step)
+    smp = GraphLatentPlmsSampler(eng, S, 2, (4, 8, 8), (5, 64), scale=7.5, alphas_cumprod=alphas_cumprod_linear()).capture()
+    assert smp.coef.shape[0] == n_exec
+    out = smp.sample_nhwc(x_T, ctx, uc)
+    smp.stream.synchronize()           # the result lives in the sampler's buffer, produced on the sampler's stream
+    out = out.clone()
+    assert int(step.item()) == n_exec
+    part = smp.sample_nhwc(x_T, ctx, uc, steps=3)
+    smp.stream.synchronize()
+    part = part.clone()
+
+    def eps(x, k):
+        step.fill_(k)
+        e2 = eng.forward(torch.cat([x, x]).contiguous(), None, torch.cat([uc, ctx]).contiguous())
+        return ops.cfg_combine(e2[:2].contiguous(), e2[2:].contiguous(), 7.5)
+
+    def run(n):
+        x, old = x_T.clone(), []
+        for i in range(n):
+            coef = smp.coef[i:i + 1]
+            e_t = eps(x, i)
+            if not old:
+                x_prev = ops.ddim_update(x, e_t, coef)
+                e_p = ops.plms_combine(1, e_t, eps(x_prev, min(i + 1, n_exec - 1)))
+            elif len(old) == 1:
+                e_p = ops.plms_combine(2, e_t, old[-1])
+            elif len(old) == 2:
+                e_p = ops.plms_combine(3, e_t, old[-1], old[-2])
+            else:
+                e_p = ops.plms_combine(4, e_t, old[-1], old[-2], old[-3])
+            x = ops.ddim_update(x, e_p, coef)
+            old = (old + [e_t])[-3:]
+        return x
+
+    with torch.cuda.stream(smp.stream):
+        ref, ref3 = run(n_exec), run(3)
+        smp.stream.synchronize()
+    assert torch.isfinite(out).all()
+    assert torch.equal(out, ref) and torch.equal(part, ref3)

@@ -125,3 +125,106 @@ class GraphLatentDdimSampler:
                 if sync_every and (i + 1) % sync_every == 0:
                     self.stream.synchronize()
         return self.x
+
+
+class GraphLatentPlmsSampler(GraphLatentDdimSampler):
+    """PLMS (pseudo linear multi-step, Adams-Bashforth orders 1-4: PLMSSampler.plms_sampling / p_sample_plms,
+    ldm/models/diffusion/plms.py:119-242 -- the sampler of the README's Stable Diffusion recipe) with classifier-free
+    guidance, as hipGraph replays.  Four captured graphs share one activation arena:
+
+      first : e_t at step 0; x' = DDIM update; e_next at step 1 (pseudo improved Euler, the one extra UNet call);
+              e' = (e_t + e_next)/2; x <- update(x, e') with row 0 of the schedule.  The step counter ends at 1.
+      2, 3  : e_t; e' = (3 e_t - h1)/2, (23 e_t - 16 h1 + 5 h2)/12;  x <- update(x, e'); rotate the history; step += 1
+      n     : e' = (55 e_t - 59 h1 + 37 h2 - 9 h3)/24; ...
+
+    The kernels (cfg_combine, plms_combine, ddim_update) and their order are those of the drop-in PLMSSampler
+    (ldm/ddim.py), so the two agree bit for bit; the Finite-Set activation group of every UNet call is the device step
+    counter, which equals DiffusionWrapper's k = t_max - (t-1)//tot for t and for t_next alike."""
+
+    def __init__(self, engine, S: int, batch: int, latent_shape, context_shape, scale: float = 7.5,
+                 alphas_cumprod: Optional[torch.Tensor] = None):
+        super().__init__(engine, S, batch, latent_shape, context_shape, scale, alphas_cumprod, 0.0)
+        if self.coef.shape[0] < 2:
+            raise TfmqError("GraphLatentPlmsSampler needs at least two steps")
+        mk = lambda: torch.empty_like(self.x)
+        self.e_t, self.e_next, self.e_prime, self.xprev = mk(), mk(), mk(), mk()
+        self.hist = [mk(), mk(), mk()]          # previous model outputs, newest first
+        self.gids = None
+
+    def _eps(self, xin, dst):
+        B = self.batch
+        self.x2[:B].copy_(xin)
+        self.x2[B:].copy_(xin)
+        with ops.use_arena(self.arena):           # every UNet call replays the same allocation log
+            eps2 = self.eng.forward(self.x2, None, self.ctx2)
+            ops.cfg_combine(eps2[:B], eps2[B:], self.scale, out=dst)
+
+    def _rotate(self):
+        h = self.hist
+        h[2].copy_(h[1])
+        h[1].copy_(h[0])
+        h[0].copy_(self.e_t)
+
+    def _body(self, kind: int):
+        h = self.hist
+        if kind == 1:
+            self._eps(self.x, self.e_t)
+            ops.ddim_update(self.x, self.e_t, self.coef[0:1], None, None, out=self.xprev)
+            ops.step_advance(self.step, 1)
+            self._eps(self.xprev, self.e_next)
+            ops.plms_combine(1, self.e_t, self.e_next, out=self.e_prime)
+            ops.ddim_update(self.x, self.e_prime, self.coef[0:1], None, None, out=self.x)
+            h[0].copy_(self.e_t)
+            return
+        self._eps(self.x, self.e_t)
+        if kind == 2:
+            ops.plms_combine(2, self.e_t, h[0], out=self.e_prime)
+        elif kind == 3:
+            ops.plms_combine(3, self.e_t, h[0], h[1], out=self.e_prime)
+        else:
+            ops.plms_combine(4, self.e_t, h[0], h[1], h[2], out=self.e_prime)
+        ops.ddim_update(self.x, self.e_prime, self.coef, self.step, None, out=self.x)
+        self._rotate()
+        ops.step_advance(self.step, 1)
+
+    def capture(self):
+        sp = C.c_void_p(self.stream.cuda_stream)
+        with torch.cuda.stream(self.stream):
+            self.step.zero_()
+            if not hasattr(self.eng, "tiles"):
+                self.eng.tiles = {}
+            self.tiles = self.eng.tiles
+            ops.set_conv_autotune(self.tiles)
+            try:
+                self._body(1)                     # eager: records the arena (first UNet call) and measures the tiles
+                self.stream.synchronize()
+                gids = []
+                for kind in (1, 2, 3, 4):
+                    self.h.call("graph_begin", sp)
+                    self._body(kind)
+                    gid = C.c_int()
+                    self.h.call("graph_end", sp, C.byref(gid))
+                    gids.append(gid.value)
+            finally:
+                ops.set_conv_autotune(None)
+            self.gids = gids
+            self.gid = gids[0]
+        return self
+
+    def sample_nhwc(self, x_T: torch.Tensor, cond: torch.Tensor, uncond: torch.Tensor, steps: Optional[int] = None):
+        """steps: run only the first `steps` iterations (untill_fake_t - 1 of the drop-in)."""
+        if self.gids is None:
+            self.capture()
+        sp = C.c_void_p(self.stream.cuda_stream)
+        n = self.coef.shape[0] if steps is None else int(steps)
+        with torch.cuda.stream(self.stream):
+            self.x.copy_(x_T, non_blocking=True)
+            self.ctx2[:self.batch].copy_(uncond, non_blocking=True)
+            self.ctx2[self.batch:].copy_(cond, non_blocking=True)
+            self.step.zero_()
+            sync_every = int(os.environ.get("TFMQ_GRAPH_SYNC_EVERY", "8"))
+            for i in range(n):
+                self.h.call("graph_launch", self.gids[min(i, 3)], sp)
+                if sync_every and (i + 1) % sync_every == 0:
+                    self.stream.synchronize()
+        return self.x
