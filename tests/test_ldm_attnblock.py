@@ -98,3 +98,28 @@ def test_unconditional_sampler_and_calibration_set(golden):
     for plms in (False, True):
         xs, ts = generate_cali_data_ldm(m, T=4, c=2, batch_size=3, shape=[3, 8, 8], plms=plms)
         assert xs.shape == (6, 3, 8, 8) and ts.tolist() == [501] * 3 + [1] * 3 and torch.isfinite(xs).all()
+
+
+@pytest.mark.gpu
+def test_unconditional_graph_sampler_matches_dropin(golden):
+    """GraphLatentDdimSampler without a context (unconditional LDM: one UNet call per step, plain DDIM update) against the
+    drop-in DDIMSampler on the same weights (and through it against the reference trajectory of F13)."""
+    from tfmq_dm_amd.ldm.ddpm import LatentDiffusion
+    from tfmq_dm_amd.ldm.ddim import DDIMSampler
+    from tfmq_dm_amd.ldm.sampler import GraphLatentDdimSampler
+    g = golden("f13_ldm_attnblock_tiny")
+    q = qnn_of(g, DEV)
+    q.set_quant_state(False, False)
+    m = LatentDiffusion(q, conditioning_key=None, linear_start=0.0015, linear_end=0.0195).to(DEV)
+    x_T = T(g["traj_xT"]).to(DEV)
+    ref, _ = DDIMSampler(m).sample(S=4, batch_size=2, shape=[3, 8, 8], verbose=False, eta=0.0, x_T=x_T)
+    eng = q.engine(DEV)
+    step = torch.zeros(1, dtype=torch.int32, device=DEV)
+    eng.prepare(None, None, step)
+    smp = GraphLatentDdimSampler(eng, 4, 2, (3, 8, 8), None, alphas_cumprod=m.alphas_cumprod.cpu()).capture()
+    out = smp.sample_nhwc(x_T.permute(0, 2, 3, 1).contiguous())
+    smp.stream.synchronize()
+    out = out.permute(0, 3, 1, 2).clone()
+    assert int(step.item()) == 4
+    assert float((out - ref).abs().max()) <= 1e-6 * float(ref.abs().max())
+    assert rel_l2(out.cpu(), T(g["traj_fp_final"])) <= 2e-2

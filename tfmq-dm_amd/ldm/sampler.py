@@ -61,8 +61,11 @@ class GraphLatentDdimSampler:
         engine.build_tib_table([float(t) for t in np.flip(ddim_timesteps(S, ac.shape[0]))])
         Cc, H, W = latent_shape
         self.x = torch.empty(batch, H, W, Cc, device=self.dev)
-        self.x2 = torch.empty(2 * batch, H, W, Cc, device=self.dev)
-        self.ctx2 = torch.empty((2 * batch,) + tuple(context_shape), device=self.dev)
+        # context_shape None: unconditional LDM (CelebA-HQ / LSUN configs, sample_diffusion_ldm.py): one UNet call on the
+        # batch itself per step, plain DDIM update -- no guidance pair
+        self.uncond = context_shape is None
+        self.x2 = None if self.uncond else torch.empty(2 * batch, H, W, Cc, device=self.dev)
+        self.ctx2 = None if self.uncond else torch.empty((2 * batch,) + tuple(context_shape), device=self.dev)
         self.stream = torch.cuda.Stream(self.dev)
         self.arena = ops.Arena()
         self.h = handle(self.dev.index or 0)
@@ -70,6 +73,11 @@ class GraphLatentDdimSampler:
 
     def _step_body(self):
         B = self.batch
+        if self.uncond:
+            eps = self.eng.forward(self.x, None, None)
+            ops.ddim_update(self.x, eps, self.coef, self.step, None, out=self.x)
+            ops.step_advance(self.step, 1)
+            return
         self.x2[:B].copy_(self.x)
         self.x2[B:].copy_(self.x)
         eps2 = self.eng.forward(self.x2, None, self.ctx2)
@@ -107,15 +115,18 @@ class GraphLatentDdimSampler:
                         print("   ", k, ops._TILE_NAMES.get(v, "rule"), file=sys.stderr)
         return self
 
-    def sample_nhwc(self, x_T: torch.Tensor, cond: torch.Tensor, uncond: torch.Tensor, steps: Optional[int] = None):
-        """x_T [B,H,W,C]; cond/uncond [B,L,D] (CLIP / class embeddings: glue, computed elsewhere)."""
+    def sample_nhwc(self, x_T: torch.Tensor, cond: Optional[torch.Tensor] = None, uncond: Optional[torch.Tensor] = None,
+                    steps: Optional[int] = None):
+        """x_T [B,H,W,C]; cond/uncond [B,L,D] (CLIP / class embeddings: glue, computed elsewhere; None for an
+        unconditional sampler)."""
         if self.gid is None:
             self.capture()
         sp = C.c_void_p(self.stream.cuda_stream)
         with torch.cuda.stream(self.stream):
             self.x.copy_(x_T, non_blocking=True)
-            self.ctx2[:self.batch].copy_(uncond, non_blocking=True)   # c_in = cat[uc, c]  (ddim.py:183)
-            self.ctx2[self.batch:].copy_(cond, non_blocking=True)
+            if not self.uncond:
+                self.ctx2[:self.batch].copy_(uncond, non_blocking=True)   # c_in = cat[uc, c]  (ddim.py:183)
+                self.ctx2[self.batch:].copy_(cond, non_blocking=True)
             self.step.zero_()
             # at most 8 step graphs (~10 k kernel dispatches) are enqueued ahead of the GPU: an unbounded run-ahead of
             # the host buys nothing and overflows rocprofv3's dispatch records at large batches (DESIGN.md section 4)
