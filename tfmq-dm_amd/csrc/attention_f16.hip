@@ -298,6 +298,7 @@ extern "C" int tfmq_attention_f16(tfmq_handle h, const uint16_t* q, const uint16
   if (d <= 96) return launch_attn_h<6, 3>(h, p, stream);
   if (d <= 128) return launch_attn_h<8, 4>(h, p, stream);
   if (d <= 160) return launch_attn_h<10, 5>(h, p, stream);   // SD v1 at 16x16 / 8x8
-  if (h) h->err = "attention_f16: head dim > 160 not supported (use tfmq_attention)";
+  if (d <= 256) return launch_attn_h<16, 8>(h, p, stream);   // DDPM UNet's single 256-channel head (one wave per SIMD)
+  if (h) h->err = "attention_f16: head dim > 256 not supported (use tfmq_attention)";
   return TFMQ_ERR_UNSUPPORTED;
 }

@@ -276,6 +276,18 @@ class DdimUNetEngine:
         L = self.layers
         B, H, W, Cc = x.shape
         po = L[p + ".proj_out"]
+        f = self.fused_qkv.get(p)
+        if (f is not None and f.kind == "w4a8" and self.calib is None and ops.attention_f16_ok(Cc, H * W)
+                and (2 * Cc) % 128 == 0 and (H * W) % 4 == 0):
+            # the fused q|k|v GEMM writes q, k as fp16 rows and v as fp16 V^T; the flash kernel reads them tile by tile
+            # (what the fp32-operand kernel rounds to on load -- same products, no fp32 round trip)
+            h, _ = self._gn(p + ".norm", x, None, False, f)
+            y16, vt = ops.conv2d_w4a8(h, f.p, f.aq, out_f16=True, t_col0=2 * Cc)
+            y16 = y16.reshape(B, H * W, 3 * Cc)
+            aq = po.aq if po.kind == "w4a8" else None
+            out, oq = ops.attention_f16(y16[..., :Cc], y16[..., Cc:2 * Cc], vt, 1, float(int(Cc) ** (-0.5)), aq,
+                                        want_f32=aq is None)
+            return po.run((oq if aq is not None else out).reshape(B, H, W, Cc), residual=x)
         if p in self.fused_qkv:
             f = self.fused_qkv[p]
             h, _ = self._gn(p + ".norm", x, None, False, f)

@@ -691,7 +691,7 @@ def _attention_wide(q, k, v, heads: int, scale: float, aq: Optional[QSel], want_
 
 def attention_f16_ok(d: int, Tk: int) -> bool:
     """Tk = keys per batch item as stored (a multiple of 8; fewer may be valid, see attention_f16(n_keys=...))."""
-    return d % 8 == 0 and d <= 160 and Tk % 8 == 0
+    return d % 8 == 0 and d <= 256 and Tk % 8 == 0
 
 
 def attention_f16(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, heads: int, scale: float,
