@@ -32,9 +32,16 @@ struct AttnHP {
 // ONES_ROW = d when 32*NT > d (else -1): V^T row d (a padding row of the last output tile) is set to 1.0 once, so the
 // PV MFMA accumulates the softmax denominator sum_k P[q][k] in output row d -- rescaled with O for free -- and the
 // 32 adds + one cross-lane exchange per key tile disappear from the VALU-bound softmax.
-template <int NKS, int NT, int ONES_ROW>
+// FOLD (needs a spare score column, 16*NKS > d, and the ones-row): the softmax shift rides in the score MFMA.  K's
+// padding column d holds 1.0, Q is pre-multiplied by scale*log2(e) and its column d holds -m (the running shift of
+// the query, kept fp16-representable), so the accumulator comes out as the exp2 argument and the 32 fused
+// multiply-adds per key tile disappear from the VALU-bound softmax.  The shift may lag the true row maximum by up to
+// 2^8 (probabilities up to 256 in fp16 -- relative precision is unchanged, the common factor cancels in O / l);
+// a tile whose maximum exceeds that re-bases the query (sub + rescale of O, as rarely as the maximum jumps).
+template <int NKS, int NT, int ONES_ROW, bool FOLD = false>
 __global__ __launch_bounds__(256) void k_attention_h(AttnHP p) {
   constexpr int DPAD = NT * 32;
+  static_assert(!FOLD || (ONES_ROW >= 0 && 16 * NKS > ONES_ROW && ONES_ROW % 8 == 0), "FOLD: spare score column + ones-row");
   static_assert(NKS <= 2 * NT, "score k-steps must fit the padded row");
   constexpr int KROW = DPAD * 2 + 16;    // bytes per K row in LDS (odd number of 16-byte slots: conflict-free)
   constexpr int VROW = 64 * 2 + 16;      // bytes per V^T row (64 keys)
@@ -75,6 +82,13 @@ __global__ __launch_bounds__(256) void k_attention_h(AttnHP p) {
       if (qrow < p.Tq && c < d)
         v = *reinterpret_cast<const uint4*>(p.q + (static_cast<size_t>(b) * p.Tq + qrow) * p.ldq + hd * d + c);
       qf[ks] = *reinterpret_cast<v8h*>(&v);
+    }
+    if constexpr (FOLD) {   // q * scale*log2(e), rounded once to fp16
+      const float c2q = p.scale * 1.44269504088896340736f;
+#pragma unroll
+      for (int ks = 0; ks < NKS; ++ks)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) qf[ks][e] = static_cast<_Float16>(static_cast<float>(qf[ks][e]) * c2q);
     }
     // Pin the arrival of the (conditional) Q loads HERE.  Otherwise the compiler's wait-count bookkeeping carries
     // "Q may still be in flight" into the key loop and puts s_waitcnt vmcnt(0) in front of every score MFMA,
@@ -132,7 +146,7 @@ __global__ __launch_bounds__(256) void k_attention_h(AttnHP p) {
       if (v_key[it] < 64) *reinterpret_cast<uint4*>(sV + buf * VBUF + v_lo[it]) = vreg[it];
   };
 
-  float m_run = -INFINITY, l_run = 0.0f;
+  float m_run = FOLD ? 0.0f : -INFINITY, l_run = 0.0f;    // FOLD: m_run = the shift carried in Q's column d
   v16f o[NT];
 #pragma unroll
   for (int t = 0; t < NT; ++t)
@@ -167,6 +181,35 @@ __global__ __launch_bounds__(256) void k_attention_h(AttnHP p) {
           if (key >= p.Tk) s[sub][r] = -INFINITY;
         }
     }
+    if constexpr (FOLD) {
+      // s already holds (score*scale - m_run) * log2(e)
+      float mx = s[0][0];
+#pragma unroll
+      for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[sub][r]);
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      if (__builtin_amdgcn_ballot_w64(mx > 8.0f) != 0) {          // re-base the queries whose maximum ran away
+        const float m_new = mx > 8.0f ? static_cast<float>(static_cast<_Float16>(m_run + mx)) : m_run;
+        const float delta = m_new - m_run;                          // exact: both fp16-representable
+        const float alpha = __builtin_amdgcn_exp2f(-delta);
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) s[sub][r] -= delta;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) o[t][r] *= alpha;
+        m_run = m_new;
+        constexpr int ksb = ONES_ROW / 16, eb = ONES_ROW % 16;      // Q column d: k-step, lane half, element
+        if (hh == eb / 8) qf[ksb][eb % 8] = static_cast<_Float16>(-m_run);
+      }
+#pragma unroll
+      for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[sub][r] = __builtin_amdgcn_exp2f(s[sub][r]);
+    } else {
     // ---- online softmax over this lane's 32 keys (+ partner lane^32)
     float mx = s[0][0];
 #pragma unroll
@@ -195,6 +238,7 @@ __global__ __launch_bounds__(256) void k_attention_h(AttnHP p) {
       m_run = m_new;
     }
     l_run += rs;
+    }
     // ---- O^T += V^T P^T : 4 MFMA k-steps of 16 keys
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
@@ -213,6 +257,10 @@ __global__ __launch_bounds__(256) void k_attention_h(AttnHP p) {
   const int nfull = p.Tk / 64;       // tiles without a ragged tail
   load_tile(0);
   __syncthreads();   // zero fill done
+  if constexpr (FOLD) {     // K's padding column d = 1.0 in both buffers (the staging never touches padding pieces)
+    if (tid < 128)
+      *reinterpret_cast<unsigned short*>(sK + (tid >> 6) * KBUF + (tid & 63) * KROW + ONES_ROW * 2) = 0x3C00u;
+  }
   if constexpr (ONES_ROW >= 0) {
     if (tid < 16) {
       const uint4 ones = make_uint4(0x3C003C00u, 0x3C003C00u, 0x3C003C00u, 0x3C003C00u);   // 8 x fp16 1.0
@@ -263,18 +311,18 @@ __global__ __launch_bounds__(256) void k_attention_h(AttnHP p) {
   }
 }
 
-template <int NKS, int NT, int ONES_ROW = -1>
+template <int NKS, int NT, int ONES_ROW = -1, bool FOLD = false>
 static int launch_attn_h(tfmq_handle h, const AttnHP& p, void* stream) {
   constexpr int DPAD = NT * 32;
   constexpr size_t smem = 2 * (64 * (DPAD * 2 + 16) + static_cast<size_t>(DPAD) * (64 * 2 + 16));
   static bool configured = false;
   if (!configured) {
-    TFMQ_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_attention_h<NKS, NT, ONES_ROW>),
+    TFMQ_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_attention_h<NKS, NT, ONES_ROW, FOLD>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(smem)));
     configured = true;
   }
   dim3 grid(static_cast<unsigned>((p.Tq + 127) / 128) * p.B * p.heads);
-  hipLaunchKernelGGL((k_attention_h<NKS, NT, ONES_ROW>), grid, dim3(256), smem, as_stream(stream), p);
+  hipLaunchKernelGGL((k_attention_h<NKS, NT, ONES_ROW, FOLD>), grid, dim3(256), smem, as_stream(stream), p);
   TFMQ_LAUNCH_CHECK(h);
   return TFMQ_OK;
 }
@@ -290,7 +338,7 @@ extern "C" int tfmq_attention_f16(tfmq_handle h, const uint16_t* q, const uint16
   AttnHP p{reinterpret_cast<const __half*>(q), reinterpret_cast<const __half*>(k), reinterpret_cast<const __half*>(vt),
            ldq, ldk, out, ldo, yq, aq, B, heads, Tq, Tk, Tk_stride, d, scale};
   if (d <= 32) return launch_attn_h<2, 1>(h, p, stream);
-  if (d == 40) return launch_attn_h<3, 2, 40>(h, p, stream);  // SD v1 at 64x64
+  if (d == 40) return launch_attn_h<3, 2, 40, true>(h, p, stream);  // SD v1 at 64x64
   if (d <= 48) return launch_attn_h<3, 2>(h, p, stream);
   if (d <= 64) return launch_attn_h<4, 2>(h, p, stream);
   if (d == 80) return launch_attn_h<5, 3, 80>(h, p, stream);  // SD v1 at 32x32
