@@ -11,7 +11,8 @@ for wl in sd cifar; do
   cp $O/r01_traffic_$wl.json $R/profiles/r01_traffic_$wl.json
   timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/st_$wl -- python $R/bench.py --workload $wl --steps 2 --warmup 1 > $O/bench_$wl.log 2> $O/bench_$wl.err
   s=$(ls /tmp/st_$wl/*/*kernel_stats.csv | head -1); cp $s $O/r01_bench_${wl}_kernel_stats.csv
-  grep '^{"metric"' $O/bench_$wl.log | tail -1 > $O/r01_bench_line_$wl.json
+  # the committed bench line is a plain run (rocprofv3 costs 2-3 %), with the fresh traffic file in place
+  python $R/bench.py --workload $wl --steps 2 --warmup 1 2> $O/plain_$wl.err | grep '^{"metric"' | tail -1 > $O/r01_bench_line_$wl.json
   a=$(ls /tmp/st_$wl/*/*agent_info.csv | head -1); cp $a $O/r01_agent_info.csv
 done
 ls -la $O | head -30
