@@ -225,7 +225,7 @@ def setup_sd(args, dev, rank, log):
 def calibration_sample(dev):
     """Second half of BASELINE.json's metric ("... + calibration wall-clock"): milliseconds per AdaRound iteration of
     SD-v1-size reconstruction units (the reference's single-GPU SD setting: mini-batch 8), measured on a bounded sample
-    (3 timed iterations per unit, synthetic cached inputs), and the wall-clock those rates imply for the block
+    (median of 5 timed iterations per unit, synthetic cached inputs), and the wall-clock those rates imply for the block
     reconstructions of the whole UNet at the recipe's 20 000 iterations per unit (16 ResBlocks + 16 transformer blocks
     with at least these sizes' cost classes; layer units, TIB and activation calibration are minutes and left out)."""
     import tfmq_dm_amd.ops as ops
@@ -238,15 +238,17 @@ def calibration_sample(dev):
         qp = ops.minmax_to_qparam(ops.minmax(w.reshape(cout, -1).contiguous(), cout), 16)
         return R.AdaLayer(w, qp[:, 0].contiguous(), qp[:, 1].contiguous(), torch.zeros(cout, device=dev) if bias else None)
 
-    def timeit(unit, bs, iters=3):
+    def timeit(unit, bs, iters=5):
         idx = torch.arange(bs, device=dev)
         unit.iterate(idx)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(iters):
+        torch.cuda.synchronize(dev)
+        ts = []
+        for _ in range(iters):          # median: the first iterations after a unit is built still grow allocator pools
+            t0 = time.perf_counter()
             unit.iterate(idx)
-        torch.cuda.synchronize()
-        return (time.perf_counter() - t0) / iters * 1e3
+            torch.cuda.synchronize(dev)
+            ts.append((time.perf_counter() - t0) * 1e3)
+        return sorted(ts)[len(ts) // 2]
     res = {}
     hours = 0.0
     # (channels, resolution, #ResBlocks, #transformer blocks) of SD v1: input + output path per level; middle at 8x8

@@ -14,10 +14,11 @@ def ada(cout, cin, k=1, bias=True):
 def timeit(unit, n, bs, iters=5):
     idx = torch.arange(bs, device=DEV)
     unit.iterate(idx); torch.cuda.synchronize()
-    t0 = time.time()
-    for _ in range(iters): unit.iterate(idx)
-    torch.cuda.synchronize()
-    return (time.time() - t0) / iters * 1e3
+    ts = []
+    for _ in range(iters):
+        t0 = time.time(); unit.iterate(idx); torch.cuda.synchronize(); ts.append((time.time() - t0) * 1e3)
+    if max(ts) > 1.5 * min(ts): print("   uneven iterations:", [round(t, 1) for t in ts], flush=True)
+    return sorted(ts)[len(ts) // 2]
 N, bs = 8, 8
 for (C, HW, heads) in [(320, 64, 8), (640, 32, 8), (1280, 16, 8)]:
     T = HW * HW

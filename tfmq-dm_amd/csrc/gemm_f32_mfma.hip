@@ -7,6 +7,7 @@
 // K-step while the current one is multiplied; 16-byte global loads along whichever dimension of an operand is
 // contiguous (any of the four transpose combinations of the strided-GEMM ABI), scalar loads otherwise.
 #include "common.hpp"
+#include <cstdlib>
 
 typedef float v16f __attribute__((ext_vector_type(16)));
 
@@ -189,14 +190,16 @@ __global__ void k_gemm_splitk_reduce(GemmP p, int batch) {
 // called from tfmq_gemm_f32 (recon_kernels.hip) when the problem is large enough for 128-row tiles
 int tfmq_gemm_f32_mfma_launch(tfmq_handle h, GemmP& p, int batch, hipStream_t st) {
   const int M = p.M, N = p.N;
-  const int BN = N > 64 ? 128 : 64;
+  // 128 x 64 tiles (4 waves along M) measured faster than 128 x 128 at every SD unit shape (no column waste at
+  // N = 320 / 640, twice the blocks for the mid-sized problems); TFMQ_GEMM_BN128 keeps the wide tile for A/B runs
+  const int BN = (N > 64 && getenv("TFMQ_GEMM_BN128")) ? 128 : 64;
   // tiles of ONE batch item: the slicing (hence the summation order) must not depend on how many items share the
   // launch -- results stay bit-identical whatever else is in the batch
   const long tiles = static_cast<long>((N + BN - 1) / BN) * ((M + 127) / 128);
   // fewer tiles than CUs and a long reduction: slice K so that ~2 blocks per CU exist, >= 256 elements per slice
   int ks = 1;
-  if (tiles < h->cu_count && p.K >= 1024) {
-    ks = static_cast<int>((2L * h->cu_count + tiles - 1) / tiles);
+  if (tiles < 2L * h->cu_count && p.K >= 1024) {
+    ks = static_cast<int>((3L * h->cu_count + tiles - 1) / tiles);
     if (ks > p.K / 256) ks = p.K / 256;
     if (ks > 64) ks = 64;
     if (static_cast<long>(batch) * ks > 65535) ks = 65535 / batch;
