@@ -34,7 +34,9 @@ class Arena:
         self.log = []             # (block index, shape, dtype)
         self.cursor = 0
         self.frozen = False
-        self.reuse = reuse
+        # liveness needs torch's storage use count (the hook CUDA-graph trees use); without it every allocation keeps
+        # its own block, which is correct and merely larger
+        self.reuse = reuse and hasattr(torch._C, "_storage_Use_Count")
         self._by_size = {}        # nbytes -> [block indices]
 
     def rewind(self):
