@@ -45,6 +45,11 @@ class _Layer:
         kw.setdefault("want_stats", True)   # conv-epilogue GroupNorm statistics (K8 split form)
         if self.kind == "w4a8":
             return ops.conv2d_w4a8(x, self.p, self.aq, **kw)
+        if x.dtype == torch.float32 and ops.f16_dma_ok(self.p.cin, self.p.kh, self.p.kw):
+            # un-quantised / weight-only layers round their input to fp16 while staging anyway: one conversion pass and
+            # the LDS-DMA pipeline beat the register-staged fp32-input kernel ~3x (FP / weight-only state: the
+            # calibration data passes and the FP sampling of the calibration set); bit-identical
+            x = ops.to_half(x)
         return ops.conv2d_f16(x, self.p, **kw)
 
 
@@ -57,6 +62,24 @@ def ddim_resblock_names(cfg) -> List[str]:
     for i in range(nlev):
         names += [f"up.{i}.block.{j}" for j in range(nres + 1)]
     return names
+
+
+class UnitReached(Exception):
+    """Raised by a StopAt tap dictionary once the requested unit's tensors are recorded."""
+
+
+class StopAt(dict):
+    """taps={} argument of forward() that ends the forward at unit `name` (the reference's DataSaverHook +
+    StopForwardException, quant/data_utill.py:76-111): what lies downstream of the unit is never launched."""
+
+    def __init__(self, name: str):
+        super().__init__()
+        self.stop = name
+
+    def __setitem__(self, k, v):
+        super().__setitem__(k, v)
+        if k == self.stop:
+            raise UnitReached(k)
 
 
 class DdimUNetEngine:
@@ -318,8 +341,11 @@ class DdimUNetEngine:
         (ops.autotuned) and reused -- the output does not depend on them."""
         if not hasattr(self, "tiles"):
             self.tiles = {}
-        with ops.autotuned(self.tiles if self.calib is None else None):
-            return self._forward(*a, **k)
+        try:
+            with ops.autotuned(self.tiles if self.calib is None else None):
+                return self._forward(*a, **k)
+        except UnitReached:
+            return None
 
     def _forward(self, x: torch.Tensor, t: Optional[torch.Tensor] = None, taps: Optional[dict] = None) -> torch.Tensor:
         """x: fp32 NHWC [B,H,W,C].  t: [B] fp32 timesteps, or None to use the per-step TIB table

@@ -19,7 +19,7 @@ import torch
 
 from .. import ops
 from .._lib import TfmqError
-from .ddim_unet import DdimUNetEngine, LayerQ, _Layer
+from .ddim_unet import UnitReached, StopAt, DdimUNetEngine, LayerQ, _Layer
 
 
 def _n_children(sd, prefix):
@@ -354,8 +354,11 @@ class LdmUNetEngine(DdimUNetEngine):
         (ops.autotuned) and reused -- the output does not depend on them."""
         if not hasattr(self, "tiles"):
             self.tiles = {}
-        with ops.autotuned(self.tiles if self.calib is None else None):
-            return self._forward(*a, **k)
+        try:
+            with ops.autotuned(self.tiles if self.calib is None else None):
+                return self._forward(*a, **k)
+        except UnitReached:
+            return None
 
     def _forward(self, x: torch.Tensor, t: Optional[torch.Tensor] = None, context: Optional[torch.Tensor] = None,
                 taps: Optional[dict] = None) -> torch.Tensor:

@@ -2,8 +2,9 @@
 input under the already-quantised upstream (asymmetric reconstruction, A7).
 
 The reference registers a forward hook on the unit and aborts the forward with an exception; here the
-engine plan exposes every unit's input/output as taps of one forward pass, so a capture is two engine
-runs per calibration batch (FP for the target, weight-quantised for the input)."""
+engine plan exposes every unit's input/output as taps of a forward pass and a `StopAt` tap dictionary ends the pass at
+the unit, so a capture is two partial engine runs per calibration batch (FP for the target, weight-quantised for the
+input)."""
 from __future__ import annotations
 
 import logging
@@ -12,6 +13,7 @@ from typing import Tuple, Union
 import torch
 
 from tfmq_dm_amd import ops
+from tfmq_dm_amd.engine import StopAt
 
 logger = logging.getLogger(__name__)
 
@@ -52,14 +54,14 @@ def save_inout(model, layer, cali_data: Tuple[torch.Tensor], asym: bool = False,
         x = ops.nchw_to_nhwc(xs[i:i + batch_size].to(dev).float().contiguous())
         t = ts[i:i + batch_size].to(dev).float().contiguous()
         c = None if cs is None else cs[i:i + batch_size].to(dev).float().contiguous()
-        taps = {}
+        taps = StopAt(name)                             # nothing downstream of the unit is launched
         model.set_quant_state(False, False)             # target: FP model
         fwd(x, t, c, taps)
         if name not in taps:
             raise KeyError(f"save_inout: the engine exposes no tap for unit '{name}'")
         outs.append(taps[name][1])
         if asym:                                        # input: upstream with the already-quantised weights
-            taps = {}
+            taps = StopAt(name)
             model.set_quant_state(True, use_act)
             fwd(x, t, c, taps)
         tin = taps[name][0]

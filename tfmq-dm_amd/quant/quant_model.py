@@ -172,6 +172,9 @@ class QuantModel(nn.Module):
                 for pn, p in mod.named_parameters(recurse=False):
                     sd[f"{n}.{pn}"] = p.detach()
         eng = engine_cls(sd, self.model.engine_cfg(), device)
+        if not hasattr(self, "_tiles"):
+            self._tiles = {}
+        eng.tiles = self._tiles      # measured tile shapes survive re-lowering (keys are shapes, not weights)
         n_steps = 1 if self._act_table is None else self._act_table.shape[0]
         qtable = torch.zeros(n_steps, max(len(act_names), 1), 2, dtype=torch.float32, device=device)
         if self._act_step is None:
