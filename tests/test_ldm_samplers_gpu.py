@@ -175,3 +175,25 @@ def test_dpm_kernels_bit_exact():
     cd = float(0.5 * f(cm))
     want = f(cx) * x - f(cm) * m0 - f(cd) * (f(ir) * (m0 - m1))
     assert torch.equal(ops.dpm_update(2, x.to(DEV), m0.to(DEV), m1.to(DEV), cx, cm, cd, ir).cpu(), want)
+
+
+def test_graph_fast_path_of_the_dropin_samplers(ldm):
+    """`sample(..., _graph=True)` (what the calibration-set generators pass): captured step graphs instead of the host
+    loop, same recurrence and kernels -- DDIM and PLMS, full length and `untill_fake_t`, CFG 7.5."""
+    from tfmq_dm_amd.ldm.ddim import DDIMSampler, PLMSSampler
+    g, q, m = ldm
+    ctx, uc, x_T = T(g["ctx"]).to(DEV), T(g["traj_uc"]).to(DEV), T(g["traj_xT"]).to(DEV)
+    for cls, S in ((DDIMSampler, 4), (PLMSSampler, 6)):
+        for until in (None, 3):
+            kw = dict(S=S, conditioning=ctx, batch_size=2, shape=[4, 8, 8], verbose=False, unconditional_guidance_scale=7.5,
+                      unconditional_conditioning=uc, eta=0.0, x_T=x_T, untill_fake_t=until)
+            ref, _ = cls(m).sample(**kw)
+            fast, inter = cls(m).sample(_graph=True, **kw)
+            assert hasattr(q, "_graph_samplers") and len(q._graph_samplers) == 1          # the fast path was taken
+            assert float((fast - ref).abs().max()) <= 1e-5 * float(ref.abs().max()), (cls.__name__, until)
+            assert len(inter["x_inter"]) == 2
+    # a call with a callback keeps the host loop
+    seen = []
+    DDIMSampler(m).sample(S=4, conditioning=ctx, batch_size=2, shape=[4, 8, 8], verbose=False, unconditional_guidance_scale=7.5,
+                          unconditional_conditioning=uc, x_T=x_T, img_callback=lambda p, i: seen.append(i), _graph=True)
+    assert seen == [0, 1, 2, 3]

@@ -38,6 +38,51 @@ class DDIMSampler:
         b = x.shape[0]
         return ops.cfg_combine(e2[:b].contiguous(), e2[b:].contiguous(), scale)
 
+    # -------------------------------------------------------------------------------------------- graph fast path
+    def _graph_sample(self, plms: bool, S: int, cond, shape, x_T, scale: float, uc, untill_fake_t):
+        """Opt-in (`sample(..., _graph=True)`, used by the calibration-set generators, which need neither callbacks nor
+        intermediates): the same recurrence as the host loop below, replayed as captured step graphs
+        (ldm/sampler.py) on the engine `model.apply_model` lowers to.  Returns None when the call does not qualify
+        (guidance-free conditional sampling, eta > 0, Finite-Set wrapper attributes set, model not lowered to an engine)."""
+        from .sampler import GraphLatentDdimSampler, GraphLatentPlmsSampler
+        wrapper = getattr(self.model, "model", None)
+        qnn = getattr(wrapper, "diffusion_model", None)
+        if qnn is None or not hasattr(qnn, "engine") or hasattr(wrapper, "tot"):
+            return None
+        dev = self.model.betas.device
+        if dev.type != "cuda":
+            return None
+        guided = uc is not None and scale != 1.0
+        if cond is not None and (not guided or not torch.is_tensor(cond) or cond.dim() != 3 or tuple(uc.shape) != tuple(cond.shape)):
+            return None
+        if cond is None and plms:
+            return None
+        eng = qnn.engine(dev)
+        if eng.step is None:
+            return None
+        b, Cc, H, W = shape
+        ctx_shape = None if cond is None else tuple(cond.shape[1:])
+        key = (id(eng), plms, int(S), b, (Cc, H, W), ctx_shape, float(scale))
+        cache = qnn.__dict__.setdefault("_graph_samplers", {})
+        smp = cache.get(key)
+        if smp is None:
+            cache.clear()                      # one captured plan (and its arena) at a time
+            ac = self.model.alphas_cumprod.detach().float().cpu()
+            if plms:
+                smp = GraphLatentPlmsSampler(eng, S, b, (Cc, H, W), ctx_shape, scale=scale, alphas_cumprod=ac)
+            else:
+                smp = GraphLatentDdimSampler(eng, S, b, (Cc, H, W), ctx_shape, scale=scale, alphas_cumprod=ac)
+            smp.capture()
+            cache[key] = smp
+        img = (torch.randn(shape, device=dev) if x_T is None else x_T.to(dev)).float().contiguous()
+        total = smp.coef.shape[0]
+        n = total if untill_fake_t == float("inf") else max(0, min(total, int(untill_fake_t) - 1))
+        out = smp.sample_nhwc(ops.nchw_to_nhwc(img), cond, uc, steps=n)
+        smp.stream.synchronize()
+        res = ops.nhwc_to_nchw(out).clone()
+        eng.step.zero_()
+        return res, {"x_inter": [img, res], "pred_x0": [img]}
+
     def _check(self, mask, x0, quantize_x0, score_corrector, temperature, noise_dropout):
         if mask is not None or x0 is not None or quantize_x0 or score_corrector is not None or noise_dropout != 0.0 \
                 or temperature != 1.0:
@@ -54,6 +99,11 @@ class DDIMSampler:
         if not untill_fake_t:
             untill_fake_t = float("inf")
         Cc, H, W = shape
+        if kwargs.get("_graph") and eta == 0.0 and callback is None and img_callback is None:
+            r = self._graph_sample(False, S, conditioning, (batch_size, Cc, H, W), x_T, float(unconditional_guidance_scale),
+                                   unconditional_conditioning, untill_fake_t)
+            if r is not None:
+                return r
         return self.ddim_sampling(conditioning, (batch_size, Cc, H, W), x_T=x_T, callback=callback, img_callback=img_callback,
                                   log_every_t=log_every_t, unconditional_guidance_scale=unconditional_guidance_scale,
                                   unconditional_conditioning=unconditional_conditioning, untill_fake_t=untill_fake_t)
@@ -104,6 +154,11 @@ class PLMSSampler(DDIMSampler):
         if not untill_fake_t:
             untill_fake_t = float("inf")
         Cc, H, W = shape
+        if kwargs.get("_graph") and callback is None and img_callback is None:
+            r = self._graph_sample(True, S, conditioning, (batch_size, Cc, H, W), x_T, float(unconditional_guidance_scale),
+                                   unconditional_conditioning, untill_fake_t)
+            if r is not None:
+                return r
         return self.plms_sampling(conditioning, (batch_size, Cc, H, W), x_T=x_T, callback=callback, img_callback=img_callback,
                                   log_every_t=log_every_t, unconditional_guidance_scale=unconditional_guidance_scale,
                                   unconditional_conditioning=unconditional_conditioning, untill_fake_t=untill_fake_t)

@@ -36,6 +36,13 @@ def _is_ddim_like(sampler) -> bool:
     return isinstance(sampler, DDIMSampler) or sampler.__class__.__name__ in ("DDIMSampler", "PLMSSampler")
 
 
+def _fast(sampler) -> dict:
+    """The package's own DDIM / PLMS samplers replay captured step graphs when neither callbacks nor intermediates are
+    asked for (ldm/ddim.py: _graph_sample) -- same recurrence, same kernels; other sampler objects are called as is."""
+    from tfmq_dm_amd.ldm.ddim import DDIMSampler
+    return {"_graph": True} if isinstance(sampler, DDIMSampler) else {}
+
+
 def generate_cali_data_ldm(model, T: int, c: int, batch_size: int, shape: List[int], vanilla: bool = False,
                            dpm: bool = False, plms: bool = False, eta: float = 0.0) -> Tuple[torch.Tensor]:
     """reference :75-112 (unconditional LDMs): for every c-th step t, sample from fresh noise until step t with the
@@ -48,7 +55,7 @@ def generate_cali_data_ldm(model, T: int, c: int, batch_size: int, shape: List[i
     tmp = []
     for t in range(1, T + 1):
         if t % c == 0:
-            x_t, t_t = sampler.sample(S=T, batch_size=batch_size, shape=shape, verbose=False, eta=eta, untill_fake_t=t)
+            x_t, t_t = sampler.sample(S=T, batch_size=batch_size, shape=shape, verbose=False, eta=eta, untill_fake_t=t, **_fast(sampler))
             if _is_ddim_like(sampler):       # DPM-Solver returns its own (continuous) time labels
                 t_t = torch.full((batch_size,), _real_time(T, t), device=sampler.model.betas.device, dtype=torch.long)
             tmp.append((x_t, t_t))
@@ -75,7 +82,7 @@ def generate_cali_data_ldm_imagenet(model, T: int, c: int, batch_size: int, shap
                     c_t = model.get_learned_conditioning({model.cond_stage_key: xc.to(model.device)})
                     x_t, _ = sampler.sample(S=T, batch_size=batch_size, shape=shape, verbose=False, eta=eta,
                                             unconditional_guidance_scale=scale, unconditional_conditioning=uc_t,
-                                            conditioning=c_t, untill_fake_t=i)
+                                            conditioning=c_t, untill_fake_t=i, **_fast(sampler))
                     t_t = torch.full((batch_size,), _real_time(T, i), device=sampler.model.betas.device, dtype=torch.long)
                     tmp += [(x_t, t_t, c_t), (x_t, t_t, uc_t)]
     return _stack(tmp)
@@ -98,7 +105,7 @@ def generate_cali_text_guided_data(model, sampler, T: int, c: int, batch_size: i
                     c_t = model.get_learned_conditioning(batch_size * [p])
                     x_t, t_t = sampler.sample(S=T, conditioning=c_t, batch_size=batch_size, shape=shape, verbose=False,
                                               unconditional_guidance_scale=7.5, unconditional_conditioning=uc_t,
-                                              untill_fake_t=t)
+                                              untill_fake_t=t, **_fast(sampler))
                     if _is_ddim_like(sampler):
                         t_t = torch.full((batch_size,), _real_time(T, t), device=sampler.model.betas.device, dtype=torch.long)
                     tmp += [(x_t, t_t, c_t), (x_t, t_t, uc_t)]

@@ -179,7 +179,7 @@ class QuantModel(nn.Module):
         qtable = torch.zeros(n_steps, max(len(act_names), 1), 2, dtype=torch.float32, device=device)
         if self._act_step is None:
             self._act_step = torch.zeros(1, dtype=torch.int32, device=device)
-        eng.prepare(wq, qtable if act_names else None, self._act_step if act_names else None)
+        eng.prepare(wq, qtable if act_names else None, self._act_step)   # the step counter also indexes the per-step TIB table
         self._plan = (eng, act_names, qtable)
         self._sync_act_params()
         return eng
