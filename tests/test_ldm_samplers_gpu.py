@@ -136,7 +136,8 @@ def test_text_guided_calibration_set(ldm):
         ref, _ = s.sample(S=T_, conditioning=m.get_learned_conditioning(bs * ["a"]), batch_size=bs, shape=[4, 8, 8], verbose=False,
                           unconditional_guidance_scale=7.5, unconditional_conditioning=m.get_learned_conditioning(bs * [""]),
                           untill_fake_t=2)
-        assert torch.equal(ref, xs[:bs])
+        # (the generator batches the prompts of a step into one captured-graph sampling: same noise order, same recurrence)
+        assert float((ref - xs[:bs]).abs().max()) <= 1e-5 * float(ref.abs().max())
         assert torch.isfinite(xs).all()
 
 
