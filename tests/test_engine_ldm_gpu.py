@@ -147,6 +147,37 @@ def test_single_wide_head_unet_vs_oracle():
     assert float((eps - ref).abs().max() / ref.abs().max()) <= 1e-2
 
 
+def test_fp_state_uses_the_f16_attention_vs_oracle():
+    """FP state (calibration data passes, FP sampling of the calibration set) at a width where the fused q|k|v
+    projection qualifies for the fp16-operand attention (2*C % 128 == 0): random-init UNet vs the CPU oracle."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from tfmq_dm_amd import ops
+    from tfmq_dm_amd.ddim.models import random_init
+    from tfmq_dm_amd.engine import LdmUNetEngine
+    from tfmq_dm_amd.ldm.unet import UNetModel
+    kw = dict(image_size=8, in_channels=4, model_channels=64, out_channels=4, num_res_blocks=1, attention_resolutions=[1, 2],
+              channel_mult=[1, 2], num_heads=2, use_spatial_transformer=True, transformer_depth=1, context_dim=48)
+    m = random_init(UNetModel(**kw), 31)
+    sd = {k: v.detach() for k, v in m.state_dict().items()}
+    cfg = m.engine_cfg()
+    gen = torch.Generator().manual_seed(6)
+    x, t, ctx = torch.randn(3, 4, 8, 8, generator=gen), torch.tensor([900.0, 400.0, 17.0]), torch.randn(3, 7, 48, generator=gen)
+    eng = LdmUNetEngine(sd, cfg, DEV)
+    eng.prepare()
+    calls = []
+    orig = ops.attention_f16
+    ops.attention_f16 = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+    try:
+        eps = nchw(eng.forward(nhwc(x), t.to(DEV), ctx.to(DEV)))
+    finally:
+        ops.attention_f16 = orig
+    assert len(calls) >= 2                                    # self attention of both levels took the fp16 kernel
+    with torch.no_grad():
+        ref = O.ldm_unet_forward(sd, dict(cfg), x, t.long(), ctx, O.QuantSpec(wq={}, aq={}))
+    assert float((eps - ref).abs().max() / ref.abs().max()) <= 1e-2
+
+
 def test_graph_plms_sampler_matches_the_eager_recurrence(env):
     """GraphLatentPlmsSampler (four captured graphs, history ring, step counter) against the PLMS recurrence of
     p_sample_plms (ldm/models/diffusion/plms.py:179-242) spelled out with the same kernels and eager engine forwards:

@@ -186,6 +186,18 @@ class LdmUNetEngine(DdimUNetEngine):
         heads = self.cfg["num_heads"]
         to_out = L[p + ".to_out.0"]
         f = self.fused_qkv.get(p) if self_attn else None
+        if f is not None and f.kind != "w4a8" and self.calib is None:
+            # FP / weight-only state (calibration data passes, FP sampling of the calibration set): the same fp16-operand
+            # attention, fed by the un-quantised fused projection
+            B, T, Cin = xq_src.shape
+            Cc = f.p.cout // 3
+            d = Cc // heads
+            if (ops.attention_f16_ok(d, T) and (2 * Cc) % 128 == 0 and T % 4 == 0 and xq_src.dtype == torch.float32
+                    and ops.f16_dma_ok(Cin, 1, 1)):
+                y16, vt = ops.conv2d_f16(ops.to_half(xq_src.reshape(B, T, 1, Cin)), f.p, out_f16=True, t_col0=2 * Cc)
+                y16 = y16.reshape(B, T, 3 * Cc)
+                o, _ = ops.attention_f16(y16[..., :Cc], y16[..., Cc:2 * Cc], vt, heads, float(d ** -0.5))
+                return self._tok(to_out, self._quant_in(to_out, o), residual=x_res)
         if f is not None and f.kind == "w4a8":
             # main path: the projection GEMM writes q | k as fp16 rows and v as fp16 V^T, the attention kernel
             # copies them tile by tile (no fp32 round trip, no conversion, no transposition)

@@ -505,9 +505,12 @@ def conv2d_w4a8(xq: torch.Tensor, pw: PackedW4, aq: QSel, stride: int = 1, pad: 
 def conv2d_f16(x: torch.Tensor, pf: PackedF16, stride: int = 1, pad: Tuple[int, int, int, int] = (0, 0, 0, 0),
                up2x: bool = False, rowadd: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
                out: Optional[torch.Tensor] = None, y_coff: int = 0, rowadd_ld=None, rowadd_step=None,
-               rowadd_step_stride: int = 0, want_stats: bool = False) -> torch.Tensor:
+               rowadd_step_stride: int = 0, want_stats: bool = False, out_f16: bool = False,
+               t_col0: Optional[int] = None):
     """x: fp32 NHWC, or fp16 NHWC written as fp16 by its producer (groupnorm(half_out=True), to_half): the fp16 input
-    takes the LDS-DMA pipeline (Cin % 32 == 0, <= 9 taps).  Un-quantised layers (f16 MFMA, fp32 accumulate)."""
+    takes the LDS-DMA pipeline (Cin % 32 == 0, <= 9 taps).  Un-quantised layers (f16 MFMA, fp32 accumulate).
+    out_f16 / t_col0: as conv2d_w4a8 (fp16 rows, channels >= t_col0 transposed into a second tensor: the operands of
+    attention_f16 from a fused q|k|v projection); returns (y, yt) when t_col0 is given."""
     d = _dev(x)
     if x.dtype not in (torch.float32, torch.float16):
         raise TfmqError("conv2d_f16: x must be fp32 or fp16")
@@ -516,9 +519,22 @@ def conv2d_f16(x: torch.Tensor, pf: PackedF16, stride: int = 1, pad: Tuple[int, 
     if cin != pf.cin:
         raise TfmqError(f"conv2d_f16: Cin mismatch {cin} vs {pf.cin}")
     Ho, Wo = out_hw(H, W, pf.kh, pf.kw, stride, pad[0], pad[1], pad[2], pad[3], up2x)
-    y = out if out is not None else _alloc(B, Ho, Wo, pf.cout, dtype=torch.float32, device=x.device)
+    if out_f16 and (rowadd is not None or residual is not None or want_stats):
+        raise TfmqError("conv2d_f16: the fp16 output mode takes no rowadd / residual / stats option")
+    y = out if out is not None else _alloc(B, Ho, Wo, pf.cout, dtype=torch.float16 if out_f16 else torch.float32, device=x.device)
+    _chk(y, torch.float16 if out_f16 else torch.float32, "out")
     dsc = _conv_desc(x, B, H, W, cin, pf.cout, pf.kh, pf.kw, stride, pad[0], pad[1], Ho, Wo, up2x, y, y.shape[-1], y_coff,
                      rowadd, residual, rowadd_ld, rowadd_step, rowadd_step_stride)
+    yt = None
+    if out_f16:
+        dsc.out_mode = 1
+        if t_col0 is not None:
+            if t_col0 % 128 or not 0 <= t_col0 < pf.cout or (Ho * Wo) % 4:
+                raise TfmqError("conv2d_f16: t_col0 needs t_col0 % 128 == 0 and Ho*Wo % 4 == 0")
+            yt = _alloc(B, pf.cout - t_col0, Ho * Wo, dtype=torch.float16, device=x.device)
+            dsc.yt, dsc.t_col0 = yt.data_ptr(), int(t_col0)
+    elif t_col0 is not None:
+        raise TfmqError("conv2d_f16: t_col0 needs out_f16")
     dsc.w = pf.w16.data_ptr()
     dsc.wscale = None if pf.wscale is None else pf.wscale.data_ptr()
     dsc.bias = None if pf.bias is None else pf.bias.data_ptr()
@@ -527,7 +543,7 @@ def conv2d_f16(x: torch.Tensor, pf: PackedF16, stride: int = 1, pad: Tuple[int, 
     _attach_stats(dsc, y, B, Ho * Wo, pf.cout, want_stats and y_coff == 0)
     nbytes = (2.0 if x.dtype == torch.float16 else 4.0) * B * H * W * cin + 2.0 * pf.cout * pf.kh * pf.kw * cin + 4.0 * B * Ho * Wo * pf.cout * (2 if residual is not None else 1)
     _profiled_conv("conv2d_f16", "f16", d, dsc, 2.0 * B * Ho * Wo * pf.cout * pf.kh * pf.kw * cin, nbytes)
-    return y
+    return y if yt is None else (y, yt)
 
 
 def f16_dma_ok(cin: int, kh: int, kw: int) -> bool:
