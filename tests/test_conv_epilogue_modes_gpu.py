@@ -175,3 +175,29 @@ def test_tile_variants_are_bit_identical(ops, k, res, mode, B, H):
         ops.set_conv_autotune(None)
     assert len(cache) == 1 and list(cache.values())[0] in (1, 2, 3, 4)
     assert torch.equal(y, outs[0][0])
+
+
+def test_f16_conv_tile_variants_are_bit_identical(ops):
+    """The fp16-activation DMA conv (un-quantised / weight-only layers) in its four tile shapes: same K order per output."""
+    import tfmq_dm_amd.ops as _o
+    g = torch.Generator().manual_seed(19)
+    B, H, W, cin, cout = 8, 32, 32, 64, 320
+    x = torch.randn(B, H, W, cin, generator=g).to(DEV)
+    w = (torch.randn(cout, cin, 3, 3, generator=g) * 0.05).to(DEV)
+    pf = ops.pack_w_f16(w, torch.randn(cout, generator=g).to(DEV))
+    xh = ops.to_half(x)
+    res = torch.randn(B, H, W, cout, generator=g).to(DEV)
+    outs = []
+    orig = _o._tune_conv
+    for tile in (1, 2, 3, 4):
+        ops.set_conv_autotune({})
+        try:
+            _o._tune_conv = lambda h, name, kind, d, dsc, t=tile: t
+            y = ops.conv2d_f16(xh, pf, pad=(1, 1, 1, 1), residual=res, want_stats=True)
+            outs.append((y.clone(), y._tfmq_stats[0].clone()))
+        finally:
+            _o._tune_conv = orig
+            ops.set_conv_autotune(None)
+    for y, st in outs[1:]:
+        assert torch.equal(y, outs[0][0]) and torch.equal(st, outs[0][1])
+    assert torch.equal(outs[0][0], ops.conv2d_f16(x, pf, pad=(1, 1, 1, 1), residual=res))      # == the fp32-input path

@@ -886,10 +886,12 @@ static int launch_conv(tfmq_handle h, const tfmq_conv_desc* dd, void* stream) {
   // large-M layers: 256 x 128 tiles move a quarter fewer L2 -> LDS bytes per MFMA (the K loop is bound by that path)
   const bool dma8 = INT8 && d.Cin % 64 == 0 && d.KH * d.KW <= 9 &&
                     static_cast<size_t>(d.B) * d.H * d.W * d.Cin < (static_cast<size_t>(1) << 31);
-  const bool big_ok = dma8 && !narrow && d.stride == 1 && !d.up2x;
+  // (the fp16-activation DMA kernel shares the pipeline, hence the tile shapes)
+  const bool dma16 = !INT8 && d.x_f16 && d.Cin % 32 == 0 && d.KH * d.KW <= 9;
+  const bool big_ok = (dma8 || dma16) && !narrow && d.stride == 1 && !d.up2x;
   const long tiles128 = static_cast<long>((p.M + 127) / 128) * ((d.Cout + 127) / 128);
   bool small, big;
-  const bool half_n = d.tile == TFMQ_TILE_128x64 && dma8 && small_ok;     // 128 x 64: no column waste for Cout = 64 (2k+1)
+  const bool half_n = d.tile == TFMQ_TILE_128x64 && (dma8 || dma16) && small_ok;     // 128 x 64: no column waste for Cout = 64 (2k+1)
   if (half_n) {
     small = big = false;
   } else if (d.tile == TFMQ_TILE_128 || (d.tile == TFMQ_TILE_64 && small_ok) || (d.tile == TFMQ_TILE_256 && big_ok)) {
@@ -961,7 +963,9 @@ static int launch_conv(tfmq_handle h, const tfmq_conv_desc* dd, void* stream) {
                           static_cast<size_t>(d.B) * d.H * d.W * d.Cin * 2 < (static_cast<size_t>(1) << 31),
                    "conv_f16: fp16 input needs Cin % 32 == 0, <= 9 taps and < 2 GiB of input");
     if (narrow) hipLaunchKernelGGL((k_conv_dma<true, 4, 1, 1, 1>), grid, dim3(256), 0, st, p);
+    else if (half_n) hipLaunchKernelGGL((k_conv_dma<true, 2, 2, 2, 1>), grid, dim3(256), 0, st, p);
     else if (small) hipLaunchKernelGGL((k_conv_dma<true, 2, 2, 1, 1>), grid, dim3(256), 0, st, p);
+    else if (big) hipLaunchKernelGGL((k_conv_dma<true, 2, 2, 4, 2>), grid, dim3(256), 0, st, p);
     else hipLaunchKernelGGL((k_conv_dma<true, 2, 2, 2, 2>), grid, dim3(256), 0, st, p);
   } else {
     // fast addressing: stride 1, no fused upsample, whole K-steps, <= 32 taps, 16-byte aligned rows

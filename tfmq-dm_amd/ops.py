@@ -370,7 +370,7 @@ def _tune_conv(h, name, kind, d, dsc):
     if torch.cuda.is_current_stream_capturing() or dsc.Cout <= 32 or (dsc.residual and dsc.residual in (dsc.y, dsc.yq)):
         return 0                      # cannot time inside a capture / nothing to choose / not idempotent
     cands = [1, 2]
-    if kind == "w4a8" and dsc.Cin % 64 == 0:
+    if (kind == "w4a8" and dsc.Cin % 64 == 0) or (kind == "f16" and dsc.x_f16):
         cands.append(4)
         if dsc.stride == 1 and not dsc.up2x:
             cands.append(3)
