@@ -26,13 +26,15 @@ def uaq2adar(model: nn.Module):
         if isinstance(child, QuantLayer):
             if not child.ignore_recon:
                 child.weight_quant_state()
-                child.wqtizer = AdaRoundQuantizer(child.wqtizer, rmode=RMODE.LEARNED_HARD_SIGMOID, w=child.original_w.data)
+                child.wqtizer = AdaRoundQuantizer(child.wqtizer, rmode=RMODE.LEARNED_HARD_SIGMOID,
+                                                  w=child.original_w.data.to(child.w.device))   # plain attribute: .to() of the model does not move it
         elif isinstance(child, BaseQuantBlock):
             if not child.ignore_recon:
                 for sub in child.modules():
                     if isinstance(sub, QuantLayer):
                         sub.weight_quant_state()
-                        sub.wqtizer = AdaRoundQuantizer(sub.wqtizer, rmode=RMODE.LEARNED_HARD_SIGMOID, w=sub.original_w.data)
+                        sub.wqtizer = AdaRoundQuantizer(sub.wqtizer, rmode=RMODE.LEARNED_HARD_SIGMOID,
+                                                        w=sub.original_w.data.to(sub.w.device))
         else:
             uaq2adar(child)
 
