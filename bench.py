@@ -216,6 +216,7 @@ def setup_sd(args, dev, rank, log):
 
     info = dict(batch=batch, sync=sampler.stream.synchronize, finite=lambda: bool(torch.isfinite(sampler.x).all().item()),
                 stream=sampler.stream, step=eng.step, plms=plms,
+                oracle_state=dict(sd=sd, wq=wq, act_names=act_names, cfg=cfg, eng=eng),     # scratch/sd_parity_full.py
                 workload=("Stable Diffusion v1-4 UNet (859.5M) w4a8 on MI355X: 64x64x4 latents (512x512 images), DDIM-50 eta=0, "
                           f"CFG 7.5 (UNet batch 2x{batch}), 77x768 context, {batch} images per GPU (BASELINE.json configs[3] = the metric's config)"),
                 extra={"batch_per_gpu": batch, "ddim_steps": S, "unet_evals_per_step": S, "unet_batch": 2 * batch, "guidance_scale": scale})
