@@ -244,6 +244,20 @@ int tfmq_attention_f16(tfmq_handle h, const uint16_t* q, const uint16_t* k, cons
                        float* out, int ldo, int8_t* yq, tfmq_qsel aq, int B, int heads, int Tq, int Tk, int Tk_stride,
                        int d, float scale, void* stream);
 
+/* ---- K15: exact-fp32 fused attention for the reconstruction of BasicTransformerBlock units (quant/reconstruction.py:
+ * 86-209 on quant_block.py:248-299; the reference runs einsum / softmax / einsum under autograd).  fp32 operands on
+ * the fp32 matrix cores, nothing of size Tq x Tk is written: the forward returns O and the per-row log-sum-exp in the
+ * exp2 domain (lse[b][h][q] = m + log2(sum_k exp2(scale*log2(e)*s_qk - m))), the backward recomputes the probabilities.
+ * q [B][Tq][ldq], k / v [B][Tk][ldk], head h at channels h*d..; d in {32, 40, 64}; Tq, Tk multiples of 32. */
+int tfmq_attention_f32_fwd(tfmq_handle h, const float* q, const float* k, const float* v, int ldq, int ldk, float* out,
+                           int ldo, float* lse, int B, int heads, int Tq, int Tk, int d, float scale, void* stream);
+/* backward of the above: dq [B][Tq][ldq], dk / dv [B][Tk][ldk] from dout [B][Tq][ldo], the forward's out and lse.
+ * dsum_ws: B*heads*Tq floats of scratch (row sums of dout o out).  Two kernels without atomics (key blocks -> dk, dv;
+ * query blocks -> dq), deterministic. */
+int tfmq_attention_f32_bwd(tfmq_handle h, const float* q, const float* k, const float* v, int ldq, int ldk, const float* out,
+                           const float* dout, int ldo, const float* lse, float* dsum_ws, float* dq, float* dk, float* dv,
+                           int B, int heads, int Tq, int Tk, int d, float scale, void* stream);
+
 /* ---- K11: sampler elementwise (generalized_steps, ddim/functions/denoising.py:31-37) ----- */
 /* coef: device [n_steps][4] = {sqrt(1-a_t), 1/sqrt(a_t)... see DESIGN.md}; step: device scalar.
  * x_next = sqrt(a_next)*x0 + c1*z + c2*eps with x0 = (x - eps*sqrt(1-a_t))/sqrt(a_t). */

@@ -115,6 +115,10 @@ _SIGS = {
                                    c_int, c_void_p]),
     "tfmq_softmax_rows": (c_int, [c_void_p, c_void_p, c_void_p, C.c_long, c_int, c_float, c_void_p]),
     "tfmq_softmax_bwd_rows": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, C.c_long, c_int, c_float, c_void_p]),
+    "tfmq_attention_f32_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_int,
+                                       c_int, c_int, c_int, c_float, c_void_p]),
+    "tfmq_attention_f32_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
+                                       c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p]),
     "tfmq_axpy": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_size_t, c_void_p]),
     "tfmq_upsample2x": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "tfmq_graph_begin": (c_int, [c_void_p, c_void_p]),

@@ -1,0 +1,379 @@
+// K15 (reconstruction): exact-fp32 fused attention, forward and backward, on the fp32 matrix cores
+// (v_mfma_f32_32x32x2f32: fp32 products, fp32 accumulation -- the arithmetic of the strided-GEMM path it replaces).
+// The block reconstruction of a BasicTransformerBlock (quant/reconstruction.py:86-209 on quant_block.py:248-299)
+// runs softmax(Q K^T / sqrt(d)) V and its backward 20 000 times per unit; through GEMMs the 4096-token self attention
+// of the SD 64x64 level materialises S, P, dP and dS (4 x 4.3 GB at mini-batch 8), which is most of the iteration.
+// Here nothing of size T x T touches memory: the forward keeps the row log-sum-exp, the backward recomputes the
+// probabilities tile by tile (two kernels, no atomics: one owns key blocks -> dK, dV; one owns query blocks -> dQ).
+//
+// Layouts: q [B][Tq][ldq], k / v [B][Tk][ldk] with head h at channels h*d .. h*d+d-1 (the packed [B,T,heads*d] tensors
+// of the unit), d even and <= 64, Tq and Tk multiples of 32.  Probabilities live in the exp2 domain:
+// p = exp2(c2 * s - lse), c2 = scale * log2(e), lse[b][h][q] = m + log2(sum exp2(c2 s - m)).
+//
+// MFMA operand map (32x32x2): A lane (row = lane&31, k = lane>>5), B lane (col = lane&31, k = lane>>5); accumulator
+// lane (col = lane&31) holds rows (r&3) + 8*(r>>2) + 4*(lane>>5).  A product whose contraction index is the row index
+// of an accumulator tile takes that tile straight from registers as its B operand: step s contracts rows
+// {rowmap(s, 0), rowmap(s, 1)}, rowmap(s, half) = (s&3) + 8*(s>>2) + 4*half.
+#include "common.hpp"
+
+struct AttnF32P {
+  const float *q, *k, *v;
+  int ldq, ldk;
+  float* out;            // fwd: O; bwd: unused
+  int ldo;
+  float* lse;            // [B][heads][Tq]
+  const float *dout;     // bwd: dO [B][Tq][ldo]
+  const float *dsum;     // bwd: D[b][h][q] = sum_j dO[q][j] O[q][j]
+  float *dq, *dk, *dv;   // bwd outputs (dq uses ldq, dk / dv use ldk)
+  int B, heads, Tq, Tk, d;
+  float scale;
+};
+
+#define PITCH 65   // floats per LDS row (d <= 64): odd -> column-wise fragment reads are conflict free
+
+__device__ __forceinline__ int rowmap(int s, int half) { return (s & 3) + 8 * (s >> 2) + 4 * half; }
+
+// copy a [32][d] tile (rows r0.., row stride ld floats) into LDS [32][PITCH]; d % 4 == 0
+__device__ __forceinline__ void stage32(float* lds, const float* src, long ld, int d, int tid) {
+  const int per = d >> 2;                  // float4 per row
+  for (int i = tid; i < 32 * per; i += 256) {
+    const int r = i / per, c = (i - r * per) * 4;
+    const float4 v = *reinterpret_cast<const float4*>(src + r * ld + c);
+    float* p = lds + r * PITCH + c;
+    p[0] = v.x; p[1] = v.y; p[2] = v.z; p[3] = v.w;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------- forward
+// block = 128 queries (4 waves x 32) of one (batch, head); loops over 32-key tiles (double-buffered K, V in LDS)
+template <int KD>   // d / 2 score MFMA steps
+__global__ __launch_bounds__(256) void k_attn_f32_fwd(AttnF32P p) {
+  __shared__ float sK[2][32 * PITCH];
+  __shared__ float sV[2][32 * PITCH];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int j = lane & 31, half = lane >> 5;
+  const int nqb = p.Tq / 128 + (p.Tq % 128 ? 1 : 0);
+  const int bh = blockIdx.x / nqb, qb = blockIdx.x - bh * nqb;
+  const int b = bh / p.heads, h = bh - b * p.heads;
+  const int d = p.d;
+  const int q_row = qb * 128 + wid * 32 + j;
+  const bool q_ok = q_row < p.Tq;
+  const float c2 = p.scale * 1.44269504088896340736f;
+  float qf[KD];
+  {
+    const float* qp = p.q + (static_cast<long>(b) * p.Tq + (q_ok ? q_row : 0)) * p.ldq + h * d;
+#pragma unroll
+    for (int s = 0; s < KD; ++s) qf[s] = q_ok ? qp[2 * s + half] * c2 : 0.0f;
+  }
+  typedef float v16f __attribute__((ext_vector_type(16)));
+  v16f o[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[t][r] = 0.0f;
+  float m_run = -INFINITY, l_run = 0.0f;
+  const float* kb = p.k + static_cast<long>(b) * p.Tk * p.ldk + h * d;
+  const float* vb = p.v + static_cast<long>(b) * p.Tk * p.ldk + h * d;
+  const int ntile = p.Tk / 32;
+  stage32(sK[0], kb, p.ldk, d, tid);
+  stage32(sV[0], vb, p.ldk, d, tid);
+  __syncthreads();
+  for (int kt = 0; kt < ntile; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < ntile) {
+      stage32(sK[buf ^ 1], kb + static_cast<long>(kt + 1) * 32 * p.ldk, p.ldk, d, tid);
+      stage32(sV[buf ^ 1], vb + static_cast<long>(kt + 1) * 32 * p.ldk, p.ldk, d, tid);
+    }
+    // S^T = K Q^T (already times c2)
+    v16f s;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s[r] = 0.0f;
+#pragma unroll
+    for (int st = 0; st < KD; ++st)
+      s = __builtin_amdgcn_mfma_f32_32x32x2f32(sK[buf][j * PITCH + 2 * st + half], qf[st], s, 0, 0, 0);
+    float mx = s[0];
+#pragma unroll
+    for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[r]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx);
+    float rs = 0.0f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      s[r] = __builtin_amdgcn_exp2f(s[r] - m_new);
+      rs += s[r];
+    }
+    rs += __shfl_xor(rs, 32, 64);
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);     // exp2(-inf) = 0 on the first tile
+    l_run = l_run * alpha + rs;
+    m_run = m_new;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[t][r] *= alpha;
+    // O^T += V^T P^T : contraction over the 32 keys, two per step, straight from the score registers
+#pragma unroll
+    for (int st = 0; st < 16; ++st) {
+      const int key = rowmap(st, half);
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int dd = t * 32 + j;
+        const float a = dd < d ? sV[buf][key * PITCH + dd] : 0.0f;
+        o[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, s[st], o[t], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+  if (!q_ok) return;
+  const float inv = 1.0f / l_run;
+  float* op = p.out + (static_cast<long>(b) * p.Tq + q_row) * p.ldo + h * d;
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int dd = t * 32 + 8 * g + 4 * half;
+      if (dd < d) *reinterpret_cast<float4*>(op + dd) = make_float4(o[t][4 * g] * inv, o[t][4 * g + 1] * inv, o[t][4 * g + 2] * inv, o[t][4 * g + 3] * inv);
+    }
+  if (half == 0) p.lse[(static_cast<long>(b) * p.heads + h) * p.Tq + q_row] = m_run + __builtin_amdgcn_logf(l_run);   // v_log_f32 = log2
+}
+
+extern "C" int tfmq_attention_f32_fwd(tfmq_handle h, const float* q, const float* k, const float* v, int ldq, int ldk,
+                                      float* out, int ldo, float* lse, int B, int heads, int Tq, int Tk, int d, float scale,
+                                      void* stream) {
+  TFMQ_CHECK_ARG(h, h && q && k && v && out && lse, "attention_f32_fwd: null pointer");
+  TFMQ_CHECK_ARG(h, B > 0 && heads > 0 && Tq > 0 && Tk > 0 && Tq % 32 == 0 && Tk % 32 == 0, "attention_f32_fwd: Tq, Tk must be multiples of 32");
+  TFMQ_CHECK_ARG(h, d == 40 || d == 64 || d == 32, "attention_f32_fwd: head dim 32, 40 or 64");
+  TFMQ_CHECK_ARG(h, ldq % 4 == 0 && ldk % 4 == 0 && ldo % 4 == 0, "attention_f32_fwd: leading dims must be multiples of 4");
+  AttnF32P p{q, k, v, ldq, ldk, out, ldo, lse, nullptr, nullptr, nullptr, nullptr, nullptr, B, heads, Tq, Tk, d, scale};
+  dim3 grid(static_cast<unsigned>((Tq + 127) / 128) * B * heads);
+  hipStream_t st = as_stream(stream);
+  if (d == 40) hipLaunchKernelGGL(k_attn_f32_fwd<20>, grid, dim3(256), 0, st, p);
+  else if (d == 32) hipLaunchKernelGGL(k_attn_f32_fwd<16>, grid, dim3(256), 0, st, p);
+  else hipLaunchKernelGGL(k_attn_f32_fwd<32>, grid, dim3(256), 0, st, p);
+  TFMQ_LAUNCH_CHECK(h);
+  return TFMQ_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- backward
+// D[b][h][q] = sum_j dO[b][q][h*d+j] * O[b][q][h*d+j]  (= sum_k P_qk dP_qk, the softmax-backward row term)
+__global__ void k_attn_f32_rowdot(const float* __restrict__ o, const float* __restrict__ dout, int ldo, float* __restrict__ dsum,
+                                  int B, int heads, int Tq, int d) {
+  const long total = static_cast<long>(B) * heads * Tq;
+  for (long i = static_cast<long>(blockIdx.x) * blockDim.x + threadIdx.x; i < total; i += static_cast<long>(gridDim.x) * blockDim.x) {
+    const int qi = static_cast<int>(i % Tq);
+    const long bh = i / Tq;
+    const int h = static_cast<int>(bh % heads), b = static_cast<int>(bh / heads);
+    const long off = (static_cast<long>(b) * Tq + qi) * ldo + h * d;
+    float a = 0.0f;
+    for (int jx = 0; jx < d; jx += 4) {
+      const float4 x = *reinterpret_cast<const float4*>(o + off + jx), y = *reinterpret_cast<const float4*>(dout + off + jx);
+      a += (x.x * y.x + x.y * y.y) + (x.z * y.z + x.w * y.w);
+    }
+    dsum[i] = a;
+  }
+}
+
+// dK, dV: block = 128 keys (4 waves x 32) of one (batch, head); loops over 32-query tiles (Q, dO double-buffered in LDS).
+// Score tile S = Q K^T with col = key, rows = queries, so P and dS feed the two accumulating products as B operands:
+//   dV^T += dO^T P,   dP = dO V^T,   dS = P o (dP - D),   dK^T += Q^T dS   (dK scaled by `scale` at the end)
+template <int KD>
+__global__ __launch_bounds__(256) void k_attn_f32_bwd_kv(AttnF32P p) {
+  __shared__ float sQ[2][32 * PITCH];
+  __shared__ float sO[2][32 * PITCH];
+  __shared__ __attribute__((aligned(16))) float sL[2][32];
+  __shared__ __attribute__((aligned(16))) float sD[2][32];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int j = lane & 31, half = lane >> 5;
+  const int nkb = (p.Tk + 127) / 128;
+  const int bh = blockIdx.x / nkb, kbk = blockIdx.x - bh * nkb;
+  const int b = bh / p.heads, h = bh - b * p.heads;
+  const int d = p.d;
+  const int key = kbk * 128 + wid * 32 + j;
+  const bool k_ok = key < p.Tk;
+  const float c2 = p.scale * 1.44269504088896340736f;
+  float kf[KD], vf[KD];
+  {
+    const long off = (static_cast<long>(b) * p.Tk + (k_ok ? key : 0)) * p.ldk + h * d;
+#pragma unroll
+    for (int s = 0; s < KD; ++s) {
+      kf[s] = k_ok ? p.k[off + 2 * s + half] * c2 : 0.0f;
+      vf[s] = k_ok ? p.v[off + 2 * s + half] : 0.0f;
+    }
+  }
+  typedef float v16f __attribute__((ext_vector_type(16)));
+  v16f dv[2], dk[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dv[t][r] = dk[t][r] = 0.0f;
+  const float* qb = p.q + static_cast<long>(b) * p.Tq * p.ldq + h * d;
+  const float* ob = p.dout + static_cast<long>(b) * p.Tq * p.ldo + h * d;
+  const float* lb = p.lse + (static_cast<long>(b) * p.heads + h) * p.Tq;
+  const float* db = p.dsum + (static_cast<long>(b) * p.heads + h) * p.Tq;
+  const int ntile = p.Tq / 32;
+  auto stage = [&](int buf, int qt) {
+    stage32(sQ[buf], qb + static_cast<long>(qt) * 32 * p.ldq, p.ldq, d, tid);
+    stage32(sO[buf], ob + static_cast<long>(qt) * 32 * p.ldo, p.ldo, d, tid);
+    if (tid < 32) sL[buf][tid] = lb[qt * 32 + tid];
+    else if (tid < 64) sD[buf][tid - 32] = db[qt * 32 + tid - 32];
+  };
+  stage(0, 0);
+  __syncthreads();
+  for (int qt = 0; qt < ntile; ++qt) {
+    const int buf = qt & 1;
+    if (qt + 1 < ntile) stage(buf ^ 1, qt + 1);
+    v16f s, dp;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s[r] = dp[r] = 0.0f;
+#pragma unroll
+    for (int st = 0; st < KD; ++st) {
+      s = __builtin_amdgcn_mfma_f32_32x32x2f32(sQ[buf][j * PITCH + 2 * st + half], kf[st], s, 0, 0, 0);
+      dp = __builtin_amdgcn_mfma_f32_32x32x2f32(sO[buf][j * PITCH + 2 * st + half], vf[st], dp, 0, 0, 0);
+    }
+    // rows of the tile = queries rowmap(r, half): four consecutive per r>>2
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const float4 l4 = *reinterpret_cast<const float4*>(&sL[buf][8 * g + 4 * half]);
+      const float4 d4 = *reinterpret_cast<const float4*>(&sD[buf][8 * g + 4 * half]);
+      const float le[4] = {l4.x, l4.y, l4.z, l4.w}, de[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float pr = __builtin_amdgcn_exp2f(s[4 * g + e] - le[e]);
+        s[4 * g + e] = pr;                          // P
+        dp[4 * g + e] = pr * (dp[4 * g + e] - de[e]);   // dS (without the scale factor)
+      }
+    }
+#pragma unroll
+    for (int st = 0; st < 16; ++st) {
+      const int qr = rowmap(st, half);
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int dd = t * 32 + j;
+        const float ao = dd < d ? sO[buf][qr * PITCH + dd] : 0.0f;
+        const float aq = dd < d ? sQ[buf][qr * PITCH + dd] : 0.0f;
+        dv[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(ao, s[st], dv[t], 0, 0, 0);
+        dk[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq, dp[st], dk[t], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+  if (!k_ok) return;
+  const long off = (static_cast<long>(b) * p.Tk + key) * p.ldk + h * d;
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int dd = t * 32 + 8 * g + 4 * half;
+      if (dd >= d) continue;
+      *reinterpret_cast<float4*>(p.dv + off + dd) = make_float4(dv[t][4 * g], dv[t][4 * g + 1], dv[t][4 * g + 2], dv[t][4 * g + 3]);
+      *reinterpret_cast<float4*>(p.dk + off + dd) = make_float4(dk[t][4 * g] * p.scale, dk[t][4 * g + 1] * p.scale, dk[t][4 * g + 2] * p.scale,
+                                                                dk[t][4 * g + 3] * p.scale);
+    }
+}
+
+// dQ: block = 128 queries of one (batch, head); loops over 32-key tiles (K, V double-buffered in LDS).
+//   S^T = K Q^T (col = query),  dP^T = V dO^T,  dS^T = P^T o (dP^T - D_q),  dQ^T += K^T dS^T   (scaled at the end)
+template <int KD>
+__global__ __launch_bounds__(256) void k_attn_f32_bwd_q(AttnF32P p) {
+  __shared__ float sK[2][32 * PITCH];
+  __shared__ float sV[2][32 * PITCH];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int j = lane & 31, half = lane >> 5;
+  const int nqb = (p.Tq + 127) / 128;
+  const int bh = blockIdx.x / nqb, qbk = blockIdx.x - bh * nqb;
+  const int b = bh / p.heads, h = bh - b * p.heads;
+  const int d = p.d;
+  const int q_row = qbk * 128 + wid * 32 + j;
+  const bool q_ok = q_row < p.Tq;
+  const float c2 = p.scale * 1.44269504088896340736f;
+  float qf[KD], dof[KD];
+  {
+    const long oq = (static_cast<long>(b) * p.Tq + (q_ok ? q_row : 0)) * p.ldq + h * d;
+    const long oo = (static_cast<long>(b) * p.Tq + (q_ok ? q_row : 0)) * p.ldo + h * d;
+#pragma unroll
+    for (int s = 0; s < KD; ++s) {
+      qf[s] = q_ok ? p.q[oq + 2 * s + half] * c2 : 0.0f;
+      dof[s] = q_ok ? p.dout[oo + 2 * s + half] : 0.0f;
+    }
+  }
+  const long li = (static_cast<long>(b) * p.heads + h) * p.Tq + (q_ok ? q_row : 0);
+  const float lse_q = p.lse[li], d_q = p.dsum[li];
+  typedef float v16f __attribute__((ext_vector_type(16)));
+  v16f dq[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dq[t][r] = 0.0f;
+  const float* kb = p.k + static_cast<long>(b) * p.Tk * p.ldk + h * d;
+  const float* vb = p.v + static_cast<long>(b) * p.Tk * p.ldk + h * d;
+  const int ntile = p.Tk / 32;
+  stage32(sK[0], kb, p.ldk, d, tid);
+  stage32(sV[0], vb, p.ldk, d, tid);
+  __syncthreads();
+  for (int kt = 0; kt < ntile; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < ntile) {
+      stage32(sK[buf ^ 1], kb + static_cast<long>(kt + 1) * 32 * p.ldk, p.ldk, d, tid);
+      stage32(sV[buf ^ 1], vb + static_cast<long>(kt + 1) * 32 * p.ldk, p.ldk, d, tid);
+    }
+    v16f s, dp;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s[r] = dp[r] = 0.0f;
+#pragma unroll
+    for (int st = 0; st < KD; ++st) {
+      s = __builtin_amdgcn_mfma_f32_32x32x2f32(sK[buf][j * PITCH + 2 * st + half], qf[st], s, 0, 0, 0);
+      dp = __builtin_amdgcn_mfma_f32_32x32x2f32(sV[buf][j * PITCH + 2 * st + half], dof[st], dp, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dp[r] = __builtin_amdgcn_exp2f(s[r] - lse_q) * (dp[r] - d_q);
+#pragma unroll
+    for (int st = 0; st < 16; ++st) {
+      const int kr = rowmap(st, half);
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int dd = t * 32 + j;
+        const float a = dd < d ? sK[buf][kr * PITCH + dd] : 0.0f;
+        dq[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, dp[st], dq[t], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+  if (!q_ok) return;
+  float* op = p.dq + (static_cast<long>(b) * p.Tq + q_row) * p.ldq + h * d;
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int dd = t * 32 + 8 * g + 4 * half;
+      if (dd < d)
+        *reinterpret_cast<float4*>(op + dd) = make_float4(dq[t][4 * g] * p.scale, dq[t][4 * g + 1] * p.scale, dq[t][4 * g + 2] * p.scale,
+                                                          dq[t][4 * g + 3] * p.scale);
+    }
+}
+
+extern "C" int tfmq_attention_f32_bwd(tfmq_handle h, const float* q, const float* k, const float* v, int ldq, int ldk,
+                                      const float* out, const float* dout, int ldo, const float* lse, float* dsum_ws, float* dq,
+                                      float* dk, float* dv, int B, int heads, int Tq, int Tk, int d, float scale, void* stream) {
+  TFMQ_CHECK_ARG(h, h && q && k && v && out && dout && lse && dsum_ws && dq && dk && dv, "attention_f32_bwd: null pointer");
+  TFMQ_CHECK_ARG(h, B > 0 && heads > 0 && Tq > 0 && Tk > 0 && Tq % 32 == 0 && Tk % 32 == 0, "attention_f32_bwd: Tq, Tk must be multiples of 32");
+  TFMQ_CHECK_ARG(h, d == 40 || d == 64 || d == 32, "attention_f32_bwd: head dim 32, 40 or 64");
+  TFMQ_CHECK_ARG(h, ldq % 4 == 0 && ldk % 4 == 0 && ldo % 4 == 0, "attention_f32_bwd: leading dims must be multiples of 4");
+  AttnF32P p{q, k, v, ldq, ldk, nullptr, ldo, const_cast<float*>(lse), dout, dsum_ws, dq, dk, dv, B, heads, Tq, Tk, d, scale};
+  hipStream_t st = as_stream(stream);
+  const long rows = static_cast<long>(B) * heads * Tq;
+  int blocks = ceil_div(rows, 256);
+  if (blocks > h->cu_count * 16) blocks = h->cu_count * 16;
+  hipLaunchKernelGGL(k_attn_f32_rowdot, dim3(blocks), dim3(256), 0, st, out, dout, ldo, dsum_ws, B, heads, Tq, d);
+  dim3 gkv(static_cast<unsigned>((Tk + 127) / 128) * B * heads), gq(static_cast<unsigned>((Tq + 127) / 128) * B * heads);
+  if (d == 40) {
+    hipLaunchKernelGGL(k_attn_f32_bwd_kv<20>, gkv, dim3(256), 0, st, p);
+    hipLaunchKernelGGL(k_attn_f32_bwd_q<20>, gq, dim3(256), 0, st, p);
+  } else if (d == 32) {
+    hipLaunchKernelGGL(k_attn_f32_bwd_kv<16>, gkv, dim3(256), 0, st, p);
+    hipLaunchKernelGGL(k_attn_f32_bwd_q<16>, gq, dim3(256), 0, st, p);
+  } else {
+    hipLaunchKernelGGL(k_attn_f32_bwd_kv<32>, gkv, dim3(256), 0, st, p);
+    hipLaunchKernelGGL(k_attn_f32_bwd_q<32>, gq, dim3(256), 0, st, p);
+  }
+  TFMQ_LAUNCH_CHECK(h);
+  return TFMQ_OK;
+}

@@ -224,11 +224,17 @@ class TransformerUnit(_Unit):
         self.x, self.ctx, self.y = x, ctx, y
 
     # ---- multi-head attention on packed heads
+    use_flash = True      # exact-fp32 fused attention where its shape rules hold (tests switch it off to compare)
+
     def _attn_fwd(self, q, k, v):
-        """q [B,T,C], k/v [B,L,C] -> (o [B,T,C], P [B,heads,T,L])"""
+        """q [B,T,C], k/v [B,L,C] -> (o [B,T,C], saved): saved = P [B,heads,T,L] on the GEMM path, or the row
+        log-sum-exp and o for the fused kernels (nothing of size T x L is materialised there)."""
         B, T, Cc = q.shape
         L, H = k.shape[1], self.heads
         d = Cc // H
+        if self.use_flash and ops.attention_f32_ok(T, L, d):
+            o, lse = ops.attention_f32_fwd(q.contiguous(), k.contiguous(), v.contiguous(), H, float(d ** -0.5))
+            return o, ("flash", lse, o)
         S = torch.empty(B, H, T, L, dtype=torch.float32, device=q.device)
         for h in range(H):
             ops.gemm_strided(q, h * d, Cc, 1, T * Cc, k, h * d, 1, Cc, L * Cc, S, h * T * L, L, H * T * L, T, L, d, B)
@@ -243,6 +249,9 @@ class TransformerUnit(_Unit):
         B, T, Cc = q.shape
         L, H = k.shape[1], self.heads
         d = Cc // H
+        if isinstance(P, tuple):
+            _, lse, o = P
+            return ops.attention_f32_bwd(q.contiguous(), k.contiguous(), v.contiguous(), o, lse, g_o.contiguous(), H, float(d ** -0.5))
         dV, dK, dQ = torch.empty_like(v), torch.empty_like(k), torch.empty_like(q)
         dP = torch.empty_like(P)
         for h in range(H):

@@ -888,6 +888,38 @@ def gemm_strided(A: torch.Tensor, a_off: int, sam: int, sak: int, bsa: int, B: t
     return Cm
 
 
+def attention_f32_ok(T: int, L: int, d: int) -> bool:
+    return d in (32, 40, 64) and T % 32 == 0 and L % 32 == 0
+
+
+def attention_f32_fwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int, scale: float):
+    """Exact-fp32 fused attention (reconstruction units).  q [B,T,C], k / v [B,L,C] contiguous -> (o [B,T,C],
+    lse [B,heads,T] in the exp2 domain)."""
+    d_ = _dev(q)
+    for t in (q, k, v):
+        _chk(t, torch.float32, "q/k/v")
+    B, T, Cc = q.shape
+    L = k.shape[1]
+    o = _alloc_like(q)
+    lse = _alloc(B, heads, T, dtype=torch.float32, device=q.device)
+    handle(d_).call("attention_f32_fwd", _p(q), _p(k), _p(v), Cc, k.shape[2], _p(o), Cc, _p(lse), B, heads, T, L, Cc // heads,
+                    float(scale), _stream(d_))
+    return o, lse
+
+
+def attention_f32_bwd(q, k, v, o, lse, g_o, heads: int, scale: float):
+    """-> (dQ, dK, dV) of attention_f32_fwd for the upstream gradient g_o [B,T,C]."""
+    d_ = _dev(q)
+    B, T, Cc = q.shape
+    L = k.shape[1]
+    dq, dk, dv = _alloc_like(q), _alloc_like(k), _alloc_like(v)
+    ws = _alloc(B, heads, T, dtype=torch.float32, device=q.device)
+    _chk(g_o, torch.float32, "g_o")
+    handle(d_).call("attention_f32_bwd", _p(q), _p(k), _p(v), Cc, k.shape[2], _p(o), _p(g_o), Cc, _p(lse), _p(ws), _p(dq), _p(dk),
+                    _p(dv), B, heads, T, L, Cc // heads, float(scale), _stream(d_))
+    return dq, dk, dv
+
+
 def layernorm_bwd(x: torch.Tensor, gy: torch.Tensor, gamma: torch.Tensor, eps: float = 1e-5) -> torch.Tensor:
     d = _dev(x)
     _chk(x, torch.float32, "x")
