@@ -198,3 +198,31 @@ def test_graph_fast_path_of_the_dropin_samplers(ldm):
     DDIMSampler(m).sample(S=4, conditioning=ctx, batch_size=2, shape=[4, 8, 8], verbose=False, unconditional_guidance_scale=7.5,
                           unconditional_conditioning=uc, x_T=x_T, img_callback=lambda p, i: seen.append(i), _graph=True)
     assert seen == [0, 1, 2, 3]
+
+
+def test_class_conditional_calibration_set(ldm):
+    """generate_cali_data_ldm_imagenet (quant/data_generate.py:115-154): 32 class labels x every c-th step, CFG with the
+    learned 'unconditional' class 1000; classes share sampler calls, order and pairing as in the reference's loops."""
+    from quant.data_generate import generate_cali_data_ldm_imagenet
+    from tfmq_dm_amd.ldm.ddim import DDIMSampler
+    g, q, m = ldm
+    gen = torch.Generator().manual_seed(9)
+    emb = torch.randn(1001, 5, 64, generator=gen)
+    m.cond_stage_key = "class_label"
+    m.get_learned_conditioning = lambda d: emb[d["class_label"].cpu()].to(DEV)
+    T_, c_, bs = 4, 2, 2
+    torch.manual_seed(21)
+    xs, ts, cs = generate_cali_data_ldm_imagenet(m, T_, c_, bs, [4, 8, 8], eta=0.0, scale=3.0, max_batch=8)
+    n_cls, n_t = 32, T_ // c_
+    assert xs.shape == (n_t * n_cls * 2 * bs, 4, 8, 8) and cs.shape == (n_t * n_cls * 2 * bs, 5, 64)
+    assert ts.tolist() == [(T_ - t) * 1000 // T_ + 1 for t in (2, 4) for _ in range(n_cls * 2 * bs)]
+    classes = [i for i in range(0, 1000, 1000 // 31)]
+    assert torch.equal(cs[:bs].cpu(), emb[classes[0]].expand(bs, 5, 64)) and torch.equal(cs[bs:2 * bs].cpu(), emb[1000].expand(bs, 5, 64))
+    assert torch.equal(cs[2 * bs:3 * bs].cpu(), emb[classes[1]].expand(bs, 5, 64))
+    assert torch.equal(xs[:bs], xs[bs:2 * bs]) and torch.isfinite(xs).all()
+    # first entry == one sampling of class 0 until step 2 from the same noise
+    torch.manual_seed(21)
+    ref, _ = DDIMSampler(m).sample(S=T_, conditioning=emb[[classes[0]] * bs].to(DEV), batch_size=bs, shape=[4, 8, 8], verbose=False,
+                                   unconditional_guidance_scale=3.0, unconditional_conditioning=emb[[1000] * bs].to(DEV),
+                                   untill_fake_t=2)
+    assert float((ref - xs[:bs]).abs().max()) <= 1e-5 * float(ref.abs().max())
