@@ -248,7 +248,7 @@ int tfmq_attention_f16(tfmq_handle h, const uint16_t* q, const uint16_t* k, cons
  * 86-209 on quant_block.py:248-299; the reference runs einsum / softmax / einsum under autograd).  fp32 operands on
  * the fp32 matrix cores, nothing of size Tq x Tk is written: the forward returns O and the per-row log-sum-exp in the
  * exp2 domain (lse[b][h][q] = m + log2(sum_k exp2(scale*log2(e)*s_qk - m))), the backward recomputes the probabilities.
- * q [B][Tq][ldq], k / v [B][Tk][ldk], head h at channels h*d..; d in {32, 40, 64}; Tq, Tk multiples of 32. */
+ * q [B][Tq][ldq], k / v [B][Tk][ldk], head h at channels h*d..; d in {32, 40, 64, 80}; Tq a multiple of 32, any Tk. */
 int tfmq_attention_f32_fwd(tfmq_handle h, const float* q, const float* k, const float* v, int ldq, int ldk, float* out,
                            int ldo, float* lse, int B, int heads, int Tq, int Tk, int d, float scale, void* stream);
 /* backward of the above: dq [B][Tq][ldq], dk / dv [B][Tk][ldk] from dout [B][Tq][ldo], the forward's out and lse.

@@ -25,7 +25,8 @@ def ref_attn(q, k, v, heads, scale):
     return o, lse2
 
 
-@pytest.mark.parametrize("B,heads,T,L,d", [(2, 8, 256, 256, 40), (1, 2, 128, 96, 64), (2, 3, 64, 160, 32), (1, 8, 1024, 1024, 40)])
+@pytest.mark.parametrize("B,heads,T,L,d", [(2, 8, 256, 256, 40), (1, 2, 128, 96, 64), (2, 3, 64, 160, 32), (1, 8, 1024, 1024, 40),
+                                             (2, 8, 128, 77, 40), (1, 2, 96, 200, 80), (2, 1, 64, 5, 32)])
 def test_forward_vs_float64(ops, B, heads, T, L, d):
     g = torch.Generator().manual_seed(T + d)
     C = heads * d
@@ -37,7 +38,8 @@ def test_forward_vs_float64(ops, B, heads, T, L, d):
     assert float((lse.cpu().double() - rl).abs().max()) <= 2e-5
 
 
-@pytest.mark.parametrize("B,heads,T,L,d", [(2, 4, 128, 128, 40), (1, 2, 96, 160, 64), (2, 3, 64, 64, 32), (1, 8, 512, 512, 40)])
+@pytest.mark.parametrize("B,heads,T,L,d", [(2, 4, 128, 128, 40), (1, 2, 96, 160, 64), (2, 3, 64, 64, 32), (1, 8, 512, 512, 40),
+                                             (2, 8, 128, 77, 40), (1, 2, 96, 200, 80), (2, 1, 64, 5, 32)])
 def test_backward_vs_float64_autograd(ops, B, heads, T, L, d):
     g = torch.Generator().manual_seed(7 * T + d)
     C = heads * d

@@ -7,7 +7,7 @@
 // probabilities tile by tile (two kernels, no atomics: one owns key blocks -> dK, dV; one owns query blocks -> dQ).
 //
 // Layouts: q [B][Tq][ldq], k / v [B][Tk][ldk] with head h at channels h*d .. h*d+d-1 (the packed [B,T,heads*d] tensors
-// of the unit), d even and <= 64, Tq and Tk multiples of 32.  Probabilities live in the exp2 domain:
+// of the unit), d in {32, 40, 64, 80}, Tq a multiple of 32, any Tk (a ragged last key tile is masked).  Probabilities live in the exp2 domain:
 // p = exp2(c2 * s - lse), c2 = scale * log2(e), lse[b][h][q] = m + log2(sum exp2(c2 s - m)).
 //
 // MFMA operand map (32x32x2): A lane (row = lane&31, k = lane>>5), B lane (col = lane&31, k = lane>>5); accumulator
@@ -29,16 +29,18 @@ struct AttnF32P {
   float scale;
 };
 
-#define PITCH 65   // floats per LDS row (d <= 64): odd -> column-wise fragment reads are conflict free
+// floats per LDS row: odd -> column-wise fragment reads are conflict free (65 for d <= 64, 97 for d <= 96)
+#define PITCH_OF(NT) ((NT) * 32 + 1)
 
 __device__ __forceinline__ int rowmap(int s, int half) { return (s & 3) + 8 * (s >> 2) + 4 * half; }
 
-// copy a [32][d] tile (rows r0.., row stride ld floats) into LDS [32][PITCH]; d % 4 == 0
-__device__ __forceinline__ void stage32(float* lds, const float* src, long ld, int d, int tid) {
+// copy a [32][d] tile (row stride ld floats; rows >= nrows are zero) into LDS [32][PITCH]; d % 4 == 0
+template <int PITCH>
+__device__ __forceinline__ void stage32(float* lds, const float* src, long ld, int d, int tid, int nrows = 32) {
   const int per = d >> 2;                  // float4 per row
   for (int i = tid; i < 32 * per; i += 256) {
     const int r = i / per, c = (i - r * per) * 4;
-    const float4 v = *reinterpret_cast<const float4*>(src + r * ld + c);
+    const float4 v = r < nrows ? *reinterpret_cast<const float4*>(src + r * ld + c) : make_float4(0.f, 0.f, 0.f, 0.f);
     float* p = lds + r * PITCH + c;
     p[0] = v.x; p[1] = v.y; p[2] = v.z; p[3] = v.w;
   }
@@ -46,8 +48,9 @@ __device__ __forceinline__ void stage32(float* lds, const float* src, long ld, i
 
 // ---------------------------------------------------------------------------------------------- forward
 // block = 128 queries (4 waves x 32) of one (batch, head); loops over 32-key tiles (double-buffered K, V in LDS)
-template <int KD>   // d / 2 score MFMA steps
+template <int KD, int NT>   // d / 2 score MFMA steps; 32-row tiles covering d
 __global__ __launch_bounds__(256) void k_attn_f32_fwd(AttnF32P p) {
+  constexpr int PITCH = PITCH_OF(NT);
   __shared__ float sK[2][32 * PITCH];
   __shared__ float sV[2][32 * PITCH];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -66,23 +69,23 @@ __global__ __launch_bounds__(256) void k_attn_f32_fwd(AttnF32P p) {
     for (int s = 0; s < KD; ++s) qf[s] = q_ok ? qp[2 * s + half] * c2 : 0.0f;
   }
   typedef float v16f __attribute__((ext_vector_type(16)));
-  v16f o[2];
+  v16f o[NT];
 #pragma unroll
-  for (int t = 0; t < 2; ++t)
+  for (int t = 0; t < NT; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) o[t][r] = 0.0f;
   float m_run = -INFINITY, l_run = 0.0f;
   const float* kb = p.k + static_cast<long>(b) * p.Tk * p.ldk + h * d;
   const float* vb = p.v + static_cast<long>(b) * p.Tk * p.ldk + h * d;
-  const int ntile = p.Tk / 32;
-  stage32(sK[0], kb, p.ldk, d, tid);
-  stage32(sV[0], vb, p.ldk, d, tid);
+  const int ntile = (p.Tk + 31) / 32;      // the last tile may be ragged: its missing keys are staged as zeros and masked
+  stage32<PITCH>(sK[0], kb, p.ldk, d, tid, p.Tk);
+  stage32<PITCH>(sV[0], vb, p.ldk, d, tid, p.Tk);
   __syncthreads();
   for (int kt = 0; kt < ntile; ++kt) {
     const int buf = kt & 1;
     if (kt + 1 < ntile) {
-      stage32(sK[buf ^ 1], kb + static_cast<long>(kt + 1) * 32 * p.ldk, p.ldk, d, tid);
-      stage32(sV[buf ^ 1], vb + static_cast<long>(kt + 1) * 32 * p.ldk, p.ldk, d, tid);
+      stage32<PITCH>(sK[buf ^ 1], kb + static_cast<long>(kt + 1) * 32 * p.ldk, p.ldk, d, tid, p.Tk - (kt + 1) * 32);
+      stage32<PITCH>(sV[buf ^ 1], vb + static_cast<long>(kt + 1) * 32 * p.ldk, p.ldk, d, tid, p.Tk - (kt + 1) * 32);
     }
     // S^T = K Q^T (already times c2)
     v16f s;
@@ -91,6 +94,11 @@ __global__ __launch_bounds__(256) void k_attn_f32_fwd(AttnF32P p) {
 #pragma unroll
     for (int st = 0; st < KD; ++st)
       s = __builtin_amdgcn_mfma_f32_32x32x2f32(sK[buf][j * PITCH + 2 * st + half], qf[st], s, 0, 0, 0);
+    if ((kt + 1) * 32 > p.Tk) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        if (kt * 32 + rowmap(r, half) >= p.Tk) s[r] = -INFINITY;
+    }
     float mx = s[0];
 #pragma unroll
     for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[r]);
@@ -107,7 +115,7 @@ __global__ __launch_bounds__(256) void k_attn_f32_fwd(AttnF32P p) {
     l_run = l_run * alpha + rs;
     m_run = m_new;
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int t = 0; t < NT; ++t)
 #pragma unroll
       for (int r = 0; r < 16; ++r) o[t][r] *= alpha;
     // O^T += V^T P^T : contraction over the 32 keys, two per step, straight from the score registers
@@ -115,7 +123,7 @@ __global__ __launch_bounds__(256) void k_attn_f32_fwd(AttnF32P p) {
     for (int st = 0; st < 16; ++st) {
       const int key = rowmap(st, half);
 #pragma unroll
-      for (int t = 0; t < 2; ++t) {
+      for (int t = 0; t < NT; ++t) {
         const int dd = t * 32 + j;
         const float a = dd < d ? sV[buf][key * PITCH + dd] : 0.0f;
         o[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, s[st], o[t], 0, 0, 0);
@@ -127,7 +135,7 @@ __global__ __launch_bounds__(256) void k_attn_f32_fwd(AttnF32P p) {
   const float inv = 1.0f / l_run;
   float* op = p.out + (static_cast<long>(b) * p.Tq + q_row) * p.ldo + h * d;
 #pragma unroll
-  for (int t = 0; t < 2; ++t)
+  for (int t = 0; t < NT; ++t)
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       const int dd = t * 32 + 8 * g + 4 * half;
@@ -140,15 +148,16 @@ extern "C" int tfmq_attention_f32_fwd(tfmq_handle h, const float* q, const float
                                       float* out, int ldo, float* lse, int B, int heads, int Tq, int Tk, int d, float scale,
                                       void* stream) {
   TFMQ_CHECK_ARG(h, h && q && k && v && out && lse, "attention_f32_fwd: null pointer");
-  TFMQ_CHECK_ARG(h, B > 0 && heads > 0 && Tq > 0 && Tk > 0 && Tq % 32 == 0 && Tk % 32 == 0, "attention_f32_fwd: Tq, Tk must be multiples of 32");
-  TFMQ_CHECK_ARG(h, d == 40 || d == 64 || d == 32, "attention_f32_fwd: head dim 32, 40 or 64");
+  TFMQ_CHECK_ARG(h, B > 0 && heads > 0 && Tq > 0 && Tk > 0 && Tq % 32 == 0, "attention_f32_fwd: Tq must be a multiple of 32");
+  TFMQ_CHECK_ARG(h, d == 40 || d == 64 || d == 32 || d == 80, "attention_f32_fwd: head dim 32, 40, 64 or 80");
   TFMQ_CHECK_ARG(h, ldq % 4 == 0 && ldk % 4 == 0 && ldo % 4 == 0, "attention_f32_fwd: leading dims must be multiples of 4");
   AttnF32P p{q, k, v, ldq, ldk, out, ldo, lse, nullptr, nullptr, nullptr, nullptr, nullptr, B, heads, Tq, Tk, d, scale};
   dim3 grid(static_cast<unsigned>((Tq + 127) / 128) * B * heads);
   hipStream_t st = as_stream(stream);
-  if (d == 40) hipLaunchKernelGGL(k_attn_f32_fwd<20>, grid, dim3(256), 0, st, p);
-  else if (d == 32) hipLaunchKernelGGL(k_attn_f32_fwd<16>, grid, dim3(256), 0, st, p);
-  else hipLaunchKernelGGL(k_attn_f32_fwd<32>, grid, dim3(256), 0, st, p);
+  if (d == 40) hipLaunchKernelGGL((k_attn_f32_fwd<20, 2>), grid, dim3(256), 0, st, p);
+  else if (d == 32) hipLaunchKernelGGL((k_attn_f32_fwd<16, 1>), grid, dim3(256), 0, st, p);
+  else if (d == 64) hipLaunchKernelGGL((k_attn_f32_fwd<32, 2>), grid, dim3(256), 0, st, p);
+  else hipLaunchKernelGGL((k_attn_f32_fwd<40, 3>), grid, dim3(256), 0, st, p);
   TFMQ_LAUNCH_CHECK(h);
   return TFMQ_OK;
 }
@@ -175,8 +184,9 @@ __global__ void k_attn_f32_rowdot(const float* __restrict__ o, const float* __re
 // dK, dV: block = 128 keys (4 waves x 32) of one (batch, head); loops over 32-query tiles (Q, dO double-buffered in LDS).
 // Score tile S = Q K^T with col = key, rows = queries, so P and dS feed the two accumulating products as B operands:
 //   dV^T += dO^T P,   dP = dO V^T,   dS = P o (dP - D),   dK^T += Q^T dS   (dK scaled by `scale` at the end)
-template <int KD>
+template <int KD, int NT>
 __global__ __launch_bounds__(256) void k_attn_f32_bwd_kv(AttnF32P p) {
+  constexpr int PITCH = PITCH_OF(NT);
   __shared__ float sQ[2][32 * PITCH];
   __shared__ float sO[2][32 * PITCH];
   __shared__ __attribute__((aligned(16))) float sL[2][32];
@@ -200,9 +210,9 @@ __global__ __launch_bounds__(256) void k_attn_f32_bwd_kv(AttnF32P p) {
     }
   }
   typedef float v16f __attribute__((ext_vector_type(16)));
-  v16f dv[2], dk[2];
+  v16f dv[NT], dk[NT];
 #pragma unroll
-  for (int t = 0; t < 2; ++t)
+  for (int t = 0; t < NT; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) dv[t][r] = dk[t][r] = 0.0f;
   const float* qb = p.q + static_cast<long>(b) * p.Tq * p.ldq + h * d;
@@ -211,8 +221,8 @@ __global__ __launch_bounds__(256) void k_attn_f32_bwd_kv(AttnF32P p) {
   const float* db = p.dsum + (static_cast<long>(b) * p.heads + h) * p.Tq;
   const int ntile = p.Tq / 32;
   auto stage = [&](int buf, int qt) {
-    stage32(sQ[buf], qb + static_cast<long>(qt) * 32 * p.ldq, p.ldq, d, tid);
-    stage32(sO[buf], ob + static_cast<long>(qt) * 32 * p.ldo, p.ldo, d, tid);
+    stage32<PITCH>(sQ[buf], qb + static_cast<long>(qt) * 32 * p.ldq, p.ldq, d, tid);
+    stage32<PITCH>(sO[buf], ob + static_cast<long>(qt) * 32 * p.ldo, p.ldo, d, tid);
     if (tid < 32) sL[buf][tid] = lb[qt * 32 + tid];
     else if (tid < 64) sD[buf][tid - 32] = db[qt * 32 + tid - 32];
   };
@@ -246,7 +256,7 @@ __global__ __launch_bounds__(256) void k_attn_f32_bwd_kv(AttnF32P p) {
     for (int st = 0; st < 16; ++st) {
       const int qr = rowmap(st, half);
 #pragma unroll
-      for (int t = 0; t < 2; ++t) {
+      for (int t = 0; t < NT; ++t) {
         const int dd = t * 32 + j;
         const float ao = dd < d ? sO[buf][qr * PITCH + dd] : 0.0f;
         const float aq = dd < d ? sQ[buf][qr * PITCH + dd] : 0.0f;
@@ -259,7 +269,7 @@ __global__ __launch_bounds__(256) void k_attn_f32_bwd_kv(AttnF32P p) {
   if (!k_ok) return;
   const long off = (static_cast<long>(b) * p.Tk + key) * p.ldk + h * d;
 #pragma unroll
-  for (int t = 0; t < 2; ++t)
+  for (int t = 0; t < NT; ++t)
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       const int dd = t * 32 + 8 * g + 4 * half;
@@ -272,8 +282,9 @@ __global__ __launch_bounds__(256) void k_attn_f32_bwd_kv(AttnF32P p) {
 
 // dQ: block = 128 queries of one (batch, head); loops over 32-key tiles (K, V double-buffered in LDS).
 //   S^T = K Q^T (col = query),  dP^T = V dO^T,  dS^T = P^T o (dP^T - D_q),  dQ^T += K^T dS^T   (scaled at the end)
-template <int KD>
+template <int KD, int NT>
 __global__ __launch_bounds__(256) void k_attn_f32_bwd_q(AttnF32P p) {
+  constexpr int PITCH = PITCH_OF(NT);
   __shared__ float sK[2][32 * PITCH];
   __shared__ float sV[2][32 * PITCH];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -298,22 +309,22 @@ __global__ __launch_bounds__(256) void k_attn_f32_bwd_q(AttnF32P p) {
   const long li = (static_cast<long>(b) * p.heads + h) * p.Tq + (q_ok ? q_row : 0);
   const float lse_q = p.lse[li], d_q = p.dsum[li];
   typedef float v16f __attribute__((ext_vector_type(16)));
-  v16f dq[2];
+  v16f dq[NT];
 #pragma unroll
-  for (int t = 0; t < 2; ++t)
+  for (int t = 0; t < NT; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) dq[t][r] = 0.0f;
   const float* kb = p.k + static_cast<long>(b) * p.Tk * p.ldk + h * d;
   const float* vb = p.v + static_cast<long>(b) * p.Tk * p.ldk + h * d;
-  const int ntile = p.Tk / 32;
-  stage32(sK[0], kb, p.ldk, d, tid);
-  stage32(sV[0], vb, p.ldk, d, tid);
+  const int ntile = (p.Tk + 31) / 32;
+  stage32<PITCH>(sK[0], kb, p.ldk, d, tid, p.Tk);
+  stage32<PITCH>(sV[0], vb, p.ldk, d, tid, p.Tk);
   __syncthreads();
   for (int kt = 0; kt < ntile; ++kt) {
     const int buf = kt & 1;
     if (kt + 1 < ntile) {
-      stage32(sK[buf ^ 1], kb + static_cast<long>(kt + 1) * 32 * p.ldk, p.ldk, d, tid);
-      stage32(sV[buf ^ 1], vb + static_cast<long>(kt + 1) * 32 * p.ldk, p.ldk, d, tid);
+      stage32<PITCH>(sK[buf ^ 1], kb + static_cast<long>(kt + 1) * 32 * p.ldk, p.ldk, d, tid, p.Tk - (kt + 1) * 32);
+      stage32<PITCH>(sV[buf ^ 1], vb + static_cast<long>(kt + 1) * 32 * p.ldk, p.ldk, d, tid, p.Tk - (kt + 1) * 32);
     }
     v16f s, dp;
 #pragma unroll
@@ -325,11 +336,16 @@ __global__ __launch_bounds__(256) void k_attn_f32_bwd_q(AttnF32P p) {
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) dp[r] = __builtin_amdgcn_exp2f(s[r] - lse_q) * (dp[r] - d_q);
+    if ((kt + 1) * 32 > p.Tk) {        // keys past the end: no gradient through them
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        if (kt * 32 + rowmap(r, half) >= p.Tk) dp[r] = 0.0f;
+    }
 #pragma unroll
     for (int st = 0; st < 16; ++st) {
       const int kr = rowmap(st, half);
 #pragma unroll
-      for (int t = 0; t < 2; ++t) {
+      for (int t = 0; t < NT; ++t) {
         const int dd = t * 32 + j;
         const float a = dd < d ? sK[buf][kr * PITCH + dd] : 0.0f;
         dq[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, dp[st], dq[t], 0, 0, 0);
@@ -340,7 +356,7 @@ __global__ __launch_bounds__(256) void k_attn_f32_bwd_q(AttnF32P p) {
   if (!q_ok) return;
   float* op = p.dq + (static_cast<long>(b) * p.Tq + q_row) * p.ldq + h * d;
 #pragma unroll
-  for (int t = 0; t < 2; ++t)
+  for (int t = 0; t < NT; ++t)
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       const int dd = t * 32 + 8 * g + 4 * half;
@@ -354,8 +370,8 @@ extern "C" int tfmq_attention_f32_bwd(tfmq_handle h, const float* q, const float
                                       const float* out, const float* dout, int ldo, const float* lse, float* dsum_ws, float* dq,
                                       float* dk, float* dv, int B, int heads, int Tq, int Tk, int d, float scale, void* stream) {
   TFMQ_CHECK_ARG(h, h && q && k && v && out && dout && lse && dsum_ws && dq && dk && dv, "attention_f32_bwd: null pointer");
-  TFMQ_CHECK_ARG(h, B > 0 && heads > 0 && Tq > 0 && Tk > 0 && Tq % 32 == 0 && Tk % 32 == 0, "attention_f32_bwd: Tq, Tk must be multiples of 32");
-  TFMQ_CHECK_ARG(h, d == 40 || d == 64 || d == 32, "attention_f32_bwd: head dim 32, 40 or 64");
+  TFMQ_CHECK_ARG(h, B > 0 && heads > 0 && Tq > 0 && Tk > 0 && Tq % 32 == 0, "attention_f32_bwd: Tq must be a multiple of 32");
+  TFMQ_CHECK_ARG(h, d == 40 || d == 64 || d == 32 || d == 80, "attention_f32_bwd: head dim 32, 40, 64 or 80");
   TFMQ_CHECK_ARG(h, ldq % 4 == 0 && ldk % 4 == 0 && ldo % 4 == 0, "attention_f32_bwd: leading dims must be multiples of 4");
   AttnF32P p{q, k, v, ldq, ldk, nullptr, ldo, const_cast<float*>(lse), dout, dsum_ws, dq, dk, dv, B, heads, Tq, Tk, d, scale};
   hipStream_t st = as_stream(stream);
@@ -364,16 +380,16 @@ extern "C" int tfmq_attention_f32_bwd(tfmq_handle h, const float* q, const float
   if (blocks > h->cu_count * 16) blocks = h->cu_count * 16;
   hipLaunchKernelGGL(k_attn_f32_rowdot, dim3(blocks), dim3(256), 0, st, out, dout, ldo, dsum_ws, B, heads, Tq, d);
   dim3 gkv(static_cast<unsigned>((Tk + 127) / 128) * B * heads), gq(static_cast<unsigned>((Tq + 127) / 128) * B * heads);
-  if (d == 40) {
-    hipLaunchKernelGGL(k_attn_f32_bwd_kv<20>, gkv, dim3(256), 0, st, p);
-    hipLaunchKernelGGL(k_attn_f32_bwd_q<20>, gq, dim3(256), 0, st, p);
-  } else if (d == 32) {
-    hipLaunchKernelGGL(k_attn_f32_bwd_kv<16>, gkv, dim3(256), 0, st, p);
-    hipLaunchKernelGGL(k_attn_f32_bwd_q<16>, gq, dim3(256), 0, st, p);
-  } else {
-    hipLaunchKernelGGL(k_attn_f32_bwd_kv<32>, gkv, dim3(256), 0, st, p);
-    hipLaunchKernelGGL(k_attn_f32_bwd_q<32>, gq, dim3(256), 0, st, p);
-  }
+#define TFMQ_BWD(KD_, NT_)                                                             \
+  do {                                                                                 \
+    hipLaunchKernelGGL((k_attn_f32_bwd_kv<KD_, NT_>), gkv, dim3(256), 0, st, p);        \
+    hipLaunchKernelGGL((k_attn_f32_bwd_q<KD_, NT_>), gq, dim3(256), 0, st, p);          \
+  } while (0)
+  if (d == 40) TFMQ_BWD(20, 2);
+  else if (d == 32) TFMQ_BWD(16, 1);
+  else if (d == 64) TFMQ_BWD(32, 2);
+  else TFMQ_BWD(40, 3);
+#undef TFMQ_BWD
   TFMQ_LAUNCH_CHECK(h);
   return TFMQ_OK;
 }

@@ -889,7 +889,7 @@ def gemm_strided(A: torch.Tensor, a_off: int, sam: int, sak: int, bsa: int, B: t
 
 
 def attention_f32_ok(T: int, L: int, d: int) -> bool:
-    return d in (32, 40, 64) and T % 32 == 0 and L % 32 == 0
+    return d in (32, 40, 64, 80) and T % 32 == 0 and L >= 1
 
 
 def attention_f32_fwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int, scale: float):
