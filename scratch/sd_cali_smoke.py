@@ -43,6 +43,14 @@ def timed(mod, name):
 for mod, name in ((QC, "tib_reconstruction"), (QC, "block_reconstruction"), (QC, "layer_reconstruction"), (QC, "_calibrate_activations"),
                   (QR, "save_inout")):
     if hasattr(mod, name): timed(mod, name)
+import quant.quant_model as QM
+timed(QM.QuantModel, "_lower")
+ncall = collections.Counter()
+_si = QR.save_inout
+def _cnt(*a, **k):
+    ncall["save_inout"] += 1
+    return _si(*a, **k)
+QR.save_inout = _cnt
 t0 = time.time()
 md = cali_model(qnn, (xs, ts, cs), (xs, ts, cs), use_aq=True, path=path, running_stat=True, interval=N, iters=ITERS,
                 batch_size=8, w=0.01, asym=True, warmup=0.2, opt_mode=RLOSS.MSE, multi_gpu=False)
@@ -51,6 +59,7 @@ dt = time.time() - t0
 nw = sum(1 for k in md["weight"] if k.endswith("alpha"))
 print(f"cali_model: {dt:.1f}s for {G*N} samples, {ITERS} iterations/unit; {nw} AdaRound tensors, act groups {[k for k in md if k.startswith('act_')]}", flush=True)
 print("phases (s):", {k: round(v, 1) for k, v in acc.items()})
+print("calls:", dict(ncall))
 print("checkpoint MB:", os.path.getsize(path) / 1e6)
 bad = [k for k, v in md["weight"].items() if torch.is_tensor(v) and v.is_floating_point() and not torch.isfinite(v).all()]
 print("non-finite entries:", bad[:5])

@@ -8,6 +8,7 @@ input)."""
 from __future__ import annotations
 
 import logging
+import os
 from typing import Tuple, Union
 
 import torch
@@ -42,6 +43,10 @@ def save_inout(model, layer, cali_data: Tuple[torch.Tensor], asym: bool = False,
     xs, ts = cali_data[0], cali_data[1]
     cs = cali_data[2] if len(cali_data) > 2 else None
     ins, outs, tembs, ctxs = [], [], [], []
+    # `batch_size` is the reconstruction mini-batch (8 in the SD recipe); the capture forwards are per-sample
+    # independent (tests/test_full_size_properties_gpu.py: batch 12 == 6 + 6 bit for bit), so they run at a batch that
+    # fills the GPU instead of a launch-bound one
+    batch_size = max(int(batch_size), int(os.environ.get("TFMQ_CAPTURE_BATCH", "32")))
 
     def fwd(x, t, c, taps):
         eng = model.engine(dev)
