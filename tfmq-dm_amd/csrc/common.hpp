@@ -38,6 +38,7 @@ struct GemmP {
   int accumulate;                    // C += result
   int ksplit, kchunk;                // split-K: blockIdx.z = batch * ksplit + split, split covers K range [split*kchunk, +kchunk)
   float* partial;                    // [ksplit][batch][M][N] raw partial sums (ksplit > 1)
+  int tiles_n;                       // column tiles (the MFMA kernel's 1-D tile grid)
 };
 
 #define TFMQ_CHECK_ARG(h, cond, msg)          \

@@ -2,29 +2,42 @@
 // accumulation -- the same arithmetic as the FMA kernel in recon_kernels.hip, 4-5x its rate).  Calibration wall-clock
 // is reconstruction-GEMM time: 20 000 Adam iterations per unit, each a block forward + backward.
 //
-// 128 x BN tile (BN = 128 or 64), 4 waves, K-step 16, double-buffered LDS stored K-major ([k][m], [k][n]) so that an
-// MFMA fragment (lane = row/col l%32, k = l/32) is one conflict-free ds_read_b32; global -> register prefetch of the next
-// K-step while the current one is multiplied; 16-byte global loads along whichever dimension of an operand is
-// contiguous (any of the four transpose combinations of the strided-GEMM ABI), scalar loads otherwise.
+// 128 x BN tile (BN = 64, or 128 for A/B runs), 4 waves, K-step 16, double-buffered LDS.  Operands reach the CU by
+// 16-byte buffer loads along whichever dimension is contiguous (any of the four transpose combinations of the
+// strided-GEMM ABI; out-of-range items read zeros from beyond the descriptor's extent: no branch), two K-steps ahead
+// of the MFMAs in two register sets.  A k-contiguous operand is stored as swizzled 64-byte rows and read back with
+// one ds_read_b128 per four MFMA k-pairs; a row-contiguous one is stored K-major ([k][rows]) and read with ds_read_b32.
+// Operands that are neither contiguous nor aligned take the generic loader (scalar loads, run-time mode).
+// Measured (SD unit shapes): 97-113 TFLOP/s of the 157 peak; the same loop without its global loads runs at 110-125,
+// the library's sgemm at 93-134.
 #include "common.hpp"
 #include <cstdlib>
+#include <type_traits>
 
 typedef float v16f __attribute__((ext_vector_type(16)));
 
 
+__device__ __forceinline__ int swz_rk(int row, int slot) { return row * 64 + ((slot ^ ((row >> 2) & 3)) << 4); }
+
 // One operand tile [R rows][16 k] -> LDS [16][R + 4].  (rs, ks) = element strides of the row / k index.
-template <int R>
+// MODE 0: any strides / alignment, decided at run time (scalar loads where nothing is contiguous and aligned).
+template <int R, int MODE>
 struct TileLoader {
   static constexpr int ITEMS = R * 16 / 4 / 256;   // float4 items per thread (R = 128 -> 2, R = 64 -> 1)
-  float4 reg[ITEMS];
+  float4 reg[2][ITEMS];                            // two register sets: the loads run two K-steps ahead
   int mode;                                        // 0 scalar, 1 vector along k, 2 vector along rows
-  __device__ __forceinline__ void init(long rs, long ks, const float* base, int rows, int K) {
+  const float* base;
+  long rs, ks;
+  int r0, rows;
+  __device__ __forceinline__ void init(const float* b, long rs_, long ks_, int r0_, int kb, int rows_, int K) {
+    base = b; rs = rs_; ks = ks_; r0 = r0_; rows = rows_;
     const bool al = (reinterpret_cast<uintptr_t>(base) & 15) == 0;
     if (ks == 1 && al && (rs & 3) == 0 && (K & 3) == 0) mode = 1;
     else if (rs == 1 && al && (ks & 3) == 0 && (rows & 3) == 0) mode = 2;
     else mode = 0;
   }
-  __device__ __forceinline__ void load(const float* base, long rs, long ks, int r0, int k0, int rows, int K) {
+  template <int S>
+  __device__ __forceinline__ void load(int k0, int K) {
     const int tid = threadIdx.x;
 #pragma unroll
     for (int it = 0; it < ITEMS; ++it) {
@@ -49,15 +62,16 @@ struct TileLoader {
         }
         v = make_float4(t[0], t[1], t[2], t[3]);
       }
-      reg[it] = v;
+      reg[S][it] = v;
     }
   }
+  template <int S>
   __device__ __forceinline__ void store(float* lds) {    // lds: [16][R + 4]
     const int tid = threadIdx.x;
 #pragma unroll
     for (int it = 0; it < ITEMS; ++it) {
       const int e = tid + it * 256;
-      const float4 v = reg[it];
+      const float4 v = reg[S][it];
       if (mode == 2) {
         const int k = e / (R / 4), rq = (e % (R / 4)) * 4;
         *reinterpret_cast<float4*>(lds + k * (R + 4) + rq) = v;
@@ -72,8 +86,91 @@ struct TileLoader {
   }
 };
 
-template <int WAVES_M, int WAVES_N, int WM_TILES, int WN_TILES>
-__global__ __launch_bounds__(256) void k_gemm_f32_mfma(GemmP p) {
+// MODE 1 (16-byte loads along k) / MODE 2 (16-byte loads along rows), chosen by the launcher: buffer loads with a
+// per-item byte offset that advances by one K-step; an out-of-range item (row past the operand, k past this slice)
+// gets an offset beyond the descriptor's extent and the hardware returns zeros.  No branch and no dependent select on
+// the loaded value: the generic loader's control flow made the compiler wait for every load where it was issued
+// (vmcnt(0) at each merge); here the loads of K-step s+2 stay in flight under the MFMAs of steps s and s+1.
+typedef int v4i32 __attribute__((ext_vector_type(4)));
+template <int R>
+struct TileLoaderBase {
+  static constexpr int ITEMS = R * 16 / 4 / 256;
+  float4 reg[2][ITEMS];
+  __amdgpu_buffer_rsrc_t rsrc;
+  unsigned off[ITEMS];
+  int kq[ITEMS];
+  bool okr[ITEMS];
+  unsigned kstep;
+  __device__ __forceinline__ void make(const float* b, long extent_elems) {
+    // raw buffer (stride 0), 32-bit data format; the launcher guarantees extent < 2^31 bytes
+    rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(b), 0, static_cast<int>(extent_elems * 4), 0x00020000);
+  }
+  template <int S>
+  __device__ __forceinline__ void load(int k0, int K) {
+#pragma unroll
+    for (int it = 0; it < ITEMS; ++it) {
+      const bool ok = okr[it] && (k0 + kq[it] < K);
+      const v4i32 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, ok ? off[it] : 0x80000000u, 0, 0);
+      reg[S][it] = __builtin_bit_cast(float4, v);
+      off[it] += kstep;
+    }
+  }
+};
+template <int R>
+struct TileLoader<R, 1> : TileLoaderBase<R> {
+  using TileLoaderBase<R>::ITEMS;
+  __device__ __forceinline__ void init(const float* b, long rs, long, int r0, int kb, int rows, int K) {
+    this->make(b, (rows - 1) * rs + K);
+    this->kstep = 16 * 4;
+#pragma unroll
+    for (int it = 0; it < ITEMS; ++it) {
+      const int e = threadIdx.x + it * 256;
+      const int gr = r0 + (e >> 2);
+      this->kq[it] = (e & 3) * 4;
+      this->okr[it] = gr < rows;
+      this->off[it] = static_cast<unsigned>((this->okr[it] ? gr * rs : 0) + kb + this->kq[it]) * 4u;
+    }
+  }
+  // LDS layout of a k-contiguous operand: [row][16 k] = 64-byte rows, the four 16-byte slots of a row XOR-swizzled
+  // (swz_rk) so that both this store and the fragments' ds_read_b128 (lane = row l%32, slot 2*half + l/32) are
+  // conflict free: one 16-byte store per loaded float4, one 16-byte read per FOUR MFMA k-pairs
+  template <int S>
+  __device__ __forceinline__ void store(float* lds) {
+#pragma unroll
+    for (int it = 0; it < ITEMS; ++it) {
+      const int e = threadIdx.x + it * 256;
+      *reinterpret_cast<float4*>(reinterpret_cast<unsigned char*>(lds) + swz_rk(e >> 2, e & 3)) = this->reg[S][it];
+    }
+  }
+};
+template <int R>
+struct TileLoader<R, 2> : TileLoaderBase<R> {
+  using TileLoaderBase<R>::ITEMS;
+  __device__ __forceinline__ void init(const float* b, long, long ks, int r0, int kb, int rows, int K) {
+    this->make(b, (K - 1) * ks + rows);
+    this->kstep = static_cast<unsigned>(16 * ks) * 4u;
+#pragma unroll
+    for (int it = 0; it < ITEMS; ++it) {
+      const int e = threadIdx.x + it * 256;
+      const int k = e / (R / 4), gr = r0 + (e % (R / 4)) * 4;
+      this->kq[it] = k;
+      this->okr[it] = gr < rows;
+      this->off[it] = static_cast<unsigned>((kb + k) * ks + (this->okr[it] ? gr : 0)) * 4u;
+    }
+  }
+  template <int S>
+  __device__ __forceinline__ void store(float* lds) {
+#pragma unroll
+    for (int it = 0; it < ITEMS; ++it) {
+      const int e = threadIdx.x + it * 256;
+      const int k = e / (R / 4), rq = (e % (R / 4)) * 4;
+      *reinterpret_cast<float4*>(lds + k * (R + 4) + rq) = this->reg[S][it];
+    }
+  }
+};
+
+template <int WAVES_M, int WAVES_N, int WM_TILES, int WN_TILES, int MA = 0, int MB = 0>
+__global__ __launch_bounds__(256, (WM_TILES * WN_TILES <= 2) ? 5 : 2) void k_gemm_f32_mfma(GemmP p) {
   constexpr int BM = WAVES_M * WM_TILES * 32, BN = WAVES_N * WN_TILES * 32;
   static_assert(WAVES_M * WAVES_N == 4, "4 waves");
   __shared__ __attribute__((aligned(16))) float sA[2][16 * (BM + 4)];
@@ -90,15 +187,24 @@ __global__ __launch_bounds__(256) void k_gemm_f32_mfma(GemmP p) {
   const float* A = p.A + bz * p.bsa;
   const float* B = p.B + bz * p.bsb;
   float* C = p.C + bz * p.bsc;
-  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  // XCD-aware tile order: the dispatcher places block b on XCD b % 8; each XCD gets a contiguous range of tiles (column
+  // tiles fastest), so the column tiles that share an A row panel -- and the row tiles that share B -- meet in ONE L2
+  // instead of fetching the panel into all eight.  Placement only: any order gives the same result.
+  int tile = blockIdx.x;
+  if (p.tiles_n > 0) {
+    const int nb = gridDim.x, xcd = tile & 7, q = nb >> 3, r = nb & 7;
+    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (tile >> 3);
+  }
+  const int tn = p.tiles_n > 0 ? p.tiles_n : -p.tiles_n;
+  const int m0 = (tile / tn) * BM, n0 = (tile % tn) * BN;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid / WAVES_N, wn = wid % WAVES_N;
   const int l32 = lane & 31, hh = lane >> 5;
 
-  TileLoader<BM> la;
-  TileLoader<BN> lb;
-  la.init(p.sam, p.sak, A, p.M, p.K);
-  lb.init(p.sbn, p.sbk, B, p.N, p.K);
+  TileLoader<BM, MA> la;
+  TileLoader<BN, MB> lb;
+  la.init(A, p.sam, p.sak, m0, kb, p.M, p.K);
+  lb.init(B, p.sbn, p.sbk, n0, kb, p.N, p.K);
 
   v16f acc[WM_TILES][WN_TILES];
 #pragma unroll
@@ -109,36 +215,76 @@ __global__ __launch_bounds__(256) void k_gemm_f32_mfma(GemmP p) {
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
   const int nk = (ke - kb + 15) / 16;
-  la.load(A, p.sam, p.sak, m0, kb, p.M, ke);
-  lb.load(B, p.sbn, p.sbk, n0, kb, p.N, ke);
-  la.store(sA[0]);
-  lb.store(sB[0]);
+  la.template load<0>(kb, ke);
+  lb.template load<0>(kb, ke);
+  la.template load<1>(kb + 16, ke);
+  lb.template load<1>(kb + 16, ke);
+  la.template store<0>(sA[0]);
+  lb.template store<0>(sB[0]);
   __syncthreads();
-  for (int s = 0; s < nk; ++s) {
-    const int buf = s & 1;
-    if (s + 1 < nk) {
-      la.load(A, p.sam, p.sak, m0, kb + (s + 1) * 16, p.M, ke);
-      lb.load(B, p.sbn, p.sbk, n0, kb + (s + 1) * 16, p.N, ke);
-    }
+  // K-step s multiplies LDS buffer s & 1.  Its loads were issued two steps earlier (register set s & 1), stored to LDS
+  // during step s - 1; the set it frees takes the loads of step s + 2 (an L2 miss has two steps to land: with one
+  // step of lookahead the mid-step store waited on HBM).  Past the last K-step every item is out of range: zeros,
+  // stored to the buffer nobody reads again -- no branch around loads or stores.
+  auto step = [&](int s, auto par_tag) {
+    constexpr int PAR = decltype(par_tag)::value;
+    const int buf = PAR;
+#ifndef TFMQ_DBG_GEMM_NO_LOAD      // diagnostics build (results are garbage): the K loop without its global loads
+    la.template load<PAR>(kb + (s + 2) * 16, ke);
+    lb.template load<PAR>(kb + (s + 2) * 16, ke);
+    __builtin_amdgcn_sched_barrier(0);   // the loads stay first in the step (the scheduler sank them below the MFMAs)
+#endif
     const float* a_l = sA[buf] + (wm * WM_TILES * 32) + l32;
     const float* b_l = sB[buf] + (wn * WN_TILES * 32) + l32;
+    const unsigned char* a_b = reinterpret_cast<const unsigned char*>(sA[buf]);
+    const unsigned char* b_b = reinterpret_cast<const unsigned char*>(sB[buf]);
+    // an MFMA multiplies the k-pair (lanes 0-31: first k, lanes 32-63: second k); any pairing is a valid order of the
+    // k sum as long as A and B use the same one: MFMA j of half h takes k = 8h + j (lanes 0-31) and 8h + 4 + j
+    // (lanes 32-63), so a k-contiguous operand feeds four MFMAs from one 16-byte read
 #pragma unroll
-    for (int kp = 0; kp < 8; ++kp) {       // 8 MFMA k-pairs per 16-wide K-step
-      float af[WM_TILES], bf[WN_TILES];
+    for (int half = 0; half < 2; ++half) {
+      float af[WM_TILES][4], bf[WN_TILES][4];
 #pragma unroll
-      for (int i = 0; i < WM_TILES; ++i) af[i] = a_l[(kp * 2 + hh) * (BM + 4) + i * 32];
+      for (int i = 0; i < WM_TILES; ++i) {
+        if constexpr (MA == 1) {
+          const float4 v = *reinterpret_cast<const float4*>(a_b + swz_rk((wm * WM_TILES + i) * 32 + l32, half * 2 + hh));
+          af[i][0] = v.x; af[i][1] = v.y; af[i][2] = v.z; af[i][3] = v.w;
+        } else {
 #pragma unroll
-      for (int j = 0; j < WN_TILES; ++j) bf[j] = b_l[(kp * 2 + hh) * (BN + 4) + j * 32];
+          for (int j = 0; j < 4; ++j) af[i][j] = a_l[(half * 8 + hh * 4 + j) * (BM + 4) + i * 32];
+        }
+      }
 #pragma unroll
-      for (int i = 0; i < WM_TILES; ++i)
+      for (int jn = 0; jn < WN_TILES; ++jn) {
+        if constexpr (MB == 1) {
+          const float4 v = *reinterpret_cast<const float4*>(b_b + swz_rk((wn * WN_TILES + jn) * 32 + l32, half * 2 + hh));
+          bf[jn][0] = v.x; bf[jn][1] = v.y; bf[jn][2] = v.z; bf[jn][3] = v.w;
+        } else {
 #pragma unroll
-        for (int j = 0; j < WN_TILES; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
-    }
-    if (s + 1 < nk) {
-      la.store(sA[buf ^ 1]);
-      lb.store(sB[buf ^ 1]);
+          for (int j = 0; j < 4; ++j) bf[jn][j] = b_l[(half * 8 + hh * 4 + j) * (BN + 4) + jn * 32];
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < WM_TILES; ++i)
+#pragma unroll
+          for (int jn = 0; jn < WN_TILES; ++jn)
+            acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][j], bf[jn][j], acc[i][jn], 0, 0, 0);
+#ifndef TFMQ_DBG_GEMM_NO_STORE
+      // the next K-step's tile goes to the other buffer (nobody reads it during this step) under the second half's
+      // MFMAs: its loads were issued a half step ago, and the barrier below then has no LDS write left to wait for
+      if (half == 0) {
+        la.template store<PAR ^ 1>(sA[buf ^ 1]);
+        lb.template store<PAR ^ 1>(sB[buf ^ 1]);
+      }
+#endif
     }
     __syncthreads();
+  };
+  for (int s = 0; s < nk; s += 2) {
+    step(s, std::integral_constant<int, 0>{});
+    if (s + 1 < nk) step(s + 1, std::integral_constant<int, 1>{});
   }
 
   // C/D layout: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
@@ -221,8 +367,29 @@ int tfmq_gemm_f32_mfma_launch(tfmq_handle h, GemmP& p, int batch, hipStream_t st
     p.ksplit = ks;
     p.partial = h->gemm_ws;
   }
-  dim3 grid((N + BN - 1) / BN, (M + 127) / 128, batch * (ks > 1 ? ks : 1));
-  if (BN == 128) hipLaunchKernelGGL((k_gemm_f32_mfma<2, 2, 2, 2>), grid, dim3(256), 0, st, p);
+  p.tiles_n = (N + BN - 1) / BN;
+  if (getenv("TFMQ_GEMM_NO_XCD")) p.tiles_n = -p.tiles_n;     // A/B runs: plain row-major tile order
+  dim3 grid(((N + BN - 1) / BN) * ((M + 127) / 128), 1, batch * (ks > 1 ? ks : 1));
+  // loader modes (the rules of the generic loader, evaluated once here; batch / split offsets keep the alignment
+  // only if the strides do, which the rules check through bsa / bsb and kchunk % 16 == 0)
+  auto mode_of = [&](const float* base, long rs, long ks, int rows, long bs) {
+    // (+ buffer addressing of the fast loaders: one batch item's extent below 2^31 bytes, offsets in 32 bits)
+    const bool al = (reinterpret_cast<uintptr_t>(base) & 15) == 0 && (bs & 3) == 0 && rs >= 0 && ks >= 0 &&
+                    ((rows - 1) * rs + (static_cast<long>(p.K) - 1) * ks + 1) * 4 + 64L * (rs > ks ? rs : ks) < (1L << 31);
+    if (ks == 1 && al && (rs & 3) == 0 && (p.K & 3) == 0) return 1;
+    if (rs == 1 && al && (ks & 3) == 0 && (rows & 3) == 0) return 2;
+    return 0;
+  };
+  int ma = mode_of(p.A, p.sam, p.sak, M, batch > 1 ? p.bsa : 0), mb = mode_of(p.B, p.sbn, p.sbk, N, batch > 1 ? p.bsb : 0);
+  if (getenv("TFMQ_GEMM_GENERIC_LOADER")) ma = mb = 0;
+  if (BN == 128 && ma == 1 && mb == 1) hipLaunchKernelGGL((k_gemm_f32_mfma<2, 2, 2, 2, 1, 1>), grid, dim3(256), 0, st, p);
+  else if (BN == 128 && ma == 1 && mb == 2) hipLaunchKernelGGL((k_gemm_f32_mfma<2, 2, 2, 2, 1, 2>), grid, dim3(256), 0, st, p);
+  else if (BN == 128 && ma == 2 && mb == 2) hipLaunchKernelGGL((k_gemm_f32_mfma<2, 2, 2, 2, 2, 2>), grid, dim3(256), 0, st, p);
+  else if (BN == 128) hipLaunchKernelGGL((k_gemm_f32_mfma<2, 2, 2, 2>), grid, dim3(256), 0, st, p);
+  else if (ma == 1 && mb == 1) hipLaunchKernelGGL((k_gemm_f32_mfma<4, 1, 1, 2, 1, 1>), grid, dim3(256), 0, st, p);
+  else if (ma == 1 && mb == 2) hipLaunchKernelGGL((k_gemm_f32_mfma<4, 1, 1, 2, 1, 2>), grid, dim3(256), 0, st, p);
+  else if (ma == 2 && mb == 1) hipLaunchKernelGGL((k_gemm_f32_mfma<4, 1, 1, 2, 2, 1>), grid, dim3(256), 0, st, p);
+  else if (ma == 2 && mb == 2) hipLaunchKernelGGL((k_gemm_f32_mfma<4, 1, 1, 2, 2, 2>), grid, dim3(256), 0, st, p);
   else hipLaunchKernelGGL((k_gemm_f32_mfma<4, 1, 1, 2>), grid, dim3(256), 0, st, p);
   if (ks > 1) {
     const size_t total = static_cast<size_t>(M) * N * batch;
