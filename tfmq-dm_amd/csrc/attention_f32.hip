@@ -46,6 +46,43 @@ __device__ __forceinline__ void stage32(float* lds, const float* src, long ld, i
   }
 }
 
+// The same tile copy split in two: buffer loads into registers at the top of a loop iteration (rows past `nrows` --
+// a ragged or non-existent next tile -- get an offset beyond the descriptor's extent and read zeros: no branch, so the
+// compiler does not wait for the loads where they are issued), LDS stores after the iteration's MFMAs.  With the
+// one-piece copy every wave sat out the full global latency of the next tile before it started multiplying.
+typedef int v4i32 __attribute__((ext_vector_type(4)));
+template <int KD, int PITCH>
+struct TileStage {
+  static constexpr int PER = KD / 2, N = 32 * PER, ITEMS = (N + 255) / 256;   // float4 per row / per tile / per thread
+  float4 r[ITEMS];
+  __amdgpu_buffer_rsrc_t rsrc;
+  long ld;
+  __device__ __forceinline__ void init(const float* base, long ld_, long extent_elems) {
+    rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, static_cast<int>(extent_elems * 4), 0x00020000);
+    ld = ld_;
+  }
+  __device__ __forceinline__ void load(int row0, int nrows) {
+#pragma unroll
+    for (int it = 0; it < ITEMS; ++it) {
+      const int i = threadIdx.x + it * 256;
+      const int rr = i / PER, c = (i - rr * PER) * 4;
+      const bool ok = i < N && rr < nrows;
+      const unsigned off = ok ? static_cast<unsigned>(((row0 + rr) * ld + c) * 4) : 0x80000000u;
+      r[it] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0));
+    }
+  }
+  __device__ __forceinline__ void store(float* lds) {
+#pragma unroll
+    for (int it = 0; it < ITEMS; ++it) {
+      const int i = threadIdx.x + it * 256;
+      if (i >= N) continue;
+      const int rr = i / PER, c = (i - rr * PER) * 4;
+      float* q = lds + rr * PITCH + c;
+      q[0] = r[it].x; q[1] = r[it].y; q[2] = r[it].z; q[3] = r[it].w;
+    }
+  }
+};
+
 // ---------------------------------------------------------------------------------------------- forward
 // block = 128 queries (4 waves x 32) of one (batch, head); loops over 32-key tiles (double-buffered K, V in LDS)
 template <int KD, int NT>   // d / 2 score MFMA steps; 32-row tiles covering d
@@ -78,15 +115,19 @@ __global__ __launch_bounds__(256) void k_attn_f32_fwd(AttnF32P p) {
   const float* kb = p.k + static_cast<long>(b) * p.Tk * p.ldk + h * d;
   const float* vb = p.v + static_cast<long>(b) * p.Tk * p.ldk + h * d;
   const int ntile = (p.Tk + 31) / 32;      // the last tile may be ragged: its missing keys are staged as zeros and masked
-  stage32<PITCH>(sK[0], kb, p.ldk, d, tid, p.Tk);
-  stage32<PITCH>(sV[0], vb, p.ldk, d, tid, p.Tk);
+  TileStage<KD, PITCH> tk, tv;
+  tk.init(kb, p.ldk, static_cast<long>(p.Tk - 1) * p.ldk + d);
+  tv.init(vb, p.ldk, static_cast<long>(p.Tk - 1) * p.ldk + d);
+  tk.load(0, p.Tk);
+  tv.load(0, p.Tk);
+  tk.store(sK[0]);
+  tv.store(sV[0]);
   __syncthreads();
   for (int kt = 0; kt < ntile; ++kt) {
     const int buf = kt & 1;
-    if (kt + 1 < ntile) {
-      stage32<PITCH>(sK[buf ^ 1], kb + static_cast<long>(kt + 1) * 32 * p.ldk, p.ldk, d, tid, p.Tk - (kt + 1) * 32);
-      stage32<PITCH>(sV[buf ^ 1], vb + static_cast<long>(kt + 1) * 32 * p.ldk, p.ldk, d, tid, p.Tk - (kt + 1) * 32);
-    }
+    tk.load((kt + 1) * 32, p.Tk - (kt + 1) * 32);
+    tv.load((kt + 1) * 32, p.Tk - (kt + 1) * 32);
+    __builtin_amdgcn_sched_barrier(0);
     // S^T = K Q^T (already times c2)
     v16f s;
 #pragma unroll
@@ -129,6 +170,8 @@ __global__ __launch_bounds__(256) void k_attn_f32_fwd(AttnF32P p) {
         o[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, s[st], o[t], 0, 0, 0);
       }
     }
+    tk.store(sK[buf ^ 1]);      // (past the last tile: zeros, into the buffer nobody reads again)
+    tv.store(sV[buf ^ 1]);
     __syncthreads();
   }
   if (!q_ok) return;
@@ -151,6 +194,8 @@ extern "C" int tfmq_attention_f32_fwd(tfmq_handle h, const float* q, const float
   TFMQ_CHECK_ARG(h, B > 0 && heads > 0 && Tq > 0 && Tk > 0 && Tq % 32 == 0, "attention_f32_fwd: Tq must be a multiple of 32");
   TFMQ_CHECK_ARG(h, d == 40 || d == 64 || d == 32 || d == 80, "attention_f32_fwd: head dim 32, 40, 64 or 80");
   TFMQ_CHECK_ARG(h, ldq % 4 == 0 && ldk % 4 == 0 && ldo % 4 == 0, "attention_f32_fwd: leading dims must be multiples of 4");
+  TFMQ_CHECK_ARG(h, static_cast<long>(Tk) * ldk < (1L << 28) && static_cast<long>(Tq) * ldq < (1L << 28),
+                 "attention_f32_fwd: one batch item's q / k / v must stay below 1 GiB (32-bit buffer offsets)");
   AttnF32P p{q, k, v, ldq, ldk, out, ldo, lse, nullptr, nullptr, nullptr, nullptr, nullptr, B, heads, Tq, Tk, d, scale};
   dim3 grid(static_cast<unsigned>((Tq + 127) / 128) * B * heads);
   hipStream_t st = as_stream(stream);
@@ -220,17 +265,33 @@ __global__ __launch_bounds__(256) void k_attn_f32_bwd_kv(AttnF32P p) {
   const float* lb = p.lse + (static_cast<long>(b) * p.heads + h) * p.Tq;
   const float* db = p.dsum + (static_cast<long>(b) * p.heads + h) * p.Tq;
   const int ntile = p.Tq / 32;
-  auto stage = [&](int buf, int qt) {
-    stage32<PITCH>(sQ[buf], qb + static_cast<long>(qt) * 32 * p.ldq, p.ldq, d, tid);
-    stage32<PITCH>(sO[buf], ob + static_cast<long>(qt) * 32 * p.ldo, p.ldo, d, tid);
-    if (tid < 32) sL[buf][tid] = lb[qt * 32 + tid];
-    else if (tid < 64) sD[buf][tid - 32] = db[qt * 32 + tid - 32];
+  TileStage<KD, PITCH> tq, to;
+  tq.init(qb, p.ldq, static_cast<long>(p.Tq - 1) * p.ldq + d);
+  to.init(ob, p.ldo, static_cast<long>(p.Tq - 1) * p.ldo + d);
+  // row terms of the tile: threads 0-31 carry lse, 32-63 carry D (everybody else reads zeros past the extent)
+  const __amdgpu_buffer_rsrc_t rl = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(lb), 0, p.Tq * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(db), 0, p.Tq * 4, 0x00020000);
+  float l_reg, d_reg;
+  auto load = [&](int qt) {
+    tq.load(qt * 32, p.Tq - qt * 32);
+    to.load(qt * 32, p.Tq - qt * 32);
+    const unsigned off = static_cast<unsigned>((qt * 32 + (tid & 31)) * 4);      // qt == ntile: past the extent
+    l_reg = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rl, tid < 32 ? off : 0x80000000u, 0, 0));
+    d_reg = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rd, (tid >= 32 && tid < 64) ? off : 0x80000000u, 0, 0));
   };
-  stage(0, 0);
+  auto store = [&](int buf) {
+    tq.store(sQ[buf]);
+    to.store(sO[buf]);
+    if (tid < 32) sL[buf][tid] = l_reg;
+    else if (tid < 64) sD[buf][tid - 32] = d_reg;
+  };
+  load(0);
+  store(0);
   __syncthreads();
   for (int qt = 0; qt < ntile; ++qt) {
     const int buf = qt & 1;
-    if (qt + 1 < ntile) stage(buf ^ 1, qt + 1);
+    load(qt + 1);
+    __builtin_amdgcn_sched_barrier(0);
     v16f s, dp;
 #pragma unroll
     for (int r = 0; r < 16; ++r) s[r] = dp[r] = 0.0f;
@@ -264,6 +325,7 @@ __global__ __launch_bounds__(256) void k_attn_f32_bwd_kv(AttnF32P p) {
         dk[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq, dp[st], dk[t], 0, 0, 0);
       }
     }
+    store(buf ^ 1);
     __syncthreads();
   }
   if (!k_ok) return;
@@ -317,15 +379,19 @@ __global__ __launch_bounds__(256) void k_attn_f32_bwd_q(AttnF32P p) {
   const float* kb = p.k + static_cast<long>(b) * p.Tk * p.ldk + h * d;
   const float* vb = p.v + static_cast<long>(b) * p.Tk * p.ldk + h * d;
   const int ntile = (p.Tk + 31) / 32;
-  stage32<PITCH>(sK[0], kb, p.ldk, d, tid, p.Tk);
-  stage32<PITCH>(sV[0], vb, p.ldk, d, tid, p.Tk);
+  TileStage<KD, PITCH> tk, tv;
+  tk.init(kb, p.ldk, static_cast<long>(p.Tk - 1) * p.ldk + d);
+  tv.init(vb, p.ldk, static_cast<long>(p.Tk - 1) * p.ldk + d);
+  tk.load(0, p.Tk);
+  tv.load(0, p.Tk);
+  tk.store(sK[0]);
+  tv.store(sV[0]);
   __syncthreads();
   for (int kt = 0; kt < ntile; ++kt) {
     const int buf = kt & 1;
-    if (kt + 1 < ntile) {
-      stage32<PITCH>(sK[buf ^ 1], kb + static_cast<long>(kt + 1) * 32 * p.ldk, p.ldk, d, tid, p.Tk - (kt + 1) * 32);
-      stage32<PITCH>(sV[buf ^ 1], vb + static_cast<long>(kt + 1) * 32 * p.ldk, p.ldk, d, tid, p.Tk - (kt + 1) * 32);
-    }
+    tk.load((kt + 1) * 32, p.Tk - (kt + 1) * 32);
+    tv.load((kt + 1) * 32, p.Tk - (kt + 1) * 32);
+    __builtin_amdgcn_sched_barrier(0);
     v16f s, dp;
 #pragma unroll
     for (int r = 0; r < 16; ++r) s[r] = dp[r] = 0.0f;
@@ -351,6 +417,8 @@ __global__ __launch_bounds__(256) void k_attn_f32_bwd_q(AttnF32P p) {
         dq[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, dp[st], dq[t], 0, 0, 0);
       }
     }
+    tk.store(sK[buf ^ 1]);
+    tv.store(sV[buf ^ 1]);
     __syncthreads();
   }
   if (!q_ok) return;
@@ -373,6 +441,9 @@ extern "C" int tfmq_attention_f32_bwd(tfmq_handle h, const float* q, const float
   TFMQ_CHECK_ARG(h, B > 0 && heads > 0 && Tq > 0 && Tk > 0 && Tq % 32 == 0, "attention_f32_bwd: Tq must be a multiple of 32");
   TFMQ_CHECK_ARG(h, d == 40 || d == 64 || d == 32 || d == 80, "attention_f32_bwd: head dim 32, 40, 64 or 80");
   TFMQ_CHECK_ARG(h, ldq % 4 == 0 && ldk % 4 == 0 && ldo % 4 == 0, "attention_f32_bwd: leading dims must be multiples of 4");
+  TFMQ_CHECK_ARG(h, static_cast<long>(Tk) * ldk < (1L << 28) && static_cast<long>(Tq) * ldq < (1L << 28) &&
+                        static_cast<long>(Tq) * ldo < (1L << 28),
+                 "attention_f32_bwd: one batch item's q / k / v / dO must stay below 1 GiB (32-bit buffer offsets)");
   AttnF32P p{q, k, v, ldq, ldk, nullptr, ldo, const_cast<float*>(lse), dout, dsum_ws, dq, dk, dv, B, heads, Tq, Tk, d, scale};
   hipStream_t st = as_stream(stream);
   const long rows = static_cast<long>(B) * heads * Tq;
