@@ -17,12 +17,20 @@
 typedef float v16f __attribute__((ext_vector_type(16)));
 
 
-__device__ __forceinline__ int swz_rk(int row, int slot) { return row * 64 + ((slot ^ ((row >> 2) & 3)) << 4); }
+// byte offset of 16-byte slot `slot` of row `row` in a [rows][BK floats] tile: 64-byte rows (BK 16) swizzle their 4 slots
+// with row bits 2-3, 128-byte rows (BK 32) their 8 slots with row bits 0-2 -- conflict free for the 16-byte stores
+// (consecutive lanes = consecutive slots of a row) and the fragment reads (consecutive lanes = consecutive rows)
+template <int BK>
+__device__ __forceinline__ int swz_rk(int row, int slot) {
+  if constexpr (BK == 16) return row * 64 + ((slot ^ ((row >> 2) & 3)) << 4);
+  else return row * 128 + ((slot ^ (row & 7)) << 4);
+}
 
 // One operand tile [R rows][16 k] -> LDS [16][R + 4].  (rs, ks) = element strides of the row / k index.
 // MODE 0: any strides / alignment, decided at run time (scalar loads where nothing is contiguous and aligned).
-template <int R, int MODE>
+template <int R, int MODE, int BK = 16>
 struct TileLoader {
+  static_assert(BK == 16, "the generic loader is built for 16-wide K-steps");
   static constexpr int ITEMS = R * 16 / 4 / 256;   // float4 items per thread (R = 128 -> 2, R = 64 -> 1)
   float4 reg[2][ITEMS];                            // two register sets: the loads run two K-steps ahead
   int mode;                                        // 0 scalar, 1 vector along k, 2 vector along rows
@@ -92,9 +100,9 @@ struct TileLoader {
 // the loaded value: the generic loader's control flow made the compiler wait for every load where it was issued
 // (vmcnt(0) at each merge); here the loads of K-step s+2 stay in flight under the MFMAs of steps s and s+1.
 typedef int v4i32 __attribute__((ext_vector_type(4)));
-template <int R>
+template <int R, int BK>
 struct TileLoaderBase {
-  static constexpr int ITEMS = R * 16 / 4 / 256;
+  static constexpr int ITEMS = R * BK / 4 / 256;
   float4 reg[2][ITEMS];
   __amdgpu_buffer_rsrc_t rsrc;
   unsigned off[ITEMS];
@@ -116,17 +124,18 @@ struct TileLoaderBase {
     }
   }
 };
-template <int R>
-struct TileLoader<R, 1> : TileLoaderBase<R> {
-  using TileLoaderBase<R>::ITEMS;
+template <int R, int BK>
+struct TileLoader<R, 1, BK> : TileLoaderBase<R, BK> {
+  using TileLoaderBase<R, BK>::ITEMS;
+  static constexpr int SPR = BK / 4;               // 16-byte slots per row
   __device__ __forceinline__ void init(const float* b, long rs, long, int r0, int kb, int rows, int K) {
     this->make(b, (rows - 1) * rs + K);
-    this->kstep = 16 * 4;
+    this->kstep = BK * 4;
 #pragma unroll
     for (int it = 0; it < ITEMS; ++it) {
       const int e = threadIdx.x + it * 256;
-      const int gr = r0 + (e >> 2);
-      this->kq[it] = (e & 3) * 4;
+      const int gr = r0 + e / SPR;
+      this->kq[it] = (e % SPR) * 4;
       this->okr[it] = gr < rows;
       this->off[it] = static_cast<unsigned>((this->okr[it] ? gr * rs : 0) + kb + this->kq[it]) * 4u;
     }
@@ -139,16 +148,16 @@ struct TileLoader<R, 1> : TileLoaderBase<R> {
 #pragma unroll
     for (int it = 0; it < ITEMS; ++it) {
       const int e = threadIdx.x + it * 256;
-      *reinterpret_cast<float4*>(reinterpret_cast<unsigned char*>(lds) + swz_rk(e >> 2, e & 3)) = this->reg[S][it];
+      *reinterpret_cast<float4*>(reinterpret_cast<unsigned char*>(lds) + swz_rk<BK>(e / SPR, e % SPR)) = this->reg[S][it];
     }
   }
 };
-template <int R>
-struct TileLoader<R, 2> : TileLoaderBase<R> {
-  using TileLoaderBase<R>::ITEMS;
+template <int R, int BK>
+struct TileLoader<R, 2, BK> : TileLoaderBase<R, BK> {
+  using TileLoaderBase<R, BK>::ITEMS;
   __device__ __forceinline__ void init(const float* b, long, long ks, int r0, int kb, int rows, int K) {
     this->make(b, (K - 1) * ks + rows);
-    this->kstep = static_cast<unsigned>(16 * ks) * 4u;
+    this->kstep = static_cast<unsigned>(BK * ks) * 4u;
 #pragma unroll
     for (int it = 0; it < ITEMS; ++it) {
       const int e = threadIdx.x + it * 256;
@@ -169,12 +178,12 @@ struct TileLoader<R, 2> : TileLoaderBase<R> {
   }
 };
 
-template <int WAVES_M, int WAVES_N, int WM_TILES, int WN_TILES, int MA = 0, int MB = 0>
-__global__ __launch_bounds__(256, (WM_TILES * WN_TILES <= 2) ? 5 : 2) void k_gemm_f32_mfma(GemmP p) {
+template <int WAVES_M, int WAVES_N, int WM_TILES, int WN_TILES, int MA = 0, int MB = 0, int BK = 16>
+__global__ __launch_bounds__(256, (WM_TILES * WN_TILES > 2) ? 2 : (BK == 32 ? 3 : 5)) void k_gemm_f32_mfma(GemmP p) {
   constexpr int BM = WAVES_M * WM_TILES * 32, BN = WAVES_N * WN_TILES * 32;
   static_assert(WAVES_M * WAVES_N == 4, "4 waves");
-  __shared__ __attribute__((aligned(16))) float sA[2][16 * (BM + 4)];
-  __shared__ __attribute__((aligned(16))) float sB[2][16 * (BN + 4)];
+  __shared__ __attribute__((aligned(128))) float sA[2][BK * (BM + 4)];
+  __shared__ __attribute__((aligned(128))) float sB[2][BK * (BN + 4)];
   // split-K (skinny outputs with a long reduction: weight gradients dW = X^T dY, K = B*T): blockIdx.z also carries the
   // K slice; slices write raw partial tiles, k_gemm_splitk_reduce adds them in slice order (deterministic)
   int bz = blockIdx.z, kb = 0, ke = p.K;
@@ -201,8 +210,8 @@ __global__ __launch_bounds__(256, (WM_TILES * WN_TILES <= 2) ? 5 : 2) void k_gem
   const int wm = wid / WAVES_N, wn = wid % WAVES_N;
   const int l32 = lane & 31, hh = lane >> 5;
 
-  TileLoader<BM, MA> la;
-  TileLoader<BN, MB> lb;
+  TileLoader<BM, MA, BK> la;
+  TileLoader<BN, MB, BK> lb;
   la.init(A, p.sam, p.sak, m0, kb, p.M, p.K);
   lb.init(B, p.sbn, p.sbk, n0, kb, p.N, p.K);
 
@@ -214,11 +223,11 @@ __global__ __launch_bounds__(256, (WM_TILES * WN_TILES <= 2) ? 5 : 2) void k_gem
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-  const int nk = (ke - kb + 15) / 16;
+  const int nk = (ke - kb + BK - 1) / BK;
   la.template load<0>(kb, ke);
   lb.template load<0>(kb, ke);
-  la.template load<1>(kb + 16, ke);
-  lb.template load<1>(kb + 16, ke);
+  la.template load<1>(kb + BK, ke);
+  lb.template load<1>(kb + BK, ke);
   la.template store<0>(sA[0]);
   lb.template store<0>(sB[0]);
   __syncthreads();
@@ -230,8 +239,8 @@ __global__ __launch_bounds__(256, (WM_TILES * WN_TILES <= 2) ? 5 : 2) void k_gem
     constexpr int PAR = decltype(par_tag)::value;
     const int buf = PAR;
 #ifndef TFMQ_DBG_GEMM_NO_LOAD      // diagnostics build (results are garbage): the K loop without its global loads
-    la.template load<PAR>(kb + (s + 2) * 16, ke);
-    lb.template load<PAR>(kb + (s + 2) * 16, ke);
+    la.template load<PAR>(kb + (s + 2) * BK, ke);
+    lb.template load<PAR>(kb + (s + 2) * BK, ke);
     __builtin_amdgcn_sched_barrier(0);   // the loads stay first in the step (the scheduler sank them below the MFMAs)
 #endif
     const float* a_l = sA[buf] + (wm * WM_TILES * 32) + l32;
@@ -242,12 +251,12 @@ __global__ __launch_bounds__(256, (WM_TILES * WN_TILES <= 2) ? 5 : 2) void k_gem
     // k sum as long as A and B use the same one: MFMA j of half h takes k = 8h + j (lanes 0-31) and 8h + 4 + j
     // (lanes 32-63), so a k-contiguous operand feeds four MFMAs from one 16-byte read
 #pragma unroll
-    for (int half = 0; half < 2; ++half) {
+    for (int half = 0; half < BK / 8; ++half) {
       float af[WM_TILES][4], bf[WN_TILES][4];
 #pragma unroll
       for (int i = 0; i < WM_TILES; ++i) {
         if constexpr (MA == 1) {
-          const float4 v = *reinterpret_cast<const float4*>(a_b + swz_rk((wm * WM_TILES + i) * 32 + l32, half * 2 + hh));
+          const float4 v = *reinterpret_cast<const float4*>(a_b + swz_rk<BK>((wm * WM_TILES + i) * 32 + l32, half * 2 + hh));
           af[i][0] = v.x; af[i][1] = v.y; af[i][2] = v.z; af[i][3] = v.w;
         } else {
 #pragma unroll
@@ -257,7 +266,7 @@ __global__ __launch_bounds__(256, (WM_TILES * WN_TILES <= 2) ? 5 : 2) void k_gem
 #pragma unroll
       for (int jn = 0; jn < WN_TILES; ++jn) {
         if constexpr (MB == 1) {
-          const float4 v = *reinterpret_cast<const float4*>(b_b + swz_rk((wn * WN_TILES + jn) * 32 + l32, half * 2 + hh));
+          const float4 v = *reinterpret_cast<const float4*>(b_b + swz_rk<BK>((wn * WN_TILES + jn) * 32 + l32, half * 2 + hh));
           bf[jn][0] = v.x; bf[jn][1] = v.y; bf[jn][2] = v.z; bf[jn][3] = v.w;
         } else {
 #pragma unroll
@@ -274,7 +283,7 @@ __global__ __launch_bounds__(256, (WM_TILES * WN_TILES <= 2) ? 5 : 2) void k_gem
 #ifndef TFMQ_DBG_GEMM_NO_STORE
       // the next K-step's tile goes to the other buffer (nobody reads it during this step) under the second half's
       // MFMAs: its loads were issued a half step ago, and the barrier below then has no LDS write left to wait for
-      if (half == 0) {
+      if (half == BK / 16 - 1) {
         la.template store<PAR ^ 1>(sA[buf ^ 1]);
         lb.template store<PAR ^ 1>(sB[buf ^ 1]);
       }
@@ -342,12 +351,23 @@ int tfmq_gemm_f32_mfma_launch(tfmq_handle h, GemmP& p, int batch, hipStream_t st
   // tiles of ONE batch item: the slicing (hence the summation order) must not depend on how many items share the
   // launch -- results stay bit-identical whatever else is in the batch
   const long tiles = static_cast<long>((N + BN - 1) / BN) * ((M + 127) / 128);
-  // fewer tiles than CUs and a long reduction: slice K so that ~2 blocks per CU exist, >= 256 elements per slice
+  // Split K so that the blocks divide evenly over the CUs.  All blocks of these problems are resident at once (up to 5
+  // per CU), a CU's time grows with the number it holds, and 640 tiles on 256 CUs leave half the chip with 3 and half
+  // with 2: 83 % busy.  In units of one tile's K loop a launch takes ceil(tiles * ks / CUs) / ks; the slices' extra
+  // pass (write + re-read of ks partial outputs) costs about 66 (ks + 1) / K of the GEMM.  Smallest cost wins, ties to
+  // the smaller ks; every slice keeps >= 256 k.  PMC (8192 x 640 x 5760): MFMA busy 71 % unsplit.
   int ks = 1;
-  if (tiles < 2L * h->cu_count && p.K >= 1024) {
-    ks = static_cast<int>((3L * h->cu_count + tiles - 1) / tiles);
-    if (ks > p.K / 256) ks = p.K / 256;
-    if (ks > 64) ks = 64;
+  if (p.K >= 512 && !getenv("TFMQ_GEMM_NO_SPLITK")) {
+    const double cu = h->cu_count, t = static_cast<double>(tiles);
+    double best = 0.0;
+    for (int c = 1; c <= 32 && p.K / c >= 256; ++c) {
+      const double rounds = static_cast<double>((tiles * c + h->cu_count - 1) / h->cu_count) / c;
+      const double cost = rounds + (c > 1 ? 66.0 * (c + 1) / p.K * (t / cu) : 0.0);
+      if (c == 1 || cost < best * 0.97) {     // a split has to buy at least 3 %
+        best = cost;
+        ks = c;
+      }
+    }
     if (static_cast<long>(batch) * ks > 65535) ks = 65535 / batch;
   }
   if (ks > 1) {
@@ -382,10 +402,14 @@ int tfmq_gemm_f32_mfma_launch(tfmq_handle h, GemmP& p, int batch, hipStream_t st
   };
   int ma = mode_of(p.A, p.sam, p.sak, M, batch > 1 ? p.bsa : 0), mb = mode_of(p.B, p.sbn, p.sbk, N, batch > 1 ? p.bsb : 0);
   if (getenv("TFMQ_GEMM_GENERIC_LOADER")) ma = mb = 0;
+  const bool bk32 = getenv("TFMQ_GEMM_BK32") != nullptr;
   if (BN == 128 && ma == 1 && mb == 1) hipLaunchKernelGGL((k_gemm_f32_mfma<2, 2, 2, 2, 1, 1>), grid, dim3(256), 0, st, p);
   else if (BN == 128 && ma == 1 && mb == 2) hipLaunchKernelGGL((k_gemm_f32_mfma<2, 2, 2, 2, 1, 2>), grid, dim3(256), 0, st, p);
   else if (BN == 128 && ma == 2 && mb == 2) hipLaunchKernelGGL((k_gemm_f32_mfma<2, 2, 2, 2, 2, 2>), grid, dim3(256), 0, st, p);
   else if (BN == 128) hipLaunchKernelGGL((k_gemm_f32_mfma<2, 2, 2, 2>), grid, dim3(256), 0, st, p);
+  else if (bk32 && ma == 1 && mb == 1) hipLaunchKernelGGL((k_gemm_f32_mfma<4, 1, 1, 2, 1, 1, 32>), grid, dim3(256), 0, st, p);
+  else if (bk32 && ma == 1 && mb == 2) hipLaunchKernelGGL((k_gemm_f32_mfma<4, 1, 1, 2, 1, 2, 32>), grid, dim3(256), 0, st, p);
+  else if (bk32 && ma == 2 && mb == 2) hipLaunchKernelGGL((k_gemm_f32_mfma<4, 1, 1, 2, 2, 2, 32>), grid, dim3(256), 0, st, p);
   else if (ma == 1 && mb == 1) hipLaunchKernelGGL((k_gemm_f32_mfma<4, 1, 1, 2, 1, 1>), grid, dim3(256), 0, st, p);
   else if (ma == 1 && mb == 2) hipLaunchKernelGGL((k_gemm_f32_mfma<4, 1, 1, 2, 1, 2>), grid, dim3(256), 0, st, p);
   else if (ma == 2 && mb == 1) hipLaunchKernelGGL((k_gemm_f32_mfma<4, 1, 1, 2, 2, 1>), grid, dim3(256), 0, st, p);
