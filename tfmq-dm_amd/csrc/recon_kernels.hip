@@ -86,8 +86,8 @@ extern "C" int tfmq_gemm_f32(tfmq_handle h, const float* A, const float* B, floa
   GemmP p{A, B, C, M, N, K, sam, sak, sbk, sbn, scm, bsa, bsb, bsc, alpha, bias, rowadd, rows_per_img, rowadd_ld, residual,
           accumulate, 1, 0, nullptr};
   // fp32 matrix cores (gemm_f32_mfma.hip); small problems keep the FMA tile.  Skinny outputs with a long reduction
-  // (the context-side gradients of cross attention: 77 x 40, K = 4096) also go there: split-K fills the chip
-  if ((M >= 96 && N >= 24 && K >= 8) || (M >= 32 && N >= 24 && K >= 1024)) {
+  // (the context-side gradients of cross attention: 77 x 40..160, K = 256..4096) also go there: split-K fills the chip
+  if ((M >= 96 && N >= 24 && K >= 8) || (M >= 32 && N >= 24 && K >= 64)) {
     const int rc = tfmq_gemm_f32_mfma_launch(h, p, batch, as_stream(stream));
     if (rc != TFMQ_OK) return rc;
     TFMQ_LAUNCH_CHECK(h);
