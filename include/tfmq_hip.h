@@ -319,6 +319,11 @@ int tfmq_gemm_f32(tfmq_handle h, const float* A, const float* B, float* C, int M
                   long sbk, long sbn, long scm, int batch, long bsa, long bsb, long bsc, float alpha, const float* bias,
                   const float* rowadd, int rows_per_img, int rowadd_ld, const float* residual, int accumulate,
                   void* stream);
+/* the same product over a two-level batch: item (b, hd), b < batch, hd < heads, at offsets b * bs? + hd * hs? -- all heads
+ * of a multi-head attention product (quant_block.py:285-299 on packed [B,T,heads*d] tensors) in one launch */
+int tfmq_gemm_f32_heads(tfmq_handle h, const float* A, const float* B, float* C, int M, int N, int K, long sam, long sak,
+                        long sbk, long sbn, long scm, int batch, long bsa, long bsb, long bsc, int heads, long hsa, long hsb,
+                        long hsc, float alpha, int accumulate, void* stream);
 /* LayerNorm / GEGLU backward w.r.t. their inputs (BasicTransformerBlock units, ldm/modules/attention.py:196-215):
  * gx = d LN(x; gamma)/dx applied to gy, rows tokens of C channels;  dh = d(h[:, :I] * gelu(h[:, I:]))/dh applied to dy */
 int tfmq_layernorm_bwd(tfmq_handle h, const float* x, const float* gy, const float* gamma, float eps, long rows, int C,

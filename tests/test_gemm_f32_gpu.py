@@ -63,3 +63,40 @@ def test_gemm_strided_batched_skinny_splitk(ops):
     tol = 8.0 * (T ** 0.5) * 2.0 ** -24 * float(torch.einsum("bhtl,bthd->blhd", dS.view(Bb, heads, T, L).abs().double(),
                                                               Q.view(Bb, T, heads, d).abs().double()).max())
     assert (out.cpu().double() - ref).abs().max() <= tol
+
+
+@pytest.mark.parametrize("B,H,T,L,d", [(2, 8, 256, 256, 160), (2, 8, 256, 77, 160), (3, 4, 64, 40, 24), (1, 2, 96, 1030, 72)])
+def test_heads_batch_is_the_per_head_loop(ops, B, H, T, L, d):
+    """tfmq_gemm_f32_heads (two-level batch: all heads of an attention product in one launch) against one launch per head,
+    bit for bit (the split-K slicing is decided per batch item), for the four operand layouts the attention backward
+    uses, and against float64."""
+    g = torch.Generator().manual_seed(T + L)
+    C = H * d
+    q = torch.randn(B, T, C, generator=g).to(DEV)
+    k = torch.randn(B, L, C, generator=g).to(DEV)
+    P = torch.randn(B, H, T, L, generator=g).to(DEV)
+    # S_h = q_h k_h^T
+    S1 = torch.empty(B, H, T, L, device=DEV)
+    S2 = torch.empty_like(S1)
+    for h in range(H):
+        ops.gemm_strided(q, h * d, C, 1, T * C, k, h * d, 1, C, L * C, S1, h * T * L, L, H * T * L, T, L, d, B)
+    ops.gemm_strided(q, 0, C, 1, T * C, k, 0, 1, C, L * C, S2, 0, L, H * T * L, T, L, d, B, heads=H, hsa=d, hsb=d, hsc=T * L)
+    assert torch.equal(S1, S2)
+    qh = q.double().reshape(B, T, H, d).permute(0, 2, 1, 3)
+    kh = k.double().reshape(B, L, H, d).permute(0, 2, 1, 3)
+    ref = qh @ kh.transpose(-1, -2)
+    assert float((S2.double() - ref).abs().max()) <= 8.0 * d ** 0.5 * 2.0 ** -24 * float((qh.abs() @ kh.abs().transpose(-1, -2)).max())
+    # o_h = P_h v_h  and  dK_h = P_h^T q_h (transposed A operand, long reduction over T)
+    o1 = torch.empty(B, T, C, device=DEV)
+    o2 = torch.empty_like(o1)
+    dk1 = torch.empty(B, L, C, device=DEV)
+    dk2 = torch.empty_like(dk1)
+    for h in range(H):
+        ops.gemm_strided(P, h * T * L, L, 1, H * T * L, k, h * d, C, 1, L * C, o1, h * d, C, T * C, T, d, L, B)
+        ops.gemm_strided(P, h * T * L, 1, L, H * T * L, q, h * d, C, 1, T * C, dk1, h * d, C, L * C, L, d, T, B)
+    ops.gemm_strided(P, 0, L, 1, H * T * L, k, 0, C, 1, L * C, o2, 0, C, T * C, T, d, L, B, heads=H, hsa=T * L, hsb=d, hsc=d)
+    ops.gemm_strided(P, 0, 1, L, H * T * L, q, 0, C, 1, T * C, dk2, 0, C, L * C, L, d, T, B, heads=H, hsa=T * L, hsb=d, hsc=d)
+    assert torch.equal(o1, o2)
+    assert torch.equal(dk1, dk2)
+    refo = (P.double() @ kh).permute(0, 2, 1, 3).reshape(B, T, C)
+    assert float((o2.double() - refo).abs().max()) <= 8.0 * L ** 0.5 * 2.0 ** -24 * float((P.double().abs() @ kh.abs()).max())

@@ -105,6 +105,9 @@ _SIGS = {
     "tfmq_gemm_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, C.c_long, C.c_long, C.c_long, C.c_long,
                               C.c_long, c_int, C.c_long, C.c_long, C.c_long, c_float, c_void_p, c_void_p, c_int, c_int, c_void_p,
                               c_int, c_void_p]),
+    "tfmq_gemm_f32_heads": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, C.c_long, C.c_long, C.c_long,
+                                    C.c_long, C.c_long, c_int, C.c_long, C.c_long, C.c_long, c_int, C.c_long, C.c_long, C.c_long,
+                                    c_float, c_int, c_void_p]),
     "tfmq_im2col": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 11 + [c_void_p]),
     "tfmq_col2im": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 11 + [c_void_p]),
     "tfmq_w_relayout": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),

@@ -39,6 +39,13 @@ struct GemmP {
   int ksplit, kchunk;                // split-K: blockIdx.z = batch * ksplit + split, split covers K range [split*kchunk, +kchunk)
   float* partial;                    // [ksplit][batch][M][N] raw partial sums (ksplit > 1)
   int tiles_n;                       // column tiles (the MFMA kernel's 1-D tile grid)
+  // two-level batch (multi-head attention on the packed [B,T,heads*d] layout): item z = (z / nb2, z % nb2), offsets
+  // (z / nb2) * bs? + (z % nb2) * bs?2.  nb2 = 1 for a plain batch.
+  int nb2;
+  long bsa2, bsb2, bsc2;
+  __host__ __device__ long off_a(int z) const { return (z / nb2) * bsa + (z % nb2) * bsa2; }
+  __host__ __device__ long off_b(int z) const { return (z / nb2) * bsb + (z % nb2) * bsb2; }
+  __host__ __device__ long off_c(int z) const { return (z / nb2) * bsc + (z % nb2) * bsc2; }
 };
 
 #define TFMQ_CHECK_ARG(h, cond, msg)          \

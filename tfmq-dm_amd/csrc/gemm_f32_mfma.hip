@@ -193,9 +193,9 @@ __global__ __launch_bounds__(256, (WM_TILES * WN_TILES > 2) ? 2 : (BK == 32 ? 3 
     kb = sp * p.kchunk;
     ke = kb + p.kchunk < p.K ? kb + p.kchunk : p.K;
   }
-  const float* A = p.A + bz * p.bsa;
-  const float* B = p.B + bz * p.bsb;
-  float* C = p.C + bz * p.bsc;
+  const float* A = p.A + p.off_a(bz);
+  const float* B = p.B + p.off_b(bz);
+  float* C = p.C + p.off_c(bz);
   // XCD-aware tile order: the dispatcher places block b on XCD b % 8; each XCD gets a contiguous range of tiles (column
   // tiles fastest), so the column tiles that share an A row panel -- and the row tiles that share B -- meet in ONE L2
   // instead of fetching the panel into all eight.  Placement only: any order gives the same result.
@@ -316,7 +316,7 @@ __global__ __launch_bounds__(256, (WM_TILES * WN_TILES > 2) ? 2 : (BK == 32 ? 3 
         float v = p.alpha * acc[i][j][r];
         if (p.bias) v += bv;
         if (p.rowadd) v += p.rowadd[static_cast<long>(m / p.rows_per_img) * p.rowadd_ld + n];
-        if (p.residual) v += p.residual[bz * p.bsc + m * p.scm + n];
+        if (p.residual) v += p.residual[p.off_c(bz) + m * p.scm + n];
         float* c = C + m * p.scm + n;
         *c = p.accumulate ? *c + v : v;
       }
@@ -336,8 +336,8 @@ __global__ void k_gemm_splitk_reduce(GemmP p, int batch) {
     float v = p.alpha * a;
     if (p.bias) v += p.bias[n];
     if (p.rowadd) v += p.rowadd[static_cast<long>(m / p.rows_per_img) * p.rowadd_ld + n];
-    if (p.residual) v += p.residual[bz * p.bsc + m * p.scm + n];
-    float* c = p.C + bz * p.bsc + m * p.scm + n;
+    if (p.residual) v += p.residual[p.off_c(bz) + m * p.scm + n];
+    float* c = p.C + p.off_c(bz) + m * p.scm + n;
     *c = p.accumulate ? *c + v : v;
   }
 }
@@ -400,7 +400,8 @@ int tfmq_gemm_f32_mfma_launch(tfmq_handle h, GemmP& p, int batch, hipStream_t st
     if (rs == 1 && al && (ks & 3) == 0 && (rows & 3) == 0) return 2;
     return 0;
   };
-  int ma = mode_of(p.A, p.sam, p.sak, M, batch > 1 ? p.bsa : 0), mb = mode_of(p.B, p.sbn, p.sbk, N, batch > 1 ? p.bsb : 0);
+  int ma = mode_of(p.A, p.sam, p.sak, M, batch > 1 ? (p.bsa | p.bsa2) : 0),
+      mb = mode_of(p.B, p.sbn, p.sbk, N, batch > 1 ? (p.bsb | p.bsb2) : 0);
   if (getenv("TFMQ_GEMM_GENERIC_LOADER")) ma = mb = 0;
   const bool bk32 = getenv("TFMQ_GEMM_BK32") != nullptr;
   if (BN == 128 && ma == 1 && mb == 1) hipLaunchKernelGGL((k_gemm_f32_mfma<2, 2, 2, 2, 1, 1>), grid, dim3(256), 0, st, p);

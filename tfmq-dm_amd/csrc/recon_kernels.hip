@@ -20,9 +20,9 @@ __global__ __launch_bounds__(256) void k_gemm_f32(GemmP p) {
   __shared__ float As[GK][GT + 4];
   __shared__ float Bs[GK][GT + 4];
   const int bz = blockIdx.z;
-  const float* A = p.A + bz * p.bsa;
-  const float* B = p.B + bz * p.bsb;
-  float* C = p.C + bz * p.bsc;
+  const float* A = p.A + p.off_a(bz);
+  const float* B = p.B + p.off_b(bz);
+  float* C = p.C + p.off_c(bz);
   const int m0 = blockIdx.y * GT, n0 = blockIdx.x * GT;
   const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;  // 16 x 16 threads, 4x4 outputs each
   float acc[4][4];
@@ -70,21 +70,23 @@ __global__ __launch_bounds__(256) void k_gemm_f32(GemmP p) {
       float v = p.alpha * acc[i][j];
       if (p.bias) v += p.bias[n];
       if (p.rowadd) v += p.rowadd[static_cast<long>(m / p.rows_per_img) * p.rowadd_ld + n];
-      if (p.residual) v += p.residual[bz * p.bsc + m * p.scm + n];
+      if (p.residual) v += p.residual[p.off_c(bz) + m * p.scm + n];
       float* c = C + m * p.scm + n;
       *c = p.accumulate ? *c + v : v;
     }
   }
 }
 
-extern "C" int tfmq_gemm_f32(tfmq_handle h, const float* A, const float* B, float* C, int M, int N, int K, long sam,
-                             long sak, long sbk, long sbn, long scm, int batch, long bsa, long bsb, long bsc, float alpha,
-                             const float* bias, const float* rowadd, int rows_per_img, int rowadd_ld,
-                             const float* residual, int accumulate, void* stream) {
-  TFMQ_CHECK_ARG(h, h && A && B && C && M > 0 && N > 0 && K > 0 && batch > 0 && batch < 65536, "gemm_f32: bad argument");
+static int gemm_f32_impl(tfmq_handle h, const float* A, const float* B, float* C, int M, int N, int K, long sam, long sak,
+                         long sbk, long sbn, long scm, int batch, long bsa, long bsb, long bsc, int heads, long hsa, long hsb,
+                         long hsc, float alpha, const float* bias, const float* rowadd, int rows_per_img, int rowadd_ld,
+                         const float* residual, int accumulate, void* stream) {
+  TFMQ_CHECK_ARG(h, h && A && B && C && M > 0 && N > 0 && K > 0 && batch > 0 && heads > 0 &&
+                        static_cast<long>(batch) * heads < 65536, "gemm_f32: bad argument");
   TFMQ_CHECK_ARG(h, !rowadd || rows_per_img > 0, "gemm_f32: rowadd needs rows_per_img");
   GemmP p{A, B, C, M, N, K, sam, sak, sbk, sbn, scm, bsa, bsb, bsc, alpha, bias, rowadd, rows_per_img, rowadd_ld, residual,
-          accumulate, 1, 0, nullptr};
+          accumulate, 1, 0, nullptr, 0, heads, hsa, hsb, hsc};
+  batch *= heads;
   // fp32 matrix cores (gemm_f32_mfma.hip); small problems keep the FMA tile.  Skinny outputs with a long reduction
   // (the context-side gradients of cross attention: 77 x 40..160, K = 256..4096) also go there: split-K fills the chip
   if ((M >= 96 && N >= 24 && K >= 8) || (M >= 32 && N >= 24 && K >= 64)) {
@@ -97,6 +99,23 @@ extern "C" int tfmq_gemm_f32(tfmq_handle h, const float* A, const float* B, floa
   hipLaunchKernelGGL(k_gemm_f32, grid, dim3(256), 0, as_stream(stream), p);
   TFMQ_LAUNCH_CHECK(h);
   return TFMQ_OK;
+}
+
+extern "C" int tfmq_gemm_f32(tfmq_handle h, const float* A, const float* B, float* C, int M, int N, int K, long sam,
+                             long sak, long sbk, long sbn, long scm, int batch, long bsa, long bsb, long bsc, float alpha,
+                             const float* bias, const float* rowadd, int rows_per_img, int rowadd_ld,
+                             const float* residual, int accumulate, void* stream) {
+  return gemm_f32_impl(h, A, B, C, M, N, K, sam, sak, sbk, sbn, scm, batch, bsa, bsb, bsc, 1, 0, 0, 0, alpha, bias, rowadd,
+                       rows_per_img, rowadd_ld, residual, accumulate, stream);
+}
+
+// Two-level batch: item (b, hd) at offsets b * bs? + hd * hs?.  One launch for all heads of a multi-head attention
+// product on the packed [B, T, heads * d] layout (per-head launches of 64 blocks left three quarters of the chip idle).
+extern "C" int tfmq_gemm_f32_heads(tfmq_handle h, const float* A, const float* B, float* C, int M, int N, int K, long sam,
+                                   long sak, long sbk, long sbn, long scm, int batch, long bsa, long bsb, long bsc, int heads,
+                                   long hsa, long hsb, long hsc, float alpha, int accumulate, void* stream) {
+  return gemm_f32_impl(h, A, B, C, M, N, K, sam, sak, sbk, sbn, scm, batch, bsa, bsb, bsc, heads, hsa, hsb, hsc, alpha, nullptr,
+                       nullptr, 1, 0, nullptr, accumulate, stream);
 }
 
 // ------------------------------------------------------------------ im2col / col2im (NHWC, zero pad)

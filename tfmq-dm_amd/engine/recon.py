@@ -236,12 +236,12 @@ class TransformerUnit(_Unit):
             o, lse = ops.attention_f32_fwd(q.contiguous(), k.contiguous(), v.contiguous(), H, float(d ** -0.5))
             return o, ("flash", lse, o)
         S = torch.empty(B, H, T, L, dtype=torch.float32, device=q.device)
-        for h in range(H):
-            ops.gemm_strided(q, h * d, Cc, 1, T * Cc, k, h * d, 1, Cc, L * Cc, S, h * T * L, L, H * T * L, T, L, d, B)
+        # all heads of a product in ONE launch (two-level batch: item (b, h) at b * batch stride + h * head stride)
+        hk = dict(heads=H)
+        ops.gemm_strided(q, 0, Cc, 1, T * Cc, k, 0, 1, Cc, L * Cc, S, 0, L, H * T * L, T, L, d, B, hsa=d, hsb=d, hsc=T * L, **hk)
         P = ops.softmax_rows(S, float(d ** -0.5))
         o = torch.empty(B, T, Cc, dtype=torch.float32, device=q.device)
-        for h in range(H):
-            ops.gemm_strided(P, h * T * L, L, 1, H * T * L, v, h * d, Cc, 1, L * Cc, o, h * d, Cc, T * Cc, T, d, L, B)
+        ops.gemm_strided(P, 0, L, 1, H * T * L, v, 0, Cc, 1, L * Cc, o, 0, Cc, T * Cc, T, d, L, B, hsa=T * L, hsb=d, hsc=d, **hk)
         return o, P
 
     def _attn_bwd(self, g_o, q, k, v, P):
@@ -254,15 +254,14 @@ class TransformerUnit(_Unit):
             return ops.attention_f32_bwd(q.contiguous(), k.contiguous(), v.contiguous(), o, lse, g_o.contiguous(), H, float(d ** -0.5))
         dV, dK, dQ = torch.empty_like(v), torch.empty_like(k), torch.empty_like(q)
         dP = torch.empty_like(P)
-        for h in range(H):
-            # dV_h = P_h^T g_o_h ; dP_h = g_o_h V_h^T
-            ops.gemm_strided(P, h * T * L, 1, L, H * T * L, g_o, h * d, Cc, 1, T * Cc, dV, h * d, Cc, L * Cc, L, d, T, B)
-            ops.gemm_strided(g_o, h * d, Cc, 1, T * Cc, v, h * d, 1, Cc, L * Cc, dP, h * T * L, L, H * T * L, T, L, d, B)
+        hk = dict(heads=H)
+        # dV_h = P_h^T g_o_h ; dP_h = g_o_h V_h^T
+        ops.gemm_strided(P, 0, 1, L, H * T * L, g_o, 0, Cc, 1, T * Cc, dV, 0, Cc, L * Cc, L, d, T, B, hsa=T * L, hsb=d, hsc=d, **hk)
+        ops.gemm_strided(g_o, 0, Cc, 1, T * Cc, v, 0, 1, Cc, L * Cc, dP, 0, L, H * T * L, T, L, d, B, hsa=d, hsb=d, hsc=T * L, **hk)
         dS = ops.softmax_bwd_rows(P, dP, float(d ** -0.5))
-        for h in range(H):
-            # dQ_h = dS_h K_h ; dK_h = dS_h^T Q_h
-            ops.gemm_strided(dS, h * T * L, L, 1, H * T * L, k, h * d, Cc, 1, L * Cc, dQ, h * d, Cc, T * Cc, T, d, L, B)
-            ops.gemm_strided(dS, h * T * L, 1, L, H * T * L, q, h * d, Cc, 1, T * Cc, dK, h * d, Cc, L * Cc, L, d, T, B)
+        # dQ_h = dS_h K_h ; dK_h = dS_h^T Q_h
+        ops.gemm_strided(dS, 0, L, 1, H * T * L, k, 0, Cc, 1, L * Cc, dQ, 0, Cc, T * Cc, T, d, L, B, hsa=T * L, hsb=d, hsc=d, **hk)
+        ops.gemm_strided(dS, 0, 1, L, H * T * L, q, 0, Cc, 1, T * Cc, dK, 0, Cc, L * Cc, L, d, T, B, hsa=T * L, hsb=d, hsc=d, **hk)
         return dQ, dK, dV
 
     def _forward_backward(self, idx):

@@ -874,14 +874,22 @@ def gemm(A: torch.Tensor, B: torch.Tensor, trans_a: bool = False, trans_b: bool 
 
 def gemm_strided(A: torch.Tensor, a_off: int, sam: int, sak: int, bsa: int, B: torch.Tensor, b_off: int, sbk: int, sbn: int,
                  bsb: int, Cm: torch.Tensor, c_off: int, scm: int, bsc: int, M: int, N: int, K: int, batch: int = 1,
-                 alpha: float = 1.0, accumulate: bool = False) -> torch.Tensor:
+                 alpha: float = 1.0, accumulate: bool = False, heads: int = 1, hsa: int = 0, hsb: int = 0,
+                 hsc: int = 0) -> torch.Tensor:
     """C[z](m,n) (+)= alpha * sum_k A[z](m,k) B[z](k,n) on views of fp32 tensors described by element offsets and strides:
     A(z,m,k) = A.flat[a_off + z*bsa + m*sam + k*sak], likewise B(k,n) and C(m,n) (row stride scm, unit column stride).
-    Lets the multi-head attention of a reconstruction unit run on the [B,T,heads*d] layout without permutes."""
+    Lets the multi-head attention of a reconstruction unit run on the [B,T,heads*d] layout without permutes.
+    heads > 1: a second batch level, item (z, hd) at the additional offsets hd*hsa / hd*hsb / hd*hsc (all heads of one
+    attention product in one launch)."""
     d = _dev(A)
     for t in (A, B, Cm):       # views are welcome: the strides are given explicitly
         if not t.is_cuda or t.dtype != torch.float32:
             raise TfmqError("gemm_strided: operands must be fp32 device tensors")
+    if heads > 1:
+        handle(d).call("gemm_f32_heads", A.data_ptr() + 4 * a_off, B.data_ptr() + 4 * b_off, Cm.data_ptr() + 4 * c_off, M, N, K,
+                       sam, sak, sbk, sbn, scm, batch, bsa, bsb, bsc, heads, hsa, hsb, hsc, float(alpha), int(accumulate),
+                       _stream(d))
+        return Cm
     handle(d).call("gemm_f32", A.data_ptr() + 4 * a_off, B.data_ptr() + 4 * b_off, Cm.data_ptr() + 4 * c_off, M, N, K,
                    sam, sak, sbk, sbn, scm, batch, bsa, bsb, bsc, float(alpha), None, None, 1, 0, None, int(accumulate),
                    _stream(d))
