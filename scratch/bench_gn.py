@@ -13,7 +13,7 @@ def t(fn, n=10):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n
 qt = torch.tensor([[0.05, 120.0]], device=DEV); sel = ops.qsel(qt)
-for (B, HW, C, C2) in [(128, 4096, 320, 0), (128, 4096, 320, 320), (128, 1024, 640, 0), (128, 256, 1280, 0), (32, 4096, 320, 0)]:
+for (B, HW, C, C2) in [(256, 1024, 128, 0), (256, 256, 256, 0), (256, 64, 256, 256), (128, 4096, 320, 0), (128, 4096, 320, 320), (128, 1024, 640, 0), (128, 256, 1280, 0), (32, 4096, 320, 0)]:
     x = torch.randn(B, HW, 1, C, device=DEV)
     seg = 64
     def stats(c):

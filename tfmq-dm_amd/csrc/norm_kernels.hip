@@ -260,24 +260,20 @@ __global__ __launch_bounds__(256) void k_gn_apply(tfmq_gn_desc d, const float* _
   const bool quant = d.aq.qtable != nullptr;
   float2 qp = make_float2(1.0f, 0.0f);
   if (quant) qp = load_qparam(d.aq);
-  // (pixel, channel group) of this thread's items without a division in the loop: two per item in 64 bits were most of
-  // the kernel's instructions (it ran at 2.6-3.3 TB/s: issue-bound, not HBM-bound).  The item index advances by the
-  // grid stride = sdiv pixels + smod channel groups (with carry); the image index follows the pixel.
-  const size_t stride = static_cast<size_t>(gridDim.x) * blockDim.x;
-  const size_t i0 = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
-  const size_t sdiv = stride / cv;
-  const int smod = static_cast<int>(stride - sdiv * cv);
-  size_t pix = i0 / cv;
-  int cq = static_cast<int>(i0 - pix * cv);
-  int b = static_cast<int>(pix / d.HW);
-  size_t img_end = static_cast<size_t>(b + 1) * d.HW;       // first pixel of image b + 1
-  for (size_t i = i0; i < total; i += stride) {
-    while (pix >= img_end) {
-      ++b;
-      img_end += d.HW;
-    }
-    const int c = cq * V;
-    const float* src = c < d.C1 ? d.x1 + pix * d.C1 + c : d.x2 + pix * d.C2 + (c - d.C1);
+  // (pixel, channel group) of this thread's items without a 64-bit division per item (two of them were a third of the
+  // kernel's instructions): 32-bit index arithmetic (the launcher checks the item count), the item index advances by
+  // the grid stride = sdiv pixels + smod channel groups with carry, the image index is a shift when HW is a power of two.
+  const unsigned stride = gridDim.x * blockDim.x;
+  const unsigned i0 = blockIdx.x * blockDim.x + threadIdx.x;
+  const unsigned ucv = static_cast<unsigned>(cv), uhw = static_cast<unsigned>(d.HW);
+  const unsigned sdiv = stride / ucv, smod = stride - sdiv * ucv;
+  const int hw_shift = (uhw & (uhw - 1)) == 0 ? __builtin_ctz(uhw) : -1;
+  unsigned pix = i0 / ucv;
+  unsigned cq = i0 - pix * ucv;
+  for (unsigned i = i0; i < static_cast<unsigned>(total); i += stride) {
+    const int b = static_cast<int>(hw_shift >= 0 ? pix >> hw_shift : pix / uhw);
+    const int c = static_cast<int>(cq) * V;
+    const float* src = c < d.C1 ? d.x1 + static_cast<size_t>(pix) * d.C1 + c : d.x2 + static_cast<size_t>(pix) * d.C2 + (c - d.C1);
     float v[V], a[V], bb[V], y[V];
     if constexpr (V == 4) {
       const float4 t = *reinterpret_cast<const float4*>(src);
@@ -294,7 +290,7 @@ __global__ __launch_bounds__(256) void k_gn_apply(tfmq_gn_desc d, const float* _
         bb[q] = Bb[static_cast<size_t>(b) * Cc + c + q];
       }
     }
-    const size_t o = pix * Cc + c;
+    const size_t o = static_cast<size_t>(pix) * Cc + c;
 #pragma unroll
     for (int q = 0; q < V; ++q) {
       y[q] = a[q] * v[q] + bb[q];
@@ -332,10 +328,11 @@ __global__ __launch_bounds__(256) void k_gn_apply(tfmq_gn_desc d, const float* _
     }
     pix += sdiv;
     cq += smod;
-    if (cq >= cv) {
-      cq -= cv;
+    if (cq >= ucv) {
+      cq -= ucv;
       ++pix;
     }
+    if (i + stride < i) break;      // 32-bit wrap of the item index (total close to 2^32)
   }
 }
 
@@ -356,6 +353,7 @@ extern "C" int tfmq_groupnorm_from_stats(tfmq_handle h, const tfmq_gn_desc* dd, 
   TFMQ_LAUNCH_CHECK(h);
   const bool v4 = (d.C1 % 4 == 0) && (d.C2 % 4 == 0);
   const size_t total = static_cast<size_t>(d.B) * d.HW * (v4 ? Cc / 4 : Cc);
+  TFMQ_CHECK_ARG(h, total < (1ull << 32), "groupnorm_from_stats: more than 2^32 items");
   int blocks = ceil_div(static_cast<long>(total), 256 * 4);
   if (blocks > h->cu_count * 16) blocks = h->cu_count * 16;
   if (blocks < 1) blocks = 1;
