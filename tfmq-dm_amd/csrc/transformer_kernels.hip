@@ -81,10 +81,19 @@ __global__ __launch_bounds__(256) void k_geglu(const float* __restrict__ hin, lo
   const bool quant = aq.qtable != nullptr;
   float2 qp = make_float2(1.0f, 0.0f);
   if (quant) qp = load_qparam(aq);
-  for (long i = static_cast<long>(blockIdx.x) * blockDim.x + threadIdx.x; i < total;
-       i += static_cast<long>(gridDim.x) * blockDim.x) {
-    const long m = i / (I / 4);
-    const int c = static_cast<int>(i - m * (I / 4)) * 4;
+  // (token, channel group) without a 64-bit division per item: 32-bit arithmetic (the launcher checks the item count),
+  // advancing by the grid stride = sdiv tokens + smod channel groups with carry
+  const unsigned cv = static_cast<unsigned>(I / 4);
+  const unsigned stride = gridDim.x * blockDim.x, i0 = blockIdx.x * blockDim.x + threadIdx.x;
+  const unsigned sdiv = stride / cv, smod = stride - sdiv * cv;
+  unsigned mu = i0 / cv, cq = i0 - mu * cv;
+  for (unsigned i = i0; i < static_cast<unsigned>(total); i += stride, mu += sdiv, cq += smod) {
+    if (cq >= cv) {
+      cq -= cv;
+      ++mu;
+    }
+    const long m = mu;
+    const int c = static_cast<int>(cq) * 4;
     const float4 a = *reinterpret_cast<const float4*>(hin + m * 2 * I + c);
     const float4 g = *reinterpret_cast<const float4*>(hin + m * 2 * I + I + c);
     float4 y;
@@ -101,6 +110,7 @@ __global__ __launch_bounds__(256) void k_geglu(const float* __restrict__ hin, lo
       q.w = static_cast<signed char>(static_cast<int>(quant_index_f(y.w, qp.x, qp.y, 255.0f)) - 128);
       *reinterpret_cast<char4*>(yq + m * I + c) = q;
     }
+    if (i + stride < i) break;      // 32-bit wrap of the item index
   }
 }
 
@@ -109,6 +119,7 @@ extern "C" int tfmq_geglu(tfmq_handle h, const float* hin, long rows, int inner,
   TFMQ_CHECK_ARG(h, h && hin && rows > 0 && inner > 0 && inner % 4 == 0, "geglu: bad argument");
   TFMQ_CHECK_ARG(h, (aq.qtable && yq) || yf, "geglu: no output requested");
   const long total = rows * (inner / 4);
+  TFMQ_CHECK_ARG(h, total < (1L << 32), "geglu: more than 2^32 items");
   int blocks = ceil_div(total, 256);
   if (blocks > h->cu_count * 16) blocks = h->cu_count * 16;
   hipLaunchKernelGGL(k_geglu, dim3(blocks), dim3(256), 0, as_stream(stream), hin, rows, inner, aq, yq, yf);
