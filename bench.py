@@ -275,6 +275,66 @@ def calibration_sample(dev):
     return res
 
 
+def calibration_sharded(dev, world):
+    """The exchange step of the sharded calibration on the real interconnect (BASELINE configs[4]): one SD-size
+    ResBlock unit and one transformer unit (320 ch @ 64x64) iterated with mini-batch 8 PER RANK -- every rank owns its
+    shard's cached inputs -- and ONE SUM all-reduce of the flattened dL/dW_hat buffer per Adam iteration through the C
+    ABI's RCCL wrapper (tfmq_allreduce_sum_f32 on the unit's stream, between the backward GEMMs and the fused
+    AdaRound-backward + Adam kernel).  Collective: every rank calls it.  world 1: the same units without the exchange."""
+    import tfmq_dm_amd.linklink as link
+    import tfmq_dm_amd.ops as ops
+    from tfmq_dm_amd.engine import recon as R
+    gen = torch.Generator().manual_seed(3)          # identical weights on every rank (replicas); shard data differs by rank
+
+    def ada(cout, cin, k=1, bias=True):
+        shape = (cout, cin, k, k) if k > 1 else (cout, cin)
+        w = (torch.randn(*shape, generator=gen) * 0.05).to(dev)
+        qp = ops.minmax_to_qparam(ops.minmax(w.reshape(cout, -1).contiguous(), cout), 16)
+        return R.AdaLayer(w, qp[:, 0].contiguous(), qp[:, 1].contiguous(), torch.zeros(cout, device=dev) if bias else None)
+    Cc, HW, N = 320, 64, 8
+    kw = dict(iters=100, world_size=world, allreduce=link.allreduce if world > 1 else None)
+    c1, c2 = ada(Cc, Cc, 3), ada(Cc, Cc, 3)
+    layers = [ada(Cc, Cc, 1, False), ada(Cc, Cc, 1, False), ada(Cc, Cc, 1, False), ada(Cc, Cc), ada(8 * Cc, Cc), ada(Cc, 4 * Cc),
+              ada(Cc, Cc, 1, False), ada(Cc, 768, 1, False), ada(Cc, 768, 1, False), ada(Cc, Cc)]
+    x = torch.randn(N, HW, HW, Cc, device=dev)      # device RNG: each rank draws its own shard
+    y = torch.randn(N, HW, HW, Cc, device=dev)
+    gn = (torch.ones(Cc, device=dev), torch.zeros(Cc, device=dev))
+    ru = R.ResnetUnit(c1, c2, gn, gn, None, x, torch.randn(N, Cc, device=dev), y, eps=1e-5, **kw)
+    tu = R.TransformerUnit(layers, [gn, gn, gn], 8, x.reshape(N, HW * HW, Cc), torch.randn(N, 77, 768, device=dev),
+                           y.reshape(N, HW * HW, Cc), **kw)
+    idx = torch.arange(N, device=dev)
+    res = {"world": world, "mini_batch_per_rank": N,
+           "collective": "RCCL ncclAllReduce(SUM, fp32) via the C ABI (tfmq_allreduce_sum_f32), one per iteration" if world > 1 else None}
+    for name, unit in (("resblock_320ch_64x64", ru), ("transformer_320ch_64x64", tu)):
+        for _ in range(2):
+            unit.iterate(idx)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(8):
+            unit.iterate(idx)
+        torch.cuda.synchronize(dev)
+        ms = (time.perf_counter() - t0) / 8 * 1e3
+        nbytes = 4 * sum(l.alpha.numel() for l in unit.layers)
+        ent = {"ms_per_iter": round(ms, 3), "allreduce_bytes": nbytes}
+        if world > 1:
+            buf = torch.empty(nbytes // 4, device=dev).normal_()
+            for _ in range(3):
+                link.allreduce(buf)
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            for _ in range(10):
+                link.allreduce(buf)
+            torch.cuda.synchronize(dev)
+            us = (time.perf_counter() - t0) / 10 * 1e6
+            ent["allreduce_us"] = round(us, 1)
+            ent["allreduce_algbw_GBps"] = round(nbytes / us / 1e3, 2)
+            ent["allreduce_busbw_GBps"] = round(nbytes / us / 1e3 * 2 * (world - 1) / world, 2)
+        res[name] = ent
+    del ru, tu, layers, x, y
+    torch.cuda.empty_cache()
+    return res
+
+
 def sd_first_stage_state(gen):
     """Random-init state dict of the SD v1 KL-f8 first stage's decode side (ch 128, mult 1-2-4-4, 2 res blocks)."""
     sd = {}
@@ -358,6 +418,16 @@ def conv_roofline(fwd, stream, n_fwd=2):
     return tot_ops, tot_ms, n, tot_bytes, n_fwd
 
 
+def _partial_line(args, info, world, dt, finite):
+    """The sampling half of the JSON line (what rank 0 still prints if the calibration leg wedges at N > 1)."""
+    cfgd = {"workload": info["workload"], "parallelism": f"replicas x{world} (no data-path collective)"}
+    cfgd.update(info["extra"])
+    return {"metric": "DDIM-50 images/sec, w4a8 SD-v1-4", "value": round(info["batch"] * world * args.steps / dt, 3), "unit": "images/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int8", "data": "synthetic",
+            "config": cfgd, "finite": finite}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -367,13 +437,27 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="images per GPU (default 64 for sd, 256 for cifar)")
     ap.add_argument("--ddim-steps", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-cali-leg", action="store_true", help="skip the sharded-calibration exchange-step leg")
     args = ap.parse_args()
 
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the TFMQ hot path has no CPU fallback")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` on its own: become N ranks (one process per GPU) under torch.distributed.run,
+        # exactly the command the driver uses
+        if torch.cuda.device_count() < args.gpus:
+            raise SystemExit(f"bench.py --gpus {args.gpus}: this node has {torch.cuda.device_count()} GPU(s)")
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        os.execv(sys.executable, [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+                                  "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:])
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: the TFMQ hot path has no CPU fallback")
+    if world != args.gpus and rank == 0:
+        print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; reporting n_gpus={world}", file=sys.stderr)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
@@ -381,6 +465,8 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world)
+        import tfmq_dm_amd.linklink as link
+        link.init_comm(local_rank)       # the C ABI's own RCCL communicator (calibration exchange step)
 
     def log(*a):
         if rank == 0:
@@ -408,6 +494,35 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     finite = info["finite"]()
+
+    # ---- second half of the metric: the sharded-calibration exchange step, every rank takes part.  A watchdog keeps a
+    # wedged collective from costing the sampling number: after the deadline rank 0 prints the line without this leg.
+    sharded = {"error": "skipped"}
+    done = {"printed": False}
+
+    def emit(out):
+        if not done["printed"]:
+            done["printed"] = True
+            print(json.dumps(out), flush=True)
+    if args.workload == "sd" and not args.no_cali_leg:
+        import threading
+        state = {"partial": None}
+
+        def bail():
+            if rank == 0 and state["partial"] is not None:
+                state["partial"]["calibration"] = {"sharded": {"error": "calibration leg exceeded its deadline"}}
+                emit(state["partial"])
+            os._exit(0 if rank == 0 and state["partial"] is not None else 3)
+        wd = threading.Timer(420.0, bail)
+        wd.daemon = True
+        if world > 1:
+            state["partial"] = dict(_partial_line(args, info, world, dt, finite)) if rank == 0 else None
+            wd.start()
+        try:
+            sharded = calibration_sharded(dev, world)
+        except Exception as e:        # noqa: BLE001 -- reported in the line, never fatal for the sampling number
+            sharded = {"error": f"{type(e).__name__}: {e}"}
+        wd.cancel()
 
     if rank == 0:
         images = info["batch"] * world * args.steps
@@ -439,8 +554,10 @@ def main():
             cpu_b = {"value": round(v, 5), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
                      "sample": "oracle (torch-CPU fake-quant UNet, same weights / act tables): " + sample}
         cali = None
+        if args.workload == "sd":
+            cali = {"sharded": sharded}
         if world == 1 and args.workload == "sd" and not args.no_cpu_baseline:
-            cali = calibration_sample(dev)
+            cali.update(calibration_sample(dev))
             cali["first_stage_decode"] = first_stage_sample(dev)
             cali["plms"] = info["plms"]()
         cfgd = {"workload": info["workload"], "parallelism": f"replicas x{world} (no data-path collective)"}
@@ -454,9 +571,10 @@ def main():
             "data": "synthetic: N(0,1) latents / context, random-init weights (zero params re-drawn N(0,0.02^2)), synthetic FSC tables",
             "config": cfgd, "finite": finite, "roofline": roof, "cpu_baseline": cpu_b, "calibration": cali,
         }
-        print(json.dumps(out), flush=True)
+        emit(out)
     if dist is not None:
         dist.barrier()
+        link.destroy_comm()
         dist.destroy_process_group()
 
 

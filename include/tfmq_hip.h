@@ -349,6 +349,24 @@ int tfmq_upsample2x(tfmq_handle h, const float* x, float* y, int B, int H, int W
 /* y += a*x */
 int tfmq_axpy(tfmq_handle h, float* y, const float* x, float a, size_t n, void* stream);
 
+/* ---- K16: the exchange step of the sharded calibration: RCCL over xGMI, one rank per GPU.
+ * Replaces linklink.allreduce / dist_helper.allaverage (linklink/__init__.py:6-13, linklink/dist_helper.py:33-36) at
+ * their call sites: the SUM of a reconstruction unit's gradients every Adam iteration (quant/reconstruction.py:72-75,
+ * 193-195,298-300) and the all-average of the activation deltas (quant/quant_model.py:127-132). --------------------- */
+#define TFMQ_COMM_ID_BYTES 128
+/* rank 0 draws the rendezvous id (host bytes) and hands it to every rank by any side channel (the Python mirror
+ * broadcasts it over the torch.distributed store the reference's init_process_group already creates) */
+int tfmq_comm_unique_id(uint8_t* id_host /* [TFMQ_COMM_ID_BYTES] */);
+/* collective: every rank calls it with the same id; binds a communicator of `world` ranks to the handle's device.
+ * TFMQ_ERR_UNSUPPORTED when librccl cannot be loaded. */
+int tfmq_comm_init(tfmq_handle h, const uint8_t* id_host, int rank, int world);
+/* rank / world of the handle's communicator (world = 0: none) */
+int tfmq_comm_info(tfmq_handle h, int* rank, int* world);
+/* in-place SUM over all ranks of n fp32 values at device pointer buf, enqueued on `stream` (ordered with the kernels
+ * launched on it before and after; no host synchronisation) */
+int tfmq_allreduce_sum_f32(tfmq_handle h, float* buf, size_t n, void* stream);
+int tfmq_comm_destroy(tfmq_handle h);
+
 /* ---- stream-capture helpers: a sampler step is captured once into a hipGraph and replayed */
 int tfmq_graph_begin(tfmq_handle h, void* stream);
 int tfmq_graph_end(tfmq_handle h, void* stream, int* graph_id);

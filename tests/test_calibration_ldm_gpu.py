@@ -50,7 +50,7 @@ def test_transformer_unit_gradients_vs_autograd():
     hc = n3 @ Wf0.T + bf0
     a, gate = hc.chunk(2, dim=-1)
     out = (a * F.gelu(gate)) @ Wf2.T + bf2 + x2
-    loss = ((out - y) ** 2).sum(-1).mean()            # lp_loss(p=2): sum over channels, mean over the rest
+    loss = ((out - y) ** 2).sum(1).mean()             # lp_loss(p=2) as the reference states it (quant_layer.py:152-153): on [B,T,C] dim 1 = tokens
     loss.backward()
 
     class Plain(R.AdaLayer):                          # AdaLayer whose "soft weight" is the weight itself

@@ -132,6 +132,11 @@ _SIGS = {
     "tfmq_event_record": (c_int, [c_void_p, c_int, c_void_p]),
     "tfmq_event_elapsed_ms": (c_int, [c_void_p, c_int, c_int, C.POINTER(c_float)]),
     "tfmq_stream_sync": (c_int, [c_void_p, c_void_p]),
+    "tfmq_comm_unique_id": (c_int, [C.POINTER(C.c_uint8)]),
+    "tfmq_comm_init": (c_int, [c_void_p, C.POINTER(C.c_uint8), c_int, c_int]),
+    "tfmq_comm_info": (c_int, [c_void_p, C.POINTER(c_int), C.POINTER(c_int)]),
+    "tfmq_allreduce_sum_f32": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
+    "tfmq_comm_destroy": (c_int, [c_void_p]),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGS)
@@ -173,6 +178,7 @@ class Handle:
                             "(the TFMQ hot path has no CPU fallback)")
         self.h = hp
         self.device = device
+        self.comm_world = 0     # > 0 once linklink.init_comm bound an RCCL communicator to this handle
 
     def call(self, name: str, *args):
         fn = getattr(self.lib, "tfmq_" + name)

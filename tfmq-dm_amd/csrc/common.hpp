@@ -22,6 +22,9 @@ struct tfmq_ctx {
   // grow-only scratch of the split-K reconstruction GEMM (partial sums); used in stream order by one stream at a time
   float* gemm_ws = nullptr;
   size_t gemm_ws_bytes = 0;
+  // RCCL communicator of the sharded calibration (comm.hip); opaque here so that no kernel file needs rccl.h
+  void* comm = nullptr;
+  int comm_rank = 0, comm_world = 0;
 };
 
 // strided fp32 GEMM of the reconstruction units (recon_kernels.hip, gemm_f32_mfma.hip)

@@ -1,7 +1,7 @@
 // Handle, device query, hipGraph capture helpers and HIP-event timing.
 #include "common.hpp"
 
-extern "C" int tfmq_abi_version(void) { return 1; }
+extern "C" int tfmq_abi_version(void) { return 2; }
 
 extern "C" int tfmq_create(int device, tfmq_handle* out) {
   if (!out) return TFMQ_ERR_ARG;
@@ -32,6 +32,7 @@ extern "C" int tfmq_create(int device, tfmq_handle* out) {
 
 extern "C" int tfmq_destroy(tfmq_handle h) {
   if (!h) return TFMQ_ERR_ARG;
+  if (h->comm) (void)tfmq_comm_destroy(h);
   for (auto g : h->graphs)
     if (g) (void)hipGraphExecDestroy(g);
   for (auto e : h->events)

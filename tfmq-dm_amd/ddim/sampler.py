@@ -81,6 +81,16 @@ def generalized_steps(x, seq, model, b, **kwargs):
     return xs, x0_preds, xt, t
 
 
+def check_fsc_rows(engine, n_steps: int, who: str) -> None:
+    """A Finite-Set-Calibration table with G > 1 rows is indexed by the device step counter 0..n_steps-1
+    (csrc/common.hpp load_qparam, no bound check on the device): a checkpoint calibrated for fewer timestep groups than
+    the sampling run would read past the table.  The reference raises KeyError on the missing `act_k` there."""
+    qt = getattr(engine, "qtable", None)
+    if qt is not None and qt.shape[0] > 1 and qt.shape[0] < n_steps:
+        raise TfmqError(f"{who}: the activation table holds {qt.shape[0]} timestep groups but the sampler runs {n_steps} steps "
+                        "(calibrate with one group per sampling step, or install a matching table)")
+
+
 class GraphDdimSampler:
     """DDIM loop over a prepared DdimUNetEngine, one hipGraph replay per step."""
 
@@ -94,6 +104,7 @@ class GraphDdimSampler:
         if engine.step is None:
             raise TfmqError("GraphDdimSampler: engine.prepare() needs a device step counter")
         self.step = engine.step
+        check_fsc_rows(engine, self.n_steps, "GraphDdimSampler")
         engine.build_tib_table([float(i) for i in reversed(self.seq)])
         cfg = engine.cfg
         self.x = torch.empty(batch, cfg["resolution"], cfg["resolution"], cfg.get("in_channels", 3), device=self.dev)

@@ -65,10 +65,13 @@ class _Unit:
     """Shared iteration driver.  Sub-classes implement _forward_backward(idx) -> (rec_loss_tensor,
     [g_what per AdaLayer, OIHW])."""
 
+    trace = None      # tests: a list -> the first iteration of every unit appends (local flat gradient, reduced flat gradient)
+
     def __init__(self, layers: Sequence[AdaLayer], iters: int, w: float = 0.01, warmup: float = 0.2, lr: float = 1e-3,
-                 world_size: int = 1, allreduce=None):
+                 world_size: int = 1, allreduce=None, b_range=(20, 2)):
         self.layers = list(layers)
         self.iters, self.w_reg, self.warmup, self.lr = iters, w, warmup, lr
+        self.b_range = (float(b_range[0]), float(b_range[1]))      # LossFunc's temperature range (reconstruction.py b_range)
         self.world_size, self.allreduce = world_size, allreduce
         self.count = 0
         dev = self.layers[0].w.device
@@ -88,13 +91,16 @@ class _Unit:
             for g in grads:
                 self._flat[off:off + g.numel()].copy_(g.reshape(-1))
                 off += g.numel()
+            local = self._flat.clone() if (_Unit.trace is not None and self.count == 1) else None
             self.allreduce(self._flat)
+            if local is not None:
+                _Unit.trace.append((type(self).__name__, local.cpu(), self._flat.cpu().clone()))
             off, red = 0, []
             for g in grads:
                 red.append(self._flat[off:off + g.numel()].view_as(g))
                 off += g.numel()
             grads = red
-        b = temp_decay(self.count, self.iters, self.warmup)
+        b = temp_decay(self.count, self.iters, self.warmup, self.b_range[0], self.b_range[1])
         reg_on = self.count >= self.iters * self.warmup
         self._rl.zero_()
         w_eff = self.w_reg * (self.world_size if (self.world_size > 1 and self.allreduce is not None) else 1)
@@ -291,7 +297,8 @@ class TransformerUnit(_Unit):
         hcat = ops.gemm(n3, wf0, trans_b=True, bias=f0l.bias)                                        # [B*T, 2I]
         gg = ops.geglu(hcat, None)[1]                                                                  # [B*T, I]
         out = ops.gemm(gg, wf2, trans_b=True, bias=f2l.bias, residual=x2)
-        loss, g = ops.recon_loss(out.reshape(B, T, Cc), y, denom=B * T)
+        # lp_loss on a [B, T, C] tensor sums over dim 1 = the tokens and averages over B * C (quant_layer.py:152-153)
+        loss, g = ops.recon_loss(out.reshape(B, T, Cc), y, denom=B * Cc)
         # ---- backward (weight gradients only; d/dx of the block input is not needed)
         g_out = g.reshape(B * T, Cc)
         gwf2 = ops.gemm(g_out, gg, trans_a=True)

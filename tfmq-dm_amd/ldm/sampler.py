@@ -18,6 +18,7 @@ import torch
 
 from .. import ops
 from .._lib import TfmqError, handle
+from ..ddim.sampler import check_fsc_rows
 
 
 def alphas_cumprod_linear(linear_start: float = 0.00085, linear_end: float = 0.012, n: int = 1000) -> torch.Tensor:
@@ -58,6 +59,7 @@ class GraphLatentDdimSampler:
         if engine.step is None:
             raise TfmqError("GraphLatentDdimSampler: engine.prepare() needs a device step counter")
         self.step = engine.step
+        check_fsc_rows(engine, self.coef.shape[0], type(self).__name__)
         engine.build_tib_table([float(t) for t in np.flip(ddim_timesteps(S, ac.shape[0]))])
         Cc, H, W = latent_shape
         self.x = torch.empty(batch, H, W, Cc, device=self.dev)

@@ -163,7 +163,7 @@ def cali_model_multi(gpu: int, dist_backend: str, world_size: int, dist_url: str
     """One process per GPU (mp.spawn target, reference :228-389): shard the calibration sets, replicate the
     model, SUM all-reduce of the unit's gradients every iteration (RCCL over xGMI), all-average of the
     activation deltas, rank 0 writes the checkpoint."""
-    import linklink as dist
+    from tfmq_dm_amd import linklink as dist
     rank = rank * ngpus_per_node + gpu
     dist.init_process_group(backend=dist_backend, init_method=dist_url, world_size=world_size, rank=rank)
     torch.cuda.set_device(gpu)
@@ -192,13 +192,18 @@ def cali_model_multi(gpu: int, dist_backend: str, world_size: int, dist_url: str
         model_dict = {"weight": {k: v.detach().cpu() for k, v in qnn.state_dict().items()}}
     if use_aq:
         def sync(delta_col):
-            delta_col /= world_size
-            dist.allreduce(delta_col)
+            # all-average of the deltas (quant_model.py:127-132): the column is a strided view of the table, the
+            # collective wants a contiguous buffer
+            d = delta_col.contiguous()
+            d /= world_size
+            dist.allreduce(d)
+            delta_col.copy_(d)
         _calibrate_activations(qnn, a_cali_data, interval // world_size, running_stat, model_dict, rank0=rank == 0,
                                sync=sync if ngpus_per_node > 1 else None)
         if path and rank == 0:
             torch.save(model_dict, path)
     logger.info("Calibration done.")
+    return qnn      # (the reference returns None; mp.spawn ignores the value -- tests read the replica's final state)
 
 
 def load_cali_model(qnn: QuantModel, init_data: Tuple[torch.Tensor], use_aq: bool = False, path: str = None) -> None:

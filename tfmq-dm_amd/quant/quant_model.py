@@ -113,7 +113,7 @@ class QuantModel(nn.Module):
     def synchorize_activation_statistics(self):
         """all-average of every initialised activation delta (reference :127-132; zero-points are not
         synchronised there either)."""
-        import linklink.dist_helper as dist
+        from tfmq_dm_amd.linklink import dist_helper as dist
         for module in self.modules():
             if isinstance(module, QuantLayer) and module.aqtizer.delta is not None:
                 dist.allaverage(module.aqtizer.delta)

@@ -30,7 +30,7 @@ logger = logging.getLogger(__name__)
 def _dist_kw(multi_gpu: bool):
     if not multi_gpu:
         return dict(world_size=1, allreduce=None)
-    import linklink as link
+    from tfmq_dm_amd import linklink as link
     return dict(world_size=link.get_world_size(), allreduce=link.allreduce)
 
 
@@ -81,7 +81,7 @@ def layer_reconstruction(model, layer: QuantLayer, cali_data: Tuple[torch.Tensor
                          decay_start=0.0, warmup=warmup, p=p)
     cached_inputs, cached_outputs = save_inout(model, layer, cali_data, asym, use_aq, batch_size, keep_gpu)
     ph, pw = layer.fwd_kwargs.get("padding", (0, 0))
-    unit = R.LayerUnit(ada, cached_inputs[0], cached_outputs, pad=(ph, pw, ph, pw), iters=iters, w=w, warmup=warmup,
+    unit = R.LayerUnit(ada, cached_inputs[0], cached_outputs, pad=(ph, pw, ph, pw), iters=iters, w=w, warmup=warmup, b_range=b_range,
                        **_dist_kw(multi_gpu))
     _run(unit, cached_inputs[0].size(0), batch_size, iters, loss_func, cached_outputs.device)
     _commit(layer, ada)
@@ -102,7 +102,7 @@ def block_reconstruction(model, block: BaseQuantBlock, cali_data: torch.Tensor, 
     loss_func = LossFunc(o=block, round_loss=RLOSS.RELAXATION, w=w, max_count=iters, rec_loss=opt_mode, b_range=b_range,
                          decay_start=0.0, warmup=warmup, p=p)
     dev = next(block.parameters()).device
-    kw = dict(iters=iters, w=w, warmup=warmup, **_dist_kw(multi_gpu))
+    kw = dict(iters=iters, w=w, warmup=warmup, b_range=b_range, **_dist_kw(multi_gpu))
     if isinstance(block, QuantResnetBlock):
         adas = {"conv1": _ada_layer(block.conv1), "conv2": _ada_layer(block.conv2)}   # temb_proj is quant_emb: excluded
         cached_inputs, cached_outputs = save_inout(model, block, cali_data, asym, use_aq, batch_size, keep_gpu)
@@ -199,7 +199,7 @@ def tib_reconstruction(block: BaseQuantBlock, cali_data: torch.Tensor, batch_siz
     s0 = ops.silu(h0)
     loss_func = LossFuncTimeEmbedding(o=block, round_loss=RLOSS.RELAXATION, w=w, max_count=iters, rec_loss=opt_mode,
                                       b_range=b_range, decay_start=0.0, warmup=warmup, p=p)
-    unit = R.TibUnit(ada1, adap, s0, targets, iters=iters, w=w, warmup=warmup, **_dist_kw(multi_gpu))
+    unit = R.TibUnit(ada1, adap, s0, targets, iters=iters, w=w, warmup=warmup, b_range=b_range, **_dist_kw(multi_gpu))
     _run(unit, ts.size(0), batch_size, iters, loss_func, dev)
     d0.wqtizer.soft_tgt = False
     _commit(d1, ada1)
