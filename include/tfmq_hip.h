@@ -59,6 +59,8 @@ typedef struct tfmq_qsel {
 /* ---- K1: activation quantizer (UniformAffineQuantizer.forward, quant_layer.py:223-226) */
 /* q[i] = clamp(rint(x[i]/delta)+zp, 0, level-1) - 128   (level <= 256) */
 int tfmq_quantize_act(tfmq_handle h, const float* x, int8_t* q, size_t n, tfmq_qsel qs, int level, void* stream);
+/* the same on an fp16 tensor (the fp16 activation stream); n % 4 == 0 */
+int tfmq_quantize_act_h(tfmq_handle h, const uint16_t* x, int8_t* q, size_t n, tfmq_qsel qs, int level, void* stream);
 /* y[i] = delta * (clamp(rint(x/delta)+zp,0,level-1) - zp); delta/zp per tensor (rows=1)
  * or per row ([rows] arrays, the per-output-channel weight quantizer, quant_layer.py:193-204) */
 int tfmq_fake_quant(tfmq_handle h, const float* x, float* y, uint8_t* idx_or_null, size_t rows, size_t cols,
@@ -173,11 +175,14 @@ typedef struct tfmq_conv_desc {
                                     128x128, 64x64, 256x128 or 128x64 output tiles -- the result does not depend on the choice
                                     (int32 sums are exact; the f16 path accumulates each output in the same K order);
                                     a shape the launch is not eligible for falls back to the rule.  Lets a host time
-                                    the variants per layer shape once and pin the fastest (ops.set_conv_autotune) */
-  int32_t pad1_;
+                                    the variants per layer shape once and pin the fastest (ops.set_conv_autotune).
+                                    TFMQ_TILE_SLAB: the 3x3 / stride-1 / pad-1 w4a8 kernel that stages the activation slab of a
+                                    256-pixel tile once per channel chunk for all nine taps (256 x 320 / 256 / 128 tiles, 8 waves) */
+  int32_t res_f16;               /* != 0: `residual` is an fp16 buffer [B][Ho][Wo][Cout] (a tensor of the fp16 activation stream:
+                                    the TFMQ_OUT_F16 output of an earlier launch) */
 } tfmq_conv_desc;
 enum { TFMQ_OUT_F32 = 0, TFMQ_OUT_F16 = 1, TFMQ_OUT_GEGLU_Q8 = 2, TFMQ_OUT_Q8 = 3 };
-enum { TFMQ_TILE_AUTO = 0, TFMQ_TILE_128 = 1, TFMQ_TILE_64 = 2, TFMQ_TILE_256 = 3, TFMQ_TILE_128x64 = 4 };
+enum { TFMQ_TILE_AUTO = 0, TFMQ_TILE_128 = 1, TFMQ_TILE_64 = 2, TFMQ_TILE_256 = 3, TFMQ_TILE_128x64 = 4, TFMQ_TILE_SLAB = 5 };
 int tfmq_conv2d_w4a8(tfmq_handle h, const tfmq_conv_desc* d, void* stream);
 int tfmq_conv2d_f16(tfmq_handle h, const tfmq_conv_desc* d, void* stream);
 
@@ -212,7 +217,8 @@ typedef struct tfmq_gn_desc {
   float* xcat_or_null;     /* optional: also materialise the concat (input of the FP nin_shortcut / skip_connection) */
   int32_t half_out;        /* !=0: yf and xcat_or_null are fp16 buffers (consumers that round to fp16 anyway:
                               tfmq_conv2d_f16 with x_f16) */
-  int32_t pad0_;
+  int32_t x_f16;           /* !=0: x1 / x2 are fp16 buffers (the fp16 activation stream: TFMQ_OUT_F16 outputs of the producing
+                              convs, whose epilogues still emit the statistics from the fp32 values) */
 } tfmq_gn_desc;
 int tfmq_groupnorm(tfmq_handle h, const tfmq_gn_desc* d, void* stream);
 /* same result when the producing conv(s) already emitted the statistics (tfmq_conv_desc.stats, segment size
@@ -226,6 +232,9 @@ int tfmq_groupnorm_from_stats(tfmq_handle h, const tfmq_gn_desc* d, const float*
 /* x: [rows][C] fp32; writes int8 (bin-128) to yq when aq.qtable != NULL and/or fp32 to yf */
 int tfmq_layernorm(tfmq_handle h, const float* x, const float* gamma, const float* beta, float eps, long rows, int C,
                    tfmq_qsel aq, int8_t* yq, float* yf, void* stream);
+/* the same on an fp16 input row (the fp16 activation stream), statistics and arithmetic in fp32 */
+int tfmq_layernorm_h(tfmq_handle h, const uint16_t* x, const float* gamma, const float* beta, float eps, long rows, int C,
+                     tfmq_qsel aq, int8_t* yq, float* yf, void* stream);
 /* hin: [rows][2*inner] (output of ff.net.0.proj): y = hin[:, :inner] * gelu(hin[:, inner:]) */
 int tfmq_geglu(tfmq_handle h, const float* hin, long rows, int inner, tfmq_qsel aq, int8_t* yq, float* yf, void* stream);
 

@@ -126,7 +126,7 @@ def f8b():
 # ---------------------------------------------------------------------------- F15
 CIN_KW = dict(image_size=8, in_channels=3, model_channels=32, out_channels=3, num_res_blocks=1,
               attention_resolutions=[1, 2], channel_mult=[1, 2], num_heads=1, use_spatial_transformer=True,
-              transformer_depth=1, context_dim=48, legacy=False)
+              transformer_depth=1, context_dim=64, legacy=False)
 
 
 def f15():
@@ -148,7 +148,7 @@ def f15():
     g = torch.Generator().manual_seed(1515)
     x = torch.randn(2, 3, 8, 8, generator=g)
     t = torch.tensor([951, 51])
-    ctx = torch.randn(2, 1, 48, generator=g)              # ONE context token: the class embedding
+    ctx = torch.randn(2, 1, 64, generator=g)              # ONE context token: the class embedding
     out.update(x=x, t=t, ctx=ctx)
     with torch.no_grad():
         out["eps_fp"] = m(x, t, ctx)
@@ -169,7 +169,7 @@ def f15():
     out["alphas_cumprod"] = ldm.alphas_cumprod
     sampler = DDIMSampler(ldm)
     x_T = torch.randn(2, 3, 8, 8, generator=g)
-    uc = torch.randn(1, 1, 48, generator=g).repeat(2, 1, 1)        # the "null class" embedding, same for every sample
+    uc = torch.randn(1, 1, 64, generator=g).repeat(2, 1, 1)        # the "null class" embedding, same for every sample
     out["traj_xT"], out["traj_uc"] = x_T, uc
     kw = dict(S=4, conditioning=ctx, batch_size=2, shape=[3, 8, 8], verbose=False, unconditional_guidance_scale=3.0,
               unconditional_conditioning=uc, eta=0.0, x_T=x_T)
@@ -181,7 +181,7 @@ def f15():
     G, I = 3, 16
     xs = torch.randn(G * I, 3, 8, 8, generator=g)
     ts = torch.cat([torch.full((I,), float(tv)) for tv in (901, 501, 101)])
-    cs = torch.randn(G * I, 1, 48, generator=g)
+    cs = torch.randn(G * I, 1, 64, generator=g)
     out["cali_x"], out["cali_t"], out["cali_c"] = xs, ts, cs
     qnn = QuantModel(m, dict(WQ), dict(AQ), aq_mode=MODE).eval()
     qnn.set_grad_ckpt(False)
@@ -193,10 +193,10 @@ def f15():
     ck = torch.load(path, map_location="cpu")
     _ckpt_arrays(out, ck, G)
     qnn2 = QuantModel(build(), dict(WQ), dict(AQ), cali=False, aq_mode=MODE).eval()
-    init = (torch.randn(1, 3, 8, 8, generator=g), torch.randint(0, 1000, (1,), generator=g), torch.randn(1, 1, 48, generator=g))
+    init = (torch.randn(1, 3, 8, 8, generator=g), torch.randint(0, 1000, (1,), generator=g), torch.randn(1, 1, 64, generator=g))
     load_cali_model(qnn2, init, use_aq=True, path=path)
     qnn2.load_state_dict(ck["act_1"], strict=False)
-    xe, te, ce = torch.randn(2, 3, 8, 8, generator=g), torch.tensor([501.0, 501.0]), torch.randn(2, 1, 48, generator=g)
+    xe, te, ce = torch.randn(2, 3, 8, 8, generator=g), torch.tensor([501.0, 501.0]), torch.randn(2, 1, 64, generator=g)
     with torch.no_grad():
         out["reload_x"], out["reload_t"], out["reload_c"] = xe, te, ce
         out["reload_eps_act1"] = qnn2(xe, te, ce)
@@ -319,7 +319,7 @@ def f17():
     f15 = np.load(os.path.join(HERE, "f15_cin_tiny.npz"), allow_pickle=False)
     mc = UNetModel(**CIN_KW).eval()
     mc.load_state_dict({k[3:]: torch.from_numpy(f15[k]) for k in f15.files if k.startswith("sd/")})
-    cldm = CondLDM(mc, 48, 1, seed=71, linear_start=0.0015, linear_end=0.0195)
+    cldm = CondLDM(mc, 64, 1, seed=71, linear_start=0.0015, linear_end=0.0195)
     out["imagenet/table"] = cldm.table
     torch.manual_seed(72)
     with RandnTape() as tape, torch.no_grad():
@@ -336,13 +336,19 @@ def f17():
     from contextlib import nullcontext
     torch.manual_seed(74)
     with RandnTape() as tape:
-        xt, tt, ct = DG.generate_cali_text_guided_data(tldm, PLMSSampler(tldm), T=3, c=1, batch_size=2, prompts=("a cat", "two dogs"),
+        xt, tt, ct = DG.generate_cali_text_guided_data(tldm, PLMSSampler(tldm), T=4, c=2, batch_size=2, prompts=("a cat", "two dogs"),
                                                        shape=[4, 8, 8], precision_scope=lambda dev: nullcontext())
     out["text/x"], out["text/t"], out["text/c"] = xt, tt, ct
     out.update(tape.arrays("text/randn"))
     # (d) pixel-space: generate_cali_data_ddim through the reference's Diffusion runner, and sample_fid's image batch
-    for name in ("torchvision", "torchvision.utils", "torchvision.transforms", "torchvision.datasets", "lmdb"):
-        sys.modules.setdefault(name, types.ModuleType(name))
+    # dataset / image-writing glue the image lacks (torchvision, lmdb): empty stand-in modules, import-only
+    for name in ("torchvision", "torchvision.utils", "torchvision.transforms", "torchvision.transforms.functional",
+                 "torchvision.datasets", "torchvision.datasets.utils", "lmdb"):
+        mod = sys.modules.setdefault(name, types.ModuleType(name))
+        mod.__path__ = []
+    sys.modules["torchvision.datasets"].CIFAR10 = object
+    sys.modules["torchvision.datasets.utils"].verify_str_arg = sys.modules["torchvision.datasets.utils"].iterable_to_str = None
+    sys.modules["torchvision.transforms"].functional = sys.modules["torchvision.transforms.functional"]
     saved = []
     sys.modules["torchvision.utils"].save_image = lambda img, path, **k: saved.append(img.detach().clone())
     sys.modules["torchvision"].utils = sys.modules["torchvision.utils"]
@@ -356,7 +362,7 @@ def f17():
     md.load_state_dict({k[3:]: torch.from_numpy(f7[k]) for k in f7.files if k.startswith("sd/")})
     import argparse
     args = argparse.Namespace(sample_type="generalized", skip_type="quad", timesteps=6, eta=0.0, image_folder="/tmp/_tfmq_f17",
-                              max_images=4, fid=True)
+                              numpy_folder="/tmp/_tfmq_f17_np", max_images=4, fid=True)
     cfg.model.var_type = "fixedlarge"
     cfg.sampling = argparse.Namespace(batch_size=4)
     cfg.data.rescaled = True
@@ -371,13 +377,15 @@ def f17():
             xt, tt = DG.generate_cali_data_ddim(r, md, T=6, c=2, batch_size=2, shape=(3, 16, 16))
         out["ddim/x"], out["ddim/t"] = xt, tt
         out.update(tape.arrays("ddim/randn"))
-        os.makedirs(args.image_folder, exist_ok=True)
-        for f in os.listdir(args.image_folder):
-            os.remove(os.path.join(args.image_folder, f))
+        for d in (args.image_folder, args.numpy_folder):
+            os.makedirs(d, exist_ok=True)
+            for f in os.listdir(d):
+                os.remove(os.path.join(d, f))
         torch.manual_seed(76)
         with RandnTape() as tape, torch.no_grad():
             r.sample_fid(md)
-        out["fid/images"] = torch.stack(saved)
+        npz = [f for f in os.listdir(args.numpy_folder) if f.endswith("-samples.npz")]
+        out["fid/uint8"] = np.load(os.path.join(args.numpy_folder, npz[0]))["arr_0"]       # the array the reference dumps
         out.update(tape.arrays("fid/randn"))
     save("f17_cali_generators", **out)
 

@@ -177,6 +177,62 @@ def test_tile_variants_are_bit_identical(ops, k, res, mode, B, H):
     assert torch.equal(y, outs[0][0])
 
 
+@pytest.mark.parametrize("B,H,cin,cout,res,mode", [
+    (2, 64, 64, 320, True, "f32"),        # 4 image rows per tile, 320-wide tiles (WN = 5: waves 0-3 stage 3 weight pieces)
+    (3, 32, 128, 640, False, "f32"),      # 8 rows per tile, two 320-wide column tiles
+    (5, 16, 192, 256, True, "q8"),        # one image per tile, 256-wide tiles, int8 output
+    (7, 8, 128, 96, True, "f32"),         # four images per tile (7 images: ragged last tile), 128-wide tile, ragged columns
+    (2, 32, 64, 384, True, "f16")])       # 256-wide tiles with a ragged second column tile, fp16 output
+def test_slab_kernel_is_bit_identical_to_the_tile_kernels(ops, B, H, cin, cout, res, mode):
+    """The 3x3 slab kernel (TFMQ_TILE_SLAB: K order (chunk, tap), activation slab staged once per chunk, 8 waves) against
+    the 128x128 kernel on the same launch: int32 sums are exact, the epilogue arithmetic and the statistics order are
+    shared, so outputs and GroupNorm statistics must agree bit for bit."""
+    import tfmq_dm_amd.ops as _o
+    W = H
+    g = torch.Generator().manual_seed(31 + H)
+    x = torch.randn(B, H, W, cin, generator=g) * 1.3 - 0.2
+    w = torch.randn(cout, cin, 3, 3, generator=g) * (2.0 / (cin * 9) ** 0.5)
+    b = torch.randn(cout, generator=g) * 0.2
+    wd, wz = O.init_channelwise(w, 16, "minmax")
+    ad, az = O.minmax(x, 256)
+    sel = ops.qsel(qtab(ad, az))
+    xq = ops.quantize_act(x.to(DEV), sel)
+    pw = ops.pack_w4(w.to(DEV), wd.to(DEV), wz.to(DEV), bias=b.to(DEV))
+    r = torch.randn(B, H, W, cout, generator=g).to(DEV) if res else None
+    ra = torch.randn(B, cout, generator=g).to(DEV)
+    kw = dict(pad=(1, 1, 1, 1), residual=r, rowadd=ra)
+    if mode == "q8":
+        kw["out_q8"] = ops.qsel(qtab(0.05, 120.0))
+    elif mode == "f16":
+        kw.update(out_f16=True, rowadd=None, residual=None)
+    else:
+        kw["want_stats"] = True
+    outs = []
+    for tile in (1, 5):
+        ops.set_conv_autotune({})
+        orig = _o._tune_conv
+        try:
+            _o._tune_conv = lambda h, name, kind, d, dsc, t=tile: t
+            y = ops.conv2d_w4a8(xq, pw, sel, **kw)
+            outs.append((y.clone(), y._tfmq_stats[0].clone() if mode == "f32" else None))
+        finally:
+            _o._tune_conv = orig
+            ops.set_conv_autotune(None)
+    assert torch.equal(outs[1][0], outs[0][0])
+    if mode == "f32":
+        assert torch.equal(outs[1][1], outs[0][1])
+    # and against the oracle's conv on the fake-quantised operands
+    if mode == "f32":
+        import torch.nn.functional as F
+        xh = O.fake_quant(x.permute(0, 3, 1, 2).contiguous(), ad, az, 256)
+        wh = O.fake_quant(w, wd.reshape(-1, 1, 1, 1), wz.reshape(-1, 1, 1, 1), 16)
+        ref = F.conv2d(xh, wh, b, padding=1) + ra.cpu()[:, :, None, None]
+        if r is not None:
+            ref = ref + r.cpu().permute(0, 3, 1, 2)
+        yy = outs[1][0].cpu().permute(0, 3, 1, 2)
+        assert float((yy - ref).abs().max() / ref.abs().max()) <= 1e-5
+
+
 def test_f16_conv_tile_variants_are_bit_identical(ops):
     """The fp16-activation DMA conv (un-quantised / weight-only layers) in its four tile shapes: same K order per output."""
     import tfmq_dm_amd.ops as _o

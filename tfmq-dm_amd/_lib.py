@@ -38,7 +38,7 @@ class ConvDesc(C.Structure):
         ("residual", c_void_p), ("y", c_void_p),
         ("ldy", C.c_int32), ("y_coff", C.c_int32),
         ("stats", c_void_p), ("stats_seg", C.c_int32), ("out_mode", C.c_int32),
-        ("oq", QSel), ("yq", c_void_p), ("yt", c_void_p), ("t_col0", C.c_int32), ("x_f16", C.c_int32), ("tile", C.c_int32), ("pad1_", C.c_int32),
+        ("oq", QSel), ("yq", c_void_p), ("yt", c_void_p), ("t_col0", C.c_int32), ("x_f16", C.c_int32), ("tile", C.c_int32), ("res_f16", C.c_int32),
     ]
 
 
@@ -50,7 +50,7 @@ class GnDesc(C.Structure):
         ("eps", c_float), ("groups", C.c_int32), ("silu", C.c_int32),
         ("aq", QSel),
         ("yq", c_void_p), ("yf", c_void_p), ("xcat", c_void_p),
-        ("half_out", C.c_int32), ("pad0_", C.c_int32),
+        ("half_out", C.c_int32), ("x_f16", C.c_int32),
     ]
 
 
@@ -62,6 +62,7 @@ _SIGS = {
     "tfmq_last_error": (C.c_char_p, [c_void_p]),
     "tfmq_device_info": (c_int, [c_void_p, C.POINTER(c_int), C.POINTER(c_int), C.POINTER(c_size_t)]),
     "tfmq_quantize_act": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, QSel, c_int, c_void_p]),
+    "tfmq_quantize_act_h": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, QSel, c_int, c_void_p]),
     "tfmq_fake_quant": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_size_t, c_void_p, c_void_p, c_int, c_void_p]),
     "tfmq_minmax_ws_bytes": (c_size_t, [c_size_t, c_size_t]),
     "tfmq_minmax": (c_int, [c_void_p, c_void_p, c_size_t, c_size_t, c_void_p, c_void_p, c_void_p]),
@@ -81,6 +82,7 @@ _SIGS = {
     "tfmq_groupnorm": (c_int, [c_void_p, C.POINTER(GnDesc), c_void_p]),
     "tfmq_groupnorm_from_stats": (c_int, [c_void_p, C.POINTER(GnDesc), c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     "tfmq_layernorm": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, C.c_long, c_int, QSel, c_void_p, c_void_p, c_void_p]),
+    "tfmq_layernorm_h": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, C.c_long, c_int, QSel, c_void_p, c_void_p, c_void_p]),
     "tfmq_geglu": (c_int, [c_void_p, c_void_p, C.c_long, c_int, QSel, c_void_p, c_void_p, c_void_p]),
     "tfmq_attention": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p, QSel,
                                c_int, c_int, c_int, c_int, c_int, c_float, c_void_p]),

@@ -1,0 +1,63 @@
+// Shared by the implicit-GEMM convolution kernels (conv_igemm.hip, conv_slab.hip).
+#pragma once
+#include "common.hpp"
+#ifdef TFMQ_PHASE_TIMERS
+#include <cstdio>
+#endif
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v16i __attribute__((ext_vector_type(16)));
+typedef float v16f __attribute__((ext_vector_type(16)));
+typedef _Float16 v8h __attribute__((ext_vector_type(8)));
+
+struct ConvP {
+  tfmq_conv_desc d;
+  int M;        // B*Ho*Wo
+  int chunks;   // K-steps per tap
+  int nsteps;   // KH*KW*chunks
+  int Ktot;     // KH*KW*Cin
+  int cin_pad;  // f16 path: padded Cin of the weight layout
+  int Hv, Wv;   // virtual input size (2H,2W when up2x)
+  int tiles_n;
+  int cout_pad;                    // w4a8: rows of the expanded weight operand (multiple of 32)
+  const unsigned char* pad_table;  // 256 x 64 B, row v = byte v (tfmq_ctx::pad_table)
+#ifdef TFMQ_PHASE_TIMERS
+  unsigned long long* dbg;         // [blocks][4] shader-clock stamps: start, loop start, loop end, end
+#endif
+};
+
+// Diagnostics build (TFMQ_EXTRA_HIPCC_FLAGS=-DTFMQ_PHASE_TIMERS python tfmq-dm_amd/build.py): every w4a8 DMA launch
+// is followed by a device sync and prints the mean cycles a block spends in prologue / K loop / epilogue.
+#ifdef TFMQ_PHASE_TIMERS
+#define TFMQ_MARK(i) do { if (p.dbg && threadIdx.x == 0) p.dbg[blockIdx.x * 4 + (i)] = clock64(); } while (0)
+#else
+#define TFMQ_MARK(i) do { } while (0)
+#endif
+
+// Workgroup barrier that only waits for LDS traffic.  __syncthreads() also drains vmcnt(0), i.e. it would wait for
+// the global prefetch loads of the NEXT K-steps at every barrier.
+#define LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+
+__device__ __forceinline__ int swz(int row, int slot) { return row * 64 + ((slot ^ ((row >> 2) & 3)) << 4); }
+
+// One LDS-DMA wave instruction: lane l moves 16 bytes from its own global pointer to LDS byte lds_dst + 16*l
+// (the destination is wave-uniform base + lane*16; M0 carries the base and is restored afterwards).
+__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(gsrc), "s"(lds_dst)
+               : "memory");
+}
+
+// XCD-aware tile order (T1): the dispatcher places block b on XCD b % 8; give each XCD a contiguous
+// range of tiles so the 3x3 taps / neighbouring rows of one image hit that XCD's private L2.
+// Bijective for any grid size; placement is a speed matter only.
+__device__ __forceinline__ int xcd_tile_id() {
+  const int bid = blockIdx.x, nb = gridDim.x, xcd = bid & 7, q = nb >> 3, r = nb & 7;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+}
+
+
+// 3x3 / stride 1 / pad 1 w4a8 convolutions on the slab kernel (conv_slab.hip): true when the launch was taken
+bool launch_conv_slab(tfmq_handle h, ConvP& p, hipStream_t st, bool forced);

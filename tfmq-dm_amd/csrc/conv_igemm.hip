@@ -21,57 +21,12 @@
 //                multiplied, counted vmcnt + one raw s_barrier per K-step, no staging registers, no ds_write,
 //                ~20 VALU instructions per K-step.
 //   k_conv_igemm (f16 layers; w4a8 shapes the DMA loop does not take): register-prefetched, double-buffered.
-#include "common.hpp"
+#include "conv_common.hpp"
 #include <type_traits>
 #include <cstdlib>
 #ifdef TFMQ_PHASE_TIMERS
 #include <cstdio>
 #endif
-
-typedef int v4i __attribute__((ext_vector_type(4)));
-typedef int v16i __attribute__((ext_vector_type(16)));
-typedef float v16f __attribute__((ext_vector_type(16)));
-typedef _Float16 v8h __attribute__((ext_vector_type(8)));
-
-struct ConvP {
-  tfmq_conv_desc d;
-  int M;        // B*Ho*Wo
-  int chunks;   // K-steps per tap
-  int nsteps;   // KH*KW*chunks
-  int Ktot;     // KH*KW*Cin
-  int cin_pad;  // f16 path: padded Cin of the weight layout
-  int Hv, Wv;   // virtual input size (2H,2W when up2x)
-  int tiles_n;
-  int cout_pad;                    // w4a8: rows of the expanded weight operand (multiple of 32)
-  const unsigned char* pad_table;  // 256 x 64 B, row v = byte v (tfmq_ctx::pad_table)
-#ifdef TFMQ_PHASE_TIMERS
-  unsigned long long* dbg;         // [blocks][4] shader-clock stamps: start, loop start, loop end, end
-#endif
-};
-
-// Diagnostics build (TFMQ_EXTRA_HIPCC_FLAGS=-DTFMQ_PHASE_TIMERS python tfmq-dm_amd/build.py): every w4a8 DMA launch
-// is followed by a device sync and prints the mean cycles a block spends in prologue / K loop / epilogue.
-#ifdef TFMQ_PHASE_TIMERS
-#define TFMQ_MARK(i) do { if (p.dbg && threadIdx.x == 0) p.dbg[blockIdx.x * 4 + (i)] = clock64(); } while (0)
-#else
-#define TFMQ_MARK(i) do { } while (0)
-#endif
-
-// Workgroup barrier that only waits for LDS traffic.  __syncthreads() also drains vmcnt(0), i.e. it would wait for
-// the global prefetch loads of the NEXT K-steps at every barrier.
-#define LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
-
-__device__ __forceinline__ int swz(int row, int slot) { return row * 64 + ((slot ^ ((row >> 2) & 3)) << 4); }
-
-// One LDS-DMA wave instruction: lane l moves 16 bytes from its own global pointer to LDS byte lds_dst + 16*l
-// (the destination is wave-uniform base + lane*16; M0 carries the base and is restored afterwards).
-__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
-  unsigned keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep)
-               : "v"(gsrc), "s"(lds_dst)
-               : "memory");
-}
 
 template <int BM, int BN>
 __host__ __device__ constexpr int epi_lds_bytes() {
@@ -86,6 +41,16 @@ __host__ __device__ constexpr int epi_lds_bytes() {
 // (per-lane 4-byte strided accesses made this phase 2.5x slower than the MFMA loop).  The same
 // pass produces the per-channel sum / sum-of-squares of every SEG-row segment for the GroupNorm
 // that consumes this tensor, so that GroupNorm never has to re-read it for statistics.
+// four consecutive channels of the residual tensor: fp32, or fp16 when it belongs to the fp16 activation stream
+__device__ __forceinline__ float4 load_res4(const tfmq_conv_desc& d, int m, int n) {
+  if (d.res_f16) {
+    const uint2 u = *reinterpret_cast<const uint2*>(reinterpret_cast<const __half*>(d.residual) + static_cast<size_t>(m) * d.Cout + n);
+    const float2 lo = __half22float2(*reinterpret_cast<const __half2*>(&u.x)), hi = __half22float2(*reinterpret_cast<const __half2*>(&u.y));
+    return make_float4(lo.x, lo.y, hi.x, hi.y);
+  }
+  return *reinterpret_cast<const float4*>(d.residual + static_cast<size_t>(m) * d.Cout + n);
+}
+
 template <bool INT8, int WAVES_M, int WAVES_N, int WM_TILES, int WN_TILES, bool RES_PRE = false, typename ACC>
 __device__ __forceinline__ void conv_epilogue(const ConvP& p, unsigned char* lds, ACC (&acc)[WM_TILES][WN_TILES],
                                               int m0, int n0, float2 aqp, int za) {
@@ -145,8 +110,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, unsigned char* lds
 #pragma unroll
       for (int k = 0; k < RPT; ++k) {
         const int m = m0 + pass * PR + tr * RPT + k, n = n0 + c4;
-        rpre[k] = (m < p.M && n < d.Cout) ? *reinterpret_cast<const float4*>(d.residual + static_cast<size_t>(m) * d.Cout + n)
-                                          : make_float4(0.f, 0.f, 0.f, 0.f);
+        rpre[k] = (m < p.M && n < d.Cout) ? load_res4(d, m, n) : make_float4(0.f, 0.f, 0.f, 0.f);
       }
     }
     __syncthreads();  // previous pass fully consumed (also orders the main loop's LDS reads before the overwrite)
@@ -230,7 +194,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, unsigned char* lds
       }
       continue;
     }
-    if (d.out_mode == TFMQ_OUT_F16) {
+    if (d.out_mode == TFMQ_OUT_F16 && !vec_ok) {
       __half* yh = reinterpret_cast<__half*>(d.y);
 #pragma unroll
       for (int k = 0; k < RPT; ++k) {
@@ -279,10 +243,16 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, unsigned char* lds
         if (d.residual) {
           float4 a;
           if constexpr (RES_PRE) a = rpre[k];
-          else a = *reinterpret_cast<const float4*>(d.residual + static_cast<size_t>(m) * d.Cout + n);
+          else a = load_res4(d, m, n);
           v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
         }
-        if (q8) {     // the only consumer is the next QuantLayer's activation quantizer: write its bins
+        if (d.out_mode == TFMQ_OUT_F16) {      // fp16 activation stream: the statistics below still see the fp32 values
+          const __half2 lo = __floats2half2_rn(v.x, v.y), hi = __floats2half2_rn(v.z, v.w);
+          uint2 u;
+          u.x = *reinterpret_cast<const unsigned*>(&lo);
+          u.y = *reinterpret_cast<const unsigned*>(&hi);
+          *reinterpret_cast<uint2*>(reinterpret_cast<__half*>(d.y) + static_cast<size_t>(m) * d.ldy + d.y_coff + n) = u;
+        } else if (q8) {     // the only consumer is the next QuantLayer's activation quantizer: write its bins
           char4 q;
           q.x = static_cast<signed char>(static_cast<int>(quant_index_f(v.x, oqp.x, oqp.y, 255.0f)) - 128);
           q.y = static_cast<signed char>(static_cast<int>(quant_index_f(v.y, oqp.x, oqp.y, 255.0f)) - 128);
@@ -352,14 +322,6 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, unsigned char* lds
       }
     }
   }
-}
-
-// XCD-aware tile order (T1): the dispatcher places block b on XCD b % 8; give each XCD a contiguous
-// range of tiles so the 3x3 taps / neighbouring rows of one image hit that XCD's private L2.
-// Bijective for any grid size; placement is a speed matter only.
-__device__ __forceinline__ int xcd_tile_id() {
-  const int bid = blockIdx.x, nb = gridDim.x, xcd = bid & 7, q = nb >> 3, r = nb & 7;
-  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
 }
 
 // ================================================================================================
@@ -845,9 +807,9 @@ static int launch_conv(tfmq_handle h, const tfmq_conv_desc* dd, void* stream) {
   TFMQ_CHECK_ARG(h, d.B > 0 && d.H > 0 && d.W > 0 && d.Cin > 0 && d.Cout > 0 && d.KH > 0 && d.KW > 0 && d.stride > 0,
                  "conv: bad geometry");
   TFMQ_CHECK_ARG(h, d.Ho > 0 && d.Wo > 0 && d.ldy >= d.Cout + d.y_coff, "conv: bad output geometry");
-  TFMQ_CHECK_ARG(h, d.out_mode == TFMQ_OUT_F32 || d.out_mode == TFMQ_OUT_Q8 || (!d.rowadd && !d.residual),
-                 "conv: rowadd / residual need out_mode F32 or Q8");
-  TFMQ_CHECK_ARG(h, d.out_mode == TFMQ_OUT_F32 || !d.stats, "conv: stats need out_mode F32");
+  TFMQ_CHECK_ARG(h, d.out_mode == TFMQ_OUT_F32 || d.out_mode == TFMQ_OUT_Q8 || d.out_mode == TFMQ_OUT_F16 || (!d.rowadd && !d.residual),
+                 "conv: rowadd / residual need out_mode F32, F16 or Q8");
+  TFMQ_CHECK_ARG(h, d.out_mode == TFMQ_OUT_F32 || d.out_mode == TFMQ_OUT_F16 || !d.stats, "conv: stats need out_mode F32 or F16");
   TFMQ_CHECK_ARG(h, d.out_mode != TFMQ_OUT_Q8 || (d.yq && d.oq.qtable && d.Cout % 4 == 0 && (!d.rowadd || d.rowadd_ld % 4 == 0)),
                  "conv: Q8 output needs yq, oq and Cout % 4 == 0");
   TFMQ_CHECK_ARG(h, d.out_mode != TFMQ_OUT_GEGLU_Q8 ||
@@ -905,6 +867,18 @@ static int launch_conv(tfmq_handle h, const tfmq_conv_desc* dd, void* stream) {
     // with the fp32 residual epilogue lose more from 2 instead of 3 resident workgroups than the K loop gains)
     big = big_ok && !small && d.out_mode == TFMQ_OUT_F16 && tiles128 >= 4L * h->cu_count;
   }
+  if constexpr (INT8) {
+    // 3x3 / stride 1 / pad 1 on a grid that fills the chip: the slab kernel (conv_slab.hip), unless the caller pinned
+    // another tile shape
+    if ((d.tile == TFMQ_TILE_AUTO || d.tile == TFMQ_TILE_SLAB) && dma8 &&
+        launch_conv_slab(h, p, as_stream(stream), d.tile == TFMQ_TILE_SLAB)) {
+      TFMQ_LAUNCH_CHECK(h);
+      return TFMQ_OK;
+    }
+  }
+  TFMQ_CHECK_ARG(h, (!d.res_f16 && (d.out_mode != TFMQ_OUT_F16 || (!d.rowadd && !d.residual && !d.stats))) ||
+                        (((d.Cout | d.ldy | d.y_coff) & 3) == 0 && (!d.rowadd || (d.rowadd_ld & 3) == 0)),
+                 "conv: fp16 residual / fp16 output with rowadd, residual or stats needs Cout, ldy, y_coff, rowadd_ld % 4 == 0");
   const int BM = big ? 256 : (small ? 64 : 128), BN = narrow ? 32 : ((small || half_n) ? 64 : 128);
   p.tiles_n = (d.Cout + BN - 1) / BN;
   const int tiles_m = (p.M + BM - 1) / BM;
@@ -921,7 +895,7 @@ static int launch_conv(tfmq_handle h, const tfmq_conv_desc* dd, void* stream) {
       p.dbg = grid.x <= (1u << 20) ? dbuf : nullptr;
 #endif
       // residual rows prefetched ahead of the staging (see conv_epilogue): the epilogue's vector path only
-      const bool res_pre = d.residual && (d.out_mode == TFMQ_OUT_F32 || d.out_mode == TFMQ_OUT_Q8) &&
+      const bool res_pre = d.residual && (d.out_mode == TFMQ_OUT_F32 || d.out_mode == TFMQ_OUT_Q8 || d.out_mode == TFMQ_OUT_F16) &&
                            ((d.Cout | d.ldy | d.y_coff) & 3) == 0 && (!d.rowadd || (d.rowadd_ld & 3) == 0);
       if (narrow) hipLaunchKernelGGL((k_conv_dma<false, 4, 1, 1, 1>), grid, dim3(256), 0, st, p);
       else if (half_n && res_pre) hipLaunchKernelGGL((k_conv_dma<false, 2, 2, 2, 1, true>), grid, dim3(256), 0, st, p);

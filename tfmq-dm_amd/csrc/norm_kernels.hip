@@ -23,6 +23,19 @@ template <int V>
 __device__ __forceinline__ void gn_load(const GnP& p, size_t pix, int c, float (&v)[V]) {
   const tfmq_gn_desc& d = p.d;
   // V consecutive channels never straddle the concat boundary (C1 % V == 0 is checked on the host)
+  if (d.x_f16) {       // fp16 activation stream: x1 / x2 are fp16 buffers
+    const __half* sh = c < d.C1 ? reinterpret_cast<const __half*>(d.x1) + pix * d.C1 + c
+                                : reinterpret_cast<const __half*>(d.x2) + pix * d.C2 + (c - d.C1);
+    if constexpr (V == 4) {
+      const uint2 u = *reinterpret_cast<const uint2*>(sh);
+      const float2 lo = __half22float2(*reinterpret_cast<const __half2*>(&u.x)), hi = __half22float2(*reinterpret_cast<const __half2*>(&u.y));
+      v[0] = lo.x; v[1] = lo.y; v[2] = hi.x; v[3] = hi.y;
+    } else {
+#pragma unroll
+      for (int i = 0; i < V; ++i) v[i] = __half2float(sh[i]);
+    }
+    return;
+  }
   const float* src = c < d.C1 ? d.x1 + pix * d.C1 + c : d.x2 + pix * d.C2 + (c - d.C1);
   if constexpr (V == 4) {
     const float4 t = *reinterpret_cast<const float4*>(src);
@@ -276,16 +289,26 @@ __global__ __launch_bounds__(256) void k_gn_apply(tfmq_gn_desc d, const float* _
     const float* src = c < d.C1 ? d.x1 + static_cast<size_t>(pix) * d.C1 + c : d.x2 + static_cast<size_t>(pix) * d.C2 + (c - d.C1);
     float v[V], a[V], bb[V], y[V];
     if constexpr (V == 4) {
-      const float4 t = *reinterpret_cast<const float4*>(src);
       const float4 ta = *reinterpret_cast<const float4*>(A + static_cast<size_t>(b) * Cc + c);
       const float4 tb = *reinterpret_cast<const float4*>(Bb + static_cast<size_t>(b) * Cc + c);
-      v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+      if (d.x_f16) {
+        const __half* sh = c < d.C1 ? reinterpret_cast<const __half*>(d.x1) + static_cast<size_t>(pix) * d.C1 + c
+                                    : reinterpret_cast<const __half*>(d.x2) + static_cast<size_t>(pix) * d.C2 + (c - d.C1);
+        const uint2 u = *reinterpret_cast<const uint2*>(sh);
+        const float2 lo = __half22float2(*reinterpret_cast<const __half2*>(&u.x)), hi = __half22float2(*reinterpret_cast<const __half2*>(&u.y));
+        v[0] = lo.x; v[1] = lo.y; v[2] = hi.x; v[3] = hi.y;
+      } else {
+        const float4 t = *reinterpret_cast<const float4*>(src);
+        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+      }
       a[0] = ta.x; a[1] = ta.y; a[2] = ta.z; a[3] = ta.w;
       bb[0] = tb.x; bb[1] = tb.y; bb[2] = tb.z; bb[3] = tb.w;
     } else {
 #pragma unroll
       for (int q = 0; q < V; ++q) {
-        v[q] = src[q];
+        v[q] = d.x_f16 ? __half2float((c < d.C1 ? reinterpret_cast<const __half*>(d.x1) + static_cast<size_t>(pix) * d.C1 + c
+                                                 : reinterpret_cast<const __half*>(d.x2) + static_cast<size_t>(pix) * d.C2 + (c - d.C1))[q])
+                       : src[q];
         a[q] = A[static_cast<size_t>(b) * Cc + c + q];
         bb[q] = Bb[static_cast<size_t>(b) * Cc + c + q];
       }

@@ -43,6 +43,39 @@ extern "C" int tfmq_quantize_act(tfmq_handle h, const float* x, int8_t* q, size_
   return TFMQ_OK;
 }
 
+// the same on a tensor of the fp16 activation stream (n % 4 == 0)
+__global__ __launch_bounds__(256) void k_quantize_act_h(const __half* __restrict__ x, int8_t* __restrict__ q, size_t n,
+                                                        tfmq_qsel qs, float lmax) {
+  const float2 p = load_qparam(qs);
+  const size_t n4 = n >> 2;
+  const size_t stride = static_cast<size_t>(gridDim.x) * blockDim.x;
+  const uint2* x4 = reinterpret_cast<const uint2*>(x);
+  char4* q4 = reinterpret_cast<char4*>(q);
+  for (size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    const uint2 u = x4[i];
+    const float2 lo = __half22float2(*reinterpret_cast<const __half2*>(&u.x)), hi = __half22float2(*reinterpret_cast<const __half2*>(&u.y));
+    char4 o;
+    o.x = static_cast<signed char>(static_cast<int>(quant_index_f(lo.x, p.x, p.y, lmax)) - 128);
+    o.y = static_cast<signed char>(static_cast<int>(quant_index_f(lo.y, p.x, p.y, lmax)) - 128);
+    o.z = static_cast<signed char>(static_cast<int>(quant_index_f(hi.x, p.x, p.y, lmax)) - 128);
+    o.w = static_cast<signed char>(static_cast<int>(quant_index_f(hi.y, p.x, p.y, lmax)) - 128);
+    q4[i] = o;
+  }
+}
+
+extern "C" int tfmq_quantize_act_h(tfmq_handle h, const uint16_t* x, int8_t* q, size_t n, tfmq_qsel qs, int level,
+                                   void* stream) {
+  TFMQ_CHECK_ARG(h, h && x && q && qs.qtable, "quantize_act_h: null pointer");
+  TFMQ_CHECK_ARG(h, level >= 2 && level <= 256 && n % 4 == 0, "quantize_act_h: level must be in [2,256], n a multiple of 4");
+  if (n == 0) return TFMQ_OK;
+  int blocks = ceil_div(static_cast<long>(n / 4), 256);
+  if (blocks > h->cu_count * 8) blocks = h->cu_count * 8;
+  hipLaunchKernelGGL(k_quantize_act_h, dim3(blocks), dim3(256), 0, as_stream(stream), reinterpret_cast<const __half*>(x), q, n, qs,
+                     static_cast<float>(level - 1));
+  TFMQ_LAUNCH_CHECK(h);
+  return TFMQ_OK;
+}
+
 // fake-quant with per-row (or per-tensor, rows==1) parameters; optional index output
 __global__ __launch_bounds__(256) void k_fake_quant(const float* __restrict__ x, float* __restrict__ y,
                                                     uint8_t* __restrict__ idx, size_t rows, size_t cols,

@@ -6,7 +6,7 @@
 #include "common.hpp"
 
 // rows of up to 64*4*MAXV floats (MAXV float4 per lane): 5 -> C <= 1280
-template <int MAXV>
+template <int MAXV, bool XH = false>
 __global__ __launch_bounds__(256) void k_layernorm(const float* __restrict__ x, const float* __restrict__ gamma,
                                                    const float* __restrict__ beta, float eps, long rows, int Cc,
                                                    tfmq_qsel aq, int8_t* __restrict__ yq, float* __restrict__ yf) {
@@ -15,12 +15,22 @@ __global__ __launch_bounds__(256) void k_layernorm(const float* __restrict__ x, 
   if (row >= rows) return;
   const int c4 = Cc / 4;
   const float4* xr = reinterpret_cast<const float4*>(x + row * Cc);
+  const uint2* xh = reinterpret_cast<const uint2*>(reinterpret_cast<const __half*>(x) + row * Cc);   // XH: fp16 row
   float4 v[MAXV];
   float s = 0.0f;
 #pragma unroll
   for (int i = 0; i < MAXV; ++i) {
     const int idx = lane + i * 64;
-    v[i] = idx < c4 ? xr[idx] : make_float4(0.f, 0.f, 0.f, 0.f);
+    if constexpr (XH) {
+      v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (idx < c4) {
+        const uint2 u = xh[idx];
+        const float2 lo = __half22float2(*reinterpret_cast<const __half2*>(&u.x)), hi = __half22float2(*reinterpret_cast<const __half2*>(&u.y));
+        v[i] = make_float4(lo.x, lo.y, hi.x, hi.y);
+      }
+    } else {
+      v[i] = idx < c4 ? xr[idx] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
     s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
   }
   s = wave_reduce_sum(s);
@@ -70,6 +80,20 @@ extern "C" int tfmq_layernorm(tfmq_handle h, const float* x, const float* gamma,
   if (C <= 64 * 4 * 2) hipLaunchKernelGGL(k_layernorm<2>, grid, dim3(256), 0, as_stream(stream), x, gamma, beta, eps, rows, C, aq, yq, yf);
   else if (C <= 64 * 4 * 5) hipLaunchKernelGGL(k_layernorm<5>, grid, dim3(256), 0, as_stream(stream), x, gamma, beta, eps, rows, C, aq, yq, yf);
   else hipLaunchKernelGGL(k_layernorm<8>, grid, dim3(256), 0, as_stream(stream), x, gamma, beta, eps, rows, C, aq, yq, yf);
+  TFMQ_LAUNCH_CHECK(h);
+  return TFMQ_OK;
+}
+
+extern "C" int tfmq_layernorm_h(tfmq_handle h, const uint16_t* x, const float* gamma, const float* beta, float eps, long rows,
+                                int C, tfmq_qsel aq, int8_t* yq, float* yf, void* stream) {
+  TFMQ_CHECK_ARG(h, h && x && gamma && beta && rows > 0 && C > 0, "layernorm_h: bad argument");
+  TFMQ_CHECK_ARG(h, (aq.qtable && yq) || yf, "layernorm_h: no output requested");
+  TFMQ_CHECK_ARG(h, C % 4 == 0 && C <= 64 * 4 * 8, "layernorm_h: C must be a multiple of 4 and <= 2048");
+  dim3 grid(static_cast<unsigned>((rows + 3) / 4));
+  const float* xf = reinterpret_cast<const float*>(x);
+  if (C <= 64 * 4 * 2) hipLaunchKernelGGL((k_layernorm<2, true>), grid, dim3(256), 0, as_stream(stream), xf, gamma, beta, eps, rows, C, aq, yq, yf);
+  else if (C <= 64 * 4 * 5) hipLaunchKernelGGL((k_layernorm<5, true>), grid, dim3(256), 0, as_stream(stream), xf, gamma, beta, eps, rows, C, aq, yq, yf);
+  else hipLaunchKernelGGL((k_layernorm<8, true>), grid, dim3(256), 0, as_stream(stream), xf, gamma, beta, eps, rows, C, aq, yq, yf);
   TFMQ_LAUNCH_CHECK(h);
   return TFMQ_OK;
 }

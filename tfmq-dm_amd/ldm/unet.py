@@ -149,7 +149,7 @@ class UNetModel(nn.Module):
 
     def __init__(self, image_size, in_channels, model_channels, out_channels, num_res_blocks, attention_resolutions,
                  dropout=0, channel_mult=(1, 2, 4, 8), conv_resample=True, dims=2, num_classes=None, use_checkpoint=False,
-                 num_heads=-1, num_head_channels=-1, use_spatial_transformer=True, transformer_depth=1, context_dim=None,
+                 num_heads=-1, num_head_channels=-1, use_spatial_transformer=False, transformer_depth=1, context_dim=None,
                  legacy=True, **unused):
         super().__init__()
         if use_spatial_transformer and context_dim is None:

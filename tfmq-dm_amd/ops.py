@@ -155,6 +155,11 @@ def qsel(qtable: Optional[torch.Tensor], qid: int = 0, step: Optional[torch.Tens
 # ------------------------------------------------------------------------------ K1 / K2 / K3
 def quantize_act(x: torch.Tensor, qs: QSel, level: int = 256, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     d = _dev(x)
+    if x.dtype == torch.float16:       # a tensor of the fp16 activation stream
+        _chk(x, torch.float16, "x")
+        q = out if out is not None else _alloc(x.shape, dtype=torch.int8, device=x.device)
+        handle(d).call("quantize_act_h", _p(x), _p(q), x.numel(), qs, level, _stream(d))
+        return q
     _chk(x, torch.float32, "x")
     q = out if out is not None else _alloc(x.shape, dtype=torch.int8, device=x.device)
     handle(d).call("quantize_act", _p(x), _p(q), x.numel(), qs, level, _stream(d))
@@ -329,7 +334,7 @@ def _attach_stats(dsc, y: torch.Tensor, B: int, hw: int, cout: int, want_stats: 
 # the launch stream; a conv is idempotent, so re-running it is harmless) and later launches -- in particular the ones
 # captured into the sampler's hipGraph -- use the winner.  The result does not depend on the tile shape.
 _AUTOTUNE = None      # None = off, else {shape key: tile id}
-_TILE_NAMES = {1: "128x128", 2: "64x64", 3: "256x128", 4: "128x64"}
+_TILE_NAMES = {1: "128x128", 2: "64x64", 3: "256x128", 4: "128x64", 5: "slab 256xN (3x3)"}
 
 
 def set_conv_autotune(cache) -> None:
@@ -361,6 +366,22 @@ def conv_autotune_report():
     return {} if _AUTOTUNE is None else {k: _TILE_NAMES.get(v, "auto") for k, v in _AUTOTUNE.items()}
 
 
+def slab_ok(dsc) -> bool:
+    """Launch geometry the 3x3 slab kernel (csrc/conv_slab.hip, TFMQ_TILE_SLAB) takes: 3x3 / stride 1 / pad 1, Cin % 64 == 0,
+    256-pixel tiles made of whole image rows (or whole images), a slab of at most 512 pixel rows."""
+    if not (dsc.KH == 3 and dsc.KW == 3 and dsc.stride == 1 and not dsc.up2x and dsc.pad_t == 1 and dsc.pad_l == 1
+            and dsc.Cin % 64 == 0 and dsc.Ho == dsc.H and dsc.Wo == dsc.W and not dsc.yt and dsc.out_mode in (0, 1, 3)):
+        return False
+    hw = dsc.H * dsc.W
+    if hw % 256 == 0 and 256 % dsc.W == 0:
+        rows = (256 // dsc.W + 2) * (dsc.W + 2)
+    elif 256 % hw == 0:
+        rows = (256 // hw) * (dsc.H + 2) * (dsc.W + 2)
+    else:
+        return False
+    return rows <= 512
+
+
 def _tune_conv(h, name, kind, d, dsc):
     key = (kind, dsc.B, dsc.H, dsc.W, dsc.Cin, dsc.Cout, dsc.KH, dsc.stride, dsc.up2x, dsc.out_mode, bool(dsc.residual),
            bool(dsc.stats), dsc.stats_seg, dsc.x_f16, bool(dsc.yt))
@@ -374,6 +395,8 @@ def _tune_conv(h, name, kind, d, dsc):
         cands.append(4)
         if dsc.stride == 1 and not dsc.up2x:
             cands.append(3)
+    if kind == "w4a8" and slab_ok(dsc):
+        cands.append(5)
     best, best_ms = 0, None
     e0, e1 = C.c_int(), C.c_int()
     h.call("event_create", C.byref(e0))
@@ -495,9 +518,15 @@ def conv2d_w4a8(xq: torch.Tensor, pw: PackedW4, aq: QSel, stride: int = 1, pad: 
             raise TfmqError("conv2d_w4a8: t_col0 needs out_f16, t_col0 % 128 == 0 and Ho*Wo % 4 == 0")
         yt = _alloc(B, pw.cout - t_col0, Ho * Wo, dtype=torch.float16, device=xq.device)
         dsc.yt, dsc.t_col0 = yt.data_ptr(), int(t_col0)
-    _attach_stats(dsc, y, B, Ho * Wo, pw.cout, want_stats and y_coff == 0 and dsc.out_mode == 0)
-    # algorithmic HBM bytes: int8 input once + int8 weight operand + output (+ fp32 residual)
-    nbytes = B * H * W * cin + pw.cout * pw.kh * pw.kw * cin + B * Ho * Wo * pw.cout * (osz + (4.0 if residual is not None else 0.0))
+    _attach_stats(dsc, y, B, Ho * Wo, pw.cout, want_stats and y_coff == 0 and dsc.out_mode in (0, 1) and yt is None)
+    rsz = 0.0
+    if residual is not None:
+        if residual.dtype not in (torch.float32, torch.float16) or not residual.is_contiguous():
+            raise TfmqError("conv2d_w4a8: residual must be contiguous fp32 or fp16")
+        dsc.res_f16 = int(residual.dtype == torch.float16)
+        rsz = 2.0 if dsc.res_f16 else 4.0
+    # algorithmic HBM bytes: int8 input once + int8 weight operand + output (+ residual)
+    nbytes = B * H * W * cin + pw.cout * pw.kh * pw.kw * cin + B * Ho * Wo * pw.cout * (osz + rsz)
     _profiled_conv("conv2d_w4a8", "w4a8", d, dsc, 2.0 * B * Ho * Wo * pw.cout * pw.kh * pw.kw * cin, nbytes)
     return y if yt is None else (y, yt)
 
@@ -519,8 +548,6 @@ def conv2d_f16(x: torch.Tensor, pf: PackedF16, stride: int = 1, pad: Tuple[int, 
     if cin != pf.cin:
         raise TfmqError(f"conv2d_f16: Cin mismatch {cin} vs {pf.cin}")
     Ho, Wo = out_hw(H, W, pf.kh, pf.kw, stride, pad[0], pad[1], pad[2], pad[3], up2x)
-    if out_f16 and (rowadd is not None or residual is not None or want_stats):
-        raise TfmqError("conv2d_f16: the fp16 output mode takes no rowadd / residual / stats option")
     y = out if out is not None else _alloc(B, Ho, Wo, pf.cout, dtype=torch.float16 if out_f16 else torch.float32, device=x.device)
     _chk(y, torch.float16 if out_f16 else torch.float32, "out")
     dsc = _conv_desc(x, B, H, W, cin, pf.cout, pf.kh, pf.kw, stride, pad[0], pad[1], Ho, Wo, up2x, y, y.shape[-1], y_coff,
@@ -540,8 +567,15 @@ def conv2d_f16(x: torch.Tensor, pf: PackedF16, stride: int = 1, pad: Tuple[int, 
     dsc.bias = None if pf.bias is None else pf.bias.data_ptr()
     dsc.aq = QSel(None, None, 0, 0)
     dsc.x_f16 = int(x.dtype == torch.float16)
-    _attach_stats(dsc, y, B, Ho * Wo, pf.cout, want_stats and y_coff == 0)
-    nbytes = (2.0 if x.dtype == torch.float16 else 4.0) * B * H * W * cin + 2.0 * pf.cout * pf.kh * pf.kw * cin + 4.0 * B * Ho * Wo * pf.cout * (2 if residual is not None else 1)
+    _attach_stats(dsc, y, B, Ho * Wo, pf.cout, want_stats and y_coff == 0 and yt is None)
+    rsz = 0.0
+    if residual is not None:
+        if residual.dtype not in (torch.float32, torch.float16) or not residual.is_contiguous():
+            raise TfmqError("conv2d_f16: residual must be contiguous fp32 or fp16")
+        dsc.res_f16 = int(residual.dtype == torch.float16)
+        rsz = 2.0 if dsc.res_f16 else 4.0
+    nbytes = ((2.0 if x.dtype == torch.float16 else 4.0) * B * H * W * cin + 2.0 * pf.cout * pf.kh * pf.kw * cin
+              + B * Ho * Wo * pf.cout * ((2.0 if out_f16 else 4.0) + rsz))
     _profiled_conv("conv2d_f16", "f16", d, dsc, 2.0 * B * Ho * Wo * pf.cout * pf.kh * pf.kw * cin, nbytes)
     return y if yt is None else (y, yt)
 
@@ -594,7 +628,10 @@ def groupnorm(x1: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: fl
     """x1 (and optional x2, concatenated on channels): fp32 NHWC.  Returns (yq int8 | None, yf | None, xcat | None).
     half_out: yf / xcat are written as fp16 (operands of conv2d_f16's fp16-input path, which rounds to fp16 anyway)."""
     d = _dev(x1)
-    _chk(x1, torch.float32, "x1")
+    if x1.dtype not in (torch.float32, torch.float16) or not x1.is_contiguous():
+        raise TfmqError("groupnorm: x1 must be contiguous fp32 or fp16")
+    if x2 is not None and (x2.dtype != x1.dtype or not x2.is_contiguous()):
+        raise TfmqError("groupnorm: x2 must have x1's dtype (one flag covers both halves of the virtual concat)")
     B = x1.shape[0]
     C1 = x1.shape[-1]
     HW = x1.numel() // (B * C1)
@@ -604,6 +641,7 @@ def groupnorm(x1: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: fl
     g.B, g.HW, g.C1, g.C2 = B, HW, C1, C2
     g.x1, g.x2 = x1.data_ptr(), (None if x2 is None else x2.data_ptr())
     g.gamma, g.beta, g.eps, g.groups, g.silu = gamma.data_ptr(), beta.data_ptr(), float(eps), groups, int(silu)
+    g.x_f16 = int(x1.dtype == torch.float16)
     yq = yf = xcat = None
     if aq is not None and aq.qtable:
         g.aq = aq
@@ -635,14 +673,15 @@ def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: flo
               want_f32: bool = False):
     """x: fp32 [..., C] tokens.  Returns (yq int8 | None, yf fp32 | None)."""
     d = _dev(x)
-    _chk(x, torch.float32, "x")
+    xh = x.dtype == torch.float16          # a tensor of the fp16 activation stream
+    _chk(x, torch.float16 if xh else torch.float32, "x")
     Cc = x.shape[-1]
     rows = x.numel() // Cc
     quant = aq is not None and bool(aq.qtable)
     yq = _alloc(x.shape, dtype=torch.int8, device=x.device) if quant else None
-    yf = _alloc_like(x) if (want_f32 or not quant) else None
-    handle(d).call("layernorm", _p(x), _p(gamma), _p(beta), float(eps), rows, Cc, aq if quant else QSel(None, None, 0, 0),
-                   _p(yq), _p(yf), _stream(d))
+    yf = _alloc(x.shape, dtype=torch.float32, device=x.device) if (want_f32 or not quant) else None
+    handle(d).call("layernorm_h" if xh else "layernorm", _p(x), _p(gamma), _p(beta), float(eps), rows, Cc,
+                   aq if quant else QSel(None, None, 0, 0), _p(yq), _p(yf), _stream(d))
     return yq, yf
 
 

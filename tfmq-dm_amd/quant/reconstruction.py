@@ -57,14 +57,22 @@ def _commit(layer: QuantLayer, ada: R.AdaLayer):
     q._version_ += 1
 
 
+LOSS_TRACE = None     # tests: {"counts": (...), "rows": [], "unit": 0} -> rows of (unit index, count, rec, round) at those counts
+
+
 def _run(unit: R._Unit, n: int, batch_size: int, iters: int, loss_func: LossFunc, device, rank0=True):
     for _ in range(iters):
         idx = torch.randperm(n)[:batch_size].to(device)       # same host RNG stream as the reference
         b, active = loss_func.tick()
         rec, rl = unit.iterate(idx)
+        if LOSS_TRACE is not None and loss_func.count in LOSS_TRACE["counts"]:
+            tot, r, q = unit.losses(rec, rl)
+            LOSS_TRACE["rows"].append((LOSS_TRACE["unit"], loss_func.count, r, q))
         if loss_func.count % 2000 == 0:
             tot, r, q = unit.losses(rec, rl)
             loss_func.log(tot, r, q, b, rank0)
+    if LOSS_TRACE is not None:
+        LOSS_TRACE["unit"] += 1
 
 
 def layer_reconstruction(model, layer: QuantLayer, cali_data: Tuple[torch.Tensor], batch_size: int = 128,
