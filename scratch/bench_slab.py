@@ -18,7 +18,10 @@ for (H, cin, cout, res) in shapes:
     w = (torch.randn(cout, cin, 3, 3, generator=gen) * 0.02).to(dev)
     qp = ops.minmax_to_qparam(ops.minmax(w.reshape(cout, -1).contiguous(), cout), 16)
     pw = ops.pack_w4(w, qp[:, 0].contiguous(), qp[:, 1].contiguous(), None, torch.zeros(cout, device=dev))
+    F16 = os.environ.get("F16", "1") == "1"          # fp16 activation stream (the sampling path) or the fp32 stream
     r = torch.randn(B, H, H, cout, device=dev) if res else None
+    if r is not None and F16:
+        r = r.half()
     ra = torch.randn(B, cout, device=dev)
     nops = 2.0 * B * H * H * cout * 9 * cin
     line = f"{B}x{H}x{H} {cin}->{cout} res={int(res)}:"
@@ -28,12 +31,12 @@ for (H, cin, cout, res) in shapes:
         ops.set_conv_autotune({})
         ops._tune_conv = lambda h, name, kind, d, dsc, t=tile: t
         try:
-            y = ops.conv2d_w4a8(xq, pw, sel, pad=(1, 1, 1, 1), residual=r, rowadd=ra, want_stats=True)
+            y = ops.conv2d_w4a8(xq, pw, sel, pad=(1, 1, 1, 1), residual=r, rowadd=ra, want_stats=True, out_f16=F16)
             torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(5):
-                y = ops.conv2d_w4a8(xq, pw, sel, pad=(1, 1, 1, 1), residual=r, rowadd=ra, want_stats=True)
+                y = ops.conv2d_w4a8(xq, pw, sel, pad=(1, 1, 1, 1), residual=r, rowadd=ra, want_stats=True, out_f16=F16)
             e1.record()
             torch.cuda.synchronize()
             us = e0.elapsed_time(e1) / 5 * 1e3

@@ -106,7 +106,11 @@ def test_cin_style_engine_and_cfg_ddim(golden):
     r = rel_l2(eps, T(g["eps_w4a8"]))
     print("cin-style w4a8 eps rel-L2:", r)
     assert r <= 3.5e-2
-    assert torch.equal(nchw(eng.forward(nhwc(x), t.to(DEV), ctx.to(DEV), taps={})), eps)       # fused == un-fused data path
+    eng.stream_f16 = False
+    eps32 = nchw(eng.forward(nhwc(x), t.to(DEV), ctx.to(DEV)))
+    eng.stream_f16 = True
+    assert torch.equal(nchw(eng.forward(nhwc(x), t.to(DEV), ctx.to(DEV), taps={})), eps32)     # fused == un-fused data path
+    assert rel_l2(eps, eps32) <= 3e-2                                                          # fp16 vs fp32 activation stream
     ac = alphas_cumprod_linear(0.0015, 0.0195)
     assert np.array_equal(ac.numpy(), g["alphas_cumprod"])
     sampler = GraphLatentDdimSampler(eng, 4, 2, (3, 8, 8), (1, 64), scale=3.0, alphas_cumprod=ac).capture()
@@ -400,3 +404,21 @@ def test_generate_cali_data_ddim_and_sample_fid_vs_reference(golden):
     with Replay(tape(g, "fid", [0])):
         model, imgs2 = r.sample(m)
     assert model is m and np.array_equal(imgs2, imgs)
+
+
+def test_unsupported_bit_widths_fail_loudly(golden):
+    """--wq 8 (a README recipe of the reference) is not built on the device path: the engine must refuse it instead of
+    packing 8-bit grids into nibbles (the bit width used to be dropped silently)."""
+    import tfmq_dm_amd.ddim.models as M
+    from quant.quant_layer import QMODE, Scaler
+    from quant.quant_model import QuantModel
+    from tfmq_dm_amd._lib import TfmqError
+    g8 = golden("f8_cali_tiny")
+    m = M.Model(M.make_config(ch=32, ch_mult=(1, 2), num_res_blocks=1, attn_resolutions=(8,), image_size=16, dropout=0.0))
+    m.load_state_dict(sd_of(g8))
+    wq = {"bits": 8, "channel_wise": True, "scaler": Scaler.MINMAX}
+    aq = {"bits": 8, "channel_wise": False, "scaler": Scaler.MINMAX, "leaf_param": True}
+    q = QuantModel(m.to(DEV).eval(), wq, aq, cali=False, aq_mode=[QMODE.NORMAL.value]).to(DEV).eval()
+    q.set_quant_state(True, True)
+    with pytest.raises(TfmqError, match="4-bit weights"):
+        q(torch.randn(2, 3, 16, 16, device=DEV), torch.tensor([10.0, 500.0], device=DEV))

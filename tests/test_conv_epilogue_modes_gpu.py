@@ -233,6 +233,67 @@ def test_slab_kernel_is_bit_identical_to_the_tile_kernels(ops, B, H, cin, cout, 
         assert float((yy - ref).abs().max() / ref.abs().max()) <= 1e-5
 
 
+@pytest.mark.parametrize("k,B,H,cin,cout", [(3, 2, 32, 64, 320), (1, 3, 16, 128, 256), (3, 5, 8, 128, 640), (1, 2, 64, 64, 64)])
+def test_f16_stream_epilogue_equals_rounded_f32_epilogue(ops, k, B, H, cin, cout):
+    """fp16 activation stream: a conv writing fp16 (+ temb row + fp16 residual, statistics from the fp32 values) must give
+    exactly fp16(fp32 result) and the same statistics as the fp32 launch fed the same (fp16-representable) residual --
+    for every tile kernel and the slab kernel (8-channel / 16-byte items in the store pass)."""
+    import tfmq_dm_amd.ops as _o
+    W = H
+    g = torch.Generator().manual_seed(77 + H)
+    x = torch.randn(B, H, W, cin, generator=g) * 1.3 - 0.2
+    w = torch.randn(cout, cin, k, k, generator=g) * (2.0 / (cin * k * k) ** 0.5)
+    b = torch.randn(cout, generator=g) * 0.2
+    wd, wz = O.init_channelwise(w, 16, "minmax")
+    ad, az = O.minmax(x, 256)
+    sel = ops.qsel(qtab(ad, az))
+    xq = ops.quantize_act(x.to(DEV), sel)
+    pw = ops.pack_w4(w.to(DEV), wd.to(DEV), wz.to(DEV), bias=b.to(DEV))
+    r16 = torch.randn(B, H, W, cout, generator=g).half().to(DEV)
+    ra = torch.randn(B, cout, generator=g).to(DEV)
+    pad = (k // 2,) * 4
+    ref = ops.conv2d_w4a8(xq, pw, sel, pad=pad, residual=r16.float(), rowadd=ra, want_stats=True)
+    ref_st = ref._tfmq_stats[0].clone()
+    tiles = (1, 2, 3, 4, 5) if k == 3 else (1, 2, 3, 4)
+    for tile in tiles:
+        ops.set_conv_autotune({})
+        orig = _o._tune_conv
+        try:
+            _o._tune_conv = lambda h, name, kind, d, dsc, t=tile: t
+            y = ops.conv2d_w4a8(xq, pw, sel, pad=pad, residual=r16, rowadd=ra, want_stats=True, out_f16=True)
+        finally:
+            _o._tune_conv = orig
+            ops.set_conv_autotune(None)
+        assert y.dtype == torch.float16 and torch.equal(y, ref.half()), tile
+        assert torch.equal(y._tfmq_stats[0], ref_st), tile
+    # consumers of the fp16 stream read exactly the values their fp32 forms would: GroupNorm from the epilogue statistics
+    # (8-channel fp16 kernel), LayerNorm over the channel rows, the plain activation quantizer
+    gq = torch.Generator().manual_seed(5)
+    g2, b2 = torch.randn(cout, generator=gq).to(DEV), torch.randn(cout, generator=gq).to(DEV)
+    y32 = y.float()
+    y32._tfmq_stats = y._tfmq_stats
+    qa, _, ca = ops.groupnorm(y, g2, b2, 1e-5, True, sel, want_cat=True, half_out=True)
+    qb, _, cb = ops.groupnorm(y32, g2, b2, 1e-5, True, sel, want_cat=True, half_out=True)
+    assert torch.equal(qa, qb) and torch.equal(ca, cb) and torch.equal(ca, y)
+    qa2, fa2 = ops.layernorm(y.reshape(B, H * W, cout), g2, b2, 1e-5, sel, want_f32=True)
+    qb2, fb2 = ops.layernorm(y32.reshape(B, H * W, cout), g2, b2, 1e-5, sel, want_f32=True)
+    assert torch.equal(qa2, qb2) and torch.equal(fa2, fb2)
+    assert torch.equal(ops.quantize_act(y, sel), ops.quantize_act(y32, sel))
+    # int8 output with an fp16 residual (16-channel items): the consumer quantizer's bins of the same fp32 values
+    oq = ops.qsel(qtab(0.04, 119.0))
+    q_ref = ops.quantize_act(ref, oq)
+    for tile in tiles:
+        ops.set_conv_autotune({})
+        orig = _o._tune_conv
+        try:
+            _o._tune_conv = lambda h, name, kind, d, dsc, t=tile: t
+            yq = ops.conv2d_w4a8(xq, pw, sel, pad=pad, residual=r16, rowadd=ra, out_q8=oq)
+        finally:
+            _o._tune_conv = orig
+            ops.set_conv_autotune(None)
+        assert torch.equal(yq, q_ref), tile
+
+
 def test_f16_conv_tile_variants_are_bit_identical(ops):
     """The fp16-activation DMA conv (un-quantised / weight-only layers) in its four tile shapes: same K order per output."""
     import tfmq_dm_amd.ops as _o

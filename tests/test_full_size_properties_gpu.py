@@ -54,6 +54,9 @@ def test_sd_full_size_properties(sd):
         ea = eng.forward(x[:1].contiguous(), t[:1], ctx[:1].contiguous()).clone()
         eb = eng.forward(x[1:].contiguous(), t[1:], ctx[1:].contiguous()).clone()
         e_taps = eng.forward(x, t, ctx, taps={}).clone()
+        eng.stream_f16 = False                  # the fp32 activation stream (what the tap-exposing forward runs on)
+        e_f32 = eng.forward(x, t, ctx).clone()
+        eng.stream_f16 = True
         info["step"].fill_(1)
         e_step1 = eng.forward(x, t, ctx).clone()
         info["step"].zero_()
@@ -61,7 +64,13 @@ def test_sd_full_size_properties(sd):
     assert torch.isfinite(e2).all()
     assert torch.equal(e2, e2b)                                   # deterministic
     assert torch.equal(e2[:1], ea) and torch.equal(e2[1:], eb)    # batch independent
-    assert torch.equal(e2, e_taps)                                # fused == un-fused
+    assert torch.equal(e_f32, e_taps)                             # fused == un-fused (same fp32 stream)
+    # the fp16 activation stream (tensors between blocks stored as fp16; statistics from the fp32 values): measured, not
+    # estimated -- deviation of eps from the fp32-stream forward at full SD size
+    dev16 = float((e2 - e_f32).norm() / e_f32.norm())
+    print("SD v1 full size: eps rel-L2 fp16 stream vs fp32 stream:", dev16)
+    assert dev16 <= 4e-2       # measured 3.1e-2: the size of the engine's own deviation from the CPU oracle (bin flips of the
+                               # 8-bit activation quantizers compound the same way for any rounding perturbation)
     assert not torch.equal(e2, e_step1)                           # the step's activation table is used
 
 

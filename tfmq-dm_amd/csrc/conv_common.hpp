@@ -59,5 +59,27 @@ __device__ __forceinline__ int xcd_tile_id() {
 }
 
 
+__device__ __forceinline__ unsigned pack_q4(float a, float b, float c, float e, float2 qp) {
+  const unsigned q0 = static_cast<unsigned>(static_cast<int>(quant_index_f(a, qp.x, qp.y, 255.0f)) - 128) & 0xffu;
+  const unsigned q1 = static_cast<unsigned>(static_cast<int>(quant_index_f(b, qp.x, qp.y, 255.0f)) - 128) & 0xffu;
+  const unsigned q2 = static_cast<unsigned>(static_cast<int>(quant_index_f(c, qp.x, qp.y, 255.0f)) - 128) & 0xffu;
+  const unsigned q3 = static_cast<unsigned>(static_cast<int>(quant_index_f(e, qp.x, qp.y, 255.0f)) - 128) & 0xffu;
+  return q0 | (q1 << 8) | (q2 << 16) | (q3 << 24);
+}
+__device__ __forceinline__ unsigned pack_h2(float a, float b) {
+  const __half2 v = __floats2half2_rn(a, b);
+  return *reinterpret_cast<const unsigned*>(&v);
+}
+
+// four consecutive channels of the residual tensor: fp32, or fp16 when it belongs to the fp16 activation stream
+__device__ __forceinline__ float4 load_res4(const tfmq_conv_desc& d, int m, int n) {
+  if (d.res_f16) {
+    const uint2 u = *reinterpret_cast<const uint2*>(reinterpret_cast<const __half*>(d.residual) + static_cast<size_t>(m) * d.Cout + n);
+    const float2 lo = __half22float2(*reinterpret_cast<const __half2*>(&u.x)), hi = __half22float2(*reinterpret_cast<const __half2*>(&u.y));
+    return make_float4(lo.x, lo.y, hi.x, hi.y);
+  }
+  return *reinterpret_cast<const float4*>(d.residual + static_cast<size_t>(m) * d.Cout + n);
+}
+
 // 3x3 / stride 1 / pad 1 w4a8 convolutions on the slab kernel (conv_slab.hip): true when the launch was taken
 bool launch_conv_slab(tfmq_handle h, ConvP& p, hipStream_t st, bool forced);

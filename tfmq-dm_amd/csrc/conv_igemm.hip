@@ -31,7 +31,9 @@
 template <int BM, int BN>
 __host__ __device__ constexpr int epi_lds_bytes() {
   constexpr int PR = (BN == 128) ? 64 : BM;
-  return PR * (BN + 4) * 4 + (256 / (BN / 4)) * BN * 8 + BN * 8;
+  constexpr int NTR = 256 / (BN / 4), RPT = PR / NTR;
+  constexpr int NTRh = RPT == 8 ? 2 * NTR : NTR;      // fp16-stream store pass: 4-row partials when a thread row holds 8 rows
+  return PR * (BN + 4) * 4 + NTRh * BN * 8 + BN * 8;
 }
 
 // ---- epilogue.  The accumulators (C/D layout of the 32x32 MFMA: col = lane&31,
@@ -41,19 +43,44 @@ __host__ __device__ constexpr int epi_lds_bytes() {
 // (per-lane 4-byte strided accesses made this phase 2.5x slower than the MFMA loop).  The same
 // pass produces the per-channel sum / sum-of-squares of every SEG-row segment for the GroupNorm
 // that consumes this tensor, so that GroupNorm never has to re-read it for statistics.
-// four consecutive channels of the residual tensor: fp32, or fp16 when it belongs to the fp16 activation stream
-__device__ __forceinline__ float4 load_res4(const tfmq_conv_desc& d, int m, int n) {
-  if (d.res_f16) {
-    const uint2 u = *reinterpret_cast<const uint2*>(reinterpret_cast<const __half*>(d.residual) + static_cast<size_t>(m) * d.Cout + n);
-    const float2 lo = __half22float2(*reinterpret_cast<const __half2*>(&u.x)), hi = __half22float2(*reinterpret_cast<const __half2*>(&u.y));
-    return make_float4(lo.x, lo.y, hi.x, hi.y);
+// per-column constants of a wave's output tiles (weight scale, bias, {zero point, row sum} of the packed weights) and the
+// consumer quantizer's parameters: plain global loads whose latency a short-K block cannot afford at the start of its
+// epilogue -- the LDS-DMA kernels request them right behind their first DMA pieces
+template <int WN_TILES>
+struct EpiCols {
+  float ws[WN_TILES], bias[WN_TILES];
+  int zp[WN_TILES], rs[WN_TILES];
+  float2 oqp;
+};
+
+template <bool INT8, int WAVES_N, int WN_TILES>
+__device__ __forceinline__ EpiCols<WN_TILES> load_epi_cols(const ConvP& p, int n0) {
+  const tfmq_conv_desc& d = p.d;
+  const int lane = threadIdx.x & 63, wn = (threadIdx.x >> 6) % WAVES_N;
+  EpiCols<WN_TILES> ec;
+#pragma unroll
+  for (int j = 0; j < WN_TILES; ++j) {
+    const int n = n0 + (wn * WN_TILES + j) * 32 + (lane & 31);
+    const bool nok = n < d.Cout;
+    ec.ws[j] = (d.wscale && nok) ? d.wscale[n] : 1.0f;
+    ec.bias[j] = (d.bias && nok) ? d.bias[n] : 0.0f;
+    ec.zp[j] = ec.rs[j] = 0;
+    if constexpr (INT8) {
+      if (nok) {
+        const int4 wmv = reinterpret_cast<const int4*>(d.wmeta)[n];
+        ec.zp[j] = wmv.x;
+        ec.rs[j] = wmv.y;
+      }
+    }
   }
-  return *reinterpret_cast<const float4*>(d.residual + static_cast<size_t>(m) * d.Cout + n);
+  ec.oqp = make_float2(1.0f, 0.0f);
+  if (d.out_mode == TFMQ_OUT_Q8 || d.out_mode == TFMQ_OUT_GEGLU_Q8) ec.oqp = load_qparam(d.oq);
+  return ec;
 }
 
 template <bool INT8, int WAVES_M, int WAVES_N, int WM_TILES, int WN_TILES, bool RES_PRE = false, typename ACC>
 __device__ __forceinline__ void conv_epilogue(const ConvP& p, unsigned char* lds, ACC (&acc)[WM_TILES][WN_TILES],
-                                              int m0, int n0, float2 aqp, int za) {
+                                              int m0, int n0, float2 aqp, int za, const EpiCols<WN_TILES>& ec) {
   constexpr int BM = WAVES_M * WM_TILES * 32;
   constexpr int BN = WAVES_N * WN_TILES * 32;
   constexpr int PR = (BN == 128) ? 64 : BM;       // rows per pass
@@ -67,7 +94,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, unsigned char* lds
   const int wm = wid / WAVES_N, wn = wid % WAVES_N;
   float* ldsO = reinterpret_cast<float*>(lds);                      // [PR][LDO]
   float2* ldsP = reinterpret_cast<float2*>(lds + PR * LDO * 4);     // [NTR][BN] partial (sum, sumsq)
-  float2* ldsG = ldsP + NTR * BN;                                   // [BN] running segment sums
+  float2* ldsG = ldsP + (RPT == 8 ? 2 * NTR : NTR) * BN;           // [BN] running segment sums (behind the fp16 pass's 4-row partials)
   const int hw = d.Ho * d.Wo;
   const float* rowadd = d.rowadd;
   if (rowadd && d.rowadd_step) rowadd += static_cast<size_t>(*d.rowadd_step) * d.rowadd_step_stride;
@@ -77,8 +104,12 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, unsigned char* lds
   // tiles of the transposed output region (V^T for the attention kernel) stage with an odd row pitch so the
   // column-wise LDS reads of their store pass are (at most 2-way) conflict free
   const bool q8 = d.out_mode == TFMQ_OUT_Q8;
-  float2 oqp = make_float2(1.0f, 0.0f);
-  if (q8) oqp = load_qparam(d.oq);
+  const float2 oqp = ec.oqp;
+  // every global access of the store pass moves 16 bytes per lane where the shapes allow it (8-byte fp16 / 4-byte int8
+  // accesses made these passes instruction-issue bound, not bandwidth bound): 8 channels per item for fp16 outputs,
+  // 16 for int8 outputs
+  const bool vec8_ok = vec_ok && ((d.Cout | d.ldy | d.y_coff) & 7) == 0;
+  const bool vec16_ok = vec_ok && (d.Cout & 15) == 0;
   const bool transposed = d.out_mode == TFMQ_OUT_F16 && d.yt && n0 >= d.t_col0;
   const int ldo = transposed ? BN + 1 : LDO;
 
@@ -88,14 +119,13 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, unsigned char* lds
   for (int j = 0; j < WN_TILES; ++j) {
     const int n = n0 + (wn * WN_TILES + j) * 32 + (lane & 31);
     const bool nok = n < d.Cout;
-    sc_[j] = (!INT8 && d.wscale && nok) ? d.wscale[n] : 1.0f;
-    bias_[j] = (d.bias && nok) ? d.bias[n] : 0.0f;
+    sc_[j] = (!INT8 && d.wscale) ? ec.ws[j] : 1.0f;
+    bias_[j] = ec.bias[j];
     corr_[j] = 0;
     if constexpr (INT8) {
       if (nok) {
-        const int4 wmv = reinterpret_cast<const int4*>(d.wmeta)[n];
-        corr_[j] = (128 - za) * (wmv.y - p.Ktot * wmv.x);
-        sc_[j] = aqp.x * d.wscale[n];
+        corr_[j] = (128 - za) * (ec.rs[j] - p.Ktot * ec.zp[j]);
+        sc_[j] = aqp.x * ec.ws[j];
       }
     }
   }
@@ -104,6 +134,42 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, unsigned char* lds
   // layers run at the fp32-activation roofline) overlaps the staging and the barrier instead of following them
   // (RES_PRE kernels are launched only for vectorisable fp32 / Q8 outputs with a residual; a separate instantiation,
   // because the 32 extra live registers cost the other output modes spills)
+  // segment sums of the GroupNorm statistics from the per-thread-row partials in ldsP (one fixed order, see phase 2)
+  auto reduce_stats = [&](int pass, auto ppg_tag) {
+    __syncthreads();
+    constexpr int PPG = decltype(ppg_tag)::value;          // stored partials per 8-row group
+    const int rows_seg = seg < PR ? seg : PR;
+    const int nseg_pass = PR / rows_seg, g8 = rows_seg / 8;
+    for (int o = tid; o < nseg_pass * BN; o += 256) {
+      const int sidx = o / BN, col = o % BN;
+      // a segment spanning several passes keeps adding its groups to the running sum, in the same order
+      float2 a = seg <= PR ? make_float2(0.0f, 0.0f) : ldsG[col];
+      for (int q = 0; q < g8; ++q) {
+        const int base = (sidx * g8 + q) * PPG;
+        float2 b = ldsP[base * BN + col];
+        if constexpr (PPG == 2) {
+          const float2 b2 = ldsP[(base + 1) * BN + col];
+          b.x += b2.x;
+          b.y += b2.y;
+        }
+        a.x += b.x;
+        a.y += b.y;
+      }
+      const int n = n0 + col;
+      if (seg <= PR) {
+        const int row0 = m0 + pass * PR + sidx * seg;
+        if (row0 < p.M && n < d.Cout) reinterpret_cast<float2*>(d.stats)[static_cast<size_t>(row0 / seg) * d.Cout + n] = a;
+      } else {  // write after the segment's last pass
+        const bool last = ((pass + 1) * PR) % seg == 0;
+        if (last) {
+          const int srow0 = m0 + (pass + 1) * PR - seg;
+          if (srow0 < p.M && n < d.Cout) reinterpret_cast<float2*>(d.stats)[static_cast<size_t>(srow0 / seg) * d.Cout + n] = a;
+          a = make_float2(0.0f, 0.0f);
+        }
+        ldsG[col] = a;
+      }
+    }
+  };
   for (int pass = 0; pass < BM / PR; ++pass) {
     float4 rpre[RES_PRE ? RPT : 1];
     if constexpr (RES_PRE) {
@@ -111,6 +177,19 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, unsigned char* lds
       for (int k = 0; k < RPT; ++k) {
         const int m = m0 + pass * PR + tr * RPT + k, n = n0 + c4;
         rpre[k] = (m < p.M && n < d.Cout) ? load_res4(d, m, n) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+    // fp16-stream store pass (below): its fp16 residual rows are requested here, branch-free, for the same reason
+    constexpr int TPR8p = BN / 8, RPThp = RPT == 8 ? 4 : RPT, NTRhp = PR / RPThp;
+    const bool act8 = d.out_mode == TFMQ_OUT_F16 && vec8_ok && !transposed && tid < NTRhp * TPR8p;
+    uint4 rpre8[RPThp];
+    if (act8 && d.residual && d.res_f16) {
+      const int nc = (n0 + (tid % TPR8p) * 8) < d.Cout ? (n0 + (tid % TPR8p) * 8) : 0;
+#pragma unroll
+      for (int k = 0; k < RPThp; ++k) {
+        const int mm = m0 + pass * PR + (tid / TPR8p) * RPThp + k;
+        const int mc = mm < p.M ? mm : p.M - 1;
+        rpre8[k] = *reinterpret_cast<const uint4*>(reinterpret_cast<const __half*>(d.residual) + static_cast<size_t>(mc) * d.Cout + nc);
       }
     }
     __syncthreads();  // previous pass fully consumed (also orders the main loop's LDS reads before the overwrite)
@@ -149,26 +228,17 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, unsigned char* lds
       if (d.out_mode == TFMQ_OUT_GEGLU_Q8) {
         // tile columns [0,64) = value, [64,128) = gate of the same 64 output channels:
         // yq = quant(value * gelu(gate)), gelu exact (erf), the arithmetic of k_geglu
-        const float2 oqp = load_qparam(d.oq);
-        const int inner = d.Cout >> 1, rg = tid >> 4, g4 = (tid & 15) * 4;
+        const int inner = d.Cout >> 1, prow = tid >> 2, g16 = (tid & 3) * 16;      // PR = 64 rows: one row x 16 outputs per thread
+        const int m = m0 + pass * PR + prow;
+        if (m < p.M) {
+          unsigned w[4];
 #pragma unroll
-        for (int k = 0; k < PR / 16; ++k) {
-          const int prow = rg + 16 * k;
-          const int m = m0 + pass * PR + prow;
-          if (m >= p.M) continue;
-          const float4 a = *reinterpret_cast<const float4*>(ldsO + prow * LDO + g4);
-          const float4 g = *reinterpret_cast<const float4*>(ldsO + prow * LDO + 64 + g4);
-          float4 y;
-          y.x = a.x * gelu_f(g.x);
-          y.y = a.y * gelu_f(g.y);
-          y.z = a.z * gelu_f(g.z);
-          y.w = a.w * gelu_f(g.w);
-          char4 q;
-          q.x = static_cast<signed char>(static_cast<int>(quant_index_f(y.x, oqp.x, oqp.y, 255.0f)) - 128);
-          q.y = static_cast<signed char>(static_cast<int>(quant_index_f(y.y, oqp.x, oqp.y, 255.0f)) - 128);
-          q.z = static_cast<signed char>(static_cast<int>(quant_index_f(y.z, oqp.x, oqp.y, 255.0f)) - 128);
-          q.w = static_cast<signed char>(static_cast<int>(quant_index_f(y.w, oqp.x, oqp.y, 255.0f)) - 128);
-          *reinterpret_cast<char4*>(d.yq + static_cast<size_t>(m) * inner + (n0 >> 1) + g4) = q;
+          for (int q4 = 0; q4 < 4; ++q4) {
+            const float4 a = *reinterpret_cast<const float4*>(ldsO + prow * LDO + g16 + 4 * q4);
+            const float4 g = *reinterpret_cast<const float4*>(ldsO + prow * LDO + 64 + g16 + 4 * q4);
+            w[q4] = pack_q4(a.x * gelu_f(g.x), a.y * gelu_f(g.y), a.z * gelu_f(g.z), a.w * gelu_f(g.w), oqp);
+          }
+          *reinterpret_cast<uint4*>(d.yq + static_cast<size_t>(m) * inner + (n0 >> 1) + g16) = make_uint4(w[0], w[1], w[2], w[3]);
         }
         continue;
       }
@@ -192,6 +262,91 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, unsigned char* lds
         const int b = m / hw, t = m - b * hw;
         *reinterpret_cast<uint2*>(reinterpret_cast<__half*>(d.yt) + (static_cast<size_t>(b) * cv + (n - d.t_col0)) * hw + t) = u;
       }
+      continue;
+    }
+    if (q8 && vec16_ok) {
+      // int8 output (the consumer quantizer's bins): items of one row x 16 channels, balanced over the 256 threads
+      constexpr int TPR16 = BN / 16, NTR16 = 256 / TPR16, RPT16 = PR / NTR16;
+      static_assert(RPT16 >= 1, "rows per thread (int8 output)");
+      const int tr16 = tid / TPR16, c16 = (tid % TPR16) * 16;
+#pragma unroll
+      for (int k = 0; k < RPT16; ++k) {
+        const int prow = tr16 * RPT16 + k;
+        const int m = m0 + pass * PR + prow, n = n0 + c16;
+        if (m >= p.M || n >= d.Cout) continue;
+        unsigned w[4];
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) {
+          float4 v = *reinterpret_cast<const float4*>(ldsO + prow * LDO + c16 + 4 * q4);
+          if (rowadd) {
+            const float4 a = *reinterpret_cast<const float4*>(rowadd + static_cast<size_t>(m / hw) * d.rowadd_ld + n + 4 * q4);
+            v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
+          }
+          if (d.residual) {
+            const float4 a = load_res4(d, m, n + 4 * q4);
+            v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
+          }
+          w[q4] = pack_q4(v.x, v.y, v.z, v.w, oqp);
+        }
+        *reinterpret_cast<uint4*>(d.yq + static_cast<size_t>(m) * d.Cout + n) = make_uint4(w[0], w[1], w[2], w[3]);
+      }
+      continue;
+    }
+    if (d.out_mode == TFMQ_OUT_F16 && vec8_ok) {
+      // fp16 activation stream: items of 8 channels (16 bytes out, 16 bytes of fp16 residual in); the thread rows keep
+      // the 4-wide mapping's NTR x RPT so that the statistics grouping -- and with it the summation order -- is the
+      // same for every output mode and tile shape; threads beyond NTR * BN/8 only join the barriers
+      constexpr int TPR8 = BN / 8;
+      constexpr int RPTh = RPT == 8 ? 4 : RPT;      // an 8-row thread row splits into its two 4-row halves: all 256 threads work
+      constexpr int NTRh = PR / RPTh;
+      static_assert(NTRh * TPR8 <= 256, "fp16 store pass mapping");
+      if (act8) {
+        const int tr8 = tid / TPR8, c8 = (tid % TPR8) * 8;
+        float ps[1][8], pss[1][8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) ps[0][q] = pss[0][q] = 0.0f;
+#pragma unroll
+        for (int k = 0; k < RPTh; ++k) {
+          const int prow = tr8 * RPTh + k;
+          const int m = m0 + pass * PR + prow, n = n0 + c8;
+          if (m >= p.M || n >= d.Cout) continue;
+          const float4 v0 = *reinterpret_cast<const float4*>(ldsO + prow * LDO + c8);
+          const float4 v1 = *reinterpret_cast<const float4*>(ldsO + prow * LDO + c8 + 4);
+          float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+          if (rowadd) {
+            const float4 a0 = *reinterpret_cast<const float4*>(rowadd + static_cast<size_t>(m / hw) * d.rowadd_ld + n);
+            const float4 a1 = *reinterpret_cast<const float4*>(rowadd + static_cast<size_t>(m / hw) * d.rowadd_ld + n + 4);
+            v[0] += a0.x; v[1] += a0.y; v[2] += a0.z; v[3] += a0.w; v[4] += a1.x; v[5] += a1.y; v[6] += a1.z; v[7] += a1.w;
+          }
+          if (d.residual) {
+            if (d.res_f16) {
+              const unsigned uw[4] = {rpre8[k].x, rpre8[k].y, rpre8[k].z, rpre8[k].w};
+#pragma unroll
+              for (int q = 0; q < 4; ++q) {
+                const float2 f = __half22float2(*reinterpret_cast<const __half2*>(&uw[q]));
+                v[2 * q] += f.x;
+                v[2 * q + 1] += f.y;
+              }
+            } else {
+              const float4 a0 = load_res4(d, m, n), a1 = load_res4(d, m, n + 4);
+              v[0] += a0.x; v[1] += a0.y; v[2] += a0.z; v[3] += a0.w; v[4] += a1.x; v[5] += a1.y; v[6] += a1.z; v[7] += a1.w;
+            }
+          }
+          *reinterpret_cast<uint4*>(reinterpret_cast<__half*>(d.y) + static_cast<size_t>(m) * d.ldy + d.y_coff + n) =
+              make_uint4(pack_h2(v[0], v[1]), pack_h2(v[2], v[3]), pack_h2(v[4], v[5]), pack_h2(v[6], v[7]));
+#pragma unroll
+          for (int q = 0; q < 8; ++q) {
+            ps[0][q] += v[q];
+            pss[0][q] += v[q] * v[q];
+          }
+        }
+        if (seg) {      // one partial per 4 rows: a group = (rows 0..3 in order) + (rows 4..7 in order), as everywhere
+          float2* pp = ldsP + tr8 * BN + c8;
+#pragma unroll
+          for (int q = 0; q < 8; ++q) pp[q] = make_float2(ps[0][q], pss[0][q]);
+        }
+      }
+      if (seg) reduce_stats(pass, std::integral_constant<int, 8 / RPTh>{});
       continue;
     }
     if (d.out_mode == TFMQ_OUT_F16 && !vec_ok) {
@@ -287,39 +442,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, unsigned char* lds
       pp[1] = make_float2(s.y, ss.y);
       pp[2] = make_float2(s.z, ss.z);
       pp[3] = make_float2(s.w, ss.w);
-      __syncthreads();
-      constexpr int PPG = 8 / RPT;          // stored partials per 8-row group
-      const int rows_seg = seg < PR ? seg : PR;
-      const int nseg_pass = PR / rows_seg, g8 = rows_seg / 8;
-      for (int o = tid; o < nseg_pass * BN; o += 256) {
-        const int sidx = o / BN, col = o % BN;
-        // a segment spanning several passes keeps adding its groups to the running sum, in the same order
-        float2 a = seg <= PR ? make_float2(0.0f, 0.0f) : ldsG[col];
-        for (int q = 0; q < g8; ++q) {
-          const int base = (sidx * g8 + q) * PPG;
-          float2 b = ldsP[base * BN + col];
-          if constexpr (PPG == 2) {
-            const float2 b2 = ldsP[(base + 1) * BN + col];
-            b.x += b2.x;
-            b.y += b2.y;
-          }
-          a.x += b.x;
-          a.y += b.y;
-        }
-        const int n = n0 + col;
-        if (seg <= PR) {
-          const int row0 = m0 + pass * PR + sidx * seg;
-          if (row0 < p.M && n < d.Cout) reinterpret_cast<float2*>(d.stats)[static_cast<size_t>(row0 / seg) * d.Cout + n] = a;
-        } else {  // write after the segment's last pass
-          const bool last = ((pass + 1) * PR) % seg == 0;
-          if (last) {
-            const int srow0 = m0 + (pass + 1) * PR - seg;
-            if (srow0 < p.M && n < d.Cout) reinterpret_cast<float2*>(d.stats)[static_cast<size_t>(srow0 / seg) * d.Cout + n] = a;
-            a = make_float2(0.0f, 0.0f);
-          }
-          ldsG[col] = a;
-        }
-      }
+      reduce_stats(pass, std::integral_constant<int, 8 / RPT>{});
     }
   }
 }
@@ -329,26 +452,29 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, unsigned char* lds
 // F16 = true: un-quantised layers on fp16 operands (fp16 NHWC activations written by the producing kernel, 32
 // channels per K-step, f16 MFMA, fp32 accumulation) -- the same 64-byte rows, swizzle and pipeline.
 // ================================================================================================
-template <bool F16, int WAVES_M, int WAVES_N, int WM_TILES, int WN_TILES, bool RES_PRE = false>
-__global__ __launch_bounds__(256, (WM_TILES * WN_TILES > 4) ? 2 : 3) void k_conv_dma(ConvP p) {
+template <bool F16, int WAVES_M, int WAVES_N, int WM_TILES, int WN_TILES, bool RES_PRE = false, int NST = 3>
+__global__ __launch_bounds__(256, (WM_TILES * WN_TILES > 4 || NST > 3) ? 2 : 3) void k_conv_dma(ConvP p) {
   constexpr int BM = WAVES_M * WM_TILES * 32;
   constexpr int BN = WAVES_N * WN_TILES * 32;
   constexpr int STAGE = (BM + BN) * 64;          // bytes of one K-step: A tile then B tile, 64-byte rows
-  constexpr int NST = 3;                          // stages: multiply s, s+1 landed/landing, s+2 landing
+  // NST stages: multiply s while s+1 .. s+NST-1 have landed or are landing.  3 for long K loops; 5 ("whole K resident")
+  // for pointwise layers of K <= 320, whose five K-steps are all requested before the first one is multiplied -- a short
+  // loop at prefetch distance 2 waits out most of a DMA latency at every step
   constexpr int A_CH = BM / 64;                   // 1-KiB (16-row) DMA pieces per wave
   constexpr int B_CH = BN >= 64 ? BN / 64 : 1;    // (BN = 32: two pieces, waves 2/3 repeat them)
   constexpr int NLOAD = A_CH + B_CH;              // DMA instructions per wave per K-step
   constexpr int MAXT = 9;
   constexpr int LDS_MAIN = NST * STAGE;
   constexpr int LDS_EPI = epi_lds_bytes<BM, BN>();
-  constexpr int LDS_BODY = LDS_MAIN > LDS_EPI ? LDS_MAIN : LDS_EPI;
   // 256-row tiles (stride 1, no fused upsample -- the launcher's rule): the offset table shrinks to {offset of the
   // window origin, bit mask of in-image taps} per row, so two workgroups (2 x 80 KiB) still share a CU
   constexpr bool COMPACT = BM > 128;
-  constexpr int TAB_BYTES = COMPACT ? BM * 8 : MAXT * BM * 4;
+  constexpr int TAB_BYTES = NST > 3 ? 0 : (COMPACT ? BM * 8 : MAXT * BM * 4);      // (the whole-K variant is pointwise: no table)
+  // the offset table is dead once the K loop ends: the epilogue's staging may overlay it
+  constexpr int LDS_ALL = (LDS_MAIN + TAB_BYTES) > LDS_EPI ? (LDS_MAIN + TAB_BYTES) : LDS_EPI;
   static_assert(WAVES_M * WAVES_N == 4, "4 waves");
-  __shared__ __attribute__((aligned(1024))) unsigned char lds[LDS_BODY + TAB_BYTES];
-  int* tab = reinterpret_cast<int*>(lds + LDS_BODY);  // [tap][row] byte offset of the input pixel, -1 = padding
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[LDS_ALL];
+  int* tab = reinterpret_cast<int*>(lds + LDS_MAIN);  // [tap][row] byte offset of the input pixel, -1 = padding
   TFMQ_MARK(0);
 
   const tfmq_conv_desc& d = p.d;
@@ -361,11 +487,15 @@ __global__ __launch_bounds__(256, (WM_TILES * WN_TILES > 4) ? 2 : 3) void k_conv
 
   // two dependent global loads (step counter -> table row): issued first, consumed after the offset table is built
   float2 aqp = make_float2(1.0f, 0.0f);
-  if constexpr (!F16) aqp = load_qparam(d.aq);
 
   // ---- pixel offset table (any stride / padding / fused 2x upsample).  A Linear / 1x1 stride-1 conv needs none:
   // pixel m reads input pixel m (most launches of a transformer UNet: no table, no barrier in the prologue)
   const bool pointwise = d.KH * d.KW == 1 && d.stride == 1 && !d.up2x && d.pad_t == 0 && d.pad_l == 0;
+  // a pointwise layer needs the activation quantizer's parameters only in its epilogue: requested after its first DMA
+  // pieces (below); a layer with padded taps needs the zero point for the pad rows first
+  if constexpr (!F16) {
+    if (!pointwise) aqp = load_qparam(d.aq);
+  }
   if (!pointwise && COMPACT) {
     const int taps = d.KH * d.KW, hw = d.Ho * d.Wo;
     for (int row = tid; row < BM; row += 256) {
@@ -437,10 +567,11 @@ __global__ __launch_bounds__(256, (WM_TILES * WN_TILES > 4) ? 2 : 3) void k_conv
     b_dst[it] = __builtin_amdgcn_readfirstlane(BM * 64 + piece * 1024);
   }
   if (!pointwise) __syncthreads();  // tab visible
-  const int za = static_cast<int>(aqp.y);
   // real zero == bin za  ->  stored byte za-128; its 64-byte row in the pad table feeds the padded taps
-  // (fp16 operands: row 0 = zeros)
-  const unsigned char* padp = p.pad_table + (F16 ? 0u : (static_cast<unsigned>(za - 128) & 0xffu)) * 64;
+  // (fp16 operands: row 0 = zeros).  A pointwise layer has no padded taps -- only rows past M, whose results are never
+  // stored -- so its first DMA does not wait for the two dependent loads behind aqp
+  const unsigned char* padp = p.pad_table;
+  if (!pointwise && !F16) padp += (static_cast<unsigned>(static_cast<int>(aqp.y) - 128) & 0xffu) * 64;
 
   int i_tap = 0, i_chunk = 0;
   auto issue = [&](int s, int stage) {
@@ -510,23 +641,31 @@ __global__ __launch_bounds__(256, (WM_TILES * WN_TILES > 4) ? 2 : 3) void k_conv
   };
 
   TFMQ_MARK(1);
-  issue(0, 0);
-  if (p.nsteps > 1) issue(1, 1);
-  int st_c = 0, st_i = 2;
+#pragma unroll
+  for (int s0 = 0; s0 < NST - 1; ++s0)
+    if (s0 < p.nsteps) issue(s0, s0);
+  // requested behind the first DMA pieces, consumed in the epilogue (the counted waits of the loop only become more
+  // conservative on its first step: these loads are younger than the pieces they must not overtake)
+  if constexpr (!F16) {
+    if (pointwise) aqp = load_qparam(d.aq);
+  }
+  const EpiCols<WN_TILES> ec = load_epi_cols<!F16, WAVES_N, WN_TILES>(p, n0);
+  int st_c = 0, st_i = NST - 1;
   for (int s = 0; s < p.nsteps; ++s) {
-    // this wave's pieces of K-step s have landed (those of s+1 may still be in flight) ...
-    if (s + 1 < p.nsteps)
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLOAD) : "memory");
-    else
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // this wave's pieces of K-step s have landed (those of the up to NST-2 later steps may still be in flight) ...
+    const int ahead = p.nsteps - 1 - s;
+    if (ahead >= NST - 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * NLOAD) : "memory");
+    else if (NST > 3 && ahead == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NLOAD) : "memory");
+    else if (NST > 3 && ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLOAD) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     // ... and after the barrier every wave's have, and nobody still reads the stage refilled below
     asm volatile("s_barrier" ::: "memory");
     // diagnostics builds (-DTFMQ_DBG_NO_DMA / -DTFMQ_DBG_NO_MFMA, results are garbage): the K loop without its
     // L2 -> LDS traffic, or without its fragment reads and MFMAs -- DESIGN.md section 4 quotes both
 #ifdef TFMQ_DBG_NO_DMA
-    if (s + 2 < p.nsteps && s < 1) issue(s + 2, st_i);
+    if (s + NST - 1 < p.nsteps && s < 1) issue(s + NST - 1, st_i);
 #else
-    if (s + 2 < p.nsteps) issue(s + 2, st_i);
+    if (s + NST - 1 < p.nsteps) issue(s + NST - 1, st_i);
 #endif
 #ifndef TFMQ_DBG_NO_MFMA
     compute(st_c);
@@ -536,7 +675,7 @@ __global__ __launch_bounds__(256, (WM_TILES * WN_TILES > 4) ? 2 : 3) void k_conv
   }
 
   TFMQ_MARK(2);
-  conv_epilogue<!F16, WAVES_M, WAVES_N, WM_TILES, WN_TILES, RES_PRE>(p, lds, acc, m0, n0, aqp, za);
+  conv_epilogue<!F16, WAVES_M, WAVES_N, WM_TILES, WN_TILES, RES_PRE>(p, lds, acc, m0, n0, aqp, static_cast<int>(aqp.y), ec);
   TFMQ_MARK(3);
 }
 
@@ -796,7 +935,8 @@ __global__ __launch_bounds__(256, 3) void k_conv_igemm(ConvP p) {
     }
   }
 
-  conv_epilogue<INT8, WAVES_M, WAVES_N, WM_TILES, WN_TILES>(p, lds, acc, m0, n0, aqp, za);
+  const EpiCols<WN_TILES> ec = load_epi_cols<INT8, WAVES_N, WN_TILES>(p, n0);
+  conv_epilogue<INT8, WAVES_M, WAVES_N, WM_TILES, WN_TILES>(p, lds, acc, m0, n0, aqp, za, ec);
 }
 
 template <bool INT8>
@@ -895,8 +1035,14 @@ static int launch_conv(tfmq_handle h, const tfmq_conv_desc* dd, void* stream) {
       p.dbg = grid.x <= (1u << 20) ? dbuf : nullptr;
 #endif
       // residual rows prefetched ahead of the staging (see conv_epilogue): the epilogue's vector path only
-      const bool res_pre = d.residual && (d.out_mode == TFMQ_OUT_F32 || d.out_mode == TFMQ_OUT_Q8 || d.out_mode == TFMQ_OUT_F16) &&
-                           ((d.Cout | d.ldy | d.y_coff) & 3) == 0 && (!d.rowadd || (d.rowadd_ld & 3) == 0);
+      const bool vec4 = ((d.Cout | d.ldy | d.y_coff) & 3) == 0 && (!d.rowadd || (d.rowadd_ld & 3) == 0);
+      const bool wide16 = d.out_mode == TFMQ_OUT_Q8 && vec4 && (d.Cout & 15) == 0;               // the epilogue's 16-byte item paths
+      const bool wide8 = d.out_mode == TFMQ_OUT_F16 && vec4 && ((d.Cout | d.ldy | d.y_coff) & 7) == 0;   // load their residual themselves
+      const bool res_pre = d.residual && vec4 && !wide16 && !wide8 &&
+                           (d.out_mode == TFMQ_OUT_F32 || d.out_mode == TFMQ_OUT_Q8 || d.out_mode == TFMQ_OUT_F16);
+      // (a "whole K resident" variant -- NST = 5 stages for the five K-steps of a K = 320 token Linear, every step requested up
+      // front -- was measured and lost: 80 KiB of LDS leaves two blocks per CU instead of three, 246 -> 282 us on the
+      // 320 -> 320 residual Linear at UNet batch 128)
       if (narrow) hipLaunchKernelGGL((k_conv_dma<false, 4, 1, 1, 1>), grid, dim3(256), 0, st, p);
       else if (half_n && res_pre) hipLaunchKernelGGL((k_conv_dma<false, 2, 2, 2, 1, true>), grid, dim3(256), 0, st, p);
       else if (half_n) hipLaunchKernelGGL((k_conv_dma<false, 2, 2, 2, 1>), grid, dim3(256), 0, st, p);

@@ -144,15 +144,17 @@ __global__ __launch_bounds__(512) void k_conv3_slab(SlabP sp) {
       if (pos + 1 < p.nsteps) wait_vmcnt<B_CH + X>();
       else wait_vmcnt<0>();
       asm volatile("s_barrier" ::: "memory");
-      if (pos + 2 < p.nsteps) {
-        if constexpr (TAP + 2 < 9) issue_b(c, TAP + 2, (TAP + 2) % 3);
-        else issue_b(c + 1, TAP + 2 - 9, (TAP + 2) % 3);
-      }
-      if constexpr (TAP < 4) {
-        // next chunk's slab into the idle buffer; the last chunk re-stages chunk 0 there (never read) so that the
-        // counted waits see the same number of loads in flight in every chunk
-        issue_slab(TAP, c + 1 < p.chunks ? c + 1 : 0, ((c + 1) & 1));
-      }
+      auto issue_next = [&]() {
+        if (pos + 2 < p.nsteps) {
+          if constexpr (TAP + 2 < 9) issue_b(c, TAP + 2, (TAP + 2) % 3);
+          else issue_b(c + 1, TAP + 2 - 9, (TAP + 2) % 3);
+        }
+        if constexpr (TAP < 4) {
+          // next chunk's slab into the idle buffer; the last chunk re-stages chunk 0 there (never read) so that the
+          // counted waits see the same number of loads in flight in every chunk
+          issue_slab(TAP, c + 1 < p.chunks ? c + 1 : 0, ((c + 1) & 1));
+        }
+      };
       constexpr int KH = TAP / 3, KW = TAP % 3;
       const int toff = KH * SW + KW;
       int a_rel[2];
@@ -173,6 +175,9 @@ __global__ __launch_bounds__(512) void k_conv3_slab(SlabP sp) {
         for (int i = 0; i < 2; ++i)
 #pragma unroll
           for (int j = 0; j < WN; ++j) acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[i], bf[j], acc[i][j], 0, 0, 0);
+        // the DMA issue of the next K-steps (SALU M0 moves + VMEM, ~100 clk a piece) sits behind the first half's MFMAs:
+        // the matrix pipe works through them while the wave issues the loads, instead of idling right after the barrier
+        if (ks == 0) issue_next();
       }
     };
 #pragma unroll
@@ -204,6 +209,7 @@ __global__ __launch_bounds__(512) void k_conv3_slab(SlabP sp) {
   if (rowadd && d.rowadd_step) rowadd += static_cast<size_t>(*d.rowadd_step) * d.rowadd_step_stride;
   const int seg = d.stats ? d.stats_seg : 0;
   const bool q8 = d.out_mode == TFMQ_OUT_Q8, o16 = d.out_mode == TFMQ_OUT_F16;
+  const bool q16 = (d.Cout & 15) == 0, h8 = ((d.Cout | d.ldy | d.y_coff) & 7) == 0;     // 16-byte item paths of the store pass
   float2 oqp = make_float2(1.0f, 0.0f);
   if (q8) oqp = load_qparam(d.oq);
   float sc_[WN], bias_[WN];
@@ -222,20 +228,128 @@ __global__ __launch_bounds__(512) void k_conv3_slab(SlabP sp) {
     }
   }
   const int gq = tid / TPR, c4 = (tid % TPR) * 4;      // phase 2: wave-row group, first of 4 channels (tid < 4 * TPR)
-  auto do_pass = [&](auto pass_tag) {             // instantiated per pass: the accumulator registers of a pass are static
+  // phase 1 of pass (i, g): 4 accumulator registers of every N-tile -> LDS.  Instantiated per pass (the registers must be
+  // static); everything else of a pass is shared code in a rolled loop -- eight copies of the store pass were ~280 KB
+  // of instructions, far beyond the instruction cache
+  auto stage = [&](auto pass_tag) {
     constexpr int pass = decltype(pass_tag)::value;
     constexpr int i = pass >> 2, g = pass & 3;
-    __syncthreads();            // previous pass consumed (first pass: every wave has left the K loop)
 #pragma unroll
     for (int j = 0; j < WN; ++j) {
       const int col = (wn * WN + j) * 32 + (lane & 31);
 #pragma unroll
-      for (int rr = 0; rr < 4; ++rr) {
+      for (int rr = 0; rr < 4; ++rr)
         ldsO[(wm * 8 + rr + 4 * h) * LDO + col] = sc_[j] * static_cast<float>(acc[i][j][g * 4 + rr] + corr_[j]) + bias_[j];
+    }
+  };
+#pragma unroll 1
+  for (int pass = 0; pass < 8; ++pass) {
+    const int i = pass >> 2, g = pass & 3;
+    // fp16-stream store pass: its residual rows (and the image's temb row) are requested here, branch-free, so that their
+    // latency runs under the staging below instead of forming a chain of 8 dependent waits in the row loop
+    constexpr int TPR8 = BN / 8;
+    const bool act8 = o16 && h8 && tid < 4 * TPR8;
+    const int gq8 = tid / TPR8, c8 = (tid % TPR8) * 8;
+    uint4 rres[8];
+    float4 ra0 = make_float4(0.f, 0.f, 0.f, 0.f), ra1 = ra0;
+    if (act8) {
+      const int row0 = gq8 * 64 + i * 32 + g * 8;
+      const int nc = (n0 + c8) < d.Cout ? (n0 + c8) : 0;
+      if (d.residual && d.res_f16) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const int mc = (m0 + row0 + k) < p.M ? (m0 + row0 + k) : p.M - 1;
+          rres[k] = *reinterpret_cast<const uint4*>(reinterpret_cast<const __half*>(d.residual) + static_cast<size_t>(mc) * d.Cout + nc);
+        }
+      }
+      if (rowadd) {
+        const int mc = (m0 + row0) < p.M ? (m0 + row0) : p.M - 1;      // the 8 rows of a group belong to one image (8 | H*W)
+        ra0 = *reinterpret_cast<const float4*>(rowadd + static_cast<size_t>(mc / hw) * d.rowadd_ld + nc);
+        ra1 = *reinterpret_cast<const float4*>(rowadd + static_cast<size_t>(mc / hw) * d.rowadd_ld + nc + 4);
       }
     }
+    __syncthreads();            // previous pass consumed (first pass: every wave has left the K loop)
+    switch (pass) {
+      case 0: stage(std::integral_constant<int, 0>{}); break;
+      case 1: stage(std::integral_constant<int, 1>{}); break;
+      case 2: stage(std::integral_constant<int, 2>{}); break;
+      case 3: stage(std::integral_constant<int, 3>{}); break;
+      case 4: stage(std::integral_constant<int, 4>{}); break;
+      case 5: stage(std::integral_constant<int, 5>{}); break;
+      case 6: stage(std::integral_constant<int, 6>{}); break;
+      default: stage(std::integral_constant<int, 7>{}); break;
+    }
     __syncthreads();
-    if (tid < 4 * TPR) {
+    if (q8 && q16) {
+      // int8 output: items of one row x 16 channels (16-byte stores), balanced over the block
+      for (int item = tid; item < 32 * (BN / 16); item += 512) {
+        const int sr = item / (BN / 16), c16 = (item - sr * (BN / 16)) * 16;
+        const int m = m0 + (sr >> 3) * 64 + i * 32 + g * 8 + (sr & 7), n = n0 + c16;
+        if (m >= p.M || n >= d.Cout) continue;
+        unsigned w[4];
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) {
+          float4 v = *reinterpret_cast<const float4*>(ldsO + sr * LDO + c16 + 4 * q4);
+          if (rowadd) {
+            const float4 a = *reinterpret_cast<const float4*>(rowadd + static_cast<size_t>(m / hw) * d.rowadd_ld + n + 4 * q4);
+            v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
+          }
+          if (d.residual) {
+            const float4 a = load_res4(d, m, n + 4 * q4);
+            v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
+          }
+          w[q4] = pack_q4(v.x, v.y, v.z, v.w, oqp);
+        }
+        *reinterpret_cast<uint4*>(d.yq + static_cast<size_t>(m) * d.Cout + n) = make_uint4(w[0], w[1], w[2], w[3]);
+      }
+    } else if (o16 && h8) {
+      // fp16 activation stream: items of 8 channels (16 bytes out, 16 bytes of fp16 residual in), 8 rows per thread
+      if (act8) {
+        const int row0 = gq8 * 64 + i * 32 + g * 8, n = n0 + c8;
+        float ps[2][8], pss[2][8];
+#pragma unroll
+        for (int gi = 0; gi < 2; ++gi)
+#pragma unroll
+          for (int q = 0; q < 8; ++q) ps[gi][q] = pss[gi][q] = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const int m = m0 + row0 + k;
+          if (m >= p.M || n >= d.Cout) continue;
+          const float4 v0 = *reinterpret_cast<const float4*>(ldsO + (gq8 * 8 + k) * LDO + c8);
+          const float4 v1 = *reinterpret_cast<const float4*>(ldsO + (gq8 * 8 + k) * LDO + c8 + 4);
+          float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+          if (rowadd) {
+            v[0] += ra0.x; v[1] += ra0.y; v[2] += ra0.z; v[3] += ra0.w; v[4] += ra1.x; v[5] += ra1.y; v[6] += ra1.z; v[7] += ra1.w;
+          }
+          if (d.residual) {
+            if (d.res_f16) {
+              const unsigned uw[4] = {rres[k].x, rres[k].y, rres[k].z, rres[k].w};
+#pragma unroll
+              for (int q = 0; q < 4; ++q) {
+                const float2 f = __half22float2(*reinterpret_cast<const __half2*>(&uw[q]));
+                v[2 * q] += f.x;
+                v[2 * q + 1] += f.y;
+              }
+            } else {
+              const float4 a0 = load_res4(d, m, n), a1 = load_res4(d, m, n + 4);
+              v[0] += a0.x; v[1] += a0.y; v[2] += a0.z; v[3] += a0.w; v[4] += a1.x; v[5] += a1.y; v[6] += a1.z; v[7] += a1.w;
+            }
+          }
+          *reinterpret_cast<uint4*>(reinterpret_cast<__half*>(d.y) + static_cast<size_t>(m) * d.ldy + d.y_coff + n) =
+              make_uint4(pack_h2(v[0], v[1]), pack_h2(v[2], v[3]), pack_h2(v[4], v[5]), pack_h2(v[6], v[7]));
+#pragma unroll
+          for (int q = 0; q < 8; ++q) {
+            ps[k >> 2][q] += v[q];
+            pss[k >> 2][q] += v[q] * v[q];
+          }
+        }
+        if (seg) {
+          float2* pp = ldsP + (gq8 * 8 + i * 4 + g) * BN + c8;
+#pragma unroll
+          for (int q = 0; q < 8; ++q) pp[q] = make_float2(ps[0][q] + ps[1][q], pss[0][q] + pss[1][q]);
+        }
+      }
+    } else     if (tid < 4 * TPR) {
       const int row0 = gq * 64 + i * 32 + g * 8, n = n0 + c4;
       float4 ps[2], pss[2];
       ps[0] = ps[1] = pss[0] = pss[1] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -287,15 +401,7 @@ __global__ __launch_bounds__(512) void k_conv3_slab(SlabP sp) {
         pp[3] = make_float2(ps[0].w + ps[1].w, pss[0].w + pss[1].w);
       }
     }
-  };
-  do_pass(std::integral_constant<int, 0>{});
-  do_pass(std::integral_constant<int, 1>{});
-  do_pass(std::integral_constant<int, 2>{});
-  do_pass(std::integral_constant<int, 3>{});
-  do_pass(std::integral_constant<int, 4>{});
-  do_pass(std::integral_constant<int, 5>{});
-  do_pass(std::integral_constant<int, 6>{});
-  do_pass(std::integral_constant<int, 7>{});
+  }
   if (seg) {
     __syncthreads();
     const int nseg = BM / seg, gps = seg / 8;

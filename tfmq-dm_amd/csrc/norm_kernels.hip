@@ -359,6 +359,87 @@ __global__ __launch_bounds__(256) void k_gn_apply(tfmq_gn_desc d, const float* _
   }
 }
 
+// fp16 activation stream: 8 channels per thread -- one 16-byte load, one 8-byte int8 store (and 16-byte fp16 stores for the
+// optional normalised / concatenated copies); the 4-channel form moves 8 / 4 bytes per lane and is instruction-issue bound.
+__global__ __launch_bounds__(256) void k_gn_apply_h8(tfmq_gn_desc d, const float* __restrict__ A, const float* __restrict__ Bb) {
+  const int Cc = d.C1 + d.C2;
+  const unsigned ucv = static_cast<unsigned>(Cc / 8), uhw = static_cast<unsigned>(d.HW);
+  const size_t total = static_cast<size_t>(d.B) * d.HW * ucv;
+  const bool quant = d.aq.qtable != nullptr;
+  float2 qp = make_float2(1.0f, 0.0f);
+  if (quant) qp = load_qparam(d.aq);
+  const unsigned stride = gridDim.x * blockDim.x;
+  const unsigned i0 = blockIdx.x * blockDim.x + threadIdx.x;
+  const unsigned sdiv = stride / ucv, smod = stride - sdiv * ucv;
+  const int hw_shift = (uhw & (uhw - 1)) == 0 ? __builtin_ctz(uhw) : -1;
+  unsigned pix = i0 / ucv;
+  unsigned cq = i0 - pix * ucv;
+  for (unsigned i = i0; i < static_cast<unsigned>(total); i += stride) {
+    const int b = static_cast<int>(hw_shift >= 0 ? pix >> hw_shift : pix / uhw);
+    const int c = static_cast<int>(cq) * 8;
+    const __half* sh = c < d.C1 ? reinterpret_cast<const __half*>(d.x1) + static_cast<size_t>(pix) * d.C1 + c
+                                : reinterpret_cast<const __half*>(d.x2) + static_cast<size_t>(pix) * d.C2 + (c - d.C1);
+    const uint4 u = *reinterpret_cast<const uint4*>(sh);
+    const float4 a0 = *reinterpret_cast<const float4*>(A + static_cast<size_t>(b) * Cc + c);
+    const float4 a1 = *reinterpret_cast<const float4*>(A + static_cast<size_t>(b) * Cc + c + 4);
+    const float4 b0 = *reinterpret_cast<const float4*>(Bb + static_cast<size_t>(b) * Cc + c);
+    const float4 b1 = *reinterpret_cast<const float4*>(Bb + static_cast<size_t>(b) * Cc + c + 4);
+    const unsigned uw[4] = {u.x, u.y, u.z, u.w};
+    const float a[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+    const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+    float v[8], y[8];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float2 f = __half22float2(*reinterpret_cast<const __half2*>(&uw[q]));
+      v[2 * q] = f.x;
+      v[2 * q + 1] = f.y;
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      y[q] = a[q] * v[q] + bb[q];
+      if (d.silu) y[q] = silu_f(y[q]);
+    }
+    const size_t o = static_cast<size_t>(pix) * Cc + c;
+    if (d.xcat_or_null) {
+      if (d.half_out) *reinterpret_cast<uint4*>(reinterpret_cast<__half*>(d.xcat_or_null) + o) = u;     // fp16 in, fp16 copy out
+      else {
+        *reinterpret_cast<float4*>(d.xcat_or_null + o) = make_float4(v[0], v[1], v[2], v[3]);
+        *reinterpret_cast<float4*>(d.xcat_or_null + o + 4) = make_float4(v[4], v[5], v[6], v[7]);
+      }
+    }
+    if (quant) {
+      unsigned w[2];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        unsigned acc = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          acc |= (static_cast<unsigned>(static_cast<int>(quant_index_f(y[4 * h + q], qp.x, qp.y, 255.0f)) - 128) & 0xffu) << (8 * q);
+        w[h] = acc;
+      }
+      *reinterpret_cast<uint2*>(d.yq + o) = make_uint2(w[0], w[1]);
+    }
+    if (d.yf) {
+      if (d.half_out) {
+        __half2 h2[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) h2[q] = __floats2half2_rn(y[2 * q], y[2 * q + 1]);
+        *reinterpret_cast<uint4*>(reinterpret_cast<__half*>(d.yf) + o) = *reinterpret_cast<const uint4*>(h2);
+      } else {
+        *reinterpret_cast<float4*>(d.yf + o) = make_float4(y[0], y[1], y[2], y[3]);
+        *reinterpret_cast<float4*>(d.yf + o + 4) = make_float4(y[4], y[5], y[6], y[7]);
+      }
+    }
+    pix += sdiv;
+    cq += smod;
+    if (cq >= ucv) {
+      cq -= ucv;
+      ++pix;
+    }
+    if (i + stride < i) break;
+  }
+}
+
 extern "C" int tfmq_groupnorm_from_stats(tfmq_handle h, const tfmq_gn_desc* dd, const float* stats1, const float* stats2,
                                          int seg, float* ws, void* stream) {
   TFMQ_CHECK_ARG(h, h && dd && stats1 && ws, "groupnorm_from_stats: null pointer");
@@ -375,12 +456,14 @@ extern "C" int tfmq_groupnorm_from_stats(tfmq_handle h, const tfmq_gn_desc* dd, 
                      reinterpret_cast<const float2*>(stats2), d.C2, d.HW, seg, d.groups, d.eps, d.gamma, d.beta, A, Bb);
   TFMQ_LAUNCH_CHECK(h);
   const bool v4 = (d.C1 % 4 == 0) && (d.C2 % 4 == 0);
-  const size_t total = static_cast<size_t>(d.B) * d.HW * (v4 ? Cc / 4 : Cc);
+  const bool h8 = d.x_f16 && (d.C1 % 8 == 0) && (d.C2 % 8 == 0);
+  const size_t total = static_cast<size_t>(d.B) * d.HW * (h8 ? Cc / 8 : (v4 ? Cc / 4 : Cc));
   TFMQ_CHECK_ARG(h, total < (1ull << 32), "groupnorm_from_stats: more than 2^32 items");
   int blocks = ceil_div(static_cast<long>(total), 256 * 4);
   if (blocks > h->cu_count * 16) blocks = h->cu_count * 16;
   if (blocks < 1) blocks = 1;
-  if (v4) hipLaunchKernelGGL(k_gn_apply<4>, dim3(blocks), dim3(256), 0, as_stream(stream), d, A, Bb);
+  if (h8) hipLaunchKernelGGL(k_gn_apply_h8, dim3(blocks), dim3(256), 0, as_stream(stream), d, A, Bb);
+  else if (v4) hipLaunchKernelGGL(k_gn_apply<4>, dim3(blocks), dim3(256), 0, as_stream(stream), d, A, Bb);
   else hipLaunchKernelGGL(k_gn_apply<1>, dim3(blocks), dim3(256), 0, as_stream(stream), d, A, Bb);
   TFMQ_LAUNCH_CHECK(h);
   return TFMQ_OK;

@@ -29,7 +29,7 @@ def _collect(block: nn.Module, prefix: str = "blk"):
                 if mod.use_aq and not mod.disable_aq and mod.aqtizer.delta is not None:
                     qid = len(rows)
                     rows.append([float(mod.aqtizer.delta), float(mod.aqtizer.zero_point)])
-                wq[full] = LayerQ(d, z, a, qid)
+                wq[full] = LayerQ(d, z, a, qid, level=mod.wqtizer.level, act_level=mod.aqtizer.level)
             else:
                 sd[full + ".weight"] = mod.original_w
                 if mod.original_b is not None:

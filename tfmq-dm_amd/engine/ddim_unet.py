@@ -33,8 +33,9 @@ class LayerQ:
     """Quantisation state of one QuantLayer handed to the engine."""
 
     def __init__(self, delta: torch.Tensor, zp: torch.Tensor, alpha: Optional[torch.Tensor] = None,
-                 qid: Optional[int] = None):
+                 qid: Optional[int] = None, level: int = 16, act_level: int = 256):
         self.delta, self.zp, self.alpha, self.qid = delta, zp, alpha, qid
+        self.level, self.act_level = int(level), int(act_level)      # 2 ** bits of the weight / activation quantizer
 
 
 class _Layer:
@@ -51,6 +52,15 @@ class _Layer:
             # calibration data passes and the FP sampling of the calibration set); bit-identical
             x = ops.to_half(x)
         return ops.conv2d_f16(x, self.p, **kw)
+
+
+def _check_w4a8_levels(name: str, q: LayerQ) -> None:
+    """The int8-MFMA path stores weights as nibbles (16 levels) and activations as 256 bins.  Another bit width (the
+    reference's --wq 8 recipe) must not be run on it silently: the deltas would have been searched for that width and the
+    packed values clamped to 4 bits."""
+    if q.level != 16 or q.act_level != 256:
+        raise TfmqError(f"{name}: the HIP engine's quantised layers are 4-bit weights x 8-bit activations; got "
+                        f"{q.level} weight levels / {q.act_level} activation levels (W8A8 is not built on the device path yet)")
 
 
 def ddim_resblock_names(cfg) -> List[str]:
@@ -100,6 +110,11 @@ class DdimUNetEngine:
         self.prepared = False
         # activation calibration (Finite-Set Calibration, quant/calibration.py:108-152)
         self.calib = None          # None | ("init", k) | ("running", k)
+        # fp16 activation stream: outside calibration / tap capture the tensors that travel between
+        # blocks (conv outputs feeding a GroupNorm / LayerNorm / residual add) are stored as fp16 -- their GroupNorm
+        # statistics still come from the fp32 values inside the producing epilogue.  TFMQ_STREAM_F32=1 keeps fp32.
+        self.stream_f16 = os.environ.get("TFMQ_STREAM_F32") is None
+        self._h16 = False
         self.act_state = None      # [n_q, 2] EMA {x_min, x_max} (quant_layer.py:229-244)
         self._qp_scratch = None
 
@@ -130,9 +145,11 @@ class DdimUNetEngine:
             if q is None:
                 self.layers[n] = _Layer("fp", ops.pack_w_f16(w, b), None)
             elif aq is None:
+                # weight-only layers hold the exact integer grid q - z in f16: any bit width up to 11 bits
                 a = None if q.alpha is None else q.alpha.to(self.dev).contiguous()
-                self.layers[n] = _Layer("w4", ops.pack_w_f16(w, b, q.delta.to(self.dev), q.zp.to(self.dev), a), None)
+                self.layers[n] = _Layer("w4", ops.pack_w_f16(w, b, q.delta.to(self.dev), q.zp.to(self.dev), a, level=q.level), None)
             else:
+                _check_w4a8_levels(n, q)
                 a = None if q.alpha is None else q.alpha.to(self.dev).contiguous()
                 self.layers[n] = _Layer("w4a8", ops.pack_w4(w, q.delta.to(self.dev), q.zp.to(self.dev), a, b), aq)
         # linears of the temporal-information block
@@ -142,6 +159,7 @@ class DdimUNetEngine:
             if q is None:
                 self.lin[n] = ("fp", w, b, None)
             else:
+                _check_w4a8_levels(n, q)
                 a = None if q.alpha is None else q.alpha.to(self.dev).contiguous()
                 self.lin[n] = ("w4", ops.pack_w4(w, q.delta.to(self.dev), q.zp.to(self.dev), a, b), None, aq_of(q))
         # fused q/k/v GEMM where the three sibling quantizers agree at every step
@@ -276,6 +294,16 @@ class DdimUNetEngine:
                                      want_cat=want_cat, half_out=half)
         return (yq if aq is not None else yf), xcat
 
+    def _o16(self) -> dict:
+        return {"out_f16": True} if self._h16 else {}
+
+    def _stream_f16_possible(self) -> bool:
+        """Every un-quantised / weight-only conv that consumes a stream tensor must take fp16 input (LDS-DMA path)."""
+        for n, l in self.layers.items():
+            if l.kind != "w4a8" and not ops.f16_dma_ok(l.p.cin, l.p.kh, l.p.kw) and l.p.cin > 4:
+                return False
+        return True
+
     def _fp_conv_half_ok(self, layer: _Layer) -> bool:
         return layer.kind != "w4a8" and ops.f16_dma_ok(layer.p.cin, layer.p.kh, layer.p.kw)
 
@@ -285,15 +313,15 @@ class DdimUNetEngine:
         if x2 is not None and not has_sc:
             raise TfmqError(f"{p}: concatenated input without nin_shortcut is not a DDPM-UNet block")
         half = has_sc and self._fp_conv_half_ok(L[p + ".nin_shortcut"])
-        h, xcat = self._gn(p + ".norm1", x1, x2, True, L[p + ".conv1"], want_cat=has_sc and (x2 is not None or half), half=half,
-                           half_main=True)
-        h = L[p + ".conv1"].run(h, pad=(1, 1, 1, 1), **rowadd_kw)
+        h, xcat = self._gn(p + ".norm1", x1, x2, True, L[p + ".conv1"],
+                           want_cat=has_sc and (x2 is not None or (half and x1.dtype != torch.float16)), half=half, half_main=True)
+        h = L[p + ".conv1"].run(h, pad=(1, 1, 1, 1), **rowadd_kw, **self._o16())
         h, _ = self._gn(p + ".norm2", h, None, True, L[p + ".conv2"], half_main=True)
         if has_sc:
-            sc = L[p + ".nin_shortcut"].run(xcat if xcat is not None else x1)
+            sc = L[p + ".nin_shortcut"].run(xcat if xcat is not None else x1, **self._o16())
         else:
             sc = x1
-        return L[p + ".conv2"].run(h, pad=(1, 1, 1, 1), residual=sc)
+        return L[p + ".conv2"].run(h, pad=(1, 1, 1, 1), residual=sc, **self._o16())
 
     def _attnblock(self, p, x):
         L = self.layers
@@ -310,7 +338,7 @@ class DdimUNetEngine:
             aq = po.aq if po.kind == "w4a8" else None
             out, oq = ops.attention_f16(y16[..., :Cc], y16[..., Cc:2 * Cc], vt, 1, float(int(Cc) ** (-0.5)), aq,
                                         want_f32=aq is None)
-            return po.run((oq if aq is not None else out).reshape(B, H, W, Cc), residual=x)
+            return po.run((oq if aq is not None else out).reshape(B, H, W, Cc), residual=x, **self._o16())
         if p in self.fused_qkv:
             f = self.fused_qkv[p]
             h, _ = self._gn(p + ".norm", x, None, False, f)
@@ -333,7 +361,7 @@ class DdimUNetEngine:
         out, oq = ops.attention(qkv[..., :Cc], qkv[..., Cc:2 * Cc], qkv[..., 2 * Cc:], 1, float(int(Cc) ** (-0.5)), aq,
                                 want_f32=aq is None)
         a = (oq if aq is not None else out).reshape(B, H, W, Cc)
-        return po.run(a, residual=x)
+        return po.run(a, residual=x, **self._o16())
 
     # ------------------------------------------------------------------ forward
     def forward(self, *a, **k):
@@ -354,6 +382,7 @@ class DdimUNetEngine:
             raise TfmqError("DdimUNetEngine.forward before prepare()")
         cfg, L = self.cfg, self.layers
         nlev, nres = len(cfg["ch_mult"]), cfg["num_res_blocks"]
+        self._h16 = self.stream_f16 and self.calib is None and taps is None and self._stream_f16_possible()
         if t is not None:
             projs = dict(zip(self.res_names, self.tib(t)))
             if taps is not None:
@@ -374,7 +403,7 @@ class DdimUNetEngine:
             if taps is not None:
                 taps[name] = (a, b)
 
-        hs = [L["conv_in"].run(x, pad=(1, 1, 1, 1))]
+        hs = [L["conv_in"].run(x, pad=(1, 1, 1, 1), **self._o16())]
         res = cfg["resolution"]
         for i in range(nlev):
             for j in range(nres):
@@ -389,7 +418,10 @@ class DdimUNetEngine:
             if i != nlev - 1:
                 # Downsample (ddim/models/diffusion.py:65-72): pad (0,1,0,1), 3x3 stride 2, un-quantised
                 dl = L[f"down.{i}.downsample.conv"]
-                hs.append(dl.run(ops.to_half(hs[-1]) if self._fp_conv_half_ok(dl) else hs[-1], stride=2, pad=(0, 0, 1, 1)))
+                hin_d = hs[-1]
+                if hin_d.dtype == torch.float32 and self._fp_conv_half_ok(dl):
+                    hin_d = ops.to_half(hin_d)
+                hs.append(dl.run(hin_d, stride=2, pad=(0, 0, 1, 1), **self._o16()))
                 res //= 2
         h = hs[-1]
         hin = h
@@ -418,7 +450,7 @@ class DdimUNetEngine:
                     self._observe(up.aq, h)
                 hq = ops.quantize_act(h, up.aq) if up.kind == "w4a8" else h
                 hlow = h
-                h = up.run(hq, pad=(1, 1, 1, 1), up2x=True)
+                h = up.run(hq, pad=(1, 1, 1, 1), up2x=True, **self._o16())
                 if taps is not None:  # layer unit: its input is the up-sampled tensor (Upsample.forward)
                     taps[f"up.{i}.upsample.conv"] = (ops.upsample2x(hlow), h)
                 res *= 2

@@ -171,14 +171,15 @@ class LdmUNetEngine(DdimUNetEngine):
         if x2 is not None and not has_skip:
             raise TfmqError(f"{p}: concatenated input without skip_connection")
         half = has_skip and self._fp_conv_half_ok(L[p + ".skip_connection"])
-        h, xcat = self._gn(p + ".in_layers.0", x1, x2, True, cin, want_cat=has_skip and (x2 is not None or half), eps=1e-5,
+        h, xcat = self._gn(p + ".in_layers.0", x1, x2, True, cin,
+                           want_cat=has_skip and (x2 is not None or (half and x1.dtype != torch.float16)), eps=1e-5,
                            half=half, half_main=True)
-        h = cin.run(h, pad=(1, 1, 1, 1), **rowadd_kw)
+        h = cin.run(h, pad=(1, 1, 1, 1), **rowadd_kw, **self._o16())
         h, _ = self._gn(p + ".out_layers.0", h, None, True, cout, eps=1e-5, half_main=True)
-        sc = L[p + ".skip_connection"].run(xcat if xcat is not None else x1, want_stats=False) if has_skip else x1
+        sc = L[p + ".skip_connection"].run(xcat if xcat is not None else x1, want_stats=False, **self._o16()) if has_skip else x1
         if out_aq is not None and cout.kind == "w4a8":
             return cout.run(h, pad=(1, 1, 1, 1), residual=sc, want_stats=False, out_q8=out_aq)
-        return cout.run(h, pad=(1, 1, 1, 1), residual=sc)
+        return cout.run(h, pad=(1, 1, 1, 1), residual=sc, **self._o16())
 
     def _attention(self, p, xq_src, ctx, x_res, self_attn: bool):
         """one CrossAttention + residual; xq_src: LN output already in to_q's input form."""
@@ -197,7 +198,7 @@ class LdmUNetEngine(DdimUNetEngine):
                 y16, vt = ops.conv2d_f16(ops.to_half(xq_src.reshape(B, T, 1, Cin)), f.p, out_f16=True, t_col0=2 * Cc)
                 y16 = y16.reshape(B, T, 3 * Cc)
                 o, _ = ops.attention_f16(y16[..., :Cc], y16[..., Cc:2 * Cc], vt, heads, float(d ** -0.5))
-                return self._tok(to_out, self._quant_in(to_out, o), residual=x_res)
+                return self._tok(to_out, self._quant_in(to_out, o), residual=x_res, **self._o16())
         if f is not None and f.kind == "w4a8":
             # main path: the projection GEMM writes q | k as fp16 rows and v as fp16 V^T, the attention kernel
             # copies them tile by tile (no fp32 round trip, no conversion, no transposition)
@@ -213,7 +214,7 @@ class LdmUNetEngine(DdimUNetEngine):
                 else:
                     o, _ = ops.attention_f16(y16[..., :Cc], y16[..., Cc:2 * Cc], vt, heads, float(d ** -0.5))
                     o = self._quant_in(to_out, o)
-                return self._tok(to_out, o, residual=x_res)
+                return self._tok(to_out, o, residual=x_res, **self._o16())
         if (not self_attn) and self.calib is None and self._ctx_pad is not None:
             # cross attention on fp16 operands: the context is stored padded to a multiple of 8 tokens (padding masked
             # in the kernel), to_q writes fp16 rows, to_k fp16 rows, to_v its fp16 transpose
@@ -233,7 +234,7 @@ class LdmUNetEngine(DdimUNetEngine):
                                              n_keys=n_ctx)
                 else:
                     o, _ = ops.attention_f16(q16, k16.reshape(Bc, Lp, Cc), vt, heads, float(d ** -0.5), n_keys=n_ctx)
-                return self._tok(to_out, o, residual=x_res)
+                return self._tok(to_out, o, residual=x_res, **self._o16())
         if self_attn and p in self.fused_qkv:
             qkv = self._tok(self.fused_qkv[p], xq_src)
             Cc = qkv.shape[-1] // 3
@@ -258,7 +259,7 @@ class LdmUNetEngine(DdimUNetEngine):
         else:
             o, _ = ops.attention(q, k, v, heads, float(d ** -0.5))
             o = self._quant_in(to_out, o)
-        return self._tok(to_out, o, residual=x_res)
+        return self._tok(to_out, o, residual=x_res, **self._o16())
 
     def _tblock(self, p, x, ctx, out_aq=None):
         L = self.layers
@@ -273,13 +274,13 @@ class LdmUNetEngine(DdimUNetEngine):
             g = ops.conv2d_w4a8(xq.reshape(B, T, 1, Cc), gp, ff0.aq, geglu_oq=ff2.aq).reshape(B, T, -1)
             if out_aq is not None:      # tokens feed only proj_out's quantizer: int8 straight from the epilogue
                 return self._tok(ff2, g, residual=x, out_q8=out_aq)
-            return self._tok(ff2, g, residual=x)
+            return self._tok(ff2, g, residual=x, **self._o16())
         h = self._tok(ff0, self._ln(p + ".norm3", x, ff0))
         if ff2.kind == "w4a8" and self.calib is None:
             g = ops.geglu(h, ff2.aq)[0]
         else:
             g = self._quant_in(ff2, ops.geglu(h, None)[1])
-        return self._tok(ff2, g, residual=x)
+        return self._tok(ff2, g, residual=x, **self._o16())
 
     def _st(self, p, x, ctx, taps=None, out_aq=None):
         """taps (reconstruction data capture): every QuantLayer / QuantBasicTransformerBlock of the SpatialTransformer is a
@@ -288,7 +289,7 @@ class LdmUNetEngine(DdimUNetEngine):
         B, H, W, Cc = x.shape
         pin, pout = L[p + ".proj_in"], L[p + ".proj_out"]
         h_in, _ = self._gn(p + ".norm", x, None, False, pin, eps=1e-6)
-        h = pin.run(h_in, want_stats=False)
+        h = pin.run(h_in, want_stats=False, **self._o16())
         if taps is not None:
             taps[p + ".proj_in"] = (h_in, h)
         tok = h.reshape(B, H * W, h.shape[-1])
@@ -307,7 +308,7 @@ class LdmUNetEngine(DdimUNetEngine):
             taps[p + ".proj_out"] = (h, pout.run(h, want_stats=False))
         if out_aq is not None and pout.kind == "w4a8":
             return pout.run(h, residual=x, want_stats=False, out_q8=out_aq)
-        return pout.run(h, residual=x)
+        return pout.run(h, residual=x, **self._o16())
 
     def _attn_block(self, p, x):
         """AttentionBlock._forward (openaimodel.py:317-326): un-quantised (Conv1d is not a QuantLayer type)."""
@@ -321,7 +322,7 @@ class LdmUNetEngine(DdimUNetEngine):
         d = Cc // heads
         # q*s . k*s with s = d^-1/4 (QKMatMul) == (q . k) * d^-1/2
         o, _ = ops.attention(qkv[..., :Cc], qkv[..., Cc:2 * Cc], qkv[..., 2 * Cc:], heads, float(d ** -0.5))
-        return po.run(o.reshape(B, H, W, Cc), residual=x, want_stats=True)
+        return po.run(o.reshape(B, H, W, Cc), residual=x, want_stats=True, **self._o16())
 
     def _seq(self, p, h, skip, ctx, rowadd, taps):
         L = self.layers
@@ -347,15 +348,16 @@ class LdmUNetEngine(DdimUNetEngine):
                     taps[q] = (hin, h)
             elif (q + ".op") in L:
                 dl = L[q + ".op"]
-                h = dl.run(ops.to_half(h) if self._fp_conv_half_ok(dl) else h, stride=2, pad=(1, 1, 1, 1))
+                hd = ops.to_half(h) if (h.dtype == torch.float32 and self._fp_conv_half_ok(dl)) else h
+                h = dl.run(hd, stride=2, pad=(1, 1, 1, 1), **self._o16())
             elif (q + ".conv") in L:
                 up = L[q + ".conv"]
                 hq = h if h.dtype == torch.int8 else self._quant_in(up, h)
-                h = up.run(hq, pad=(1, 1, 1, 1), up2x=True)
+                h = up.run(hq, pad=(1, 1, 1, 1), up2x=True, **self._o16())
                 if taps is not None and hq.dtype == torch.float32:
                     taps[q + ".conv"] = (ops.upsample2x(hq), h)
             elif q in L:
-                h = L[q].run(h, pad=(1, 1, 1, 1))
+                h = L[q].run(h, pad=(1, 1, 1, 1), **self._o16())
             else:
                 raise TfmqError(f"LdmUNetEngine: unknown child {q}")
         return h
@@ -380,6 +382,7 @@ class LdmUNetEngine(DdimUNetEngine):
         if context is None and any(k.endswith(".attn2.to_k.weight") for k in self.sd):
             raise TfmqError("LdmUNetEngine: SpatialTransformer UNets need a context tensor")
         L = self.layers
+        self._h16 = self.stream_f16 and self.calib is None and taps is None and self._stream_f16_possible()
         if t is not None:
             projs = dict(zip(self.res_names, self.tib(t)))
             if taps is not None:

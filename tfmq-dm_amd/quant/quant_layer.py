@@ -207,6 +207,9 @@ class QuantLayer(nn.Module):
             d, z, a = self.weight_quant_state()
             w = self.w.detach().float().contiguous()
             a = None if a is None else a.float().contiguous()
+            if mode == "w4a8" and (self.wqtizer.level != 16 or self.aqtizer.level != 256):
+                raise TfmqError(f"QuantLayer: the device path is 4-bit weights x 8-bit activations; got {self.wqtizer.level} weight "
+                                f"levels / {self.aqtizer.level} activation levels")
             pk = ops.pack_w4(w, d, z, a, b) if mode == "w4a8" else ops.pack_w_f16(w, b, d, z, a, self.wqtizer.level)
         self._packed = (key, pk)
         return pk

@@ -163,7 +163,7 @@ class QuantModel(nn.Module):
                     sd[n + ".weight"] = mod.w.detach()
                     if mod.b is not None:
                         sd[n + ".bias"] = mod.b.detach()
-                    wq[n] = LayerQ(d, z, a, qid.get(n))
+                    wq[n] = LayerQ(d, z, a, qid.get(n), level=mod.wqtizer.level, act_level=mod.aqtizer.level)
                 else:
                     sd[n + ".weight"] = mod.original_w
                     if mod.original_b is not None:
