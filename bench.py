@@ -532,15 +532,18 @@ def main():
             tot_ops, tot_ms, n_launch, tot_bytes, n_fwd = conv_roofline(fwd, info["stream"])
         achieved = tot_ops / (tot_ms * 1e-3) / 1e12 if tot_ms > 0 else 0.0
         traffic, traffic_src = None, None
-        tpath = os.path.join(ROOT, "profiles", f"r01_traffic_{args.workload}.json")
-        if os.path.exists(tpath):
-            tj = json.load(open(tpath))["kernels"]
-            ks = [v for k, v in tj.items() if k.startswith("void k_conv_dma<false") or k.startswith("void k_conv_igemm<true")]
+        tname = next((f"r{r:02d}_traffic_{args.workload}.json" for r in (2, 1)
+                      if os.path.exists(os.path.join(ROOT, "profiles", f"r{r:02d}_traffic_{args.workload}.json"))), None)
+        if tname is not None:
+            tj = json.load(open(os.path.join(ROOT, "profiles", tname)))["kernels"]
+            ks = [v for k, v in tj.items() if ("k_conv_dma<false" in k or "k_conv_igemm<true" in k or "k_conv3_slab" in k
+                                                or "k_lin_direct" in k)]
             if ks:
                 traffic = sum(v["hbm_bytes_per_launch"] * v["launches"] for v in ks) / sum(v["launches"] for v in ks)
-                traffic_src = (f"profiles/r01_traffic_{args.workload}.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, "
+                traffic_src = (f"profiles/{tname} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, "
                                "separate passes, eager forwards of the same workload)")
-        roof = {"bound": "mfma", "kernel": "k_conv_dma<false,...> (w4a8 implicit-GEMM conv / linear, LDS-DMA pipeline, all tile variants)",
+        roof = {"bound": "mfma", "kernel": ("the w4a8 implicit-GEMM family: k_conv3_slab<WN> (3x3, activation slab staged once per channel chunk), "
+                                            "k_lin_direct<mode> (pointwise, register-direct epilogue), k_conv_dma<false,...> (tile kernels)"),
                 "achieved": round(achieved, 2), "peak": INT8_PEAK_TOPS, "unit": "TOP/s",
                 "frac": round(achieved / INT8_PEAK_TOPS, 4), "traffic": traffic, "traffic_unit": "bytes/launch (PMC)",
                 "traffic_source": traffic_src,
@@ -567,7 +570,7 @@ def main():
             "value": round(value, 3), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "int8 (u8 activation bins x int4 weights, int32 accumulate; f16 MFMA for un-quantised layers / attention, fp32 residual stream)",
+            "dtype": "int8 (u8 activation bins x int4 weights, int32 accumulate; f16 MFMA for un-quantised layers / attention, fp16 activation stream with fp32 statistics / arithmetic)",
             "data": "synthetic: N(0,1) latents / context, random-init weights (zero params re-drawn N(0,0.02^2)), synthetic FSC tables",
             "config": cfgd, "finite": finite, "roofline": roof, "cpu_baseline": cpu_b, "calibration": cali,
         }

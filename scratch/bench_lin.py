@@ -1,0 +1,53 @@
+"""Pointwise w4a8 layers of the SD UNet at UNet batch 128: tile kernels (1..4) vs the register-direct-epilogue kernel (6)."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+import tfmq_dm_amd.ops as ops
+dev = torch.device("cuda", 0)
+B = int(os.environ.get("BATCH", "128"))
+# (tokens per image, Cin, Cout, mode)
+shapes = [(4096, 320, 2560, "geglu"), (4096, 320, 320, "f16res"), (4096, 1280, 320, "f16res"), (4096, 320, 320, "f16"),
+          (1024, 640, 5120, "geglu"), (1024, 640, 640, "f16res"), (1024, 2560, 640, "f16res"),
+          (256, 1280, 10240, "geglu"), (256, 1280, 1280, "f16res"), (256, 5120, 1280, "f16res"), (4096, 1280, 320, "q8res")]
+gen = torch.Generator().manual_seed(0)
+qt = torch.tensor([[[0.05, 120.0]]], device=dev)
+sel = ops.qsel(qt)
+for (T, cin, cout, mode) in shapes:
+    xq = torch.randint(-128, 128, (B, T, 1, cin), dtype=torch.int8, device=dev)
+    w = (torch.randn(cout, cin, generator=gen) * 0.02).to(dev)
+    qp = ops.minmax_to_qparam(ops.minmax(w, cout), 16)
+    pw = ops.pack_w4(w, qp[:, 0].contiguous(), qp[:, 1].contiguous(), None, torch.zeros(cout, device=dev))
+    kw = {}
+    if mode == "geglu":
+        kw["geglu_oq"] = sel
+    elif mode.startswith("q8"):
+        kw["out_q8"] = sel
+    else:
+        kw["out_f16"] = True
+    if mode.endswith("res"):
+        kw["residual"] = torch.randn(B, T, 1, cout, device=dev).half()
+    nops = 2.0 * B * T * cout * cin
+    line = f"{B}x{T} {cin}->{cout} {mode}:"
+    ref = None
+    for tile in (1, 2, 3, 4, 6):
+        orig = ops._tune_conv
+        ops.set_conv_autotune({})
+        ops._tune_conv = lambda h, name, kind, d, dsc, t=tile: t
+        try:
+            y = ops.conv2d_w4a8(xq, pw, sel, **kw)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(5):
+                y = ops.conv2d_w4a8(xq, pw, sel, **kw)
+            e1.record()
+            torch.cuda.synchronize()
+            us = e0.elapsed_time(e1) / 5 * 1e3
+        finally:
+            ops._tune_conv = orig
+            ops.set_conv_autotune(None)
+        if ref is None:
+            ref = y.clone()
+        line += f"  t{tile}: {us:7.1f} us{'' if torch.equal(y, ref) else ' MISMATCH'}"
+    print(line, flush=True)

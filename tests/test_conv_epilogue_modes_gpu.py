@@ -173,7 +173,7 @@ def test_tile_variants_are_bit_identical(ops, k, res, mode, B, H):
         y = ops.conv2d_w4a8(xq, pw, sel, **kw)
     finally:
         ops.set_conv_autotune(None)
-    assert len(cache) == 1 and list(cache.values())[0] in (1, 2, 3, 4)
+    assert len(cache) == 1 and list(cache.values())[0] in (1, 2, 3, 4, 5, 6)
     assert torch.equal(y, outs[0][0])
 
 
@@ -292,6 +292,54 @@ def test_f16_stream_epilogue_equals_rounded_f32_epilogue(ops, k, B, H, cin, cout
             _o._tune_conv = orig
             ops.set_conv_autotune(None)
         assert torch.equal(yq, q_ref), tile
+
+
+@pytest.mark.parametrize("T,cin,cout,mode", [(4096, 320, 320, "f16res"), (1000, 64, 192, "f16"), (520, 1280, 320, "q8res"),
+                                              (300, 128, 100, "q8"), (777, 320, 2560, "geglu"), (256, 640, 5120, "geglu")])
+def test_direct_pointwise_kernel_is_bit_identical_to_the_tile_kernels(ops, T, cin, cout, mode):
+    """The pointwise kernel with the register-direct epilogue (TFMQ_TILE_DIRECT: swapped MFMA operands, a lane owns 4
+    consecutive channels of one pixel, no LDS staging) against the 128x128 tile kernel: fp16 output (+ fp16 residual),
+    int8 output (+ residual), fused GEGLU -> int8; ragged rows and columns."""
+    import tfmq_dm_amd.ops as _o
+    B = 2
+    g = torch.Generator().manual_seed(cin + cout)
+    x = torch.randn(B, T, 1, cin, generator=g) * 1.3 - 0.2
+    w = torch.randn(cout, cin, generator=g) * (2.0 / cin ** 0.5)
+    b = torch.randn(cout, generator=g) * 0.2
+    wd, wz = O.init_channelwise(w, 16, "minmax")
+    ad, az = O.minmax(x, 256)
+    sel = ops.qsel(qtab(ad, az))
+    oq = ops.qsel(qtab(0.05, 121.0))
+    xq = ops.quantize_act(x.to(DEV), sel)
+    kw = {}
+    if mode == "geglu":
+        perm = ops.geglu_perm(cout // 2, DEV)
+        pw = ops.pack_w4(w.to(DEV)[perm].contiguous(), wd.to(DEV).reshape(-1)[perm].contiguous(), wz.to(DEV).reshape(-1)[perm].contiguous(),
+                         bias=b.to(DEV)[perm].contiguous())
+        kw["geglu_oq"] = oq
+    else:
+        pw = ops.pack_w4(w.to(DEV), wd.to(DEV), wz.to(DEV), bias=b.to(DEV))
+        if mode.startswith("f16"):
+            kw["out_f16"] = True
+        else:
+            kw["out_q8"] = oq
+        if mode.endswith("res"):
+            kw["residual"] = torch.randn(B, T, 1, cout, generator=g).half().to(DEV)
+    outs = []
+    for tile in (1, 6):
+        ops.set_conv_autotune({})
+        orig = _o._tune_conv
+        try:
+            _o._tune_conv = lambda h, name, kind, d, dsc, t=tile: t
+            outs.append(ops.conv2d_w4a8(xq, pw, sel, **kw).clone())
+        finally:
+            _o._tune_conv = orig
+            ops.set_conv_autotune(None)
+    assert torch.equal(outs[0], outs[1])
+    if mode == "geglu":     # and against the arithmetic spelled out: x * gelu(gate) of the un-fused projection, then the quantizer
+        h = ops.conv2d_w4a8(xq, ops.pack_w4(w.to(DEV), wd.to(DEV), wz.to(DEV), bias=b.to(DEV)), sel)
+        ref = ops.geglu(h.reshape(B * T, cout), oq)[0].reshape(B, T, 1, cout // 2)
+        assert torch.equal(outs[1], ref)
 
 
 def test_f16_conv_tile_variants_are_bit_identical(ops):

@@ -1008,6 +1008,14 @@ static int launch_conv(tfmq_handle h, const tfmq_conv_desc* dd, void* stream) {
     big = big_ok && !small && d.out_mode == TFMQ_OUT_F16 && tiles128 >= 4L * h->cu_count;
   }
   if constexpr (INT8) {
+    // token Linears / 1x1 convs writing fp16, int8 or GEGLU-int8: the register-direct-epilogue kernel (conv_lin.hip)
+    if ((d.tile == TFMQ_TILE_AUTO || d.tile == TFMQ_TILE_DIRECT) && d.wmeta && d.wscale && d.aq.qtable &&
+        launch_conv_lin(h, p, as_stream(stream))) {
+      TFMQ_LAUNCH_CHECK(h);
+      return TFMQ_OK;
+    }
+  }
+  if constexpr (INT8) {
     // 3x3 / stride 1 / pad 1 on a grid that fills the chip: the slab kernel (conv_slab.hip), unless the caller pinned
     // another tile shape
     if ((d.tile == TFMQ_TILE_AUTO || d.tile == TFMQ_TILE_SLAB) && dma8 &&
