@@ -187,18 +187,19 @@ def setup_sd(args, dev, rank, log):
         def shp(n, v):
             return v.cpu().reshape((-1,) + (1,) * (sdc[n + ".weight"].dim() - 1))
         wqc = {n: {"delta": shp(n, q.delta), "zp": shp(n, q.zp), "alpha": None} for n, q in wq.items()}
-        cs = 1
-        xc = torch.randn(1, 4, 64, 64)
-        c1, u1 = torch.randn(1, 77, 768), torch.randn(1, 77, 768)
+        cs, ci = 2, 2          # 2 DDIM steps of 2 images (UNet batch 4 with guidance): bounded sample, host cores busy
+        xc = torch.randn(ci, 4, 64, 64)
+        c1, u1 = torch.randn(ci, 77, 768), torch.randn(ci, 77, 768)
         tsn, _, _ = O.ldm_ddim_schedule(O.ldm_alphas_cumprod(), S)
         with torch.no_grad():
             t0 = time.time()
             for i, stp in enumerate(list(np.flip(tsn))[:cs]):
-                t = torch.full((2,), int(stp), dtype=torch.long)
+                t = torch.full((2 * ci,), int(stp), dtype=torch.long)
                 aq = {n: (qt[i, j, 0], qt[i, j, 1]) for j, n in enumerate(act_names)}
                 O.ldm_unet_forward(sdc, dict(cfg), torch.cat([xc] * 2), t, torch.cat([u1, c1]), O.QuantSpec(wq=wqc, aq=aq))
             dt = time.time() - t0
-        return 1.0 / (dt / cs * S), f"1 image (UNet batch 2, CFG) x {cs} of the {S} DDIM steps = {dt:.1f}s, extrapolated to the full schedule"
+        return ci / (dt / cs * S), (f"{ci} images (UNet batch {2 * ci}, CFG) x {cs} of the {S} DDIM steps = {dt:.1f}s on {torch.get_num_threads()} "
+                                    "threads, extrapolated to the full schedule")
 
     def plms():
         """The README's SD recipe samples with PLMS (S + 1 UNet calls): reported beside the metric, one
@@ -214,8 +215,31 @@ def setup_sd(args, dev, rank, log):
         return {"images_per_s": round(batch / dt, 3), "unet_evals": S + 1, "finite": bool(torch.isfinite(out).all().item()),
                 "sampler": "PLMS-50 (Adams-Bashforth 1-4), CFG 7.5, four captured step graphs"}
 
+    def sweep(batches=(1, 4, 8, 16, 32)):
+        """images/s by images per GPU (SURVEY 8d asks for 1-32; the metric batch itself is the timed region): one full DDIM-50
+        sampling per batch size on its own captured graph, after a warm one.  UNet forward time per step and the time the
+        int8 weight operand alone would need from HBM are printed beside it: below ~8 images the forward is bound by the
+        latency of its ~600 launches, not by weight bytes."""
+        out = {}
+        wbytes = sum(l.p.w8.numel() for l in eng.layers.values() if getattr(l.p, "w8", None) is not None)
+        for b in batches:
+            sp = GraphLatentDdimSampler(eng, S, b, (4, 64, 64), (77, 768), scale=scale, alphas_cumprod=alphas_cumprod_linear()).capture()
+            xb, cb, ub = x_T[:b].contiguous(), cond[:b].contiguous(), uncond[:b].contiguous()
+            sp.sample_nhwc(xb, cb, ub)
+            sp.stream.synchronize()
+            t0 = time.perf_counter()
+            sp.sample_nhwc(xb, cb, ub)
+            sp.stream.synchronize()
+            dt = time.perf_counter() - t0
+            out[str(b)] = {"images_per_s": round(b / dt, 3), "ms_per_unet_forward": round(dt / S * 1e3, 3)}
+            del sp
+            torch.cuda.empty_cache()
+        out["int8_weight_operand_MB"] = round(wbytes / 1e6, 1)
+        out["weight_stream_floor_ms_at_5TBps"] = round(wbytes / 5e12 * 1e3, 3)
+        return out
+
     info = dict(batch=batch, sync=sampler.stream.synchronize, finite=lambda: bool(torch.isfinite(sampler.x).all().item()),
-                stream=sampler.stream, step=eng.step, plms=plms,
+                stream=sampler.stream, step=eng.step, plms=plms, sweep=sweep,
                 oracle_state=dict(sd=sd, wq=wq, act_names=act_names, cfg=cfg, eng=eng),     # scratch/sd_parity_full.py
                 workload=("Stable Diffusion v1-4 UNet (859.5M) w4a8 on MI355X: 64x64x4 latents (512x512 images), DDIM-50 eta=0, "
                           f"CFG 7.5 (UNet batch 2x{batch}), 77x768 context, {batch} images per GPU (BASELINE.json configs[3] = the metric's config)"),
@@ -335,6 +359,100 @@ def calibration_sharded(dev, world):
     return res
 
 
+def run_cali_workload(args, dev, rank, local_rank, world, log):
+    """`--workload cali`: the calibration half of the metric as ONE measured job -- `cali_model` (N = 1) or `cali_model_multi`
+    (N > 1: per-timestep-group shards, one RCCL SUM all-reduce per AdaRound iteration through the C ABI, all-averaged
+    activation deltas) end to end on the full SD v1 UNet (859.5 M, random init): weight-scale search, TIAR, every block and
+    single-layer reconstruction unit, Finite-Set activation calibration, checkpoint.  The recipe is the README's with the
+    calibration set and the iteration count cut so that the run takes minutes (`--cali-iters`, `--cali-samples`,
+    `--cali-groups`); the line says what was run and scales nothing."""
+    import collections, tempfile
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "tfmq-dm_amd"))      # the drop-in module names (`quant`, `linklink`), as the reference's scripts import them
+    from tfmq_dm_amd.ldm.unet import UNetModel, SD_V1_UNET
+    from quant.quant_layer import QMODE, Scaler
+    import quant.calibration as QC, quant.reconstruction as QR
+    from quant.reconstruction_util import RLOSS
+    N, G, ITERS = args.cali_samples, args.cali_groups, args.cali_iters
+    torch.manual_seed(1234)
+    m = UNetModel(**SD_V1_UNET)
+    g = torch.Generator().manual_seed(7)
+    with torch.no_grad():
+        for p in m.parameters():
+            if p.numel() and float(p.abs().max()) == 0.0:
+                p.copy_(torch.randn(p.shape, generator=g) * 0.02)
+    m = m.to(dev)
+    wq = {"bits": 4, "channel_wise": True, "scaler": Scaler.MINMAX}
+    aq = {"bits": 8, "channel_wise": False, "scaler": Scaler.MINMAX, "leaf_param": True}
+    xs = torch.randn(G * N, 4, 64, 64, generator=g)
+    ts = torch.cat([torch.full((N,), float(t)) for t in np.linspace(981, 1, G).astype(int)])
+    cs = torch.randn(G * N, 77, 768, generator=g)
+    path = os.path.join(tempfile.mkdtemp(), "sd_w4a8.pth")
+    acc, calls = collections.defaultdict(float), collections.Counter()
+
+    def timed(mod, name):
+        f = getattr(mod, name)
+
+        def g_(*a, **k):
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            r = f(*a, **k)
+            torch.cuda.synchronize()
+            acc[name] += time.perf_counter() - t
+            calls[name] += 1
+            return r
+        setattr(mod, name, g_)
+    for mod, name in ((QC, "tib_reconstruction"), (QC, "block_reconstruction"), (QC, "layer_reconstruction"), (QC, "_calibrate_activations")):
+        timed(mod, name)
+    kw = dict(iters=ITERS, batch_size=8, w=0.01, asym=True, warmup=0.2, opt_mode=RLOSS.MSE)
+    torch.cuda.synchronize()
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+    t0 = time.perf_counter()
+    if world > 1:
+        kw.update(wq_params=wq, aq_params=aq, aq_mode=[QMODE.NORMAL.value, QMODE.QDIFF.value], multi_gpu=True)
+        QC.cali_model_multi(local_rank, "nccl", world, "env://", 0, world, m, True, path, (xs, ts, cs), (xs, ts, cs), N, True, kw)
+    else:
+        from quant.quant_model import QuantModel
+        qnn = QuantModel(m, wq, aq, cali=True, aq_mode=[QMODE.NORMAL.value, QMODE.QDIFF.value]).eval()
+        md = QC.cali_model(qnn, (xs, ts, cs), (xs, ts, cs), use_aq=True, path=path, running_stat=True, interval=N, multi_gpu=False, **kw)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    if rank != 0:
+        return None
+    ck = torch.load(path, map_location="cpu")
+    n_units = calls["tib_reconstruction"] + calls["block_reconstruction"] + calls["layer_reconstruction"]
+    rec_s = acc["tib_reconstruction"] + acc["block_reconstruction"] + acc["layer_reconstruction"]
+    finite = all(bool(torch.isfinite(v).all()) for v in ck["weight"].values() if torch.is_tensor(v) and v.is_floating_point())
+    return {
+        "metric": "w4a8 calibration wall-clock, SD-v1-4 UNet (reduced recipe, see config)", "value": round(dt, 2), "unit": "s",
+        "n_gpus": world, "steps": 1, "warmup": 0, "ms_per_step": round(dt * 1e3, 1), "higher_is_better": False,
+        "scaling": "strong" if world > 1 else "weak", "vs_baseline": None,
+        "dtype": "f32 (AdaRound iterations: exact fp32 GEMMs) + int8/f16 (capture forwards)", "data": "synthetic",
+        "config": {"workload": (f"cali_model{'_multi' if world > 1 else ''} on the SD v1-4 UNet (859.5M, random init): {G} timestep groups x {N} "
+                                f"samples, {ITERS} AdaRound iterations per unit at mini-batch 8/rank (the recipe: 25 groups x 512, 20000), "
+                                "w4 channel-wise + a8 Finite-Set, running_stat"),
+                   "parallelism": "single GPU" if world == 1 else f"timestep-group shards x{world}, one RCCL SUM all-reduce per iteration"},
+        "finite": finite,
+        "calibration": {"measured": True, "wall_clock_s": round(dt, 2), "reconstruction_units": n_units,
+                        "iterations_per_unit": ITERS, "adaround_iterations_per_s": round(n_units * ITERS / max(rec_s, 1e-9), 1),
+                        "phases_s": {"tib_reconstruction": round(acc["tib_reconstruction"], 2),
+                                     "block_reconstruction (incl. input/target capture)": round(acc["block_reconstruction"], 2),
+                                     "layer_reconstruction (incl. capture)": round(acc["layer_reconstruction"], 2),
+                                     "finite_set_activation_calibration": round(acc["_calibrate_activations"], 2)},
+                        "adaround_tensors": sum(1 for k in ck["weight"] if k.endswith("alpha")),
+                        "act_groups": len([k for k in ck if k.startswith("act_")]),
+                        "checkpoint_MB": round(os.path.getsize(path) / 1e6, 1)},
+    }
+
+
 def sd_first_stage_state(gen):
     """Random-init state dict of the SD v1 KL-f8 first stage's decode side (ch 128, mult 1-2-4-4, 2 res blocks)."""
     sd = {}
@@ -433,7 +551,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", choices=["sd", "cifar"], default="sd")
+    ap.add_argument("--workload", choices=["sd", "cifar", "cali"], default="sd")
+    ap.add_argument("--cali-iters", type=int, default=100, help="--workload cali: AdaRound iterations per unit (recipe: 20000)")
+    ap.add_argument("--cali-samples", type=int, default=32, help="--workload cali: samples per timestep group (recipe: 512)")
+    ap.add_argument("--cali-groups", type=int, default=2, help="--workload cali: timestep groups (recipe: 25)")
     ap.add_argument("--batch", type=int, default=0, help="images per GPU (default 64 for sd, 256 for cifar)")
     ap.add_argument("--ddim-steps", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -472,6 +593,15 @@ def main():
         if rank == 0:
             print("[bench]", *a, file=sys.stderr, flush=True)
 
+    if args.workload == "cali":
+        out = run_cali_workload(args, dev, rank, local_rank, world, log)
+        if rank == 0:
+            print(json.dumps(out), flush=True)
+        if dist is not None:
+            dist.barrier()
+            link.destroy_comm()
+            dist.destroy_process_group()
+        return
     run, fwd, cpu, info = (setup_sd if args.workload == "sd" else setup_cifar)(args, dev, rank, log)
 
     def barrier():
@@ -563,6 +693,12 @@ def main():
             cali.update(calibration_sample(dev))
             cali["first_stage_decode"] = first_stage_sample(dev)
             cali["plms"] = info["plms"]()
+            mpath = os.path.join(ROOT, "profiles", "r02_cifar_calibration_full.json")
+            if os.path.exists(mpath):       # the whole CIFAR recipe, measured once end to end with this code (scratch/cifar_cali_full.py)
+                mj = json.load(open(mpath))
+                cali["measured_full_recipe_cifar"] = {k: mj[k] for k in ("recipe", "wall_clock_s", "phases_s", "reconstruction_units",
+                                                                       "iterations_per_unit", "ms_per_iteration_all_units") if k in mj}
+                cali["measured_full_recipe_cifar"]["source"] = "profiles/r02_cifar_calibration_full.json"
         cfgd = {"workload": info["workload"], "parallelism": f"replicas x{world} (no data-path collective)"}
         cfgd.update(info["extra"])
         out = {
@@ -574,6 +710,8 @@ def main():
             "data": "synthetic: N(0,1) latents / context, random-init weights (zero params re-drawn N(0,0.02^2)), synthetic FSC tables",
             "config": cfgd, "finite": finite, "roofline": roof, "cpu_baseline": cpu_b, "calibration": cali,
         }
+        if world == 1 and args.workload == "sd" and not args.no_cpu_baseline and args.batch in (0, 64) and "sweep" in info:
+            out["batch_sweep"] = info["sweep"]()
         emit(out)
     if dist is not None:
         dist.barrier()

@@ -151,10 +151,7 @@ __global__ __launch_bounds__(256) void k_attention(AttnP p) {
       if (p.out) *reinterpret_cast<float4*>(p.out + tok * p.ldo + hd * d + dc) = v;
       if (quant) {
         char4 c;
-        c.x = static_cast<signed char>(static_cast<int>(quant_index_f(v.x, qp.x, qp.y, 255.0f)) - 128);
-        c.y = static_cast<signed char>(static_cast<int>(quant_index_f(v.y, qp.x, qp.y, 255.0f)) - 128);
-        c.z = static_cast<signed char>(static_cast<int>(quant_index_f(v.z, qp.x, qp.y, 255.0f)) - 128);
-        c.w = static_cast<signed char>(static_cast<int>(quant_index_f(v.w, qp.x, qp.y, 255.0f)) - 128);
+        c = quant_char4(v.x, v.y, v.z, v.w, make_quantp(qp));
         *reinterpret_cast<char4*>(p.yq + tok * (static_cast<size_t>(p.heads) * d) + hd * d + dc) = c;
       }
     }

@@ -107,6 +107,57 @@ __device__ __forceinline__ float quant_index_f(float x, float delta, float zp, f
   return fminf(fmaxf(q, 0.0f), lmax);
 }
 
+// ---- the 8-bit activation quantizer on packed fp32 (v_pk_mul / v_pk_fma / v_pk_add: two lanes of arithmetic per
+// instruction) with the byte packing done by v_cvt_pk_u8_f32.  Same arithmetic, operation for operation, as
+// quant_index_f (every packed operation is the IEEE operation on each half), so the bins are bit-identical; what changes
+// is the instruction count: 4 bins = 10 packed + 4 rndne + 4 med3 + 4 cvt_pk + 1 xor instead of ~60 scalar-lane ones.
+// Epilogues that apply a transcendental and the quantizer to every output (GEGLU) are VALU-bound, not MFMA-bound.
+typedef float f2 __attribute__((ext_vector_type(2)));
+struct QuantP {
+  float d, r, zp;   // delta, RN(1 / delta) (one true division per kernel), zero point
+  bool bad;         // delta's significand is all ones: the one divisor the reciprocal-refinement does not cover
+};
+__device__ __forceinline__ QuantP make_quantp(float2 qp) {
+  QuantP q;
+  q.d = qp.x;
+  q.zp = qp.y;
+  q.r = 1.0f / qp.x;
+  q.bad = (__float_as_uint(qp.x) & 0x7fffffu) == 0x7fffffu;
+  return q;
+}
+__device__ __forceinline__ f2 pk_fma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+// RN(x / delta) for both halves (div_rn_f's sequence)
+template <bool EXACT_DIV>
+__device__ __forceinline__ f2 quant_quot2(f2 x, const QuantP& p) {
+  if constexpr (EXACT_DIV) return f2{x.x / p.d, x.y / p.d};
+  const f2 r = {p.r, p.r}, d = {p.d, p.d};
+  f2 q = x * r;
+  q = pk_fma(pk_fma(-q, d, x), r, q);
+  q = pk_fma(pk_fma(-q, d, x), r, q);
+  return q;
+}
+// four values -> their bins - 128 as the four bytes of a word (bins clamp to [0, 255])
+template <bool EXACT_DIV>
+__device__ __forceinline__ unsigned quant_pack4_t(f2 lo, f2 hi, const QuantP& p) {
+  const f2 z = {p.zp, p.zp};
+  f2 a = quant_quot2<EXACT_DIV>(lo, p), b = quant_quot2<EXACT_DIV>(hi, p);
+  a = f2{__builtin_rintf(a.x), __builtin_rintf(a.y)} + z;
+  b = f2{__builtin_rintf(b.x), __builtin_rintf(b.y)} + z;
+  unsigned w = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_amdgcn_fmed3f(a.x, 0.0f, 255.0f), 0, 0u);
+  w = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_amdgcn_fmed3f(a.y, 0.0f, 255.0f), 1, w);
+  w = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_amdgcn_fmed3f(b.x, 0.0f, 255.0f), 2, w);
+  w = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_amdgcn_fmed3f(b.y, 0.0f, 255.0f), 3, w);
+  return w ^ 0x80808080u;
+}
+__device__ __forceinline__ unsigned quant_pack4(float a, float b, float c, float e, const QuantP& p) {
+  if (__builtin_expect(p.bad, 0)) return quant_pack4_t<true>(f2{a, b}, f2{c, e}, p);
+  return quant_pack4_t<false>(f2{a, b}, f2{c, e}, p);
+}
+__device__ __forceinline__ char4 quant_char4(float a, float b, float c, float e, const QuantP& p) {
+  const unsigned w = quant_pack4(a, b, c, e, p);
+  return *reinterpret_cast<const char4*>(&w);
+}
+
 __device__ __forceinline__ float wave_reduce_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -150,8 +201,37 @@ __device__ __forceinline__ float erf_fast_f(float x) {
   const float e = __builtin_amdgcn_exp2f(-1.44269504088896340736f * ax * ax);
   return copysignf(__builtin_fmaf(-pl, e, 1.0f), x);
 }
-// gelu(g) = 0.5 g (1 + erf(g / sqrt 2))   (F.gelu default, "none" approximation)
-__device__ __forceinline__ float gelu_f(float g) { return 0.5f * g * (1.0f + erf_fast_f(g * 0.70710678118654752440f)); }
+// gelu(g) = g Phi(g), Phi(g) = 0.5 (1 + erf(g / sqrt 2))   (F.gelu default, "none" approximation), the same 7.1.26
+// polynomial arranged for the fewest instructions: h = Phi(-|g|) = 0.5 poly(t) exp(-g^2 / 2) with the halves folded into
+// the coefficients and 1/sqrt 2 into the constants, Phi = 0.5 + copysign(0.5 - h, g).  |error| <= 5e-7 absolute over
+// [-12, 12] (the arrangement above it: 4.7e-7).  gelu2 is the same operation sequence on packed fp32 -- bit-identical
+// halves -- for the GEMM epilogues.
+__device__ __forceinline__ float gelu_f(float g) {
+  const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(0.23164189f, fabsf(g), 1.0f));
+  float pl = __builtin_fmaf(0.5307027145f, t, -0.7265760135f);
+  pl = __builtin_fmaf(pl, t, 0.7107068705f);
+  pl = __builtin_fmaf(pl, t, -0.142248368f);
+  pl = __builtin_fmaf(pl, t, 0.127414796f);
+  pl *= t;
+  const float e = __builtin_amdgcn_exp2f((g * g) * -0.72134752044448170368f);
+  const float s = 0.5f - pl * e;
+  return g * (0.5f + copysignf(s, g));
+}
+__device__ __forceinline__ f2 gelu2(f2 g) {
+  const f2 one = {1.0f, 1.0f}, half = {0.5f, 0.5f};
+  const f2 ag = {fabsf(g.x), fabsf(g.y)};
+  const f2 dn = pk_fma(f2{0.23164189f, 0.23164189f}, ag, one);
+  const f2 t = {__builtin_amdgcn_rcpf(dn.x), __builtin_amdgcn_rcpf(dn.y)};
+  f2 pl = pk_fma(f2{0.5307027145f, 0.5307027145f}, t, f2{-0.7265760135f, -0.7265760135f});
+  pl = pk_fma(pl, t, f2{0.7107068705f, 0.7107068705f});
+  pl = pk_fma(pl, t, f2{-0.142248368f, -0.142248368f});
+  pl = pk_fma(pl, t, f2{0.127414796f, 0.127414796f});
+  pl = pl * t;
+  const f2 m = (g * g) * f2{-0.72134752044448170368f, -0.72134752044448170368f};
+  const f2 e = {__builtin_amdgcn_exp2f(m.x), __builtin_amdgcn_exp2f(m.y)};
+  const f2 s = half - pl * e;
+  return g * (half + f2{copysignf(s.x, g.x), copysignf(s.y, g.y)});
+}
 
 static inline int ceil_div(long a, long b) { return static_cast<int>((a + b - 1) / b); }
 

@@ -60,11 +60,7 @@ __device__ __forceinline__ int xcd_tile_id() {
 
 
 __device__ __forceinline__ unsigned pack_q4(float a, float b, float c, float e, float2 qp) {
-  const unsigned q0 = static_cast<unsigned>(static_cast<int>(quant_index_f(a, qp.x, qp.y, 255.0f)) - 128) & 0xffu;
-  const unsigned q1 = static_cast<unsigned>(static_cast<int>(quant_index_f(b, qp.x, qp.y, 255.0f)) - 128) & 0xffu;
-  const unsigned q2 = static_cast<unsigned>(static_cast<int>(quant_index_f(c, qp.x, qp.y, 255.0f)) - 128) & 0xffu;
-  const unsigned q3 = static_cast<unsigned>(static_cast<int>(quant_index_f(e, qp.x, qp.y, 255.0f)) - 128) & 0xffu;
-  return q0 | (q1 << 8) | (q2 << 16) | (q3 << 24);
+  return quant_pack4(a, b, c, e, make_quantp(qp));
 }
 __device__ __forceinline__ unsigned pack_h2(float a, float b) {
   const __half2 v = __floats2half2_rn(a, b);

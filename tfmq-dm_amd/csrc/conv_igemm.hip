@@ -236,7 +236,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, unsigned char* lds
           for (int q4 = 0; q4 < 4; ++q4) {
             const float4 a = *reinterpret_cast<const float4*>(ldsO + prow * LDO + g16 + 4 * q4);
             const float4 g = *reinterpret_cast<const float4*>(ldsO + prow * LDO + 64 + g16 + 4 * q4);
-            w[q4] = pack_q4(a.x * gelu_f(g.x), a.y * gelu_f(g.y), a.z * gelu_f(g.z), a.w * gelu_f(g.w), oqp);
+            const f2 o01 = f2{a.x, a.y} * gelu2(f2{g.x, g.y}), o23 = f2{a.z, a.w} * gelu2(f2{g.z, g.w});
+            w[q4] = pack_q4(o01.x, o01.y, o23.x, o23.y, oqp);
           }
           *reinterpret_cast<uint4*>(d.yq + static_cast<size_t>(m) * inner + (n0 >> 1) + g16) = make_uint4(w[0], w[1], w[2], w[3]);
         }
@@ -409,10 +410,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, unsigned char* lds
           *reinterpret_cast<uint2*>(reinterpret_cast<__half*>(d.y) + static_cast<size_t>(m) * d.ldy + d.y_coff + n) = u;
         } else if (q8) {     // the only consumer is the next QuantLayer's activation quantizer: write its bins
           char4 q;
-          q.x = static_cast<signed char>(static_cast<int>(quant_index_f(v.x, oqp.x, oqp.y, 255.0f)) - 128);
-          q.y = static_cast<signed char>(static_cast<int>(quant_index_f(v.y, oqp.x, oqp.y, 255.0f)) - 128);
-          q.z = static_cast<signed char>(static_cast<int>(quant_index_f(v.z, oqp.x, oqp.y, 255.0f)) - 128);
-          q.w = static_cast<signed char>(static_cast<int>(quant_index_f(v.w, oqp.x, oqp.y, 255.0f)) - 128);
+          q = quant_char4(v.x, v.y, v.z, v.w, make_quantp(oqp));
           *reinterpret_cast<char4*>(d.yq + static_cast<size_t>(m) * d.Cout + n) = q;
         } else {
           *reinterpret_cast<float4*>(d.y + static_cast<size_t>(m) * d.ldy + d.y_coff + n) = v;

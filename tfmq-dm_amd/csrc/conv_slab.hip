@@ -375,10 +375,7 @@ __global__ __launch_bounds__(512) void k_conv3_slab(SlabP sp) {
         }
         if (q8) {
           char4 q;
-          q.x = static_cast<signed char>(static_cast<int>(quant_index_f(v.x, oqp.x, oqp.y, 255.0f)) - 128);
-          q.y = static_cast<signed char>(static_cast<int>(quant_index_f(v.y, oqp.x, oqp.y, 255.0f)) - 128);
-          q.z = static_cast<signed char>(static_cast<int>(quant_index_f(v.z, oqp.x, oqp.y, 255.0f)) - 128);
-          q.w = static_cast<signed char>(static_cast<int>(quant_index_f(v.w, oqp.x, oqp.y, 255.0f)) - 128);
+          q = quant_char4(v.x, v.y, v.z, v.w, make_quantp(oqp));
           *reinterpret_cast<char4*>(d.yq + static_cast<size_t>(m) * d.Cout + n) = q;
         } else if (o16) {
           const __half2 lo = __floats2half2_rn(v.x, v.y), hi = __floats2half2_rn(v.z, v.w);

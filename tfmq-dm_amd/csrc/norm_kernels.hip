@@ -70,11 +70,13 @@ __device__ __forceinline__ void gn_apply_store(const GnP& p, size_t o, const flo
   }
   if (quant) {
     signed char q[V];
+    if constexpr (V != 4) {
 #pragma unroll
-    for (int i = 0; i < V; ++i)
-      q[i] = static_cast<signed char>(static_cast<int>(quant_index_f(y[i], qp.x, qp.y, 255.0f)) - 128);
+      for (int i = 0; i < V; ++i)
+        q[i] = static_cast<signed char>(static_cast<int>(quant_index_f(y[i], qp.x, qp.y, 255.0f)) - 128);
+    }
     if constexpr (V == 4) {
-      *reinterpret_cast<char4*>(d.yq + o) = make_char4(q[0], q[1], q[2], q[3]);
+      *reinterpret_cast<char4*>(d.yq + o) = quant_char4(y[0], y[1], y[2], y[3], make_quantp(qp));
     } else if constexpr (V == 2) {
       *reinterpret_cast<char2*>(d.yq + o) = make_char2(q[0], q[1]);
     } else {
@@ -331,10 +333,12 @@ __global__ __launch_bounds__(256) void k_gn_apply(tfmq_gn_desc d, const float* _
     }
     if (quant) {
       signed char qq[V];
+      if constexpr (V != 4) {
 #pragma unroll
-      for (int q = 0; q < V; ++q)
-        qq[q] = static_cast<signed char>(static_cast<int>(quant_index_f(y[q], qp.x, qp.y, 255.0f)) - 128);
-      if constexpr (V == 4) *reinterpret_cast<char4*>(d.yq + o) = make_char4(qq[0], qq[1], qq[2], qq[3]);
+        for (int q = 0; q < V; ++q)
+          qq[q] = static_cast<signed char>(static_cast<int>(quant_index_f(y[q], qp.x, qp.y, 255.0f)) - 128);
+      }
+      if constexpr (V == 4) *reinterpret_cast<char4*>(d.yq + o) = quant_char4(y[0], y[1], y[2], y[3], make_quantp(qp));
       else
 #pragma unroll
         for (int q = 0; q < V; ++q) d.yq[o + q] = qq[q];
@@ -409,14 +413,9 @@ __global__ __launch_bounds__(256) void k_gn_apply_h8(tfmq_gn_desc d, const float
     }
     if (quant) {
       unsigned w[2];
+      const QuantP qq = make_quantp(qp);
 #pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        unsigned acc = 0;
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-          acc |= (static_cast<unsigned>(static_cast<int>(quant_index_f(y[4 * h + q], qp.x, qp.y, 255.0f)) - 128) & 0xffu) << (8 * q);
-        w[h] = acc;
-      }
+      for (int h = 0; h < 2; ++h) w[h] = quant_pack4(y[4 * h], y[4 * h + 1], y[4 * h + 2], y[4 * h + 3], qq);
       *reinterpret_cast<uint2*>(d.yq + o) = make_uint2(w[0], w[1]);
     }
     if (d.yf) {

@@ -62,10 +62,7 @@ __global__ __launch_bounds__(256) void k_layernorm(const float* __restrict__ x, 
     if (yf) reinterpret_cast<float4*>(yf + row * Cc)[idx] = y;
     if (quant) {
       char4 q;
-      q.x = static_cast<signed char>(static_cast<int>(quant_index_f(y.x, qp.x, qp.y, 255.0f)) - 128);
-      q.y = static_cast<signed char>(static_cast<int>(quant_index_f(y.y, qp.x, qp.y, 255.0f)) - 128);
-      q.z = static_cast<signed char>(static_cast<int>(quant_index_f(y.z, qp.x, qp.y, 255.0f)) - 128);
-      q.w = static_cast<signed char>(static_cast<int>(quant_index_f(y.w, qp.x, qp.y, 255.0f)) - 128);
+      q = quant_char4(y.x, y.y, y.z, y.w, make_quantp(qp));
       reinterpret_cast<char4*>(yq + row * Cc)[idx] = q;
     }
   }
@@ -121,17 +118,12 @@ __global__ __launch_bounds__(256) void k_geglu(const float* __restrict__ hin, lo
     const float4 a = *reinterpret_cast<const float4*>(hin + m * 2 * I + c);
     const float4 g = *reinterpret_cast<const float4*>(hin + m * 2 * I + I + c);
     float4 y;
-    y.x = a.x * gelu_f(g.x);
-    y.y = a.y * gelu_f(g.y);
-    y.z = a.z * gelu_f(g.z);
-    y.w = a.w * gelu_f(g.w);
+    const f2 y01 = f2{a.x, a.y} * gelu2(f2{g.x, g.y}), y23 = f2{a.z, a.w} * gelu2(f2{g.z, g.w});
+    y = make_float4(y01.x, y01.y, y23.x, y23.y);
     if (yf) *reinterpret_cast<float4*>(yf + m * I + c) = y;
     if (quant) {
       char4 q;
-      q.x = static_cast<signed char>(static_cast<int>(quant_index_f(y.x, qp.x, qp.y, 255.0f)) - 128);
-      q.y = static_cast<signed char>(static_cast<int>(quant_index_f(y.y, qp.x, qp.y, 255.0f)) - 128);
-      q.z = static_cast<signed char>(static_cast<int>(quant_index_f(y.z, qp.x, qp.y, 255.0f)) - 128);
-      q.w = static_cast<signed char>(static_cast<int>(quant_index_f(y.w, qp.x, qp.y, 255.0f)) - 128);
+      q = quant_char4(y.x, y.y, y.z, y.w, make_quantp(qp));
       *reinterpret_cast<char4*>(yq + m * I + c) = q;
     }
     if (i + stride < i) break;      // 32-bit wrap of the item index

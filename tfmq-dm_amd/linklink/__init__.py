@@ -64,7 +64,8 @@ def destroy_comm():
 
 
 def init_process_group(backend="nccl", init_method=None, world_size=-1, rank=-1, **kw):
-    dist.init_process_group(backend=backend, init_method=init_method, world_size=world_size, rank=rank, **kw)
+    if not dist.is_initialized():      # a launcher (torchrun-style driver, bench.py) may have made the rendezvous already
+        dist.init_process_group(backend=backend, init_method=init_method, world_size=world_size, rank=rank, **kw)
     if str(backend).lower() == "nccl" and _torch.cuda.is_available():
         init_comm()
 
