@@ -179,12 +179,15 @@ typedef struct tfmq_conv_desc {
                                     TFMQ_TILE_SLAB: the 3x3 / stride-1 / pad-1 w4a8 kernel that stages the activation slab of a
                                     256-pixel tile once per channel chunk for all nine taps (256 x 320 / 256 / 128 tiles, 8 waves).
                                     TFMQ_TILE_DIRECT: pointwise w4a8 layers with fp16 / int8 / GEGLU-int8 output on the kernel whose
-                                    epilogue runs out of the accumulator registers (swapped MFMA operands, no LDS staging) */
+                                    epilogue runs out of the accumulator registers (swapped MFMA operands, no LDS staging).
+                                    TFMQ_TILE_STREAM: the same GEMM as persistent blocks -- a producer wave streams the LDS-DMA of
+                                    consecutive tiles through one ring, four consumer waves multiply and store (>= 3 K-steps,
+                                    residual only from the fp16 stream) */
   int32_t res_f16;               /* != 0: `residual` is an fp16 buffer [B][Ho][Wo][Cout] (a tensor of the fp16 activation stream:
                                     the TFMQ_OUT_F16 output of an earlier launch) */
 } tfmq_conv_desc;
 enum { TFMQ_OUT_F32 = 0, TFMQ_OUT_F16 = 1, TFMQ_OUT_GEGLU_Q8 = 2, TFMQ_OUT_Q8 = 3 };
-enum { TFMQ_TILE_AUTO = 0, TFMQ_TILE_128 = 1, TFMQ_TILE_64 = 2, TFMQ_TILE_256 = 3, TFMQ_TILE_128x64 = 4, TFMQ_TILE_SLAB = 5, TFMQ_TILE_DIRECT = 6 };
+enum { TFMQ_TILE_AUTO = 0, TFMQ_TILE_128 = 1, TFMQ_TILE_64 = 2, TFMQ_TILE_256 = 3, TFMQ_TILE_128x64 = 4, TFMQ_TILE_SLAB = 5, TFMQ_TILE_DIRECT = 6, TFMQ_TILE_STREAM = 7 };
 int tfmq_conv2d_w4a8(tfmq_handle h, const tfmq_conv_desc* d, void* stream);
 int tfmq_conv2d_f16(tfmq_handle h, const tfmq_conv_desc* d, void* stream);
 

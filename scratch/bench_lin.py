@@ -10,6 +10,10 @@ B = int(os.environ.get("BATCH", "128"))
 shapes = [(4096, 320, 2560, "geglu"), (4096, 320, 320, "f16res"), (4096, 1280, 320, "f16res"), (4096, 320, 320, "f16"),
           (1024, 640, 5120, "geglu"), (1024, 640, 640, "f16res"), (1024, 2560, 640, "f16res"),
           (256, 1280, 10240, "geglu"), (256, 1280, 1280, "f16res"), (256, 5120, 1280, "f16res"), (4096, 1280, 320, "q8res")]
+if os.environ.get("SHAPES") == "qkv":        # fused q|k|v projections: q|k fp16 rows + V^T
+    shapes = [(4096, 320, 960, "qkv"), (1024, 640, 1920, "qkv"), (256, 1280, 3840, "qkv"), (64, 1280, 3840, "qkv")]
+if os.environ.get("SHAPES") == "modes":      # one GEMM shape, the three epilogues: what the epilogue arithmetic / stores cost
+    shapes = [(4096, 320, 2560, "geglu"), (4096, 320, 2560, "q8"), (4096, 320, 2560, "f16"), (4096, 320, 1280, "q8"), (4096, 320, 1280, "f16")]
 gen = torch.Generator().manual_seed(0)
 qt = torch.tensor([[[0.05, 120.0]]], device=dev)
 sel = ops.qsel(qt)
@@ -19,7 +23,9 @@ for (T, cin, cout, mode) in shapes:
     qp = ops.minmax_to_qparam(ops.minmax(w, cout), 16)
     pw = ops.pack_w4(w, qp[:, 0].contiguous(), qp[:, 1].contiguous(), None, torch.zeros(cout, device=dev))
     kw = {}
-    if mode == "geglu":
+    if mode == "qkv":
+        kw["out_f16"], kw["t_col0"] = True, 2 * cin
+    elif mode == "geglu":
         kw["geglu_oq"] = sel
     elif mode.startswith("q8"):
         kw["out_q8"] = sel
@@ -30,7 +36,7 @@ for (T, cin, cout, mode) in shapes:
     nops = 2.0 * B * T * cout * cin
     line = f"{B}x{T} {cin}->{cout} {mode}:"
     ref = None
-    for tile in (1, 2, 3, 4, 6):
+    for tile in (1, 3, 4, 6, 7):
         orig = ops._tune_conv
         ops.set_conv_autotune({})
         ops._tune_conv = lambda h, name, kind, d, dsc, t=tile: t
@@ -47,6 +53,8 @@ for (T, cin, cout, mode) in shapes:
         finally:
             ops._tune_conv = orig
             ops.set_conv_autotune(None)
+        if isinstance(y, tuple):
+            y = y[1]                    # fused q|k|v: compare the transposed V part
         if ref is None:
             ref = y.clone()
         line += f"  t{tile}: {us:7.1f} us{'' if torch.equal(y, ref) else ' MISMATCH'}"

@@ -173,7 +173,7 @@ def test_tile_variants_are_bit_identical(ops, k, res, mode, B, H):
         y = ops.conv2d_w4a8(xq, pw, sel, **kw)
     finally:
         ops.set_conv_autotune(None)
-    assert len(cache) == 1 and list(cache.values())[0] in (1, 2, 3, 4, 5, 6)
+    assert len(cache) == 1 and list(cache.values())[0] in (1, 2, 3, 4, 5, 6, 7)
     assert torch.equal(y, outs[0][0])
 
 
@@ -295,7 +295,9 @@ def test_f16_stream_epilogue_equals_rounded_f32_epilogue(ops, k, B, H, cin, cout
 
 
 @pytest.mark.parametrize("T,cin,cout,mode", [(4096, 320, 320, "f16res"), (1000, 64, 192, "f16"), (520, 1280, 320, "q8res"),
-                                              (300, 128, 100, "q8"), (777, 320, 2560, "geglu"), (256, 640, 5120, "geglu")])
+                                              (300, 128, 100, "q8"), (777, 320, 2560, "geglu"), (256, 640, 5120, "geglu"),
+                                              (40000, 320, 320, "f16res"), (9000, 320, 2560, "geglu"), (33000, 192, 200, "q8res"),
+                                              (20000, 640, 1920, "f16")])
 def test_direct_pointwise_kernel_is_bit_identical_to_the_tile_kernels(ops, T, cin, cout, mode):
     """The pointwise kernel with the register-direct epilogue (TFMQ_TILE_DIRECT: swapped MFMA operands, a lane owns 4
     consecutive channels of one pixel, no LDS staging) against the 128x128 tile kernel: fp16 output (+ fp16 residual),
@@ -326,8 +328,8 @@ def test_direct_pointwise_kernel_is_bit_identical_to_the_tile_kernels(ops, T, ci
         if mode.endswith("res"):
             kw["residual"] = torch.randn(B, T, 1, cout, generator=g).half().to(DEV)
     outs = []
-    for tile in (1, 6):
-        ops.set_conv_autotune({})
+    for tile in (1, 6, 7):      # 7 = TFMQ_TILE_STREAM: persistent blocks, producer wave + four consumer waves (several tiles per block
+        ops.set_conv_autotune({})       # in the large cases; fewer than 3 K-steps falls back to the tile kernel)
         orig = _o._tune_conv
         try:
             _o._tune_conv = lambda h, name, kind, d, dsc, t=tile: t
@@ -336,10 +338,41 @@ def test_direct_pointwise_kernel_is_bit_identical_to_the_tile_kernels(ops, T, ci
             _o._tune_conv = orig
             ops.set_conv_autotune(None)
     assert torch.equal(outs[0], outs[1])
+    assert torch.equal(outs[0], outs[2])
     if mode == "geglu":     # and against the arithmetic spelled out: x * gelu(gate) of the un-fused projection, then the quantizer
         h = ops.conv2d_w4a8(xq, ops.pack_w4(w.to(DEV), wd.to(DEV), wz.to(DEV), bias=b.to(DEV)), sel)
         ref = ops.geglu(h.reshape(B * T, cout), oq)[0].reshape(B, T, 1, cout // 2)
         assert torch.equal(outs[1], ref)
+
+
+@pytest.mark.parametrize("B,T,C", [(2, 1024, 128), (3, 4096, 320), (1, 64, 640), (2, 100, 128)])
+def test_direct_kernel_transposed_region_is_bit_identical(ops, B, T, C):
+    """Fused q|k|v projection: q|k as fp16 rows, V transposed ([B, C, T]: the attention kernel's V^T operand) -- the
+    register-direct pointwise kernel (lane = pixel: one channel's 32 pixels are 64 contiguous bytes per store) against the
+    tile kernel's LDS-staged transposed pass; T a multiple of 4 only."""
+    import tfmq_dm_amd.ops as _o
+    g = torch.Generator().manual_seed(C + T)
+    x = torch.randn(B, T, 1, C, generator=g)
+    w = torch.randn(3 * C, C, generator=g) * (2.0 / C ** 0.5)
+    wd, wz = O.init_channelwise(w, 16, "minmax")
+    ad, az = O.minmax(x, 256)
+    sel = ops.qsel(qtab(ad, az))
+    xq = ops.quantize_act(x.to(DEV), sel)
+    pw = ops.pack_w4(w.to(DEV), wd.to(DEV), wz.to(DEV), bias=None)
+    t0 = 2 * C if (2 * C) % 128 == 0 else 256
+    outs = []
+    for tile in (1, 6):
+        ops.set_conv_autotune({})
+        orig = _o._tune_conv
+        try:
+            _o._tune_conv = lambda h, name, kind, d, dsc, t=tile: t
+            y, yt = ops.conv2d_w4a8(xq, pw, sel, out_f16=True, t_col0=t0)
+            outs.append((y[..., :t0].clone(), yt.clone()))
+        finally:
+            _o._tune_conv = orig
+            ops.set_conv_autotune(None)
+    assert torch.equal(outs[0][0], outs[1][0])
+    assert torch.equal(outs[0][1], outs[1][1])
 
 
 def test_f16_conv_tile_variants_are_bit_identical(ops):

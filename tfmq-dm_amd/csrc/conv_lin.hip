@@ -16,10 +16,157 @@
 // TFMQ_OUT_GEGLU_Q8.  Same int32 sums and the same epilogue arithmetic as k_conv_dma: bit-identical outputs.
 #include "conv_common.hpp"
 #include <type_traits>
+#ifdef TFMQ_PHASE_TIMERS
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#endif
 
 namespace {
 
 enum { LIN_F16 = 0, LIN_Q8 = 1, LIN_GEGLU = 2 };
+
+// diagnostics build (-DTFMQ_PHASE_TIMERS): cycles a wave of k_lin_stream spends in each phase of its loop, per block
+#ifdef TFMQ_PHASE_TIMERS
+#define TFMQ_T0() unsigned long long t_acc[3] = {0, 0, 0}; unsigned long long t_last = wall_clock64()
+#define TFMQ_TACC(i) do { const unsigned long long t_now = wall_clock64(); t_acc[i] += t_now - t_last; t_last = t_now; } while (0)
+#define TFMQ_TDUMP(off, n) do { if (p.dbg && lane == 0) for (int i_ = 0; i_ < (n); ++i_) p.dbg[blockIdx.x * 8 + (off) + i_] = t_acc[i_]; } while (0)
+#else
+#define TFMQ_T0() do { } while (0)
+#define TFMQ_TACC(i) do { } while (0)
+#define TFMQ_TDUMP(off, n) do { } while (0)
+#endif
+
+// Epilogue out of the accumulator registers (both pointwise kernels).  acc[i][j][4q + c] = channel ncol0(j) + 8q + 4h + c of
+// pixel (wm*2+i)*32 + lane%32; cs = this tile's table {scale[BN], zero-point correction[BN] (int bits), bias[BN]} in LDS.
+// Packed fp32 arithmetic (two outputs per VALU instruction); same operations as k_conv_dma's epilogue: bit-identical.
+// PHASE 0: everything.  PHASE 1: affine map + residual only, results left in `acc` as float bits.  PHASE 2: conversion
+// and stores of what phase 1 left (k_lin_stream puts the next tile's residual loads between the two).
+template <int MODE, int PHASE = 0>
+__device__ __forceinline__ void lin_epilogue(const ConvP& p, v16i (&acc)[2][2], const float* cs, uint2 (&rres)[2][2][4], bool has_res,
+                                             int m0, int n0, int wm, int wn, int lane, float2 oqp) {
+  constexpr int BN = 128;
+  const tfmq_conv_desc& d = p.d;
+  const int h = lane >> 5;
+  auto ncol0 = [&](int j) { return MODE == LIN_GEGLU ? j * 64 + wn * 32 : (wn * 2 + j) * 32; };
+  auto affine2 = [&](int a0, int a1, float sx, float sy, int kx, int ky, float bx, float by) -> f2 {
+    return f2{sx, sy} * f2{static_cast<float>(a0 + kx), static_cast<float>(a1 + ky)} + f2{bx, by};
+  };
+  const bool transposed = MODE == LIN_F16 && d.yt != nullptr && n0 >= d.t_col0;      // tile-uniform (t_col0 % 128 == 0)
+  auto epi = [&](auto exact_div) {
+    constexpr bool EX = decltype(exact_div)::value;
+    const QuantP qP = make_quantp(oqp);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int m = m0 + (wm * 2 + i) * 32 + (lane & 31);
+      const bool mok = m < p.M;
+      const int thw = d.Ho * d.Wo;
+      const int tb = transposed ? m / thw : 0, tt = m - tb * thw;
+      if constexpr (MODE == LIN_GEGLU) {
+        const int inner = d.Cout >> 1;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int cv = ncol0(0) + 8 * q + 4 * h, cg = ncol0(1) + 8 * q + 4 * h;     // value / gate columns inside the tile
+          const float4 sv = *reinterpret_cast<const float4*>(cs + cv), sg = *reinterpret_cast<const float4*>(cs + cg);
+          const int4 kv = *reinterpret_cast<const int4*>(reinterpret_cast<const int*>(cs) + BN + cv);
+          const int4 kg = *reinterpret_cast<const int4*>(reinterpret_cast<const int*>(cs) + BN + cg);
+          const float4 bv = *reinterpret_cast<const float4*>(cs + 2 * BN + cv), bg = *reinterpret_cast<const float4*>(cs + 2 * BN + cg);
+          const f2 a01 = affine2(acc[i][0][4 * q + 0], acc[i][0][4 * q + 1], sv.x, sv.y, kv.x, kv.y, bv.x, bv.y);
+          const f2 a23 = affine2(acc[i][0][4 * q + 2], acc[i][0][4 * q + 3], sv.z, sv.w, kv.z, kv.w, bv.z, bv.w);
+          const f2 g01 = affine2(acc[i][1][4 * q + 0], acc[i][1][4 * q + 1], sg.x, sg.y, kg.x, kg.y, bg.x, bg.y);
+          const f2 g23 = affine2(acc[i][1][4 * q + 2], acc[i][1][4 * q + 3], sg.z, sg.w, kg.z, kg.w, bg.z, bg.w);
+          const unsigned w = quant_pack4_t<EX>(a01 * gelu2(g01), a23 * gelu2(g23), qP);
+          const int oc = (n0 >> 1) + wn * 32 + 8 * q + 4 * h;                           // output channel (of Cout / 2)
+          if (mok && oc < inner) *reinterpret_cast<unsigned*>(d.yq + static_cast<size_t>(m) * inner + oc) = w;
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int ct = ncol0(j) + 8 * q + 4 * h, n = n0 + ct;
+            f2 v01, v23;
+            if (PHASE != 2) {
+              const float4 sc = *reinterpret_cast<const float4*>(cs + ct);
+              const int4 kc = *reinterpret_cast<const int4*>(reinterpret_cast<const int*>(cs) + BN + ct);
+              const float4 bb = *reinterpret_cast<const float4*>(cs + 2 * BN + ct);
+              v01 = affine2(acc[i][j][4 * q + 0], acc[i][j][4 * q + 1], sc.x, sc.y, kc.x, kc.y, bb.x, bb.y);
+              v23 = affine2(acc[i][j][4 * q + 2], acc[i][j][4 * q + 3], sc.z, sc.w, kc.z, kc.w, bb.z, bb.w);
+              if (has_res) {
+                if (d.res_f16) {
+                  const float2 lo = __half22float2(*reinterpret_cast<const __half2*>(&rres[i][j][q].x));
+                  const float2 hi = __half22float2(*reinterpret_cast<const __half2*>(&rres[i][j][q].y));
+                  v01 += f2{lo.x, lo.y};
+                  v23 += f2{hi.x, hi.y};
+                } else if (mok && n < d.Cout) {
+                  const float4 a = *reinterpret_cast<const float4*>(d.residual + static_cast<size_t>(m) * d.Cout + n);
+                  v01 += f2{a.x, a.y};
+                  v23 += f2{a.z, a.w};
+                }
+              }
+            }
+            if (PHASE == 1) {        // combined values parked in the accumulator registers (the int32 sums are dead)
+              acc[i][j][4 * q + 0] = __float_as_int(v01.x);
+              acc[i][j][4 * q + 1] = __float_as_int(v01.y);
+              acc[i][j][4 * q + 2] = __float_as_int(v23.x);
+              acc[i][j][4 * q + 3] = __float_as_int(v23.y);
+              __builtin_amdgcn_sched_barrier(0);
+              continue;
+            }
+            if (PHASE == 2) {
+              v01 = f2{__int_as_float(acc[i][j][4 * q + 0]), __int_as_float(acc[i][j][4 * q + 1])};
+              v23 = f2{__int_as_float(acc[i][j][4 * q + 2]), __int_as_float(acc[i][j][4 * q + 3])};
+            }
+            if (mok && n < d.Cout) {
+              if constexpr (MODE == LIN_F16) {
+                if (transposed) {
+                  // yt[b][n - t_col0][t]: the 32 lanes of a half-wave hold 32 consecutive pixels of one channel -> every
+                  // 2-byte store instruction writes two contiguous 64-byte runs (channels n and n + 4)
+                  __half* dst = reinterpret_cast<__half*>(d.yt) + (static_cast<size_t>(tb) * (d.Cout - d.t_col0) + (n - d.t_col0)) * thw + tt;
+                  dst[0] = __float2half_rn(v01.x);
+                  dst[thw] = __float2half_rn(v01.y);
+                  dst[2 * static_cast<size_t>(thw)] = __float2half_rn(v23.x);
+                  dst[3 * static_cast<size_t>(thw)] = __float2half_rn(v23.y);
+                } else {
+                  *reinterpret_cast<uint2*>(reinterpret_cast<__half*>(d.y) + static_cast<size_t>(m) * d.ldy + d.y_coff + n) =
+                      make_uint2(pack_h2(v01.x, v01.y), pack_h2(v23.x, v23.y));
+                }
+              } else {
+                *reinterpret_cast<unsigned*>(d.yq + static_cast<size_t>(m) * d.Cout + n) = quant_pack4_t<EX>(v01, v23, qP);
+              }
+            }
+            __builtin_amdgcn_sched_barrier(0);      // one quad at a time: interleaving them all spilled the accumulators
+          }
+      }
+    }
+  };
+  if constexpr (MODE == LIN_F16) {
+    epi(std::false_type{});
+  } else {
+    if (__builtin_expect((__float_as_uint(oqp.x) & 0x7fffffu) == 0x7fffffu, 0)) epi(std::true_type{});
+    else epi(std::false_type{});
+  }
+}
+
+// this lane's residual values (fp16 stream) of tile (m0, n0), branch-free: clamped addresses
+template <int MODE>
+__device__ __forceinline__ void lin_load_res(const ConvP& p, uint2 (&rres)[2][2][4], int m0, int n0, int wm, int wn, int lane) {
+  const tfmq_conv_desc& d = p.d;
+  const int h = lane >> 5;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int m = m0 + (wm * 2 + i) * 32 + (lane & 31);
+    const int mc = m < p.M ? m : p.M - 1;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int n = n0 + (MODE == LIN_GEGLU ? j * 64 + wn * 32 : (wn * 2 + j) * 32) + 8 * q + 4 * h;
+        const int nc = n < d.Cout ? n : 0;
+        rres[i][j][q] = *reinterpret_cast<const uint2*>(reinterpret_cast<const __half*>(d.residual) + static_cast<size_t>(mc) * d.Cout + nc);
+      }
+  }
+}
 
 template <int MODE>
 __global__ __launch_bounds__(256, 3) void k_lin_direct(ConvP p) {
@@ -151,86 +298,217 @@ __global__ __launch_bounds__(256, 3) void k_lin_direct(ConvP p) {
   }
   __syncthreads();
 
-  // ---- epilogue out of the registers.  acc[i][j][4q + c] = channel ncol0(j) + 8q + 4h + c of pixel (wm*2+i)*32 + lane%32.
-  // Packed fp32 arithmetic (two outputs per VALU instruction: the GEGLU epilogue -- 2 affine maps, the erf polynomial, exp,
-  // rcp and the quantizer per output -- is what bounds these layers, ~45 scalar-lane instructions per output before).
-  auto affine2 = [&](int a0, int a1, float sx, float sy, int kx, int ky, float bx, float by) -> f2 {
-    return f2{sx, sy} * f2{static_cast<float>(a0 + kx), static_cast<float>(a1 + ky)} + f2{bx, by};
-  };
-  auto epi = [&](auto exact_div) {
-    constexpr bool EX = decltype(exact_div)::value;
-    const QuantP qP = make_quantp(oqp);
+  lin_epilogue<MODE>(p, acc, cs, rres, has_res, m0, n0, wm, wn, lane, oqp);
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// K5q: the same GEMM as a PERSISTENT, warp-specialised pipeline.  Measured on k_lin_direct (scratch/lat_lin.py): a block
+// lives ~10 us for 0.5 us of MFMA work at K = 320 -- first-DMA latency, the K loop, store issue -- and three resident
+// blocks per CU cannot hide that chain: 3-4 us per tile and CU whatever the epilogue costs (halving its VALU work moved
+// nothing).  Here a block walks a contiguous range of tiles (N fastest: the A rows stay in L1 / L2) and
+//   * wave 4 is the producer: it alone issues the LDS-DMA of every (tile, K-step) of the block's flat step sequence, two
+//     steps ahead through a three-stage ring that runs ACROSS tile boundaries -- the first stages of tile t+1 land
+//     while tile t is in its epilogue.  Its vmcnt sees nothing but its own DMA (and the per-tile column constants it
+//     fetches one tile ahead and writes to a double-buffered LDS table), so the counted waits stay exact;
+//   * waves 0-3 are consumers: one raw s_barrier per step, MFMAs, then the register epilogue.  Their stores are never
+//     waited for (the in-order vmcnt of a wave that also issued DMA would make the next tile's first wait a wait for
+//     these stores); the fp16 residual values of tile t+1 are requested right after tile t's stores.
+// All five waves execute exactly one s_barrier per step.  Same sums, same epilogue arithmetic: bit-identical output.
+// RES: the launch has an fp16 residual (the variant that keeps 32 more registers and runs two blocks per CU)
+template <int MODE, bool RES>
+__global__ __launch_bounds__(320, RES ? 3 : 4) void k_lin_stream(ConvP p, int n_tiles) {
+  constexpr int BM = 128, BN = 128;
+  constexpr int STAGE = (BM + BN) * 64;
+  constexpr int NST = 3;
+  constexpr int NP = 16;                          // DMA pieces per step (all issued by the producer wave): 8 of A, 8 of B
+  constexpr int NC = 6;                           // constant loads per tile in the producer wave
+  constexpr int CS_BYTES = 3 * BN * 4;
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[NST * STAGE + 2 * CS_BYTES];
+
+  const tfmq_conv_desc& d = p.d;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nb = gridDim.x, b = xcd_tile_id();
+  const int t_begin = static_cast<int>(static_cast<long long>(n_tiles) * b / nb);
+  const int t_end = static_cast<int>(static_cast<long long>(n_tiles) * (b + 1) / nb);
+  const int ns = p.nsteps;
+  const int G = (t_end - t_begin) * ns;
+  if (G == 0) return;
+  const unsigned lds0 = static_cast<unsigned>(reinterpret_cast<uintptr_t>(lds));
+  float* const cs_base = reinterpret_cast<float*>(lds + NST * STAGE);
+
+  if (wid == 4) {
+    // ------------------------------------------------------------------------------------------------ producer
+    const unsigned char* xb = static_cast<const unsigned char*>(d.x);
+    const unsigned char* wb = static_cast<const unsigned char*>(d.w);
+    const int dcol = ((lane & 3) ^ ((lane >> 4) & 3)) * 16;
+    const float* biasp = d.bias ? d.bias : d.wscale;       // always a valid address: the number of loads is a constant
+    const float bias_on = d.bias ? 1.0f : 0.0f;
+    const float2 aqp = load_qparam(d.aq);
+    unsigned aoff[8], boff[8];
+    auto set_tile = [&](int t) {
+      const int tm = t / p.tiles_n, tn = t - tm * p.tiles_n;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int m = m0 + (wm * 2 + i) * 32 + (lane & 31);
-      const bool mok = m < p.M;
-      if constexpr (MODE == LIN_GEGLU) {
-        const int inner = d.Cout >> 1;
+      for (int it = 0; it < 8; ++it) {
+        int m = tm * BM + it * 16 + (lane >> 2);
+        m = m < p.M ? m : p.M - 1;                            // rows past M: any valid row (their outputs are never stored)
+        aoff[it] = static_cast<unsigned>(m) * static_cast<unsigned>(d.Cin) + dcol;
+        int n = tn * BN + it * 16 + (lane >> 2);
+        n = n < p.cout_pad ? n : p.cout_pad - 1;
+        boff[it] = (static_cast<unsigned>(n / 32) * ns * 32 + (n % 32)) * 64 + dcol;
+      }
+    };
+    auto issue = [&](int s, int stage) {
+      const unsigned sbase = lds0 + stage * STAGE;
+      const unsigned char* xs = xb + static_cast<size_t>(s) * 64;
+      const unsigned char* ws = wb + static_cast<size_t>(s) * 2048;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int cv = ncol0(0) + 8 * q + 4 * h, cg = ncol0(1) + 8 * q + 4 * h;     // value / gate columns inside the tile
-          const float4 sv = *reinterpret_cast<const float4*>(cs + cv), sg = *reinterpret_cast<const float4*>(cs + cg);
-          const int4 kv = *reinterpret_cast<const int4*>(reinterpret_cast<const int*>(cs) + BN + cv);
-          const int4 kg = *reinterpret_cast<const int4*>(reinterpret_cast<const int*>(cs) + BN + cg);
-          const float4 bv = *reinterpret_cast<const float4*>(cs + 2 * BN + cv), bg = *reinterpret_cast<const float4*>(cs + 2 * BN + cg);
-          const f2 a01 = affine2(acc[i][0][4 * q + 0], acc[i][0][4 * q + 1], sv.x, sv.y, kv.x, kv.y, bv.x, bv.y);
-          const f2 a23 = affine2(acc[i][0][4 * q + 2], acc[i][0][4 * q + 3], sv.z, sv.w, kv.z, kv.w, bv.z, bv.w);
-          const f2 g01 = affine2(acc[i][1][4 * q + 0], acc[i][1][4 * q + 1], sg.x, sg.y, kg.x, kg.y, bg.x, bg.y);
-          const f2 g23 = affine2(acc[i][1][4 * q + 2], acc[i][1][4 * q + 3], sg.z, sg.w, kg.z, kg.w, bg.z, bg.w);
-          const unsigned w = quant_pack4_t<EX>(a01 * gelu2(g01), a23 * gelu2(g23), qP);
-          const int oc = (n0 >> 1) + wn * 32 + 8 * q + 4 * h;                           // output channel (of Cout / 2)
-          if (mok && oc < inner) *reinterpret_cast<unsigned*>(d.yq + static_cast<size_t>(m) * inner + oc) = w;
+      for (int it = 0; it < 8; ++it) glds16(xs + aoff[it], sbase + it * 1024);
+#pragma unroll
+      for (int it = 0; it < 8; ++it) glds16(ws + boff[it], sbase + BM * 64 + it * 1024);
+    };
+    // column constants of a tile: lane l owns columns l and l + 64
+    int2 c_meta[2];
+    float c_ws[2], c_b[2];
+    auto load_consts = [&](int t) {
+      const int tn = t % p.tiles_n;
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        int n = tn * BN + c * 64 + lane;
+        n = n < d.Cout ? n : d.Cout - 1;
+        c_meta[c] = *reinterpret_cast<const int2*>(reinterpret_cast<const int4*>(d.wmeta) + n);
+        c_ws[c] = d.wscale[n];
+        c_b[c] = biasp[n];
+      }
+    };
+    const int za = static_cast<int>(aqp.y);
+    auto write_consts = [&](int t) {
+      float* cs = cs_base + (t & 1) * (3 * BN);
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        const int col = c * 64 + lane;
+        cs[col] = aqp.x * c_ws[c];
+        reinterpret_cast<int*>(cs)[BN + col] = (128 - za) * (c_meta[c].y - p.Ktot * c_meta[c].x);
+        cs[2 * BN + col] = c_b[c] * bias_on;
+      }
+    };
+
+    int t = t_begin, s = 0;                  // (tile, step) of global step g
+    int ti = t_begin, si = 0;                // (tile, step) of the next step to issue
+    load_consts(t_begin);
+    set_tile(ti);
+    issue(0, 0);
+    si = 1;
+    if (G > 1) {
+      issue(1, 1);                           // ns >= 3: still tile t_begin
+      si = 2;
+    }
+    int st_i = 2;
+    TFMQ_T0();
+    for (int g = 0; g < G; ++g) {
+      if (g + 2 >= G) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      else if (s == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NP + NC) : "memory");
+      else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NP) : "memory");
+      TFMQ_TACC(0);
+      if (g == 0) write_consts(t_begin);
+      else if (s == 2) write_consts(t + 1);          // table of the NEXT tile (harmless past the last tile)
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      TFMQ_TACC(1);
+      if (g + 2 < G) {
+        if (si == 0) set_tile(ti);
+        issue(si, st_i);
+        st_i = st_i == NST - 1 ? 0 : st_i + 1;
+        if (++si == ns) { si = 0; ++ti; }
+      }
+      if (s == 0) load_consts(t + 1 < t_end ? t + 1 : t);
+      if (++s == ns) { s = 0; ++t; }
+      TFMQ_TACC(2);
+    }
+    TFMQ_TDUMP(0, 3);
+    return;
+  }
+
+  // -------------------------------------------------------------------------------------------------- consumers
+  const int h = lane >> 5;
+  const int wm = wid >> 1, wn = wid & 1;
+  auto ncol0 = [&](int j) { return MODE == LIN_GEGLU ? j * 64 + wn * 32 : (wn * 2 + j) * 32; };
+  const int fsw = (h ^ ((lane >> 2) & 3)) << 4;
+  float2 oqp = make_float2(1.0f, 0.0f);
+  if constexpr (MODE != LIN_F16) oqp = load_qparam(d.oq);
+  constexpr bool has_res = RES;
+  uint2 rres[2][2][4];
+  if constexpr (RES) {
+    const int tm = t_begin / p.tiles_n, tn = t_begin - tm * p.tiles_n;
+    lin_load_res<MODE>(p, rres, tm * BM, tn * BN, wm, wn, lane);
+  }
+  int st_c = 0;
+  bool prev_full = false;
+  TFMQ_T0();
+  for (int t = t_begin; t < t_end; ++t) {
+    const int tm = t / p.tiles_n, tn = t - tm * p.tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+    v16i acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0;
+    for (int s = 0; s < ns; ++s) {
+      asm volatile("s_barrier" ::: "memory");
+      TFMQ_TACC(0);
+      const unsigned char* sa = lds + st_c * STAGE;
+      const unsigned char* sb = sa + BM * 64;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        v4i af[2], bf[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) af[i] = *reinterpret_cast<const v4i*>(sa + ((wm * 2 + i) * 32 + (lane & 31)) * 64 + (fsw ^ (ks << 5)));
+#pragma unroll
+        for (int j = 0; j < 2; ++j) bf[j] = *reinterpret_cast<const v4i*>(sb + (ncol0(j) + (lane & 31)) * 64 + (fsw ^ (ks << 5)));
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(bf[j], af[i], acc[i][j], 0, 0, 0);
+      }
+      st_c = st_c == NST - 1 ? 0 : st_c + 1;
+      TFMQ_TACC(1);
+    }
+    // the fragment reads of the last step must have left LDS before the barrier of the next step lets the producer
+    // overwrite that stage: they have -- the MFMAs above consumed them (lgkmcnt(0) is implied by the data dependence)
+    // A consumer never waits for its stores: their acknowledgement takes longer than a short-K tile's whole K loop.
+    // With a residual, the next tile's values are requested BEFORE this tile's stores (after the affine + residual phase
+    // has consumed the current ones), so the counted wait below -- everything but the youngest 16 operations, the stores
+    // of a full tile -- covers the loads and leaves the stores in flight.
+    if constexpr (!RES) {
+      lin_epilogue<MODE>(p, acc, cs_base + (t & 1) * (3 * BN), rres, false, m0, n0, wm, wn, lane, oqp);
+    } else {
+      {
+        if (prev_full) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        lin_epilogue<MODE, 1>(p, acc, cs_base + (t & 1) * (3 * BN), rres, true, m0, n0, wm, wn, lane, oqp);
+        if (t + 1 < t_end) {
+          const int t2 = t + 1, tm2 = t2 / p.tiles_n, tn2 = t2 - tm2 * p.tiles_n;
+          lin_load_res<MODE>(p, rres, tm2 * BM, tn2 * BN, wm, wn, lane);
         }
-      } else {
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const int ct = ncol0(j) + 8 * q + 4 * h, n = n0 + ct;
-            const float4 sc = *reinterpret_cast<const float4*>(cs + ct);
-            const int4 kc = *reinterpret_cast<const int4*>(reinterpret_cast<const int*>(cs) + BN + ct);
-            const float4 bb = *reinterpret_cast<const float4*>(cs + 2 * BN + ct);
-            f2 v01 = affine2(acc[i][j][4 * q + 0], acc[i][j][4 * q + 1], sc.x, sc.y, kc.x, kc.y, bb.x, bb.y);
-            f2 v23 = affine2(acc[i][j][4 * q + 2], acc[i][j][4 * q + 3], sc.z, sc.w, kc.z, kc.w, bb.z, bb.w);
-            if (has_res) {
-              if (d.res_f16) {
-                const float2 lo = __half22float2(*reinterpret_cast<const __half2*>(&rres[i][j][q].x));
-                const float2 hi = __half22float2(*reinterpret_cast<const __half2*>(&rres[i][j][q].y));
-                v01 += f2{lo.x, lo.y};
-                v23 += f2{hi.x, hi.y};
-              } else if (mok && n < d.Cout) {
-                const float4 a = *reinterpret_cast<const float4*>(d.residual + static_cast<size_t>(m) * d.Cout + n);
-                v01 += f2{a.x, a.y};
-                v23 += f2{a.z, a.w};
-              }
-            }
-            if (!mok || n >= d.Cout) continue;
-            if constexpr (MODE == LIN_F16) {
-              *reinterpret_cast<uint2*>(reinterpret_cast<__half*>(d.y) + static_cast<size_t>(m) * d.ldy + d.y_coff + n) =
-                  make_uint2(pack_h2(v01.x, v01.y), pack_h2(v23.x, v23.y));
-            } else {
-              *reinterpret_cast<unsigned*>(d.yq + static_cast<size_t>(m) * d.Cout + n) = quant_pack4_t<EX>(v01, v23, qP);
-            }
-            __builtin_amdgcn_sched_barrier(0);      // one quad at a time: interleaving them all spilled the accumulators
-          }
+        lin_epilogue<MODE, 2>(p, acc, cs_base + (t & 1) * (3 * BN), rres, true, m0, n0, wm, wn, lane, oqp);
+        prev_full = m0 + BM <= p.M && n0 + BN <= d.Cout;      // all 16 store instructions of this wave were issued
       }
     }
-  };
-  if constexpr (MODE == LIN_F16) {
-    epi(std::false_type{});
-  } else {
-    if (__builtin_expect((__float_as_uint(oqp.x) & 0x7fffffu) == 0x7fffffu, 0)) epi(std::true_type{});
-    else epi(std::false_type{});
+    TFMQ_TACC(2);
   }
+  if (wid == 0) TFMQ_TDUMP(4, 3);
 }
 
 }  // namespace
 
-bool launch_conv_lin(tfmq_handle h, ConvP& p, hipStream_t st) {
+bool launch_conv_lin(tfmq_handle h, ConvP& p, hipStream_t st, bool stream) {
   const tfmq_conv_desc& d = p.d;
   if (d.KH != 1 || d.KW != 1 || d.stride != 1 || d.up2x || d.pad_t != 0 || d.pad_l != 0 || d.Ho != d.H || d.Wo != d.W) return false;
   if (d.Cin % 64 != 0 || static_cast<size_t>(d.B) * d.H * d.W * d.Cin >= (static_cast<size_t>(1) << 31)) return false;
-  if (d.rowadd || d.stats || d.yt || (d.Cout & 3) != 0) return false;
+  if (d.rowadd || d.stats || (d.Cout & 3) != 0) return false;
+  if (d.yt && (d.out_mode != TFMQ_OUT_F16 || d.residual)) return false;
   int mode;
   if (d.out_mode == TFMQ_OUT_F16) {
     if (((d.ldy | d.y_coff) & 3) != 0) return false;
@@ -243,10 +521,42 @@ bool launch_conv_lin(tfmq_handle h, ConvP& p, hipStream_t st) {
   } else {
     return false;
   }
-  (void)h;
   p.tiles_n = (d.Cout + 127) / 128;
   const int tiles_m = (p.M + 127) / 128;
-  dim3 grid(static_cast<unsigned>(p.tiles_n) * tiles_m);
+  const int n_tiles = p.tiles_n * tiles_m;
+  const bool stream_ok = p.nsteps >= 3 && (!d.residual || d.res_f16) && static_cast<size_t>(p.cout_pad) * p.Ktot < (static_cast<size_t>(1) << 31);
+  if (stream && !stream_ok) return false;
+  if (stream) {
+    // persistent blocks: three per CU (51 KiB of LDS, five waves each), two for the residual variants (register budget)
+    const int per_cu = d.residual ? 2 : 3;
+    const int nblk = n_tiles < h->cu_count * per_cu ? n_tiles : h->cu_count * per_cu;
+    dim3 g2(static_cast<unsigned>(nblk));
+#ifdef TFMQ_PHASE_TIMERS
+    static unsigned long long* dbuf = nullptr;
+    if (!dbuf) (void)hipMalloc(reinterpret_cast<void**>(&dbuf), sizeof(unsigned long long) * 8 * 4096);
+    p.dbg = dbuf;
+#endif
+    const bool res = d.residual != nullptr;
+    if (mode == LIN_F16 && res) hipLaunchKernelGGL((k_lin_stream<LIN_F16, true>), g2, dim3(320), 0, st, p, n_tiles);
+    else if (mode == LIN_F16) hipLaunchKernelGGL((k_lin_stream<LIN_F16, false>), g2, dim3(320), 0, st, p, n_tiles);
+    else if (mode == LIN_Q8 && res) hipLaunchKernelGGL((k_lin_stream<LIN_Q8, true>), g2, dim3(320), 0, st, p, n_tiles);
+    else if (mode == LIN_Q8) hipLaunchKernelGGL((k_lin_stream<LIN_Q8, false>), g2, dim3(320), 0, st, p, n_tiles);
+    else hipLaunchKernelGGL((k_lin_stream<LIN_GEGLU, false>), g2, dim3(320), 0, st, p, n_tiles);
+#ifdef TFMQ_PHASE_TIMERS
+    if (getenv("TFMQ_PHASE_PRINT")) {
+      (void)hipStreamSynchronize(st);
+      std::vector<unsigned long long> hb(static_cast<size_t>(nblk) * 8);
+      (void)hipMemcpy(hb.data(), dbuf, hb.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+      double a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      for (int i = 0; i < nblk; ++i)
+        for (int k = 0; k < 8; ++k) a[k] += double(hb[i * 8 + k]) / nblk;
+      fprintf(stderr, "[lin_stream Cin%d Cout%d mode%d] blocks %d tiles %d steps/tile %d | producer: wait %.0f barrier %.0f issue %.0f | consumer: barrier %.0f mfma %.0f epilogue %.0f  (10 ns ticks per block)\n",
+              d.Cin, d.Cout, mode, nblk, n_tiles, p.nsteps, a[0], a[1], a[2], a[4], a[5], a[6]);
+    }
+#endif
+    return true;
+  }
+  dim3 grid(static_cast<unsigned>(n_tiles));
   if (mode == LIN_F16) hipLaunchKernelGGL((k_lin_direct<LIN_F16>), grid, dim3(256), 0, st, p);
   else if (mode == LIN_Q8) hipLaunchKernelGGL((k_lin_direct<LIN_Q8>), grid, dim3(256), 0, st, p);
   else hipLaunchKernelGGL((k_lin_direct<LIN_GEGLU>), grid, dim3(256), 0, st, p);

@@ -334,7 +334,7 @@ def _attach_stats(dsc, y: torch.Tensor, B: int, hw: int, cout: int, want_stats: 
 # the launch stream; a conv is idempotent, so re-running it is harmless) and later launches -- in particular the ones
 # captured into the sampler's hipGraph -- use the winner.  The result does not depend on the tile shape.
 _AUTOTUNE = None      # None = off, else {shape key: tile id}
-_TILE_NAMES = {1: "128x128", 2: "64x64", 3: "256x128", 4: "128x64", 5: "slab 256xN (3x3)", 6: "direct 128x128 (pointwise)"}
+_TILE_NAMES = {1: "128x128", 2: "64x64", 3: "256x128", 4: "128x64", 5: "slab 256xN (3x3)", 6: "direct 128x128 (pointwise)", 7: "stream 128x128 (pointwise, persistent)"}
 
 
 def set_conv_autotune(cache) -> None:
@@ -398,8 +398,10 @@ def _tune_conv(h, name, kind, d, dsc):
     if kind == "w4a8" and slab_ok(dsc):
         cands.append(5)
     if (kind == "w4a8" and dsc.KH == 1 and dsc.KW == 1 and dsc.stride == 1 and not dsc.up2x and dsc.Cin % 64 == 0 and dsc.Cout % 4 == 0
-            and dsc.out_mode in (1, 2, 3) and not dsc.rowadd and not dsc.stats and not dsc.yt):
+            and dsc.out_mode in (1, 2, 3) and not dsc.rowadd and not dsc.stats and not (dsc.yt and dsc.residual)):
         cands.append(6)
+        # (7 = TFMQ_TILE_STREAM, the persistent producer / consumer variant, is selectable but not a candidate: measured
+        # 3-60 % slower than 6 on every SD shape -- DESIGN.md section 4)
     best, best_ms = 0, None
     e0, e1 = C.c_int(), C.c_int()
     h.call("event_create", C.byref(e0))
