@@ -37,13 +37,25 @@ enum { LIN_F16 = 0, LIN_Q8 = 1, LIN_GEGLU = 2 };
 #define TFMQ_TDUMP(off, n) do { } while (0)
 #endif
 
-// Epilogue out of the accumulator registers (both pointwise kernels).  acc[i][j][4q + c] = channel ncol0(j) + 8q + 4h + c of
-// pixel (wm*2+i)*32 + lane%32; cs = this tile's table {scale[BN], zero-point correction[BN] (int bits), bias[BN]} in LDS.
-// Packed fp32 arithmetic (two outputs per VALU instruction); same operations as k_conv_dma's epilogue: bit-identical.
+// Channel owned by an accumulator register.  The weight rows of a 32-channel MFMA tile are read from LDS in a PERMUTED
+// order (lin_brow below: MFMA row i <- tile channel 4(i>>3) + (i&3) for the rows of lane half 0, 16 + 4((i>>3)+2 & 3) + (i&3)
+// for those of lane half 1), so that lane half h owns the 16 CONSECUTIVE channels 16h .. 16h+15 of the tile: register octet u
+// (acc[8u .. 8u+7]) = channels 16h + 8(u ^ h) .. +7.  A lane therefore moves 16 contiguous bytes per store / residual load
+// (8 fp16 channels; 8 int8 channels = 8 bytes): the write path of a CU retires roughly one touched 128-byte line per 4 cycles
+// whatever the bytes, and 8-byte fp16 / 4-byte int8 pieces made the epilogue's stores the longest phase of a short-K tile.
+// Each 16-lane group of the fragment read still covers all four swizzle classes of the 64-byte LDS rows (conflict-free).
+__device__ __forceinline__ int lin_brow(int i) {      // LDS row (tile channel) feeding MFMA row i of a 32-channel tile
+  const int q = i >> 3, c = i & 3;
+  return ((i >> 2) & 1) ? 16 + (((q + 2) & 3) << 2) + c : (q << 2) + c;
+}
+
+// Epilogue out of the accumulator registers (both pointwise kernels).  cs = this tile's table {scale[BN], zero-point
+// correction[BN] (int bits), bias[BN]} in LDS.  Packed fp32 arithmetic (two outputs per VALU instruction); same operations
+// as k_conv_dma's epilogue: bit-identical.
 // PHASE 0: everything.  PHASE 1: affine map + residual only, results left in `acc` as float bits.  PHASE 2: conversion
 // and stores of what phase 1 left (k_lin_stream puts the next tile's residual loads between the two).
 template <int MODE, int PHASE = 0>
-__device__ __forceinline__ void lin_epilogue(const ConvP& p, v16i (&acc)[2][2], const float* cs, uint2 (&rres)[2][2][4], bool has_res,
+__device__ __forceinline__ void lin_epilogue(const ConvP& p, v16i (&acc)[2][2], const float* cs, uint4 (&rres)[2][2][2], bool has_res,
                                              int m0, int n0, int wm, int wn, int lane, float2 oqp) {
   constexpr int BN = 128;
   const tfmq_conv_desc& d = p.d;
@@ -51,6 +63,17 @@ __device__ __forceinline__ void lin_epilogue(const ConvP& p, v16i (&acc)[2][2], 
   auto ncol0 = [&](int j) { return MODE == LIN_GEGLU ? j * 64 + wn * 32 : (wn * 2 + j) * 32; };
   auto affine2 = [&](int a0, int a1, float sx, float sy, int kx, int ky, float bx, float by) -> f2 {
     return f2{sx, sy} * f2{static_cast<float>(a0 + kx), static_cast<float>(a1 + ky)} + f2{bx, by};
+  };
+  // the eight values of one register octet: scale * float(acc + k) + bias
+  auto affine8 = [&](const v16i& a, int u, int ct, f2 (&v)[4]) {
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const float4 sc = *reinterpret_cast<const float4*>(cs + ct + 4 * e);
+      const int4 kc = *reinterpret_cast<const int4*>(reinterpret_cast<const int*>(cs) + BN + ct + 4 * e);
+      const float4 bb = *reinterpret_cast<const float4*>(cs + 2 * BN + ct + 4 * e);
+      v[2 * e] = affine2(a[8 * u + 4 * e + 0], a[8 * u + 4 * e + 1], sc.x, sc.y, kc.x, kc.y, bb.x, bb.y);
+      v[2 * e + 1] = affine2(a[8 * u + 4 * e + 2], a[8 * u + 4 * e + 3], sc.z, sc.w, kc.z, kc.w, bb.z, bb.w);
+    }
   };
   const bool transposed = MODE == LIN_F16 && d.yt != nullptr && n0 >= d.t_col0;      // tile-uniform (t_col0 % 128 == 0)
   auto epi = [&](auto exact_div) {
@@ -65,77 +88,79 @@ __device__ __forceinline__ void lin_epilogue(const ConvP& p, v16i (&acc)[2][2], 
       if constexpr (MODE == LIN_GEGLU) {
         const int inner = d.Cout >> 1;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int cv = ncol0(0) + 8 * q + 4 * h, cg = ncol0(1) + 8 * q + 4 * h;     // value / gate columns inside the tile
-          const float4 sv = *reinterpret_cast<const float4*>(cs + cv), sg = *reinterpret_cast<const float4*>(cs + cg);
-          const int4 kv = *reinterpret_cast<const int4*>(reinterpret_cast<const int*>(cs) + BN + cv);
-          const int4 kg = *reinterpret_cast<const int4*>(reinterpret_cast<const int*>(cs) + BN + cg);
-          const float4 bv = *reinterpret_cast<const float4*>(cs + 2 * BN + cv), bg = *reinterpret_cast<const float4*>(cs + 2 * BN + cg);
-          const f2 a01 = affine2(acc[i][0][4 * q + 0], acc[i][0][4 * q + 1], sv.x, sv.y, kv.x, kv.y, bv.x, bv.y);
-          const f2 a23 = affine2(acc[i][0][4 * q + 2], acc[i][0][4 * q + 3], sv.z, sv.w, kv.z, kv.w, bv.z, bv.w);
-          const f2 g01 = affine2(acc[i][1][4 * q + 0], acc[i][1][4 * q + 1], sg.x, sg.y, kg.x, kg.y, bg.x, bg.y);
-          const f2 g23 = affine2(acc[i][1][4 * q + 2], acc[i][1][4 * q + 3], sg.z, sg.w, kg.z, kg.w, bg.z, bg.w);
-          const unsigned w = quant_pack4_t<EX>(a01 * gelu2(g01), a23 * gelu2(g23), qP);
-          const int oc = (n0 >> 1) + wn * 32 + 8 * q + 4 * h;                           // output channel (of Cout / 2)
-          if (mok && oc < inner) *reinterpret_cast<unsigned*>(d.yq + static_cast<size_t>(m) * inner + oc) = w;
+        for (int u = 0; u < 2; ++u) {
+          const int co = 16 * h + 8 * (u ^ h);                 // channel offset of this octet inside a 32-channel tile
+          f2 a[4], g[4];
+          affine8(acc[i][0], u, ncol0(0) + co, a);
+          affine8(acc[i][1], u, ncol0(1) + co, g);
+          const unsigned w0 = quant_pack4_t<EX>(a[0] * gelu2(g[0]), a[1] * gelu2(g[1]), qP);
+          const unsigned w1 = quant_pack4_t<EX>(a[2] * gelu2(g[2]), a[3] * gelu2(g[3]), qP);
+          const int oc = (n0 >> 1) + wn * 32 + co;                // output channel (of Cout / 2)
+          if (mok && oc < inner) *reinterpret_cast<uint2*>(d.yq + static_cast<size_t>(m) * inner + oc) = make_uint2(w0, w1);
+          __builtin_amdgcn_sched_barrier(0);
         }
       } else {
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const int ct = ncol0(j) + 8 * q + 4 * h, n = n0 + ct;
-            f2 v01, v23;
+          for (int u = 0; u < 2; ++u) {
+            const int ct = ncol0(j) + 16 * h + 8 * (u ^ h), n = n0 + ct;
+            f2 v[4];
             if (PHASE != 2) {
-              const float4 sc = *reinterpret_cast<const float4*>(cs + ct);
-              const int4 kc = *reinterpret_cast<const int4*>(reinterpret_cast<const int*>(cs) + BN + ct);
-              const float4 bb = *reinterpret_cast<const float4*>(cs + 2 * BN + ct);
-              v01 = affine2(acc[i][j][4 * q + 0], acc[i][j][4 * q + 1], sc.x, sc.y, kc.x, kc.y, bb.x, bb.y);
-              v23 = affine2(acc[i][j][4 * q + 2], acc[i][j][4 * q + 3], sc.z, sc.w, kc.z, kc.w, bb.z, bb.w);
+              affine8(acc[i][j], u, ct, v);
               if (has_res) {
                 if (d.res_f16) {
-                  const float2 lo = __half22float2(*reinterpret_cast<const __half2*>(&rres[i][j][q].x));
-                  const float2 hi = __half22float2(*reinterpret_cast<const __half2*>(&rres[i][j][q].y));
-                  v01 += f2{lo.x, lo.y};
-                  v23 += f2{hi.x, hi.y};
+                  const uint4 rr = rres[i][j][u];
+                  const float2 r0 = __half22float2(*reinterpret_cast<const __half2*>(&rr.x)), r1 = __half22float2(*reinterpret_cast<const __half2*>(&rr.y));
+                  const float2 r2 = __half22float2(*reinterpret_cast<const __half2*>(&rr.z)), r3 = __half22float2(*reinterpret_cast<const __half2*>(&rr.w));
+                  v[0] += f2{r0.x, r0.y};
+                  v[1] += f2{r1.x, r1.y};
+                  v[2] += f2{r2.x, r2.y};
+                  v[3] += f2{r3.x, r3.y};
                 } else if (mok && n < d.Cout) {
-                  const float4 a = *reinterpret_cast<const float4*>(d.residual + static_cast<size_t>(m) * d.Cout + n);
-                  v01 += f2{a.x, a.y};
-                  v23 += f2{a.z, a.w};
+                  const float4 a0 = *reinterpret_cast<const float4*>(d.residual + static_cast<size_t>(m) * d.Cout + n);
+                  const float4 a1 = *reinterpret_cast<const float4*>(d.residual + static_cast<size_t>(m) * d.Cout + n + 4);
+                  v[0] += f2{a0.x, a0.y};
+                  v[1] += f2{a0.z, a0.w};
+                  v[2] += f2{a1.x, a1.y};
+                  v[3] += f2{a1.z, a1.w};
                 }
               }
             }
             if (PHASE == 1) {        // combined values parked in the accumulator registers (the int32 sums are dead)
-              acc[i][j][4 * q + 0] = __float_as_int(v01.x);
-              acc[i][j][4 * q + 1] = __float_as_int(v01.y);
-              acc[i][j][4 * q + 2] = __float_as_int(v23.x);
-              acc[i][j][4 * q + 3] = __float_as_int(v23.y);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                acc[i][j][8 * u + 2 * e] = __float_as_int(v[e].x);
+                acc[i][j][8 * u + 2 * e + 1] = __float_as_int(v[e].y);
+              }
               __builtin_amdgcn_sched_barrier(0);
               continue;
             }
             if (PHASE == 2) {
-              v01 = f2{__int_as_float(acc[i][j][4 * q + 0]), __int_as_float(acc[i][j][4 * q + 1])};
-              v23 = f2{__int_as_float(acc[i][j][4 * q + 2]), __int_as_float(acc[i][j][4 * q + 3])};
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] = f2{__int_as_float(acc[i][j][8 * u + 2 * e]), __int_as_float(acc[i][j][8 * u + 2 * e + 1])};
             }
             if (mok && n < d.Cout) {
               if constexpr (MODE == LIN_F16) {
                 if (transposed) {
                   // yt[b][n - t_col0][t]: the 32 lanes of a half-wave hold 32 consecutive pixels of one channel -> every
-                  // 2-byte store instruction writes two contiguous 64-byte runs (channels n and n + 4)
+                  // 2-byte store instruction writes two contiguous 64-byte runs
                   __half* dst = reinterpret_cast<__half*>(d.yt) + (static_cast<size_t>(tb) * (d.Cout - d.t_col0) + (n - d.t_col0)) * thw + tt;
-                  dst[0] = __float2half_rn(v01.x);
-                  dst[thw] = __float2half_rn(v01.y);
-                  dst[2 * static_cast<size_t>(thw)] = __float2half_rn(v23.x);
-                  dst[3 * static_cast<size_t>(thw)] = __float2half_rn(v23.y);
+#pragma unroll
+                  for (int e = 0; e < 4; ++e) {
+                    dst[(2 * e) * static_cast<size_t>(thw)] = __float2half_rn(v[e].x);
+                    dst[(2 * e + 1) * static_cast<size_t>(thw)] = __float2half_rn(v[e].y);
+                  }
                 } else {
-                  *reinterpret_cast<uint2*>(reinterpret_cast<__half*>(d.y) + static_cast<size_t>(m) * d.ldy + d.y_coff + n) =
-                      make_uint2(pack_h2(v01.x, v01.y), pack_h2(v23.x, v23.y));
+                  *reinterpret_cast<uint4*>(reinterpret_cast<__half*>(d.y) + static_cast<size_t>(m) * d.ldy + d.y_coff + n) =
+                      make_uint4(pack_h2(v[0].x, v[0].y), pack_h2(v[1].x, v[1].y), pack_h2(v[2].x, v[2].y), pack_h2(v[3].x, v[3].y));
                 }
               } else {
-                *reinterpret_cast<unsigned*>(d.yq + static_cast<size_t>(m) * d.Cout + n) = quant_pack4_t<EX>(v01, v23, qP);
+                *reinterpret_cast<uint2*>(d.yq + static_cast<size_t>(m) * d.Cout + n) =
+                    make_uint2(quant_pack4_t<EX>(v[0], v[1], qP), quant_pack4_t<EX>(v[2], v[3], qP));
               }
             }
-            __builtin_amdgcn_sched_barrier(0);      // one quad at a time: interleaving them all spilled the accumulators
+            __builtin_amdgcn_sched_barrier(0);      // one octet at a time: interleaving them all spilled the accumulators
           }
       }
     }
@@ -148,9 +173,9 @@ __device__ __forceinline__ void lin_epilogue(const ConvP& p, v16i (&acc)[2][2], 
   }
 }
 
-// this lane's residual values (fp16 stream) of tile (m0, n0), branch-free: clamped addresses
+// this lane's residual values (fp16 stream) of tile (m0, n0), 16 bytes per register octet, branch-free: clamped addresses
 template <int MODE>
-__device__ __forceinline__ void lin_load_res(const ConvP& p, uint2 (&rres)[2][2][4], int m0, int n0, int wm, int wn, int lane) {
+__device__ __forceinline__ void lin_load_res(const ConvP& p, uint4 (&rres)[2][2][2], int m0, int n0, int wm, int wn, int lane) {
   const tfmq_conv_desc& d = p.d;
   const int h = lane >> 5;
 #pragma unroll
@@ -160,10 +185,10 @@ __device__ __forceinline__ void lin_load_res(const ConvP& p, uint2 (&rres)[2][2]
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int n = n0 + (MODE == LIN_GEGLU ? j * 64 + wn * 32 : (wn * 2 + j) * 32) + 8 * q + 4 * h;
+      for (int u = 0; u < 2; ++u) {
+        const int n = n0 + (MODE == LIN_GEGLU ? j * 64 + wn * 32 : (wn * 2 + j) * 32) + 16 * h + 8 * (u ^ h);
         const int nc = n < d.Cout ? n : 0;
-        rres[i][j][q] = *reinterpret_cast<const uint2*>(reinterpret_cast<const __half*>(d.residual) + static_cast<size_t>(mc) * d.Cout + nc);
+        rres[i][j][u] = *reinterpret_cast<const uint4*>(reinterpret_cast<const __half*>(d.residual) + static_cast<size_t>(mc) * d.Cout + nc);
       }
   }
 }
@@ -213,6 +238,8 @@ __global__ __launch_bounds__(256, 3) void k_lin_direct(ConvP p) {
   // (tile columns [0, 64) = value, [64, 128) = gate of the same 64 output channels)
   auto ncol0 = [&](int j) { return MODE == LIN_GEGLU ? j * 64 + wn * 32 : (wn * 2 + j) * 32; };
   const int fsw = (h ^ ((lane >> 2) & 3)) << 4;           // physical 16-byte slot of k-slot h in this lane's row
+  const int brow = lin_brow(lane & 31);                    // weight rows in the permuted order (see lin_brow)
+  const int bsw = (h ^ ((brow >> 2) & 3)) << 4;
 
   v16i acc[2][2];
 #pragma unroll
@@ -243,25 +270,9 @@ __global__ __launch_bounds__(256, 3) void k_lin_direct(ConvP p) {
   const float2 aqp = load_qparam(d.aq);
   float2 oqp = make_float2(1.0f, 0.0f);
   if constexpr (MODE != LIN_F16) oqp = load_qparam(d.oq);
-  uint2 rres[2][2][4];                     // MODE F16 / Q8 with a residual: 4 channels x fp16 per (i, j, quad)
-  float4 rres32[MODE == LIN_GEGLU ? 1 : 1];
-  (void)rres32;
+  uint4 rres[2][2][2];                     // MODE F16 / Q8 with a residual: 8 channels x fp16 per (i, j, register octet)
   const bool has_res = MODE != LIN_GEGLU && d.residual != nullptr;
-  if (has_res && d.res_f16) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int m = m0 + (wm * 2 + i) * 32 + (lane & 31);
-      const int mc = m < p.M ? m : p.M - 1;
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int n = n0 + ncol0(j) + 8 * q + 4 * h;
-          const int nc = n < d.Cout ? n : 0;
-          rres[i][j][q] = *reinterpret_cast<const uint2*>(reinterpret_cast<const __half*>(d.residual) + static_cast<size_t>(mc) * d.Cout + nc);
-        }
-    }
-  }
+  if (has_res && d.res_f16) lin_load_res<MODE>(p, rres, m0, n0, wm, wn, lane);
 
   int st_c = 0, st_i = 2;
   for (int s = 0; s < p.nsteps; ++s) {
@@ -277,7 +288,7 @@ __global__ __launch_bounds__(256, 3) void k_lin_direct(ConvP p) {
 #pragma unroll
       for (int i = 0; i < 2; ++i) af[i] = *reinterpret_cast<const v4i*>(sa + ((wm * 2 + i) * 32 + (lane & 31)) * 64 + (fsw ^ (ks << 5)));
 #pragma unroll
-      for (int j = 0; j < 2; ++j) bf[j] = *reinterpret_cast<const v4i*>(sb + (ncol0(j) + (lane & 31)) * 64 + (fsw ^ (ks << 5)));
+      for (int j = 0; j < 2; ++j) bf[j] = *reinterpret_cast<const v4i*>(sb + (ncol0(j) + brow) * 64 + (bsw ^ (ks << 5)));
       // operands swapped: the accumulator tile is (channels x pixels) -- lane = pixel, register quad = 4 consecutive channels
 #pragma unroll
       for (int i = 0; i < 2; ++i)
@@ -434,10 +445,12 @@ __global__ __launch_bounds__(320, RES ? 3 : 4) void k_lin_stream(ConvP p, int n_
   const int wm = wid >> 1, wn = wid & 1;
   auto ncol0 = [&](int j) { return MODE == LIN_GEGLU ? j * 64 + wn * 32 : (wn * 2 + j) * 32; };
   const int fsw = (h ^ ((lane >> 2) & 3)) << 4;
+  const int brow = lin_brow(lane & 31);
+  const int bsw = (h ^ ((brow >> 2) & 3)) << 4;
   float2 oqp = make_float2(1.0f, 0.0f);
   if constexpr (MODE != LIN_F16) oqp = load_qparam(d.oq);
   constexpr bool has_res = RES;
-  uint2 rres[2][2][4];
+  uint4 rres[2][2][2];
   if constexpr (RES) {
     const int tm = t_begin / p.tiles_n, tn = t_begin - tm * p.tiles_n;
     lin_load_res<MODE>(p, rres, tm * BM, tn * BN, wm, wn, lane);
@@ -466,7 +479,7 @@ __global__ __launch_bounds__(320, RES ? 3 : 4) void k_lin_stream(ConvP p, int n_
 #pragma unroll
         for (int i = 0; i < 2; ++i) af[i] = *reinterpret_cast<const v4i*>(sa + ((wm * 2 + i) * 32 + (lane & 31)) * 64 + (fsw ^ (ks << 5)));
 #pragma unroll
-        for (int j = 0; j < 2; ++j) bf[j] = *reinterpret_cast<const v4i*>(sb + (ncol0(j) + (lane & 31)) * 64 + (fsw ^ (ks << 5)));
+        for (int j = 0; j < 2; ++j) bf[j] = *reinterpret_cast<const v4i*>(sb + (ncol0(j) + brow) * 64 + (bsw ^ (ks << 5)));
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -479,13 +492,13 @@ __global__ __launch_bounds__(320, RES ? 3 : 4) void k_lin_stream(ConvP p, int n_
     // overwrite that stage: they have -- the MFMAs above consumed them (lgkmcnt(0) is implied by the data dependence)
     // A consumer never waits for its stores: their acknowledgement takes longer than a short-K tile's whole K loop.
     // With a residual, the next tile's values are requested BEFORE this tile's stores (after the affine + residual phase
-    // has consumed the current ones), so the counted wait below -- everything but the youngest 16 operations, the stores
+    // has consumed the current ones), so the counted wait below -- everything but the youngest 8 operations, the stores
     // of a full tile -- covers the loads and leaves the stores in flight.
     if constexpr (!RES) {
       lin_epilogue<MODE>(p, acc, cs_base + (t & 1) * (3 * BN), rres, false, m0, n0, wm, wn, lane, oqp);
     } else {
       {
-        if (prev_full) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        if (prev_full) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         lin_epilogue<MODE, 1>(p, acc, cs_base + (t & 1) * (3 * BN), rres, true, m0, n0, wm, wn, lane, oqp);
         if (t + 1 < t_end) {
@@ -493,7 +506,7 @@ __global__ __launch_bounds__(320, RES ? 3 : 4) void k_lin_stream(ConvP p, int n_
           lin_load_res<MODE>(p, rres, tm2 * BM, tn2 * BN, wm, wn, lane);
         }
         lin_epilogue<MODE, 2>(p, acc, cs_base + (t & 1) * (3 * BN), rres, true, m0, n0, wm, wn, lane, oqp);
-        prev_full = m0 + BM <= p.M && n0 + BN <= d.Cout;      // all 16 store instructions of this wave were issued
+        prev_full = m0 + BM <= p.M && n0 + BN <= d.Cout;      // all 8 store instructions of this wave were issued
       }
     }
     TFMQ_TACC(2);
@@ -507,16 +520,16 @@ bool launch_conv_lin(tfmq_handle h, ConvP& p, hipStream_t st, bool stream) {
   const tfmq_conv_desc& d = p.d;
   if (d.KH != 1 || d.KW != 1 || d.stride != 1 || d.up2x || d.pad_t != 0 || d.pad_l != 0 || d.Ho != d.H || d.Wo != d.W) return false;
   if (d.Cin % 64 != 0 || static_cast<size_t>(d.B) * d.H * d.W * d.Cin >= (static_cast<size_t>(1) << 31)) return false;
-  if (d.rowadd || d.stats || (d.Cout & 3) != 0) return false;
+  if (d.rowadd || d.stats || (d.Cout & 7) != 0) return false;      // a lane moves whole 8-channel octets
   if (d.yt && (d.out_mode != TFMQ_OUT_F16 || d.residual)) return false;
   int mode;
   if (d.out_mode == TFMQ_OUT_F16) {
-    if (((d.ldy | d.y_coff) & 3) != 0) return false;
+    if (((d.ldy | d.y_coff) & 7) != 0) return false;
     mode = LIN_F16;
   } else if (d.out_mode == TFMQ_OUT_Q8) {
     mode = LIN_Q8;
   } else if (d.out_mode == TFMQ_OUT_GEGLU_Q8) {
-    if (d.residual || d.Cout % 128 != 0) return false;
+    if (d.residual || d.Cout % 128 != 0 || (d.Cout >> 1) % 8 != 0) return false;
     mode = LIN_GEGLU;
   } else {
     return false;
