@@ -8,6 +8,9 @@ dev = torch.device("cuda", 0)
 B = int(os.environ.get("BATCH", "128"))
 shapes = [(64, 320, 320, True), (64, 640, 320, False), (64, 960, 320, False), (32, 640, 640, True), (32, 1280, 640, False),
           (32, 1920, 640, False), (16, 1280, 1280, True), (16, 2560, 1280, False), (8, 1280, 1280, True), (8, 2560, 1280, False)]
+UP = os.environ.get("UP") == "1"                 # the Upsample convs: nearest-2x fused into the 3x3 conv (H = input size)
+if UP:
+    shapes = [(32, 640, 640, False), (16, 1280, 1280, False), (8, 1280, 1280, False)]
 if os.environ.get("SHAPES"):
     shapes = [shapes[int(i)] for i in os.environ["SHAPES"].split(",")]
 gen = torch.Generator().manual_seed(0)
@@ -19,11 +22,12 @@ for (H, cin, cout, res) in shapes:
     qp = ops.minmax_to_qparam(ops.minmax(w.reshape(cout, -1).contiguous(), cout), 16)
     pw = ops.pack_w4(w, qp[:, 0].contiguous(), qp[:, 1].contiguous(), None, torch.zeros(cout, device=dev))
     F16 = os.environ.get("F16", "1") == "1"          # fp16 activation stream (the sampling path) or the fp32 stream
-    r = torch.randn(B, H, H, cout, device=dev) if res else None
+    Ho = 2 * H if UP else H
+    r = torch.randn(B, Ho, Ho, cout, device=dev) if res else None
     if r is not None and F16:
         r = r.half()
     ra = torch.randn(B, cout, device=dev)
-    nops = 2.0 * B * H * H * cout * 9 * cin
+    nops = 2.0 * B * Ho * Ho * cout * 9 * cin
     line = f"{B}x{H}x{H} {cin}->{cout} res={int(res)}:"
     ref = None
     for tile in (1, 3, 4, 5):
@@ -31,12 +35,12 @@ for (H, cin, cout, res) in shapes:
         ops.set_conv_autotune({})
         ops._tune_conv = lambda h, name, kind, d, dsc, t=tile: t
         try:
-            y = ops.conv2d_w4a8(xq, pw, sel, pad=(1, 1, 1, 1), residual=r, rowadd=ra, want_stats=True, out_f16=F16)
+            y = ops.conv2d_w4a8(xq, pw, sel, pad=(1, 1, 1, 1), residual=r, rowadd=None if UP else ra, want_stats=True, out_f16=F16, up2x=UP)
             torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(5):
-                y = ops.conv2d_w4a8(xq, pw, sel, pad=(1, 1, 1, 1), residual=r, rowadd=ra, want_stats=True, out_f16=F16)
+                y = ops.conv2d_w4a8(xq, pw, sel, pad=(1, 1, 1, 1), residual=r, rowadd=None if UP else ra, want_stats=True, out_f16=F16, up2x=UP)
             e1.record()
             torch.cuda.synchronize()
             us = e0.elapsed_time(e1) / 5 * 1e3

@@ -1,4 +1,4 @@
-"""Fold two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) into profiles/r01_traffic_<workload>.json.
+"""Fold two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) into profiles/<round>_traffic_<workload>.json.
 Only dispatches after the last k_upsample2x marker kernel (scratch/pmc_forward.py) are kept.
 usage: make_traffic_json.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json> <note>"""
 import csv, json, sys, collections, re
@@ -12,7 +12,7 @@ def load(path, counter):
     rows = rows[marks[-1] + 1:]
     agg = collections.defaultdict(lambda: [0, 0.0])
     for r in rows:
-        name = re.sub(r"\(.*$", "", r["Kernel_Name"]).strip()[:60]
+        name = re.sub(r"\(.*$", "", r["Kernel_Name"].replace("(anonymous namespace)::", "")).strip()[:60]
         a = agg[name]
         a[0] += 1
         a[1] += float(r["Counter_Value"])

@@ -233,6 +233,47 @@ def test_slab_kernel_is_bit_identical_to_the_tile_kernels(ops, B, H, cin, cout, 
         assert float((yy - ref).abs().max() / ref.abs().max()) <= 1e-5
 
 
+@pytest.mark.parametrize("B,H,cin,cout,mode", [(2, 32, 64, 320, "f32"), (3, 16, 128, 256, "f16"), (5, 8, 192, 640, "f32"), (9, 4, 64, 128, "q8")])
+def test_slab_kernel_fused_upsample_is_bit_identical(ops, B, H, cin, cout, mode):
+    """Nearest-2x upsample fused into the 3x3 conv (Upsample.conv of the UNets): the slab kernel stages the UPSAMPLED rows
+    (virtual pixel (y, x) reads input (y >> 1, x >> 1)); against the 128x128 tile kernel and against upsampling first."""
+    import tfmq_dm_amd.ops as _o
+    g = torch.Generator().manual_seed(77 + H)
+    x = torch.randn(B, H, H, cin, generator=g) * 1.1 + 0.1
+    w = torch.randn(cout, cin, 3, 3, generator=g) * (2.0 / (cin * 9) ** 0.5)
+    b = torch.randn(cout, generator=g) * 0.2
+    wd, wz = O.init_channelwise(w, 16, "minmax")
+    ad, az = O.minmax(x, 256)
+    sel = ops.qsel(qtab(ad, az))
+    xq = ops.quantize_act(x.to(DEV), sel)
+    pw = ops.pack_w4(w.to(DEV), wd.to(DEV), wz.to(DEV), bias=b.to(DEV))
+    kw = dict(pad=(1, 1, 1, 1), up2x=True)
+    if mode == "q8":
+        kw["out_q8"] = ops.qsel(qtab(0.05, 120.0))
+    elif mode == "f16":
+        kw["out_f16"] = True
+    else:
+        kw["want_stats"] = True
+    outs = []
+    for tile in (1, 5):
+        ops.set_conv_autotune({})
+        orig = _o._tune_conv
+        try:
+            _o._tune_conv = lambda h, name, kind, d, dsc, t=tile: t
+            y = ops.conv2d_w4a8(xq, pw, sel, **kw)
+            outs.append((y.clone(), y._tfmq_stats[0].clone() if mode == "f32" else None))
+        finally:
+            _o._tune_conv = orig
+            ops.set_conv_autotune(None)
+    assert torch.equal(outs[1][0], outs[0][0])
+    if mode == "f32":
+        assert torch.equal(outs[1][1], outs[0][1])
+    kw.pop("up2x")
+    x2 = xq.repeat_interleave(2, dim=1).repeat_interleave(2, dim=2).contiguous()
+    y2 = ops.conv2d_w4a8(x2, pw, sel, **kw)
+    assert torch.equal(y2, outs[1][0])
+
+
 @pytest.mark.parametrize("k,B,H,cin,cout", [(3, 2, 32, 64, 320), (1, 3, 16, 128, 256), (3, 5, 8, 128, 640), (1, 2, 64, 64, 64)])
 def test_f16_stream_epilogue_equals_rounded_f32_epilogue(ops, k, B, H, cin, cout):
     """fp16 activation stream: a conv writing fp16 (+ temb row + fp16 residual, statistics from the fp32 values) must give

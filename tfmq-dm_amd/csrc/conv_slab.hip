@@ -60,7 +60,8 @@ __global__ __launch_bounds__(512) void k_conv3_slab(SlabP sp) {
   const int bid = xcd_tile_id();
   const int tile_n = bid % p.tiles_n, tile_m = bid / p.tiles_n;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
-  const int W = d.W, H = d.H, SW = sp.SW;
+  const int W = p.Wv, H = p.Hv, SW = sp.SW;      // the (virtual, when the nearest-2x upsample is fused) input image
+  const int ups = d.up2x ? 1 : 0;
 
   const float2 aqp = load_qparam(d.aq);
 
@@ -93,7 +94,9 @@ __global__ __launch_bounds__(512) void k_conv3_slab(SlabP sp) {
       const int rem = j - k * sp.SI;
       const int sy = rem / SW, sx = rem - sy * SW;
       const int b = b0 + k, y = (sp.imgs == 1 ? y0 : 0) - 1 + sy, x = sx - 1;
-      if (b < d.B && y >= 0 && y < H && x >= 0 && x < W) off = ((b * H + y) * W + x) * d.Cin;
+      // fused upsample: the slab holds the UPSAMPLED pixels -- virtual (y, x) reads input (y >> 1, x >> 1), four slab rows
+      // per input pixel, all but the first from L2
+      if (b < d.B && y >= 0 && y < H && x >= 0 && x < W) off = ((b * d.H + (y >> ups)) * d.W + (x >> ups)) * d.Cin;
     }
     s_off[it] = off;
   }
@@ -420,21 +423,22 @@ __global__ __launch_bounds__(512) void k_conv3_slab(SlabP sp) {
 
 bool launch_conv_slab(tfmq_handle h, ConvP& p, hipStream_t st, bool forced) {
   const tfmq_conv_desc& d = p.d;
-  if (d.KH != 3 || d.KW != 3 || d.stride != 1 || d.up2x || d.pad_t != 1 || d.pad_l != 1 || d.Ho != d.H || d.Wo != d.W) return false;
+  const int Hv = d.up2x ? 2 * d.H : d.H, Wv = d.up2x ? 2 * d.W : d.W;
+  if (d.KH != 3 || d.KW != 3 || d.stride != 1 || d.pad_t != 1 || d.pad_l != 1 || d.Ho != Hv || d.Wo != Wv || p.Hv != Hv || p.Wv != Wv) return false;
   if (d.Cin % 64 != 0 || static_cast<size_t>(d.B) * d.H * d.W * d.Cin >= (static_cast<size_t>(1) << 31)) return false;
   if (!(d.out_mode == TFMQ_OUT_F32 || d.out_mode == TFMQ_OUT_Q8 || (d.out_mode == TFMQ_OUT_F16 && !d.yt))) return false;
   if (((d.Cout | d.ldy | d.y_coff) & 3) != 0 || (d.rowadd && (d.rowadd_ld & 3) != 0)) return false;
   if (d.stats && 256 % d.stats_seg != 0) return false;
   SlabP sp;
-  sp.HW = d.H * d.W;
-  sp.SW = d.W + 2;
-  if (sp.HW % 256 == 0 && 256 % d.W == 0) {
+  sp.HW = Hv * Wv;
+  sp.SW = Wv + 2;
+  if (sp.HW % 256 == 0 && 256 % Wv == 0) {
     sp.imgs = 1;
-    sp.slab_rows = (256 / d.W + 2) * sp.SW;
+    sp.slab_rows = (256 / Wv + 2) * sp.SW;
     sp.SI = sp.slab_rows;
   } else if (256 % sp.HW == 0) {
     sp.imgs = 256 / sp.HW;
-    sp.SI = (d.H + 2) * sp.SW;
+    sp.SI = (Hv + 2) * sp.SW;
     sp.slab_rows = sp.imgs * sp.SI;
   } else {
     return false;

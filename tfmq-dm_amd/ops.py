@@ -369,14 +369,15 @@ def conv_autotune_report():
 def slab_ok(dsc) -> bool:
     """Launch geometry the 3x3 slab kernel (csrc/conv_slab.hip, TFMQ_TILE_SLAB) takes: 3x3 / stride 1 / pad 1, Cin % 64 == 0,
     256-pixel tiles made of whole image rows (or whole images), a slab of at most 512 pixel rows."""
-    if not (dsc.KH == 3 and dsc.KW == 3 and dsc.stride == 1 and not dsc.up2x and dsc.pad_t == 1 and dsc.pad_l == 1
-            and dsc.Cin % 64 == 0 and dsc.Ho == dsc.H and dsc.Wo == dsc.W and not dsc.yt and dsc.out_mode in (0, 1, 3)):
+    hv, wv = (2 * dsc.H, 2 * dsc.W) if dsc.up2x else (dsc.H, dsc.W)      # the fused nearest-2x upsample stages upsampled rows
+    if not (dsc.KH == 3 and dsc.KW == 3 and dsc.stride == 1 and dsc.pad_t == 1 and dsc.pad_l == 1
+            and dsc.Cin % 64 == 0 and dsc.Ho == hv and dsc.Wo == wv and not dsc.yt and dsc.out_mode in (0, 1, 3)):
         return False
-    hw = dsc.H * dsc.W
-    if hw % 256 == 0 and 256 % dsc.W == 0:
-        rows = (256 // dsc.W + 2) * (dsc.W + 2)
+    hw = hv * wv
+    if hw % 256 == 0 and 256 % wv == 0:
+        rows = (256 // wv + 2) * (wv + 2)
     elif 256 % hw == 0:
-        rows = (256 // hw) * (dsc.H + 2) * (dsc.W + 2)
+        rows = (256 // hw) * (hv + 2) * (wv + 2)
     else:
         return False
     return rows <= 512
