@@ -11,7 +11,7 @@ import os
 from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libtfmq_hip.so")
+LIB_PATH = os.environ.get("TFMQ_LIB_PATH") or os.path.join(_HERE, "libtfmq_hip.so")     # override: same-box A/B of two builds (scratch/)
 
 c_void_p, c_int, c_size_t, c_float, c_double = C.c_void_p, C.c_int, C.c_size_t, C.c_float, C.c_double
 

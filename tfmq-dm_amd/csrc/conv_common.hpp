@@ -67,6 +67,33 @@ __device__ __forceinline__ unsigned pack_h2(float a, float b) {
   return *reinterpret_cast<const unsigned*>(&v);
 }
 
+// Channel owned by an accumulator register.  The weight rows of a 32-channel MFMA tile are read from LDS in a PERMUTED
+// order (lin_brow: MFMA row i <- tile channel (i & 3) + 4 (i >> 3) + 16 ((i >> 2) & 1)), so that lane half h -- which owns
+// the MFMA rows with (i >> 2) & 1 == h -- holds the 16 CONSECUTIVE channels 16h .. 16h+15 of the tile, register r = channel
+// 16h + r.  A lane therefore moves 16 contiguous bytes per store / residual load (8 fp16 channels; 8 int8 channels = 8
+// bytes): the write path of a CU retires roughly one touched 128-byte line per 4 cycles whatever the bytes, and 8-byte
+// fp16 / 4-byte int8 pieces made the epilogue's stores the longest phase of a short-K tile.
+// ds_read_b128 is serviced in the lane groups {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31} (+32 for the upper half): with this
+// permutation each group still reads one row of every (row % 4, swizzle class) combination -- conflict-free.  (A first
+// version that assumed groups of 16 consecutive lanes rotated the upper half's octets and cost the K loop 6-10 %.)
+__device__ __forceinline__ int lin_brow(int i) {      // LDS row (tile channel) feeding MFMA row i of a 32-channel tile
+  return (i & 3) + ((i >> 3) << 2) + (((i >> 2) & 1) << 4);
+}
+
+// DPP lane exchanges for the GroupNorm statistics of the register-direct epilogues (lane = pixel)
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+// Sum over 8 consecutive lanes (= 8 consecutive pixel rows) in the ONE order every kernel uses for the statistics:
+// ((r0 + r1) + r2) + r3 added to ((r4 + r5) + r6) + r7.  Valid in the lanes with (lane & 7) == 0.
+__device__ __forceinline__ float group8_sum(float v) {
+  float a = v + dpp_f<0x55>(v);      // quad_perm [1,1,1,1]
+  a = a + dpp_f<0xAA>(v);            // quad_perm [2,2,2,2]
+  a = a + dpp_f<0xFF>(v);            // quad_perm [3,3,3,3]
+  return a + dpp_f<0x104>(a);        // row_shl:4 -- lane i reads lane i + 4
+}
+
 // four consecutive channels of the residual tensor: fp32, or fp16 when it belongs to the fp16 activation stream
 __device__ __forceinline__ float4 load_res4(const tfmq_conv_desc& d, int m, int n) {
   if (d.res_f16) {

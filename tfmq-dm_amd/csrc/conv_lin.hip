@@ -37,18 +37,6 @@ enum { LIN_F16 = 0, LIN_Q8 = 1, LIN_GEGLU = 2 };
 #define TFMQ_TDUMP(off, n) do { } while (0)
 #endif
 
-// Channel owned by an accumulator register.  The weight rows of a 32-channel MFMA tile are read from LDS in a PERMUTED
-// order (lin_brow below: MFMA row i <- tile channel 4(i>>3) + (i&3) for the rows of lane half 0, 16 + 4((i>>3)+2 & 3) + (i&3)
-// for those of lane half 1), so that lane half h owns the 16 CONSECUTIVE channels 16h .. 16h+15 of the tile: register octet u
-// (acc[8u .. 8u+7]) = channels 16h + 8(u ^ h) .. +7.  A lane therefore moves 16 contiguous bytes per store / residual load
-// (8 fp16 channels; 8 int8 channels = 8 bytes): the write path of a CU retires roughly one touched 128-byte line per 4 cycles
-// whatever the bytes, and 8-byte fp16 / 4-byte int8 pieces made the epilogue's stores the longest phase of a short-K tile.
-// Each 16-lane group of the fragment read still covers all four swizzle classes of the 64-byte LDS rows (conflict-free).
-__device__ __forceinline__ int lin_brow(int i) {      // LDS row (tile channel) feeding MFMA row i of a 32-channel tile
-  const int q = i >> 3, c = i & 3;
-  return ((i >> 2) & 1) ? 16 + (((q + 2) & 3) << 2) + c : (q << 2) + c;
-}
-
 // Epilogue out of the accumulator registers (both pointwise kernels).  cs = this tile's table {scale[BN], zero-point
 // correction[BN] (int bits), bias[BN]} in LDS.  Packed fp32 arithmetic (two outputs per VALU instruction); same operations
 // as k_conv_dma's epilogue: bit-identical.
@@ -89,7 +77,7 @@ __device__ __forceinline__ void lin_epilogue(const ConvP& p, v16i (&acc)[2][2], 
         const int inner = d.Cout >> 1;
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-          const int co = 16 * h + 8 * (u ^ h);                 // channel offset of this octet inside a 32-channel tile
+          const int co = 16 * h + 8 * u;                 // channel offset of this octet inside a 32-channel tile
           f2 a[4], g[4];
           affine8(acc[i][0], u, ncol0(0) + co, a);
           affine8(acc[i][1], u, ncol0(1) + co, g);
@@ -104,7 +92,7 @@ __device__ __forceinline__ void lin_epilogue(const ConvP& p, v16i (&acc)[2][2], 
         for (int j = 0; j < 2; ++j)
 #pragma unroll
           for (int u = 0; u < 2; ++u) {
-            const int ct = ncol0(j) + 16 * h + 8 * (u ^ h), n = n0 + ct;
+            const int ct = ncol0(j) + 16 * h + 8 * u, n = n0 + ct;
             f2 v[4];
             if (PHASE != 2) {
               affine8(acc[i][j], u, ct, v);
@@ -186,7 +174,7 @@ __device__ __forceinline__ void lin_load_res(const ConvP& p, uint4 (&rres)[2][2]
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
-        const int n = n0 + (MODE == LIN_GEGLU ? j * 64 + wn * 32 : (wn * 2 + j) * 32) + 16 * h + 8 * (u ^ h);
+        const int n = n0 + (MODE == LIN_GEGLU ? j * 64 + wn * 32 : (wn * 2 + j) * 32) + 16 * h + 8 * u;
         const int nc = n < d.Cout ? n : 0;
         rres[i][j][u] = *reinterpret_cast<const uint4*>(reinterpret_cast<const __half*>(d.residual) + static_cast<size_t>(mc) * d.Cout + nc);
       }
@@ -449,7 +437,6 @@ __global__ __launch_bounds__(320, RES ? 3 : 4) void k_lin_stream(ConvP p, int n_
   const int bsw = (h ^ ((brow >> 2) & 3)) << 4;
   float2 oqp = make_float2(1.0f, 0.0f);
   if constexpr (MODE != LIN_F16) oqp = load_qparam(d.oq);
-  constexpr bool has_res = RES;
   uint4 rres[2][2][2];
   if constexpr (RES) {
     const int tm = t_begin / p.tiles_n, tn = t_begin - tm * p.tiles_n;

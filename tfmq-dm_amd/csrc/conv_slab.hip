@@ -16,6 +16,14 @@
 // uses) stages 32 tile rows at a time through LDS and writes whole rows.
 #include "conv_common.hpp"
 #include <type_traits>
+#ifdef TFMQ_PHASE_TIMERS
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#define SLAB_MARK(i) do { if (p.dbg && threadIdx.x == 0) p.dbg[blockIdx.x * 4 + (i)] = wall_clock64(); } while (0)
+#else
+#define SLAB_MARK(i) do { } while (0)
+#endif
 
 namespace {
 
@@ -35,7 +43,7 @@ template <int WN>
 __host__ __device__ constexpr int slab_lds_bytes() {
   constexpr int BN = 64 * WN;
   constexpr int main_ = 2 * SLAB_BYTES + 3 * BN * 64;
-  constexpr int epi = 32 * (BN + 4) * 4 + 32 * BN * 8;
+  constexpr int epi = 32 * BN * 8 + (3 + 4) * BN * 4;      // 8-row-group partial sums + the table of per-column constants
   return main_ > epi ? main_ : epi;
 }
 
@@ -63,6 +71,7 @@ __global__ __launch_bounds__(512) void k_conv3_slab(SlabP sp) {
   const int W = p.Wv, H = p.Hv, SW = sp.SW;      // the (virtual, when the nearest-2x upsample is fused) input image
   const int ups = d.up2x ? 1 : 0;
 
+  SLAB_MARK(0);
   const float2 aqp = load_qparam(d.aq);
 
   // ---- slab geometry of this tile
@@ -120,7 +129,13 @@ __global__ __launch_bounds__(512) void k_conv3_slab(SlabP sp) {
   }
 
   // fragment read offsets
-  const int b_rel = (wn * WN * 32 + (lane & 31)) * 64 + ((h ^ ((lane >> 2) & 3)) << 4);
+  // weight rows in the permuted order of lin_brow: lane half h then owns 16 consecutive channels of every 32-channel tile
+#ifdef TFMQ_DBG_NATURAL_ROWS      // timing experiment only (wrong channel order): are the permuted fragment rows slower to read?
+  const int brow = lane & 31;
+#else
+  const int brow = lin_brow(lane & 31);
+#endif
+  const int b_rel = (wn * WN * 32 + brow) * 64 + ((h ^ ((brow >> 2) & 3)) << 4);
   int slab_toggle = 0;
 
   v16i acc[2][WN];
@@ -177,7 +192,7 @@ __global__ __launch_bounds__(512) void k_conv3_slab(SlabP sp) {
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-          for (int j = 0; j < WN; ++j) acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[i], bf[j], acc[i][j], 0, 0, 0);
+          for (int j = 0; j < WN; ++j) acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(bf[j], af[i], acc[i][j], 0, 0, 0);      // (channels x pixels): lane = pixel
         // the DMA issue of the next K-steps (SALU M0 moves + VMEM, ~100 clk a piece) sits behind the first half's MFMAs:
         // the matrix pipe works through them while the wave issues the loads, instead of idling right after the barrier
         if (ks == 0) issue_next();
@@ -202,204 +217,135 @@ __global__ __launch_bounds__(512) void k_conv3_slab(SlabP sp) {
   };
   if (NBP % 8 != 0 && wid < NBP % 8) kloop(std::integral_constant<int, NBP / 8 + 1>{});
   else kloop(std::integral_constant<int, NBP / 8>{});
+  SLAB_MARK(1);
 
-  // ================================================================================ epilogue
-  constexpr int LDO = BN + 4, TPR = BN / 4;
-  float* ldsO = reinterpret_cast<float*>(lds);                          // [32][LDO]
-  float2* ldsP = reinterpret_cast<float2*>(lds + 32 * LDO * 4);         // [32 eight-row groups][BN] (sum, sum of squares)
+  // ================================================================================ epilogue (out of the registers)
+  // acc[i][j][8u .. 8u+7] = channels (wn*WN + j)*32 + 16h + 8u .. +7 of pixel row wm*64 + i*32 + lane%32 (lin_brow).
+  // No LDS staging and no barriers between the K loop and the stores (the staged epilogue -- eight passes of stage /
+  // barrier / 160 of 512 threads storing -- took 34 us of a 133 us block without a residual and 75 us of 121 us with one:
+  // scratch/phase_slab.py): every lane converts its own values, 16-byte stores and residual loads, the fp16 residual
+  // octets requested three channel tiles ahead, statistics by DPP sums over the 8 lanes of a pixel-row group in the
+  // canonical order.
+  float2* ldsP = reinterpret_cast<float2*>(lds);                         // [32 eight-row groups][BN] (sum, sum of squares)
+  float* cs = reinterpret_cast<float*>(lds + 32 * BN * 8);               // scale[BN], corr[BN] (int), bias[BN], rowadd[imgs][BN]
   const int hw = sp.HW;
   const float* rowadd = d.rowadd;
   if (rowadd && d.rowadd_step) rowadd += static_cast<size_t>(*d.rowadd_step) * d.rowadd_step_stride;
   const int seg = d.stats ? d.stats_seg : 0;
   const bool q8 = d.out_mode == TFMQ_OUT_Q8, o16 = d.out_mode == TFMQ_OUT_F16;
-  const bool q16 = (d.Cout & 15) == 0, h8 = ((d.Cout | d.ldy | d.y_coff) & 7) == 0;     // 16-byte item paths of the store pass
   float2 oqp = make_float2(1.0f, 0.0f);
   if (q8) oqp = load_qparam(d.oq);
-  float sc_[WN], bias_[WN];
-  int corr_[WN];
-#pragma unroll
-  for (int j = 0; j < WN; ++j) {
-    const int n = n0 + (wn * WN + j) * 32 + (lane & 31);
-    sc_[j] = 1.0f;
-    bias_[j] = 0.0f;
-    corr_[j] = 0;
+  const QuantP qP = make_quantp(oqp);
+  __syncthreads();                       // every wave has left the K loop: its LDS becomes the table and the partial sums
+  if (tid < BN) {
+    const int n = n0 + tid;
+    float c_sc = 1.0f, c_bias = 0.0f;
+    int c_corr = 0;
     if (n < d.Cout) {
       const int4 wmv = reinterpret_cast<const int4*>(d.wmeta)[n];
-      corr_[j] = (128 - za) * (wmv.y - p.Ktot * wmv.x);
-      sc_[j] = aqp.x * d.wscale[n];
-      bias_[j] = d.bias ? d.bias[n] : 0.0f;
+      c_corr = (128 - za) * (wmv.y - p.Ktot * wmv.x);
+      c_sc = aqp.x * d.wscale[n];
+      c_bias = d.bias ? d.bias[n] : 0.0f;
+    }
+    cs[tid] = c_sc;
+    reinterpret_cast<int*>(cs)[BN + tid] = c_corr;
+    cs[2 * BN + tid] = c_bias;
+    if (rowadd) {
+      for (int k = 0; k < sp.imgs; ++k) {
+        const int b = (b0 + k) < d.B ? (b0 + k) : d.B - 1;
+        cs[(3 + k) * BN + tid] = n < d.Cout ? rowadd[static_cast<size_t>(b) * d.rowadd_ld + n] : 0.0f;
+      }
     }
   }
-  const int gq = tid / TPR, c4 = (tid % TPR) * 4;      // phase 2: wave-row group, first of 4 channels (tid < 4 * TPR)
-  // phase 1 of pass (i, g): 4 accumulator registers of every N-tile -> LDS.  Instantiated per pass (the registers must be
-  // static); everything else of a pass is shared code in a rolled loop -- eight copies of the store pass were ~280 KB
-  // of instructions, far beyond the instruction cache
-  auto stage = [&](auto pass_tag) {
-    constexpr int pass = decltype(pass_tag)::value;
-    constexpr int i = pass >> 2, g = pass & 3;
+  const bool res16 = d.residual && d.res_f16;
+  constexpr int NS = 2 * WN, PD = 3;       // (i, j) steps of a wave; prefetch distance of the fp16 residual octets
+  uint4 rq[PD][2];
+  auto rrow = [&](int i) { const int m = m0 + wm * 64 + i * 32 + (lane & 31); return m < p.M ? m : p.M - 1; };
+  auto load_rq = [&](int st, uint4 (&dst)[2]) {
+    const int i = st / WN, j = st - i * WN;
+    const size_t base = static_cast<size_t>(rrow(i)) * d.Cout;
 #pragma unroll
-    for (int j = 0; j < WN; ++j) {
-      const int col = (wn * WN + j) * 32 + (lane & 31);
-#pragma unroll
-      for (int rr = 0; rr < 4; ++rr)
-        ldsO[(wm * 8 + rr + 4 * h) * LDO + col] = sc_[j] * static_cast<float>(acc[i][j][g * 4 + rr] + corr_[j]) + bias_[j];
+    for (int u = 0; u < 2; ++u) {
+      const int n = n0 + (wn * WN + j) * 32 + 16 * h + 8 * u;
+      dst[u] = *reinterpret_cast<const uint4*>(reinterpret_cast<const __half*>(d.residual) + base + (n < d.Cout ? n : 0));
     }
   };
-#pragma unroll 1
-  for (int pass = 0; pass < 8; ++pass) {
-    const int i = pass >> 2, g = pass & 3;
-    // fp16-stream store pass: its residual rows (and the image's temb row) are requested here, branch-free, so that their
-    // latency runs under the staging below instead of forming a chain of 8 dependent waits in the row loop
-    constexpr int TPR8 = BN / 8;
-    const bool act8 = o16 && h8 && tid < 4 * TPR8;
-    const int gq8 = tid / TPR8, c8 = (tid % TPR8) * 8;
-    uint4 rres[8];
-    float4 ra0 = make_float4(0.f, 0.f, 0.f, 0.f), ra1 = ra0;
-    if (act8) {
-      const int row0 = gq8 * 64 + i * 32 + g * 8;
-      const int nc = (n0 + c8) < d.Cout ? (n0 + c8) : 0;
-      if (d.residual && d.res_f16) {
+  if (res16) {
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-          const int mc = (m0 + row0 + k) < p.M ? (m0 + row0 + k) : p.M - 1;
-          rres[k] = *reinterpret_cast<const uint4*>(reinterpret_cast<const __half*>(d.residual) + static_cast<size_t>(mc) * d.Cout + nc);
-        }
-      }
-      if (rowadd) {
-        const int mc = (m0 + row0) < p.M ? (m0 + row0) : p.M - 1;      // the 8 rows of a group belong to one image (8 | H*W)
-        ra0 = *reinterpret_cast<const float4*>(rowadd + static_cast<size_t>(mc / hw) * d.rowadd_ld + nc);
-        ra1 = *reinterpret_cast<const float4*>(rowadd + static_cast<size_t>(mc / hw) * d.rowadd_ld + nc + 4);
-      }
-    }
-    __syncthreads();            // previous pass consumed (first pass: every wave has left the K loop)
-    switch (pass) {
-      case 0: stage(std::integral_constant<int, 0>{}); break;
-      case 1: stage(std::integral_constant<int, 1>{}); break;
-      case 2: stage(std::integral_constant<int, 2>{}); break;
-      case 3: stage(std::integral_constant<int, 3>{}); break;
-      case 4: stage(std::integral_constant<int, 4>{}); break;
-      case 5: stage(std::integral_constant<int, 5>{}); break;
-      case 6: stage(std::integral_constant<int, 6>{}); break;
-      default: stage(std::integral_constant<int, 7>{}); break;
-    }
-    __syncthreads();
-    if (q8 && q16) {
-      // int8 output: items of one row x 16 channels (16-byte stores), balanced over the block
-      for (int item = tid; item < 32 * (BN / 16); item += 512) {
-        const int sr = item / (BN / 16), c16 = (item - sr * (BN / 16)) * 16;
-        const int m = m0 + (sr >> 3) * 64 + i * 32 + g * 8 + (sr & 7), n = n0 + c16;
-        if (m >= p.M || n >= d.Cout) continue;
-        unsigned w[4];
+    for (int st = 0; st < PD; ++st) load_rq(st, rq[st]);
+  }
+  __syncthreads();                       // table visible
+
 #pragma unroll
-        for (int q4 = 0; q4 < 4; ++q4) {
-          float4 v = *reinterpret_cast<const float4*>(ldsO + sr * LDO + c16 + 4 * q4);
-          if (rowadd) {
-            const float4 a = *reinterpret_cast<const float4*>(rowadd + static_cast<size_t>(m / hw) * d.rowadd_ld + n + 4 * q4);
-            v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
-          }
-          if (d.residual) {
-            const float4 a = load_res4(d, m, n + 4 * q4);
-            v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
-          }
-          w[q4] = pack_q4(v.x, v.y, v.z, v.w, oqp);
-        }
-        *reinterpret_cast<uint4*>(d.yq + static_cast<size_t>(m) * d.Cout + n) = make_uint4(w[0], w[1], w[2], w[3]);
-      }
-    } else if (o16 && h8) {
-      // fp16 activation stream: items of 8 channels (16 bytes out, 16 bytes of fp16 residual in), 8 rows per thread
-      if (act8) {
-        const int row0 = gq8 * 64 + i * 32 + g * 8, n = n0 + c8;
-        float ps[2][8], pss[2][8];
+  for (int st = 0; st < NS; ++st) {
+    const int i = st / WN, j = st - i * WN;
+    const int ml = wm * 64 + i * 32 + (lane & 31), m = m0 + ml;
+    const bool mok = m < p.M;
+    const int im = sp.imgs == 1 ? 0 : ml / hw;
+    uint4 rcur[2] = {rq[st % PD][0], rq[st % PD][1]};
+    if (res16 && st + PD < NS) load_rq(st + PD, rq[st % PD]);
 #pragma unroll
-        for (int gi = 0; gi < 2; ++gi)
+    for (int u = 0; u < 2; ++u) {
+      const int ct = (wn * WN + j) * 32 + 16 * h + 8 * u, n = n0 + ct;
+      const bool ok = mok && n < d.Cout;
+      f2 v[4];
 #pragma unroll
-          for (int q = 0; q < 8; ++q) ps[gi][q] = pss[gi][q] = 0.0f;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-          const int m = m0 + row0 + k;
-          if (m >= p.M || n >= d.Cout) continue;
-          const float4 v0 = *reinterpret_cast<const float4*>(ldsO + (gq8 * 8 + k) * LDO + c8);
-          const float4 v1 = *reinterpret_cast<const float4*>(ldsO + (gq8 * 8 + k) * LDO + c8 + 4);
-          float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-          if (rowadd) {
-            v[0] += ra0.x; v[1] += ra0.y; v[2] += ra0.z; v[3] += ra0.w; v[4] += ra1.x; v[5] += ra1.y; v[6] += ra1.z; v[7] += ra1.w;
-          }
-          if (d.residual) {
-            if (d.res_f16) {
-              const unsigned uw[4] = {rres[k].x, rres[k].y, rres[k].z, rres[k].w};
-#pragma unroll
-              for (int q = 0; q < 4; ++q) {
-                const float2 f = __half22float2(*reinterpret_cast<const __half2*>(&uw[q]));
-                v[2 * q] += f.x;
-                v[2 * q + 1] += f.y;
-              }
-            } else {
-              const float4 a0 = load_res4(d, m, n), a1 = load_res4(d, m, n + 4);
-              v[0] += a0.x; v[1] += a0.y; v[2] += a0.z; v[3] += a0.w; v[4] += a1.x; v[5] += a1.y; v[6] += a1.z; v[7] += a1.w;
-            }
-          }
-          *reinterpret_cast<uint4*>(reinterpret_cast<__half*>(d.y) + static_cast<size_t>(m) * d.ldy + d.y_coff + n) =
-              make_uint4(pack_h2(v[0], v[1]), pack_h2(v[2], v[3]), pack_h2(v[4], v[5]), pack_h2(v[6], v[7]));
-#pragma unroll
-          for (int q = 0; q < 8; ++q) {
-            ps[k >> 2][q] += v[q];
-            pss[k >> 2][q] += v[q] * v[q];
-          }
-        }
-        if (seg) {
-          float2* pp = ldsP + (gq8 * 8 + i * 4 + g) * BN + c8;
-#pragma unroll
-          for (int q = 0; q < 8; ++q) pp[q] = make_float2(ps[0][q] + ps[1][q], pss[0][q] + pss[1][q]);
-        }
-      }
-    } else     if (tid < 4 * TPR) {
-      const int row0 = gq * 64 + i * 32 + g * 8, n = n0 + c4;
-      float4 ps[2], pss[2];
-      ps[0] = ps[1] = pss[0] = pss[1] = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        const int m = m0 + row0 + k;
-        if (m >= p.M || n >= d.Cout) continue;
-        float4 v = *reinterpret_cast<const float4*>(ldsO + (gq * 8 + k) * LDO + c4);
+      for (int e = 0; e < 2; ++e) {
+        const float4 sc = *reinterpret_cast<const float4*>(cs + ct + 4 * e);
+        const int4 kc = *reinterpret_cast<const int4*>(reinterpret_cast<const int*>(cs) + BN + ct + 4 * e);
+        const float4 bb = *reinterpret_cast<const float4*>(cs + 2 * BN + ct + 4 * e);
+        const v16i& a = acc[i][j];
+        v[2 * e] = f2{sc.x, sc.y} * f2{static_cast<float>(a[8 * u + 4 * e] + kc.x), static_cast<float>(a[8 * u + 4 * e + 1] + kc.y)} + f2{bb.x, bb.y};
+        v[2 * e + 1] = f2{sc.z, sc.w} * f2{static_cast<float>(a[8 * u + 4 * e + 2] + kc.z), static_cast<float>(a[8 * u + 4 * e + 3] + kc.w)} + f2{bb.z, bb.w};
         if (rowadd) {
-          const float4 a = *reinterpret_cast<const float4*>(rowadd + static_cast<size_t>(m / hw) * d.rowadd_ld + n);
-          v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
+          const float4 ra = *reinterpret_cast<const float4*>(cs + (3 + im) * BN + ct + 4 * e);
+          v[2 * e] += f2{ra.x, ra.y};
+          v[2 * e + 1] += f2{ra.z, ra.w};
         }
-        if (d.residual) {
-          float4 a;
-          if (d.res_f16) {
-            const uint2 u = *reinterpret_cast<const uint2*>(reinterpret_cast<const __half*>(d.residual) + static_cast<size_t>(m) * d.Cout + n);
-            const float2 lo = __half22float2(*reinterpret_cast<const __half2*>(&u.x)), hi = __half22float2(*reinterpret_cast<const __half2*>(&u.y));
-            a = make_float4(lo.x, lo.y, hi.x, hi.y);
-          } else {
-            a = *reinterpret_cast<const float4*>(d.residual + static_cast<size_t>(m) * d.Cout + n);
+      }
+      if (d.residual) {
+        if (d.res_f16) {
+          const unsigned uw[4] = {rcur[u].x, rcur[u].y, rcur[u].z, rcur[u].w};
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const float2 f = __half22float2(*reinterpret_cast<const __half2*>(&uw[q]));
+            v[q] += f2{f.x, f.y};
           }
-          v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
+        } else if (ok) {
+          const float4 a0 = *reinterpret_cast<const float4*>(d.residual + static_cast<size_t>(m) * d.Cout + n);
+          const float4 a1 = *reinterpret_cast<const float4*>(d.residual + static_cast<size_t>(m) * d.Cout + n + 4);
+          v[0] += f2{a0.x, a0.y};
+          v[1] += f2{a0.z, a0.w};
+          v[2] += f2{a1.x, a1.y};
+          v[3] += f2{a1.z, a1.w};
         }
+      }
+      if (ok) {
         if (q8) {
-          char4 q;
-          q = quant_char4(v.x, v.y, v.z, v.w, make_quantp(oqp));
-          *reinterpret_cast<char4*>(d.yq + static_cast<size_t>(m) * d.Cout + n) = q;
+          *reinterpret_cast<uint2*>(d.yq + static_cast<size_t>(m) * d.Cout + n) =
+              make_uint2(quant_pack4(v[0].x, v[0].y, v[1].x, v[1].y, qP), quant_pack4(v[2].x, v[2].y, v[3].x, v[3].y, qP));
         } else if (o16) {
-          const __half2 lo = __floats2half2_rn(v.x, v.y), hi = __floats2half2_rn(v.z, v.w);
-          uint2 u;
-          u.x = *reinterpret_cast<const unsigned*>(&lo);
-          u.y = *reinterpret_cast<const unsigned*>(&hi);
-          *reinterpret_cast<uint2*>(reinterpret_cast<__half*>(d.y) + static_cast<size_t>(m) * d.ldy + d.y_coff + n) = u;
+          *reinterpret_cast<uint4*>(reinterpret_cast<__half*>(d.y) + static_cast<size_t>(m) * d.ldy + d.y_coff + n) =
+              make_uint4(pack_h2(v[0].x, v[0].y), pack_h2(v[1].x, v[1].y), pack_h2(v[2].x, v[2].y), pack_h2(v[3].x, v[3].y));
         } else {
-          *reinterpret_cast<float4*>(d.y + static_cast<size_t>(m) * d.ldy + d.y_coff + n) = v;
+          float* dst = d.y + static_cast<size_t>(m) * d.ldy + d.y_coff + n;
+          *reinterpret_cast<float4*>(dst) = make_float4(v[0].x, v[0].y, v[1].x, v[1].y);
+          *reinterpret_cast<float4*>(dst + 4) = make_float4(v[2].x, v[2].y, v[3].x, v[3].y);
         }
-        ps[k >> 2].x += v.x; ps[k >> 2].y += v.y; ps[k >> 2].z += v.z; ps[k >> 2].w += v.w;
-        pss[k >> 2].x += v.x * v.x; pss[k >> 2].y += v.y * v.y; pss[k >> 2].z += v.z * v.z; pss[k >> 2].w += v.w * v.w;
       }
       if (seg) {
-        // an 8-row group = (rows 0..3 added in order) + (rows 4..7 added in order): the order of every tile shape
-        float2* pp = ldsP + (gq * 8 + i * 4 + g) * BN + c4;
-        pp[0] = make_float2(ps[0].x + ps[1].x, pss[0].x + pss[1].x);
-        pp[1] = make_float2(ps[0].y + ps[1].y, pss[0].y + pss[1].y);
-        pp[2] = make_float2(ps[0].z + ps[1].z, pss[0].z + pss[1].z);
-        pp[3] = make_float2(ps[0].w + ps[1].w, pss[0].w + pss[1].w);
+        // per channel: the 8-row group's (sum, sum of squares) of the fp32 values (before any rounding of the output);
+        // rows / columns outside the tensor add exact zeros
+        const int grp = wm * 8 + i * 4 + ((lane & 31) >> 3);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float x0 = ok ? v[e].x : 0.0f, x1 = ok ? v[e].y : 0.0f;
+          const float s0 = group8_sum(x0), s1 = group8_sum(x1);
+          const float q0 = group8_sum(x0 * x0), q1 = group8_sum(x1 * x1);
+          if ((lane & 7) == 0) *reinterpret_cast<float4*>(ldsP + grp * BN + ct + 2 * e) = make_float4(s0, q0, s1, q1);
+        }
       }
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
   if (seg) {
@@ -417,6 +363,7 @@ __global__ __launch_bounds__(512) void k_conv3_slab(SlabP sp) {
       if (row0 < p.M && n < d.Cout) reinterpret_cast<float2*>(d.stats)[static_cast<size_t>(row0 / seg) * d.Cout + n] = a;
     }
   }
+  SLAB_MARK(2);
 }
 
 }  // namespace
@@ -427,7 +374,7 @@ bool launch_conv_slab(tfmq_handle h, ConvP& p, hipStream_t st, bool forced) {
   if (d.KH != 3 || d.KW != 3 || d.stride != 1 || d.pad_t != 1 || d.pad_l != 1 || d.Ho != Hv || d.Wo != Wv || p.Hv != Hv || p.Wv != Wv) return false;
   if (d.Cin % 64 != 0 || static_cast<size_t>(d.B) * d.H * d.W * d.Cin >= (static_cast<size_t>(1) << 31)) return false;
   if (!(d.out_mode == TFMQ_OUT_F32 || d.out_mode == TFMQ_OUT_Q8 || (d.out_mode == TFMQ_OUT_F16 && !d.yt))) return false;
-  if (((d.Cout | d.ldy | d.y_coff) & 3) != 0 || (d.rowadd && (d.rowadd_ld & 3) != 0)) return false;
+  if (((d.Cout | d.ldy | d.y_coff) & 7) != 0) return false;             // a lane moves whole 8-channel octets
   if (d.stats && 256 % d.stats_seg != 0) return false;
   SlabP sp;
   sp.HW = Hv * Wv;
@@ -452,8 +399,35 @@ bool launch_conv_slab(tfmq_handle h, ConvP& p, hipStream_t st, bool forced) {
   p.tiles_n = tiles_n;
   sp.p = p;
   dim3 grid(static_cast<unsigned>(tiles_n) * tiles_m);
+#ifdef TFMQ_PHASE_TIMERS
+  static unsigned long long* dbuf = nullptr;
+  if (!dbuf) (void)hipMalloc(reinterpret_cast<void**>(&dbuf), sizeof(unsigned long long) * 4 * (1u << 16));
+  sp.p.dbg = grid.x <= (1u << 16) ? dbuf : nullptr;
+#endif
   if (WN == 5) hipLaunchKernelGGL((k_conv3_slab<5>), grid, dim3(512), 0, st, sp);
   else if (WN == 4) hipLaunchKernelGGL((k_conv3_slab<4>), grid, dim3(512), 0, st, sp);
   else hipLaunchKernelGGL((k_conv3_slab<2>), grid, dim3(512), 0, st, sp);
+#ifdef TFMQ_PHASE_TIMERS
+  if (sp.p.dbg && getenv("TFMQ_PHASE_PRINT")) {
+    (void)hipStreamSynchronize(st);
+    std::vector<unsigned long long> hb(static_cast<size_t>(grid.x) * 4);
+    (void)hipMemcpy(hb.data(), dbuf, hb.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+    unsigned long long t0 = ~0ull, t1 = 0;
+    double kl = 0, ep = 0;
+    for (unsigned i = 0; i < grid.x; ++i) {
+      t0 = hb[i * 4] < t0 ? hb[i * 4] : t0;
+      t1 = hb[i * 4 + 2] > t1 ? hb[i * 4 + 2] : t1;
+      kl += double(hb[i * 4 + 1] - hb[i * 4]);
+      ep += double(hb[i * 4 + 2] - hb[i * 4 + 1]);
+    }
+    // how synchronised are the blocks: histogram of epilogue-start times over the launch span, 20 bins
+    int hist[20] = {0};
+    for (unsigned i = 0; i < grid.x; ++i) hist[int(double(hb[i * 4 + 1] - t0) / double(t1 - t0 + 1) * 20)]++;
+    fprintf(stderr, "[slab %dx%dx%d Cin%d Cout%d res%d up%d] blocks %u: K loop %.2f us, epilogue %.2f us per block; span %.1f us; epilogue starts per 5%% of the span:",
+            d.B, d.H, d.W, d.Cin, d.Cout, d.residual ? 1 : 0, d.up2x, grid.x, kl / grid.x / 100, ep / grid.x / 100, double(t1 - t0) / 100);
+    for (int k = 0; k < 20; ++k) fprintf(stderr, " %d", hist[k]);
+    fprintf(stderr, "\n");
+  }
+#endif
   return true;
 }
