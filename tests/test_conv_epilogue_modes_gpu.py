@@ -338,7 +338,8 @@ def test_f16_stream_epilogue_equals_rounded_f32_epilogue(ops, k, B, H, cin, cout
 @pytest.mark.parametrize("T,cin,cout,mode", [(4096, 320, 320, "f16res"), (1000, 64, 192, "f16"), (520, 1280, 320, "q8res"),
                                               (300, 128, 100, "q8"), (777, 320, 2560, "geglu"), (256, 640, 5120, "geglu"),
                                               (40000, 320, 320, "f16res"), (9000, 320, 2560, "geglu"), (33000, 192, 200, "q8res"),
-                                              (20000, 640, 1920, "f16")])
+                                              (20000, 640, 1920, "f16"), (4096, 320, 320, "f16res+stats"), (1024, 640, 640, "f16res+stats"),
+                                              (64, 1280, 1280, "f16+stats")])
 def test_direct_pointwise_kernel_is_bit_identical_to_the_tile_kernels(ops, T, cin, cout, mode):
     """The pointwise kernel with the register-direct epilogue (TFMQ_TILE_DIRECT: swapped MFMA operands, a lane owns 4
     consecutive channels of one pixel, no LDS staging) against the 128x128 tile kernel: fp16 output (+ fp16 residual),
@@ -366,20 +367,27 @@ def test_direct_pointwise_kernel_is_bit_identical_to_the_tile_kernels(ops, T, ci
             kw["out_f16"] = True
         else:
             kw["out_q8"] = oq
-        if mode.endswith("res"):
+        if "res" in mode:
             kw["residual"] = torch.randn(B, T, 1, cout, generator=g).half().to(DEV)
-    outs = []
+        if mode.endswith("+stats"):      # the SpatialTransformer's proj_out: GroupNorm statistics of the consumer (DPP sums)
+            kw["want_stats"] = True
+    outs, stats = [], []
     for tile in (1, 6, 7):      # 7 = TFMQ_TILE_STREAM: persistent blocks, producer wave + four consumer waves (several tiles per block
         ops.set_conv_autotune({})       # in the large cases; fewer than 3 K-steps falls back to the tile kernel)
         orig = _o._tune_conv
         try:
             _o._tune_conv = lambda h, name, kind, d, dsc, t=tile: t
-            outs.append(ops.conv2d_w4a8(xq, pw, sel, **kw).clone())
+            y = ops.conv2d_w4a8(xq, pw, sel, **kw)
+            outs.append(y.clone())
+            if mode.endswith("+stats"):
+                stats.append(y._tfmq_stats[0].clone())
         finally:
             _o._tune_conv = orig
             ops.set_conv_autotune(None)
     assert torch.equal(outs[0], outs[1])
     assert torch.equal(outs[0], outs[2])
+    if stats:
+        assert torch.equal(stats[0], stats[1])
     if mode == "geglu":     # and against the arithmetic spelled out: x * gelu(gate) of the un-fused projection, then the quantizer
         h = ops.conv2d_w4a8(xq, ops.pack_w4(w.to(DEV), wd.to(DEV), wz.to(DEV), bias=b.to(DEV)), sel)
         ref = ops.geglu(h.reshape(B * T, cout), oq)[0].reshape(B, T, 1, cout // 2)

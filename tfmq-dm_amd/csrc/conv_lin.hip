@@ -44,7 +44,7 @@ enum { LIN_F16 = 0, LIN_Q8 = 1, LIN_GEGLU = 2 };
 // and stores of what phase 1 left (k_lin_stream puts the next tile's residual loads between the two).
 template <int MODE, int PHASE = 0>
 __device__ __forceinline__ void lin_epilogue(const ConvP& p, v16i (&acc)[2][2], const float* cs, uint4 (&rres)[2][2][2], bool has_res,
-                                             int m0, int n0, int wm, int wn, int lane, float2 oqp) {
+                                             int m0, int n0, int wm, int wn, int lane, float2 oqp, float2* ldsP = nullptr) {
   constexpr int BN = 128;
   const tfmq_conv_desc& d = p.d;
   const int h = lane >> 5;
@@ -113,6 +113,19 @@ __device__ __forceinline__ void lin_epilogue(const ConvP& p, v16i (&acc)[2][2], 
                   v[2] += f2{a1.x, a1.y};
                   v[3] += f2{a1.z, a1.w};
                 }
+              }
+            }
+            if (MODE == LIN_F16 && PHASE == 0 && ldsP != nullptr) {
+              // GroupNorm statistics of the consumer: per channel the 8-row group's (sum, sum of squares) of the fp32 values,
+              // DPP sums over the 8 lanes of a pixel-row group in the canonical order (conv_common.hpp: group8_sum)
+              const bool ok = mok && n < d.Cout;
+              const int grp = (wm * 2 + i) * 4 + ((lane & 31) >> 3);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                const float x0 = ok ? v[e].x : 0.0f, x1 = ok ? v[e].y : 0.0f;
+                const float s0 = group8_sum(x0), s1 = group8_sum(x1);
+                const float q0 = group8_sum(x0 * x0), q1 = group8_sum(x1 * x1);
+                if ((lane & 7) == 0) *reinterpret_cast<float4*>(ldsP + grp * BN + ct + 2 * e) = make_float4(s0, q0, s1, q1);
               }
             }
             if (PHASE == 1) {        // combined values parked in the accumulator registers (the int32 sums are dead)
@@ -194,8 +207,22 @@ __global__ __launch_bounds__(256, 3) void k_lin_direct(ConvP p) {
   const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wid >> 1, wn = wid & 1;
+  // Tile order inside an XCD's contiguous range: panels of GM row tiles, inside a panel the row tile runs fastest and the
+  // column tile slowest -- the ~96 blocks an XCD holds at once then share GM activation tiles (GM * 128 * Cin bytes, sized
+  // to stay in the 4 MB L2 for the whole panel) and 96 / GM weight tiles, instead of one or two activation tiles and EVERY
+  // weight tile: with N fastest the 13 MB weight matrix of the 1280 -> 10240 projection was re-streamed through the fabric
+  // for every row tile (PMC: 14x the algorithmic fetch bytes on the GEGLU launches).
   const int bid = xcd_tile_id();
-  const int tile_n = bid % p.tiles_n, tile_m = bid / p.tiles_n;
+  const int tiles_m = (p.M + BM - 1) / BM;
+  int gm = (3 << 19) / (BM * d.Cin);                       // 1.5 MB of activation rows
+  gm = gm < 1 ? 1 : (gm > 16 ? 16 : gm);
+  // weights that fit beside the activations keep N fastest (gm = 1): the column tiles of a row tile then run at the same
+  // moment and its activation rows are fetched once (1280 -> 320 with three column tiles: panels were 16 % slower)
+  if (static_cast<long>(p.cout_pad) * d.Cin < (2L << 20)) gm = 1;
+  const int per_panel = gm * p.tiles_n;
+  const int panel = bid / per_panel, rp = bid - panel * per_panel;
+  const int gml = (tiles_m - panel * gm) < gm ? (tiles_m - panel * gm) : gm;      // rows of this (possibly last, shorter) panel
+  const int tile_n = rp / gml, tile_m = panel * gm + (rp - tile_n * gml);
   const int m0 = tile_m * BM, n0 = tile_n * BN;
 
   // ---- DMA sources (pointwise: pixel m reads input pixel m; rows past M read the zero row of the pad table)
@@ -297,7 +324,26 @@ __global__ __launch_bounds__(256, 3) void k_lin_direct(ConvP p) {
   }
   __syncthreads();
 
-  lin_epilogue<MODE>(p, acc, cs, rres, has_res, m0, n0, wm, wn, lane, oqp);
+  // statistics partials [16 eight-row groups][BN] live in the (now idle) DMA stages
+  float2* ldsP = (MODE == LIN_F16 && d.stats) ? reinterpret_cast<float2*>(lds) : nullptr;
+  lin_epilogue<MODE>(p, acc, cs, rres, has_res, m0, n0, wm, wn, lane, oqp, ldsP);
+  if constexpr (MODE == LIN_F16) {
+    if (d.stats) {
+      __syncthreads();
+      const int seg = d.stats_seg, nseg = BM / seg, gps = seg / 8;
+      for (int o = tid; o < nseg * BN; o += 256) {
+        const int sidx = o / BN, col = o - sidx * BN;
+        float2 a = make_float2(0.0f, 0.0f);
+        for (int q = 0; q < gps; ++q) {            // a segment = its 8-row groups added in row order
+          const float2 b = ldsP[(sidx * gps + q) * BN + col];
+          a.x += b.x;
+          a.y += b.y;
+        }
+        const int row0 = m0 + sidx * seg, n = n0 + col;
+        if (row0 < p.M && n < d.Cout) reinterpret_cast<float2*>(d.stats)[static_cast<size_t>(row0 / seg) * d.Cout + n] = a;
+      }
+    }
+  }
 }
 
 
@@ -507,7 +553,8 @@ bool launch_conv_lin(tfmq_handle h, ConvP& p, hipStream_t st, bool stream) {
   const tfmq_conv_desc& d = p.d;
   if (d.KH != 1 || d.KW != 1 || d.stride != 1 || d.up2x || d.pad_t != 0 || d.pad_l != 0 || d.Ho != d.H || d.Wo != d.W) return false;
   if (d.Cin % 64 != 0 || static_cast<size_t>(d.B) * d.H * d.W * d.Cin >= (static_cast<size_t>(1) << 31)) return false;
-  if (d.rowadd || d.stats || (d.Cout & 7) != 0) return false;      // a lane moves whole 8-channel octets
+  if (d.rowadd || (d.Cout & 7) != 0) return false;                 // a lane moves whole 8-channel octets
+  if (d.stats && (stream || d.out_mode != TFMQ_OUT_F16 || d.yt || 128 % d.stats_seg != 0)) return false;
   if (d.yt && (d.out_mode != TFMQ_OUT_F16 || d.residual)) return false;
   int mode;
   if (d.out_mode == TFMQ_OUT_F16) {

@@ -399,7 +399,7 @@ def _tune_conv(h, name, kind, d, dsc):
     if kind == "w4a8" and slab_ok(dsc):
         cands.append(5)
     if (kind == "w4a8" and dsc.KH == 1 and dsc.KW == 1 and dsc.stride == 1 and not dsc.up2x and dsc.Cin % 64 == 0 and dsc.Cout % 4 == 0
-            and dsc.out_mode in (1, 2, 3) and not dsc.rowadd and not dsc.stats and not (dsc.yt and dsc.residual)):
+            and dsc.out_mode in (1, 2, 3) and not dsc.rowadd and not (dsc.stats and dsc.out_mode != 1) and not (dsc.yt and dsc.residual)):
         cands.append(6)
         # (7 = TFMQ_TILE_STREAM, the persistent producer / consumer variant, is selectable but not a candidate: measured
         # 3-60 % slower than 6 on every SD shape -- DESIGN.md section 4)
