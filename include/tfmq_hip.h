@@ -182,12 +182,14 @@ typedef struct tfmq_conv_desc {
                                     epilogue runs out of the accumulator registers (swapped MFMA operands, no LDS staging).
                                     TFMQ_TILE_STREAM: the same GEMM as persistent blocks -- a producer wave streams the LDS-DMA of
                                     consecutive tiles through one ring, four consumer waves multiply and store (>= 3 K-steps,
-                                    residual only from the fp16 stream) */
+                                    residual only from the fp16 stream).
+                                    TFMQ_TILE_PERSIST: TFMQ_TILE_DIRECT's block looping over tiles, the LDS-DMA ring running across tile
+                                    boundaries with exact counted waits (>= 3 K-steps, no transposed region, no statistics) */
   int32_t res_f16;               /* != 0: `residual` is an fp16 buffer [B][Ho][Wo][Cout] (a tensor of the fp16 activation stream:
                                     the TFMQ_OUT_F16 output of an earlier launch) */
 } tfmq_conv_desc;
 enum { TFMQ_OUT_F32 = 0, TFMQ_OUT_F16 = 1, TFMQ_OUT_GEGLU_Q8 = 2, TFMQ_OUT_Q8 = 3 };
-enum { TFMQ_TILE_AUTO = 0, TFMQ_TILE_128 = 1, TFMQ_TILE_64 = 2, TFMQ_TILE_256 = 3, TFMQ_TILE_128x64 = 4, TFMQ_TILE_SLAB = 5, TFMQ_TILE_DIRECT = 6, TFMQ_TILE_STREAM = 7 };
+enum { TFMQ_TILE_AUTO = 0, TFMQ_TILE_128 = 1, TFMQ_TILE_64 = 2, TFMQ_TILE_256 = 3, TFMQ_TILE_128x64 = 4, TFMQ_TILE_SLAB = 5, TFMQ_TILE_DIRECT = 6, TFMQ_TILE_STREAM = 7, TFMQ_TILE_PERSIST = 8 };
 int tfmq_conv2d_w4a8(tfmq_handle h, const tfmq_conv_desc* d, void* stream);
 int tfmq_conv2d_f16(tfmq_handle h, const tfmq_conv_desc* d, void* stream);
 
@@ -296,6 +298,10 @@ int tfmq_dpm_x0(tfmq_handle h, const float* x, const float* eps, float sigma, fl
 int tfmq_dpm_update(tfmq_handle h, int order, const float* x, const float* m0, const float* m1_or_null, float c_x, float c_m,
                     float c_d, float inv_r0, float* out, size_t n, void* stream);
 int tfmq_step_advance(tfmq_handle h, int32_t* step, int delta, void* stream);
+/* Device self-test of instruction semantics the kernels rely on (v_cvt_pk_u8_f32 saturation to [0, 255], DPP lane
+ * selection of the statistics sums).  0 = all hold; otherwise an error with *report = failing-check bit mask.  Synchronous,
+ * allocates 4 bytes for the duration of the call; not for use under stream capture. */
+int tfmq_hw_selftest(tfmq_handle h, uint32_t* report);
 /* fp32 -> fp16 copy (round to nearest even): operand of tfmq_conv2d_f16 with x_f16 when the producer writes fp32 */
 int tfmq_f32_to_f16(tfmq_handle h, const float* x, uint16_t* y, size_t n, void* stream);
 /* y = x*sigmoid(x)  (nonlinearity, ddim/models/diffusion.py:27-29) */

@@ -14,6 +14,9 @@ if os.environ.get("SHAPES") == "qkv":        # fused q|k|v projections: q|k fp16
     shapes = [(4096, 320, 960, "qkv"), (1024, 640, 1920, "qkv"), (256, 1280, 3840, "qkv"), (64, 1280, 3840, "qkv")]
 if os.environ.get("SHAPES") == "modes":      # one GEMM shape, the three epilogues: what the epilogue arithmetic / stores cost
     shapes = [(4096, 320, 2560, "geglu"), (4096, 320, 2560, "q8"), (4096, 320, 2560, "f16"), (4096, 320, 1280, "q8"), (4096, 320, 1280, "f16")]
+if os.environ.get("ONLY"):
+    shapes = [shapes[int(i)] for i in os.environ["ONLY"].split(",")]
+TILES = tuple(int(t) for t in os.environ.get("TILES", "1,4,6,8").split(","))
 gen = torch.Generator().manual_seed(0)
 qt = torch.tensor([[[0.05, 120.0]]], device=dev)
 sel = ops.qsel(qt)
@@ -36,7 +39,7 @@ for (T, cin, cout, mode) in shapes:
     nops = 2.0 * B * T * cout * cin
     line = f"{B}x{T} {cin}->{cout} {mode}:"
     ref = None
-    for tile in (1, 3, 4, 6, 7):
+    for tile in TILES:
         orig = ops._tune_conv
         ops.set_conv_autotune({})
         ops._tune_conv = lambda h, name, kind, d, dsc, t=tile: t

@@ -11,7 +11,8 @@ shapes = [(4096, 320, 2560, "geglu"), (4096, 320, 320, "f16res"), (4096, 320, 32
 gen = torch.Generator().manual_seed(0)
 sel = ops.qsel(torch.tensor([[[0.05, 120.0]]], device=dev))
 ops.set_conv_autotune({})
-ops._tune_conv = lambda h, name, kind, d, dsc: 7
+TILE = int(os.environ.get('TILE', '7'))
+ops._tune_conv = lambda h, name, kind, d, dsc: TILE
 for (T, cin, cout, mode) in shapes:
     xq = torch.randint(-128, 128, (B, T, 1, cin), dtype=torch.int8, device=dev)
     w = (torch.randn(cout, cin, generator=gen) * 0.02).to(dev)

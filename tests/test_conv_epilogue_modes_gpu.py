@@ -173,7 +173,7 @@ def test_tile_variants_are_bit_identical(ops, k, res, mode, B, H):
         y = ops.conv2d_w4a8(xq, pw, sel, **kw)
     finally:
         ops.set_conv_autotune(None)
-    assert len(cache) == 1 and list(cache.values())[0] in (1, 2, 3, 4, 5, 6, 7)
+    assert len(cache) == 1 and list(cache.values())[0] in (1, 2, 3, 4, 5, 6, 7, 8)
     assert torch.equal(y, outs[0][0])
 
 
@@ -372,7 +372,7 @@ def test_direct_pointwise_kernel_is_bit_identical_to_the_tile_kernels(ops, T, ci
         if mode.endswith("+stats"):      # the SpatialTransformer's proj_out: GroupNorm statistics of the consumer (DPP sums)
             kw["want_stats"] = True
     outs, stats = [], []
-    for tile in (1, 6, 7):      # 7 = TFMQ_TILE_STREAM: persistent blocks, producer wave + four consumer waves (several tiles per block
+    for tile in (1, 6, 7, 8):   # 7 = TFMQ_TILE_STREAM: persistent blocks, producer wave + four consumer waves (several tiles per block
         ops.set_conv_autotune({})       # in the large cases; fewer than 3 K-steps falls back to the tile kernel)
         orig = _o._tune_conv
         try:
@@ -386,6 +386,7 @@ def test_direct_pointwise_kernel_is_bit_identical_to_the_tile_kernels(ops, T, ci
             ops.set_conv_autotune(None)
     assert torch.equal(outs[0], outs[1])
     assert torch.equal(outs[0], outs[2])
+    assert torch.equal(outs[0], outs[3])      # 8 = TFMQ_TILE_PERSIST: symmetric waves, DMA ring across tiles, exact counted waits
     if stats:
         assert torch.equal(stats[0], stats[1])
     if mode == "geglu":     # and against the arithmetic spelled out: x * gelu(gate) of the un-fused projection, then the quantizer

@@ -96,6 +96,7 @@ _SIGS = {
                                      c_void_p, c_void_p, c_void_p]),
     "tfmq_step_advance": (c_int, [c_void_p, c_void_p, c_int, c_void_p]),
     "tfmq_f32_to_f16": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "tfmq_hw_selftest": (c_int, [c_void_p, c_void_p]),
     "tfmq_silu": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "tfmq_nchw_to_nhwc": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "tfmq_nhwc_to_nchw": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
@@ -181,6 +182,8 @@ class Handle:
         self.h = hp
         self.device = device
         self.comm_world = 0     # > 0 once linklink.init_comm bound an RCCL communicator to this handle
+        rep = C.c_uint32(0)
+        self.call("hw_selftest", C.byref(rep))      # instruction semantics the epilogues rely on: fail loudly, never mis-quantise
 
     def call(self, name: str, *args):
         fn = getattr(self.lib, "tfmq_" + name)

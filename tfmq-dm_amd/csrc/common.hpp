@@ -110,7 +110,7 @@ __device__ __forceinline__ float quant_index_f(float x, float delta, float zp, f
 // ---- the 8-bit activation quantizer on packed fp32 (v_pk_mul / v_pk_fma / v_pk_add: two lanes of arithmetic per
 // instruction) with the byte packing done by v_cvt_pk_u8_f32.  Same arithmetic, operation for operation, as
 // quant_index_f (every packed operation is the IEEE operation on each half), so the bins are bit-identical; what changes
-// is the instruction count: 4 bins = 10 packed + 4 rndne + 4 med3 + 4 cvt_pk + 1 xor instead of ~60 scalar-lane ones.
+// is the instruction count: 4 bins = 10 packed + 4 rndne + 4 cvt_pk (saturating) + 1 xor instead of ~60 scalar-lane ones.
 // Epilogues that apply a transcendental and the quantizer to every output (GEGLU) are VALU-bound, not MFMA-bound.
 typedef float f2 __attribute__((ext_vector_type(2)));
 struct QuantP {
@@ -143,10 +143,11 @@ __device__ __forceinline__ unsigned quant_pack4_t(f2 lo, f2 hi, const QuantP& p)
   f2 a = quant_quot2<EXACT_DIV>(lo, p), b = quant_quot2<EXACT_DIV>(hi, p);
   a = f2{__builtin_rintf(a.x), __builtin_rintf(a.y)} + z;
   b = f2{__builtin_rintf(b.x), __builtin_rintf(b.y)} + z;
-  unsigned w = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_amdgcn_fmed3f(a.x, 0.0f, 255.0f), 0, 0u);
-  w = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_amdgcn_fmed3f(a.y, 0.0f, 255.0f), 1, w);
-  w = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_amdgcn_fmed3f(b.x, 0.0f, 255.0f), 2, w);
-  w = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_amdgcn_fmed3f(b.y, 0.0f, 255.0f), 3, w);
+  // the clamp to [0, 255] is the conversion's own saturation (tfmq_hw_selftest pins it on the device)
+  unsigned w = __builtin_amdgcn_cvt_pk_u8_f32(a.x, 0, 0u);
+  w = __builtin_amdgcn_cvt_pk_u8_f32(a.y, 1, w);
+  w = __builtin_amdgcn_cvt_pk_u8_f32(b.x, 2, w);
+  w = __builtin_amdgcn_cvt_pk_u8_f32(b.y, 3, w);
   return w ^ 0x80808080u;
 }
 __device__ __forceinline__ unsigned quant_pack4(float a, float b, float c, float e, const QuantP& p) {
@@ -203,22 +204,22 @@ __device__ __forceinline__ float erf_fast_f(float x) {
 }
 // gelu(g) = g Phi(g), Phi(g) = 0.5 (1 + erf(g / sqrt 2))   (F.gelu default, "none" approximation), the same 7.1.26
 // polynomial arranged for the fewest instructions: h = Phi(-|g|) = 0.5 poly(t) exp(-g^2 / 2) with the halves folded into
-// the coefficients and 1/sqrt 2 into the constants, Phi = 0.5 + copysign(0.5 - h, g).  |error| <= 5e-7 absolute over
+// the coefficients and 1/sqrt 2 into the constants, and g Phi(g) = relu(g) - |g| h.  |error| <= 5e-7 absolute over
 // [-12, 12] (the arrangement above it: 4.7e-7).  gelu2 is the same operation sequence on packed fp32 -- bit-identical
 // halves -- for the GEMM epilogues.
 __device__ __forceinline__ float gelu_f(float g) {
-  const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(0.23164189f, fabsf(g), 1.0f));
+  const float ag = fabsf(g);
+  const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(0.23164189f, ag, 1.0f));
   float pl = __builtin_fmaf(0.5307027145f, t, -0.7265760135f);
   pl = __builtin_fmaf(pl, t, 0.7107068705f);
   pl = __builtin_fmaf(pl, t, -0.142248368f);
   pl = __builtin_fmaf(pl, t, 0.127414796f);
   pl *= t;
   const float e = __builtin_amdgcn_exp2f((g * g) * -0.72134752044448170368f);
-  const float s = 0.5f - pl * e;
-  return g * (0.5f + copysignf(s, g));
+  return fmaxf(g, 0.0f) - ag * (pl * e);          // g Phi(g) = relu(g) - |g| Phi(-|g|)
 }
 __device__ __forceinline__ f2 gelu2(f2 g) {
-  const f2 one = {1.0f, 1.0f}, half = {0.5f, 0.5f};
+  const f2 one = {1.0f, 1.0f};
   const f2 ag = {fabsf(g.x), fabsf(g.y)};
   const f2 dn = pk_fma(f2{0.23164189f, 0.23164189f}, ag, one);
   const f2 t = {__builtin_amdgcn_rcpf(dn.x), __builtin_amdgcn_rcpf(dn.y)};
@@ -229,8 +230,7 @@ __device__ __forceinline__ f2 gelu2(f2 g) {
   pl = pl * t;
   const f2 m = (g * g) * f2{-0.72134752044448170368f, -0.72134752044448170368f};
   const f2 e = {__builtin_amdgcn_exp2f(m.x), __builtin_amdgcn_exp2f(m.y)};
-  const f2 s = half - pl * e;
-  return g * (half + f2{copysignf(s.x, g.x), copysignf(s.y, g.y)});
+  return f2{fmaxf(g.x, 0.0f), fmaxf(g.y, 0.0f)} - ag * (pl * e);
 }
 
 static inline int ceil_div(long a, long b) { return static_cast<int>((a + b - 1) / b); }

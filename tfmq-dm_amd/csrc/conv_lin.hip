@@ -28,11 +28,13 @@ enum { LIN_F16 = 0, LIN_Q8 = 1, LIN_GEGLU = 2 };
 
 // diagnostics build (-DTFMQ_PHASE_TIMERS): cycles a wave of k_lin_stream spends in each phase of its loop, per block
 #ifdef TFMQ_PHASE_TIMERS
+#define LIN_MARK(i) do { if (p.dbg && threadIdx.x == 0) p.dbg[static_cast<size_t>(blockIdx.x) * 4 + (i)] = wall_clock64(); } while (0)
 #define TFMQ_T0() unsigned long long t_acc[3] = {0, 0, 0}; unsigned long long t_last = wall_clock64()
 #define TFMQ_TACC(i) do { const unsigned long long t_now = wall_clock64(); t_acc[i] += t_now - t_last; t_last = t_now; } while (0)
 #define TFMQ_TDUMP(off, n) do { if (p.dbg && lane == 0) for (int i_ = 0; i_ < (n); ++i_) p.dbg[blockIdx.x * 8 + (off) + i_] = t_acc[i_]; } while (0)
 #else
 #define TFMQ_T0() do { } while (0)
+#define LIN_MARK(i) do { } while (0)
 #define TFMQ_TACC(i) do { } while (0)
 #define TFMQ_TDUMP(off, n) do { } while (0)
 #endif
@@ -207,6 +209,7 @@ __global__ __launch_bounds__(256, 3) void k_lin_direct(ConvP p) {
   const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wid >> 1, wn = wid & 1;
+  LIN_MARK(0);
   // Tile order inside an XCD's contiguous range: panels of GM row tiles, inside a panel the row tile runs fastest and the
   // column tile slowest -- the ~96 blocks an XCD holds at once then share GM activation tiles (GM * 128 * Cin bytes, sized
   // to stay in the 4 MB L2 for the whole panel) and 96 / GM weight tiles, instead of one or two activation tiles and EVERY
@@ -270,6 +273,8 @@ __global__ __launch_bounds__(256, 3) void k_lin_direct(ConvP p) {
   // ---- requested now, consumed after the K loop: per-column constants (threads < BN), the quantizer parameters, and the
   // residual values of this lane's outputs (branch-free: clamped addresses).  They are younger than the first DMA
   // pieces, so the loop's counted waits stay correct (only its first step waits for more than it needs).
+  // (Writing the table before step 0 and starting the accumulators at the zero-point correction -- no zero fill, no integer
+  // add per output -- was measured: 4-7 % SLOWER on the GEGLU projections; the LDS round trip sits on the block's latency chain.)
   float c_ws = 1.0f, c_bias = 0.0f;
   int c_zp = 0, c_rs = 0;
   if (tid < BN) {
@@ -294,6 +299,7 @@ __global__ __launch_bounds__(256, 3) void k_lin_direct(ConvP p) {
     if (s + 1 < p.nsteps) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLOAD) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     asm volatile("s_barrier" ::: "memory");
+    if (s == 0) LIN_MARK(1);
     if (s + 2 < p.nsteps) issue(s + 2, st_i);
     const unsigned char* sa = lds + st_c * STAGE;
     const unsigned char* sb = sa + BM * 64;
@@ -314,6 +320,7 @@ __global__ __launch_bounds__(256, 3) void k_lin_direct(ConvP p) {
     st_i = st_i == NST - 1 ? 0 : st_i + 1;
   }
 
+  LIN_MARK(2);
   // ---- per-column constants -> LDS table {scale, zero-point correction (as float bits of an int), bias}
   float* cs = reinterpret_cast<float*>(lds + CONST_OFF);
   const int za = static_cast<int>(aqp.y);
@@ -343,6 +350,201 @@ __global__ __launch_bounds__(256, 3) void k_lin_direct(ConvP p) {
         if (row0 < p.M && n < d.Cout) reinterpret_cast<float2*>(d.stats)[static_cast<size_t>(row0 / seg) * d.Cout + n] = a;
       }
     }
+  }
+  LIN_MARK(3);
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// K5r: k_lin_direct as a PERSISTENT block with symmetric waves.  scratch/phase_lin.py (TILE=6) on k_lin_direct at K = 320: a
+// block lives 3.3 us until its first DMA data, 2.8 us in the K loop, 4.8 us in the epilogue, three blocks per CU -- 3.3-4 us
+// per tile and CU whatever the arithmetic costs.  Here a block walks tiles bid, bid + G, bid + 2G, ... and its LDS-DMA ring
+// runs across tile boundaries: steps 0 and 1 of tile t+1 are requested at the last two steps of tile t, i.e. BEFORE tile t's
+// epilogue, which therefore hides their latency; nothing of a tile's life is spent waiting for a first load or for stores to
+// drain.  Every wave issues DMA *and* stores (a single producer wave cannot feed the stream: K5q), which the in-order vmcnt
+// allows only with EXACT counted waits: the first two steps of a tile wait for everything but {the next step's DMA, the
+// previous tile's stores, the constants and residual values requested behind them}, a number that is a compile-time
+// constant for full tiles (a ragged tile falls back to the conservative count for the tile after it).  The constants and
+// residual values are ordinary loads: the compiler, which cannot see the DMA instructions, waits for "everything" at their
+// first use in the epilogue -- i.e. also for the two prefetched steps of the next tile, which have been in flight since the
+// last two K-steps (inline-asm loads would avoid that wait, but any register copy the compiler places behind such an asm
+// reads the register before the data has landed).
+template <int MODE, bool RES>
+__global__ __launch_bounds__(256, 3) void k_lin_persist(ConvP p, int n_tiles) {
+  constexpr int BM = 128, BN = 128;
+  constexpr int STAGE = (BM + BN) * 64;
+  constexpr int NST = 3;
+  constexpr int NLOAD = 4;                                   // DMA pieces per wave per K-step
+  constexpr int NSTO = MODE == LIN_GEGLU ? 4 : 8;            // store instructions per wave of a full tile
+  constexpr int NC = 3, NR = RES ? 8 : 0;                    // constant / residual loads per wave per tile
+  constexpr int EXTRA = NSTO + NC + NR;
+  constexpr int CONST_OFF = NST * STAGE;
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[NST * STAGE + 3 * BN * 4];
+
+  const tfmq_conv_desc& d = p.d;
+  const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wid >> 1, wn = wid & 1;
+  const int G = gridDim.x, bid = xcd_tile_id();
+  const int tiles_m = (p.M + BM - 1) / BM;
+  int gm = (3 << 19) / (BM * d.Cin);
+  gm = gm < 1 ? 1 : (gm > 16 ? 16 : gm);
+  if (static_cast<long>(p.cout_pad) * d.Cin < (2L << 20)) gm = 1;
+  const int per_panel = gm * p.tiles_n;
+  auto coords = [&](int t, int& m0, int& n0) {              // tile order of k_lin_direct (panels for weights beyond L2)
+    const int panel = t / per_panel, rp = t - panel * per_panel;
+    const int gml = (tiles_m - panel * gm) < gm ? (tiles_m - panel * gm) : gm;
+    const int tn = rp / gml;
+    m0 = (panel * gm + (rp - tn * gml)) * BM;
+    n0 = tn * BN;
+  };
+
+  const unsigned lds0 = static_cast<unsigned>(reinterpret_cast<uintptr_t>(lds));
+  const unsigned char* xb = static_cast<const unsigned char*>(d.x);
+  const int dcol = ((lane & 3) ^ ((lane >> 4) & 3)) * 16;
+  const unsigned char* a_ptr[2];
+  const unsigned char* b_ptr[2];
+  auto set_ptrs = [&](int m0, int n0) {
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int piece = wid * 2 + it;
+      int m = m0 + piece * 16 + (lane >> 2);
+      m = m < p.M ? m : p.M - 1;                               // rows past M: any valid row (never stored)
+      a_ptr[it] = xb + static_cast<size_t>(m) * d.Cin + dcol;
+      int n = n0 + piece * 16 + (lane >> 2);
+      n = n < p.cout_pad ? n : p.cout_pad - 1;
+      b_ptr[it] = static_cast<const unsigned char*>(d.w) + (static_cast<size_t>(n / 32) * p.nsteps * 32 + (n % 32)) * 64 + dcol;
+    }
+  };
+  auto issue = [&](int s, int stage) {
+    const unsigned sbase = lds0 + stage * STAGE;
+    glds16(a_ptr[0] + s * 64, sbase + __builtin_amdgcn_readfirstlane((wid * 2) * 1024));
+    glds16(a_ptr[1] + s * 64, sbase + __builtin_amdgcn_readfirstlane((wid * 2 + 1) * 1024));
+    glds16(b_ptr[0] + static_cast<size_t>(s) * 2048, sbase + __builtin_amdgcn_readfirstlane(BM * 64 + (wid * 2) * 1024));
+    glds16(b_ptr[1] + static_cast<size_t>(s) * 2048, sbase + __builtin_amdgcn_readfirstlane(BM * 64 + (wid * 2 + 1) * 1024));
+  };
+  auto ncol0 = [&](int j) { return MODE == LIN_GEGLU ? j * 64 + wn * 32 : (wn * 2 + j) * 32; };
+  const int fsw = (h ^ ((lane >> 2) & 3)) << 4;
+  const int brow = lin_brow(lane & 31);
+  const int bsw = (h ^ ((brow >> 2) & 3)) << 4;
+
+  // quantizer parameters: needed (and therefore complete) before anything else is requested
+  const float2 aqp = load_qparam(d.aq);
+  float2 oqp = make_float2(1.0f, 0.0f);
+  if constexpr (MODE != LIN_F16) oqp = load_qparam(d.oq);
+  const int za = static_cast<int>(aqp.y);
+  const float a_delta = aqp.x + 0.0f * oqp.x;               // (uses both: the compiler waits for them here)
+  asm volatile("" ::"v"(a_delta), "v"(za));
+
+  // per-column constants of a tile: every thread loads column tid % BN (the same instruction count in every wave)
+  const float* biasp = d.bias ? d.bias : d.wscale;
+  const float bias_on = d.bias ? 1.0f : 0.0f;
+  int c_zp, c_rs, c_ws, c_b;                                // raw bits; valid one tile later
+  auto load_consts = [&](int n0) {
+    int n = n0 + (tid & (BN - 1));
+    n = n < d.Cout ? n : d.Cout - 1;
+    const int4 m4 = reinterpret_cast<const int4*>(d.wmeta)[n];
+    c_zp = m4.x;
+    c_rs = m4.y;
+    c_ws = __float_as_int(d.wscale[n]);
+    c_b = __float_as_int(biasp[n]);
+  };
+  uint4 rres[2][2][2];
+  auto load_res = [&](int m0, int n0) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int m = m0 + (wm * 2 + i) * 32 + (lane & 31);
+      const int mc = m < p.M ? m : p.M - 1;
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int n = n0 + ncol0(j) + 16 * h + 8 * u;
+          const int nc = n < d.Cout ? n : 0;
+          rres[i][j][u] = *reinterpret_cast<const uint4*>(reinterpret_cast<const __half*>(d.residual) + static_cast<size_t>(mc) * d.Cout + nc);
+        }
+    }
+  };
+  float* cs = reinterpret_cast<float*>(lds + CONST_OFF);
+
+  int t = bid;
+  if (t >= n_tiles) return;
+  int m0, n0;
+  coords(t, m0, n0);
+  set_ptrs(m0, n0);
+  load_consts(n0);
+  if constexpr (RES) load_res(m0, n0);
+  issue(0, 0);
+  issue(1, 1);                                               // nsteps >= 3
+  int st_c = 0, st_i = 2;
+  bool steady = false;                                       // the counted waits of steps 0 / 1 may leave EXTRA operations in flight
+  const int ns = p.nsteps;
+
+  while (true) {
+    const int t_next = t + G;
+    const bool has_next = t_next < n_tiles;
+    int m1 = 0, n1 = 0;
+    if (has_next) coords(t_next, m1, n1);
+    v16i acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0;
+
+    for (int s = 0; s < ns; ++s) {
+      const bool younger = (s + 1 < ns) || has_next;          // the next flat step's DMA is in flight behind this step's
+      if (!younger) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      else if (steady && s < 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLOAD + EXTRA) : "memory");
+      else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLOAD) : "memory");
+      asm volatile("s_barrier" ::: "memory");
+      const int s2 = s + 2;
+      if (s2 < ns) {
+        issue(s2, st_i);
+        st_i = st_i == NST - 1 ? 0 : st_i + 1;
+      } else if (has_next) {
+        if (s2 == ns) set_ptrs(m1, n1);
+        issue(s2 - ns, st_i);
+        st_i = st_i == NST - 1 ? 0 : st_i + 1;
+      }
+      const unsigned char* sa = lds + st_c * STAGE;
+      const unsigned char* sb = sa + BM * 64;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        v4i af[2], bf[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) af[i] = *reinterpret_cast<const v4i*>(sa + ((wm * 2 + i) * 32 + (lane & 31)) * 64 + (fsw ^ (ks << 5)));
+#pragma unroll
+        for (int j = 0; j < 2; ++j) bf[j] = *reinterpret_cast<const v4i*>(sb + (ncol0(j) + brow) * 64 + (bsw ^ (ks << 5)));
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(bf[j], af[i], acc[i][j], 0, 0, 0);
+      }
+      st_c = st_c == NST - 1 ? 0 : st_c + 1;
+    }
+
+    // ---- epilogue of tile t (the constants / residual values were requested a tile ago and are complete: step 2's wait)
+    if (tid < BN) {
+      cs[tid] = aqp.x * __int_as_float(c_ws);
+      reinterpret_cast<int*>(cs)[BN + tid] = (128 - za) * (c_rs - p.Ktot * c_zp);
+      cs[2 * BN + tid] = __int_as_float(c_b) * bias_on;
+    }
+    LDS_BARRIER();
+    if constexpr (RES) {
+      lin_epilogue<MODE, 1>(p, acc, cs, rres, true, m0, n0, wm, wn, lane, oqp);
+      load_res(has_next ? m1 : m0, has_next ? n1 : n0);
+      lin_epilogue<MODE, 2>(p, acc, cs, rres, true, m0, n0, wm, wn, lane, oqp);
+    } else {
+      lin_epilogue<MODE>(p, acc, cs, rres, false, m0, n0, wm, wn, lane, oqp);
+    }
+    load_consts(has_next ? n1 : n0);
+    steady = (m0 + BM <= p.M) && (n0 + BN <= d.Cout);       // exactly NSTO store instructions were issued
+    if (!has_next) break;
+    t = t_next;
+    m0 = m1;
+    n0 = n1;
   }
 }
 
@@ -549,7 +751,8 @@ __global__ __launch_bounds__(320, RES ? 3 : 4) void k_lin_stream(ConvP p, int n_
 
 }  // namespace
 
-bool launch_conv_lin(tfmq_handle h, ConvP& p, hipStream_t st, bool stream) {
+bool launch_conv_lin(tfmq_handle h, ConvP& p, hipStream_t st, int variant) {
+  const bool stream = variant == 1, persist = variant == 2;
   const tfmq_conv_desc& d = p.d;
   if (d.KH != 1 || d.KW != 1 || d.stride != 1 || d.up2x || d.pad_t != 0 || d.pad_l != 0 || d.Ho != d.H || d.Wo != d.W) return false;
   if (d.Cin % 64 != 0 || static_cast<size_t>(d.B) * d.H * d.W * d.Cin >= (static_cast<size_t>(1) << 31)) return false;
@@ -573,6 +776,18 @@ bool launch_conv_lin(tfmq_handle h, ConvP& p, hipStream_t st, bool stream) {
   const int n_tiles = p.tiles_n * tiles_m;
   const bool stream_ok = p.nsteps >= 3 && (!d.residual || d.res_f16) && static_cast<size_t>(p.cout_pad) * p.Ktot < (static_cast<size_t>(1) << 31);
   if (stream && !stream_ok) return false;
+  if (persist) {
+    if (!stream_ok || d.yt || d.stats || d.B * d.H * static_cast<long>(d.W) * d.Cin >= (1L << 31)) return false;
+    const int nblk = n_tiles < h->cu_count * 3 ? n_tiles : h->cu_count * 3;
+    dim3 g3(static_cast<unsigned>(nblk));
+    const bool res = d.residual != nullptr;
+    if (mode == LIN_F16 && res) hipLaunchKernelGGL((k_lin_persist<LIN_F16, true>), g3, dim3(256), 0, st, p, n_tiles);
+    else if (mode == LIN_F16) hipLaunchKernelGGL((k_lin_persist<LIN_F16, false>), g3, dim3(256), 0, st, p, n_tiles);
+    else if (mode == LIN_Q8 && res) hipLaunchKernelGGL((k_lin_persist<LIN_Q8, true>), g3, dim3(256), 0, st, p, n_tiles);
+    else if (mode == LIN_Q8) hipLaunchKernelGGL((k_lin_persist<LIN_Q8, false>), g3, dim3(256), 0, st, p, n_tiles);
+    else hipLaunchKernelGGL((k_lin_persist<LIN_GEGLU, false>), g3, dim3(256), 0, st, p, n_tiles);
+    return true;
+  }
   if (stream) {
     // persistent blocks: three per CU (51 KiB of LDS, five waves each), two for the residual variants (register budget)
     const int per_cu = d.residual ? 2 : 3;
@@ -604,8 +819,32 @@ bool launch_conv_lin(tfmq_handle h, ConvP& p, hipStream_t st, bool stream) {
     return true;
   }
   dim3 grid(static_cast<unsigned>(n_tiles));
+#ifdef TFMQ_PHASE_TIMERS
+  static unsigned long long* dbuf2 = nullptr;
+  if (!dbuf2) (void)hipMalloc(reinterpret_cast<void**>(&dbuf2), sizeof(unsigned long long) * 4 * (1u << 18));
+  p.dbg = grid.x <= (1u << 18) ? dbuf2 : nullptr;
+#endif
   if (mode == LIN_F16) hipLaunchKernelGGL((k_lin_direct<LIN_F16>), grid, dim3(256), 0, st, p);
   else if (mode == LIN_Q8) hipLaunchKernelGGL((k_lin_direct<LIN_Q8>), grid, dim3(256), 0, st, p);
   else hipLaunchKernelGGL((k_lin_direct<LIN_GEGLU>), grid, dim3(256), 0, st, p);
+#ifdef TFMQ_PHASE_TIMERS
+  if (p.dbg && getenv("TFMQ_PHASE_PRINT")) {
+    (void)hipStreamSynchronize(st);
+    std::vector<unsigned long long> hb(static_cast<size_t>(grid.x) * 4);
+    (void)hipMemcpy(hb.data(), dbuf2, hb.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+    double a = 0, b = 0, c = 0;
+    unsigned long long t0 = ~0ull, t1 = 0;
+    for (unsigned i = 0; i < grid.x; ++i) {
+      a += double(hb[i * 4 + 1] - hb[i * 4]);
+      b += double(hb[i * 4 + 2] - hb[i * 4 + 1]);
+      c += double(hb[i * 4 + 3] - hb[i * 4 + 2]);
+      t0 = hb[i * 4] < t0 ? hb[i * 4] : t0;
+      t1 = hb[i * 4 + 3] > t1 ? hb[i * 4 + 3] : t1;
+    }
+    const double span = double(t1 - t0) / 100.0, blocks_per_cu = double(grid.x) / h->cu_count;
+    fprintf(stderr, "[lin_direct Cin%d Cout%d mode%d] blocks %u (%.1f per CU): start->first data %.2f us, K loop %.2f us, epilogue (to last store issued) %.2f us per block; span %.1f us = %.2f us per block slot of 3 per CU\n",
+            d.Cin, d.Cout, mode, grid.x, blocks_per_cu, a / grid.x / 100, b / grid.x / 100, c / grid.x / 100, span, span / (blocks_per_cu / 3.0));
+  }
+#endif
   return true;
 }

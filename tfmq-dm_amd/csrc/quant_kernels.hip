@@ -519,3 +519,51 @@ extern "C" int tfmq_pack_w_f16(tfmq_handle h, const float* w, const float* alpha
   TFMQ_LAUNCH_CHECK(h);
   return TFMQ_OK;
 }
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Hardware semantics the epilogues rely on and the ISA text leaves implicit, checked on the device once per handle user
+// (tfmq_hw_selftest; the Python layer calls it when it creates a handle and refuses to run otherwise):
+//   * v_cvt_pk_u8_f32 SATURATES to [0, 255] (quant_pack4 leaves the clamp of clamp(rint(x / delta) + zp, 0, 255) to it), converts
+//     integers exactly and keeps the other three bytes of the destination;
+//   * DPP quad_perm / row_shl source lanes as group8_sum (conv_common.hpp) assumes them.
+__global__ void k_hw_selftest(unsigned* out) {
+  const int lane = threadIdx.x;
+  unsigned fail = 0;
+  const float vals[13] = {-1e30f, -300.0f, -1.0f, -0.0f, 0.0f, 1.0f, 127.0f, 128.0f, 254.0f, 255.0f, 256.0f, 300.0f, 1e30f};
+  const unsigned want[13] = {0, 0, 0, 0, 0, 1, 127, 128, 254, 255, 255, 255, 255};
+#pragma unroll
+  for (int i = 0; i < 13; ++i) {
+    const unsigned w = __builtin_amdgcn_cvt_pk_u8_f32(vals[i], 2, 0xAABBCCDDu);
+    if (((w >> 16) & 0xffu) != want[i] || (w & 0xff00ffffu) != 0xAA00CCDDu) fail |= 1u;
+  }
+  for (int k = 0; k < 4; ++k) {                       // every integer 0..255
+    const unsigned v = lane * 4 + k;
+    if ((__builtin_amdgcn_cvt_pk_u8_f32(static_cast<float>(v), 0, 0u) & 0xffu) != v) fail |= 2u;
+  }
+  const float x = static_cast<float>(lane);
+  const float q1 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x55, 0xf, 0xf, true));
+  const float q3 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0xFF, 0xf, 0xf, true));
+  const float s4 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x104, 0xf, 0xf, true));
+  if (q1 != static_cast<float>((lane & ~3) + 1) || q3 != static_cast<float>((lane & ~3) + 3)) fail |= 4u;
+  if ((lane & 15) < 12 && s4 != static_cast<float>(lane + 4)) fail |= 8u;
+  if (fail) atomicOr(out, fail);
+}
+
+extern "C" int tfmq_hw_selftest(tfmq_handle h, uint32_t* report) {
+  TFMQ_CHECK_ARG(h, h != nullptr, "hw_selftest: null handle");
+  unsigned* d = nullptr;
+  if (hipMalloc(reinterpret_cast<void**>(&d), sizeof(unsigned)) != hipSuccess) return TFMQ_ERR_HIP;
+  (void)hipMemset(d, 0, sizeof(unsigned));
+  hipLaunchKernelGGL(k_hw_selftest, dim3(1), dim3(64), 0, nullptr, d);
+  unsigned r = 0xffffffffu;
+  const hipError_t e = hipMemcpy(&r, d, sizeof(unsigned), hipMemcpyDeviceToHost);
+  (void)hipFree(d);
+  if (e != hipSuccess) return TFMQ_ERR_HIP;
+  if (report) *report = r;
+  if (r != 0) {
+    h->err = "hardware self-test failed (bit 0/1: v_cvt_pk_u8_f32 saturation / exactness, bit 2/3: DPP lane selection): mask " + std::to_string(r);
+    return TFMQ_ERR_HIP;
+  }
+  return TFMQ_OK;
+}

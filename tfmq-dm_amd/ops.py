@@ -334,7 +334,7 @@ def _attach_stats(dsc, y: torch.Tensor, B: int, hw: int, cout: int, want_stats: 
 # the launch stream; a conv is idempotent, so re-running it is harmless) and later launches -- in particular the ones
 # captured into the sampler's hipGraph -- use the winner.  The result does not depend on the tile shape.
 _AUTOTUNE = None      # None = off, else {shape key: tile id}
-_TILE_NAMES = {1: "128x128", 2: "64x64", 3: "256x128", 4: "128x64", 5: "slab 256xN (3x3)", 6: "direct 128x128 (pointwise)", 7: "stream 128x128 (pointwise, persistent)"}
+_TILE_NAMES = {1: "128x128", 2: "64x64", 3: "256x128", 4: "128x64", 5: "slab 256xN (3x3)", 6: "direct 128x128 (pointwise)", 7: "stream 128x128 (pointwise, persistent producer/consumer)", 8: "persist 128x128 (pointwise, persistent symmetric)"}
 
 
 def set_conv_autotune(cache) -> None:
