@@ -14,6 +14,9 @@ if os.environ.get("SHAPES") == "qkv":        # fused q|k|v projections: q|k fp16
     shapes = [(4096, 320, 960, "qkv"), (1024, 640, 1920, "qkv"), (256, 1280, 3840, "qkv"), (64, 1280, 3840, "qkv")]
 if os.environ.get("SHAPES") == "modes":      # one GEMM shape, the three epilogues: what the epilogue arithmetic / stores cost
     shapes = [(4096, 320, 2560, "geglu"), (4096, 320, 2560, "q8"), (4096, 320, 2560, "f16"), (4096, 320, 1280, "q8"), (4096, 320, 1280, "f16")]
+if os.environ.get("SHAPES") == "f16":        # un-quantised skip-connection 1x1 convs (fp16 operands)
+    shapes = [(4096, 640, 320, "h16"), (4096, 960, 320, "h16"), (1024, 1920, 640, "h16"), (1024, 1280, 640, "h16"), (256, 2560, 1280, "h16"),
+              (64, 2560, 1280, "h16")]
 if os.environ.get("ONLY"):
     shapes = [shapes[int(i)] for i in os.environ["ONLY"].split(",")]
 TILES = tuple(int(t) for t in os.environ.get("TILES", "1,4,6,8").split(","))
@@ -21,6 +24,33 @@ gen = torch.Generator().manual_seed(0)
 qt = torch.tensor([[[0.05, 120.0]]], device=dev)
 sel = ops.qsel(qt)
 for (T, cin, cout, mode) in shapes:
+    if mode == "h16":
+        xh = torch.randn(B, T, 1, cin, device=dev).half()
+        pf = ops.pack_w_f16((torch.randn(cout, cin, generator=gen) * 0.02).to(dev), torch.zeros(cout, device=dev))
+        line = f"{B}x{T} {cin}->{cout} f16 operands:"
+        ref = None
+        for tile in TILES:
+            orig = ops._tune_conv
+            ops.set_conv_autotune({})
+            ops._tune_conv = lambda h, name, kind, d, dsc, t=tile: t
+            try:
+                y = ops.conv2d_f16(xh, pf, out_f16=True)
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(5):
+                    y = ops.conv2d_f16(xh, pf, out_f16=True)
+                e1.record()
+                torch.cuda.synchronize()
+                us = e0.elapsed_time(e1) / 5 * 1e3
+            finally:
+                ops._tune_conv = orig
+                ops.set_conv_autotune(None)
+            if ref is None:
+                ref = y.clone()
+            line += f"  t{tile}: {us:7.1f} us{'' if torch.equal(y, ref) else ' MISMATCH'}"
+        print(line, flush=True)
+        continue
     xq = torch.randint(-128, 128, (B, T, 1, cin), dtype=torch.int8, device=dev)
     w = (torch.randn(cout, cin, generator=gen) * 0.02).to(dev)
     qp = ops.minmax_to_qparam(ops.minmax(w, cout), 16)

@@ -50,3 +50,24 @@ def test_cpu_tensor_is_refused_loudly(lib):
 def test_no_device_no_handle(lib):
     with pytest.raises(lib.TfmqError):
         lib.Handle(0)
+
+
+def test_slab_kernel_launch_geometry_rule(lib):
+    """Host-side rule deciding whether the 3x3 slab kernel can take a launch (ops.slab_ok mirrors launch_conv_slab): 256-pixel
+    tiles made of whole image rows or whole images, a slab of at most 512 pixel rows, also with the fused upsample."""
+    import tfmq_dm_amd.ops as ops
+
+    def desc(H, W, cin=320, up=0, k=3, stride=1, pad=1, out_mode=1):
+        d = lib.ConvDesc()
+        d.H, d.W, d.Cin, d.KH, d.KW, d.stride, d.up2x, d.pad_t, d.pad_l, d.out_mode = H, W, cin, k, k, stride, up, pad, pad, out_mode
+        d.Ho, d.Wo = (2 * H, 2 * W) if up else (H, W)
+        return d
+    assert ops.slab_ok(desc(64, 64)) and ops.slab_ok(desc(32, 32)) and ops.slab_ok(desc(16, 16)) and ops.slab_ok(desc(8, 8))
+    assert ops.slab_ok(desc(32, 32, up=1)) and ops.slab_ok(desc(8, 8, up=1))          # Upsample convs: upsampled rows are staged
+    assert not ops.slab_ok(desc(64, 64, cin=96))                                       # Cin % 64
+    assert not ops.slab_ok(desc(64, 64, k=1, pad=0))                                   # pointwise layers go to the direct kernel
+    assert not ops.slab_ok(desc(64, 64, stride=2))
+    assert not ops.slab_ok(desc(24, 24))                                               # 576 pixels: neither 256 | HW nor HW | 256
+    assert not ops.slab_ok(desc(128, 128))                                             # (2 + 2) * 130 = 520 slab rows > 512
+    assert not ops.slab_ok(desc(64, 64, out_mode=2))                                   # GEGLU output is a pointwise mode
+    assert set(ops._TILE_NAMES) == {1, 2, 3, 4, 5, 6, 7, 8}

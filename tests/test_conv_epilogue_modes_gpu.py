@@ -449,3 +449,34 @@ def test_f16_conv_tile_variants_are_bit_identical(ops):
     for y, st in outs[1:]:
         assert torch.equal(y, outs[0][0]) and torch.equal(st, outs[0][1])
     assert torch.equal(outs[0][0], ops.conv2d_f16(x, pf, pad=(1, 1, 1, 1), residual=res))      # == the fp32-input path
+
+
+@pytest.mark.parametrize("B,T,cin,cout,res,wq", [(2, 4096, 640, 320, False, False), (3, 1000, 96, 200, True, False), (1, 256, 2560, 1280, False, True),
+                                                 (4, 64, 320, 648, True, True)])
+def test_direct_pointwise_kernel_on_fp16_operands(ops, B, T, cin, cout, res, wq):
+    """Un-quantised / weight-only pointwise layers (skip-connection 1x1 convs: fp16 activations written by the producing
+    GroupNorm, fp16 weights, f16 MFMA): the register-direct kernel (tile 6) against the LDS-staged tile kernel (tile 1) --
+    fp16 output, optional fp16 residual, with and without a weight-only integer grid + scale; ragged rows and columns."""
+    import tfmq_dm_amd.ops as _o
+    g = torch.Generator().manual_seed(cin + cout)
+    x = (torch.randn(B, T, 1, cin, generator=g) * 1.2).to(DEV)
+    w = torch.randn(cout, cin, generator=g) * (2.0 / cin ** 0.5)
+    b = (torch.randn(cout, generator=g) * 0.2).to(DEV)
+    if wq:
+        wd, wz = O.init_channelwise(w, 16, "minmax")
+        pf = ops.pack_w_f16(w.to(DEV), b, delta=wd.to(DEV), zp=wz.to(DEV))
+    else:
+        pf = ops.pack_w_f16(w.to(DEV), b)
+    xh = ops.to_half(x)
+    r16 = torch.randn(B, T, 1, cout, generator=g).half().to(DEV) if res else None
+    outs = []
+    orig = _o._tune_conv
+    for tile in (1, 6):
+        ops.set_conv_autotune({})
+        try:
+            _o._tune_conv = lambda h, name, kind, d, dsc, t=tile: t
+            outs.append(ops.conv2d_f16(xh, pf, residual=r16, out_f16=True).clone())
+        finally:
+            _o._tune_conv = orig
+            ops.set_conv_autotune(None)
+    assert outs[0].dtype == torch.float16 and torch.equal(outs[0], outs[1])

@@ -110,3 +110,5 @@ bool launch_conv_slab(tfmq_handle h, ConvP& p, hipStream_t st, bool forced);
 // variant 0: one block per tile (k_lin_direct); 1: persistent producer / consumer waves (k_lin_stream); 2: persistent symmetric waves
 // with exact counted waits (k_lin_persist)
 bool launch_conv_lin(tfmq_handle h, ConvP& p, hipStream_t st, int variant);
+// fp16-operand pointwise layers (tfmq_conv2d_f16 with x_f16) on the same kernel
+bool launch_conv_lin_f16(tfmq_handle h, ConvP& p, hipStream_t st);

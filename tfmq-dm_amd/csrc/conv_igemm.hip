@@ -1005,6 +1005,12 @@ static int launch_conv(tfmq_handle h, const tfmq_conv_desc* dd, void* stream) {
     // with the fp32 residual epilogue lose more from 2 instead of 3 resident workgroups than the K loop gains)
     big = big_ok && !small && d.out_mode == TFMQ_OUT_F16 && tiles128 >= 4L * h->cu_count;
   }
+  if constexpr (!INT8) {
+    if ((d.tile == TFMQ_TILE_AUTO || d.tile == TFMQ_TILE_DIRECT) && dma16 && launch_conv_lin_f16(h, p, as_stream(stream))) {
+      TFMQ_LAUNCH_CHECK(h);
+      return TFMQ_OK;
+    }
+  }
   if constexpr (INT8) {
     // token Linears / 1x1 convs writing fp16, int8 or GEGLU-int8: the register-direct-epilogue kernel (conv_lin.hip)
     if (d.tile == TFMQ_TILE_STREAM && d.wmeta && d.wscale && d.aq.qtable && launch_conv_lin(h, p, as_stream(stream), 1)) {

@@ -44,7 +44,9 @@ enum { LIN_F16 = 0, LIN_Q8 = 1, LIN_GEGLU = 2 };
 // as k_conv_dma's epilogue: bit-identical.
 // PHASE 0: everything.  PHASE 1: affine map + residual only, results left in `acc` as float bits.  PHASE 2: conversion
 // and stores of what phase 1 left (k_lin_stream puts the next tile's residual loads between the two).
-template <int MODE, int PHASE = 0>
+// F16OP: fp16 operands (un-quantised layers): the accumulators are fp32 bit patterns and value = scale * acc + bias
+// (scale = 1 unless the weight-only integer grid carries one), the arithmetic of k_conv_dma<true>.
+template <int MODE, int PHASE = 0, bool F16OP = false>
 __device__ __forceinline__ void lin_epilogue(const ConvP& p, v16i (&acc)[2][2], const float* cs, uint4 (&rres)[2][2][2], bool has_res,
                                              int m0, int n0, int wm, int wn, int lane, float2 oqp, float2* ldsP = nullptr) {
   constexpr int BN = 128;
@@ -59,10 +61,15 @@ __device__ __forceinline__ void lin_epilogue(const ConvP& p, v16i (&acc)[2][2], 
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
       const float4 sc = *reinterpret_cast<const float4*>(cs + ct + 4 * e);
-      const int4 kc = *reinterpret_cast<const int4*>(reinterpret_cast<const int*>(cs) + BN + ct + 4 * e);
       const float4 bb = *reinterpret_cast<const float4*>(cs + 2 * BN + ct + 4 * e);
-      v[2 * e] = affine2(a[8 * u + 4 * e + 0], a[8 * u + 4 * e + 1], sc.x, sc.y, kc.x, kc.y, bb.x, bb.y);
-      v[2 * e + 1] = affine2(a[8 * u + 4 * e + 2], a[8 * u + 4 * e + 3], sc.z, sc.w, kc.z, kc.w, bb.z, bb.w);
+      if constexpr (F16OP) {
+        v[2 * e] = f2{sc.x, sc.y} * f2{__int_as_float(a[8 * u + 4 * e + 0]), __int_as_float(a[8 * u + 4 * e + 1])} + f2{bb.x, bb.y};
+        v[2 * e + 1] = f2{sc.z, sc.w} * f2{__int_as_float(a[8 * u + 4 * e + 2]), __int_as_float(a[8 * u + 4 * e + 3])} + f2{bb.z, bb.w};
+      } else {
+        const int4 kc = *reinterpret_cast<const int4*>(reinterpret_cast<const int*>(cs) + BN + ct + 4 * e);
+        v[2 * e] = affine2(a[8 * u + 4 * e + 0], a[8 * u + 4 * e + 1], sc.x, sc.y, kc.x, kc.y, bb.x, bb.y);
+        v[2 * e + 1] = affine2(a[8 * u + 4 * e + 2], a[8 * u + 4 * e + 3], sc.z, sc.w, kc.z, kc.w, bb.z, bb.w);
+      }
     }
   };
   const bool transposed = MODE == LIN_F16 && d.yt != nullptr && n0 >= d.t_col0;      // tile-uniform (t_col0 % 128 == 0)
@@ -196,7 +203,7 @@ __device__ __forceinline__ void lin_load_res(const ConvP& p, uint4 (&rres)[2][2]
   }
 }
 
-template <int MODE>
+template <int MODE, bool F16OP = false>
 __global__ __launch_bounds__(256, 3) void k_lin_direct(ConvP p) {
   constexpr int BM = 128, BN = 128;
   constexpr int STAGE = (BM + BN) * 64;
@@ -238,18 +245,24 @@ __global__ __launch_bounds__(256, 3) void k_lin_direct(ConvP p) {
   for (int it = 0; it < 2; ++it) {
     const int piece = wid * 2 + it;
     const int m = m0 + piece * 16 + (lane >> 2);
-    a_ptr[it] = m < p.M ? xb + static_cast<size_t>(m) * d.Cin + dcol : p.pad_table + dcol;
+    a_ptr[it] = m < p.M ? xb + static_cast<size_t>(m) * d.Cin * (F16OP ? 2 : 1) + dcol : p.pad_table + dcol;
     int n = n0 + piece * 16 + (lane >> 2);
-    n = n < p.cout_pad ? n : p.cout_pad - 1;
-    b_ptr[it] = static_cast<const unsigned char*>(d.w) + (static_cast<size_t>(n / 32) * p.nsteps * 32 + (n % 32)) * 64 + dcol;
+    if constexpr (F16OP) {           // fp16 weights [cout][cin_pad] row-major (tfmq_pack_w_f16), fp16 activations: 32 channels per K-step
+      n = n < d.Cout ? n : d.Cout - 1;
+      b_ptr[it] = static_cast<const unsigned char*>(d.w) + static_cast<size_t>(n) * p.cin_pad * 2 + dcol;
+    } else {
+      n = n < p.cout_pad ? n : p.cout_pad - 1;
+      b_ptr[it] = static_cast<const unsigned char*>(d.w) + (static_cast<size_t>(n / 32) * p.nsteps * 32 + (n % 32)) * 64 + dcol;
+    }
   }
+  constexpr size_t BSTEP = F16OP ? 64 : 2048;
   const bool a_live0 = m0 + (wid * 2) * 16 + (lane >> 2) < p.M, a_live1 = m0 + (wid * 2 + 1) * 16 + (lane >> 2) < p.M;
   auto issue = [&](int s, int stage) {
     const unsigned sbase = lds0 + stage * STAGE;
     glds16(a_ptr[0] + (a_live0 ? s * 64 : 0), sbase + __builtin_amdgcn_readfirstlane((wid * 2) * 1024));
     glds16(a_ptr[1] + (a_live1 ? s * 64 : 0), sbase + __builtin_amdgcn_readfirstlane((wid * 2 + 1) * 1024));
-    glds16(b_ptr[0] + static_cast<size_t>(s) * 2048, sbase + __builtin_amdgcn_readfirstlane(BM * 64 + (wid * 2) * 1024));
-    glds16(b_ptr[1] + static_cast<size_t>(s) * 2048, sbase + __builtin_amdgcn_readfirstlane(BM * 64 + (wid * 2 + 1) * 1024));
+    glds16(b_ptr[0] + static_cast<size_t>(s) * BSTEP, sbase + __builtin_amdgcn_readfirstlane(BM * 64 + (wid * 2) * 1024));
+    glds16(b_ptr[1] + static_cast<size_t>(s) * BSTEP, sbase + __builtin_amdgcn_readfirstlane(BM * 64 + (wid * 2 + 1) * 1024));
   };
 
   // fragment rows: pixels (wm * 2 + i) * 32 + lane % 32; channels of N-tile j: plain (wn * 2 + j) * 32, GEGLU j * 64 + wn * 32
@@ -282,14 +295,19 @@ __global__ __launch_bounds__(256, 3) void k_lin_direct(ConvP p) {
   if (tid < BN) {
     const int n = n0 + tid;
     if (n < d.Cout) {
-      const int4 wmv = reinterpret_cast<const int4*>(d.wmeta)[n];
-      c_zp = wmv.x;
-      c_rs = wmv.y;
-      c_ws = d.wscale[n];
+      if constexpr (!F16OP) {
+        const int4 wmv = reinterpret_cast<const int4*>(d.wmeta)[n];
+        c_zp = wmv.x;
+        c_rs = wmv.y;
+        c_ws = d.wscale[n];
+      } else if (d.wscale) {
+        c_ws = d.wscale[n];
+      }
       c_bias = d.bias ? d.bias[n] : 0.0f;
     }
   }
-  const float2 aqp = load_qparam(d.aq);
+  float2 aqp = make_float2(1.0f, 128.0f);
+  if constexpr (!F16OP) aqp = load_qparam(d.aq);
   float2 oqp = make_float2(1.0f, 0.0f);
   if constexpr (MODE != LIN_F16) oqp = load_qparam(d.oq);
   uint4 rres[2][2][2];                     // MODE F16 / Q8 with a residual: 8 channels x fp16 per (i, j, register octet)
@@ -316,7 +334,16 @@ __global__ __launch_bounds__(256, 3) void k_lin_direct(ConvP p) {
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(bf[j], af[i], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < 2; ++j) {
+          if constexpr (F16OP) {
+            typedef _Float16 v8h_t __attribute__((ext_vector_type(8)));
+            typedef float v16f_t __attribute__((ext_vector_type(16)));
+            v16f_t& af32 = *reinterpret_cast<v16f_t*>(&acc[i][j]);
+            af32 = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<v8h_t*>(&bf[j]), *reinterpret_cast<v8h_t*>(&af[i]), af32, 0, 0, 0);
+          } else {
+            acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(bf[j], af[i], acc[i][j], 0, 0, 0);
+          }
+        }
     }
     st_c = st_c == NST - 1 ? 0 : st_c + 1;
     st_i = st_i == NST - 1 ? 0 : st_i + 1;
@@ -335,7 +362,7 @@ __global__ __launch_bounds__(256, 3) void k_lin_direct(ConvP p) {
 
   // statistics partials [16 eight-row groups][BN] live in the (now idle) DMA stages
   float2* ldsP = (MODE == LIN_F16 && d.stats) ? reinterpret_cast<float2*>(lds) : nullptr;
-  lin_epilogue<MODE>(p, acc, cs, rres, has_res, m0, n0, wm, wn, lane, oqp, ldsP);
+  lin_epilogue<MODE, 0, F16OP>(p, acc, cs, rres, has_res, m0, n0, wm, wn, lane, oqp, ldsP);
   if constexpr (MODE == LIN_F16) {
     if (d.stats) {
       __syncthreads();
@@ -848,5 +875,22 @@ bool launch_conv_lin(tfmq_handle h, ConvP& p, hipStream_t st, int variant) {
             d.Cin, d.Cout, mode, grid.x, blocks_per_cu, a / grid.x / 100, b / grid.x / 100, c / grid.x / 100, span, span / (blocks_per_cu / 3.0));
   }
 #endif
+  return true;
+}
+
+// Un-quantised pointwise layers (skip-connection 1x1 convs of the UNets' up path: fp16 NHWC input written by the producing
+// GroupNorm, fp16 weights): the same register-direct kernel on f16 MFMA.  fp16 output only; false = not taken.
+bool launch_conv_lin_f16(tfmq_handle h, ConvP& p, hipStream_t st) {
+  const tfmq_conv_desc& d = p.d;
+  if (d.KH != 1 || d.KW != 1 || d.stride != 1 || d.up2x || d.pad_t != 0 || d.pad_l != 0 || d.Ho != d.H || d.Wo != d.W) return false;
+  if (!d.x_f16 || d.Cin % 32 != 0 || p.cin_pad != d.Cin || static_cast<size_t>(d.B) * d.H * d.W * d.Cin * 2 >= (static_cast<size_t>(1) << 31)) return false;
+  if (d.out_mode != TFMQ_OUT_F16 || d.rowadd || d.yt || (d.Cout & 7) != 0 || ((d.ldy | d.y_coff) & 7) != 0) return false;
+  if (d.residual && !d.res_f16) return false;
+  if (d.stats && 128 % d.stats_seg != 0) return false;
+  (void)h;
+  p.tiles_n = (d.Cout + 127) / 128;
+  const int tiles_m = (p.M + 127) / 128;
+  dim3 grid(static_cast<unsigned>(p.tiles_n) * tiles_m);
+  hipLaunchKernelGGL((k_lin_direct<LIN_F16, true>), grid, dim3(256), 0, st, p);
   return true;
 }

@@ -401,8 +401,11 @@ def _tune_conv(h, name, kind, d, dsc):
     if (kind == "w4a8" and dsc.KH == 1 and dsc.KW == 1 and dsc.stride == 1 and not dsc.up2x and dsc.Cin % 64 == 0 and dsc.Cout % 4 == 0
             and dsc.out_mode in (1, 2, 3) and not dsc.rowadd and not (dsc.stats and dsc.out_mode != 1) and not (dsc.yt and dsc.residual)):
         cands.append(6)
-        # (7 = TFMQ_TILE_STREAM, the persistent producer / consumer variant, is selectable but not a candidate: measured
-        # 3-60 % slower than 6 on every SD shape -- DESIGN.md section 4)
+        # (7 = TFMQ_TILE_STREAM and 8 = TFMQ_TILE_PERSIST, the persistent variants, are selectable but not candidates: measured
+        # slower than 6 on the SD shapes -- DESIGN.md section 4)
+    if (kind == "f16" and dsc.x_f16 and dsc.KH == 1 and dsc.KW == 1 and dsc.stride == 1 and not dsc.up2x and dsc.Cin % 32 == 0
+            and dsc.Cout % 8 == 0 and dsc.out_mode == 1 and not dsc.rowadd and not dsc.yt):
+        cands.append(6)             # the same register-direct kernel on fp16 operands (skip-connection 1x1 convs)
     best, best_ms = 0, None
     e0, e1 = C.c_int(), C.c_int()
     h.call("event_create", C.byref(e0))
