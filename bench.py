@@ -34,6 +34,10 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+# TFMQ_BENCH_ONE_DEVICE=1: exercise the whole N > 1 flow (self-spawn, barriers, max-over-ranks time, sharded-calibration leg, one
+# JSON line from rank 0) on a box with ONE GPU -- all ranks share cuda:0, torch.distributed runs on gloo, the C ABI's RCCL
+# communicator is not created (linklink falls back to torch.distributed).  A test mode: its number means nothing.
+ONE_DEVICE = os.environ.get("TFMQ_BENCH_ONE_DEVICE") == "1"
 INT8_PEAK_TOPS = 5000.0  # dense int8 MFMA peak of MI355X (2x the 2.5 PF bf16 dense peak, MI355X_MICROARCH.md)
 
 
@@ -429,7 +433,7 @@ def run_cali_workload(args, dev, rank, local_rank, world, log):
         dist.barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        tt = torch.tensor([dt], device="cpu" if ONE_DEVICE else dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     if rank != 0:
@@ -573,7 +577,7 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # `python bench.py --gpus N` on its own: become N ranks (one process per GPU) under torch.distributed.run,
         # exactly the command the driver uses
-        if torch.cuda.device_count() < args.gpus:
+        if torch.cuda.device_count() < args.gpus and not ONE_DEVICE:
             raise SystemExit(f"bench.py --gpus {args.gpus}: this node has {torch.cuda.device_count()} GPU(s)")
         import socket
         with socket.socket() as sk:
@@ -586,16 +590,19 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus and rank == 0:
         print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; reporting n_gpus={world}", file=sys.stderr)
+    if ONE_DEVICE:                       # dry run of the N > 1 path on a 1-GPU box: every rank on cuda:0, gloo collectives
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group("gloo" if ONE_DEVICE else "nccl", rank=rank, world_size=world)
         import tfmq_dm_amd.linklink as link
         try:
-            link.init_comm(local_rank)   # the C ABI's own RCCL communicator (calibration exchange step)
+            if not ONE_DEVICE:
+                link.init_comm(local_rank)   # the C ABI's own RCCL communicator (calibration exchange step)
         except Exception as e:           # noqa: BLE001 -- sampling needs no collective: keep the number, report the leg's error
             print(f"[bench] rank {rank}: tfmq_comm_init failed ({type(e).__name__}: {e}); the calibration leg falls back to torch.distributed",
                   file=sys.stderr, flush=True)
@@ -631,7 +638,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        tt = torch.tensor([dt], device="cpu" if ONE_DEVICE else dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     finite = info["finite"]()
