@@ -11,12 +11,13 @@ def timeit(fn, n=10):
     for _ in range(n): fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1)/n
-for (B, heads, T, d) in [(16, 8, 4096, 40), (16, 8, 1024, 80), (16, 8, 256, 160)]:
+BB = int(os.environ.get('BATCH', '16'))
+for (B, heads, T, d) in [(BB, 8, 4096, 40), (BB, 8, 1024, 80), (BB, 8, 256, 160)]:
     C = heads*d
     q = torch.randn(B, T, C, device=DEV); k = torch.randn(B, T, C, device=DEV); v = torch.randn(B, T, C, device=DEV)
     qh, kh, vt = q.half(), k.half(), v.transpose(1, 2).contiguous().half()
     qt = torch.tensor([[0.02, 128.0]], device=DEV); sel = ops.qsel(qt)
-    t32 = timeit(lambda: ops.attention(q, k, v, heads, d**-0.5, sel, want_f32=False))
+    t32 = timeit(lambda: ops.attention(q, k, v, heads, d**-0.5, sel, want_f32=False)) if os.environ.get('F32') else float('nan')
     t16 = timeit(lambda: ops.attention_f16(qh, kh, vt, heads, d**-0.5, sel, want_f32=False))
     fl = 4.0*B*heads*T*T*d
     print(f"B{B} h{heads} T{T} d{d}: fp32-in {t32*1e3:8.1f} us ({fl/t32/1e9:6.1f} TF/s)   f16-in {t16*1e3:8.1f} us ({fl/t16/1e9:6.1f} TF/s)")

@@ -154,6 +154,10 @@ __global__ __launch_bounds__(256) void k_attention_h(AttnHP p) {
     for (int r = 0; r < 16; ++r) o[t][r] = 0.0f;
   const float c2 = p.scale * 1.44269504088896340736f;   // exp(x*scale) = exp2(x*c2)
 
+  // (Round 2, measured and dropped: PMC on the d = 40 self-attention at UNet batch 128 -- MFMA pipe 47 % busy, VALU 62 %, 100
+  // VALU instructions + 14 MFMAs per key tile and wave, ~950 cycles per tile where max(MFMA, VALU) would be ~580.  s_setprio(1)
+  // around the two MFMA clusters: -1 %.  Issuing the next tile's score MFMAs before this tile's softmax (K staged two tiles
+  // ahead, V one, still one barrier per tile; bit-identical): 182 VGPRs = two waves per SIMD instead of three, 4.2 -> 6.0 ms.)
   // one 64-key tile: scores, online softmax, O += P V.  MASK (compile time) = the ragged last tile.
   auto tile = [&](int kt, int buf, auto mask_tag) {
     constexpr bool MASK = decltype(mask_tag)::value;
