@@ -5,46 +5,66 @@
 // statistics and the apply step (one read of fp32, one write of int8).
 #include "common.hpp"
 
-// rows of up to 64*4*MAXV floats (MAXV float4 per lane): 5 -> C <= 1280
-template <int MAXV, bool XH = false>
+// rows of up to 64*4*MAXV floats (MAXV float4 per lane): 5 -> C <= 1280.  A wave works on R rows at once: one row per wave
+// was latency-bound at full occupancy (load -> two dependent wave reductions -> gamma / beta -> store, ~4 us per row with
+// eight waves per SIMD resident = 2 TB/s at C = 320); with the loads of R rows in flight and their reductions interleaved
+// the same chain is paid once per R rows (R = 4 for C <= 512: 266 -> 234 us at 524288 x 320 fp16; wider rows measured
+// 3-8 % slower with R = 2 and keep R = 1).  Per-row arithmetic unchanged.
+template <int MAXV, bool XH = false, int R = 1>
 __global__ __launch_bounds__(256) void k_layernorm(const float* __restrict__ x, const float* __restrict__ gamma,
                                                    const float* __restrict__ beta, float eps, long rows, int Cc,
                                                    tfmq_qsel aq, int8_t* __restrict__ yq, float* __restrict__ yf) {
-  const long row = static_cast<long>(blockIdx.x) * 4 + (threadIdx.x >> 6);
+  const long row0 = (static_cast<long>(blockIdx.x) * 4 + (threadIdx.x >> 6)) * R;
   const int lane = threadIdx.x & 63;
-  if (row >= rows) return;
+  if (row0 >= rows) return;
   const int c4 = Cc / 4;
-  const float4* xr = reinterpret_cast<const float4*>(x + row * Cc);
-  const uint2* xh = reinterpret_cast<const uint2*>(reinterpret_cast<const __half*>(x) + row * Cc);   // XH: fp16 row
-  float4 v[MAXV];
-  float s = 0.0f;
+  float4 v[R][MAXV];
+  float s[R];
 #pragma unroll
-  for (int i = 0; i < MAXV; ++i) {
-    const int idx = lane + i * 64;
-    if constexpr (XH) {
-      v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (idx < c4) {
-        const uint2 u = xh[idx];
-        const float2 lo = __half22float2(*reinterpret_cast<const __half2*>(&u.x)), hi = __half22float2(*reinterpret_cast<const __half2*>(&u.y));
-        v[i] = make_float4(lo.x, lo.y, hi.x, hi.y);
+  for (int r = 0; r < R; ++r) {
+    const long row = row0 + r < rows ? row0 + r : rows - 1;          // past the end: a valid row, never stored
+    const float4* xr = reinterpret_cast<const float4*>(x + row * Cc);
+    const uint2* xh = reinterpret_cast<const uint2*>(reinterpret_cast<const __half*>(x) + row * Cc);   // XH: fp16 row
+    s[r] = 0.0f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+      const int idx = lane + i * 64;
+      if constexpr (XH) {
+        v[r][i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (idx < c4) {
+          const uint2 u = xh[idx];
+          const float2 lo = __half22float2(*reinterpret_cast<const __half2*>(&u.x)), hi = __half22float2(*reinterpret_cast<const __half2*>(&u.y));
+          v[r][i] = make_float4(lo.x, lo.y, hi.x, hi.y);
+        }
+      } else {
+        v[r][i] = idx < c4 ? xr[idx] : make_float4(0.f, 0.f, 0.f, 0.f);
       }
-    } else {
-      v[i] = idx < c4 ? xr[idx] : make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
   }
-  s = wave_reduce_sum(s);
-  const float mean = s / static_cast<float>(Cc);
-  float ss = 0.0f;
 #pragma unroll
-  for (int i = 0; i < MAXV; ++i) {
-    if (lane + i * 64 < c4) {
-      const float a = v[i].x - mean, b = v[i].y - mean, c = v[i].z - mean, d = v[i].w - mean;
-      ss += (a * a + b * b) + (c * c + d * d);
+  for (int r = 0; r < R; ++r) {
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) s[r] += (v[r][i].x + v[r][i].y) + (v[r][i].z + v[r][i].w);
+  }
+#pragma unroll
+  for (int r = 0; r < R; ++r) s[r] = wave_reduce_sum(s[r]);
+  float mean[R], ss[R], rstd[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    mean[r] = s[r] / static_cast<float>(Cc);
+    ss[r] = 0.0f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+      if (lane + i * 64 < c4) {
+        const float a = v[r][i].x - mean[r], b = v[r][i].y - mean[r], c = v[r][i].z - mean[r], d = v[r][i].w - mean[r];
+        ss[r] += (a * a + b * b) + (c * c + d * d);
+      }
     }
   }
-  ss = wave_reduce_sum(ss);
-  const float rstd = 1.0f / sqrtf(ss / static_cast<float>(Cc) + eps);
+#pragma unroll
+  for (int r = 0; r < R; ++r) ss[r] = wave_reduce_sum(ss[r]);
+#pragma unroll
+  for (int r = 0; r < R; ++r) rstd[r] = 1.0f / sqrtf(ss[r] / static_cast<float>(Cc) + eps);
   const bool quant = aq.qtable != nullptr;
   float2 qp = make_float2(1.0f, 0.0f);
   if (quant) qp = load_qparam(aq);
@@ -54,16 +74,21 @@ __global__ __launch_bounds__(256) void k_layernorm(const float* __restrict__ x, 
     if (idx >= c4) continue;
     const float4 g = reinterpret_cast<const float4*>(gamma)[idx];
     const float4 b = reinterpret_cast<const float4*>(beta)[idx];
-    float4 y;
-    y.x = (v[i].x - mean) * rstd * g.x + b.x;
-    y.y = (v[i].y - mean) * rstd * g.y + b.y;
-    y.z = (v[i].z - mean) * rstd * g.z + b.z;
-    y.w = (v[i].w - mean) * rstd * g.w + b.w;
-    if (yf) reinterpret_cast<float4*>(yf + row * Cc)[idx] = y;
-    if (quant) {
-      char4 q;
-      q = quant_char4(y.x, y.y, y.z, y.w, make_quantp(qp));
-      reinterpret_cast<char4*>(yq + row * Cc)[idx] = q;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const long row = row0 + r;
+      if (row >= rows) continue;
+      float4 y;
+      y.x = (v[r][i].x - mean[r]) * rstd[r] * g.x + b.x;
+      y.y = (v[r][i].y - mean[r]) * rstd[r] * g.y + b.y;
+      y.z = (v[r][i].z - mean[r]) * rstd[r] * g.z + b.z;
+      y.w = (v[r][i].w - mean[r]) * rstd[r] * g.w + b.w;
+      if (yf) reinterpret_cast<float4*>(yf + row * Cc)[idx] = y;
+      if (quant) {
+        char4 q;
+        q = quant_char4(y.x, y.y, y.z, y.w, make_quantp(qp));
+        reinterpret_cast<char4*>(yq + row * Cc)[idx] = q;
+      }
     }
   }
 }
@@ -73,10 +98,10 @@ extern "C" int tfmq_layernorm(tfmq_handle h, const float* x, const float* gamma,
   TFMQ_CHECK_ARG(h, h && x && gamma && beta && rows > 0 && C > 0, "layernorm: bad argument");
   TFMQ_CHECK_ARG(h, (aq.qtable && yq) || yf, "layernorm: no output requested");
   TFMQ_CHECK_ARG(h, C % 4 == 0 && C <= 64 * 4 * 8, "layernorm: C must be a multiple of 4 and <= 2048");
-  dim3 grid(static_cast<unsigned>((rows + 3) / 4));
-  if (C <= 64 * 4 * 2) hipLaunchKernelGGL(k_layernorm<2>, grid, dim3(256), 0, as_stream(stream), x, gamma, beta, eps, rows, C, aq, yq, yf);
-  else if (C <= 64 * 4 * 5) hipLaunchKernelGGL(k_layernorm<5>, grid, dim3(256), 0, as_stream(stream), x, gamma, beta, eps, rows, C, aq, yq, yf);
-  else hipLaunchKernelGGL(k_layernorm<8>, grid, dim3(256), 0, as_stream(stream), x, gamma, beta, eps, rows, C, aq, yq, yf);
+  auto grid = [&](int r) { return dim3(static_cast<unsigned>((rows + 4 * r - 1) / (4 * r))); };
+  if (C <= 64 * 4 * 2) hipLaunchKernelGGL((k_layernorm<2, false, 4>), grid(4), dim3(256), 0, as_stream(stream), x, gamma, beta, eps, rows, C, aq, yq, yf);
+  else if (C <= 64 * 4 * 5) hipLaunchKernelGGL((k_layernorm<5, false, 1>), grid(1), dim3(256), 0, as_stream(stream), x, gamma, beta, eps, rows, C, aq, yq, yf);
+  else hipLaunchKernelGGL((k_layernorm<8, false, 1>), grid(1), dim3(256), 0, as_stream(stream), x, gamma, beta, eps, rows, C, aq, yq, yf);
   TFMQ_LAUNCH_CHECK(h);
   return TFMQ_OK;
 }
@@ -86,11 +111,11 @@ extern "C" int tfmq_layernorm_h(tfmq_handle h, const uint16_t* x, const float* g
   TFMQ_CHECK_ARG(h, h && x && gamma && beta && rows > 0 && C > 0, "layernorm_h: bad argument");
   TFMQ_CHECK_ARG(h, (aq.qtable && yq) || yf, "layernorm_h: no output requested");
   TFMQ_CHECK_ARG(h, C % 4 == 0 && C <= 64 * 4 * 8, "layernorm_h: C must be a multiple of 4 and <= 2048");
-  dim3 grid(static_cast<unsigned>((rows + 3) / 4));
+  auto grid = [&](int r) { return dim3(static_cast<unsigned>((rows + 4 * r - 1) / (4 * r))); };
   const float* xf = reinterpret_cast<const float*>(x);
-  if (C <= 64 * 4 * 2) hipLaunchKernelGGL((k_layernorm<2, true>), grid, dim3(256), 0, as_stream(stream), xf, gamma, beta, eps, rows, C, aq, yq, yf);
-  else if (C <= 64 * 4 * 5) hipLaunchKernelGGL((k_layernorm<5, true>), grid, dim3(256), 0, as_stream(stream), xf, gamma, beta, eps, rows, C, aq, yq, yf);
-  else hipLaunchKernelGGL((k_layernorm<8, true>), grid, dim3(256), 0, as_stream(stream), xf, gamma, beta, eps, rows, C, aq, yq, yf);
+  if (C <= 64 * 4 * 2) hipLaunchKernelGGL((k_layernorm<2, true, 4>), grid(4), dim3(256), 0, as_stream(stream), xf, gamma, beta, eps, rows, C, aq, yq, yf);
+  else if (C <= 64 * 4 * 5) hipLaunchKernelGGL((k_layernorm<5, true, 1>), grid(1), dim3(256), 0, as_stream(stream), xf, gamma, beta, eps, rows, C, aq, yq, yf);
+  else hipLaunchKernelGGL((k_layernorm<8, true, 1>), grid(1), dim3(256), 0, as_stream(stream), xf, gamma, beta, eps, rows, C, aq, yq, yf);
   TFMQ_LAUNCH_CHECK(h);
   return TFMQ_OK;
 }
