@@ -118,7 +118,18 @@ def setup_cifar(args, dev, rank, log):
 
 
 # ------------------------------------------------------------------------------------------------ stable diffusion
-def setup_sd(args, dev, rank, log):
+LDM_PRESETS = {
+    # BASELINE.json configs[3] (the metric's config), configs[4] and configs[2]
+    "sd": dict(unet="SD_V1_UNET", latent=(4, 64, 64), ctx=(77, 768), scale=7.5, steps=50, batch=64,
+               name="Stable Diffusion v1-4 UNet", tail="BASELINE.json configs[3] = the metric's config"),
+    "cin256": dict(unet="CIN256_V2_UNET", latent=(3, 64, 64), ctx=(1, 512), scale=3.0, steps=20, batch=64,
+                   name="LDM ImageNet-256 class-conditional UNet (cin256-v2)", tail="BASELINE.json configs[4]; latent_imagenet_diffusion.py --ddim_steps 20 --scale 3.0"),
+    "celeba": dict(unet="CELEBAHQ_LDM_VQ4_UNET", latent=(3, 64, 64), ctx=None, scale=1.0, steps=200, batch=64,
+                   name="LDM-4 CelebA-HQ 256 unconditional UNet", tail="BASELINE.json configs[2]; sample_diffusion_ldm.py -c 200 -e 0.0"),
+}
+
+
+def setup_sd(args, dev, rank, log, preset="sd"):
     import numpy as np
     import tfmq_dm_amd.ldm.unet as U
     import tfmq_dm_amd.ops as ops
@@ -126,15 +137,20 @@ def setup_sd(args, dev, rank, log):
     from tfmq_dm_amd.engine import LayerQ, LdmUNetEngine
     from tfmq_dm_amd.ldm.sampler import GraphLatentDdimSampler, alphas_cumprod_linear, ddim_timesteps
 
-    batch = args.batch or 64
-    S = args.ddim_steps or 50
-    scale = 7.5
+    P = LDM_PRESETS[preset]
+    batch = args.batch or P["batch"]
+    S = args.ddim_steps or P["steps"]
+    scale = P["scale"]
+    LAT, CTX = P["latent"], P["ctx"]
+    LC, LH, LW = LAT
+    NB = batch * (2 if CTX is not None else 1)         # UNet batch: cond + uncond halves under guidance
     t0 = time.time()
     torch.manual_seed(40)
-    model = random_init(U.UNetModel(**U.SD_V1_UNET), 40)
+    model = random_init(U.UNetModel(**getattr(U, P["unet"])), 40)
     cfg = model.engine_cfg()
     sd = {k: v.detach() for k, v in model.state_dict().items()}
-    log(f"SD v1 UNet random init ({sum(v.numel() for v in sd.values()) / 1e6:.1f} M params): {time.time() - t0:.1f}s")
+    n_params = sum(v.numel() for v in sd.values()) / 1e6
+    log(f"{P['name']} random init ({n_params:.1f} M params): {time.time() - t0:.1f}s")
     # QuantLayers in module order = every Conv2d / Linear except skip_connection / op (quant_model.py:57-58)
     qnames = [k[:-7] for k in sd if k.endswith(".weight") and sd[k].dim() in (2, 4) and "skip_connection" not in k
               and not k.endswith(".op.weight")]
@@ -160,27 +176,32 @@ def setup_sd(args, dev, rank, log):
     # synthetic FSC: MINMAX of the activations at every step, on UNet batch 2 x batch
     t0 = time.time()
     g = torch.Generator(device="cpu").manual_seed(41 + rank)
-    ctx = torch.randn(2 * batch, 77, 768, generator=g).to(dev)
+    ctx = None if CTX is None else torch.randn(NB, CTX[0], CTX[1], generator=g).to(dev)
     ts = np.flip(ddim_timesteps(S))
     for k, tv in enumerate(ts):
         eng.set_calibration("init_minmax", k)
-        x = torch.randn(2 * batch, 64, 64, 4, generator=g).to(dev)
-        eng.forward(x, torch.full((2 * batch,), float(tv), device=dev), ctx)
+        x = torch.randn(NB, LH, LW, LC, generator=g).to(dev)
+        eng.forward(x, torch.full((NB,), float(tv), device=dev), ctx)
     eng.set_calibration(None)
     eng.prepare(wq, eng.qtable, step)   # re-evaluate the sibling-quantizer fusion with the calibrated table
     torch.cuda.synchronize()
-    log(f"synthetic activation calibration ({S} groups x {2 * batch}, minmax): {time.time() - t0:.2f}s")
-    sampler = GraphLatentDdimSampler(eng, S, batch, (4, 64, 64), (77, 768), scale=scale,
-                                     alphas_cumprod=alphas_cumprod_linear()).capture()
-    log(f"captured CFG-DDIM step graph; activations arena {sampler.arena.nbytes() / 2**30:.2f} GiB")
-    x_T = torch.randn(batch, 64, 64, 4, generator=g).to(dev)
-    cond, uncond = ctx[batch:].contiguous(), ctx[:batch].contiguous()
+    log(f"synthetic activation calibration ({S} groups x {NB}, minmax): {time.time() - t0:.2f}s")
+    sampler = GraphLatentDdimSampler(eng, S, batch, LAT, CTX, scale=scale, alphas_cumprod=alphas_cumprod_linear()).capture()
+    log(f"captured DDIM step graph; activations arena {sampler.arena.nbytes() / 2**30:.2f} GiB")
+    x_T = torch.randn(batch, LH, LW, LC, generator=g).to(dev)
+    cond, uncond = (None, None) if CTX is None else (ctx[batch:].contiguous(), ctx[:batch].contiguous())
 
     def run():
-        sampler.sample_nhwc(x_T, cond, uncond)
+        if CTX is None:
+            sampler.sample_nhwc(x_T)
+        else:
+            sampler.sample_nhwc(x_T, cond, uncond)
 
     def fwd():
-        eng.forward(sampler.x2, None, sampler.ctx2)
+        if CTX is None:
+            eng.forward(sampler.x, None)
+        else:
+            eng.forward(sampler.x2, None, sampler.ctx2)
 
     def cpu():
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -192,24 +213,27 @@ def setup_sd(args, dev, rank, log):
             return v.cpu().reshape((-1,) + (1,) * (sdc[n + ".weight"].dim() - 1))
         wqc = {n: {"delta": shp(n, q.delta), "zp": shp(n, q.zp), "alpha": None} for n, q in wq.items()}
         cs, ci = 2, 2          # 2 DDIM steps of 2 images (UNet batch 4 with guidance): bounded sample, host cores busy
-        xc = torch.randn(ci, 4, 64, 64)
-        c1, u1 = torch.randn(ci, 77, 768), torch.randn(ci, 77, 768)
+        xc = torch.randn(ci, LC, LH, LW)
         tsn, _, _ = O.ldm_ddim_schedule(O.ldm_alphas_cumprod(), S)
         with torch.no_grad():
             t0 = time.time()
             for i, stp in enumerate(list(np.flip(tsn))[:cs]):
-                t = torch.full((2 * ci,), int(stp), dtype=torch.long)
                 aq = {n: (qt[i, j, 0], qt[i, j, 1]) for j, n in enumerate(act_names)}
-                O.ldm_unet_forward(sdc, dict(cfg), torch.cat([xc] * 2), t, torch.cat([u1, c1]), O.QuantSpec(wq=wqc, aq=aq))
+                if CTX is None:
+                    O.ldm_unet_forward(sdc, dict(cfg), xc, torch.full((ci,), int(stp), dtype=torch.long), None, O.QuantSpec(wq=wqc, aq=aq))
+                else:
+                    c1, u1 = torch.randn(ci, CTX[0], CTX[1]), torch.randn(ci, CTX[0], CTX[1])
+                    O.ldm_unet_forward(sdc, dict(cfg), torch.cat([xc] * 2), torch.full((2 * ci,), int(stp), dtype=torch.long), torch.cat([u1, c1]),
+                                       O.QuantSpec(wq=wqc, aq=aq))
             dt = time.time() - t0
-        return ci / (dt / cs * S), (f"{ci} images (UNet batch {2 * ci}, CFG) x {cs} of the {S} DDIM steps = {dt:.1f}s on {torch.get_num_threads()} "
-                                    "threads, extrapolated to the full schedule")
+        return ci / (dt / cs * S), (f"{ci} images (UNet batch {ci * (1 if CTX is None else 2)}) x {cs} of the {S} DDIM steps = {dt:.1f}s on "
+                                    f"{torch.get_num_threads()} threads, extrapolated to the full schedule")
 
     def plms():
         """The README's SD recipe samples with PLMS (S + 1 UNet calls): reported beside the metric, one
         sampling after a warm one, on the same engine, tables and inputs."""
         from tfmq_dm_amd.ldm.sampler import GraphLatentPlmsSampler
-        ps = GraphLatentPlmsSampler(eng, S, batch, (4, 64, 64), (77, 768), scale=scale, alphas_cumprod=alphas_cumprod_linear()).capture()
+        ps = GraphLatentPlmsSampler(eng, S, batch, LAT, CTX, scale=scale, alphas_cumprod=alphas_cumprod_linear()).capture()
         ps.sample_nhwc(x_T, cond, uncond)
         ps.stream.synchronize()
         t0 = time.perf_counter()
@@ -227,7 +251,7 @@ def setup_sd(args, dev, rank, log):
         out = {}
         wbytes = sum(l.p.w8.numel() for l in eng.layers.values() if getattr(l.p, "w8", None) is not None)
         for b in batches:
-            sp = GraphLatentDdimSampler(eng, S, b, (4, 64, 64), (77, 768), scale=scale, alphas_cumprod=alphas_cumprod_linear()).capture()
+            sp = GraphLatentDdimSampler(eng, S, b, LAT, CTX, scale=scale, alphas_cumprod=alphas_cumprod_linear()).capture()
             xb, cb, ub = x_T[:b].contiguous(), cond[:b].contiguous(), uncond[:b].contiguous()
             sp.sample_nhwc(xb, cb, ub)
             sp.stream.synchronize()
@@ -245,9 +269,11 @@ def setup_sd(args, dev, rank, log):
     info = dict(batch=batch, sync=sampler.stream.synchronize, finite=lambda: bool(torch.isfinite(sampler.x).all().item()),
                 stream=sampler.stream, step=eng.step, plms=plms, sweep=sweep,
                 oracle_state=dict(sd=sd, wq=wq, act_names=act_names, cfg=cfg, eng=eng),     # scratch/sd_parity_full.py
-                workload=("Stable Diffusion v1-4 UNet (859.5M) w4a8 on MI355X: 64x64x4 latents (512x512 images), DDIM-50 eta=0, "
-                          f"CFG 7.5 (UNet batch 2x{batch}), 77x768 context, {batch} images per GPU (BASELINE.json configs[3] = the metric's config)"),
-                extra={"batch_per_gpu": batch, "ddim_steps": S, "unet_evals_per_step": S, "unet_batch": 2 * batch, "guidance_scale": scale})
+                workload=(f"{P['name']} ({n_params:.1f}M) w4a8 on MI355X: {LH}x{LW}x{LC} latents, DDIM-{S} eta=0, "
+                          + (f"CFG {scale} (UNet batch 2x{batch}), {CTX[0]}x{CTX[1]} context, " if CTX is not None else "unconditional, ")
+                          + f"{batch} images per GPU ({P['tail']})"),
+                preset=preset,
+                extra={"batch_per_gpu": batch, "ddim_steps": S, "unet_evals_per_step": S, "unet_batch": NB, "guidance_scale": scale})
     return run, fwd, cpu, info
 
 
@@ -562,7 +588,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", choices=["sd", "cifar", "cali"], default="sd")
+    ap.add_argument("--workload", choices=["sd", "cifar", "cali", "cin256", "celeba"], default="sd")
     ap.add_argument("--cali-iters", type=int, default=100, help="--workload cali: AdaRound iterations per unit (recipe: 20000)")
     ap.add_argument("--cali-samples", type=int, default=32, help="--workload cali: samples per timestep group (recipe: 512)")
     ap.add_argument("--cali-groups", type=int, default=2, help="--workload cali: timestep groups (recipe: 25)")
@@ -620,7 +646,10 @@ def main():
             link.destroy_comm()
             dist.destroy_process_group()
         return
-    run, fwd, cpu, info = (setup_sd if args.workload == "sd" else setup_cifar)(args, dev, rank, log)
+    if args.workload == "cifar":
+        run, fwd, cpu, info = setup_cifar(args, dev, rank, log)
+    else:
+        run, fwd, cpu, info = setup_sd(args, dev, rank, log, preset=args.workload)
 
     def barrier():
         torch.cuda.synchronize()
@@ -720,7 +749,9 @@ def main():
         cfgd = {"workload": info["workload"], "parallelism": f"replicas x{world} (no data-path collective)"}
         cfgd.update(info["extra"])
         out = {
-            "metric": "DDIM-50 images/sec, w4a8 SD-v1-4" if args.workload == "sd" else "DDIM-100 images/sec, w4a8 CIFAR-10 DDPM",
+            "metric": {"sd": "DDIM-50 images/sec, w4a8 SD-v1-4", "cifar": "DDIM-100 images/sec, w4a8 CIFAR-10 DDPM",
+                       "cin256": "DDIM-20 images/sec, w4a8 LDM ImageNet-256 (cin256-v2, CFG 3.0)",
+                       "celeba": "DDIM-200 images/sec, w4a8 LDM-4 CelebA-HQ 256"}[args.workload],
             "value": round(value, 3), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None,

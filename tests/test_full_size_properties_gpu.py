@@ -135,3 +135,59 @@ def test_quantizer_idempotent_at_size():
     q1 = ops.quantize_act(x, sel)
     deq = (q1.float() + 128.0 - 113.0) * 0.0471
     assert torch.equal(ops.quantize_act(deq, sel), q1)
+
+
+@pytest.mark.parametrize("preset", ["cin256", "celeba"])
+def test_ldm_full_size_presets(preset):
+    """BASELINE.json configs[4] / configs[2] at their full sizes -- the cin256-v2 class-conditional UNet (one attention head per
+    level: head dims 384 / 576 / 960, cross attention over ONE class token, CFG) and the unconditional LDM-4 CelebA-HQ UNet
+    (224 ... 896 channels: Cin % 64 != 0 layers, plain AttentionBlocks with 32-channel heads), w4a8 with a Finite-Set table:
+    run-to-run determinism and batch independence bit for bit, fused forward == tap-exposing forward on the fp32 stream,
+    the step's table row is honoured, and one sample / CFG pair against the CPU oracle (same bar as the SD test)."""
+    import numpy as np
+    import bench
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import tfmq_oracle as O
+    from tfmq_dm_amd.ldm.sampler import ddim_timesteps
+    args = argparse.Namespace(batch=1, ddim_steps=2)
+    run, fwd, cpu, info = bench.setup_sd(args, torch.device(DEV), 0, lambda *a: None, preset=preset)
+    st = info["oracle_state"]
+    eng, sdw, wq, act_names, cfg = st["eng"], st["sd"], st["wq"], st["act_names"], st["cfg"]
+    P = bench.LDM_PRESETS[preset]
+    C, H, W = P["latent"]
+    g = torch.Generator().manual_seed(31)
+    x = torch.randn(2, C, H, W, generator=g)
+    ctx = None if P["ctx"] is None else torch.randn(2, P["ctx"][0], P["ctx"][1], generator=g)
+    t = torch.full((2,), float(np.flip(ddim_timesteps(2))[0]))
+    xd, td = x.permute(0, 2, 3, 1).contiguous().to(DEV), t.to(DEV)
+    cd = None if ctx is None else ctx.to(DEV)
+
+    def f(xx, tt, cc, **kw):
+        return eng.forward(xx, tt, cc, **kw).clone()
+    with torch.cuda.stream(info["stream"]):
+        info["step"].zero_()
+        e2, e2b = f(xd, td, cd), f(xd, td, cd)
+        ea = f(xd[:1].contiguous(), td[:1], None if cd is None else cd[:1].contiguous())
+        eb = f(xd[1:].contiguous(), td[1:], None if cd is None else cd[1:].contiguous())
+        e_taps = f(xd, td, cd, taps={})
+        eng.stream_f16 = False
+        e_f32 = f(xd, td, cd)
+        eng.stream_f16 = True
+        info["step"].fill_(1)
+        e_step1 = f(xd, td, cd)
+        info["step"].zero_()
+        info["stream"].synchronize()
+    assert torch.isfinite(e2).all() and torch.equal(e2, e2b)
+    assert torch.equal(e2[:1], ea) and torch.equal(e2[1:], eb)
+    assert torch.equal(e_f32, e_taps)
+    assert not torch.equal(e2, e_step1)
+    sdc = {k: v.cpu() for k, v in sdw.items()}
+    wqc = {n: {"delta": q.delta.cpu().reshape((-1,) + (1,) * (sdc[n + ".weight"].dim() - 1)),
+               "zp": q.zp.cpu().reshape((-1,) + (1,) * (sdc[n + ".weight"].dim() - 1)), "alpha": None} for n, q in wq.items()}
+    qt = eng.qtable.cpu()
+    aq = {n: (qt[0, j, 0], qt[0, j, 1]) for j, n in enumerate(act_names)}
+    with torch.no_grad():
+        ref = O.ldm_unet_forward(sdc, dict(cfg), x, t.long(), ctx, O.QuantSpec(wq=wqc, aq=aq))
+    rel = float((e2.permute(0, 3, 1, 2).cpu() - ref).norm() / ref.norm())
+    print(f"full-size {preset} w4a8 eps rel-L2 vs oracle:", rel)
+    assert rel <= 5e-2

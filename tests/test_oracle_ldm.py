@@ -59,3 +59,16 @@ def test_ldm_schedule_and_cfg_ddim(f11):
         assert np.array_equal(torch.stack(pred).numpy(), g["traj_w4a8_predx0"])
         img, _ = O.ldm_ddim_sample(x_T, lambda x, t, c, k: O.ldm_unet_forward(sd, CFG, x, t, c), ac, 4, ctx, uc, 7.5)
         assert np.array_equal(img.numpy(), g["traj_fp_final"])
+
+
+def test_ldm_attention_block_unet_fp_w4_w4a8(golden):
+    """The oracle's plain AttentionBlock (unconditional LDM configs: CelebA-HQ, LSUN) pinned to the reference: fixture F13 holds the
+    reference UNetModel's eps (FP) and the reference QuantModel's w4 / w4a8 eps on the same inputs -- bit for bit."""
+    g = golden("f13_ldm_attnblock_tiny")
+    sd = {k[3:]: T(g[k]) for k in g.files if k.startswith("sd/")}
+    cfg = dict(model_channels=32, num_heads=-1, num_head_channels=16)
+    x, t = T(g["x"]), T(g["t"])
+    with torch.no_grad():
+        assert np.array_equal(O.ldm_unet_forward(sd, cfg, x, t, None).numpy(), g["eps_fp"])
+        assert np.array_equal(O.ldm_unet_forward(sd, cfg, x, t, None, spec(g, False)).numpy(), g["eps_w4"])
+        assert np.array_equal(O.ldm_unet_forward(sd, cfg, x, t, None, spec(g, True)).numpy(), g["eps_w4a8"])

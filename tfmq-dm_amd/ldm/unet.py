@@ -228,3 +228,14 @@ SD_V1_UNET = dict(image_size=32, in_channels=4, out_channels=4, model_channels=3
                   num_res_blocks=2, channel_mult=[1, 2, 4, 4], num_heads=8, use_spatial_transformer=True,
                   transformer_depth=1, context_dim=768, use_checkpoint=True, legacy=False)
 """unet_config.params of stable-diffusion/configs/stable-diffusion/v1-inference.yaml"""
+
+CIN256_V2_UNET = dict(image_size=64, in_channels=3, out_channels=3, model_channels=192, attention_resolutions=[8, 4, 2],
+                      num_res_blocks=2, channel_mult=[1, 2, 3, 5], num_heads=1, use_spatial_transformer=True,
+                      transformer_depth=1, context_dim=512)
+"""unet_config.params of stable-diffusion/configs/latent-diffusion/cin256-v2.yaml (latent_imagenet_diffusion.py:35: class-conditional
+ImageNet 256, 64x64x3 latents, ONE attention head per level, cross attention over ONE class-embedding token)"""
+
+CELEBAHQ_LDM_VQ4_UNET = dict(image_size=64, in_channels=3, out_channels=3, model_channels=224, attention_resolutions=[8, 4, 2],
+                             num_res_blocks=2, channel_mult=[1, 2, 3, 4], num_head_channels=32)
+"""unet_config.params of stable-diffusion/configs/latent-diffusion/celebahq-ldm-vq-4.yaml (sample_diffusion_ldm.py -r
+models/ldm/celeba256: unconditional LDM-4, 64x64x3 latents, plain AttentionBlocks with 32-channel heads)"""
