@@ -298,6 +298,11 @@ int tfmq_dpm_x0(tfmq_handle h, const float* x, const float* eps, float sigma, fl
 int tfmq_dpm_update(tfmq_handle h, int order, const float* x, const float* m0, const float* m1_or_null, float c_x, float c_m,
                     float c_d, float inv_r0, float* out, size_t n, void* stream);
 int tfmq_step_advance(tfmq_handle h, int32_t* step, int delta, void* stream);
+/* np.histogram(a, bins) bin counts of x (optionally clipped in float64 to [clip_lo, clip_hi] first) on `bins` equal-width bins
+ * given by the edge table edges[bins + 1] (device; float when f64 == 0, double otherwise): numpy's index arithmetic and edge
+ * correction, values outside [edges[0], edges[bins]] dropped.  For Scaler.KL / Scaler.HIST (quant/quant_layer.py:67-133). */
+int tfmq_np_histogram(tfmq_handle h, const float* x, size_t n, int f64, int do_clip, double clip_lo, double clip_hi,
+                      const void* edges, int bins, uint32_t* counts, void* stream);
 /* Device self-test of instruction semantics the kernels rely on (v_cvt_pk_u8_f32 saturation to [0, 255], DPP lane
  * selection of the statistics sums).  0 = all hold; otherwise an error with *report = failing-check bit mask.  Synchronous,
  * allocates 4 bytes for the duration of the call; not for use under stream capture. */

@@ -1,6 +1,6 @@
 """Round-2 golden vectors, produced by importing the reference (build container only):
 
-    python tests/golden/gen_golden_r02.py [f8b f15 f16 f17]
+    python tests/golden/gen_golden_r02.py [f8b f15 f16 f17 f18]
 
   f8b  the tiny DDPM calibration of F8 run for 400 Adam iterations per unit (warm-up 0.2): reconstruction / total loss of
        every unit at counts {1, 80, 200, 400} (through the warm-up boundary and most of the b: 20 -> 2 decay) and the
@@ -12,7 +12,8 @@
        activation calibration) on the AttentionBlock UNet of F13 (unconditional LDM-4 family).
   f17  the calibration-set generators (quant/data_generate.py) and the pixel-space runner's sample_fid
        (ddim/runners/diffusion.py) run by the reference on tiny FP models; every torch.randn draw is recorded so the
-       HIP path can be fed the same noise."""
+       HIP path can be fed the same noise.
+  f18  the histogram scalers kl / hist of quant/quant_layer.py on five input distributions."""
 import os
 import sys
 import types
@@ -390,8 +391,35 @@ def f17():
     save("f17_cali_generators", **out)
 
 
+def f18():
+    """The two histogram scalers (quant/quant_layer.py:67-133): kl -- the clip ratio in linspace(0.5, 1, 50) whose
+    clipped-data histogram is closest (KL divergence, level bins) to the raw histogram, then MINMAX of the clipped tensor; hist --
+    the smallest symmetric clip that keeps 99.96 % of the mass of the (0, max|x|) histogram, then MINMAX.  Inputs of the shapes a
+    layer sees (normal, post-SiLU, heavy-tailed, one-sided) and (delta, zero_point) by the reference's own functions."""
+    from quant.quant_layer import hist, kl
+    g = torch.Generator().manual_seed(18)
+    xs = {
+        "normal": torch.randn(40000, generator=g) * 1.7 + 0.3,
+        "silu": torch.nn.functional.silu(torch.randn(8, 64, 14, 14, generator=g) * 2.0),
+        "heavy": torch.randn(30000, generator=g) * torch.exp(torch.randn(30000, generator=g)),
+        "positive": torch.rand(5000, generator=g) ** 3 * 9.0,
+        "small": torch.randn(700, generator=g) * 0.05 - 0.02,
+    }
+    out = {"names": np.array(sorted(xs))}
+    for n, x in xs.items():
+        out[f"x/{n}"] = x.numpy()
+        for level in (256, 16):
+            for az in (False, True):
+                if az and float(x.min()) < 0 and n != "silu":
+                    continue            # always_zero is used on non-negative (softmax) inputs; silu's small negative part is a stress case
+                for fn in (kl, hist):
+                    d, z = fn(x, False, level, az)
+                    out[f"{fn.__name__}/{n}/{level}/{int(az)}"] = np.array([float(d), float(z)], dtype=np.float64)
+    save("f18_hist_scalers", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["f8b", "f15", "f16", "f17"]
-    for name in ("f8b", "f15", "f16", "f17"):
+    which = sys.argv[1:] or ["f8b", "f15", "f16", "f17", "f18"]
+    for name in ("f8b", "f15", "f16", "f17", "f18"):
         if name in which:
             globals()[name]()

@@ -402,3 +402,43 @@ def test_recon_loss_kernel(ops):
     loss, gr = ops.recon_loss(nhwc(p), nhwc(t), denom=8 * 6 * 6)
     assert abs(float(loss) - float(ref)) <= 1e-5 * float(ref)
     np.testing.assert_allclose(nchw(gr).numpy(), pr.grad.numpy(), rtol=1e-6, atol=1e-9)
+
+
+@pytest.mark.gpu
+def test_histogram_scalers_kl_and_hist_vs_reference(golden):
+    """Scaler.KL / Scaler.HIST of the drop-in quant_layer on the device histogram (tfmq_np_histogram: numpy's bin arithmetic,
+    fp32 for the raw data, float64 for the clipped data) against the reference's own functions (fixture F18: five input
+    distributions, 256 / 16 levels, with and without always_zero): delta and zero point bit for bit; and the histogram kernel
+    itself against np.histogram."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tfmq-dm_amd"))
+    from quant.quant_layer import Scaler, UniformAffineQuantizer, hist, kl
+    import tfmq_dm_amd.ops as ops
+    g = golden("f18_hist_scalers")
+    n = 0
+    for k in g.files:
+        if not (k.startswith("kl/") or k.startswith("hist/")):
+            continue
+        fn, name, level, az = k.split("/")
+        x = torch.from_numpy(g[f"x/{name}"]).to(DEV)
+        d, z = (kl if fn == "kl" else hist)(x, False, int(level), bool(int(az)))
+        assert float(d) == float(np.float32(g[k][0])) and float(z) == g[k][1], (k, float(d), float(z), g[k])
+        n += 1
+    assert n == 28
+    a = g["x/heavy"]
+    ref, edges = np.histogram(a, bins=256)
+    assert np.array_equal(ops.np_histogram(torch.from_numpy(a).to(DEV), edges.astype(np.float32)), ref)
+    lo, hi = np.min(a) * np.float64(0.7), np.max(a) * np.float64(0.7)      # float64 bounds, as linspace's ratios make them
+    ref, edges = np.histogram(np.clip(a, lo, hi), bins=64)
+    assert edges.dtype == np.float64
+    assert np.array_equal(ops.np_histogram(torch.from_numpy(a).to(DEV), edges, clip=(lo, hi)), ref)
+    # through the quantizer's lazy initialisation, per tensor and per channel
+    q = UniformAffineQuantizer(bits=8, scaler=Scaler.KL, leaf_param=True)
+    q(torch.from_numpy(g["x/normal"]).to(DEV))
+    assert float(q.delta) == float(np.float32(g["kl/normal/256/0"][0])) and float(q.zero_point) == g["kl/normal/256/0"][1]
+    w = torch.stack([torch.from_numpy(g["x/small"])[:600], torch.from_numpy(g["x/positive"])[:600]]).to(DEV)
+    qc = UniformAffineQuantizer(bits=4, scaler=Scaler.HIST, channel_wise=True)
+    qc(w)
+    d0, z0 = hist(w[0], False, 16, False)
+    assert qc.delta.shape == (2, 1) and float(qc.delta[0]) == float(d0) and float(qc.zero_point[0]) == float(z0)

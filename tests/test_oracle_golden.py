@@ -133,3 +133,20 @@ def test_f10_shards(golden):
     for I, W in ((256, 8), (512, 8), (256, 4), (16, 2)):
         for r in range(W):
             assert O.shard_indices(I * 3, I, W, r) == list(g[f"I{I}_W{W}_r{r}"])
+
+
+def test_histogram_scalers_kl_and_hist(golden):
+    """Scaler.KL / Scaler.HIST restated in the oracle against the reference's own functions on five input
+    distributions, 256 and 16 levels, with and without always_zero (fixture F18): delta and zero point bit for bit."""
+    import tfmq_oracle as O
+    g = golden("f18_hist_scalers")
+    n = 0
+    for k in g.files:
+        if not (k.startswith("kl/") or k.startswith("hist/")):
+            continue
+        fn, name, level, az = k.split("/")
+        x = torch.from_numpy(g[f"x/{name}"])
+        d, z = (O.kl_scaler if fn == "kl" else O.hist_scaler)(x, int(level), bool(int(az)))
+        assert float(d) == float(np.float32(g[k][0])) and float(z) == g[k][1], (k, float(d), float(z), g[k])
+        n += 1
+    assert n == 28

@@ -567,3 +567,53 @@ extern "C" int tfmq_hw_selftest(tfmq_handle h, uint32_t* report) {
   }
   return TFMQ_OK;
 }
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Histogram with numpy's bin assignment (np.histogram on `bins` equal-width bins), for the KL / HIST scalers
+// (quant/quant_layer.py:67-133): index = trunc(((v - first) / (last - first)) * bins) in the edges' own precision, the
+// value on the last edge goes to the last bin, then the +-1 correction against the edge table (numpy's guard against the
+// ~1 ulp inconsistency of the index arithmetic); values outside [first, last] are dropped.  T = float for fp32 data with
+// fp32 edges (np.histogram(a_f32)), double for the clipped data (np.clip with float64 bounds promotes to float64).
+template <typename T>
+__global__ __launch_bounds__(256) void k_np_histogram(const float* __restrict__ x, size_t n, int do_clip, double clip_lo, double clip_hi,
+                                                      const T* __restrict__ edges, int bins, unsigned* __restrict__ counts) {
+  extern __shared__ unsigned sh[];
+  for (int i = threadIdx.x; i < bins; i += blockDim.x) sh[i] = 0;
+  __syncthreads();
+  const T first = edges[0], last = edges[bins];
+  const T denom = last - first;
+  const size_t stride = static_cast<size_t>(gridDim.x) * blockDim.x;
+  for (size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) {
+    T v = static_cast<T>(x[i]);
+    if (do_clip) {                       // np.clip(a, lo, hi) = minimum(maximum(a, lo), hi) in float64
+      const double c = fmin(fmax(static_cast<double>(x[i]), clip_lo), clip_hi);
+      v = static_cast<T>(c);
+    }
+    if (!(v >= first) || !(v <= last)) continue;
+    int idx = static_cast<int>(((v - first) / denom) * static_cast<T>(bins));
+    if (idx == bins) idx -= 1;
+    if (v < edges[idx]) idx -= 1;
+    if (idx != bins - 1 && v >= edges[idx + 1]) idx += 1;
+    atomicAdd(&sh[idx], 1u);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < bins; i += blockDim.x)
+    if (sh[i]) atomicAdd(&counts[i], sh[i]);
+}
+
+extern "C" int tfmq_np_histogram(tfmq_handle h, const float* x, size_t n, int f64, int do_clip, double clip_lo, double clip_hi,
+                                 const void* edges, int bins, uint32_t* counts, void* stream) {
+  TFMQ_CHECK_ARG(h, h && x && edges && counts && n > 0 && bins > 0 && bins <= 4096, "np_histogram: bad argument");
+  TFMQ_HIP(h, hipMemsetAsync(counts, 0, sizeof(uint32_t) * bins, as_stream(stream)));
+  int blocks = ceil_div(static_cast<long>(n), 256 * 8);
+  if (blocks > h->cu_count * 8) blocks = h->cu_count * 8;
+  if (blocks < 1) blocks = 1;
+  const size_t shm = sizeof(unsigned) * bins;
+  if (f64) hipLaunchKernelGGL(k_np_histogram<double>, dim3(blocks), dim3(256), shm, as_stream(stream), x, n, do_clip, clip_lo, clip_hi,
+                              static_cast<const double*>(edges), bins, counts);
+  else hipLaunchKernelGGL(k_np_histogram<float>, dim3(blocks), dim3(256), shm, as_stream(stream), x, n, do_clip, clip_lo, clip_hi,
+                          static_cast<const float*>(edges), bins, counts);
+  TFMQ_LAUNCH_CHECK(h);
+  return TFMQ_OK;
+}

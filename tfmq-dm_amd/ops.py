@@ -200,6 +200,24 @@ def minmax_to_qparam(mm: torch.Tensor, level: int, always_zero: bool = False) ->
     return qp
 
 
+def np_histogram(x: torch.Tensor, edges, clip=None):
+    """Bin counts of np.histogram(x, bins) for the equal-width edge table `edges` (numpy float32 or float64, bins + 1 entries):
+    numpy's own index arithmetic in the edges' precision; clip = (lo, hi) applies np.clip in float64 first.  -> numpy int64."""
+    import numpy as np
+    d = _dev(x)
+    _chk(x, torch.float32, "x")
+    edges = np.ascontiguousarray(edges)
+    if edges.dtype not in (np.float32, np.float64):
+        raise TfmqError("np_histogram: edges must be float32 or float64")
+    bins = edges.shape[0] - 1
+    ed = torch.from_numpy(edges).to(x.device)
+    counts = _alloc(bins, dtype=torch.int32, device=x.device)
+    lo, hi = (0.0, 0.0) if clip is None else (float(clip[0]), float(clip[1]))
+    handle(d).call("np_histogram", _p(x), x.numel(), int(edges.dtype == np.float64), int(clip is not None), C.c_double(lo), C.c_double(hi),
+                   _p(ed), bins, _p(counts), _stream(d))
+    return counts.cpu().numpy().astype(np.int64)
+
+
 def act_range_update(mm: torch.Tensor, state: torch.Tensor, qparam: torch.Tensor, momentum: float, level: int, init: bool):
     d = _dev(mm)
     handle(d).call("act_range_update", _p(mm), _p(state), _p(qparam), float(momentum), level, int(init), _stream(d))

@@ -41,20 +41,97 @@ def mse(x: torch.Tensor, symmetric: bool = False, level: int = 256, always_zero:
     return _scalar(qp, 0), _scalar(qp, 1)
 
 
-def _unsupported(name):
-    def fn(*a, **k):
-        raise NotImplementedError(f"Scaler.{name} is selectable in the reference but never chosen by its drivers; "
-                                  "not on the MI355X hot path (SURVEY §8f-4)")
-    fn.__name__ = name.lower()
-    return fn
+def _np_density(counts, edges):
+    """np.histogram(..., density=True) from the bin counts."""
+    import numpy as np
+    return counts / np.diff(edges) / counts.sum()
+
+
+def _clipped_qparam(x: torch.Tensor, xmin, xmax, lo, hi, level: int, always_zero: bool):
+    """MINMAX of x after `torch.where(x < lo, lo, x)`, `torch.where(x > hi, hi, x)` (reference :110-112): the extremes of the
+    clipped tensor are fp32(lo) / fp32(hi) where something was clipped and the data's own extremes otherwise."""
+    import numpy as np
+    cmin = np.float32(lo) if float(xmin) < lo else np.float32(xmin)
+    cmax = np.float32(hi) if float(xmax) > hi else np.float32(xmax)
+    if cmin > np.float32(hi):        # everything above hi: the first pass keeps x, the second lowers all of it to hi
+        cmin = np.float32(hi)
+    mm = torch.tensor([[float(cmin), float(cmax)]], dtype=torch.float32, device=x.device)
+    qp = ops.minmax_to_qparam(mm, level, always_zero)
+    return _scalar(qp, 0), _scalar(qp, 1)
+
+
+def kl(x: torch.Tensor, symmetric: bool = False, level: int = 256, always_zero: bool = False):
+    """KL scaler (reference quant_layer.py:67-113): clip ratio in linspace(0.5, 1, 50) whose clipped-data histogram, re-binned on
+    the raw histogram's grid, has the smallest KL divergence from the raw histogram (level density bins, 1e-5 smoothing, first
+    strict minimum); then MINMAX of the clipped tensor.  The 51 histograms are device passes (tfmq_np_histogram: numpy's bin
+    arithmetic, fp32 for the raw data, float64 for the clipped data as np.clip's float64 bounds make it); the 256-bin
+    bookkeeping is host arithmetic on the counts."""
+    import numpy as np
+    if symmetric:
+        raise NotImplementedError("symmetric quantisation is never selected by the TFMQ drivers")
+    xf = x.detach().contiguous().float()
+    mm = ops.minmax(xf, 1).cpu().numpy()
+    xmin, xmax = np.float32(mm[0, 0]), np.float32(mm[0, 1])
+    ref_edges = np.linspace(xmin, xmax, level + 1, endpoint=True, dtype=np.float32)
+    ref_hist = _np_density(ops.np_histogram(xf, ref_edges), ref_edges)
+    width = np.sum(np.diff(ref_edges))
+    p = (ref_hist + 1e-5) / (1.0 + width * 1e-5)
+    best, best_r = 1e5, 1.0
+    for r in np.linspace(0.5, 1.0, 50):
+        lo, hi = xmin * r, xmax * r                                   # float64 (np.float32 * np.float64)
+        first, last = min(max(float(xmin), lo), hi), min(max(float(xmax), lo), hi)     # extremes of the clipped data
+        q_edges = np.linspace(first, last, level + 1, endpoint=True, dtype=np.float64)
+        q_hist = _np_density(ops.np_histogram(xf, q_edges, clip=(lo, hi)), q_edges)
+        # walk the raw grid's left edges, stepping ONE clipped bin forward whenever its right edge has been reached (:73-90)
+        out = np.zeros(level, dtype=q_hist.dtype)
+        v, j, edge = 0.0, 0, q_edges[0]
+        for i in range(level):
+            left = ref_edges[i]
+            if edge <= left:
+                if j < level:
+                    v = q_hist[j]
+                    j += 1
+                    edge = q_edges[j]
+                else:
+                    v = 0.0
+                    edge = left + 1.0
+            out[i] = v
+        q = (out + 1e-5) / (1.0 + width * 1e-5)
+        dkl = np.sum(p * np.log(p / q))
+        if dkl < best:
+            best, best_r = dkl, r
+    return _clipped_qparam(xf, xmin, xmax, xmin * best_r, xmax * best_r, level, always_zero)
+
+
+def hist(x: torch.Tensor, symmetric: bool = False, level: int = 256, always_zero: bool = False):
+    """HIST scaler (reference quant_layer.py:116-132): the smallest clip value (i + 0.5) max|x| / level at which the fp32 running
+    sum of the (0, max|x|) histogram reaches 99.96 % of its mass; clip to [max(-c, min x), min(c, max x)], then MINMAX."""
+    import numpy as np
+    if symmetric:
+        raise NotImplementedError("symmetric quantisation is never selected by the TFMQ drivers")
+    xf = x.detach().contiguous().float()
+    mm = ops.minmax(xf, 1).cpu().numpy()
+    xmin, xmax = np.float32(mm[0, 0]), np.float32(mm[0, 1])
+    amax = max(-xmin, xmax)
+    edges = np.linspace(0, amax, level + 1, endpoint=True, dtype=np.float32)
+    h = _np_density(ops.np_histogram(xf, edges), edges)
+    h = h.astype(np.float32) / h.sum()
+    acc, lo, hi = 0, None, None
+    for i in range(level):
+        acc += h[i]
+        if acc >= 0.9996:
+            c = (i + 0.5) * (amax / level)
+            lo, hi = max(-c, xmin), min(c, xmax)
+            break
+    return _clipped_qparam(xf, xmin, xmax, float(lo), float(hi), level, always_zero)
 
 
 class Scaler:
     """Namespace of scaler functions (the reference's Enum of plain functions is just that)."""
     MINMAX = staticmethod(minmax)
     MSE = staticmethod(mse)
-    KL = staticmethod(_unsupported("KL"))
-    HIST = staticmethod(_unsupported("HIST"))
+    KL = staticmethod(kl)
+    HIST = staticmethod(hist)
 
 
 REDUCTION = Enum("REDUCTION", ("NONE", "ALL"))
@@ -72,8 +149,8 @@ def lp_loss(pred: torch.Tensor, tgt: torch.Tensor, p: float = 2.0, reduction: RE
 
 def _scaler_kind(fn) -> str:
     name = getattr(fn, "__name__", str(fn))
-    if name not in ("mse", "minmax"):
-        fn()  # raises the NotImplementedError of the unsupported scalers
+    if name not in ("mse", "minmax", "kl", "hist"):
+        raise NotImplementedError(f"unknown scaler {name}")
     return name
 
 
@@ -103,6 +180,17 @@ class UniformAffineQuantizer(nn.Module):
         kind = _scaler_kind(self.scaler)
         x = x.detach().contiguous().float()
         rows = x.shape[0] if channel_wise else 1
+        if kind in ("kl", "hist"):
+            # the histogram scalers work on one tensor at a time (reference :193-204 loops the channels through the scaler)
+            fn = kl if kind == "kl" else hist
+            if channel_wise:
+                pairs = [fn(x[c], False, self.level, self.always_zero) for c in range(rows)]
+                shape = (-1,) + (1,) * (x.dim() - 1)
+                return torch.stack([p[0] for p in pairs]).view(shape), torch.stack([p[1] for p in pairs]).view(shape)
+            if self.leaf_param:
+                mm = ops.minmax(x, 1)
+                self.x_min, self.x_max = mm[0, 0].clone(), mm[0, 1].clone()
+            return fn(x, False, self.level, self.always_zero)
         if kind == "mse":
             qp = ops.mse_search(x, rows, self.level, self.always_zero)
         else:
