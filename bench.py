@@ -411,6 +411,9 @@ def run_cali_workload(args, dev, rank, local_rank, world, log):
     import quant.calibration as QC, quant.reconstruction as QR
     from quant.reconstruction_util import RLOSS
     N, G, ITERS = args.cali_samples, args.cali_groups, args.cali_iters
+    if N // world < 16:
+        raise SystemExit(f"--workload cali: {N} samples per group over {world} rank(s) -- the activation calibration draws 16 per group and rank "
+                         "without replacement (quant/calibration.py, as the reference does)")
     torch.manual_seed(1234)
     m = UNetModel(**SD_V1_UNET)
     g = torch.Generator().manual_seed(7)
@@ -449,7 +452,11 @@ def run_cali_workload(args, dev, rank, local_rank, world, log):
     t0 = time.perf_counter()
     if world > 1:
         kw.update(wq_params=wq, aq_params=aq, aq_mode=[QMODE.NORMAL.value, QMODE.QDIFF.value], multi_gpu=True)
-        QC.cali_model_multi(local_rank, "nccl", world, "env://", 0, world, m, True, path, (xs, ts, cs), (xs, ts, cs), N, True, kw)
+        if ONE_DEVICE:       # dry run on one GPU: every rank on cuda:0 over gloo (cali_model_multi's torch.cuda.set_device(gpu) -> device 0)
+            real_set = torch.cuda.set_device
+            torch.cuda.set_device = lambda d: real_set(0)
+        QC.cali_model_multi(local_rank if not ONE_DEVICE else rank, "gloo" if ONE_DEVICE else "nccl", world, "env://", 0, world, m, True, path,
+                            (xs, ts, cs), (xs, ts, cs), N, True, kw)
     else:
         from quant.quant_model import QuantModel
         qnn = QuantModel(m, wq, aq, cali=True, aq_mode=[QMODE.NORMAL.value, QMODE.QDIFF.value]).eval()

@@ -37,3 +37,12 @@ def test_two_ranks_sd_with_sharded_calibration_leg():
     assert sh.get("world") == 2, sh
     assert sh["resblock_320ch_64x64"]["ms_per_iter"] > 0 and sh["transformer_320ch_64x64"]["allreduce_bytes"] > 0
     assert "torch.distributed" in sh["collective"] or "RCCL" in sh["collective"]
+
+
+def test_two_ranks_calibration_workload():
+    """`--workload cali` with two ranks: cali_model_multi on the full SD UNet -- shards by timestep group, one all-reduce per AdaRound
+    iteration, all-averaged activation deltas, rank 0 writes the checkpoint -- at a few iterations per unit."""
+    j = _run(["--workload", "cali", "--cali-iters", "3", "--cali-samples", "32", "--cali-groups", "2"])      # >= 16 samples per group and rank (calibration.py:97)
+    assert j["n_gpus"] == 2 and j["finite"] and j["scaling"] == "strong" and j["higher_is_better"] is False
+    c = j["calibration"]
+    assert c["measured"] and c["reconstruction_units"] == 74 and c["adaround_tensors"] == 263 and c["act_groups"] == 2
