@@ -39,7 +39,9 @@ struct AttnHP {
 // 2^8 (probabilities up to 256 in fp16 -- relative precision is unchanged, the common factor cancels in O / l);
 // a tile whose maximum exceeds that re-bases the query (sub + rescale of O, as rarely as the maximum jumps).
 template <int NKS, int NT, int ONES_ROW, bool FOLD = false>
-__global__ __launch_bounds__(256) void k_attention_h(AttnHP p) {
+// (the d = 40 self-attention variant is held to 128 VGPRs = four waves per SIMD -- its 37 KB of LDS allow four blocks per CU: 4.21 -> 4.08 ms
+// at UNet batch 128, same-box A/B)
+__global__ __launch_bounds__(256, (NT <= 2 && FOLD) ? 4 : 1) void k_attention_h(AttnHP p) {
   constexpr int DPAD = NT * 32;
   static_assert(!FOLD || (ONES_ROW >= 0 && 16 * NKS > ONES_ROW && ONES_ROW % 8 == 0), "FOLD: spare score column + ones-row");
   static_assert(NKS <= 2 * NT, "score k-steps must fit the padded row");
