@@ -160,3 +160,58 @@ def test_tib_table_and_graph_replay(env):
             stream.synchronize()
             assert torch.equal(out, ref[s]), s
         assert int(step.item()) == 3
+
+
+def test_w4a8_bin_flip_rate_per_layer(env):
+    """UNet-level bin agreement: the bins every activation quantizer of the tiny DDPM UNet produces in the engine against the
+    bins the oracle's fake-quant forward produces for the same layer, same weights, same Finite-Set row.  The engine's un-quantised
+    layers and attention run fp16 operands where the reference runs fp32, so bins start to move at the first quantizer behind
+    such a layer (measured 0.9 %) and every moved bin perturbs all outputs of the next integer GEMM, so the share compounds with depth
+    (measured 22-47 % in the deep layers of this random-weight net, 29 % overall; 2.8 % of bins move by more than one).  What stays
+    small is the size of the move: the dequantised layer inputs differ by <= 3.0e-2 rel-L2 at every layer.  The time-embedding
+    projections see exactly the reference's bins (fp32 TIB path).  Bars = measured values with headroom."""
+    import tfmq_dm_amd.ops as ops
+    g, sd, Engine, LayerQ = env
+    wq, qtable, act_names = layerq_from_fixture(g, LayerQ, True)
+    eng = Engine(sd, CFG, DEV)
+    eng.prepare(wq, qtable.to(DEV))
+    x, t = T(g["x"]), T(g["t"])
+    eng.set_calibration("record", 0)
+    eng.forward(nhwc(x), t.to(DEV))
+    eng.set_calibration(None)
+    owq = {n: {"delta": q.delta.cpu().reshape((-1,) + (1,) * (sd[n + ".weight"].dim() - 1)),
+               "zp": q.zp.cpu().reshape((-1,) + (1,) * (sd[n + ".weight"].dim() - 1)), "alpha": None} for n, q in wq.items()}
+    oaq = {n: (qtable[0, i, 0], qtable[0, i, 1]) for i, n in enumerate(act_names)}
+    qs = O.QuantSpec(wq=owq, aq=oaq)
+    qs.trace = {}
+    with torch.no_grad():
+        O.ddim_unet_forward(sd, dict(CFG), x, t, qs)
+    rates, l2, tot_flip, tot_n, big = {}, {}, 0, 0, 0
+    for i, n in enumerate(act_names):
+        if i not in eng.observed or n not in qs.trace:
+            continue
+        xe = eng.observed[i]
+        be = (ops.quantize_act(xe.contiguous(), ops.qsel(qtable[:, i:i + 1].contiguous().to(DEV))).to(torch.int32) + 128).cpu()
+        bo = qs.trace[n].to(torch.int32)
+        if bo.dim() == 4:
+            bo = bo.permute(0, 2, 3, 1)
+        if bo.numel() == 4 * be.numel():   # Upsample conv: the engine quantises before the nearest-neighbour 2x (the two commute exactly)
+            bo = bo[:, ::2, ::2, :]
+        bo = bo.reshape(be.shape)
+        diff = (be - bo).abs()
+        rates[n] = float((diff > 0).float().mean())
+        zp = float(qtable[0, i, 1])
+        l2[n] = float(diff.float().norm() / (bo.float() - zp).norm().clamp_min(1e-9))   # rel-L2 of the dequantised layer inputs
+        tot_flip += int((diff > 0).sum())
+        tot_n += diff.numel()
+        big += int((diff > 1).sum())
+    assert len(rates) >= len(act_names) - 2, (len(rates), len(act_names))
+    overall = tot_flip / tot_n
+    print("per layer flip rate / dequantised rel-L2:", " ".join(f"{n}={r:.3f}/{l2[n]:.3f}" for n, r in rates.items()))
+    print("bin flip rate overall", overall, "worst", max(rates.items(), key=lambda kv: kv[1]), "moves by more than one bin", big / tot_n)
+    first = next(n for n in rates if not n.endswith("temb_proj"))
+    assert rates[first] <= 2e-2, (first, rates[first])
+    assert all(r == 0.0 for n, r in rates.items() if n.endswith("temb_proj"))
+    assert overall <= 0.40 and max(rates.values()) <= 0.60
+    assert big / tot_n <= 5e-2
+    assert max(l2.values()) <= 4.5e-2, max(l2.items(), key=lambda kv: kv[1])

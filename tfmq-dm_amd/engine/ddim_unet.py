@@ -193,7 +193,8 @@ class DdimUNetEngine:
         the MSE scaler, in execution order, upstream layers already quantised (lazy init of
         UniformAffineQuantizer.forward, quant_layer.py:211-221, as driven by calibration.py:113-127).
         mode 'running': EMA min/max update then MINMAX (act_momentum_update, quant_layer.py:229-244).
-        Results land in qtable[k]."""
+        Results land in qtable[k].  mode 'record': nothing is updated; the fp32 tensor every live quantizer sees under table
+        row k is kept in self.observed[qid] (bin-flip-rate tests)."""
         if mode is None:
             self.calib = None
             return
@@ -203,6 +204,8 @@ class DdimUNetEngine:
             self.act_state = torch.zeros(self.qtable.shape[1], 2, dtype=torch.float32, device=self.dev)
             self._qp_scratch = torch.zeros(1, 2, dtype=torch.float32, device=self.dev)
         self.calib = (mode, int(k))
+        if mode == "record":
+            self.observed = {}
         if self.step is not None:
             self.step.fill_(int(k))
 
@@ -210,6 +213,11 @@ class DdimUNetEngine:
         mode, k = self.calib
         qid = aq.qid
         if self.calib_mask is not None and qid not in self.calib_mask:
+            return
+        if mode == "record":       # parity instrumentation: keep the tensor every live quantizer sees (tests compare its bins with the oracle's)
+            self.observed[qid] = x.detach().clone()
+            for s in siblings:
+                self.observed[s] = self.observed[qid]
             return
         if mode == "init":
             qp = ops.mse_search(x, 1, 256)
