@@ -13,7 +13,11 @@ def t(fn, n=10):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n
 qt = torch.tensor([[0.05, 120.0]], device=DEV); sel = ops.qsel(qt)
-for (B, HW, C, C2) in [(256, 1024, 128, 0), (256, 256, 256, 0), (256, 64, 256, 256), (128, 4096, 320, 0), (128, 4096, 320, 320), (128, 1024, 640, 0), (128, 256, 1280, 0), (32, 4096, 320, 0)]:
+SHAPES = [(256, 1024, 128, 0), (256, 256, 256, 0), (256, 64, 256, 256), (128, 4096, 320, 0), (128, 4096, 320, 320), (128, 1024, 640, 0), (128, 256, 1280, 0), (32, 4096, 320, 0)]
+if os.environ.get("SHAPES") == "cat":         # the SD up path's ResBlock inputs: GroupNorm over cat(h, skip) + the fp16 copy for the shortcut conv
+    SHAPES = [(128, 4096, 320, 320), (128, 4096, 640, 320), (128, 1024, 640, 320), (128, 1024, 640, 640), (128, 1024, 1280, 640),
+              (128, 256, 1280, 640), (128, 256, 1280, 1280), (128, 64, 1280, 1280)]
+for (B, HW, C, C2) in SHAPES:
     H16 = os.environ.get("F16", "1") == "1"        # the fp16 activation stream
     x = torch.randn(B, HW, 1, C, device=DEV)
     if H16:

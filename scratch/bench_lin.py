@@ -12,6 +12,8 @@ shapes = [(4096, 320, 2560, "geglu"), (4096, 320, 320, "f16res"), (4096, 1280, 3
           (256, 1280, 10240, "geglu"), (256, 1280, 1280, "f16res"), (256, 5120, 1280, "f16res"), (4096, 1280, 320, "q8res")]
 if os.environ.get("SHAPES") == "qkv":        # fused q|k|v projections: q|k fp16 rows + V^T
     shapes = [(4096, 320, 960, "qkv"), (1024, 640, 1920, "qkv"), (256, 1280, 3840, "qkv"), (64, 1280, 3840, "qkv")]
+if os.environ.get("SHAPES") == "qkvcmp":     # what the transposed V^T third costs: the same GEMM with plain fp16 rows
+    shapes = [(4096, 320, 960, "qkv"), (4096, 320, 960, "f16"), (1024, 640, 1920, "qkv"), (1024, 640, 1920, "f16"), (256, 1280, 3840, "qkv"), (256, 1280, 3840, "f16")]
 if os.environ.get("SHAPES") == "modes":      # one GEMM shape, the three epilogues: what the epilogue arithmetic / stores cost
     shapes = [(4096, 320, 2560, "geglu"), (4096, 320, 2560, "q8"), (4096, 320, 2560, "f16"), (4096, 320, 1280, "q8"), (4096, 320, 1280, "f16")]
 if os.environ.get("SHAPES") == "f16":        # un-quantised skip-connection 1x1 convs (fp16 operands)

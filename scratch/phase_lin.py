@@ -7,7 +7,7 @@ import torch
 import tfmq_dm_amd.ops as ops
 dev = torch.device("cuda", 0)
 B = int(os.environ.get("BATCH", "128"))
-shapes = [(4096, 320, 2560, "geglu"), (4096, 320, 320, "f16res"), (4096, 320, 320, "f16"), (1024, 2560, 640, "f16res"), (256, 1280, 10240, "geglu")]
+shapes = [(4096, 320, 2560, "geglu"), (4096, 320, 320, "f16res"), (4096, 320, 320, "f16"), (4096, 320, 960, "f16"), (1024, 2560, 640, "f16res"), (256, 1280, 10240, "geglu")]
 gen = torch.Generator().manual_seed(0)
 sel = ops.qsel(torch.tensor([[[0.05, 120.0]]], device=dev))
 ops.set_conv_autotune({})

@@ -11,6 +11,7 @@
 // Statistics: fp32 partial sums per thread (<= 128 values), combined in double in a fixed order
 // (deterministic run to run).
 #include "common.hpp"
+#include <cstdlib>
 
 struct GnP {
   tfmq_gn_desc d;
@@ -439,6 +440,140 @@ __global__ __launch_bounds__(256) void k_gn_apply_h8(tfmq_gn_desc d, const float
   }
 }
 
+// The same pass with the layout of k_layernorm_hs (transformer_kernels.hip): LPR lanes share a pixel, lane j owns the 8-channel
+// pieces j, j + LPR, ... of every pixel it visits, a wave walks a contiguous range of pixels and keeps the (image, channel)
+// scale / shift pairs of its pieces in registers until the image changes -- one 16-byte load per 16 bytes of activation instead
+// of five, no per-item index arithmetic, the next pixel group's pieces requested before this group's arithmetic.
+// Per-element arithmetic unchanged (bit-identical outputs).  C <= 40 * LPR, HW % (64 / LPR) == 0.
+template <int LPR>
+__global__ __launch_bounds__(256, 2) void k_gn_apply_hs(tfmq_gn_desc d, const float* __restrict__ A, const float* __restrict__ Bb,
+                                                        int wpi, int nslots) {
+  constexpr int NCH = 5, RPW = 64 / LPR;
+  const int Cc = d.C1 + d.C2, chunks = Cc >> 3;
+  const int lane = threadIdx.x & 63, sub = lane / LPR, j = lane % LPR;
+  // wpi waves share an image and stride through its pixel groups together (the chip sweeps the tensor front to back; a
+  // contiguous range per wave = 2048 separate streams measured 20 % slower); a wave's images are slot, slot + nslots, ...
+  const int gpi = d.HW / RPW;                                  // pixel groups per image
+  const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int slot = wave / wpi, wl = wave - slot * wpi;
+  if (slot >= nslots || slot >= d.B) return;
+  const bool quant = d.aq.qtable != nullptr;
+  float2 qp = make_float2(1.0f, 0.0f);
+  if (quant) qp = load_qparam(d.aq);
+  const QuantP qq = make_quantp(qp);
+  // per piece: source pointer select (virtual concat) and column offsets, fixed for the whole kernel
+  int coff[NCH];
+  bool ok[NCH], second[NCH];
+#pragma unroll
+  for (int k = 0; k < NCH; ++k) {
+    const int idx = j + LPR * k;
+    ok[k] = idx < chunks;
+    const int c = (ok[k] ? idx : 0) * 8;
+    second[k] = c >= d.C1;
+    coff[k] = c;
+  }
+  auto fetch = [&](long grp, uint4* dst) {
+    const long pix = grp * RPW + sub;
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+      const __half* sh = second[k] ? reinterpret_cast<const __half*>(d.x2) + pix * d.C2 + (coff[k] - d.C1)
+                                   : reinterpret_cast<const __half*>(d.x1) + pix * d.C1 + coff[k];
+      dst[k] = *reinterpret_cast<const uint4*>(sh);
+    }
+  };
+  float4 a[NCH][2], bsh[NCH][2];
+  int cur_b = -1;
+  uint4 raw[NCH];
+  int img = slot, g = wl;
+  fetch(static_cast<long>(img) * gpi + g, raw);
+  for (bool have = true; have;) {
+    uint4 nxt[NCH];
+    int ng = g + wpi, nimg = img;
+    if (ng >= gpi) {
+      ng = wl;
+      nimg = img + nslots;
+    }
+    const bool nhave = nimg < d.B;
+    const long grp = static_cast<long>(img) * gpi + g;
+    fetch(nhave ? static_cast<long>(nimg) * gpi + ng : grp, nxt);   // (the last iteration re-reads its own pixels: no branch around loads)
+    const long pix = grp * RPW + sub;
+    const int b = img;
+    if (b != cur_b) {
+      cur_b = b;
+#pragma unroll
+      for (int k = 0; k < NCH; ++k)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          a[k][u] = *reinterpret_cast<const float4*>(A + static_cast<size_t>(b) * Cc + coff[k] + 4 * u);
+          bsh[k][u] = *reinterpret_cast<const float4*>(Bb + static_cast<size_t>(b) * Cc + coff[k] + 4 * u);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+      if (!ok[k]) continue;
+      const uint4 u = raw[k];
+      const unsigned uw[4] = {u.x, u.y, u.z, u.w};
+      const float* ak = reinterpret_cast<const float*>(&a[k][0]);
+      const float* bk = reinterpret_cast<const float*>(&bsh[k][0]);
+      float v[8], y[8];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float2 f = __half22float2(*reinterpret_cast<const __half2*>(&uw[q]));
+        v[2 * q] = f.x;
+        v[2 * q + 1] = f.y;
+      }
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        y[q] = ak[q] * v[q] + bk[q];
+        if (d.silu) y[q] = silu_f(y[q]);
+      }
+      const size_t o = static_cast<size_t>(pix) * Cc + coff[k];
+      if (d.xcat_or_null) {
+        if (d.half_out) *reinterpret_cast<uint4*>(reinterpret_cast<__half*>(d.xcat_or_null) + o) = u;
+        else {
+          *reinterpret_cast<float4*>(d.xcat_or_null + o) = make_float4(v[0], v[1], v[2], v[3]);
+          *reinterpret_cast<float4*>(d.xcat_or_null + o + 4) = make_float4(v[4], v[5], v[6], v[7]);
+        }
+      }
+      if (quant) {
+        unsigned w[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) w[h] = quant_pack4(y[4 * h], y[4 * h + 1], y[4 * h + 2], y[4 * h + 3], qq);
+        *reinterpret_cast<uint2*>(d.yq + o) = make_uint2(w[0], w[1]);
+      }
+      if (d.yf) {
+        if (d.half_out) {
+          __half2 h2[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) h2[q] = __floats2half2_rn(y[2 * q], y[2 * q + 1]);
+          *reinterpret_cast<uint4*>(reinterpret_cast<__half*>(d.yf) + o) = *reinterpret_cast<const uint4*>(h2);
+        } else {
+          *reinterpret_cast<float4*>(d.yf + o) = make_float4(y[0], y[1], y[2], y[3]);
+          *reinterpret_cast<float4*>(d.yf + o + 4) = make_float4(y[4], y[5], y[6], y[7]);
+        }
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) raw[k] = nxt[k];
+    img = nimg;
+    g = ng;
+    have = nhave;
+  }
+}
+
+template <int LPR>
+static void launch_gn_apply_hs(tfmq_handle h, const tfmq_gn_desc& d, const float* A, const float* Bb, hipStream_t st) {
+  constexpr int RPW = 64 / LPR;
+  const int gpi = d.HW / RPW;
+  const int resident = h->cu_count * 2 * 4;                     // two blocks per CU, one round
+  int wpi = resident / d.B;
+  wpi = wpi < 1 ? 1 : (wpi > gpi ? gpi : wpi);
+  int nslots = resident / wpi;
+  nslots = nslots > d.B ? d.B : nslots;
+  const int blocks = (nslots * wpi + 3) / 4;
+  hipLaunchKernelGGL((k_gn_apply_hs<LPR>), dim3(static_cast<unsigned>(blocks)), dim3(256), 0, st, d, A, Bb, wpi, nslots);
+}
+
 extern "C" int tfmq_groupnorm_from_stats(tfmq_handle h, const tfmq_gn_desc* dd, const float* stats1, const float* stats2,
                                          int seg, float* ws, void* stream) {
   TFMQ_CHECK_ARG(h, h && dd && stats1 && ws, "groupnorm_from_stats: null pointer");
@@ -461,7 +596,18 @@ extern "C" int tfmq_groupnorm_from_stats(tfmq_handle h, const tfmq_gn_desc* dd, 
   int blocks = ceil_div(static_cast<long>(total), 256 * 4);
   if (blocks > h->cu_count * 16) blocks = h->cu_count * 16;
   if (blocks < 1) blocks = 1;
-  if (h8) hipLaunchKernelGGL(k_gn_apply_h8, dim3(blocks), dim3(256), 0, as_stream(stream), d, A, Bb);
+  const int chunks8 = Cc / 8;
+  const int lpr = chunks8 <= 40 ? 8 : (chunks8 <= 80 ? 16 : (chunks8 <= 160 ? 32 : (chunks8 <= 320 ? 64 : 0)));
+  // measured at the SD shapes (scratch/bench_gn.py): the sub-wave kernel is 25-30 % faster where a pass reads two sources and / or
+  // writes the fp16 concat copy beside its int8 output (the up path's ResBlock inputs: 4.2-5.1 TB/s against 3.0-3.6), the per-item
+  // kernel 0-20 % faster on the plain single-source pass
+  const bool hs = (d.C2 > 0 || d.xcat_or_null != nullptr) ? !getenv("TFMQ_GN_APPLY_ITEMS") : getenv("TFMQ_GN_APPLY_ROWS") != nullptr;
+  if (h8 && lpr && d.HW % (64 / lpr) == 0 && hs) {
+    if (lpr == 8) launch_gn_apply_hs<8>(h, d, A, Bb, as_stream(stream));
+    else if (lpr == 16) launch_gn_apply_hs<16>(h, d, A, Bb, as_stream(stream));
+    else if (lpr == 32) launch_gn_apply_hs<32>(h, d, A, Bb, as_stream(stream));
+    else launch_gn_apply_hs<64>(h, d, A, Bb, as_stream(stream));
+  } else if (h8) hipLaunchKernelGGL(k_gn_apply_h8, dim3(blocks), dim3(256), 0, as_stream(stream), d, A, Bb);
   else if (v4) hipLaunchKernelGGL(k_gn_apply<4>, dim3(blocks), dim3(256), 0, as_stream(stream), d, A, Bb);
   else hipLaunchKernelGGL(k_gn_apply<1>, dim3(blocks), dim3(256), 0, as_stream(stream), d, A, Bb);
   TFMQ_LAUNCH_CHECK(h);
