@@ -46,9 +46,12 @@ enum { LIN_F16 = 0, LIN_Q8 = 1, LIN_GEGLU = 2 };
 // and stores of what phase 1 left (k_lin_stream puts the next tile's residual loads between the two).
 // F16OP: fp16 operands (un-quantised layers): the accumulators are fp32 bit patterns and value = scale * acc + bias
 // (scale = 1 unless the weight-only integer grid carries one), the arithmetic of k_conv_dma<true>.
+constexpr int LIN_STG_ROW_Q8 = 80;        // int8 rows: 64 + 16
+constexpr int LIN_STG_ROW = 144;          // bytes per staged pixel row: 64 fp16 + 16 (rows 16 bytes apart in the banks: conflict-free)
 template <int MODE, int PHASE = 0, bool F16OP = false>
 __device__ __forceinline__ void lin_epilogue(const ConvP& p, v16i (&acc)[2][2], const float* cs, uint4 (&rres)[2][2][2], bool has_res,
-                                             int m0, int n0, int wm, int wn, int lane, float2 oqp, float2* ldsP = nullptr) {
+                                             int m0, int n0, int wm, int wn, int lane, float2 oqp, float2* ldsP = nullptr,
+                                             unsigned char* stg = nullptr) {
   constexpr int BN = 128;
   const tfmq_conv_desc& d = p.d;
   const int h = lane >> 5;
@@ -161,17 +164,59 @@ __device__ __forceinline__ void lin_epilogue(const ConvP& p, v16i (&acc)[2][2], 
                     dst[(2 * e) * static_cast<size_t>(thw)] = __float2half_rn(v[e].x);
                     dst[(2 * e + 1) * static_cast<size_t>(thw)] = __float2half_rn(v[e].y);
                   }
-                } else {
+                } else if (!(PHASE == 0 && stg != nullptr)) {
                   *reinterpret_cast<uint4*>(reinterpret_cast<__half*>(d.y) + static_cast<size_t>(m) * d.ldy + d.y_coff + n) =
                       make_uint4(pack_h2(v[0].x, v[0].y), pack_h2(v[1].x, v[1].y), pack_h2(v[2].x, v[2].y), pack_h2(v[3].x, v[3].y));
                 }
-              } else {
+              } else if (!(PHASE == 0 && stg != nullptr)) {
                 *reinterpret_cast<uint2*>(d.yq + static_cast<size_t>(m) * d.Cout + n) =
                     make_uint2(quant_pack4_t<EX>(v[0], v[1], qP), quant_pack4_t<EX>(v[2], v[3], qP));
               }
             }
+            if constexpr (MODE == LIN_Q8 && PHASE == 0) {      // int8 output: the same transpose with 80-byte staged rows (64 + 16)
+              if (stg != nullptr)
+                *reinterpret_cast<uint2*>(stg + (lane & 31) * LIN_STG_ROW_Q8 + j * 32 + 16 * h + 8 * u) =
+                    make_uint2(quant_pack4_t<EX>(v[0], v[1], qP), quant_pack4_t<EX>(v[2], v[3], qP));
+            }
+            if constexpr (MODE == LIN_F16 && PHASE == 0) {
+              // row-major fp16 output through a wave-private LDS transpose (see below): this lane's 8 channels of pixel row lane % 32
+              if (stg != nullptr && !transposed)
+                *reinterpret_cast<uint4*>(stg + (lane & 31) * LIN_STG_ROW + (j * 32 + 16 * h + 8 * u) * 2) =
+                    make_uint4(pack_h2(v[0].x, v[0].y), pack_h2(v[1].x, v[1].y), pack_h2(v[2].x, v[2].y), pack_h2(v[3].x, v[3].y));
+            }
             __builtin_amdgcn_sched_barrier(0);      // one octet at a time: interleaving them all spilled the accumulators
           }
+        if constexpr (MODE == LIN_F16 && PHASE == 0) {
+          // The register layout gives a store instruction 32 pixel rows x two 16-byte pieces: 32 partially written lines and 64
+          // 16-byte write requests to the L2 per instruction (PMC: 16 bytes per L2 write request; a CU retires about one touched
+          // line per 4 cycles).  Through LDS the wave's 32 x 64 fp16 block goes out as whole 128-byte row segments: 8 lanes per
+          // row, 8 rows = 8 full lines per instruction.  Wave-private region, DS operations of a wave execute in order: no barrier.
+          if (stg != nullptr && !transposed) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+              const int row = t * 8 + (lane >> 3), pc = lane & 7;
+              const uint4 w = *reinterpret_cast<const uint4*>(stg + row * LIN_STG_ROW + pc * 16);
+              const int m2 = m0 + (wm * 2 + i) * 32 + row, n2 = n0 + wn * 64 + pc * 8;
+              if (m2 < p.M && n2 < d.Cout)
+                *reinterpret_cast<uint4*>(reinterpret_cast<__half*>(d.y) + static_cast<size_t>(m2) * d.ldy + d.y_coff + n2) = w;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+          }
+        }
+        if constexpr (MODE == LIN_Q8 && PHASE == 0) {
+          if (stg != nullptr) {            // 4 lanes per 64-byte row segment, 16 rows per store instruction
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+              const int row = t * 16 + (lane >> 2), pc = lane & 3;
+              const uint4 w = *reinterpret_cast<const uint4*>(stg + row * LIN_STG_ROW_Q8 + pc * 16);
+              const int m2 = m0 + (wm * 2 + i) * 32 + row, n2 = n0 + wn * 64 + pc * 16;
+              if (m2 < p.M && n2 < d.Cout) *reinterpret_cast<uint4*>(d.yq + static_cast<size_t>(m2) * d.Cout + n2) = w;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+          }
+        }
       }
     }
   };
@@ -362,7 +407,10 @@ __global__ __launch_bounds__(256, 3) void k_lin_direct(ConvP p) {
 
   // statistics partials [16 eight-row groups][BN] live in the (now idle) DMA stages
   float2* ldsP = (MODE == LIN_F16 && d.stats) ? reinterpret_cast<float2*>(lds) : nullptr;
-  lin_epilogue<MODE, 0, F16OP>(p, acc, cs, rres, has_res, m0, n0, wm, wn, lane, oqp, ldsP);
+  // (store staging: 32 rows x 144 bytes per wave behind the 16 KB of statistics partials, all inside the idle DMA stages)
+  unsigned char* stg = MODE == LIN_F16 ? lds + 16384 + wid * (32 * LIN_STG_ROW) : nullptr;
+  if constexpr (MODE == LIN_Q8) stg = (d.Cout & 15) == 0 ? lds + wid * (32 * LIN_STG_ROW_Q8) : nullptr;
+  lin_epilogue<MODE, 0, F16OP>(p, acc, cs, rres, has_res, m0, n0, wm, wn, lane, oqp, ldsP, stg);
   if constexpr (MODE == LIN_F16) {
     if (d.stats) {
       __syncthreads();
