@@ -34,7 +34,8 @@ for (B, HW, C, C2) in SHAPES:
             x2 = x2.half()
         x2._tfmq_stats = (stats(C2), seg)
     g = torch.ones(C + C2, device=DEV); b = torch.zeros(C + C2, device=DEV)
-    fn = lambda: ops.groupnorm(x, g, b, 1e-5, True, sel, x2=x2, want_cat=bool(C2), half_out=bool(C2))
+    SILU = os.environ.get("SILU", "1") == "1"
+    fn = lambda: ops.groupnorm(x, g, b, 1e-5, SILU, sel, x2=x2, want_cat=bool(C2), half_out=bool(C2))
     ms = t(fn)
     byts = B * HW * (C + C2) * ((3 if H16 else 5) + (2 if C2 else 0))
     print(f"B={B} HW={HW} C={C}+{C2}: gn_apply from stats {ms*1e3:8.1f} us  ({byts/ms/1e9:6.2f} TB/s algorithmic)", flush=True)
