@@ -4,6 +4,7 @@
 // Elementwise over weight-sized tensors, HBM-bound: one fused pass reads w, alpha, m, v, g and
 // writes alpha, m, v (32 B/element) instead of the ~20 ATen passes of one reference iteration.
 #include "common.hpp"
+#include <cstdint>
 
 #define ADA_GAMMA (-0.1f)
 #define ADA_ZETA_M_GAMMA (1.2f)  // fp32(1.1 - (-0.1))
@@ -48,10 +49,43 @@ __global__ __launch_bounds__(256) void k_adaround_soft_fwd(const float* __restri
   }
 }
 
+// four consecutive columns per thread (see k_adaround_bwd_adam4); per-element arithmetic = the scalar kernel's
+__global__ __launch_bounds__(256) void k_adaround_soft_fwd4(const float* __restrict__ w, const float* __restrict__ alpha,
+                                                            const float* __restrict__ delta, const float* __restrict__ zp,
+                                                            float* __restrict__ w_hat, unsigned rows, unsigned cols4, float lmax, int hard) {
+  const unsigned n4 = rows * cols4, stride = gridDim.x * blockDim.x;
+  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    const unsigned r = i / cols4;
+    const float d = delta[r], z = zp[r];
+    const float4 a4 = reinterpret_cast<const float4*>(alpha)[i], w4 = reinterpret_cast<const float4*>(w)[i];
+    const float av[4] = {a4.x, a4.y, a4.z, a4.w}, wv[4] = {w4.x, w4.y, w4.z, w4.w};
+    float o[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float hsoft = sigmoid_f(av[e]) * ADA_ZETA_M_GAMMA + ADA_GAMMA;
+      hsoft = fminf(fmaxf(hsoft, 0.0f), 1.0f);
+      if (hard) hsoft = av[e] >= 0.0f ? 1.0f : 0.0f;
+      float q = floorf(wv[e] / d) + hsoft;
+      q = fminf(fmaxf(q + z, 0.0f), lmax);
+      o[e] = d * (q - z);
+    }
+    reinterpret_cast<float4*>(w_hat)[i] = make_float4(o[0], o[1], o[2], o[3]);
+  }
+}
+
 extern "C" int tfmq_adaround_soft_fwd(tfmq_handle h, const float* w, const float* alpha, const float* delta,
                                       const float* zp, float* w_hat, size_t rows, size_t cols, int level, int hard,
                                       void* stream) {
   TFMQ_CHECK_ARG(h, h && w && alpha && delta && zp && w_hat && rows > 0 && cols > 0, "adaround_soft_fwd: bad argument");
+  const bool al16 = ((reinterpret_cast<uintptr_t>(w) | reinterpret_cast<uintptr_t>(alpha) | reinterpret_cast<uintptr_t>(w_hat)) & 15) == 0;
+  if (cols % 4 == 0 && al16 && rows * cols < (1ull << 32)) {
+    int blocks4 = ceil_div(static_cast<long>(rows * cols / 4), 256);
+    if (blocks4 > h->cu_count * 8) blocks4 = h->cu_count * 8;
+    hipLaunchKernelGGL(k_adaround_soft_fwd4, dim3(blocks4), dim3(256), 0, as_stream(stream), w, alpha, delta, zp, w_hat,
+                       static_cast<unsigned>(rows), static_cast<unsigned>(cols / 4), static_cast<float>(level - 1), hard);
+    TFMQ_LAUNCH_CHECK(h);
+    return TFMQ_OK;
+  }
   int blocks = ceil_div(static_cast<long>(rows * cols), 256);
   if (blocks > h->cu_count * 8) blocks = h->cu_count * 8;
   hipLaunchKernelGGL(k_adaround_soft_fwd, dim3(blocks), dim3(256), 0, as_stream(stream), w, alpha, delta, zp, w_hat,
@@ -103,12 +137,80 @@ __global__ __launch_bounds__(256) void k_adaround_bwd_adam(const float* __restri
   }
 }
 
+// Four consecutive columns per thread (cols % 4 == 0: every conv / Linear of the UNets): 16-byte loads and stores of the six
+// streams, one 32-bit row division per item instead of a 64-bit one per element.  Per-element arithmetic = the scalar kernel's.
+__global__ __launch_bounds__(256) void k_adaround_bwd_adam4(const float* __restrict__ w, float* __restrict__ alpha,
+                                                            const float* __restrict__ delta, const float* __restrict__ zp,
+                                                            const float* __restrict__ g_what, float* __restrict__ m,
+                                                            float* __restrict__ v, unsigned rows, unsigned cols4, float lmax,
+                                                            float w_reg, float b_temp, float step_size, float bc2_sqrt,
+                                                            float* __restrict__ round_loss) {
+  const float beta1 = 0.9f, beta2 = 0.999f, eps = 1e-8f;
+  const unsigned n4 = rows * cols4, stride = gridDim.x * blockDim.x;
+  float rl = 0.0f;
+  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    const unsigned r = i / cols4;
+    const float d = delta[r], z = zp[r];
+    const float4 a4 = reinterpret_cast<const float4*>(alpha)[i], w4 = reinterpret_cast<const float4*>(w)[i];
+    const float4 g4 = reinterpret_cast<const float4*>(g_what)[i];
+    const float4 m4 = reinterpret_cast<const float4*>(m)[i], v4 = reinterpret_cast<const float4*>(v)[i];
+    const float av[4] = {a4.x, a4.y, a4.z, a4.w}, wv[4] = {w4.x, w4.y, w4.z, w4.w}, gv[4] = {g4.x, g4.y, g4.z, g4.w};
+    const float mv[4] = {m4.x, m4.y, m4.z, m4.w}, vv[4] = {v4.x, v4.y, v4.z, v4.w};
+    float ao[4], mo[4], vo[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float a = av[e];
+      const float sg = sigmoid_f(a);
+      const float hs = sg * ADA_ZETA_M_GAMMA + ADA_GAMMA;
+      const float hsoft = fminf(fmaxf(hs, 0.0f), 1.0f);
+      const float qv = floorf(wv[e] / d) + hsoft + z;
+      float gh = (qv >= 0.0f && qv <= lmax) ? gv[e] * d : 0.0f;
+      if (b_temp > 0.0f) {
+        const float c = hsoft - 0.5f;
+        const float u = fabsf(c) * 2.0f;
+        const float ub1 = powf(u, b_temp - 1.0f);
+        rl += 1.0f - ub1 * u;
+        const float sgn = c > 0.0f ? 1.0f : (c < 0.0f ? -1.0f : 0.0f);
+        gh += -w_reg * b_temp * ub1 * 2.0f * sgn;
+      }
+      const float g = (hs >= 0.0f && hs <= 1.0f) ? gh * (ADA_ZETA_M_GAMMA * sg * (1.0f - sg)) : 0.0f;
+      const float mi = mv[e] + (g - mv[e]) * (1.0f - beta1);
+      const float vi = vv[e] * beta2 + (1.0f - beta2) * g * g;
+      mo[e] = mi;
+      vo[e] = vi;
+      const float denom = sqrtf(vi) / bc2_sqrt + eps;
+      ao[e] = a - step_size * (mi / denom);
+    }
+    reinterpret_cast<float4*>(m)[i] = make_float4(mo[0], mo[1], mo[2], mo[3]);
+    reinterpret_cast<float4*>(v)[i] = make_float4(vo[0], vo[1], vo[2], vo[3]);
+    reinterpret_cast<float4*>(alpha)[i] = make_float4(ao[0], ao[1], ao[2], ao[3]);
+  }
+  if (round_loss && b_temp > 0.0f) {      // one atomic per block: 8192 wave atomics on the one address cost ~100 us per launch
+    __shared__ float part[4];
+    rl = wave_reduce_sum(rl);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = rl;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(round_loss, w_reg * ((part[0] + part[1]) + (part[2] + part[3])));
+  }
+}
+
 extern "C" int tfmq_adaround_bwd_adam(tfmq_handle h, const float* w, float* alpha, const float* delta, const float* zp,
                                       const float* g_what, float* m, float* v, size_t rows, size_t cols, int level,
                                       float w_reg, float b_temp, float lr, int t, float* round_loss, void* stream) {
   TFMQ_CHECK_ARG(h, h && w && alpha && delta && zp && g_what && m && v && rows > 0 && cols > 0 && t >= 1,
                  "adaround_bwd_adam: bad argument");
   const double bc1 = 1.0 - pow(0.9, t), bc2 = 1.0 - pow(0.999, t);
+  const bool al16 = ((reinterpret_cast<uintptr_t>(w) | reinterpret_cast<uintptr_t>(alpha) | reinterpret_cast<uintptr_t>(g_what) |
+                      reinterpret_cast<uintptr_t>(m) | reinterpret_cast<uintptr_t>(v)) & 15) == 0;
+  if (cols % 4 == 0 && al16 && rows * cols < (1ull << 32)) {
+    int blocks4 = ceil_div(static_cast<long>(rows * cols / 4), 256);
+    if (blocks4 > h->cu_count * 4) blocks4 = h->cu_count * 4;
+    hipLaunchKernelGGL(k_adaround_bwd_adam4, dim3(blocks4), dim3(256), 0, as_stream(stream), w, alpha, delta, zp, g_what, m, v,
+                       static_cast<unsigned>(rows), static_cast<unsigned>(cols / 4), static_cast<float>(level - 1), w_reg, b_temp,
+                       static_cast<float>(lr / bc1), static_cast<float>(sqrt(bc2)), round_loss);
+    TFMQ_LAUNCH_CHECK(h);
+    return TFMQ_OK;
+  }
   int blocks = ceil_div(static_cast<long>(rows * cols), 256);
   if (blocks > h->cu_count * 8) blocks = h->cu_count * 8;
   hipLaunchKernelGGL(k_adaround_bwd_adam, dim3(blocks), dim3(256), 0, as_stream(stream), w, alpha, delta, zp, g_what, m,
@@ -125,13 +227,28 @@ __global__ __launch_bounds__(256) void k_recon_loss(const float* __restrict__ pr
                                                     float* __restrict__ loss) {
   const size_t stride = static_cast<size_t>(gridDim.x) * blockDim.x;
   double acc = 0.0;
-  for (size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) {
-    const float dlt = pred[i] - tgt[i];
-    acc += static_cast<double>(dlt) * dlt;
-    if (g) g[i] = 2.0f * dlt * inv_denom;
+  const bool v4 = (n & 3) == 0 && ((reinterpret_cast<uintptr_t>(pred) | reinterpret_cast<uintptr_t>(tgt) | reinterpret_cast<uintptr_t>(g)) & 15) == 0;
+  if (v4) {                               // 16-byte items; per element the same operations in the same order within a thread
+    for (size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n / 4; i += stride) {
+      const float4 p4 = reinterpret_cast<const float4*>(pred)[i], t4 = reinterpret_cast<const float4*>(tgt)[i];
+      const float dl[4] = {p4.x - t4.x, p4.y - t4.y, p4.z - t4.z, p4.w - t4.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc += static_cast<double>(dl[e]) * dl[e];
+      if (g) reinterpret_cast<float4*>(g)[i] = make_float4(2.0f * dl[0] * inv_denom, 2.0f * dl[1] * inv_denom, 2.0f * dl[2] * inv_denom, 2.0f * dl[3] * inv_denom);
+    }
+  } else {
+    for (size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) {
+      const float dlt = pred[i] - tgt[i];
+      acc += static_cast<double>(dlt) * dlt;
+      if (g) g[i] = 2.0f * dlt * inv_denom;
+    }
   }
+  // one atomic per block (the wave atomics of a full grid on the one address cost more than the pass itself)
+  __shared__ double part[4];
   acc = wave_reduce_sum_d(acc);
-  if ((threadIdx.x & 63) == 0) atomicAdd(loss, static_cast<float>(acc * inv_denom));
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(loss, static_cast<float>(((part[0] + part[1]) + (part[2] + part[3])) * inv_denom));
 }
 
 extern "C" int tfmq_recon_loss(tfmq_handle h, const float* pred, const float* tgt, float* g, size_t n, size_t denom,
