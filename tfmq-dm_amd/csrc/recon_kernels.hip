@@ -89,7 +89,8 @@ static int gemm_f32_impl(tfmq_handle h, const float* A, const float* B, float* C
   batch *= heads;
   // fp32 matrix cores (gemm_f32_mfma.hip); small problems keep the FMA tile.  Skinny outputs with a long reduction
   // (the context-side gradients of cross attention: 77 x 40..160, K = 256..4096) also go there: split-K fills the chip
-  if ((M >= 96 && N >= 24 && K >= 8) || (M >= 32 && N >= 24 && K >= 64)) {
+  // ... and the mini-batch-row GEMMs of the TIB unit (8 x 1280 x 1280: 96 us on the FMA tile, 20 blocks walking K; 24 us here)
+  if ((M >= 96 && N >= 24 && K >= 8) || (M >= 32 && N >= 24 && K >= 64) || (N >= 64 && K >= 256)) {
     const int rc = tfmq_gemm_f32_mfma_launch(h, p, batch, as_stream(stream));
     if (rc != TFMQ_OK) return rc;
     TFMQ_LAUNCH_CHECK(h);
