@@ -187,6 +187,13 @@ typedef struct tfmq_conv_desc {
                                     boundaries with exact counted waits (>= 3 K-steps, no transposed region, no statistics) */
   int32_t res_f16;               /* != 0: `residual` is an fp16 buffer [B][Ho][Wo][Cout] (a tensor of the fp16 activation stream:
                                     the TFMQ_OUT_F16 output of an earlier launch) */
+  const void* x2;                /* tfmq_conv2d_f16, pointwise, x_f16 only; NULL = one source.  Input channels [cin1, Cin) are read
+                                    from x2, an fp16 tensor [B][H][W][Cin - cin1]: the layer sees the channel concat cat(x, x2)
+                                    without its copy (the skip_connection / nin_shortcut of an up-path ResBlock reading
+                                    th.cat([h, hs.pop()], dim=1), openaimodel.py:771 / ddim/models/diffusion.py:337).  x is then
+                                    [B][H][W][cin1].  Needs cin1 % 32 == 0, (Cin - cin1) % 32 == 0 and a launch the register-direct
+                                    pointwise kernel takes (fp16 output, no rowadd); anything else is TFMQ_ERR_ARG */
+  int32_t cin1;
 } tfmq_conv_desc;
 enum { TFMQ_OUT_F32 = 0, TFMQ_OUT_F16 = 1, TFMQ_OUT_GEGLU_Q8 = 2, TFMQ_OUT_Q8 = 3 };
 enum { TFMQ_TILE_AUTO = 0, TFMQ_TILE_128 = 1, TFMQ_TILE_64 = 2, TFMQ_TILE_256 = 3, TFMQ_TILE_128x64 = 4, TFMQ_TILE_SLAB = 5, TFMQ_TILE_DIRECT = 6, TFMQ_TILE_STREAM = 7, TFMQ_TILE_PERSIST = 8 };

@@ -480,3 +480,36 @@ def test_direct_pointwise_kernel_on_fp16_operands(ops, B, T, cin, cout, res, wq)
             _o._tune_conv = orig
             ops.set_conv_autotune(None)
     assert outs[0].dtype == torch.float16 and torch.equal(outs[0], outs[1])
+
+
+@pytest.mark.parametrize("B,T,c1,c2,cout,res", [(2, 256, 320, 320, 320, False), (3, 77, 640, 320, 320, True), (1, 300, 1280, 640, 640, False), (2, 64, 32, 96, 64, True)])
+def test_f16_pointwise_reads_a_virtual_concat(ops, B, T, c1, c2, cout, res):
+    """tfmq_conv_desc.x2: the shortcut conv of an up-path ResBlock (openaimodel.py:771 th.cat([h, hs.pop()], dim=1) ->
+    skip_connection) reads its two fp16 sources directly -- bit-identical to the conv over the materialised concat, with and
+    without a residual and GroupNorm statistics; launches the kernel cannot take are refused, not computed some other way."""
+    from tfmq_dm_amd._lib import TfmqError
+    gen = torch.Generator().manual_seed(B * T + c1)
+    x1 = (torch.randn(B, T, 1, c1, generator=gen) * 1.2).to(DEV).half()
+    x2 = (torch.randn(B, T, 1, c2, generator=gen) * 0.7 + 0.1).to(DEV).half()
+    w = (torch.randn(cout, c1 + c2, 1, 1, generator=gen) * 0.05).to(DEV)
+    bias = torch.randn(cout, generator=gen).to(DEV)
+    pf = ops.pack_w_f16(w.reshape(cout, c1 + c2), bias)
+    kw = {}
+    if res:
+        kw["residual"] = torch.randn(B, T, 1, cout, generator=gen).to(DEV).half()
+    xc = torch.cat([x1, x2], dim=-1).contiguous()
+    ref = ops.conv2d_f16(xc, pf, out_f16=True, want_stats=True, **kw)
+    got = ops.conv2d_f16(x1, pf, out_f16=True, want_stats=True, x2=x2, **kw)
+    assert torch.equal(got, ref)
+    assert hasattr(got, "_tfmq_stats") == hasattr(ref, "_tfmq_stats")
+    if hasattr(ref, "_tfmq_stats"):
+        assert torch.equal(got._tfmq_stats[0], ref._tfmq_stats[0])
+    # value check against torch (fp16 operands, fp32 accumulate)
+    y = torch.nn.functional.linear(xc.float().reshape(-1, c1 + c2), w.reshape(cout, -1).half().float(), bias).reshape(B, T, 1, cout)
+    if res:
+        y = y + kw["residual"].float()
+    assert float((got.float() - y).abs().max()) <= 4e-3 * float(y.abs().max())
+    with pytest.raises(TfmqError):
+        ops.conv2d_f16(x1, pf, x2=x2)                       # fp32 output: not a launch of the pointwise kernel
+    with pytest.raises(TfmqError):
+        ops.conv2d_f16(x1.float(), pf, out_f16=True, x2=x2)  # fp32 first source

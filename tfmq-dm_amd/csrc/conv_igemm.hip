@@ -1006,11 +1006,12 @@ static int launch_conv(tfmq_handle h, const tfmq_conv_desc* dd, void* stream) {
     big = big_ok && !small && d.out_mode == TFMQ_OUT_F16 && tiles128 >= 4L * h->cu_count;
   }
   if constexpr (!INT8) {
-    if ((d.tile == TFMQ_TILE_AUTO || d.tile == TFMQ_TILE_DIRECT) && dma16 && launch_conv_lin_f16(h, p, as_stream(stream))) {
+    if ((d.tile == TFMQ_TILE_AUTO || d.tile == TFMQ_TILE_DIRECT || d.x2) && dma16 && launch_conv_lin_f16(h, p, as_stream(stream))) {
       TFMQ_LAUNCH_CHECK(h);
       return TFMQ_OK;
     }
   }
+  TFMQ_CHECK_ARG(h, !d.x2, "conv2d: a second input source (x2) is only read by the fp16 pointwise kernel (tfmq_conv_desc.x2)");
   if constexpr (INT8) {
     // token Linears / 1x1 convs writing fp16, int8 or GEGLU-int8: the register-direct-epilogue kernel (conv_lin.hip)
     if (d.tile == TFMQ_TILE_STREAM && d.wmeta && d.wscale && d.aq.qtable && launch_conv_lin(h, p, as_stream(stream), 1)) {

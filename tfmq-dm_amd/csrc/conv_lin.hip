@@ -285,12 +285,16 @@ __global__ __launch_bounds__(256, 3) void k_lin_direct(ConvP p) {
   const unsigned char* xb = static_cast<const unsigned char*>(d.x);
   const int dcol = ((lane & 3) ^ ((lane >> 4) & 3)) * 16;
   const unsigned char* a_ptr[2];
+  const unsigned char* a2_ptr[2] = {nullptr, nullptr};
   const unsigned char* b_ptr[2];
 #pragma unroll
   for (int it = 0; it < 2; ++it) {
     const int piece = wid * 2 + it;
     const int m = m0 + piece * 16 + (lane >> 2);
-    a_ptr[it] = m < p.M ? xb + static_cast<size_t>(m) * d.Cin * (F16OP ? 2 : 1) + dcol : p.pad_table + dcol;
+    a_ptr[it] = m < p.M ? xb + static_cast<size_t>(m) * (F16OP && d.x2 ? d.cin1 : d.Cin) * (F16OP ? 2 : 1) + dcol : p.pad_table + dcol;
+    if constexpr (F16OP) {         // second source of a virtual channel concat (tfmq_conv_desc.x2): K-steps >= cin1 / 32 read it
+      a2_ptr[it] = (d.x2 && m < p.M) ? static_cast<const unsigned char*>(d.x2) + static_cast<size_t>(m) * (d.Cin - d.cin1) * 2 + dcol : a_ptr[it];
+    }
     int n = n0 + piece * 16 + (lane >> 2);
     if constexpr (F16OP) {           // fp16 weights [cout][cin_pad] row-major (tfmq_pack_w_f16), fp16 activations: 32 channels per K-step
       n = n < d.Cout ? n : d.Cout - 1;
@@ -302,10 +306,16 @@ __global__ __launch_bounds__(256, 3) void k_lin_direct(ConvP p) {
   }
   constexpr size_t BSTEP = F16OP ? 64 : 2048;
   const bool a_live0 = m0 + (wid * 2) * 16 + (lane >> 2) < p.M, a_live1 = m0 + (wid * 2 + 1) * 16 + (lane >> 2) < p.M;
+  const int s_split = (F16OP && d.x2) ? d.cin1 / 32 : (1 << 30);
   auto issue = [&](int s, int stage) {
     const unsigned sbase = lds0 + stage * STAGE;
-    glds16(a_ptr[0] + (a_live0 ? s * 64 : 0), sbase + __builtin_amdgcn_readfirstlane((wid * 2) * 1024));
-    glds16(a_ptr[1] + (a_live1 ? s * 64 : 0), sbase + __builtin_amdgcn_readfirstlane((wid * 2 + 1) * 1024));
+    if (F16OP && s >= s_split) {
+      glds16(a2_ptr[0] + (a_live0 ? (s - s_split) * 64 : 0), sbase + __builtin_amdgcn_readfirstlane((wid * 2) * 1024));
+      glds16(a2_ptr[1] + (a_live1 ? (s - s_split) * 64 : 0), sbase + __builtin_amdgcn_readfirstlane((wid * 2 + 1) * 1024));
+    } else {
+      glds16(a_ptr[0] + (a_live0 ? s * 64 : 0), sbase + __builtin_amdgcn_readfirstlane((wid * 2) * 1024));
+      glds16(a_ptr[1] + (a_live1 ? s * 64 : 0), sbase + __builtin_amdgcn_readfirstlane((wid * 2 + 1) * 1024));
+    }
     glds16(b_ptr[0] + static_cast<size_t>(s) * BSTEP, sbase + __builtin_amdgcn_readfirstlane(BM * 64 + (wid * 2) * 1024));
     glds16(b_ptr[1] + static_cast<size_t>(s) * BSTEP, sbase + __builtin_amdgcn_readfirstlane(BM * 64 + (wid * 2 + 1) * 1024));
   };
@@ -932,6 +942,7 @@ bool launch_conv_lin_f16(tfmq_handle h, ConvP& p, hipStream_t st) {
   const tfmq_conv_desc& d = p.d;
   if (d.KH != 1 || d.KW != 1 || d.stride != 1 || d.up2x || d.pad_t != 0 || d.pad_l != 0 || d.Ho != d.H || d.Wo != d.W) return false;
   if (!d.x_f16 || d.Cin % 32 != 0 || p.cin_pad != d.Cin || static_cast<size_t>(d.B) * d.H * d.W * d.Cin * 2 >= (static_cast<size_t>(1) << 31)) return false;
+  if (d.x2 && (d.cin1 <= 0 || d.cin1 >= d.Cin || d.cin1 % 32 != 0)) return false;
   if (d.out_mode != TFMQ_OUT_F16 || d.rowadd || d.yt || (d.Cout & 7) != 0 || ((d.ldy | d.y_coff) & 7) != 0) return false;
   if (d.residual && !d.res_f16) return false;
   if (d.stats && 128 % d.stats_seg != 0) return false;

@@ -315,17 +315,26 @@ class DdimUNetEngine:
     def _fp_conv_half_ok(self, layer: _Layer) -> bool:
         return layer.kind != "w4a8" and ops.f16_dma_ok(layer.p.cin, layer.p.kh, layer.p.kw)
 
+    def _virtual_cat_ok(self, layer: _Layer, x1, x2) -> bool:
+        """The shortcut conv of an up-path block can read cat(x1, x2) from its two fp16 sources (tfmq_conv_desc.x2): the
+        GroupNorm then does not write the concat copy (2 of its 5 bytes per element).  fp16 stream only."""
+        return (x2 is not None and self._h16 and os.environ.get("TFMQ_VIRTUAL_CAT", "1") != "0" and layer.kind != "w4a8" and x1.dtype == torch.float16 and x2.dtype == torch.float16
+                and layer.p.cout % 8 == 0 and ops.f16_cat_ok(x1.shape[-1], x2.shape[-1], layer.p.kh, layer.p.kw))
+
     def _resblock(self, p, x1, x2, rowadd_kw):
         L = self.layers
         has_sc = (p + ".nin_shortcut") in L
         if x2 is not None and not has_sc:
             raise TfmqError(f"{p}: concatenated input without nin_shortcut is not a DDPM-UNet block")
         half = has_sc and self._fp_conv_half_ok(L[p + ".nin_shortcut"])
+        virt = has_sc and self._virtual_cat_ok(L[p + ".nin_shortcut"], x1, x2)
         h, xcat = self._gn(p + ".norm1", x1, x2, True, L[p + ".conv1"],
-                           want_cat=has_sc and (x2 is not None or (half and x1.dtype != torch.float16)), half=half, half_main=True)
+                           want_cat=has_sc and not virt and (x2 is not None or (half and x1.dtype != torch.float16)), half=half, half_main=True)
         h = L[p + ".conv1"].run(h, pad=(1, 1, 1, 1), **rowadd_kw, **self._o16())
         h, _ = self._gn(p + ".norm2", h, None, True, L[p + ".conv2"], half_main=True)
-        if has_sc:
+        if virt:
+            sc = L[p + ".nin_shortcut"].run(x1, x2=x2, **self._o16())
+        elif has_sc:
             sc = L[p + ".nin_shortcut"].run(xcat if xcat is not None else x1, **self._o16())
         else:
             sc = x1

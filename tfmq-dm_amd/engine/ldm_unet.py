@@ -171,12 +171,16 @@ class LdmUNetEngine(DdimUNetEngine):
         if x2 is not None and not has_skip:
             raise TfmqError(f"{p}: concatenated input without skip_connection")
         half = has_skip and self._fp_conv_half_ok(L[p + ".skip_connection"])
+        virt = has_skip and self._virtual_cat_ok(L[p + ".skip_connection"], x1, x2)     # the skip conv reads its two sources itself
         h, xcat = self._gn(p + ".in_layers.0", x1, x2, True, cin,
-                           want_cat=has_skip and (x2 is not None or (half and x1.dtype != torch.float16)), eps=1e-5,
+                           want_cat=has_skip and not virt and (x2 is not None or (half and x1.dtype != torch.float16)), eps=1e-5,
                            half=half, half_main=True)
         h = cin.run(h, pad=(1, 1, 1, 1), **rowadd_kw, **self._o16())
         h, _ = self._gn(p + ".out_layers.0", h, None, True, cout, eps=1e-5, half_main=True)
-        sc = L[p + ".skip_connection"].run(xcat if xcat is not None else x1, want_stats=False, **self._o16()) if has_skip else x1
+        if virt:
+            sc = L[p + ".skip_connection"].run(x1, x2=x2, want_stats=False, **self._o16())
+        else:
+            sc = L[p + ".skip_connection"].run(xcat if xcat is not None else x1, want_stats=False, **self._o16()) if has_skip else x1
         if out_aq is not None and cout.kind == "w4a8":
             return cout.run(h, pad=(1, 1, 1, 1), residual=sc, want_stats=False, out_q8=out_aq)
         return cout.run(h, pad=(1, 1, 1, 1), residual=sc, **self._o16())

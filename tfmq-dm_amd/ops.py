@@ -409,6 +409,8 @@ def _tune_conv(h, name, kind, d, dsc):
         return t
     if torch.cuda.is_current_stream_capturing() or dsc.Cout <= 32 or (dsc.residual and dsc.residual in (dsc.y, dsc.yq)):
         return 0                      # cannot time inside a capture / nothing to choose / not idempotent
+    if kind == "f16" and dsc.x2:
+        return 6                      # two sources: only the register-direct pointwise kernel reads them
     cands = [1, 2]
     if (kind == "w4a8" and dsc.Cin % 64 == 0) or (kind == "f16" and dsc.x_f16):
         cands.append(4)
@@ -562,8 +564,10 @@ def conv2d_f16(x: torch.Tensor, pf: PackedF16, stride: int = 1, pad: Tuple[int, 
                up2x: bool = False, rowadd: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
                out: Optional[torch.Tensor] = None, y_coff: int = 0, rowadd_ld=None, rowadd_step=None,
                rowadd_step_stride: int = 0, want_stats: bool = False, out_f16: bool = False,
-               t_col0: Optional[int] = None):
-    """x: fp32 NHWC, or fp16 NHWC written as fp16 by its producer (groupnorm(half_out=True), to_half): the fp16 input
+               t_col0: Optional[int] = None, x2: Optional[torch.Tensor] = None):
+    """x2: second fp16 source of a virtual channel concat -- the layer reads cat(x, x2) without the copy (tfmq_conv_desc.x2;
+    `f16_cat_ok` says which launches take it).
+    x: fp32 NHWC, or fp16 NHWC written as fp16 by its producer (groupnorm(half_out=True), to_half): the fp16 input
     takes the LDS-DMA pipeline (Cin % 32 == 0, <= 9 taps).  Un-quantised layers (f16 MFMA, fp32 accumulate).
     out_f16 / t_col0: as conv2d_w4a8 (fp16 rows, channels >= t_col0 transposed into a second tensor: the operands of
     attention_f16 from a fused q|k|v projection); returns (y, yt) when t_col0 is given."""
@@ -572,6 +576,13 @@ def conv2d_f16(x: torch.Tensor, pf: PackedF16, stride: int = 1, pad: Tuple[int, 
         raise TfmqError("conv2d_f16: x must be fp32 or fp16")
     _chk(x, x.dtype, "x")
     B, H, W, cin = x.shape
+    cin1 = cin
+    if x2 is not None:
+        _chk(x2, torch.float16, "x2")
+        if x.dtype != torch.float16 or tuple(x2.shape[:3]) != (B, H, W) or not f16_cat_ok(cin, x2.shape[-1], pf.kh, pf.kw, stride, up2x, pad) \
+                or not out_f16 or rowadd is not None or t_col0 is not None:
+            raise TfmqError("conv2d_f16: x2 needs two fp16 sources of the same pixels, a pointwise layer, channel counts % 32 == 0 and fp16 output")
+        cin = cin1 + x2.shape[-1]
     if cin != pf.cin:
         raise TfmqError(f"conv2d_f16: Cin mismatch {cin} vs {pf.cin}")
     Ho, Wo = out_hw(H, W, pf.kh, pf.kw, stride, pad[0], pad[1], pad[2], pad[3], up2x)
@@ -594,6 +605,9 @@ def conv2d_f16(x: torch.Tensor, pf: PackedF16, stride: int = 1, pad: Tuple[int, 
     dsc.bias = None if pf.bias is None else pf.bias.data_ptr()
     dsc.aq = QSel(None, None, 0, 0)
     dsc.x_f16 = int(x.dtype == torch.float16)
+    if x2 is not None:
+        dsc.x2, dsc.cin1 = x2.data_ptr(), int(cin1)
+        dsc._keep_x2 = x2
     _attach_stats(dsc, y, B, Ho * Wo, pf.cout, want_stats and y_coff == 0 and yt is None)
     rsz = 0.0
     if residual is not None:
@@ -605,6 +619,12 @@ def conv2d_f16(x: torch.Tensor, pf: PackedF16, stride: int = 1, pad: Tuple[int, 
               + B * Ho * Wo * pf.cout * ((2.0 if out_f16 else 4.0) + rsz))
     _profiled_conv("conv2d_f16", "f16", d, dsc, 2.0 * B * Ho * Wo * pf.cout * pf.kh * pf.kw * cin, nbytes)
     return y if yt is None else (y, yt)
+
+
+def f16_cat_ok(c1: int, c2: int, kh: int = 1, kw: int = 1, stride: int = 1, up2x: bool = False, pad=(0, 0, 0, 0)) -> bool:
+    """conv2d_f16(x, ..., x2=...) reads the channel concat of two fp16 tensors without its copy for these launches."""
+    return (kh == 1 and kw == 1 and stride == 1 and not up2x and tuple(pad) == (0, 0, 0, 0) and c1 % 32 == 0 and c2 % 32 == 0
+            and c1 > 0 and c2 > 0 and (c1 + c2) % 8 == 0)
 
 
 def f16_dma_ok(cin: int, kh: int, kw: int) -> bool:
