@@ -366,6 +366,13 @@ int tfmq_im2col(tfmq_handle h, const float* x, float* col, int B, int H, int W, 
                 int pad_t, int pad_l, int Ho, int Wo, void* stream);
 int tfmq_col2im(tfmq_handle h, const float* dcol, float* dx, int B, int H, int W, int C, int KH, int KW, int stride,
                 int pad_t, int pad_l, int Ho, int Wo, void* stream);
+/* fp16 im2col rows for a narrow-input 3x3 (or kh x kw) stride-1 convolution run as a pointwise GEMM: col[m][k] =
+ * fp16(x[b][y + k/C/kw - pad_t][x + (k/C)%kw - pad_l][k%C]) for k < kh*kw*C (zero outside the image), 0 for k in
+ * [kh*kw*C, kp); kp % 8 == 0, kp >= kh*kw*C.  The first conv of the UNets (`conv_in` ddim/models/diffusion.py:310,
+ * `input_blocks.0.0` openaimodel.py:502-506: 3 or 4 input channels) then takes the register-direct fp16 pointwise kernel with
+ * K = kp instead of nine K-steps of 4 live channels out of 32. */
+int tfmq_im2col_f16(tfmq_handle h, const float* x, uint16_t* col, int B, int H, int W, int C, int KH, int KW, int pad_t,
+                    int pad_l, int kp, void* stream);
 /* weights OIHW <-> [cout][(kh,kw,cin)] (dir 0: to the GEMM layout, 1: back) */
 int tfmq_w_relayout(tfmq_handle h, const float* src, float* dst, int cout, int cin, int kh, int kw, int dir, void* stream);
 int tfmq_silu_bwd(tfmq_handle h, const float* x, const float* gy, float* gx, size_t n, void* stream);

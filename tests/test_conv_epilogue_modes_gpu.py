@@ -513,3 +513,34 @@ def test_f16_pointwise_reads_a_virtual_concat(ops, B, T, c1, c2, cout, res):
         ops.conv2d_f16(x1, pf, x2=x2)                       # fp32 output: not a launch of the pointwise kernel
     with pytest.raises(TfmqError):
         ops.conv2d_f16(x1.float(), pf, out_f16=True, x2=x2)  # fp32 first source
+
+
+@pytest.mark.parametrize("B,H,W,cin,cout", [(2, 16, 16, 4, 320), (3, 8, 12, 3, 128), (1, 32, 32, 4, 64), (2, 5, 7, 7, 96)])
+def test_narrow_input_conv_as_im2col_gemm(ops, B, H, W, cin, cout):
+    """The UNet's first conv (conv_in, ddim/models/diffusion.py:310; input_blocks.0.0, openaimodel.py:502-506) in the fp16 stream:
+    tfmq_im2col_f16 rows + the pointwise fp16 kernel.  Same fp16 operand values and fp32 accumulation as the 3x3 tile kernel in
+    another K order: equal to it within fp32 summation noise (<= 2e-6 of the output scale before the fp16 rounding, i.e. at
+    most one fp16 ulp apart), and to torch's conv on the fp16-rounded operands within 1e-3."""
+    gen = torch.Generator().manual_seed(B * H + cin)
+    x = (torch.randn(B, H, W, cin, generator=gen) * 1.1).to(DEV)
+    w = (torch.randn(cout, cin, 3, 3, generator=gen) * 0.2).to(DEV)
+    bias = torch.randn(cout, generator=gen).to(DEV)
+    pf = ops.pack_w_f16(w, bias)
+    g = ops.narrow_conv_as_gemm(pf)
+    assert g is not None and g.cin % 32 == 0 and g.cin >= 9 * cin
+    col = ops.im2col_f16(x, 3, 3, 1, 1, g.cin)
+    # the rows are the zero-padded patches, fp16-rounded, (tap, channel) order
+    xp = torch.nn.functional.pad(x.permute(0, 3, 1, 2), (1, 1, 1, 1))
+    pat = torch.stack([xp[:, :, dy:dy + H, dx:dx + W] for dy in range(3) for dx in range(3)], dim=1)      # [B, 9, C, H, W]
+    ref_col = pat.permute(0, 3, 4, 1, 2).reshape(B, H, W, 9 * cin).half()
+    assert torch.equal(col[..., :9 * cin], ref_col) and not bool(col[..., 9 * cin:].any())
+    y_gemm = ops.conv2d_f16(col, g, out_f16=True, want_stats=True)
+    y_tile = ops.conv2d_f16(x, pf, pad=(1, 1, 1, 1), out_f16=True, want_stats=True)
+    ref = torch.nn.functional.conv2d(x.half().float().permute(0, 3, 1, 2), w.half().float(), bias, padding=1).permute(0, 2, 3, 1)
+    scale = float(ref.abs().max())
+    assert float((y_gemm.float() - ref).abs().max()) <= 1e-3 * scale
+    assert float((y_gemm.float() - y_tile.float()).abs().max()) <= 1.0e-3 * scale       # one fp16 ulp at the output scale
+    assert float((y_gemm.float() - y_tile.float()).abs().mean()) <= 2e-5 * scale        # ... and rarely: most values identical
+    if hasattr(y_tile, "_tfmq_stats"):
+        a, b = y_gemm._tfmq_stats[0], y_tile._tfmq_stats[0]
+        assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max())

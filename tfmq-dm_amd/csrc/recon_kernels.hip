@@ -216,6 +216,41 @@ __global__ __launch_bounds__(256) void k_col2im(const float* __restrict__ dcol, 
   }
 }
 
+// fp16 im2col rows of a narrow-input conv (see tfmq_im2col_f16): one 16-byte piece (8 k-values) per thread
+__global__ __launch_bounds__(256) void k_im2col_h(const float* __restrict__ x, __half* __restrict__ col, unsigned total, int H, int W,
+                                                  int Cc, int KW, int KK, int pad_t, int pad_l, int pieces) {
+  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const unsigned m = i / pieces, pc = i - m * pieces;
+    const int xx = m % W, yy = (m / W) % H;
+    const unsigned b = m / (static_cast<unsigned>(W) * H);
+    __half v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int k = pc * 8 + e;
+      const int tap = k / Cc, ci = k - tap * Cc;
+      const int sy = yy + tap / KW - pad_t, sx = xx + tap % KW - pad_l;
+      float f = 0.0f;
+      if (tap < KK && sy >= 0 && sy < H && sx >= 0 && sx < W) f = x[((static_cast<size_t>(b) * H + sy) * W + sx) * Cc + ci];
+      v[e] = __float2half_rn(f);
+    }
+    *reinterpret_cast<uint4*>(col + static_cast<size_t>(i) * 8) = *reinterpret_cast<const uint4*>(v);
+  }
+}
+
+extern "C" int tfmq_im2col_f16(tfmq_handle h, const float* x, uint16_t* col, int B, int H, int W, int C, int KH, int KW, int pad_t,
+                               int pad_l, int kp, void* stream) {
+  TFMQ_CHECK_ARG(h, h && x && col && B > 0 && H > 0 && W > 0 && C > 0 && KH > 0 && KW > 0, "im2col_f16: bad argument");
+  TFMQ_CHECK_ARG(h, kp % 8 == 0 && kp >= KH * KW * C, "im2col_f16: kp must be a multiple of 8 and hold kh*kw*C values");
+  const long total = static_cast<long>(B) * H * W * (kp / 8);
+  TFMQ_CHECK_ARG(h, total < (1L << 32), "im2col_f16: more than 2^32 pieces");
+  int blocks = ceil_div(total, 256);
+  if (blocks > h->cu_count * 16) blocks = h->cu_count * 16;
+  hipLaunchKernelGGL(k_im2col_h, dim3(blocks), dim3(256), 0, as_stream(stream), x, reinterpret_cast<__half*>(col),
+                     static_cast<unsigned>(total), H, W, C, KW, KH * KW, pad_t, pad_l, kp / 8);
+  TFMQ_LAUNCH_CHECK(h);
+  return TFMQ_OK;
+}
+
 extern "C" int tfmq_col2im(tfmq_handle h, const float* dcol, float* dx, int B, int H, int W, int C, int KH, int KW,
                            int stride, int pad_t, int pad_l, int Ho, int Wo, void* stream) {
   TFMQ_CHECK_ARG(h, h && dcol && dx && B > 0 && H > 0 && W > 0 && C > 0, "col2im: bad argument");

@@ -46,6 +46,19 @@ class _Layer:
         kw.setdefault("want_stats", True)   # conv-epilogue GroupNorm statistics (K8 split form)
         if self.kind == "w4a8":
             return ops.conv2d_w4a8(x, self.p, self.aq, **kw)
+        if (x.dtype == torch.float32 and kw.get("out_f16") and self.p.kh * self.p.kw > 1 and self.p.kh * self.p.kw * self.p.cin <= 64
+                and kw.get("pad") == (self.p.kh // 2, self.p.kw // 2, self.p.kh // 2, self.p.kw // 2) and kw.get("stride", 1) == 1
+                and not kw.get("up2x") and kw.get("rowadd") is None and kw.get("out") is None
+                and os.environ.get("TFMQ_NARROW_CONV_GEMM", "1") != "0"):
+            # the UNet's first conv (3 / 4 input channels) in the fp16 stream: fp16 im2col rows (kh*kw*cin values padded to 32 / 64)
+            # + the register-direct pointwise kernel, instead of nine K-steps with 4 live channels of 32 on the tile kernel
+            g = getattr(self, "_gemm", None)
+            if g is None:
+                g = self._gemm = ops.narrow_conv_as_gemm(self.p) or False
+            if g:
+                col = ops.im2col_f16(x, self.p.kh, self.p.kw, self.p.kh // 2, self.p.kw // 2, g.cin)
+                kw2 = {k: v for k, v in kw.items() if k not in ("pad", "stride", "up2x")}
+                return ops.conv2d_f16(col, g, **kw2)
         if x.dtype == torch.float32 and ops.f16_dma_ok(self.p.cin, self.p.kh, self.p.kw):
             # un-quantised / weight-only layers round their input to fp16 while staging anyway: one conversion pass and
             # the LDS-DMA pipeline beat the register-staged fp32-input kernel ~3x (FP / weight-only state: the

@@ -1045,6 +1045,30 @@ def im2col(x: torch.Tensor, kh: int, kw: int, stride: int = 1, pad=(0, 0, 0, 0))
     return col
 
 
+def im2col_f16(x: torch.Tensor, kh: int, kw: int, pad_t: int, pad_l: int, kp: int) -> torch.Tensor:
+    """fp32 NHWC -> fp16 [B, H, W, kp] rows of (tap, channel) values, zero beyond kh*kw*C and outside the image (stride 1,
+    output size = input size): the A operand of a narrow-input conv run as a pointwise GEMM (tfmq_im2col_f16)."""
+    d = _dev(x)
+    _chk(x, torch.float32, "x")
+    B, H, W, Cc = x.shape
+    col = _alloc(B, H, W, kp, dtype=torch.float16, device=x.device)
+    handle(d).call("im2col_f16", _p(x), _p(col), B, H, W, Cc, kh, kw, pad_t, pad_l, kp, _stream(d))
+    return col
+
+
+def narrow_conv_as_gemm(pf: PackedF16) -> Optional[PackedF16]:
+    """The pointwise layer that computes a narrow-input conv from im2col_f16 rows: weights [cout][(tap, ci)] zero-padded to a
+    multiple of 32 values -- the same fp16 weight values, the same fp32 accumulation, another K order.  None if the layer is not
+    a narrow-input conv (kh*kw*cin <= 64, more than one tap)."""
+    kk = pf.kh * pf.kw
+    if kk == 1 or kk * pf.cin > 64 or pf.cout % 8:
+        return None
+    kp = (kk * pf.cin + 31) // 32 * 32
+    w = torch.zeros(pf.cout, 1, kp, dtype=torch.float16, device=pf.w16.device)
+    w[:, 0, :kk * pf.cin] = pf.w16[:, :, :pf.cin].reshape(pf.cout, kk * pf.cin)
+    return PackedF16(w.contiguous(), pf.bias, pf.cout, kp, 1, 1, wscale=pf.wscale)
+
+
 def col2im(dcol: torch.Tensor, shape, kh: int, kw: int, stride: int = 1, pad=(0, 0, 0, 0)) -> torch.Tensor:
     d = _dev(dcol)
     B, H, W, Cc = shape
