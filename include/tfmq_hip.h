@@ -373,6 +373,12 @@ int tfmq_col2im(tfmq_handle h, const float* dcol, float* dx, int B, int H, int W
  * K = kp instead of nine K-steps of 4 live channels out of 32. */
 int tfmq_im2col_f16(tfmq_handle h, const float* x, uint16_t* col, int B, int H, int W, int C, int KH, int KW, int pad_t,
                     int pad_l, int kp, void* stream);
+/* The other end: a conv with a handful of output channels (`conv_out` ddim/models/diffusion.py:353, `out.2` openaimodel.py:700-704:
+ * 320 -> 4) computed as ONE pointwise GEMM to kh*kw*cout per-tap partial sums, y9[m][tap*cout + co] = sum_ci x[m][ci] w[co][tap][ci]
+ * (fp32), and this gather: out[b][y][x][co] = bias[co] + sum_tap y9[b][y + tap/kw - pad_t][x + tap%kw - pad_l][tap*cout + co], taps
+ * in ascending order, positions outside the image skipped.  The input is read once instead of once per tap. */
+int tfmq_tap_gather_sum(tfmq_handle h, const float* y9, int B, int H, int W, int KH, int KW, int cout, int ld, int pad_t, int pad_l,
+                        const float* bias, float* out, void* stream);
 /* weights OIHW <-> [cout][(kh,kw,cin)] (dir 0: to the GEMM layout, 1: back) */
 int tfmq_w_relayout(tfmq_handle h, const float* src, float* dst, int cout, int cin, int kh, int kw, int dir, void* stream);
 int tfmq_silu_bwd(tfmq_handle h, const float* x, const float* gy, float* gx, size_t n, void* stream);

@@ -544,3 +544,32 @@ def test_narrow_input_conv_as_im2col_gemm(ops, B, H, W, cin, cout):
     if hasattr(y_tile, "_tfmq_stats"):
         a, b = y_gemm._tfmq_stats[0], y_tile._tfmq_stats[0]
         assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max())
+
+
+@pytest.mark.parametrize("B,H,W,cin,cout", [(2, 16, 16, 320, 4), (3, 8, 12, 128, 3), (1, 32, 32, 64, 4), (2, 5, 7, 96, 1)])
+def test_narrow_output_conv_as_gemm_plus_tap_gather(ops, B, H, W, cin, cout):
+    """The UNet's last conv (conv_out, ddim/models/diffusion.py:353; out.2, openaimodel.py:700-704): one pointwise fp16 GEMM to the
+    kh*kw*cout per-tap partial sums (fp32) + tfmq_tap_gather_sum.  Same fp16 operands, fp32 accumulation per tap, taps added in
+    ascending order: equal to the 3x3 tile kernel within fp32 summation noise and to torch's conv on the rounded operands."""
+    gen = torch.Generator().manual_seed(B * W + cin)
+    x = (torch.randn(B, H, W, cin, generator=gen) * 0.9).to(DEV).half()
+    w = (torch.randn(cout, cin, 3, 3, generator=gen) * 0.05).to(DEV)
+    bias = torch.randn(cout, generator=gen).to(DEV)
+    pf = ops.pack_w_f16(w, bias)
+    g = ops.narrow_out_conv_as_gemm(pf)
+    assert g is not None and g.cout % 8 == 0 and g.cout >= 9 * cout
+    y9 = ops.conv2d_f16(x, g)
+    got = ops.tap_gather_sum(y9, 3, 3, cout, 1, 1, pf.bias)
+    tile = ops.conv2d_f16(x, pf, pad=(1, 1, 1, 1))
+    ref = torch.nn.functional.conv2d(x.float().permute(0, 3, 1, 2), w.half().float(), bias, padding=1).permute(0, 2, 3, 1)
+    scale = float(ref.abs().max())
+    assert float((got - ref).abs().max()) <= 2e-5 * scale
+    assert float((got - tile).abs().max()) <= 2e-5 * scale
+    # the gather itself, on arbitrary partial sums, against a plain restatement
+    y = torch.randn(B, H, W, g.cout, generator=gen).to(DEV)
+    yp = torch.nn.functional.pad(y.permute(0, 3, 1, 2), (1, 1, 1, 1))
+    want = bias.view(1, 1, 1, cout).expand(B, H, W, cout).clone()
+    for tap in range(9):
+        dy, dx = tap // 3, tap % 3
+        want = want + yp[:, tap * cout:(tap + 1) * cout, dy:dy + H, dx:dx + W].permute(0, 2, 3, 1)
+    assert torch.equal(ops.tap_gather_sum(y, 3, 3, cout, 1, 1, bias), want)

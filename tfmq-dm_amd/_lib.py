@@ -116,6 +116,7 @@ _SIGS = {
     "tfmq_im2col": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 11 + [c_void_p]),
     "tfmq_col2im": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 11 + [c_void_p]),
     "tfmq_im2col_f16": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 9 + [c_void_p]),
+    "tfmq_tap_gather_sum": (c_int, [c_void_p, c_void_p] + [c_int] * 9 + [c_void_p, c_void_p, c_void_p]),
     "tfmq_w_relayout": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "tfmq_layernorm_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, C.c_long, c_int, c_void_p, c_void_p]),
     "tfmq_geglu_bwd": (c_int, [c_void_p, c_void_p, c_void_p, C.c_long, c_int, c_void_p, c_void_p]),

@@ -251,6 +251,50 @@ extern "C" int tfmq_im2col_f16(tfmq_handle h, const float* x, uint16_t* col, int
   return TFMQ_OK;
 }
 
+// per-tap partial sums -> the few output channels of a narrow-output conv (see tfmq_tap_gather_sum); one pixel per thread
+template <int CO>
+__global__ __launch_bounds__(256) void k_tap_gather(const float* __restrict__ y9, unsigned total, int H, int W, int KH, int KW, int ld,
+                                                    int pad_t, int pad_l, const float* __restrict__ bias, float* __restrict__ out) {
+  for (unsigned m = blockIdx.x * blockDim.x + threadIdx.x; m < total; m += gridDim.x * blockDim.x) {
+    const int xx = m % W, yy = (m / W) % H;
+    float acc[CO];
+#pragma unroll
+    for (int c = 0; c < CO; ++c) acc[c] = bias ? bias[c] : 0.0f;
+    for (int tap = 0; tap < KH * KW; ++tap) {
+      const int dy = tap / KW - pad_t, dx = tap % KW - pad_l;
+      const int sy = yy + dy, sx = xx + dx;
+      if (sy < 0 || sy >= H || sx < 0 || sx >= W) continue;
+      const float* src = y9 + (static_cast<size_t>(m) + static_cast<long>(dy) * W + dx) * ld + tap * CO;
+      if constexpr (CO == 4) {
+        const float4 v = *reinterpret_cast<const float4*>(src);
+        acc[0] += v.x; acc[1] += v.y; acc[2] += v.z; acc[3] += v.w;
+      } else {
+#pragma unroll
+        for (int c = 0; c < CO; ++c) acc[c] += src[c];
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < CO; ++c) out[static_cast<size_t>(m) * CO + c] = acc[c];
+  }
+}
+
+extern "C" int tfmq_tap_gather_sum(tfmq_handle h, const float* y9, int B, int H, int W, int KH, int KW, int cout, int ld, int pad_t,
+                                   int pad_l, const float* bias, float* out, void* stream) {
+  TFMQ_CHECK_ARG(h, h && y9 && out && B > 0 && H > 0 && W > 0 && KH > 0 && KW > 0, "tap_gather_sum: bad argument");
+  TFMQ_CHECK_ARG(h, cout >= 1 && cout <= 4 && ld >= KH * KW * cout && (cout != 4 || ld % 4 == 0), "tap_gather_sum: 1..4 output channels, ld >= kh*kw*cout");
+  const long total = static_cast<long>(B) * H * W;
+  TFMQ_CHECK_ARG(h, total < (1L << 31), "tap_gather_sum: too many pixels");
+  int blocks = ceil_div(total, 256);
+  if (blocks > h->cu_count * 16) blocks = h->cu_count * 16;
+  const unsigned t = static_cast<unsigned>(total);
+  if (cout == 4) hipLaunchKernelGGL(k_tap_gather<4>, dim3(blocks), dim3(256), 0, as_stream(stream), y9, t, H, W, KH, KW, ld, pad_t, pad_l, bias, out);
+  else if (cout == 3) hipLaunchKernelGGL(k_tap_gather<3>, dim3(blocks), dim3(256), 0, as_stream(stream), y9, t, H, W, KH, KW, ld, pad_t, pad_l, bias, out);
+  else if (cout == 2) hipLaunchKernelGGL(k_tap_gather<2>, dim3(blocks), dim3(256), 0, as_stream(stream), y9, t, H, W, KH, KW, ld, pad_t, pad_l, bias, out);
+  else hipLaunchKernelGGL(k_tap_gather<1>, dim3(blocks), dim3(256), 0, as_stream(stream), y9, t, H, W, KH, KW, ld, pad_t, pad_l, bias, out);
+  TFMQ_LAUNCH_CHECK(h);
+  return TFMQ_OK;
+}
+
 extern "C" int tfmq_col2im(tfmq_handle h, const float* dcol, float* dx, int B, int H, int W, int C, int KH, int KW,
                            int stride, int pad_t, int pad_l, int Ho, int Wo, void* stream) {
   TFMQ_CHECK_ARG(h, h && dcol && dx && B > 0 && H > 0 && W > 0 && C > 0, "col2im: bad argument");

@@ -59,6 +59,18 @@ class _Layer:
                 col = ops.im2col_f16(x, self.p.kh, self.p.kw, self.p.kh // 2, self.p.kw // 2, g.cin)
                 kw2 = {k: v for k, v in kw.items() if k not in ("pad", "stride", "up2x")}
                 return ops.conv2d_f16(col, g, **kw2)
+        if (x.dtype == torch.float16 and self.p.cout <= 4 and self.p.kh * self.p.kw > 1 and not kw.get("out_f16")
+                and kw.get("pad") == (self.p.kh // 2, self.p.kw // 2, self.p.kh // 2, self.p.kw // 2) and kw.get("stride", 1) == 1
+                and not kw.get("up2x") and kw.get("rowadd") is None and kw.get("residual") is None and kw.get("out") is None
+                and os.environ.get("TFMQ_NARROW_CONV_GEMM", "1") != "0"):
+            # the UNet's last conv (a few output channels): one pointwise GEMM to the per-tap partial sums + a gather over the taps;
+            # the tile kernel re-reads the input per tap (PMC: 4x its bytes from HBM)
+            g = getattr(self, "_gemm_out", None)
+            if g is None:
+                g = self._gemm_out = ops.narrow_out_conv_as_gemm(self.p) or False
+            if g:
+                y9 = ops.conv2d_f16(x, g, want_stats=False)
+                return ops.tap_gather_sum(y9, self.p.kh, self.p.kw, self.p.cout, self.p.kh // 2, self.p.kw // 2, self.p.bias)
         if x.dtype == torch.float32 and ops.f16_dma_ok(self.p.cin, self.p.kh, self.p.kw):
             # un-quantised / weight-only layers round their input to fp16 while staging anyway: one conversion pass and
             # the LDS-DMA pipeline beat the register-staged fp32-input kernel ~3x (FP / weight-only state: the

@@ -1069,6 +1069,35 @@ def narrow_conv_as_gemm(pf: PackedF16) -> Optional[PackedF16]:
     return PackedF16(w.contiguous(), pf.bias, pf.cout, kp, 1, 1, wscale=pf.wscale)
 
 
+def narrow_out_conv_as_gemm(pf: PackedF16) -> Optional[PackedF16]:
+    """The pointwise layer whose kh*kw*cout outputs are the per-tap partial sums of a conv with a handful of output channels
+    (conv_out, out.2: 320 -> 4): row tap*cout + co holds w[co][tap][:].  None if the layer is not one (cout <= 4, more than one tap,
+    fp16-input shape).  No bias (tap_gather_sum adds it)."""
+    kk = pf.kh * pf.kw
+    if kk == 1 or pf.cout > 4 or not f16_dma_ok(pf.cin, 1, 1):
+        return None
+    n9 = kk * pf.cout
+    n9p = (n9 + 7) // 8 * 8
+    cin_pad = pf.w16.shape[-1]
+    w = torch.zeros(n9p, 1, cin_pad, dtype=torch.float16, device=pf.w16.device)
+    w[:n9, 0] = pf.w16.permute(1, 0, 2).reshape(n9, cin_pad)
+    ws = None
+    if pf.wscale is not None:
+        ws = torch.ones(n9p, dtype=torch.float32, device=pf.w16.device)
+        ws[:n9] = pf.wscale.reshape(1, pf.cout).repeat(kk, 1).reshape(-1)
+    return PackedF16(w.contiguous(), None, n9p, pf.cin, 1, 1, wscale=ws)
+
+
+def tap_gather_sum(y9: torch.Tensor, kh: int, kw: int, cout: int, pad_t: int, pad_l: int, bias: Optional[torch.Tensor]) -> torch.Tensor:
+    """y9 fp32 [B, H, W, ld] per-tap partial sums -> fp32 [B, H, W, cout] (tfmq_tap_gather_sum)."""
+    d = _dev(y9)
+    _chk(y9, torch.float32, "y9")
+    B, H, W, ld = y9.shape
+    out = _alloc(B, H, W, cout, dtype=torch.float32, device=y9.device)
+    handle(d).call("tap_gather_sum", _p(y9), B, H, W, kh, kw, cout, ld, pad_t, pad_l, _p(bias), _p(out), _stream(d))
+    return out
+
+
 def col2im(dcol: torch.Tensor, shape, kh: int, kw: int, stride: int = 1, pad=(0, 0, 0, 0)) -> torch.Tensor:
     d = _dev(dcol)
     B, H, W, Cc = shape
