@@ -573,3 +573,46 @@ def test_narrow_output_conv_as_gemm_plus_tap_gather(ops, B, H, W, cin, cout):
         dy, dx = tap // 3, tap % 3
         want = want + yp[:, tap * cout:(tap + 1) * cout, dy:dy + H, dx:dx + W].permute(0, 2, 3, 1)
     assert torch.equal(ops.tap_gather_sum(y, 3, 3, cout, 1, 1, bias), want)
+
+
+@pytest.mark.parametrize("B,H,W,cin,cout,res,o16,up", [(2, 16, 16, 64, 320, False, True, False), (4, 8, 8, 96, 128, True, True, False),
+                                                      (1, 32, 32, 32, 64, False, False, False), (2, 16, 16, 64, 640, True, False, False),
+                                                      (2, 8, 8, 64, 320, False, True, True)])
+def test_f16_slab_kernel_vs_tile_kernel(ops, B, H, W, cin, cout, res, o16, up):
+    """The 3x3 slab kernel on fp16 operands (un-quantised / weight-only layers: the first ResBlock conv of the SD UNet, every 3x3
+    conv of the FP passes that generate and capture calibration data).  Same fp16 operand values and fp32 accumulation as the
+    tile kernel in (channel chunk, tap) instead of (tap, channel chunk) order: equal within fp32 summation noise; GroupNorm
+    statistics, fp16 residual, fp16 / fp32 output, fused nearest-2x upsample."""
+    import tfmq_dm_amd.ops as _o
+    gen = torch.Generator().manual_seed(H * W + cin + cout)
+    x = (torch.randn(B, H, W, cin, generator=gen) * 0.8).to(DEV).half()
+    w = (torch.randn(cout, cin, 3, 3, generator=gen) * (1.5 / (9 * cin) ** 0.5)).to(DEV)
+    bias = torch.randn(cout, generator=gen).to(DEV)
+    pf = ops.pack_w_f16(w, bias)
+    Ho, Wo = (2 * H, 2 * W) if up else (H, W)
+    kw = dict(pad=(1, 1, 1, 1), out_f16=o16, want_stats=True, up2x=up)
+    if res:
+        kw["residual"] = torch.randn(B, Ho, Wo, cout, generator=gen).to(DEV).half()
+    outs = {}
+    for tile in (1, 5):
+        ops.set_conv_autotune({})
+        orig = _o._tune_conv
+        try:
+            _o._tune_conv = lambda h, name, kind, d, dsc, t=tile: t
+            outs[tile] = ops.conv2d_f16(x, pf, **kw)
+        finally:
+            _o._tune_conv = orig
+            ops.set_conv_autotune(None)
+    xin = x.float().permute(0, 3, 1, 2)
+    if up:
+        xin = torch.nn.functional.interpolate(xin, scale_factor=2, mode="nearest")
+    ref = torch.nn.functional.conv2d(xin, w.half().float(), bias, padding=1).permute(0, 2, 3, 1)
+    if res:
+        ref = ref + kw["residual"].float()
+    scale = float(ref.abs().max())
+    a, b = outs[5].float(), outs[1].float()
+    tol = 1.0e-3 if o16 else 2e-6          # one fp16 ulp at the output scale / fp32 summation noise
+    assert float((a - ref).abs().max()) <= (1.5e-3 if o16 else 2e-5) * scale
+    assert float((a - b).abs().max()) <= tol * scale
+    sa, sb = outs[5]._tfmq_stats[0], outs[1]._tfmq_stats[0]
+    assert float((sa - sb).abs().max()) <= 1e-5 * float(sb.abs().max())

@@ -1036,6 +1036,13 @@ static int launch_conv(tfmq_handle h, const tfmq_conv_desc* dd, void* stream) {
       TFMQ_LAUNCH_CHECK(h);
       return TFMQ_OK;
     }
+  } else {
+    // the same kernel on fp16 operands (un-quantised / weight-only 3x3 layers, fp16 input)
+    if ((d.tile == TFMQ_TILE_AUTO || d.tile == TFMQ_TILE_SLAB) && dma16 && !d.x2 &&
+        launch_conv_slab(h, p, as_stream(stream), d.tile == TFMQ_TILE_SLAB, true)) {
+      TFMQ_LAUNCH_CHECK(h);
+      return TFMQ_OK;
+    }
   }
   TFMQ_CHECK_ARG(h, (!d.res_f16 && (d.out_mode != TFMQ_OUT_F16 || (!d.rowadd && !d.residual && !d.stats))) ||
                         (((d.Cout | d.ldy | d.y_coff) & 3) == 0 && (!d.rowadd || (d.rowadd_ld & 3) == 0)),

@@ -52,7 +52,10 @@ __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int WN>
+// F16OP: the un-quantised / weight-only 3x3 layers on the same pipeline -- fp16 activations (a 64-byte slab row = 32 channels), fp16
+// weights [cout][tap][cin_pad] row-major (tfmq_pack_w_f16), v_mfma_f32_32x32x16_f16, value = scale * acc + bias (k_conv_dma<true>'s
+// arithmetic; the K order differs from its tap-major one, so the two agree to fp32 summation noise, not bit for bit).
+template <int WN, bool F16OP = false>
 __global__ __launch_bounds__(512) void k_conv3_slab(SlabP sp) {
   constexpr int BM = 256, BN = 64 * WN;
   constexpr int BST = BN * 64;                 // bytes of one weight K-step stage
@@ -72,7 +75,9 @@ __global__ __launch_bounds__(512) void k_conv3_slab(SlabP sp) {
   const int ups = d.up2x ? 1 : 0;
 
   SLAB_MARK(0);
-  const float2 aqp = load_qparam(d.aq);
+  float2 aqp = make_float2(1.0f, 128.0f);
+  if constexpr (!F16OP) aqp = load_qparam(d.aq);
+  constexpr int EB = F16OP ? 2 : 1;              // bytes per activation element
 
   // ---- slab geometry of this tile
   const int b0 = m0 / sp.HW;
@@ -110,11 +115,11 @@ __global__ __launch_bounds__(512) void k_conv3_slab(SlabP sp) {
     s_off[it] = off;
   }
   const int za = static_cast<int>(aqp.y);
-  const unsigned char* padp = p.pad_table + (static_cast<unsigned>(za - 128) & 0xffu) * 64 + dcol;
+  const unsigned char* padp = p.pad_table + (F16OP ? 0u : (static_cast<unsigned>(za - 128) & 0xffu)) * 64 + dcol;   // fp16: the zero row
   const unsigned lds0 = static_cast<unsigned>(reinterpret_cast<uintptr_t>(lds));
 
   auto issue_slab = [&](int it, int c, int buf) {
-    const unsigned char* src = s_off[it] >= 0 ? xb + static_cast<size_t>(static_cast<unsigned>(s_off[it])) + c * 64 + dcol : padp;
+    const unsigned char* src = s_off[it] >= 0 ? xb + static_cast<size_t>(static_cast<unsigned>(s_off[it])) * EB + c * 64 + dcol : padp;
     glds16(src, lds0 + buf * SLAB_BYTES + __builtin_amdgcn_readfirstlane((it * 8 + wid) * 1024));
   };
 
@@ -124,8 +129,13 @@ __global__ __launch_bounds__(512) void k_conv3_slab(SlabP sp) {
   for (int k = 0; k < 3; ++k) {
     const int piece = wid + 8 * k;
     int n = n0 + piece * 16 + (lane >> 2);
-    n = n < p.cout_pad ? n : p.cout_pad - 1;
-    b_ptr[k] = static_cast<const unsigned char*>(d.w) + (static_cast<size_t>(n / 32) * p.nsteps * 32 + (n % 32)) * 64 + dcol;
+    if constexpr (F16OP) {
+      n = n < d.Cout ? n : d.Cout - 1;
+      b_ptr[k] = static_cast<const unsigned char*>(d.w) + static_cast<size_t>(n) * 9 * p.cin_pad * 2 + dcol;
+    } else {
+      n = n < p.cout_pad ? n : p.cout_pad - 1;
+      b_ptr[k] = static_cast<const unsigned char*>(d.w) + (static_cast<size_t>(n / 32) * p.nsteps * 32 + (n % 32)) * 64 + dcol;
+    }
   }
 
   // fragment read offsets
@@ -149,7 +159,7 @@ __global__ __launch_bounds__(512) void k_conv3_slab(SlabP sp) {
   auto kloop = [&](auto bch_tag) {
     constexpr int B_CH = decltype(bch_tag)::value;
     auto issue_b = [&](int c, int tap, int stage) {
-      const size_t boff = static_cast<size_t>(tap * p.chunks + c) * 2048;
+      const size_t boff = F16OP ? static_cast<size_t>(tap * p.cin_pad + c * 32) * 2 : static_cast<size_t>(tap * p.chunks + c) * 2048;
 #pragma unroll
       for (int k = 0; k < B_CH; ++k)
         glds16(b_ptr[k] + boff, lds0 + BOFF + stage * BST + __builtin_amdgcn_readfirstlane((wid + 8 * k) * 1024));
@@ -192,7 +202,16 @@ __global__ __launch_bounds__(512) void k_conv3_slab(SlabP sp) {
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-          for (int j = 0; j < WN; ++j) acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(bf[j], af[i], acc[i][j], 0, 0, 0);      // (channels x pixels): lane = pixel
+          for (int j = 0; j < WN; ++j) {
+            if constexpr (F16OP) {
+              typedef _Float16 v8h_t __attribute__((ext_vector_type(8)));
+              typedef float v16f_t __attribute__((ext_vector_type(16)));
+              v16f_t& af32 = *reinterpret_cast<v16f_t*>(&acc[i][j]);
+              af32 = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<v8h_t*>(&bf[j]), *reinterpret_cast<v8h_t*>(&af[i]), af32, 0, 0, 0);
+            } else {
+              acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(bf[j], af[i], acc[i][j], 0, 0, 0);      // (channels x pixels): lane = pixel
+            }
+          }
         // the DMA issue of the next K-steps (SALU M0 moves + VMEM, ~100 clk a piece) sits behind the first half's MFMAs:
         // the matrix pipe works through them while the wave issues the loads, instead of idling right after the barrier
         if (ks == 0) issue_next();
@@ -242,9 +261,13 @@ __global__ __launch_bounds__(512) void k_conv3_slab(SlabP sp) {
     float c_sc = 1.0f, c_bias = 0.0f;
     int c_corr = 0;
     if (n < d.Cout) {
-      const int4 wmv = reinterpret_cast<const int4*>(d.wmeta)[n];
-      c_corr = (128 - za) * (wmv.y - p.Ktot * wmv.x);
-      c_sc = aqp.x * d.wscale[n];
+      if constexpr (F16OP) {
+        c_sc = d.wscale ? d.wscale[n] : 1.0f;
+      } else {
+        const int4 wmv = reinterpret_cast<const int4*>(d.wmeta)[n];
+        c_corr = (128 - za) * (wmv.y - p.Ktot * wmv.x);
+        c_sc = aqp.x * d.wscale[n];
+      }
       c_bias = d.bias ? d.bias[n] : 0.0f;
     }
     cs[tid] = c_sc;
@@ -295,8 +318,13 @@ __global__ __launch_bounds__(512) void k_conv3_slab(SlabP sp) {
         const int4 kc = *reinterpret_cast<const int4*>(reinterpret_cast<const int*>(cs) + BN + ct + 4 * e);
         const float4 bb = *reinterpret_cast<const float4*>(cs + 2 * BN + ct + 4 * e);
         const v16i& a = acc[i][j];
-        v[2 * e] = f2{sc.x, sc.y} * f2{static_cast<float>(a[8 * u + 4 * e] + kc.x), static_cast<float>(a[8 * u + 4 * e + 1] + kc.y)} + f2{bb.x, bb.y};
-        v[2 * e + 1] = f2{sc.z, sc.w} * f2{static_cast<float>(a[8 * u + 4 * e + 2] + kc.z), static_cast<float>(a[8 * u + 4 * e + 3] + kc.w)} + f2{bb.z, bb.w};
+        if constexpr (F16OP) {
+          v[2 * e] = f2{sc.x, sc.y} * f2{__int_as_float(a[8 * u + 4 * e]), __int_as_float(a[8 * u + 4 * e + 1])} + f2{bb.x, bb.y};
+          v[2 * e + 1] = f2{sc.z, sc.w} * f2{__int_as_float(a[8 * u + 4 * e + 2]), __int_as_float(a[8 * u + 4 * e + 3])} + f2{bb.z, bb.w};
+        } else {
+          v[2 * e] = f2{sc.x, sc.y} * f2{static_cast<float>(a[8 * u + 4 * e] + kc.x), static_cast<float>(a[8 * u + 4 * e + 1] + kc.y)} + f2{bb.x, bb.y};
+          v[2 * e + 1] = f2{sc.z, sc.w} * f2{static_cast<float>(a[8 * u + 4 * e + 2] + kc.z), static_cast<float>(a[8 * u + 4 * e + 3] + kc.w)} + f2{bb.z, bb.w};
+        }
         if (rowadd) {
           const float4 ra = *reinterpret_cast<const float4*>(cs + (3 + im) * BN + ct + 4 * e);
           v[2 * e] += f2{ra.x, ra.y};
@@ -368,11 +396,12 @@ __global__ __launch_bounds__(512) void k_conv3_slab(SlabP sp) {
 
 }  // namespace
 
-bool launch_conv_slab(tfmq_handle h, ConvP& p, hipStream_t st, bool forced) {
+bool launch_conv_slab(tfmq_handle h, ConvP& p, hipStream_t st, bool forced, bool f16) {
   const tfmq_conv_desc& d = p.d;
   const int Hv = d.up2x ? 2 * d.H : d.H, Wv = d.up2x ? 2 * d.W : d.W;
   if (d.KH != 3 || d.KW != 3 || d.stride != 1 || d.pad_t != 1 || d.pad_l != 1 || d.Ho != Hv || d.Wo != Wv || p.Hv != Hv || p.Wv != Wv) return false;
-  if (d.Cin % 64 != 0 || static_cast<size_t>(d.B) * d.H * d.W * d.Cin >= (static_cast<size_t>(1) << 31)) return false;
+  if (d.Cin % (f16 ? 32 : 64) != 0 || static_cast<size_t>(d.B) * d.H * d.W * d.Cin * (f16 ? 2 : 1) >= (static_cast<size_t>(1) << 31)) return false;
+  if (f16 && (!d.x_f16 || p.cin_pad != d.Cin || p.chunks != d.Cin / 32 || d.out_mode == TFMQ_OUT_Q8)) return false;
   if (!(d.out_mode == TFMQ_OUT_F32 || d.out_mode == TFMQ_OUT_Q8 || (d.out_mode == TFMQ_OUT_F16 && !d.yt))) return false;
   if (((d.Cout | d.ldy | d.y_coff) & 7) != 0) return false;             // a lane moves whole 8-channel octets
   if (d.stats && 256 % d.stats_seg != 0) return false;
@@ -404,7 +433,11 @@ bool launch_conv_slab(tfmq_handle h, ConvP& p, hipStream_t st, bool forced) {
   if (!dbuf) (void)hipMalloc(reinterpret_cast<void**>(&dbuf), sizeof(unsigned long long) * 4 * (1u << 16));
   sp.p.dbg = grid.x <= (1u << 16) ? dbuf : nullptr;
 #endif
-  if (WN == 5) hipLaunchKernelGGL((k_conv3_slab<5>), grid, dim3(512), 0, st, sp);
+  if (f16) {
+    if (WN == 5) hipLaunchKernelGGL((k_conv3_slab<5, true>), grid, dim3(512), 0, st, sp);
+    else if (WN == 4) hipLaunchKernelGGL((k_conv3_slab<4, true>), grid, dim3(512), 0, st, sp);
+    else hipLaunchKernelGGL((k_conv3_slab<2, true>), grid, dim3(512), 0, st, sp);
+  } else if (WN == 5) hipLaunchKernelGGL((k_conv3_slab<5>), grid, dim3(512), 0, st, sp);
   else if (WN == 4) hipLaunchKernelGGL((k_conv3_slab<4>), grid, dim3(512), 0, st, sp);
   else hipLaunchKernelGGL((k_conv3_slab<2>), grid, dim3(512), 0, st, sp);
 #ifdef TFMQ_PHASE_TIMERS

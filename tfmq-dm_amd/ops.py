@@ -388,8 +388,10 @@ def slab_ok(dsc) -> bool:
     """Launch geometry the 3x3 slab kernel (csrc/conv_slab.hip, TFMQ_TILE_SLAB) takes: 3x3 / stride 1 / pad 1, Cin % 64 == 0,
     256-pixel tiles made of whole image rows (or whole images), a slab of at most 512 pixel rows."""
     hv, wv = (2 * dsc.H, 2 * dsc.W) if dsc.up2x else (dsc.H, dsc.W)      # the fused nearest-2x upsample stages upsampled rows
+    f16 = bool(dsc.x_f16)              # the fp16-operand form: 32 channels per 64-byte slab row, no int8 output
     if not (dsc.KH == 3 and dsc.KW == 3 and dsc.stride == 1 and dsc.pad_t == 1 and dsc.pad_l == 1
-            and dsc.Cin % 64 == 0 and dsc.Ho == hv and dsc.Wo == wv and not dsc.yt and dsc.out_mode in (0, 1, 3)):
+            and dsc.Cin % (32 if f16 else 64) == 0 and dsc.Ho == hv and dsc.Wo == wv and not dsc.yt
+            and dsc.out_mode in ((0, 1) if f16 else (0, 1, 3)) and dsc.Cout % 8 == 0):
         return False
     hw = hv * wv
     if hw % 256 == 0 and 256 % wv == 0:
@@ -416,7 +418,7 @@ def _tune_conv(h, name, kind, d, dsc):
         cands.append(4)
         if dsc.stride == 1 and not dsc.up2x:
             cands.append(3)
-    if kind == "w4a8" and slab_ok(dsc):
+    if (kind == "w4a8" or (kind == "f16" and dsc.x_f16)) and slab_ok(dsc):
         cands.append(5)
     if (kind == "w4a8" and dsc.KH == 1 and dsc.KW == 1 and dsc.stride == 1 and not dsc.up2x and dsc.Cin % 64 == 0 and dsc.Cout % 4 == 0
             and dsc.out_mode in (1, 2, 3) and not dsc.rowadd and not (dsc.stats and dsc.out_mode != 1) and not (dsc.yt and dsc.residual)):
