@@ -413,12 +413,14 @@ def _tune_conv(h, name, kind, d, dsc):
         return 0                      # cannot time inside a capture / nothing to choose / not idempotent
     if kind == "f16" and dsc.x2:
         return 6                      # two sources: only the register-direct pointwise kernel reads them
+    if kind == "f16" and dsc.x_f16 and slab_ok(dsc):
+        return 5                      # fp16 3x3: the slab kernel's K order differs from the tile kernels' -- one rule for every batch size
     cands = [1, 2]
     if (kind == "w4a8" and dsc.Cin % 64 == 0) or (kind == "f16" and dsc.x_f16):
         cands.append(4)
         if dsc.stride == 1 and not dsc.up2x:
             cands.append(3)
-    if (kind == "w4a8" or (kind == "f16" and dsc.x_f16)) and slab_ok(dsc):
+    if kind == "w4a8" and slab_ok(dsc):
         cands.append(5)
     if (kind == "w4a8" and dsc.KH == 1 and dsc.KW == 1 and dsc.stride == 1 and not dsc.up2x and dsc.Cin % 64 == 0 and dsc.Cout % 4 == 0
             and dsc.out_mode in (1, 2, 3) and not dsc.rowadd and not (dsc.stats and dsc.out_mode != 1) and not (dsc.yt and dsc.residual)):
