@@ -1,5 +1,5 @@
 """Which kernel each conv / linear shape of a bench workload runs on (the engine's autotune cache) and its measured time:
-usage: tile_report.py [sd|cifar].  Prints one line per distinct launch shape, slowest total first."""
+usage: tile_report.py [sd|cifar|cin256|celeba].  Prints one line per distinct launch shape, slowest total first."""
 import sys, os, argparse
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -8,7 +8,10 @@ import tfmq_dm_amd.ops as ops
 wl = sys.argv[1] if len(sys.argv) > 1 else "sd"
 dev = torch.device("cuda", 0)
 args = argparse.Namespace(batch=0, ddim_steps=4)
-run, fwd, cpu, info = (bench.setup_sd if wl == "sd" else bench.setup_cifar)(args, dev, 0, lambda *a: None)
+if wl == "cifar":
+    run, fwd, cpu, info = bench.setup_cifar(args, dev, 0, lambda *a: None)
+else:
+    run, fwd, cpu, info = bench.setup_sd(args, dev, 0, lambda *a: None, preset=wl)
 eng = info["oracle_state"]["eng"] if "oracle_state" in info else info["eng"]
 names = ops._TILE_NAMES
 keys = ("kind", "B", "H", "W", "Cin", "Cout", "KH", "stride", "up2x", "out_mode", "res", "stats", "seg", "x_f16", "yt")
