@@ -324,14 +324,23 @@ class LdmUNetEngine(DdimUNetEngine):
         d = Cc // heads
         T = H * W
         if (self.calib is None and qkv_l.kind != "w4a8" and self._fp_conv_half_ok(qkv_l) and ops.attention_f16_ok(d, T)
-                and (2 * Cc) % 128 == 0 and T % 4 == 0 and os.environ.get("TFMQ_ATTNBLOCK_F16", "1") != "0"):
+                and T % 4 == 0 and os.environ.get("TFMQ_ATTNBLOCK_F16", "1") != "0"):
             # fp16 operands end to end: the GroupNorm writes fp16, the qkv conv writes q | k as fp16 rows and v as fp16 V^T, the flash
             # kernel copies them tile by tile -- the values the fp32-operand kernel below rounds to on load (same products), without
             # the fp32 q / k / v round trip (the pattern of the SpatialTransformer's FP state in _attention)
             hn, _ = self._gn(p + ".norm", x, None, False, qkv_l, eps=1e-5, half_main=True)
             if hn.dtype == torch.float16:
-                y16, vt = ops.conv2d_f16(hn.reshape(B, T, 1, Cc), qkv_l.p, out_f16=True, t_col0=2 * Cc)
-                y16 = y16.reshape(B, T, 3 * Cc)
+                if (2 * Cc) % 128 == 0:
+                    y16, vt = ops.conv2d_f16(hn.reshape(B, T, 1, Cc), qkv_l.p, out_f16=True, t_col0=2 * Cc)
+                    y16 = y16.reshape(B, T, 3 * Cc)
+                else:
+                    # the transposed region of a launch starts at a multiple of 128 output channels: two launches on the weight
+                    # rows of q | k and of v (C = 672 of the CelebA UNet)
+                    sp = getattr(qkv_l, "_qk_v", None)
+                    if sp is None:
+                        sp = qkv_l._qk_v = (ops.slice_f16_rows(qkv_l.p, 0, 2 * Cc), ops.slice_f16_rows(qkv_l.p, 2 * Cc, 3 * Cc))
+                    y16 = ops.conv2d_f16(hn.reshape(B, T, 1, Cc), sp[0], out_f16=True).reshape(B, T, 2 * Cc)
+                    _, vt = ops.conv2d_f16(hn.reshape(B, T, 1, Cc), sp[1], out_f16=True, t_col0=0)
                 o, _ = ops.attention_f16(y16[..., :Cc], y16[..., Cc:2 * Cc], vt, heads, float(d ** -0.5))
                 return po.run(o.reshape(B, H, W, Cc), residual=x, want_stats=True, **self._o16())
         else:

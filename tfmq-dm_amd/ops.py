@@ -625,6 +625,12 @@ def conv2d_f16(x: torch.Tensor, pf: PackedF16, stride: int = 1, pad: Tuple[int, 
     return y if yt is None else (y, yt)
 
 
+def slice_f16_rows(pf: PackedF16, r0: int, r1: int) -> PackedF16:
+    """Output channels [r0, r1) of an fp16 layer as a layer of its own (same weight values, bias, scales)."""
+    return PackedF16(pf.w16[r0:r1].contiguous(), None if pf.bias is None else pf.bias[r0:r1].contiguous(), r1 - r0, pf.cin, pf.kh, pf.kw,
+                     wscale=None if pf.wscale is None else pf.wscale[r0:r1].contiguous())
+
+
 def f16_cat_ok(c1: int, c2: int, kh: int = 1, kw: int = 1, stride: int = 1, up2x: bool = False, pad=(0, 0, 0, 0)) -> bool:
     """conv2d_f16(x, ..., x2=...) reads the channel concat of two fp16 tensors without its copy for these launches."""
     return (kh == 1 and kw == 1 and stride == 1 and not up2x and tuple(pad) == (0, 0, 0, 0) and c1 % 32 == 0 and c2 % 32 == 0
