@@ -33,7 +33,8 @@ def maxnorm(a, b):
 
 @pytest.mark.parametrize("B,heads,Tq,Tk,d", [(2, 8, 256, 256, 40), (1, 2, 200, 200, 64), (2, 1, 130, 136, 160),
                                              (1, 4, 64, 72, 32), (1, 2, 128, 1000, 80), (2, 1, 256, 256, 128),
-                                             (3, 1, 256, 256, 256), (1, 2, 130, 200, 208)])
+                                             (3, 1, 256, 256, 256), (1, 2, 130, 200, 208),
+                                             (2, 1, 256, 256, 384), (1, 1, 130, 200, 320), (1, 2, 128, 136, 264)])   # wide heads: sliced output
 def test_attention_f16_vs_fp32(ops, B, heads, Tq, Tk, d):
     gen = torch.Generator().manual_seed(Tq + d)
     C = heads * d

@@ -24,6 +24,7 @@ struct AttnHP {
   tfmq_qsel aq;
   int B, heads, Tq, Tk, Tks, d;   // Tks: keys per batch item in memory (K rows, V^T row length), >= Tk, % 8 == 0
   float scale;
+  int nsl;                        // output slices of 32*NT channels (1 unless 16*NKS > 32*NT: wide heads, see below)
 };
 
 // NKS = k-steps of the score MFMA (16 channels each), NT = 32-column output tiles: compile-time, so that the MFMA
@@ -44,11 +45,15 @@ template <int NKS, int NT, int ONES_ROW, bool FOLD = false>
 __global__ __launch_bounds__(256, (NT <= 2 && FOLD) ? 4 : 1) void k_attention_h(AttnHP p) {
   constexpr int DPAD = NT * 32;
   static_assert(!FOLD || (ONES_ROW >= 0 && 16 * NKS > ONES_ROW && ONES_ROW % 8 == 0), "FOLD: spare score column + ones-row");
-  static_assert(NKS <= 2 * NT, "score k-steps must fit the padded row");
-  constexpr int KROW = DPAD * 2 + 16;    // bytes per K row in LDS (odd number of 16-byte slots: conflict-free)
+  // Wide heads (16 * NKS > 32 * NT; the single 384-channel head of cin256-v2): the scores need the whole head dimension, the
+  // output does not -- a block computes the scores over all 16 * NKS channels and the 32 * NT output channels of ITS slice
+  // (p.nsl slices, blockIdx fastest); the softmax is recomputed per slice, identically.
+  constexpr int KD = NKS * 16 > DPAD ? NKS * 16 : DPAD;   // channels of a staged K row
+  static_assert(NKS * 16 <= DPAD || ONES_ROW < 0, "sliced output: no ones-row / fold");
+  constexpr int KROW = KD * 2 + 16;      // bytes per K row in LDS (odd number of 16-byte slots: conflict-free)
   constexpr int VROW = 64 * 2 + 16;      // bytes per V^T row (64 keys)
   constexpr int KBUF = 64 * KROW, VBUF = DPAD * VROW;
-  constexpr int KPT = (64 * (DPAD / 8) + 255) / 256;   // 16-byte pieces per thread, K tile (upper bound)
+  constexpr int KPT = (64 * (KD / 8) + 255) / 256;   // 16-byte pieces per thread, K tile (upper bound)
   constexpr int VPT = (DPAD * 8 + 255) / 256;          // ... V^T tile
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* sK = smem;                 // [2][64][KROW]
@@ -64,6 +69,8 @@ __global__ __launch_bounds__(256, (NT <= 2 && FOLD) ? 4 : 1) void k_attention_h(
     const int nb = gridDim.x, xcd = bid & 7, qn = nb >> 3, r = nb & 7;
     bid = (xcd < r ? xcd * (qn + 1) : r * (qn + 1) + (xcd - r) * qn) + (bid >> 3);
   }
+  const int sl = bid % p.nsl;               // output slice (wide heads; nsl = 1 otherwise)
+  bid /= p.nsl;
   const int nqb = (p.Tq + 127) / 128;
   const int bh = bid / nqb;
   const int b = bh / p.heads, hd = bh % p.heads;
@@ -100,9 +107,10 @@ __global__ __launch_bounds__(256, (NT <= 2 && FOLD) ? 4 : 1) void k_attention_h(
   }
 
   const __half* kbase = p.k + static_cast<size_t>(b) * p.Tks * p.ldk + hd * d;
-  const __half* vbase = p.vt + (static_cast<size_t>(b) * p.heads + hd) * d * p.Tks;
+  const __half* vbase = p.vt + ((static_cast<size_t>(b) * p.heads + hd) * d + static_cast<size_t>(sl) * DPAD) * p.Tks;
+  const int drows = (d - sl * DPAD) < DPAD ? (d - sl * DPAD) : DPAD;       // V^T rows / output channels of this slice
   // ---- staging plan of this thread (the same for every key tile): global offset, LDS offset, first key
-  const int kpieces = 64 * dp8, vpieces = d * 8;
+  const int kpieces = 64 * dp8, vpieces = drows * 8;
   int k_go[KPT], k_lo[KPT], k_key[KPT], v_go[VPT], v_lo[VPT], v_key[VPT];
 #pragma unroll
   for (int it = 0; it < KPT; ++it) {
@@ -316,8 +324,8 @@ __global__ __launch_bounds__(256, (NT <= 2 && FOLD) ? 4 : 1) void k_attention_h(
   for (int t = 0; t < NT; ++t) {
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      const int dc = t * 32 + 8 * g + 4 * hh;
-      if (dc >= d) continue;
+      const int dc = sl * DPAD + t * 32 + 8 * g + 4 * hh;
+      if (dc >= d || t * 32 + 8 * g + 4 * hh >= drows) continue;
       float4 v = make_float4(o[t][4 * g] * inv, o[t][4 * g + 1] * inv, o[t][4 * g + 2] * inv, o[t][4 * g + 3] * inv);
       if (p.out) *reinterpret_cast<float4*>(p.out + tok * p.ldo + hd * d + dc) = v;
       if (quant) {
@@ -332,15 +340,18 @@ __global__ __launch_bounds__(256, (NT <= 2 && FOLD) ? 4 : 1) void k_attention_h(
 template <int NKS, int NT, int ONES_ROW = -1, bool FOLD = false>
 static int launch_attn_h(tfmq_handle h, const AttnHP& p, void* stream) {
   constexpr int DPAD = NT * 32;
-  constexpr size_t smem = 2 * (64 * (DPAD * 2 + 16) + static_cast<size_t>(DPAD) * (64 * 2 + 16));
+  constexpr int KD = NKS * 16 > DPAD ? NKS * 16 : DPAD;
+  constexpr size_t smem = 2 * (64 * (KD * 2 + 16) + static_cast<size_t>(DPAD) * (64 * 2 + 16));
   static bool configured = false;
   if (!configured) {
     TFMQ_HIP(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_attention_h<NKS, NT, ONES_ROW, FOLD>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(smem)));
     configured = true;
   }
-  dim3 grid(static_cast<unsigned>((p.Tq + 127) / 128) * p.B * p.heads);
-  hipLaunchKernelGGL((k_attention_h<NKS, NT, ONES_ROW, FOLD>), grid, dim3(256), smem, as_stream(stream), p);
+  AttnHP q = p;
+  q.nsl = NKS * 16 > DPAD ? (p.d + DPAD - 1) / DPAD : 1;
+  dim3 grid(static_cast<unsigned>((p.Tq + 127) / 128) * p.B * p.heads * q.nsl);
+  hipLaunchKernelGGL((k_attention_h<NKS, NT, ONES_ROW, FOLD>), grid, dim3(256), smem, as_stream(stream), q);
   TFMQ_LAUNCH_CHECK(h);
   return TFMQ_OK;
 }
@@ -354,7 +365,7 @@ extern "C" int tfmq_attention_f16(tfmq_handle h, const uint16_t* q, const uint16
                  "attention_f16: head dim, leading dims and Tk_stride must be multiples of 8, Tk_stride >= Tk");
   TFMQ_CHECK_ARG(h, !yq || aq.qtable, "attention_f16: quantised output needs a qparam");
   AttnHP p{reinterpret_cast<const __half*>(q), reinterpret_cast<const __half*>(k), reinterpret_cast<const __half*>(vt),
-           ldq, ldk, out, ldo, yq, aq, B, heads, Tq, Tk, Tk_stride, d, scale};
+           ldq, ldk, out, ldo, yq, aq, B, heads, Tq, Tk, Tk_stride, d, scale, 1};
   if (d <= 32) return launch_attn_h<2, 1>(h, p, stream);
   if (d == 40) return launch_attn_h<3, 2, 40, true>(h, p, stream);  // SD v1 at 64x64
   if (d <= 48) return launch_attn_h<3, 2>(h, p, stream);
@@ -365,6 +376,7 @@ extern "C" int tfmq_attention_f16(tfmq_handle h, const uint16_t* q, const uint16
   if (d <= 128) return launch_attn_h<8, 4>(h, p, stream);
   if (d <= 160) return launch_attn_h<10, 5>(h, p, stream);   // SD v1 at 16x16 / 8x8
   if (d <= 256) return launch_attn_h<16, 8>(h, p, stream);   // DDPM UNet's single 256-channel head (one wave per SIMD)
-  if (h) h->err = "attention_f16: head dim > 256 not supported (use tfmq_attention)";
+  if (d <= 384) return launch_attn_h<24, 4>(h, p, stream);   // cin256-v2's single head at 32x32: scores over 384 channels, 3 output slices of 128
+  if (h) h->err = "attention_f16: head dim > 384 not supported (use tfmq_attention)";
   return TFMQ_ERR_UNSUPPORTED;
 }

@@ -805,7 +805,8 @@ def _attention_wide(q, k, v, heads: int, scale: float, aq: Optional[QSel], want_
 
 def attention_f16_ok(d: int, Tk: int) -> bool:
     """Tk = keys per batch item as stored (a multiple of 8; fewer may be valid, see attention_f16(n_keys=...))."""
-    return d % 8 == 0 and d <= 256 and Tk % 8 == 0
+    dmax = 256 if os.environ.get("TFMQ_ATTN_WIDE", "1") == "0" else 384      # (256, 384]: scores over the whole head, output in 128-channel slices
+    return d % 8 == 0 and d <= dmax and Tk % 8 == 0
 
 
 def attention_f16(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, heads: int, scale: float,
