@@ -262,7 +262,8 @@ int tfmq_attention(tfmq_handle h, const float* q, const float* k, const float* v
 /* Same operation on fp16 operands written by the projection GEMM (TFMQ_OUT_F16): q,k as above (ld in halves),
  * vt = V transposed, fp16 [B][heads*d][Tk_stride] (tfmq_conv_desc.yt).  Tk_stride >= Tk keys per batch item are
  * present in memory (k: [B][Tk_stride][ldk]); keys >= Tk are masked (a 77-token context is stored padded to 80).
- * d % 8 == 0, d <= 160, Tk_stride % 8 == 0. */
+ * d % 8 == 0, d <= 384 (above 256 a block computes the scores over the whole head and the 128 output channels of its slice;
+ * larger heads: TFMQ_ERR_UNSUPPORTED, use tfmq_attention), Tk_stride % 8 == 0. */
 int tfmq_attention_f16(tfmq_handle h, const uint16_t* q, const uint16_t* k, const uint16_t* vt, int ldq, int ldk,
                        float* out, int ldo, int8_t* yq, tfmq_qsel aq, int B, int heads, int Tq, int Tk, int Tk_stride,
                        int d, float scale, void* stream);
