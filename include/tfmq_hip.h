@@ -109,6 +109,11 @@ int tfmq_unpack_w4(tfmq_handle h, const uint8_t* packed, int cout, int cin, int 
  * cout_pad32 * kh*kw*cin bytes.  This is what tfmq_conv_desc.w points at for tfmq_conv2d_w4a8. */
 int tfmq_expand_w4(tfmq_handle h, const uint8_t* packed, const int32_t* wmeta, int cout, int cin, int kh, int kw,
                    int8_t* w8, void* stream);
+/* The same operand with every tap's channels padded to a multiple of 64 (zeros): byte(n, tap, c) =
+ * ((n/32 * nsteps + tap*chunks + c/64) * 32 + n%32) * 64 + c%64, chunks = ceil(cin/64), nsteps = kh*kw*chunks; for cin % 64 == 32
+ * (tfmq_conv_desc.w64).  w8p: cout_pad32 * nsteps * 64 bytes. */
+int tfmq_expand_w4_k64(tfmq_handle h, const uint8_t* packed, const int32_t* wmeta, int cout, int cin, int kh, int kw, int8_t* w8p,
+                       void* stream);
 /* fp16 weights for the un-quantised convs, reordered to [cout][kh][kw][cin_pad],
  * cin_pad = cin rounded up to a multiple of 32 (zero filled).  With delta/zp (and optional
  * alpha) non-NULL the stored value is the integer grid coordinate q - zp (exact in f16) of the
@@ -194,6 +199,11 @@ typedef struct tfmq_conv_desc {
                                     [B][H][W][cin1].  Needs cin1 % 32 == 0, (Cin - cin1) % 32 == 0 and a launch the register-direct
                                     pointwise kernel takes (fp16 output, no rowadd); anything else is TFMQ_ERR_ARG */
   int32_t cin1;
+  const void* w64;               /* tfmq_conv2d_w4a8, Cin % 64 == 32 only (optional): the weight operand of tfmq_expand_w4_k64 -- 64-channel
+                                    K-steps with the last one of every tap zero-padded.  The LDS-DMA kernels (slab, register-direct
+                                    pointwise, DMA tile kernels) then take such layers too: their last K-step of a pixel reads 32 bytes
+                                    past its channel row (the next pixel's, times zero weights), so x must be followed by >= 32 readable
+                                    bytes.  NULL: those layers run on the register-staged kernel with 32-channel K-steps */
 } tfmq_conv_desc;
 enum { TFMQ_OUT_F32 = 0, TFMQ_OUT_F16 = 1, TFMQ_OUT_GEGLU_Q8 = 2, TFMQ_OUT_Q8 = 3 };
 enum { TFMQ_TILE_AUTO = 0, TFMQ_TILE_128 = 1, TFMQ_TILE_64 = 2, TFMQ_TILE_256 = 3, TFMQ_TILE_128x64 = 4, TFMQ_TILE_SLAB = 5, TFMQ_TILE_DIRECT = 6, TFMQ_TILE_STREAM = 7, TFMQ_TILE_PERSIST = 8 };

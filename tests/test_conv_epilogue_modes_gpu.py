@@ -616,3 +616,52 @@ def test_f16_slab_kernel_vs_tile_kernel(ops, B, H, W, cin, cout, res, o16, up):
     assert float((a - b).abs().max()) <= tol * scale
     sa, sb = outs[5]._tfmq_stats[0], outs[1]._tfmq_stats[0]
     assert float((sa - sb).abs().max()) <= 1e-5 * float(sb.abs().max())
+
+
+@pytest.mark.parametrize("B,H,W,cin,cout,k,res", [(2, 16, 16, 224, 224, 3, True), (3, 8, 8, 96, 128, 3, False), (2, 20, 1, 160, 320, 1, True),
+                                                  (1, 32, 32, 224, 448, 1, False), (2, 16, 16, 672, 224, 3, False)])
+def test_w4a8_k_padded_operand_cin_32_mod_64(ops, B, H, W, cin, cout, k, res):
+    """Cin % 64 == 32 (the 224-channel multiples of the LDM-4 CelebA UNet): tfmq_expand_w4_k64 pads every tap's channels to 64-channel
+    K-steps with zero weights, so the LDS-DMA kernels (slab, register-direct pointwise, DMA tile kernels) take the layer; their last
+    K-step of a pixel reads 32 bytes of the NEXT pixel, times zero.  Integer sums: bit-identical to the register-staged kernel with
+    32-channel steps (TFMQ_W4_KPAD=0 packs without the padded operand), whatever the tile."""
+    import tfmq_dm_amd.ops as _o
+    gen = torch.Generator().manual_seed(cin + cout + H)
+    x = torch.randn(B, H, W, cin, generator=gen) * 1.1
+    w = torch.randn(cout, cin, k, k, generator=gen) * (1.5 / (k * k * cin) ** 0.5)
+    bias = torch.randn(cout, generator=gen) * 0.1
+    wd, wz = O.init_channelwise(w, 16, "minmax")
+    ad, az = O.minmax(x, 256)
+    sel = ops.qsel(qtab(ad, az))
+    xq = ops.quantize_act(x.to(DEV), sel)
+    os.environ["TFMQ_W4_KPAD"] = "0"
+    try:
+        pw_ref = ops.pack_w4(w.to(DEV), wd.reshape(-1).to(DEV), wz.reshape(-1).to(DEV), None, bias.to(DEV))
+    finally:
+        del os.environ["TFMQ_W4_KPAD"]
+    pw = ops.pack_w4(w.to(DEV), wd.reshape(-1).to(DEV), wz.reshape(-1).to(DEV), None, bias.to(DEV))
+    assert pw_ref.w8p is None and pw.w8p is not None
+    pad = (1, 1, 1, 1) if k == 3 else (0, 0, 0, 0)
+    kw = dict(pad=pad, want_stats=True, out_f16=True)
+    if res:
+        kw["residual"] = torch.randn(B, H, W, cout, generator=gen).to(DEV).half()
+    ref = ops.conv2d_w4a8(xq, pw_ref, sel, **kw)
+    tiles = (1, 2, 4, 5) if k == 3 else (1, 2, 4, 6)
+    for tile in tiles:
+        ops.set_conv_autotune({})
+        orig = _o._tune_conv
+        try:
+            _o._tune_conv = lambda h, name, kind, d, dsc, t=tile: t
+            y = ops.conv2d_w4a8(xq, pw, sel, **kw)
+        finally:
+            _o._tune_conv = orig
+            ops.set_conv_autotune(None)
+        assert torch.equal(y, ref), tile
+        if hasattr(ref, "_tfmq_stats"):
+            assert torch.equal(y._tfmq_stats[0], ref._tfmq_stats[0]), tile
+    # the last pixel's padded K-step reads past the tensor: a tensor that ends exactly at its last channel gives the same result
+    # whatever follows it in memory
+    big = torch.full((xq.numel() + 4096,), 77, dtype=torch.int8, device=DEV)
+    big[:xq.numel()] = xq.reshape(-1)
+    y2 = ops.conv2d_w4a8(big[:xq.numel()].view(xq.shape), pw, sel, **kw)
+    assert torch.equal(y2, ref)

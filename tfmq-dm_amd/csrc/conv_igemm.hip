@@ -973,6 +973,12 @@ static int launch_conv(tfmq_handle h, const tfmq_conv_desc* dd, void* stream) {
     TFMQ_CHECK_ARG(h, d.wmeta && d.wscale && d.aq.qtable, "conv_w4a8: wmeta/wscale/aq required");
     p.chunks = d.Cin % 64 == 0 ? d.Cin / 64 : d.Cin / 32;
     p.cin_pad = d.Cin;
+    // Cin % 64 == 32 with the K-padded operand (tfmq_conv_desc.w64): 64-channel K-steps, the LDS-DMA kernels.  Only when the DMA
+    // kernels are sure to take the launch (the register-staged fallback reads the 32-channel-step operand d.w)
+    if (d.Cin % 64 != 0 && d.w64 && d.KH * d.KW <= 9 && static_cast<size_t>(d.B) * d.H * d.W * d.Cin < (static_cast<size_t>(1) << 31)) {
+      p.chunks = (d.Cin + 63) / 64;
+      p.d.w = d.w64;
+    }
   } else {
     p.chunks = (d.Cin + 31) / 32;
     p.cin_pad = p.chunks * 32;
@@ -984,7 +990,7 @@ static int launch_conv(tfmq_handle h, const tfmq_conv_desc* dd, void* stream) {
   // (a statistics segment must not span tiles, so 128-pixel segments keep the 128-row tile)
   const bool small_ok = !narrow && !geglu && !(d.stats && d.stats_seg > 64);
   // large-M layers: 256 x 128 tiles move a quarter fewer L2 -> LDS bytes per MFMA (the K loop is bound by that path)
-  const bool dma8 = INT8 && d.Cin % 64 == 0 && d.KH * d.KW <= 9 &&
+  const bool dma8 = INT8 && p.chunks == (d.Cin + 63) / 64 && d.KH * d.KW <= 9 &&
                     static_cast<size_t>(d.B) * d.H * d.W * d.Cin < (static_cast<size_t>(1) << 31);
   // (the fp16-activation DMA kernel shares the pipeline, hence the tile shapes)
   const bool dma16 = !INT8 && d.x_f16 && d.Cin % 32 == 0 && d.KH * d.KW <= 9;
@@ -1056,7 +1062,7 @@ static int launch_conv(tfmq_handle h, const tfmq_conv_desc* dd, void* stream) {
   dim3 grid(static_cast<unsigned>(p.tiles_n) * tiles_m);
   hipStream_t st = as_stream(stream);
   if constexpr (INT8) {
-    const bool dma = d.Cin % 64 == 0 && d.KH * d.KW <= 9 &&
+    const bool dma = p.chunks == (d.Cin + 63) / 64 && d.KH * d.KW <= 9 &&
                      static_cast<size_t>(d.B) * d.H * d.W * d.Cin < (static_cast<size_t>(1) << 31);
     if (dma) {
 #ifdef TFMQ_PHASE_TIMERS

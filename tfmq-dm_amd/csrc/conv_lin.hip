@@ -842,7 +842,7 @@ bool launch_conv_lin(tfmq_handle h, ConvP& p, hipStream_t st, int variant) {
   const bool stream = variant == 1, persist = variant == 2;
   const tfmq_conv_desc& d = p.d;
   if (d.KH != 1 || d.KW != 1 || d.stride != 1 || d.up2x || d.pad_t != 0 || d.pad_l != 0 || d.Ho != d.H || d.Wo != d.W) return false;
-  if (d.Cin % 64 != 0 || static_cast<size_t>(d.B) * d.H * d.W * d.Cin >= (static_cast<size_t>(1) << 31)) return false;
+  if (d.Cin % 32 != 0 || p.chunks != (d.Cin + 63) / 64 || static_cast<size_t>(d.B) * d.H * d.W * d.Cin >= (static_cast<size_t>(1) << 31)) return false;
   if (d.rowadd || (d.Cout & 7) != 0) return false;                 // a lane moves whole 8-channel octets
   if (d.stats && (stream || d.out_mode != TFMQ_OUT_F16 || d.yt || 128 % d.stats_seg != 0)) return false;
   if (d.yt && (d.out_mode != TFMQ_OUT_F16 || d.residual)) return false;

@@ -400,7 +400,8 @@ bool launch_conv_slab(tfmq_handle h, ConvP& p, hipStream_t st, bool forced, bool
   const tfmq_conv_desc& d = p.d;
   const int Hv = d.up2x ? 2 * d.H : d.H, Wv = d.up2x ? 2 * d.W : d.W;
   if (d.KH != 3 || d.KW != 3 || d.stride != 1 || d.pad_t != 1 || d.pad_l != 1 || d.Ho != Hv || d.Wo != Wv || p.Hv != Hv || p.Wv != Wv) return false;
-  if (d.Cin % (f16 ? 32 : 64) != 0 || static_cast<size_t>(d.B) * d.H * d.W * d.Cin * (f16 ? 2 : 1) >= (static_cast<size_t>(1) << 31)) return false;
+  if (d.Cin % 32 != 0 || (!f16 && p.chunks != (d.Cin + 63) / 64) ||
+      static_cast<size_t>(d.B) * d.H * d.W * d.Cin * (f16 ? 2 : 1) >= (static_cast<size_t>(1) << 31)) return false;
   if (f16 && (!d.x_f16 || p.cin_pad != d.Cin || p.chunks != d.Cin / 32 || d.out_mode == TFMQ_OUT_Q8)) return false;
   if (!(d.out_mode == TFMQ_OUT_F32 || d.out_mode == TFMQ_OUT_Q8 || (d.out_mode == TFMQ_OUT_F16 && !d.yt))) return false;
   if (((d.Cout | d.ldy | d.y_coff) & 7) != 0) return false;             // a lane moves whole 8-channel octets

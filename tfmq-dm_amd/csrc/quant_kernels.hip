@@ -483,6 +483,40 @@ extern "C" int tfmq_expand_w4(tfmq_handle h, const uint8_t* packed, const int32_
   return TFMQ_OK;
 }
 
+// K-padded form (tfmq_expand_w4_k64): 64-channel K-steps, the channels cin .. 64*chunks of every tap are zero
+__global__ void k_expand_w4_k64(const uint32_t* __restrict__ packed, const int32_t* __restrict__ wmeta, int cout, int cout_pad,
+                                int cin, int khw, int ck, int8_t* __restrict__ w8p) {
+  const int chunks = (cin + 63) / 64, nsteps = khw * chunks, K = khw * cin;
+  const size_t total = static_cast<size_t>(cout_pad) * nsteps * 8;          // 8-channel groups
+  for (size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < total;
+       i += static_cast<size_t>(gridDim.x) * blockDim.x) {
+    const int n = static_cast<int>(i / (static_cast<size_t>(nsteps) * 8));
+    const int r = static_cast<int>(i - static_cast<size_t>(n) * nsteps * 8);
+    const int step = r >> 3, c0 = (step % chunks) * 64 + (r & 7) * 8, tap = step / chunks;
+    int8_t o[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (n < cout && c0 < cin) {
+      const uint32_t word = packed[w4_word_index(n, (tap * cin + c0) / 8, K, ck)];
+      const int z = wmeta[4 * n];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = static_cast<int8_t>(static_cast<int>((word >> ((j & 3) * 8 + (j >> 2) * 4)) & 15u) - z);
+    }
+    const size_t dst = ((static_cast<size_t>(n / 32) * nsteps + step) * 32 + (n % 32)) * 64 + (r & 7) * 8;
+    *reinterpret_cast<uint2*>(w8p + dst) = *reinterpret_cast<const uint2*>(o);
+  }
+}
+
+extern "C" int tfmq_expand_w4_k64(tfmq_handle h, const uint8_t* packed, const int32_t* wmeta, int cout, int cin, int kh, int kw,
+                                  int8_t* w8p, void* stream) {
+  TFMQ_CHECK_ARG(h, h && packed && wmeta && w8p, "expand_w4_k64: null pointer");
+  TFMQ_CHECK_ARG(h, cout > 0 && cin > 0 && kh > 0 && kw > 0 && cin % 32 == 0, "expand_w4_k64: cin must be a multiple of 32");
+  const int cout_pad = (cout + 31) / 32 * 32, chunks = (cin + 63) / 64;
+  const size_t total = static_cast<size_t>(cout_pad) * kh * kw * chunks * 8;
+  hipLaunchKernelGGL(k_expand_w4_k64, dim3(ceil_div(static_cast<long>(total), 256)), dim3(256), 0, as_stream(stream),
+                     reinterpret_cast<const uint32_t*>(packed), wmeta, cout, cout_pad, cin, kh * kw, w4_ck(cin), w8p);
+  TFMQ_LAUNCH_CHECK(h);
+  return TFMQ_OK;
+}
+
 __global__ void k_pack_w_f16(const float* __restrict__ w, const float* __restrict__ alpha,
                              const float* __restrict__ delta, const float* __restrict__ zp, float lmax, int cout,
                              int cin, int cin_pad, int khw, __half* __restrict__ out) {

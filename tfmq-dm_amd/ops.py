@@ -66,7 +66,7 @@ class Arena:
             n = 1
             for s_ in shape:
                 n *= s_
-            need = max(256, (n * torch.empty(0, dtype=dtype).element_size() + 255) // 256 * 256)
+            need = max(256, (n * torch.empty(0, dtype=dtype).element_size() + (64 if dtype == torch.int8 else 0) + 255) // 256 * 256)
             bi = None
             if self.reuse:
                 for cand in self._by_size.get(need, ()):
@@ -114,6 +114,11 @@ def _alloc(*shape, dtype=torch.float32, device=None):
         shape = tuple(shape[0])
     if _arena is not None:
         return _arena.take(shape, dtype, device)
+    if dtype == torch.int8:       # the K-padded int8 operand path reads up to 32 bytes past the last pixel row (tfmq_conv_desc.w64)
+        n = 1
+        for s_ in shape:
+            n *= int(s_)
+        return torch.empty(n + 64, dtype=dtype, device=device)[:n].view(shape)
     return torch.empty(shape, dtype=dtype, device=device)
 
 
@@ -254,6 +259,11 @@ class PackedW4:
             d = _dev(packed)
             self.w8 = torch.empty((cout + 31) // 32 * 32 * kh * kw * cin, dtype=torch.int8, device=packed.device)
             handle(d).call("expand_w4", _p(packed), _p(wmeta), cout, cin, kh, kw, _p(self.w8), _stream(d))
+        # Cin % 64 == 32 (the 224-channel multiples of the CelebA UNet): the K-padded operand of the LDS-DMA kernels
+        self.w8p = None
+        if cin % 64 == 32 and kh * kw <= 9 and os.environ.get("TFMQ_W4_KPAD", "1") != "0":
+            self.w8p = torch.empty((cout + 31) // 32 * 32 * kh * kw * ((cin + 63) // 64) * 64, dtype=torch.int8, device=packed.device)
+            handle(_dev(packed)).call("expand_w4_k64", _p(packed), _p(wmeta), cout, cin, kh, kw, _p(self.w8p), _stream(_dev(packed)))
 
 
 def pack_w4(w: torch.Tensor, delta: torch.Tensor, zp: torch.Tensor, alpha: Optional[torch.Tensor] = None,
@@ -390,7 +400,7 @@ def slab_ok(dsc) -> bool:
     hv, wv = (2 * dsc.H, 2 * dsc.W) if dsc.up2x else (dsc.H, dsc.W)      # the fused nearest-2x upsample stages upsampled rows
     f16 = bool(dsc.x_f16)              # the fp16-operand form: 32 channels per 64-byte slab row, no int8 output
     if not (dsc.KH == 3 and dsc.KW == 3 and dsc.stride == 1 and dsc.pad_t == 1 and dsc.pad_l == 1
-            and dsc.Cin % (32 if f16 else 64) == 0 and dsc.Ho == hv and dsc.Wo == wv and not dsc.yt
+            and (dsc.Cin % 64 == 0 or (dsc.Cin % 32 == 0 and (f16 or bool(dsc.w64)))) and dsc.Ho == hv and dsc.Wo == wv and not dsc.yt
             and dsc.out_mode in ((0, 1) if f16 else (0, 1, 3)) and dsc.Cout % 8 == 0):
         return False
     hw = hv * wv
@@ -416,13 +426,14 @@ def _tune_conv(h, name, kind, d, dsc):
     if kind == "f16" and dsc.x_f16 and slab_ok(dsc):
         return 5                      # fp16 3x3: the slab kernel's K order differs from the tile kernels' -- one rule for every batch size
     cands = [1, 2]
-    if (kind == "w4a8" and dsc.Cin % 64 == 0) or (kind == "f16" and dsc.x_f16):
+    k64 = dsc.Cin % 64 == 0 or (dsc.Cin % 32 == 0 and bool(dsc.w64))      # int8 layers the LDS-DMA kernels take
+    if (kind == "w4a8" and k64) or (kind == "f16" and dsc.x_f16):
         cands.append(4)
         if dsc.stride == 1 and not dsc.up2x:
             cands.append(3)
     if kind == "w4a8" and slab_ok(dsc):
         cands.append(5)
-    if (kind == "w4a8" and dsc.KH == 1 and dsc.KW == 1 and dsc.stride == 1 and not dsc.up2x and dsc.Cin % 64 == 0 and dsc.Cout % 4 == 0
+    if (kind == "w4a8" and dsc.KH == 1 and dsc.KW == 1 and dsc.stride == 1 and not dsc.up2x and k64 and dsc.Cout % 4 == 0
             and dsc.out_mode in (1, 2, 3) and not dsc.rowadd and not (dsc.stats and dsc.out_mode != 1) and not (dsc.yt and dsc.residual)):
         cands.append(6)
         # (7 = TFMQ_TILE_STREAM and 8 = TFMQ_TILE_PERSIST, the persistent variants, are selectable but not candidates: measured
@@ -533,6 +544,8 @@ def conv2d_w4a8(xq: torch.Tensor, pw: PackedW4, aq: QSel, stride: int = 1, pad: 
     if pw.w8 is None:
         raise TfmqError("conv2d_w4a8: Cin must be a multiple of 32")
     dsc.w, dsc.wmeta, dsc.wscale = pw.w8.data_ptr(), pw.wmeta.data_ptr(), pw.wscale.data_ptr()
+    if getattr(pw, "w8p", None) is not None:
+        dsc.w64 = pw.w8p.data_ptr()
     dsc.bias = None if pw.bias is None else pw.bias.data_ptr()
     dsc.aq = aq
     osz = 4.0
