@@ -327,6 +327,10 @@ int tfmq_np_histogram(tfmq_handle h, const float* x, size_t n, int f64, int do_c
 int tfmq_hw_selftest(tfmq_handle h, uint32_t* report);
 /* fp32 -> fp16 copy (round to nearest even): operand of tfmq_conv2d_f16 with x_f16 when the producer writes fp32 */
 int tfmq_f32_to_f16(tfmq_handle h, const float* x, uint16_t* y, size_t n, void* stream);
+/* y[b][t][c] = x[b][t][c] + r[b][c] (fp32 arithmetic; x / y fp16 when x_f16 != 0, else fp32; C % 8 == 0; y may alias x).  The residual
+ * add of a cross attention whose context is ONE token (class-conditional LDM: softmax over one key is exactly 1, so the attention
+ * output of every query is v of that token and to_out's result one row per batch item -- ldm/modules/attention.py:168-194). */
+int tfmq_row_broadcast_add(tfmq_handle h, const void* x, const float* r, int B, long T, int C, int x_f16, void* y, void* stream);
 /* y = x*sigmoid(x)  (nonlinearity, ddim/models/diffusion.py:27-29) */
 int tfmq_silu(tfmq_handle h, const float* x, float* y, size_t n, void* stream);
 int tfmq_nchw_to_nhwc(tfmq_handle h, const float* x, float* y, int B, int C, int HW, void* stream);

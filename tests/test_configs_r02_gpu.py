@@ -111,6 +111,16 @@ def test_cin_style_engine_and_cfg_ddim(golden):
     eng.stream_f16 = True
     assert torch.equal(nchw(eng.forward(nhwc(x), t.to(DEV), ctx.to(DEV), taps={})), eps32)     # fused == un-fused data path
     assert rel_l2(eps, eps32) <= 3e-2                                                          # fp16 vs fp32 activation stream
+    # ONE context token: the block adds to_out(to_v(context)) to every token (softmax over one key is exactly 1).  The whole cross
+    # attention -- norm2, to_q, to_k, the attention kernel on fp16 operands -- gives the same eps up to the fp16 rounding of v there
+    os.environ["TFMQ_SINGLE_CTX_TOKEN"] = "0"
+    try:
+        eps_full = nchw(eng.forward(nhwc(x), t.to(DEV), ctx.to(DEV)))
+    finally:
+        del os.environ["TFMQ_SINGLE_CTX_TOKEN"]
+    print("single-token shortcut vs whole cross attention, eps rel-L2:", rel_l2(eps, eps_full))
+    assert rel_l2(eps, eps_full) <= 2e-2 and not torch.equal(eps, eps_full)
+    assert rel_l2(eps_full, T(g["eps_w4a8"])) <= 3.5e-2
     ac = alphas_cumprod_linear(0.0015, 0.0195)
     assert np.array_equal(ac.numpy(), g["alphas_cumprod"])
     sampler = GraphLatentDdimSampler(eng, 4, 2, (3, 8, 8), (1, 64), scale=3.0, alphas_cumprod=ac).capture()
@@ -422,3 +432,17 @@ def test_unsupported_bit_widths_fail_loudly(golden):
     q.set_quant_state(True, True)
     with pytest.raises(TfmqError, match="4-bit weights"):
         q(torch.randn(2, 3, 16, 16, device=DEV), torch.tensor([10.0, 500.0], device=DEV))
+
+
+@pytest.mark.parametrize("B,T_,C,half", [(3, 50, 64, True), (2, 1024, 384, True), (4, 7, 960, False)])
+def test_row_broadcast_add(B, T_, C, half):
+    import tfmq_dm_amd.ops as ops
+    gen = torch.Generator().manual_seed(T_ + C)
+    x = torch.randn(B, T_, C, generator=gen).to(DEV)
+    r = torch.randn(B, C, generator=gen).to(DEV)
+    if half:
+        x = x.half()
+    y = ops.row_broadcast_add(x, r)
+    want = (x.float() + r[:, None, :])
+    want = want.half() if half else want
+    assert y.dtype == x.dtype and torch.equal(y, want)

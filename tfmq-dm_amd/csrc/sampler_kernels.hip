@@ -357,6 +357,46 @@ __global__ __launch_bounds__(256) void k_f32_to_f16(const float* __restrict__ x,
     y[i] = __float2half_rn(x[i]);
 }
 
+// y[b][t][c] = x[b][t][c] + r[b][c], eight channels per thread (tfmq_row_broadcast_add)
+template <bool XH>
+__global__ __launch_bounds__(256) void k_row_broadcast_add(const void* __restrict__ xv, const float* __restrict__ r, unsigned total8,
+                                                           unsigned tc8, unsigned c8, void* __restrict__ yv) {
+  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total8; i += gridDim.x * blockDim.x) {
+    const unsigned b = i / tc8, c = (i % c8) * 8;
+    const float4 r0 = *reinterpret_cast<const float4*>(r + static_cast<size_t>(b) * c8 * 8 + c);
+    const float4 r1 = *reinterpret_cast<const float4*>(r + static_cast<size_t>(b) * c8 * 8 + c + 4);
+    const float rr[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
+    if constexpr (XH) {
+      const uint4 u = reinterpret_cast<const uint4*>(xv)[i];
+      const __half2* hp = reinterpret_cast<const __half2*>(&u);
+      __half2 o[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float2 f = __half22float2(hp[e]);
+        o[e] = __floats2half2_rn(f.x + rr[2 * e], f.y + rr[2 * e + 1]);
+      }
+      reinterpret_cast<uint4*>(yv)[i] = *reinterpret_cast<const uint4*>(o);
+    } else {
+      const float4 a = reinterpret_cast<const float4*>(xv)[2 * static_cast<size_t>(i)], bq = reinterpret_cast<const float4*>(xv)[2 * static_cast<size_t>(i) + 1];
+      reinterpret_cast<float4*>(yv)[2 * static_cast<size_t>(i)] = make_float4(a.x + rr[0], a.y + rr[1], a.z + rr[2], a.w + rr[3]);
+      reinterpret_cast<float4*>(yv)[2 * static_cast<size_t>(i) + 1] = make_float4(bq.x + rr[4], bq.y + rr[5], bq.z + rr[6], bq.w + rr[7]);
+    }
+  }
+}
+
+extern "C" int tfmq_row_broadcast_add(tfmq_handle h, const void* x, const float* r, int B, long T, int C, int x_f16, void* y, void* stream) {
+  TFMQ_CHECK_ARG(h, h && x && r && y && B > 0 && T > 0 && C > 0 && C % 8 == 0, "row_broadcast_add: bad argument");
+  const long total8 = static_cast<long>(B) * T * (C / 8);
+  TFMQ_CHECK_ARG(h, total8 < (1L << 32), "row_broadcast_add: more than 2^32 items");
+  int blocks = ceil_div(total8, 256);
+  if (blocks > h->cu_count * 16) blocks = h->cu_count * 16;
+  const unsigned c8 = static_cast<unsigned>(C / 8), tc8 = static_cast<unsigned>(T * c8);
+  if (x_f16) hipLaunchKernelGGL(k_row_broadcast_add<true>, dim3(blocks), dim3(256), 0, as_stream(stream), x, r, static_cast<unsigned>(total8), tc8, c8, y);
+  else hipLaunchKernelGGL(k_row_broadcast_add<false>, dim3(blocks), dim3(256), 0, as_stream(stream), x, r, static_cast<unsigned>(total8), tc8, c8, y);
+  TFMQ_LAUNCH_CHECK(h);
+  return TFMQ_OK;
+}
+
 extern "C" int tfmq_f32_to_f16(tfmq_handle h, const float* x, uint16_t* y, size_t n, void* stream) {
   TFMQ_CHECK_ARG(h, h && x && y, "f32_to_f16: null pointer");
   if (n == 0) return TFMQ_OK;

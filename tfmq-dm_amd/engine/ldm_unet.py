@@ -265,11 +265,28 @@ class LdmUNetEngine(DdimUNetEngine):
             o = self._quant_in(to_out, o)
         return self._tok(to_out, o, residual=x_res, **self._o16())
 
+    def _attn2_single_token(self, p, ctx, x):
+        """Cross attention over a context of ONE token (the class embedding of the class-conditional LDM): the softmax over one key
+        is exactly 1, so every query's attention output is to_v(context) of its batch item, to_out of it is one row per batch item
+        and the block adds that row to every token -- what CrossAttention.forward (ldm/modules/attention.py:168-194) computes, without
+        norm2 / to_q / to_k / the attention kernel, whose values cannot reach the output.  (Activation calibration runs the whole
+        block: the quantizers of to_q / to_k still see their inputs.)"""
+        L = self.layers
+        lv, to_out = L[p + ".to_v"], L[p + ".to_out.0"]
+        B, T, Cc = x.shape
+        v = self._tok(lv, self._quant_in(lv, ctx))                 # [B, 1, C] fp32
+        r = self._tok(to_out, self._quant_in(to_out, v))           # [B, 1, C] fp32: to_out(v) + bias
+        return ops.row_broadcast_add(x, r.reshape(B, Cc))
+
     def _tblock(self, p, x, ctx, out_aq=None):
         L = self.layers
         q1 = self.fused_qkv.get(p + ".attn1", L[p + ".attn1.to_q"])
         x = self._attention(p + ".attn1", self._ln(p + ".norm1", x, q1), None, x, True)
-        x = self._attention(p + ".attn2", self._ln(p + ".norm2", x, L[p + ".attn2.to_q"]), ctx, x, False)
+        if (ctx is not None and ctx.shape[1] == 1 and self.calib is None and x.shape[-1] % 8 == 0
+                and os.environ.get("TFMQ_SINGLE_CTX_TOKEN", "1") != "0"):
+            x = self._attn2_single_token(p + ".attn2", ctx, x)
+        else:
+            x = self._attention(p + ".attn2", self._ln(p + ".norm2", x, L[p + ".attn2.to_q"]), ctx, x, False)
         ff0, ff2 = L[p + ".ff.net.0.proj"], L[p + ".ff.net.2"]
         gp = self.geglu_fused.get(p + ".ff.net.0.proj")
         if gp is not None and self.calib is None:

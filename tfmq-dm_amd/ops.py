@@ -655,6 +655,20 @@ def f16_dma_ok(cin: int, kh: int, kw: int) -> bool:
     return cin % 32 == 0 and kh * kw <= 9
 
 
+def row_broadcast_add(x: torch.Tensor, r: torch.Tensor) -> torch.Tensor:
+    """x [B, T, C] (fp16 or fp32) + r [B, C] (fp32) broadcast over the tokens, fp32 arithmetic, x's dtype (tfmq_row_broadcast_add)."""
+    d = _dev(x)
+    if x.dtype not in (torch.float16, torch.float32) or not x.is_contiguous():
+        raise TfmqError("row_broadcast_add: x must be contiguous fp16 or fp32")
+    _chk(r, torch.float32, "r")
+    B, T, Cc = x.shape[0], x.numel() // (x.shape[0] * x.shape[-1]), x.shape[-1]
+    if tuple(r.shape) != (B, Cc) or Cc % 8:
+        raise TfmqError("row_broadcast_add: r must be [B, C], C % 8 == 0")
+    y = _alloc_like(x)
+    handle(d).call("row_broadcast_add", _p(x), _p(r), B, T, Cc, int(x.dtype == torch.float16), _p(y), _stream(d))
+    return y
+
+
 def to_half(x: torch.Tensor) -> torch.Tensor:
     """fp32 -> fp16 copy (round to nearest even) for an un-quantised conv whose producer cannot write fp16 itself."""
     d = _dev(x)
