@@ -133,3 +133,31 @@ def test_attention_f16_padded_keys(ops):
     out, _ = ops.attention_f16(q.half().to(DEV), kp.half().to(DEV), vp.transpose(1, 2).contiguous().half().to(DEV), heads, scale,
                                n_keys=Tk)
     assert maxnorm(out.cpu(), ref) <= 3e-3
+
+
+@pytest.mark.parametrize("B,T,cin,C", [(2, 256, 128, 128), (1, 64, 64, 320), (2, 100, 448, 448)])
+def test_f16_qkv_conv_writes_v_transposed_on_the_direct_kernel(ops, B, T, cin, C):
+    """The un-quantised fused q|k|v conv (LDM AttentionBlock, FP state of the SpatialTransformer): fp16 rows for q | k and V^T for v,
+    from the register-direct pointwise kernel on fp16 operands -- bit-identical to the tile kernel's output."""
+    import tfmq_dm_amd.ops as _o
+    if (2 * C) % 128:
+        pytest.skip("transposed region must start at a multiple of 128 channels")
+    gen = torch.Generator().manual_seed(C + T)
+    x = torch.randn(B, T, 1, cin, generator=gen).to(DEV).half()
+    w = (torch.randn(3 * C, cin, generator=gen) * (2.0 / cin ** 0.5)).to(DEV)
+    b = (torch.randn(3 * C, generator=gen) * 0.1).to(DEV)
+    pf = ops.pack_w_f16(w, b)
+    outs = {}
+    for tile in (1, 6):
+        ops.set_conv_autotune({})
+        orig = _o._tune_conv
+        try:
+            _o._tune_conv = lambda h, name, kind, d, dsc, t=tile: t
+            outs[tile] = ops.conv2d_f16(x, pf, out_f16=True, t_col0=2 * C)
+        finally:
+            _o._tune_conv = orig
+            ops.set_conv_autotune(None)
+    (y1, vt1), (y6, vt6) = outs[1], outs[6]
+    assert torch.equal(y1[..., :2 * C], y6[..., :2 * C]) and torch.equal(vt1, vt6)
+    ref = torch.nn.functional.linear(x.float().reshape(B, T, cin), w.half().float(), b)
+    assert float((vt6.float().transpose(1, 2) - ref[..., 2 * C:]).abs().max()) <= 2e-3 * float(ref.abs().max())

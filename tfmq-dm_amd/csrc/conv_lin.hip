@@ -943,7 +943,8 @@ bool launch_conv_lin_f16(tfmq_handle h, ConvP& p, hipStream_t st) {
   if (d.KH != 1 || d.KW != 1 || d.stride != 1 || d.up2x || d.pad_t != 0 || d.pad_l != 0 || d.Ho != d.H || d.Wo != d.W) return false;
   if (!d.x_f16 || d.Cin % 32 != 0 || p.cin_pad != d.Cin || static_cast<size_t>(d.B) * d.H * d.W * d.Cin * 2 >= (static_cast<size_t>(1) << 31)) return false;
   if (d.x2 && (d.cin1 <= 0 || d.cin1 >= d.Cin || d.cin1 % 32 != 0)) return false;
-  if (d.out_mode != TFMQ_OUT_F16 || d.rowadd || d.yt || (d.Cout & 7) != 0 || ((d.ldy | d.y_coff) & 7) != 0) return false;
+  if (d.out_mode != TFMQ_OUT_F16 || d.rowadd || (d.Cout & 7) != 0 || ((d.ldy | d.y_coff) & 7) != 0) return false;
+  if (d.yt && (d.residual || d.stats || d.t_col0 % 128 != 0)) return false;       // transposed V^T region: as the w4a8 launcher
   if (d.residual && !d.res_f16) return false;
   if (d.stats && 128 % d.stats_seg != 0) return false;
   (void)h;

@@ -439,8 +439,8 @@ def _tune_conv(h, name, kind, d, dsc):
         # (7 = TFMQ_TILE_STREAM and 8 = TFMQ_TILE_PERSIST, the persistent variants, are selectable but not candidates: measured
         # slower than 6 on the SD shapes -- DESIGN.md section 4)
     if (kind == "f16" and dsc.x_f16 and dsc.KH == 1 and dsc.KW == 1 and dsc.stride == 1 and not dsc.up2x and dsc.Cin % 32 == 0
-            and dsc.Cout % 8 == 0 and dsc.out_mode == 1 and not dsc.rowadd and not dsc.yt):
-        cands.append(6)             # the same register-direct kernel on fp16 operands (skip-connection 1x1 convs)
+            and dsc.Cout % 8 == 0 and dsc.out_mode == 1 and not dsc.rowadd and not (dsc.yt and (dsc.residual or dsc.stats))):
+        cands.append(6)             # the same register-direct kernel on fp16 operands (skip-connection 1x1 convs, un-quantised q|k|v)
     best, best_ms = 0, None
     e0, e1 = C.c_int(), C.c_int()
     h.call("event_create", C.byref(e0))
