@@ -161,3 +161,71 @@ def test_f16_qkv_conv_writes_v_transposed_on_the_direct_kernel(ops, B, T, cin, C
     assert torch.equal(y1[..., :2 * C], y6[..., :2 * C]) and torch.equal(vt1, vt6)
     ref = torch.nn.functional.linear(x.float().reshape(B, T, cin), w.half().float(), b)
     assert float((vt6.float().transpose(1, 2) - ref[..., 2 * C:]).abs().max()) <= 2e-3 * float(ref.abs().max())
+
+
+def _ref64(q, k, v, heads, scale):
+    B, Tq, C = q.shape
+    Tk, d = k.shape[1], C // heads
+    qh = q.double().reshape(B, Tq, heads, d).permute(0, 2, 1, 3)
+    kh = k.double().reshape(B, Tk, heads, d).permute(0, 2, 1, 3)
+    vh = v.double().reshape(B, Tk, heads, d).permute(0, 2, 1, 3)
+    return (torch.softmax(qh @ kh.transpose(-1, -2) * scale, -1) @ vh).permute(0, 2, 1, 3).reshape(B, Tq, C).float()
+
+
+@pytest.mark.parametrize("B,heads,T", [(1, 2, 1024), (2, 8, 256), (1, 1, 128), (1, 3, 384)])
+def test_attention_d40_pipelined_kernel(ops, B, heads, T):
+    """The software-pipelined d = 40 self-attention kernel (k_attention_d40: Tq, Tk multiples of 128) against a float64
+    reference on fp16-rounded operands and against the kernel it replaces (TFMQ_ATTN_PIPE=0 selects that one at library
+    load; here the ragged-key entry n_keys = Tk - 8 + padding is what still takes it).  Bar 3e-3 max-normalised, as for
+    every fp16-operand attention; the two kernels take the same exponentials against shifts that may differ -> 1e-3."""
+    d = 40
+    gen = torch.Generator().manual_seed(T + heads)
+    C = heads * d
+    q = torch.randn(B, T, C, generator=gen).half().float()
+    k = torch.randn(B, T, C, generator=gen).half().float()
+    v = torch.randn(B, T, C, generator=gen).half().float()
+    scale = d ** -0.5
+    ref = _ref64(q, k, v, heads, scale)
+    ad, az = O.minmax(ref, 256)
+    vt = v.transpose(1, 2).contiguous().half().to(DEV)
+    out, yq = ops.attention_f16(q.half().to(DEV), k.half().to(DEV), vt, heads, scale, ops.qsel(qtab(ad, az)))
+    assert maxnorm(out.cpu(), ref) <= 1.5e-3
+    assert torch.equal(yq.cpu().float() + 128, O.quant_index(out.cpu(), ad, az, 256))
+    # the tile-at-a-time kernel on the same operands (72 padding keys, masked: the ragged-tail entry never takes the pipelined kernel)
+    kp = torch.cat([k, torch.full((B, 72, C), 30.0)], 1)
+    vp = torch.cat([v, torch.full((B, 72, C), 1e4)], 1)
+    old, _ = ops.attention_f16(q.half().to(DEV), kp.half().to(DEV), vp.transpose(1, 2).contiguous().half().to(DEV), heads, scale, n_keys=T)
+    assert maxnorm(out.cpu(), old.cpu()) <= 1e-3
+
+
+@pytest.mark.parametrize("spike_tile,gain", [(0, 40.0), (3, 40.0), (5, 400.0), (7, -60.0)])
+def test_attention_d40_rescale_branch(ops, spike_tile, gain):
+    """Force the rare branches of the folded softmax shift (cdna guide rule 26: a refcheck on bounded random data never takes
+    them): one key of a chosen 64-key tile is aligned with a block of queries so that their scores jump by `gain` there
+    (far above the 2^8 slack of the shift -> re-base, O / pending P / next scores rescaled exactly once), or every score of
+    the first tile is far BELOW zero (gain < 0: the first tile sets the shift downwards, nothing underflows)."""
+    d, heads, B, T = 40, 2, 1, 512
+    gen = torch.Generator().manual_seed(11 + spike_tile)
+    C = heads * d
+    q = torch.randn(B, T, C, generator=gen)
+    k = torch.randn(B, T, C, generator=gen)
+    v = torch.randn(B, T, C, generator=gen)
+    scale = d ** -0.5
+    if gain > 0:
+        key = spike_tile * 64 + 17
+        u = torch.randn(d, generator=gen)
+        u = u / u.norm()
+        for hd in range(heads):
+            k[0, key, hd * d:(hd + 1) * d] = u * (gain / scale) ** 0.5
+            q[0, 40:200, hd * d:(hd + 1) * d] = u * (gain / scale) ** 0.5 + 0.1 * q[0, 40:200, hd * d:(hd + 1) * d]
+    else:           # all scores of queries 0..127 strongly negative in the first tiles, ordinary later
+        for hd in range(heads):
+            u = torch.ones(d) / d ** 0.5
+            q[0, :128, hd * d:(hd + 1) * d] = u * (-gain / scale) ** 0.5
+            k[0, :128, hd * d:(hd + 1) * d] = -u * (-gain / scale) ** 0.5 + 0.05 * k[0, :128, hd * d:(hd + 1) * d]
+    q, k, v = q.half().float(), k.half().float(), v.half().float()
+    ref = _ref64(q, k, v, heads, scale)
+    vt = v.transpose(1, 2).contiguous().half().to(DEV)
+    out, _ = ops.attention_f16(q.half().to(DEV), k.half().to(DEV), vt, heads, scale)
+    assert torch.isfinite(out).all()
+    assert maxnorm(out.cpu(), ref) <= 3e-3

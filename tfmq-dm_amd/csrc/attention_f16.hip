@@ -10,6 +10,7 @@
 //     then hold 8 CONSECUTIVE keys per 16-key MFMA step, so the V^T fragment is one ds_read_b128;
 //   * exp2 with the softmax scale folded in, running-max rescale of O skipped when no lane's max moved.
 #include "common.hpp"
+#include <cstdlib>
 #include <type_traits>
 
 typedef float v16f __attribute__((ext_vector_type(16)));
@@ -337,6 +338,424 @@ __global__ __launch_bounds__(256, (NT <= 2 && FOLD) ? 4 : 1) void k_attention_h(
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// K10p: the d = 40 self-attention (SD v1 at 64x64: T = 4096, 8 heads -- the largest single kernel of the sampling step)
+// as a SOFTWARE-PIPELINED loop.  Same operand roles, fold of the softmax shift into the score MFMA and ones-row
+// denominator as k_attention_h<3, 2, 40, true>; what changes is the schedule.  In k_attention_h a wave runs
+// scores -> softmax -> P V of one key tile as ONE dependence chain (every PV MFMA waits for the ds_read issued right
+// before it, the softmax waits for the score MFMAs, a 17-deep max chain, an LDS round trip for the lane exchange), and
+// measured MFMA time + VALU time add up: 4.06 ms at UNet batch 128.  scratch/ubench/mfma_valu_overlap.hip: on one SIMD a
+// v_mfma_f32_32x32x16_f16 (15 ns) hides ~5 plain VALU instructions or ~2.5 v_exp_f32 of the waves resident there, but only
+// when they sit next to it in the instruction streams.  Here iteration t of a wave holds three INDEPENDENT pieces of work,
+//
+//       P V of tile t-1        (8 MFMAs, operands: the packed P of the previous iteration, V^T(t-1) fragments read then)
+//       softmax of tile t      (VALU: max tree, 32 exp2, 16 cvt_pk; input: the scores computed in iteration t-1)
+//       scores of tile t+1     (6 MFMAs, K(t+1) fragments)
+//
+// so every MFMA has VALU work of the same wave beside it that does not wait for it.  K and V^T tiles arrive by LDS-DMA
+// (global_load_lds_dwordx4: no staging registers, no ds_write) into rings of four buffers, K three tiles ahead of its
+// use and V^T two, with COUNTED waits (only the batch issued one iteration earlier must have landed); the V^T fragments
+// of the next iteration are read before the barrier, so the first MFMAs behind it wait for nothing.  One barrier per
+// tile; 2 waves per SIMD (two 4-wave blocks per CU).
+//
+// LDS image (lane-linear DMA destinations, so the layouts are chosen on the SOURCE side):
+//   K tile   64 rows x 80 B (5 pieces, no padding); row rho holds key swap_bits_2_3(rho) (P^T fragments = 8 consecutive
+//            keys).  80-byte rows are conflict-free for ds_read_b128 (5 rho mod 16 is a bijection on each lane group).
+//            The third k-step (channels 32..47) reads channels 32..39 in the lower lane half; the upper half -- the
+//            padding columns 40..47, of which column 40 carries the folded shift -- reads a constant piece {1, 0 x 7}.
+//   V^T tile 64 rows x 128 B (rows 0..39 by DMA, row 40 = ones, rows 41..63 zero); slot s of row r holds the piece
+//            s ^ ((r >> 1) & 7): conflict-free for the 16-lane groups of ds_read_b128.
+// The rescale decision of tile t (some query's score above the shift by more than 2^8) sits between the P V MFMAs and the
+// score MFMAs: O *= alpha after P V(t-1) is complete, the exponentials of tile t already taken against the old shift are
+// taken again, the others get the new shift, and the scores of tile t+1 are computed with the new Q column.
+// v_max3_f32 without the canonicalising v_max_f32 x, x the compiler puts in front of fmaxf on MFMA outputs (6 per tile)
+__device__ __forceinline__ float vmax3(float a, float b, float c) {
+  float r;
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+__device__ __forceinline__ void glds16_s(const void* sbase, unsigned voff, unsigned lds_dst) {
+  // lane l: 16 bytes from sbase + voff(l) -> LDS byte lds_dst + 16 l
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(voff), "s"(sbase), "s"(lds_dst)
+               : "memory");
+}
+
+// (Measured and dropped: the P V accumulator in AccVGPRs -- inline-asm MFMAs with "+a" operands; in scratch/ubench/mfma_valu_overlap.hip six
+// plain VALU instructions hide beside such an MFMA against four beside the arch-VGPR form.  In this kernel it is 4 % SLOWER (3.89 vs 3.72 ms):
+// the compiler schedules nothing around opaque asm statements, and with AccVGPRs in use it splits a 256-register budget 128 : 128.)
+// DBG (timing-only ablations, results are garbage): 1 no exp2, 2 no PV MFMAs, 4 no score MFMAs, 8 no fragment reads, 16 no max tree,
+// 32 no fp16 packing, 64 no DMA, 128 no sched_group_barrier, 256 no barrier / waits
+// NW = waves per block (32 queries each): 4, or 8 -- half the DMA instructions and L2 -> LDS bytes per query, one barrier for both waves of a SIMD
+template <int NW, int DBG = 0, int OCC = 2>
+__global__ __launch_bounds__(64 * NW, OCC) void k_attention_d40(AttnHP p) {
+  constexpr int NTH = 64 * NW, QB = 32 * NW;
+  constexpr int NSLOT = (10 + NW - 1) / NW, NFULL = 10 % NW;      // DMA wave-instructions per wave: NSLOT for waves < NFULL, else NSLOT - 1
+  constexpr int KROW = 80, KSUB = 32 * KROW, KBUF = 64 * KROW;   // 2560, 5120
+  constexpr int ONES = 4 * KBUF;                                // constant pieces at ONES, ONES + KSUB
+  constexpr int VBASE = 23552, VROW = 128, VBUF = 64 * VROW;    // 8192
+  constexpr int LDS_BYTES = VBASE + 4 * VBUF;                   // 56320
+  constexpr int NE1 = 20;                                       // exponentials taken before the rescale decision
+  __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = lane & 31, hh = lane >> 5;
+  int bid = blockIdx.x;
+  {
+    const int nb = gridDim.x, xcd = bid & 7, qn = nb >> 3, r = nb & 7;
+    bid = (xcd < r ? xcd * (qn + 1) : r * (qn + 1) + (xcd - r) * qn) + (bid >> 3);
+  }
+  const int nqb = p.Tq / QB;
+  const int bh = bid / nqb;
+  const int b = bh / p.heads, hd = bh % p.heads;
+  const int q0 = (bid - bh * nqb) * QB;
+  constexpr int d = 40;
+
+  for (int i = tid; i < LDS_BYTES / 16; i += NTH) reinterpret_cast<uint4*>(smem)[i] = make_uint4(0, 0, 0, 0);
+
+  // ---- Q fragments, pre-multiplied by scale * log2(e) (rounded once to fp16); column 40 will carry -shift
+  v8h qf[3];
+  {
+    const int qrow = q0 + wid * 32 + j;
+    const float c2q = p.scale * 1.44269504088896340736f;
+#pragma unroll
+    for (int ks = 0; ks < 3; ++ks) {
+      uint4 v = make_uint4(0, 0, 0, 0);
+      const int c = ks * 16 + hh * 8;
+      if (c < d) v = *reinterpret_cast<const uint4*>(p.q + (static_cast<size_t>(b) * p.Tq + qrow) * p.ldq + hd * d + c);
+      qf[ks] = *reinterpret_cast<v8h*>(&v);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) qf[ks][e] = static_cast<_Float16>(static_cast<float>(qf[ks][e]) * c2q);
+    }
+#pragma unroll
+    for (int ks = 0; ks < 3; ++ks) asm volatile("" : "+v"(qf[ks]));
+  }
+
+  // ---- DMA plan: wave-instructions 0..4 = a K tile (320 pieces), 5..9 = a V^T tile; wave w issues w, w + NW, ...
+  const unsigned char* kptr = reinterpret_cast<const unsigned char*>(p.k + static_cast<size_t>(b) * p.Tks * p.ldk + hd * d);
+  const unsigned char* vptr = reinterpret_cast<const unsigned char*>(p.vt + (static_cast<size_t>(b) * p.heads + hd) * d * p.Tks);
+  const size_t kstep = static_cast<size_t>(64) * p.ldk * 2;     // bytes per K tile (a V^T tile: 128)
+  unsigned dma_off[NSLOT], slot_dst[NSLOT];
+  bool slot_k[NSLOT];
+#pragma unroll
+  for (int s = 0; s < NSLOT; ++s) {
+    const int id = wid + NW * s;
+    slot_k[s] = id < 5;
+    if (id < 5) {
+      const int n = id * 64 + lane, rho = n / 5, c = n - rho * 5;
+      const int key = (rho & 0x33) | ((rho & 4) << 1) | ((rho & 8) >> 1);
+      dma_off[s] = static_cast<unsigned>(key * p.ldk * 2 + c * 16);
+      slot_dst[s] = id * 1024;
+    } else {
+      const int n = (id - 5) * 64 + lane, r = n >> 3, sl = n & 7;
+      dma_off[s] = static_cast<unsigned>(r * p.Tks * 2 + ((sl ^ ((r >> 1) & 7)) << 4));
+      slot_dst[s] = VBASE + (id - 5) * 1024;
+    }
+  }
+  const bool slot2 = wid < NFULL;  // the last slot exists only for the first waves
+  const unsigned lds0 = static_cast<unsigned>(reinterpret_cast<uintptr_t>(smem));   // LDS byte address of the image
+  unsigned slot_lds[NSLOT];        // wave-uniform LDS destinations, in SGPRs (M0 is written from them)
+#pragma unroll
+  for (int s = 0; s < NSLOT; ++s) slot_lds[s] = __builtin_amdgcn_readfirstlane(lds0 + slot_dst[s]);
+  auto dma = [&](const unsigned char* kp, const unsigned char* vp, int kb, int vb, bool do_k, bool do_v) {
+#pragma unroll
+    for (int s = 0; s < NSLOT; ++s) {
+      if (s == NSLOT - 1 && !slot2) continue;
+      const bool isk = slot_k[s];          // wave-uniform
+      if (isk ? do_k : do_v) glds16_s(isk ? kp : vp, dma_off[s], slot_lds[s] + (isk ? kb * KBUF : vb * VBUF));
+    }
+  };
+
+  // ---- fragment addresses (bytes; + buffer offset as an immediate)
+  const unsigned ka = j * KROW + hh * 16;                         // k-steps 0, 1 at +0, +32
+  unsigned ka2[4];                                                // k-step 2: the upper lane half reads the constant piece
+#pragma unroll
+  for (int kb = 0; kb < 4; ++kb) ka2[kb] = hh ? static_cast<unsigned>(ONES - kb * KBUF) : static_cast<unsigned>(j * KROW + 64);
+  unsigned va[4];
+  {
+    const int g = (j >> 1) & 7;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) va[u] = VBASE + j * VROW + (((2 * u + hh) ^ g) << 4);      // row j + 32 tt: + 4096 tt, same g
+  }
+
+  float m_run = 0.0f;
+  v16f o[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[t][r] = 0.0f;
+  unsigned pp[16];                 // packed fp16 P of the previous tile: pp[4 u + e] = keys 16 u + 8 hh + 2 e, +1
+#pragma unroll
+  for (int i = 0; i < 16; ++i) pp[i] = 0u;
+  v8h vf[4][2];                    // V^T fragments of the tile whose P is in pp
+#pragma unroll
+  for (int u = 0; u < 4; ++u)
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) vf[u][tt] = qf[0];   // finite; multiplied by P = 0 in the first iteration
+
+  __syncthreads();                 // zero fill done
+  if (tid < 2) *reinterpret_cast<uint4*>(smem + ONES + tid * KSUB) = make_uint4(0x00003C00u, 0, 0, 0);
+  if (tid >= 64 && tid < 96) {
+    const uint4 ones = make_uint4(0x3C003C00u, 0x3C003C00u, 0x3C003C00u, 0x3C003C00u);
+    *reinterpret_cast<uint4*>(smem + VBASE + ((tid - 64) >> 3) * VBUF + 40 * VROW + ((tid - 64) & 7) * 16) = ones;
+  }
+  const int nt = p.Tk >> 6;        // a multiple of 4
+  dma(kptr, vptr, 0, 0, true, true);                          // K(0), V(0)
+  dma(kptr + kstep, vptr + 128, 1, 1, true, true);            // K(1), V(1)
+  dma(kptr + 2 * kstep, vptr, 2, 0, true, false);             // K(2)
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+
+  auto row_max = [&](const v16f (&s)[2]) {
+    float m0 = vmax3(s[0][0], s[0][1], s[0][2]), m1 = vmax3(s[0][3], s[0][4], s[0][5]);
+    float m2 = vmax3(s[1][0], s[1][1], s[1][2]), m3 = vmax3(s[1][3], s[1][4], s[1][5]);
+    m0 = vmax3(m0, s[0][6], s[0][7]);   m1 = vmax3(m1, s[0][8], s[0][9]);
+    m2 = vmax3(m2, s[1][6], s[1][7]);   m3 = vmax3(m3, s[1][8], s[1][9]);
+    m0 = vmax3(m0, s[0][10], s[0][11]); m1 = vmax3(m1, s[0][12], s[0][13]);
+    m2 = vmax3(m2, s[1][10], s[1][11]); m3 = vmax3(m3, s[1][12], s[1][13]);
+    m0 = vmax3(m0, s[0][14], s[0][15]); m2 = vmax3(m2, s[1][14], s[1][15]);
+    m0 = vmax3(m0, m1, m2);
+    m0 = vmax3(m0, m3, m3);
+    const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(m0), __float_as_uint(m0), false, false);   // lane ^ 32: the query's other 32 keys
+    return vmax3(__uint_as_float(sw[0]), __uint_as_float(sw[1]), __uint_as_float(sw[1]));
+  };
+  constexpr int ksb = 2, qe = 0;       // Q column 40 = k-step 2, upper lane half, element 0
+
+  v16f sA[2], sB[2];
+  {   // scores of tile 0; its row maximum is the first shift (fp16-representable), in both directions
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sA[sub][r] = 0.0f;
+      const v8h k0 = *reinterpret_cast<const v8h*>(smem + ka + sub * KSUB), k1 = *reinterpret_cast<const v8h*>(smem + ka + sub * KSUB + 32);
+      const v8h k2 = *reinterpret_cast<const v8h*>(smem + ka2[0] + sub * KSUB);
+      sA[sub] = __builtin_amdgcn_mfma_f32_32x32x16_f16(k0, qf[0], sA[sub], 0, 0, 0);
+      sA[sub] = __builtin_amdgcn_mfma_f32_32x32x16_f16(k1, qf[1], sA[sub], 0, 0, 0);
+      sA[sub] = __builtin_amdgcn_mfma_f32_32x32x16_f16(k2, qf[2], sA[sub], 0, 0, 0);
+    }
+    const float mx = row_max(sA);
+    m_run = static_cast<float>(static_cast<_Float16>(mx));
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sA[sub][r] -= m_run;
+    if (hh) qf[ksb][qe] = static_cast<_Float16>(-m_run);
+  }
+
+  // Iteration t (B = t & 3): sc = scores of tile t (in), sn = scores of tile t+1 (out).  DMA of K(t+3) -> K buffer (t+3)&3
+  // and V^T(t+2) -> V buffer (t+2)&3; K(t+1) fragments from K buffer (t+1)&3; vf / pp hold V^T(t-1) / P(t-1) on entry and
+  // V^T(t) (from V buffer t&3) / P(t) on exit.  COUNTED: only the batch of the previous iteration must have landed.
+  auto iter = [&](v16f (&sc)[2], v16f (&sn)[2], auto b_tag, auto kdma_tag, auto vdma_tag, auto last_tag, auto counted_tag,
+                  const unsigned char* kp, const unsigned char* vp) {
+    constexpr int B = decltype(b_tag)::value, KB = (B + 1) & 3;
+    constexpr bool KDMA = decltype(kdma_tag)::value, VDMA = decltype(vdma_tag)::value, LAST = decltype(last_tag)::value;
+    constexpr bool COUNTED = decltype(counted_tag)::value;
+    if constexpr (!(DBG & 64)) dma(kp, vp, (B + 3) & 3, (B + 2) & 3, KDMA, VDMA);
+    v8h kf[2][3];
+    if constexpr (!LAST) {
+#pragma unroll
+      for (int sub = 0; sub < 2; ++sub) {
+        if constexpr (DBG & 8) {
+          kf[sub][0] = qf[0]; kf[sub][1] = qf[1]; kf[sub][2] = qf[2];
+        } else {
+          kf[sub][0] = *reinterpret_cast<const v8h*>(smem + KB * KBUF + ka + sub * KSUB);
+          kf[sub][1] = *reinterpret_cast<const v8h*>(smem + KB * KBUF + ka + sub * KSUB + 32);
+          kf[sub][2] = *reinterpret_cast<const v8h*>(smem + KB * KBUF + ka2[KB] + sub * KSUB);
+        }
+      }
+    }
+    // ---- block 1: P V of tile t-1  ||  row maximum of tile t, its first NE1 exponentials
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      v8h bp;
+      unsigned* bw = reinterpret_cast<unsigned*>(&bp);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) bw[e] = pp[4 * u + e];
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt) {
+        if constexpr (DBG & 2) { o[tt][u] += static_cast<float>(vf[u][tt][0]) + __uint_as_float(bw[tt]); }
+        else o[tt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[u][tt], bp, o[tt], 0, 0, 0);
+      }
+    }
+    float mx;
+    if constexpr (DBG & 16) mx = sc[0][3] + sc[1][5];
+    else mx = row_max(sc);
+    float pe[32];                          // P in fp32
+#pragma unroll
+    for (int i = 0; i < NE1; ++i) {
+      if constexpr (DBG & 1) pe[i] = sc[i >> 4][i & 15];
+      else pe[i] = __builtin_amdgcn_exp2f(sc[i >> 4][i & 15]);
+    }
+    if constexpr (DBG & 128) {
+      // interleave: the K fragment reads first, then per MFMA two exponentials and three plain VALU instructions of the maximum tree
+      __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
+#define TFMQ_SGB1(NT_) __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x400, NT_, 0); __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+      TFMQ_SGB1(3) TFMQ_SGB1(3) TFMQ_SGB1(3) TFMQ_SGB1(3) TFMQ_SGB1(2) TFMQ_SGB1(2) TFMQ_SGB1(2) TFMQ_SGB1(2)
+    }
+    // (the exponentials are pinned in front of the branch: the compiler would otherwise sink them into both of its arms, behind the MFMAs)
+#pragma unroll
+    for (int i = 0; i < NE1; ++i) asm volatile("" : "+v"(pe[i]));
+    // ---- the rescale decision (rare)
+    if (__builtin_amdgcn_ballot_w64(mx > 8.0f) != 0) {
+      const float m_new = mx > 8.0f ? static_cast<float>(static_cast<_Float16>(m_run + mx)) : m_run;
+      const float delta = m_new - m_run;                 // exact: both fp16-representable
+      const float alpha = __builtin_amdgcn_exp2f(-delta);
+#pragma unroll
+      for (int i = 0; i < 32; ++i) sc[i >> 4][i & 15] -= delta;
+#pragma unroll
+      for (int i = 0; i < NE1; ++i) pe[i] = __builtin_amdgcn_exp2f(sc[i >> 4][i & 15]);
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[tt][r] *= alpha;
+      m_run = m_new;
+      if (hh) qf[ksb][qe] = static_cast<_Float16>(-m_run);
+    }
+    // ---- block 2: scores of tile t+1  ||  the other exponentials, packing of P; V^T(t) fragments for the next iteration
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt) {
+        if constexpr (!(DBG & 8)) vf[u][tt] = *reinterpret_cast<const v8h*>(smem + B * VBUF + va[u] + tt * 32 * VROW);
+      }
+    if constexpr (!LAST) {
+#pragma unroll
+      for (int sub = 0; sub < 2; ++sub) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sn[sub][r] = 0.0f;
+#pragma unroll
+        for (int ks = 0; ks < 3; ++ks) {
+          if constexpr (DBG & 4) sn[sub][ks] += static_cast<float>(kf[sub][ks][0]);
+          else sn[sub] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[sub][ks], qf[ks], sn[sub], 0, 0, 0);
+        }
+      }
+    }
+#pragma unroll
+    for (int i = NE1; i < 32; ++i) {
+      if constexpr (DBG & 1) pe[i] = sc[i >> 4][i & 15];
+      else pe[i] = __builtin_amdgcn_exp2f(sc[i >> 4][i & 15]);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int i0 = 16 * (u >> 1) + 8 * (u & 1) + 2 * e;
+        if constexpr (DBG & 32) pp[4 * u + e] = __float_as_uint(pe[i0]) ^ __float_as_uint(pe[i0 + 1]);
+        else {
+          const __half2 h2 = __floats2half2_rn(pe[i0], pe[i0 + 1]);
+          pp[4 * u + e] = *reinterpret_cast<const unsigned*>(&h2);
+        }
+      }
+    if constexpr (DBG & 128) {
+      __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+      TFMQ_SGB1(2) TFMQ_SGB1(2) TFMQ_SGB1(2) TFMQ_SGB1(2) TFMQ_SGB1(2) TFMQ_SGB1(2)
+    }
+    // The packed P and the fragments are operands of an (empty) volatile statement in front of the barrier: otherwise the compiler
+    // sinks the exponentials, conversions and reads behind the barrier, next to their use in the next iteration.
+    asm volatile(""
+                 : "+v"(pp[0]), "+v"(pp[1]), "+v"(pp[2]), "+v"(pp[3]), "+v"(pp[4]), "+v"(pp[5]), "+v"(pp[6]), "+v"(pp[7]),
+                   "+v"(pp[8]), "+v"(pp[9]), "+v"(pp[10]), "+v"(pp[11]), "+v"(pp[12]), "+v"(pp[13]), "+v"(pp[14]), "+v"(pp[15]),
+                   "+v"(vf[0][0]), "+v"(vf[0][1]), "+v"(vf[1][0]), "+v"(vf[1][1]), "+v"(vf[2][0]), "+v"(vf[2][1]), "+v"(vf[3][0]), "+v"(vf[3][1]));
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (DBG & 256) {
+    } else if constexpr (COUNTED) {
+      if (slot2) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(NSLOT) : "memory");
+      else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(NSLOT - 1) : "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  using I2 = std::integral_constant<int, 2>;
+  using I3 = std::integral_constant<int, 3>;
+  using Y = std::true_type;
+  using N = std::false_type;
+  const unsigned char* kp = kptr + 3 * kstep;     // K(t + 3)
+  const unsigned char* vp = vptr + 256;           // V^T(t + 2)
+  for (int t = 0; t + 4 < nt; t += 4) {
+    iter(sA, sB, I0{}, Y{}, Y{}, N{}, Y{}, kp, vp);
+    iter(sB, sA, I1{}, Y{}, Y{}, N{}, Y{}, kp + kstep, vp + 128);
+    iter(sA, sB, I2{}, Y{}, Y{}, N{}, Y{}, kp + 2 * kstep, vp + 256);
+    iter(sB, sA, I3{}, Y{}, Y{}, N{}, Y{}, kp + 3 * kstep, vp + 384);
+    kp += 4 * kstep;
+    vp += 512;
+  }
+  iter(sA, sB, I0{}, Y{}, Y{}, N{}, N{}, kp, vp);                 // t = nt-4: K(nt-1), V(nt-2)
+  iter(sB, sA, I1{}, N{}, Y{}, N{}, N{}, kp, vp + 128);           // t = nt-3: V(nt-1)
+  iter(sA, sB, I2{}, N{}, N{}, N{}, N{}, kp, vp);                 // t = nt-2
+  iter(sB, sA, I3{}, N{}, N{}, Y{}, N{}, kp, vp);                 // t = nt-1: no scores left to compute
+  // ---- P V of the last tile
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    v8h bp;
+    unsigned* bw = reinterpret_cast<unsigned*>(&bp);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) bw[e] = pp[4 * u + e];
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) o[tt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[u][tt], bp, o[tt], 0, 0, 0);
+  }
+
+  // ---- normalise and store (as k_attention_h): lane (query j, half hh) owns channels t*32 + (r&3) + 8*(r>>2) + 4*hh;
+  // the denominator sits in output row 40 = tile 1, lanes of the lower half, register 4
+  const int qg = q0 + wid * 32 + j;
+  float l_run;
+  {
+    constexpr int lr = 40 % 32, hh_one = (lr >> 2) & 1, r_one = (lr & 3) + 4 * (lr >> 3);
+    const float mine = o[1][r_one];
+    const float other = __shfl_xor(mine, 32, 64);
+    l_run = hh == hh_one ? mine : other;
+  }
+  const float inv = 1.0f / l_run;
+  const bool quant = p.yq != nullptr;
+  float2 qp = make_float2(1.0f, 0.0f);
+  if (quant) qp = load_qparam(p.aq);
+  const size_t tok = static_cast<size_t>(b) * p.Tq + qg;
+#pragma unroll
+  for (int tt = 0; tt < 2; ++tt) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int dc = tt * 32 + 8 * g + 4 * hh;
+      if (dc >= d) continue;
+      float4 v = make_float4(o[tt][4 * g] * inv, o[tt][4 * g + 1] * inv, o[tt][4 * g + 2] * inv, o[tt][4 * g + 3] * inv);
+      if (p.out) *reinterpret_cast<float4*>(p.out + tok * p.ldo + hd * d + dc) = v;
+      if (quant) {
+        char4 c = quant_char4(v.x, v.y, v.z, v.w, make_quantp(qp));
+        *reinterpret_cast<char4*>(p.yq + tok * (static_cast<size_t>(p.heads) * d) + hd * d + dc) = c;
+      }
+    }
+  }
+}
+
+static int launch_attn_d40(tfmq_handle h, const AttnHP& p, void* stream) {
+  static const int nw = getenv("TFMQ_ATTN_PIPE_NW") ? atoi(getenv("TFMQ_ATTN_PIPE_NW")) : 4;
+  if (nw == 8 && p.Tq % 256 == 0) {
+    dim3 grid8(static_cast<unsigned>(p.Tq / 256) * p.B * p.heads);
+#ifdef TFMQ_ATTN_ABLATE
+    static const int dbg8 = getenv("TFMQ_ATTN_DBG") ? atoi(getenv("TFMQ_ATTN_DBG")) : 0;
+#define TFMQ_ABL8(D) if (dbg8 == D) { hipLaunchKernelGGL((k_attention_d40<8, D>), grid8, dim3(512), 0, as_stream(stream), p); TFMQ_LAUNCH_CHECK(h); return TFMQ_OK; }
+    TFMQ_ABL8(1) TFMQ_ABL8(6) TFMQ_ABL8(8) TFMQ_ABL8(64) TFMQ_ABL8(49) TFMQ_ABL8(14) TFMQ_ABL8(78) TFMQ_ABL8(128)
+#endif
+    hipLaunchKernelGGL((k_attention_d40<8>), grid8, dim3(512), 0, as_stream(stream), p);
+    TFMQ_LAUNCH_CHECK(h);
+    return TFMQ_OK;
+  }
+  dim3 grid(static_cast<unsigned>(p.Tq / 128) * p.B * p.heads);
+#ifdef TFMQ_ATTN_ABLATE
+  static const int dbg = getenv("TFMQ_ATTN_DBG") ? atoi(getenv("TFMQ_ATTN_DBG")) : 0;
+#define TFMQ_ABL(D) if (dbg == D) { hipLaunchKernelGGL((k_attention_d40<4, D>), grid, dim3(256), 0, as_stream(stream), p); TFMQ_LAUNCH_CHECK(h); return TFMQ_OK; }
+  TFMQ_ABL(1) TFMQ_ABL(2) TFMQ_ABL(4) TFMQ_ABL(6) TFMQ_ABL(8) TFMQ_ABL(16) TFMQ_ABL(32) TFMQ_ABL(64) TFMQ_ABL(49) TFMQ_ABL(14) TFMQ_ABL(78) TFMQ_ABL(128) TFMQ_ABL(328) TFMQ_ABL(456) TFMQ_ABL(320) TFMQ_ABL(256) TFMQ_ABL(72)
+  if (dbg == 1000) { hipLaunchKernelGGL((k_attention_d40<4, 0, 3>), grid, dim3(256), 0, as_stream(stream), p); TFMQ_LAUNCH_CHECK(h); return TFMQ_OK; }
+#endif
+  hipLaunchKernelGGL((k_attention_d40<4>), grid, dim3(256), 0, as_stream(stream), p);
+  TFMQ_LAUNCH_CHECK(h);
+  return TFMQ_OK;
+}
+
 template <int NKS, int NT, int ONES_ROW = -1, bool FOLD = false>
 static int launch_attn_h(tfmq_handle h, const AttnHP& p, void* stream) {
   constexpr int DPAD = NT * 32;
@@ -367,7 +786,11 @@ extern "C" int tfmq_attention_f16(tfmq_handle h, const uint16_t* q, const uint16
   AttnHP p{reinterpret_cast<const __half*>(q), reinterpret_cast<const __half*>(k), reinterpret_cast<const __half*>(vt),
            ldq, ldk, out, ldo, yq, aq, B, heads, Tq, Tk, Tk_stride, d, scale, 1};
   if (d <= 32) return launch_attn_h<2, 1>(h, p, stream);
-  if (d == 40) return launch_attn_h<3, 2, 40, true>(h, p, stream);  // SD v1 at 64x64
+  if (d == 40) {   // SD v1 at 64x64
+    static const bool pipe = !(getenv("TFMQ_ATTN_PIPE") && atoi(getenv("TFMQ_ATTN_PIPE")) == 0);
+    if (pipe && Tq % 128 == 0 && Tk % 256 == 0) return launch_attn_d40(h, p, stream);
+    return launch_attn_h<3, 2, 40, true>(h, p, stream);
+  }
   if (d <= 48) return launch_attn_h<3, 2>(h, p, stream);
   if (d <= 64) return launch_attn_h<4, 2>(h, p, stream);
   if (d == 80) return launch_attn_h<5, 3, 80>(h, p, stream);  // SD v1 at 32x32
