@@ -1,0 +1,144 @@
+"""TFMQ_EXACT_FP=1 -- the engine's parity-diagnostics mode -- explains the end-to-end numbers of the fast mode.
+
+The fast path runs the layers the reference leaves un-quantised (first / last conv, Downsample and shortcut convs, the FP / weight-only
+states) and every attention matmul on fp16-operand MFMA, where the reference computes them in fp32 (quant/quant_layer.py:306-340,
+quant/quant_block.py:483-500).  Every quantised GEMM, the quantizers, GroupNorm / LayerNorm and the samplers are exact or ~1e-6.  The fast
+mode's 29-30 % of moved activation bins and 2-3e-2 eps rel-L2 (tests/test_engine_*_gpu.py) are therefore claimed to be fp16 operand
+rounding compounding through the quantizers and nothing else.  This file tests that claim: with the same weights, tables and inputs, the
+mode that routes those layers through the exact-fp32 MFMA GEMM (im2col + tfmq_gemm_f32) and exact-fp32 attention (tfmq_gemm_f32 products +
+row softmax) on an fp32 activation stream must make the flips collapse and eps agree with the reference's fixture to rounding.
+
+Yardstick printed and asserted beside every bar: rel_l2(eps_w4a8_ref, eps_fp_ref), the size of the quantisation noise itself in the
+reference -- a deviation of a few percent of THAT is 'within quantisation noise', a deviation of its size is not."""
+import numpy as np
+import pytest
+import torch
+
+import tfmq_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def T(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def nhwc(x):
+    return x.permute(0, 2, 3, 1).contiguous().to(DEV)
+
+
+def nchw(y):
+    return y.permute(0, 3, 1, 2).contiguous().cpu()
+
+
+def rel_l2(a, b):
+    return float((a - b).norm() / b.norm())
+
+
+def maxnorm(a, b):
+    return float((a - b).abs().max() / b.abs().max())
+
+
+CASES = {
+    "ddim": dict(fixture="f7_ddim_tiny", cfg=dict(ch=32, ch_mult=[1, 2], num_res_blocks=1, attn_resolutions=[8], resolution=16)),
+    "ldm": dict(fixture="f11_ldm_tiny", cfg=dict(model_channels=32, num_heads=2, in_channels=4)),
+}
+
+
+def _setup(golden, which, monkeypatch, exact):
+    from tfmq_dm_amd.engine import DdimUNetEngine, LayerQ, LdmUNetEngine
+    case = CASES[which]
+    g = golden(case["fixture"])
+    sd = {k[3:]: T(g[k]) for k in g.files if k.startswith("sd/")}
+    if exact:
+        monkeypatch.setenv("TFMQ_EXACT_FP", "1")
+    else:
+        monkeypatch.delenv("TFMQ_EXACT_FP", raising=False)
+    eng = (DdimUNetEngine if which == "ddim" else LdmUNetEngine)(sd, case["cfg"], DEV)
+    assert eng.exact_fp == exact
+    act_names = sorted(k[3:-6] for k in g.files if k.startswith("aq/") and k.endswith("/delta"))
+    qid = {n: i for i, n in enumerate(act_names)}
+
+    def wq(with_act):
+        return {k[3:-6]: LayerQ(T(g[k]), T(g[f"wq/{k[3:-6]}/zp"]), None, qid.get(k[3:-6]) if with_act else None)
+                for k in g.files if k.startswith("wq/") and k.endswith("/delta")}
+    qtable = torch.tensor([[[float(g[f"aq/{n}/delta"]), float(g[f"aq/{n}/zp"])] for n in act_names]])
+    x, t = T(g["x"]), T(g["t"]).float()
+    args = (nhwc(x), t.to(DEV)) + ((T(g["ctx"]).to(DEV),) if which == "ldm" else ())
+    return g, sd, case["cfg"], eng, wq, qtable, act_names, args
+
+
+def _flip_rates(which, g, sd, cfg, eng, wqd, qtable, act_names, args):
+    import tfmq_dm_amd.ops as ops
+    eng.prepare(wqd, qtable.to(DEV))
+    eng.set_calibration("record", 0)
+    eng.forward(*args)
+    eng.set_calibration(None)
+    owq = {n: {"delta": q.delta.reshape((-1,) + (1,) * (sd[n + ".weight"].dim() - 1)),
+               "zp": q.zp.reshape((-1,) + (1,) * (sd[n + ".weight"].dim() - 1)), "alpha": None} for n, q in wqd.items()}
+    qs = O.QuantSpec(wq=owq, aq={n: (qtable[0, i, 0], qtable[0, i, 1]) for i, n in enumerate(act_names)})
+    qs.trace = {}
+    x, t = T(g["x"]), T(g["t"])
+    with torch.no_grad():
+        if which == "ddim":
+            O.ddim_unet_forward(sd, dict(cfg), x, t, qs)
+        else:
+            O.ldm_unet_forward(sd, dict(cfg), x, t.long(), T(g["ctx"]), qs)
+    rates, flips, total, big = {}, 0, 0, 0
+    for i, n in enumerate(act_names):
+        if i not in eng.observed or n not in qs.trace:
+            continue
+        be = (ops.quantize_act(eng.observed[i].float().contiguous(), ops.qsel(qtable[:, i:i + 1].contiguous().to(DEV))).to(torch.int32) + 128).cpu()
+        bo = qs.trace[n].to(torch.int32)
+        if bo.dim() == 4:
+            bo = bo.permute(0, 2, 3, 1)
+        if bo.numel() == 4 * be.numel():
+            bo = bo[:, ::2, ::2, :]
+        diff = (be - bo.reshape(be.shape)).abs()
+        rates[n] = float((diff > 0).float().mean())
+        flips += int((diff > 0).sum())
+        big += int((diff > 1).sum())
+        total += diff.numel()
+    assert len(rates) >= len(act_names) - 2
+    return rates, flips / total, big / total
+
+
+@pytest.mark.parametrize("which", ["ddim", "ldm"])
+def test_bin_flips_collapse_in_the_exact_mode(golden, monkeypatch, which):
+    res = {}
+    for exact in (False, True):
+        g, sd, cfg, eng, wq, qtable, act_names, args = _setup(golden, which, monkeypatch, exact)
+        rates, overall, big = _flip_rates(which, g, sd, cfg, eng, wq(True), qtable, act_names, args)
+        eps = nchw(eng.forward(*args))
+        res[exact] = (rates, overall, big, rel_l2(eps, T(g["eps_w4a8"])))
+    yard = rel_l2(T(g["eps_w4a8"]), T(g["eps_fp"]))
+    (rf, of, bf, ef), (re_, oe, be, ee) = res[False], res[True]
+    print(f"[{which}] quantisation-noise yardstick rel_l2(eps_w4a8_ref, eps_fp_ref) = {yard:.3e}")
+    print(f"[{which}] fast mode : bins moved {of:.4f} (by more than one: {bf:.4f}), worst layer {max(rf.values()):.3f}, w4a8 eps rel-L2 {ef:.3e} = {ef / yard:.2f} x yardstick")
+    print(f"[{which}] exact mode: bins moved {oe:.4f} (by more than one: {be:.4f}), worst layer {max(re_.values()):.3f}, w4a8 eps rel-L2 {ee:.3e} = {ee / yard:.3f} x yardstick")
+    # the fast mode sits where the round-2 tests found it ...
+    assert 0.05 <= of <= 0.40 and ef <= 3e-2
+    # ... and with fp32 operands in the un-quantised layers and the attention the same engine reproduces the reference's bins:
+    assert oe <= 5e-3, oe                      # <= 0.5 % of all activation bins move (rounding-boundary cases of a different summation order)
+    assert be <= 1e-4, be                      # essentially none by more than one bin
+    assert ee <= 5e-3, ee                      # eps within 5e-3 rel-L2 of the reference's w4a8 eps
+    assert ee <= 0.1 * yard                    # i.e. far inside the quantisation noise, where the fast mode is of its order
+    assert all(r == 0.0 for n, r in re_.items() if n.endswith("temb_proj") or ".emb_layers." in n)
+
+
+@pytest.mark.parametrize("which", ["ddim", "ldm"])
+def test_fp_and_weight_only_states_in_the_exact_mode(golden, monkeypatch, which):
+    """FP and weight-only (w4) eps against the reference's fp32 forward: the fast mode's bar is 1e-2 max-normalised (fp16 operands); the
+    exact mode shows what the rest of the engine contributes: <= 2e-5."""
+    g, sd, cfg, eng, wq, qtable, act_names, args = _setup(golden, which, monkeypatch, True)
+    eng.prepare()
+    e_fp = maxnorm(nchw(eng.forward(*args)), T(g["eps_fp"]))
+    eng.prepare(wq(False))
+    e_w4 = maxnorm(nchw(eng.forward(*args)), T(g["eps_w4"]))
+    print(f"[{which}] exact mode: FP eps max-normalised error {e_fp:.2e}, w4 {e_w4:.2e}")
+    assert e_fp <= 2e-5 and e_w4 <= 2e-5
+    # taps (reconstruction data capture) run the same exact layers
+    taps = {}
+    eng.forward(*args, taps=taps)
+    assert len(taps) > 3

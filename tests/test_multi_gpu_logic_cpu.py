@@ -68,3 +68,79 @@ def test_gloo_world2_allreduce_matches_single_process_emulation(tmp_path):
         assert res["n"] == 24
         np.testing.assert_allclose(res["flat"].numpy(), ref.numpy(), rtol=1e-5, atol=1e-5)
         assert abs(float(res["delta"]) - 1.5) < 1e-6       # (1 + 2) / 2
+
+
+def _lazy_comm_worker(rank, world, port, out_dir):
+    """What a spawned calibration rank does in the reference's order (quant/calibration.py:241-245): rendezvous FIRST, device
+    chosen afterwards.  The RCCL communicator of the C ABI must not be bound at the rendezvous (every rank would still be on
+    device 0: 'Duplicate GPU detected' / a hang) but at the first device all-reduce, to that tensor's device, with the id
+    handed round through the store.  No GPU here: the handle / library calls are recorded by stand-ins."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tfmq-dm_amd"))
+    import types
+    import linklink as link
+    from tfmq_dm_amd import _lib
+    calls = []
+
+    class FakeHandle:
+        comm_world = 0
+
+        def __init__(self, dev):
+            self.dev = dev
+
+        def call(self, name, *a):
+            calls.append((name, self.dev) + tuple(a[1:3] if name == "comm_init" else ()))
+            if name == "comm_init":
+                self.ident = bytes(a[0])
+
+    class FakeLib:
+        @staticmethod
+        def tfmq_comm_unique_id(buf):
+            for i in range(128):
+                buf[i] = (i * 7 + 3) % 251
+            return 0
+
+    _lib._handles.clear()
+
+    def fake_handle(dev=0):
+        if dev not in _lib._handles:
+            _lib._handles[dev] = FakeHandle(dev)
+        return _lib._handles[dev]
+    _lib.handle, _lib.load = fake_handle, (lambda: FakeLib)
+    torch.cuda.is_available = lambda: True
+    real_init = link.dist.init_process_group
+    link.dist.init_process_group = lambda backend=None, **kw: real_init(backend="gloo", **kw)    # "nccl" asked for, gloo underneath
+    link.init_process_group(backend="nccl", init_method=f"tcp://127.0.0.1:{port}", world_size=world, rank=rank)
+    assert calls == [] and link.comm_device() is None          # nothing bound at the rendezvous
+    dev = rank + 2                                             # the device this rank picks afterwards
+
+    class FakeDevTensor:
+        is_cuda, dtype = True, torch.float32
+        device = types.SimpleNamespace(index=dev)
+
+        def is_contiguous(self):
+            return True
+
+        def data_ptr(self):
+            return 4096
+
+        def numel(self):
+            return 8
+    torch.cuda.current_stream = lambda d=None: types.SimpleNamespace(cuda_stream=0)
+    link.allreduce(FakeDevTensor())
+    link.allreduce(FakeDevTensor())
+    h = _lib._handles[dev]
+    torch.save({"calls": calls, "ident": h.ident, "comm_dev": link.comm_device()}, os.path.join(out_dir, f"lazy{rank}.pt"))
+    link.barrier()
+
+
+def test_rccl_communicator_binds_lazily_to_the_tensors_device(tmp_path):
+    world, port = 2, 31000 + (os.getpid() % 2000)
+    mp.start_processes(_lazy_comm_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True, start_method="spawn")
+    res = [torch.load(os.path.join(str(tmp_path), f"lazy{r}.pt")) for r in range(world)]
+    for r in range(world):
+        assert res[r]["comm_dev"] == r + 2
+        names = [c[0] for c in res[r]["calls"]]
+        assert names == ["comm_init", "allreduce_sum_f32", "allreduce_sum_f32"]          # created once, on first use
+        assert res[r]["calls"][0][1:] == (r + 2, r, world)                              # device, rank, world
+    assert res[0]["ident"] == res[1]["ident"] == bytes((i * 7 + 3) % 251 for i in range(128))   # rank 0's id reached rank 1 via the store

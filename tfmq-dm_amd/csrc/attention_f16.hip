@@ -536,6 +536,7 @@ __global__ __launch_bounds__(64 * NW, OCC) void k_attention_d40(AttnHP p) {
       sA[sub] = __builtin_amdgcn_mfma_f32_32x32x16_f16(k1, qf[1], sA[sub], 0, 0, 0);
       sA[sub] = __builtin_amdgcn_mfma_f32_32x32x16_f16(k2, qf[2], sA[sub], 0, 0, 0);
     }
+    asm volatile("s_nop 15" : "+v"(sA[0]), "+v"(sA[1]));     // MFMA results -> inline-asm VALU readers: the wait states the compiler cannot count
     const float mx = row_max(sA);
     m_run = static_cast<float>(static_cast<_Float16>(mx));
 #pragma unroll
@@ -552,7 +553,8 @@ __global__ __launch_bounds__(64 * NW, OCC) void k_attention_d40(AttnHP p) {
                   const unsigned char* kp, const unsigned char* vp) {
     constexpr int B = decltype(b_tag)::value, KB = (B + 1) & 3;
     constexpr bool KDMA = decltype(kdma_tag)::value, VDMA = decltype(vdma_tag)::value, LAST = decltype(last_tag)::value;
-    constexpr bool COUNTED = decltype(counted_tag)::value;
+    constexpr bool COUNTED = decltype(counted_tag)::value && !(DBG & 2048);
+    if constexpr (DBG & 4096) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     if constexpr (!(DBG & 64)) dma(kp, vp, (B + 3) & 3, (B + 2) & 3, KDMA, VDMA);
     v8h kf[2][3];
     if constexpr (!LAST) {
@@ -581,6 +583,10 @@ __global__ __launch_bounds__(64 * NW, OCC) void k_attention_d40(AttnHP p) {
       }
     }
     float mx;
+    // The maximum tree is inline asm (v_max3_f32 without the compiler's canonicalising v_max): the compiler's hazard recogniser does not
+    // know that these statements READ registers an MFMA wrote (11 wait states after an 8-pass MFMA).  The barrier and the DMA issue lie
+    // in between, except in the last iterations, which issue no DMA: pad.
+    asm volatile("s_nop 7");
     if constexpr (DBG & 16) mx = sc[0][3] + sc[1][5];
     else mx = row_max(sc);
     float pe[32];                          // P in fp32
@@ -748,7 +754,7 @@ static int launch_attn_d40(tfmq_handle h, const AttnHP& p, void* stream) {
 #ifdef TFMQ_ATTN_ABLATE
   static const int dbg = getenv("TFMQ_ATTN_DBG") ? atoi(getenv("TFMQ_ATTN_DBG")) : 0;
 #define TFMQ_ABL(D) if (dbg == D) { hipLaunchKernelGGL((k_attention_d40<4, D>), grid, dim3(256), 0, as_stream(stream), p); TFMQ_LAUNCH_CHECK(h); return TFMQ_OK; }
-  TFMQ_ABL(1) TFMQ_ABL(2) TFMQ_ABL(4) TFMQ_ABL(6) TFMQ_ABL(8) TFMQ_ABL(16) TFMQ_ABL(32) TFMQ_ABL(64) TFMQ_ABL(49) TFMQ_ABL(14) TFMQ_ABL(78) TFMQ_ABL(128) TFMQ_ABL(328) TFMQ_ABL(456) TFMQ_ABL(320) TFMQ_ABL(256) TFMQ_ABL(72)
+  TFMQ_ABL(1) TFMQ_ABL(2) TFMQ_ABL(4) TFMQ_ABL(6) TFMQ_ABL(8) TFMQ_ABL(16) TFMQ_ABL(32) TFMQ_ABL(64) TFMQ_ABL(49) TFMQ_ABL(14) TFMQ_ABL(78) TFMQ_ABL(128) TFMQ_ABL(328) TFMQ_ABL(456) TFMQ_ABL(320) TFMQ_ABL(256) TFMQ_ABL(72) TFMQ_ABL(2048) TFMQ_ABL(4096) TFMQ_ABL(6144)
   if (dbg == 1000) { hipLaunchKernelGGL((k_attention_d40<4, 0, 3>), grid, dim3(256), 0, as_stream(stream), p); TFMQ_LAUNCH_CHECK(h); return TFMQ_OK; }
 #endif
   hipLaunchKernelGGL((k_attention_d40<4>), grid, dim3(256), 0, as_stream(stream), p);

@@ -39,13 +39,47 @@ class LayerQ:
 
 
 class _Layer:
-    def __init__(self, kind, packed, aq):
+    def __init__(self, kind, packed, aq, w32=None):
         self.kind, self.p, self.aq = kind, packed, aq
+        # TFMQ_EXACT_FP=1 (parity diagnostics): fp32 weights [cout, kh*kw*cin] in the im2col column order.  An un-quantised /
+        # weight-only layer then runs as im2col + the exact-fp32 MFMA GEMM (the reference's fp32 F.conv2d / F.linear up to the
+        # summation order) instead of the fp16-operand kernels.
+        self.w32 = w32
+
+    def _run_exact(self, x, stride=1, pad=(0, 0, 0, 0), up2x=False, rowadd=None, residual=None, out=None, y_coff=0,
+                   rowadd_ld=None, rowadd_step=None, rowadd_step_stride=0, x2=None, **_):
+        if out is not None or x2 is not None or x.dtype != torch.float32:
+            raise TfmqError("exact-fp32 layer: fp32 NHWC input, own output buffer, no virtual concat")
+        if up2x:
+            x = ops.upsample2x(x)
+        B, H, W, cin = x.shape
+        kh, kw, cout = self.p.kh, self.p.kw, self.p.cout
+        Ho, Wo = ops.out_hw(H, W, kh, kw, stride, pad[0], pad[1], pad[2], pad[3])
+        if kh == 1 and kw == 1 and stride == 1 and tuple(pad) == (0, 0, 0, 0):
+            col = x.reshape(B * H * W, cin)
+        else:
+            col = ops.im2col(x, kh, kw, stride, pad)
+        ra = None
+        if rowadd is not None:
+            if rowadd_step is not None:      # per-step TIB table row (host read of the step counter: diagnostics mode only)
+                k = int(rowadd_step.item())
+                ra = rowadd[k * rowadd_step_stride: k * rowadd_step_stride + cout].reshape(1, cout).expand(B, cout).contiguous()
+            else:
+                ra = rowadd.reshape(-1, cout).contiguous()
+                if ra.shape[0] == 1 and B > 1:
+                    ra = ra.expand(B, cout).contiguous()
+        res = None if residual is None else residual.reshape(B * Ho * Wo, cout)
+        if res is not None and res.dtype != torch.float32:
+            raise TfmqError("exact-fp32 layer: fp32 residual expected (fp32 stream)")
+        y = ops.gemm(col, self.w32, trans_b=True, bias=self.p.bias, rowadd=ra, rows_per_img=Ho * Wo, residual=res)
+        return y.reshape(B, Ho, Wo, cout)
 
     def run(self, x, **kw):
         kw.setdefault("want_stats", True)   # conv-epilogue GroupNorm statistics (K8 split form)
         if self.kind == "w4a8":
             return ops.conv2d_w4a8(x, self.p, self.aq, **kw)
+        if self.w32 is not None:
+            return self._run_exact(x, **kw)
         if (x.dtype == torch.float32 and kw.get("out_f16") and self.p.kh * self.p.kw > 1 and self.p.kh * self.p.kw * self.p.cin <= 64
                 and kw.get("pad") == (self.p.kh // 2, self.p.kw // 2, self.p.kh // 2, self.p.kw // 2) and kw.get("stride", 1) == 1
                 and not kw.get("up2x") and kw.get("rowadd") is None and kw.get("out") is None
@@ -138,12 +172,29 @@ class DdimUNetEngine:
         # fp16 activation stream: outside calibration / tap capture the tensors that travel between
         # blocks (conv outputs feeding a GroupNorm / LayerNorm / residual add) are stored as fp16 -- their GroupNorm
         # statistics still come from the fp32 values inside the producing epilogue.  TFMQ_STREAM_F32=1 keeps fp32.
-        self.stream_f16 = os.environ.get("TFMQ_STREAM_F32") is None
+        # TFMQ_EXACT_FP=1: parity diagnostics -- every un-quantised / weight-only conv and Linear as an exact-fp32 GEMM, every
+        # attention as exact-fp32 matmuls + row softmax, fp32 activation stream.  What remains against the reference's fp32
+        # path is summation order and the hardware exp2 / rcp of SiLU / GELU (a few 1e-7): tests/test_exact_fp_mode_gpu.py
+        # shows the activation-bin flips of the fast mode collapse in this one, i.e. they are fp16 operand rounding.
+        self.exact_fp = os.environ.get("TFMQ_EXACT_FP", "0") not in ("", "0")
+        self.stream_f16 = os.environ.get("TFMQ_STREAM_F32") is None and not self.exact_fp
         self._h16 = False
         self.act_state = None      # [n_q, 2] EMA {x_min, x_max} (quant_layer.py:229-244)
         self._qp_scratch = None
 
     # ------------------------------------------------------------------ weights
+    def _w32(self, w: torch.Tensor, pf):
+        """fp32 GEMM operand [cout, kh*kw*cin] of an un-quantised (pf None) or weight-only layer for the exact mode; None otherwise.
+        Weight-only: (q - z) * delta in fp32 -- the integer grid the fp16 pack holds exactly, times the channel scale, which is
+        what the reference's fake-quantised fp32 weight is (quant_layer.py:225-227)."""
+        if not self.exact_fp:
+            return None
+        cout, cin, kh, kw = w.shape
+        if pf is None:
+            return ops.w_relayout(w.contiguous(), cout, cin, kh, kw, to_gemm=True)
+        grid = pf.w16[:, :, :cin].float() * pf.wscale.reshape(cout, 1, 1)          # [cout][tap][cin]
+        return grid.reshape(cout, kh * kw * cin).contiguous()
+
     def _conv_names(self):
         return [k[:-7] for k in self.sd if k.endswith(".weight") and self.sd[k].dim() == 4]
 
@@ -168,11 +219,12 @@ class DdimUNetEngine:
             q = wq.get(n)
             aq = aq_of(q)
             if q is None:
-                self.layers[n] = _Layer("fp", ops.pack_w_f16(w, b), None)
+                self.layers[n] = _Layer("fp", ops.pack_w_f16(w, b), None, self._w32(w, None))
             elif aq is None:
                 # weight-only layers hold the exact integer grid q - z in f16: any bit width up to 11 bits
                 a = None if q.alpha is None else q.alpha.to(self.dev).contiguous()
-                self.layers[n] = _Layer("w4", ops.pack_w_f16(w, b, q.delta.to(self.dev), q.zp.to(self.dev), a, level=q.level), None)
+                pf = ops.pack_w_f16(w, b, q.delta.to(self.dev), q.zp.to(self.dev), a, level=q.level)
+                self.layers[n] = _Layer("w4", pf, None, self._w32(w, pf))
             else:
                 _check_w4a8_levels(n, q)
                 a = None if q.alpha is None else q.alpha.to(self.dev).contiguous()
@@ -208,7 +260,7 @@ class DdimUNetEngine:
                 ws = None if pf.wscale is None else torch.cat([l.p.wscale for l in ls])
                 pk = ops.PackedF16(torch.cat([l.p.w16 for l in ls]), torch.cat([l.p.bias for l in ls]), 3 * pf.cout,
                                    pf.cin, 1, 1, ws)
-                self.fused_qkv[p] = _Layer(ls[0].kind, pk, None)
+                self.fused_qkv[p] = _Layer(ls[0].kind, pk, None, torch.cat([l.w32 for l in ls]) if self.exact_fp else None)
         self.tib_table = None
         self.prepared = True
 
@@ -338,7 +390,12 @@ class DdimUNetEngine:
         return True
 
     def _fp_conv_half_ok(self, layer: _Layer) -> bool:
-        return layer.kind != "w4a8" and ops.f16_dma_ok(layer.p.cin, layer.p.kh, layer.p.kw)
+        return (not self.exact_fp) and layer.kind != "w4a8" and ops.f16_dma_ok(layer.p.cin, layer.p.kh, layer.p.kw)
+
+    def _attention_exact(self, q, k, v, heads: int, scale: float, aq):
+        """softmax(q k^T scale) v as exact-fp32 matmuls and a row softmax (three launches per head); (fp32 out, int8 bins | None)"""
+        out, _ = ops._attention_wide(q, k, v, heads, scale, None, True)
+        return out, (ops.quantize_act(out, aq) if aq is not None else None)
 
     def _virtual_cat_ok(self, layer: _Layer, x1, x2) -> bool:
         """The shortcut conv of an up-path block can read cat(x1, x2) from its two fp16 sources (tfmq_conv_desc.x2): the
@@ -370,7 +427,7 @@ class DdimUNetEngine:
         B, H, W, Cc = x.shape
         po = L[p + ".proj_out"]
         f = self.fused_qkv.get(p)
-        if (f is not None and f.kind == "w4a8" and self.calib is None and ops.attention_f16_ok(Cc, H * W)
+        if (f is not None and f.kind == "w4a8" and self.calib is None and not self.exact_fp and ops.attention_f16_ok(Cc, H * W)
                 and (2 * Cc) % 128 == 0 and (H * W) % 4 == 0):
             # the fused q|k|v GEMM writes q, k as fp16 rows and v as fp16 V^T; the flash kernel reads them tile by tile
             # (what the fp32-operand kernel rounds to on load -- same products, no fp32 round trip)
@@ -396,12 +453,12 @@ class DdimUNetEngine:
                 l.run(cache[key], out=qkv, y_coff=i * Cc, want_stats=False)
         qkv = qkv.reshape(B, H * W, 3 * Cc)
         aq = po.aq if po.kind == "w4a8" else None
+        attn = self._attention_exact if self.exact_fp else (lambda q, k, v, h, sc, a=None: ops.attention(q, k, v, h, sc, a, want_f32=a is None))
         if aq is not None and self.calib is not None:
-            out, _ = ops.attention(qkv[..., :Cc], qkv[..., Cc:2 * Cc], qkv[..., 2 * Cc:], 1, float(int(Cc) ** (-0.5)))
+            out, _ = attn(qkv[..., :Cc], qkv[..., Cc:2 * Cc], qkv[..., 2 * Cc:], 1, float(int(Cc) ** (-0.5)), None)
             self._observe(aq, out)
             return po.run(ops.quantize_act(out, aq).reshape(B, H, W, Cc), residual=x)
-        out, oq = ops.attention(qkv[..., :Cc], qkv[..., Cc:2 * Cc], qkv[..., 2 * Cc:], 1, float(int(Cc) ** (-0.5)), aq,
-                                want_f32=aq is None)
+        out, oq = attn(qkv[..., :Cc], qkv[..., Cc:2 * Cc], qkv[..., 2 * Cc:], 1, float(int(Cc) ** (-0.5)), aq)
         a = (oq if aq is not None else out).reshape(B, H, W, Cc)
         return po.run(a, residual=x, **self._o16())
 

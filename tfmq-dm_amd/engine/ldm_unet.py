@@ -134,7 +134,8 @@ class LdmUNetEngine(DdimUNetEngine):
         pf = ls[0].p
         ws = None if pf.wscale is None else torch.cat([l.p.wscale for l in ls])
         bias = None if pf.bias is None else torch.cat([l.p.bias for l in ls])
-        return _Layer(ls[0].kind, ops.PackedF16(torch.cat([l.p.w16 for l in ls]), bias, sum(l.p.cout for l in ls), pf.cin, 1, 1, ws), None)
+        return _Layer(ls[0].kind, ops.PackedF16(torch.cat([l.p.w16 for l in ls]), bias, sum(l.p.cout for l in ls), pf.cin, 1, 1, ws), None,
+                      torch.cat([l.w32 for l in ls]) if self.exact_fp else None)
 
     # ------------------------------------------------------------------ helpers
     def _quant_in(self, layer: _Layer, x: torch.Tensor, siblings=()):
@@ -191,7 +192,9 @@ class LdmUNetEngine(DdimUNetEngine):
         heads = self.cfg["num_heads"]
         to_out = L[p + ".to_out.0"]
         f = self.fused_qkv.get(p) if self_attn else None
-        if f is not None and f.kind != "w4a8" and self.calib is None:
+        if self.exact_fp:
+            f = None if f is None or f.kind == "w4a8" else f      # (the w4a8 fused projection would write fp16 attention operands)
+        if f is not None and f.kind != "w4a8" and self.calib is None and not self.exact_fp:
             # FP / weight-only state (calibration data passes, FP sampling of the calibration set): the same fp16-operand
             # attention, fed by the un-quantised fused projection
             B, T, Cin = xq_src.shape
@@ -219,7 +222,7 @@ class LdmUNetEngine(DdimUNetEngine):
                     o, _ = ops.attention_f16(y16[..., :Cc], y16[..., Cc:2 * Cc], vt, heads, float(d ** -0.5))
                     o = self._quant_in(to_out, o)
                 return self._tok(to_out, o, residual=x_res, **self._o16())
-        if (not self_attn) and self.calib is None and self._ctx_pad is not None:
+        if (not self_attn) and self.calib is None and self._ctx_pad is not None and not self.exact_fp:
             # cross attention on fp16 operands: the context is stored padded to a multiple of 8 tokens (padding masked
             # in the kernel), to_q writes fp16 rows, to_k fp16 rows, to_v its fp16 transpose
             lq, lk, lv = L[p + ".to_q"], L[p + ".to_k"], L[p + ".to_v"]
@@ -258,7 +261,10 @@ class LdmUNetEngine(DdimUNetEngine):
                 v = self._tok(L[p + ".to_v"], self._quant_in(L[p + ".to_v"], ctx))
         d = Cc // heads
         aq = to_out.aq if to_out.kind == "w4a8" else None
-        if aq is not None and self.calib is None:
+        if self.exact_fp:
+            o, oq = self._attention_exact(q, k, v, heads, float(d ** -0.5), aq if self.calib is None else None)
+            o = oq if oq is not None else self._quant_in(to_out, o)
+        elif aq is not None and self.calib is None:
             _, o = ops.attention(q, k, v, heads, float(d ** -0.5), aq, want_f32=False)
         else:
             o, _ = ops.attention(q, k, v, heads, float(d ** -0.5))
@@ -282,7 +288,7 @@ class LdmUNetEngine(DdimUNetEngine):
         L = self.layers
         q1 = self.fused_qkv.get(p + ".attn1", L[p + ".attn1.to_q"])
         x = self._attention(p + ".attn1", self._ln(p + ".norm1", x, q1), None, x, True)
-        if (ctx is not None and ctx.shape[1] == 1 and self.calib is None and x.shape[-1] % 8 == 0
+        if (ctx is not None and ctx.shape[1] == 1 and self.calib is None and x.shape[-1] % 8 == 0 and not self.exact_fp
                 and os.environ.get("TFMQ_SINGLE_CTX_TOKEN", "1") != "0"):
             x = self._attn2_single_token(p + ".attn2", ctx, x)
         else:
@@ -340,7 +346,7 @@ class LdmUNetEngine(DdimUNetEngine):
         heads = self.cfg["num_heads"] if nhc in (-1, None) else Cc // nhc
         d = Cc // heads
         T = H * W
-        if (self.calib is None and qkv_l.kind != "w4a8" and self._fp_conv_half_ok(qkv_l) and ops.attention_f16_ok(d, T)
+        if (self.calib is None and not self.exact_fp and qkv_l.kind != "w4a8" and self._fp_conv_half_ok(qkv_l) and ops.attention_f16_ok(d, T)
                 and T % 4 == 0 and os.environ.get("TFMQ_ATTNBLOCK_F16", "1") != "0"):
             # fp16 operands end to end: the GroupNorm writes fp16, the qkv conv writes q | k as fp16 rows and v as fp16 V^T, the flash
             # kernel copies them tile by tile -- the values the fp32-operand kernel below rounds to on load (same products), without
@@ -364,7 +370,10 @@ class LdmUNetEngine(DdimUNetEngine):
             hn, _ = self._gn(p + ".norm", x, None, False, qkv_l, eps=1e-5)
         qkv = qkv_l.run(hn, want_stats=False).reshape(B, H * W, 3 * Cc)
         # q*s . k*s with s = d^-1/4 (QKMatMul) == (q . k) * d^-1/2
-        o, _ = ops.attention(qkv[..., :Cc], qkv[..., Cc:2 * Cc], qkv[..., 2 * Cc:], heads, float(d ** -0.5))
+        if self.exact_fp:
+            o, _ = self._attention_exact(qkv[..., :Cc], qkv[..., Cc:2 * Cc], qkv[..., 2 * Cc:], heads, float(d ** -0.5), None)
+        else:
+            o, _ = ops.attention(qkv[..., :Cc], qkv[..., Cc:2 * Cc], qkv[..., 2 * Cc:], heads, float(d ** -0.5))
         return po.run(o.reshape(B, H, W, Cc), residual=x, want_stats=True, **self._o16())
 
     def _seq(self, p, h, skip, ctx, rowadd, taps):

@@ -3,12 +3,15 @@
 Same names as the reference module (`allreduce`, `allgather`, `broadcast`, `barrier`, `synchronize`,
 `init_process_group`, `get_rank`, `get_world_size`).  Control plane = torch.distributed (rendezvous, barriers,
 the gloo backend of the CPU multi-process tests).  Data plane on GPUs = the C ABI's RCCL wrappers
-(include/tfmq_hip.h: tfmq_comm_init / tfmq_allreduce_sum_f32): `init_process_group` with the "nccl" backend
-(= RCCL on ROCm) draws a rendezvous id on rank 0, hands it to every rank through the process group's store and
-binds one communicator per GPU to the tfmq handle of that device; `allreduce` of a contiguous fp32 device tensor
-is then ONE ncclAllReduce enqueued on the caller's current stream -- between the unit's backward GEMMs and the
-fused AdaRound-backward + Adam kernel, with no host synchronisation (quant/reconstruction.py:72-75,193-195,298-300).
-Everything else (CPU tensors, other dtypes, gloo) goes to torch.distributed unchanged."""
+(include/tfmq_hip.h: tfmq_comm_init / tfmq_allreduce_sum_f32).  `init_process_group` with the "nccl" backend
+(= RCCL on ROCm) only RECORDS that a communicator is wanted: the reference's entry point calls it before
+`torch.cuda.set_device(gpu)` (quant/calibration.py:241-245), when every spawned rank still sits on device 0.  The
+communicator is created by the first `allreduce` of a device tensor, on THAT tensor's device: rank 0 draws the
+rendezvous id and hands it round through the process group's key-value store (no device collective is involved).
+`allreduce` of a contiguous fp32 device tensor is then ONE ncclAllReduce enqueued on the caller's current stream --
+between the unit's backward GEMMs and the fused AdaRound-backward + Adam kernel, with no host synchronisation
+(quant/reconstruction.py:72-75,193-195,298-300).  Everything else (CPU tensors, other dtypes, gloo) goes to
+torch.distributed unchanged."""
 import ctypes as _C
 
 import torch as _torch
@@ -32,48 +35,83 @@ def comm_device():
     return None
 
 
+_want_comm = False      # an "nccl" rendezvous was made: the first device all-reduce creates the communicator
+_comm_epoch = 0         # communicators created so far (key of the rendezvous id in the store)
+
+
+def _exchange_id(ident):
+    """Rank 0's 128-byte rendezvous id to every rank through the default process group's store (host side only: the
+    ranks need not have chosen their devices yet, and no NCCL communicator of torch's own is created for it)."""
+    key = f"tfmq_comm_id_{_comm_epoch}"
+    try:
+        store = dist.distributed_c10d._get_default_store()
+    except Exception:
+        store = None
+    if store is None:                      # no store (exotic init methods): fall back to an object broadcast
+        box = [ident]
+        dist.broadcast_object_list(box, src=0)
+        return box[0]
+    if dist.get_rank() == 0:
+        store.set(key, ident)
+        return ident
+    return bytes(store.get(key))           # blocks until rank 0 has set it
+
+
 def init_comm(device=None):
-    """Create the C-ABI RCCL communicator of this process over the ranks of the default process group (collective).
-    Called by init_process_group for the "nccl" backend; callable on its own after a gloo rendezvous."""
+    """Create the C-ABI RCCL communicator of this process over the ranks of the default process group (collective: every
+    rank calls it, each with ITS device).  Called lazily by the first device all-reduce after an "nccl" rendezvous;
+    callable on its own after a gloo rendezvous.  Refuses a rank / device mismatch the process group can see."""
+    global _comm_epoch
     from tfmq_dm_amd._lib import TfmqError, handle, load
     if comm_device() is not None:
         return
     dev = _torch.cuda.current_device() if device is None else int(device)
     lib = load()
     world, rank = dist.get_world_size(), dist.get_rank()
-    ident = [None]
+    ident = None
     if rank == 0:
         buf = (_C.c_uint8 * 128)()
         rc = lib.tfmq_comm_unique_id(buf)
         if rc != 0:
             raise TfmqError(f"tfmq_comm_unique_id failed ({rc}): librccl could not be loaded")
-        ident[0] = bytes(buf)
-    dist.broadcast_object_list(ident, src=0)
-    buf = (_C.c_uint8 * 128).from_buffer_copy(ident[0])
+        ident = bytes(buf)
+    ident = _exchange_id(ident)
+    _comm_epoch += 1
+    buf = (_C.c_uint8 * 128).from_buffer_copy(ident)
     h = handle(dev)
     h.call("comm_init", buf, rank, world)
     h.comm_world = world
 
 
 def destroy_comm():
+    global _want_comm
     dev = comm_device()
     if dev is not None:
         from tfmq_dm_amd._lib import handle
         handle(dev).call("comm_destroy")
         handle(dev).comm_world = 0
+    _want_comm = False
 
 
-def init_process_group(backend="nccl", init_method=None, world_size=-1, rank=-1, **kw):
+def init_process_group(backend="nccl", init_method=None, world_size=-1, rank=-1, device=None, **kw):
+    """reference linklink.init_process_group = dist.init_process_group.  `device` (optional, not in the reference) binds the
+    RCCL communicator at once to that device instead of at the first device all-reduce."""
+    global _want_comm
     if not dist.is_initialized():      # a launcher (torchrun-style driver, bench.py) may have made the rendezvous already
         dist.init_process_group(backend=backend, init_method=init_method, world_size=world_size, rank=rank, **kw)
     if str(backend).lower() == "nccl" and _torch.cuda.is_available():
-        init_comm()
+        _want_comm = True
+        if device is not None:
+            init_comm(device)
 
 
 def allreduce(tensor, *a, **kw):
     """SUM all-reduce in place (reference linklink.allreduce = dist.all_reduce)."""
     if not a and not kw and tensor.is_cuda and tensor.dtype == _torch.float32 and tensor.is_contiguous():
         dev = comm_device()
+        if dev is None and _want_comm:     # first device all-reduce after an "nccl" rendezvous: bind to THIS tensor's device
+            init_comm(tensor.device.index or 0)
+            dev = comm_device()
         if dev is not None and (tensor.device.index or 0) == dev:
             from tfmq_dm_amd._lib import handle
             handle(dev).call("allreduce_sum_f32", _C.c_void_p(tensor.data_ptr()), tensor.numel(),

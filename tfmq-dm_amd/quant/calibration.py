@@ -165,8 +165,10 @@ def cali_model_multi(gpu: int, dist_backend: str, world_size: int, dist_url: str
     activation deltas, rank 0 writes the checkpoint."""
     from tfmq_dm_amd import linklink as dist
     rank = rank * ngpus_per_node + gpu
-    dist.init_process_group(backend=dist_backend, init_method=dist_url, world_size=world_size, rank=rank)
+    # (the reference selects the device AFTER the rendezvous, :241-245; doing it first costs nothing and every collective --
+    # torch's own and the C ABI's lazily created RCCL communicator, linklink.init_comm -- then sees one rank per GPU)
     torch.cuda.set_device(gpu)
+    dist.init_process_group(backend=dist_backend, init_method=dist_url, world_size=world_size, rank=rank)
     net = model.diffusion_model if hasattr(model, "diffusion_model") else model
     net.cuda()
     qnn = QuantModel(net, wq_params=kwargs.pop("wq_params"), aq_params=kwargs.pop("aq_params"),
