@@ -362,7 +362,14 @@ def calibration_sharded(dev, world):
     tu = R.TransformerUnit(layers, [gn, gn, gn], 8, x.reshape(N, HW * HW, Cc), torch.randn(N, 77, 768, device=dev),
                            y.reshape(N, HW * HW, Cc), **kw)
     idx = torch.arange(N, device=dev)
-    res = {"world": world, "mini_batch_per_rank": N,
+    rccl_ranks = None
+    if world > 1 and link_comm_ready():
+        import ctypes as C
+        from tfmq_dm_amd._lib import handle
+        r_, w_ = C.c_int(-1), C.c_int(-1)
+        handle(link.comm_device()).call("comm_info", C.byref(r_), C.byref(w_))
+        rccl_ranks = int(w_.value)               # ranks the C ABI's RCCL communicator actually spans
+    res = {"world": world, "rccl_ranks": rccl_ranks, "mini_batch_per_rank": N,
            "collective": (None if world == 1 else
                           "RCCL ncclAllReduce(SUM, fp32) via the C ABI (tfmq_allreduce_sum_f32), one per iteration" if link_comm_ready()
                           else "torch.distributed all_reduce (the C ABI communicator could not be created), one per iteration")}
@@ -390,6 +397,10 @@ def calibration_sharded(dev, world):
             ent["allreduce_us"] = round(us, 1)
             ent["allreduce_algbw_GBps"] = round(nbytes / us / 1e3, 2)
             ent["allreduce_busbw_GBps"] = round(nbytes / us / 1e3 * 2 * (world - 1) / world, 2)
+            # share of an iteration the exchange would take if nothing overlapped it (the pieces after the first overlap the
+            # previous piece's Adam kernels: engine/recon.py, TFMQ_EXCHANGE_CHUNKS)
+            ent["exchange_share_of_iteration"] = round(us / (ms * 1e3), 4)
+            ent["exchange_pieces"] = len(getattr(unit, "_cuts", [0]))
         res[name] = ent
     del ru, tu, layers, x, y
     torch.cuda.empty_cache()
@@ -445,6 +456,8 @@ def run_cali_workload(args, dev, rank, local_rank, world, log):
     for mod, name in ((QC, "tib_reconstruction"), (QC, "block_reconstruction"), (QC, "layer_reconstruction"), (QC, "_calibrate_activations")):
         timed(mod, name)
     kw = dict(iters=ITERS, batch_size=8, w=0.01, asym=True, warmup=0.2, opt_mode=RLOSS.MSE)
+    if args.cali_only:
+        QC.ONLY_UNITS = tuple(p for p in args.cali_only.split(",") if p)
     torch.cuda.synchronize()
     if world > 1:
         import torch.distributed as dist
@@ -482,7 +495,8 @@ def run_cali_workload(args, dev, rank, local_rank, world, log):
         "dtype": "f32 (AdaRound iterations: exact fp32 GEMMs) + int8/f16 (capture forwards)", "data": "synthetic",
         "config": {"workload": (f"cali_model{'_multi' if world > 1 else ''} on the SD v1-4 UNet (859.5M, random init): {G} timestep groups x {N} "
                                 f"samples, {ITERS} AdaRound iterations per unit at mini-batch 8/rank (the recipe: 25 groups x 512, 20000), "
-                                "w4 channel-wise + a8 Finite-Set, running_stat"),
+                                "w4 channel-wise + a8 Finite-Set, running_stat"
+                                + (f"; reconstruction restricted to the units under {args.cali_only}" if args.cali_only else "")),
                    "parallelism": "single GPU" if world == 1 else f"timestep-group shards x{world}, one RCCL SUM all-reduce per iteration"},
         "finite": finite,
         "calibration": {"measured": True, "wall_clock_s": round(dt, 2), "reconstruction_units": n_units,
@@ -599,6 +613,8 @@ def main():
     ap.add_argument("--cali-iters", type=int, default=100, help="--workload cali: AdaRound iterations per unit (recipe: 20000)")
     ap.add_argument("--cali-samples", type=int, default=32, help="--workload cali: samples per timestep group (recipe: 512)")
     ap.add_argument("--cali-groups", type=int, default=2, help="--workload cali: timestep groups (recipe: 25)")
+    ap.add_argument("--cali-only", default="", help="--workload cali: comma-separated unit-name prefixes (e.g. model.middle_block,model.input_blocks.10); "
+                    "only these reconstruction units run (at --cali-iters), the others keep nearest rounding -- for measuring a resolution level at the recipe's length")
     ap.add_argument("--batch", type=int, default=0, help="images per GPU (default 64 for sd, 256 for cifar)")
     ap.add_argument("--ddim-steps", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")

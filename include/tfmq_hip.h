@@ -61,6 +61,20 @@ typedef struct tfmq_qsel {
 int tfmq_quantize_act(tfmq_handle h, const float* x, int8_t* q, size_t n, tfmq_qsel qs, int level, void* stream);
 /* the same on an fp16 tensor (the fp16 activation stream); n % 4 == 0 */
 int tfmq_quantize_act_h(tfmq_handle h, const uint16_t* x, int8_t* q, size_t n, tfmq_qsel qs, int level, void* stream);
+/* y[i] = delta * (clamp(rint(x[i] * pre / delta) + zp, 0, level - 1) - zp) with {delta, zp} of the current Finite-Set group (device
+ * step counter): a fake-quantised activation for the enable-able attention-matmul quantizers (aqtizer_q / _k / _v / _w of
+ * QuantAttnBlock, cross_attn_forward, QuantQKMatMul / QuantSMVMatMul: quant_block.py:226-243,318-323,350-351,487-498; level up to 2^16
+ * for the softmax quantizer, pre = the d^-1/4 scale QuantQKMatMul applies in front of its quantizers, else 1). */
+int tfmq_fake_quant_sel(tfmq_handle h, const float* x, float* y, size_t n, tfmq_qsel qs, int level, float pre, void* stream);
+/* ---- W8A8 (the README's --wq 8 recipes, README.md:86-125; QuantLayer.forward quant_layer.py:306-340 with 8-bit weights):
+ * 8-bit weights with a per-channel zero point need 9 bits as (q_w - z_w), which does not fit the int8 MFMA operand; both integer
+ * grids are exact in fp16, so such a layer runs tfmq_conv2d_f16 on (b - z_a) x (q_w - z_w) with fp32 accumulation (at least as
+ * exact as the reference's fp32 conv of the dequantised values) and the per-channel output scale delta_a * delta_w[c].
+ * grid[i] = (xq[i] + 128) - zp(step) as fp16 (out_f16 != 0; n % 4 == 0) or fp32: the activation bins of tfmq_quantize_act on
+ * their integer grid. */
+int tfmq_bins_to_grid(tfmq_handle h, const int8_t* xq, tfmq_qsel qs, void* out, int out_f16, size_t n, void* stream);
+/* out[c] = delta(step) * ws[c], c < n: the output scale of a W8A8 layer under the current Finite-Set group */
+int tfmq_scale_by_qdelta(tfmq_handle h, const float* ws, tfmq_qsel qs, float* out, int n, void* stream);
 /* y[i] = delta * (clamp(rint(x/delta)+zp,0,level-1) - zp); delta/zp per tensor (rows=1)
  * or per row ([rows] arrays, the per-output-channel weight quantizer, quant_layer.py:193-204) */
 int tfmq_fake_quant(tfmq_handle h, const float* x, float* y, uint8_t* idx_or_null, size_t rows, size_t cols,
@@ -360,6 +374,12 @@ int tfmq_recon_loss(tfmq_handle h, const float* pred, const float* tgt, float* g
 /* ---- K15: block-reconstruction forward/backward pieces (replace autograd through `block(*cur_inputs)`,
  * quant/reconstruction.py:69-71,190-192,295-297).  Exact fp32: the soft AdaRound targets are
  * non-integer, so this path is floating point by construction. ------------------------------ */
+/* Operand precision of the matrix-core path of tfmq_gemm_f32 / _heads on this handle, until changed: 0 = exact fp32 products
+ * (v_mfma_f32_32x32x2f32; default, what every exactness-critical caller relies on), 1 = "bf16x3" (each fp32 operand value split into
+ * bf16 hi + lo, three bf16 MFMAs per product: relative error 2^-16 per product, fp32 accumulation), 2 = fp16 operands (2^-11).
+ * Meant for the AdaRound reconstruction iterations only (reference quant/reconstruction.py:63-78,182-198 runs them in fp32 autograd;
+ * SURVEY section 7-1); small problems on the FMA tile stay exact. */
+int tfmq_set_gemm_precision(tfmq_handle h, int mode);
 /* batched strided GEMM: C[z] (M x N, row stride scm) = alpha * A[z] B[z] (+bias[n]) (+rowadd) (+residual), or C += ...
  * A(m,k) = A[m*sam + k*sak], B(k,n) = B[k*sbk + n*sbn]; rowadd[(m / rows_per_img)*rowadd_ld + n] */
 int tfmq_gemm_f32(tfmq_handle h, const float* A, const float* B, float* C, int M, int N, int K, long sam, long sak,

@@ -5,6 +5,8 @@ sys.path.insert(0, ROOT)
 import torch
 import tfmq_dm_amd.ops as ops
 DEV = "cuda:0"
+MODE = os.environ.get("GEMM_PREC", "f32")      # f32 | bf16x3 | f16 (ops.gemm_precision)
+print("operand precision:", MODE)
 def t(fn, n=5):
     fn(); torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -18,7 +20,8 @@ for (M, N, K, ta, tb) in [(32768, 320, 2880, False, True), (32768, 2880, 320, Fa
     A = torch.randn((K, M) if ta else (M, K), device=DEV)
     B = torch.randn((N, K) if tb else (K, N), device=DEV)
     out = torch.empty(M, N, device=DEV)
-    ms = t(lambda: ops.gemm(A, B, trans_a=ta, trans_b=tb, out=out))
+    with ops.gemm_precision(MODE):
+        ms = t(lambda: ops.gemm(A, B, trans_a=ta, trans_b=tb, out=out))
     # library sgemm at the same shape / layouts (headroom check only; the product never calls it)
     At, Bt = (A.t() if ta else A), (B.t() if tb else B)
     ms_lib = t(lambda: torch.matmul(At, Bt, out=out))

@@ -181,3 +181,101 @@ def test_rccl_c_abi_world1_allreduce():
         assert link.comm_device() is None
         if own:
             dist.destroy_process_group()
+
+
+def _rccl_world2_worker(rank, world, port, out_dir):
+    """One process per GPU in the REFERENCE's order (rendezvous first, device second): the communicator is created by the
+    first device all-reduce, on the tensor's device."""
+    _paths()
+    os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    import ctypes as C
+    import tfmq_dm_amd.linklink as link
+    from tfmq_dm_amd._lib import handle
+    from tfmq_dm_amd.engine import recon as R
+    link.init_process_group(backend="nccl", init_method=f"tcp://127.0.0.1:{port}", world_size=world, rank=rank)
+    assert link.comm_device() is None                      # nothing bound while every rank still sits on device 0
+    torch.cuda.set_device(rank)
+    dev = f"cuda:{rank}"
+    g = torch.Generator().manual_seed(100 + rank)
+    local = torch.randn(1 << 18, generator=g)
+    buf = local.to(dev)
+    link.allreduce(buf)                                     # creates the communicator on cuda:<rank>, then ncclAllReduce
+    torch.cuda.synchronize(rank)
+    r, w = C.c_int(-1), C.c_int(-1)
+    handle(rank).call("comm_info", C.byref(r), C.byref(w))
+    # the chunked side-stream exchange of a reconstruction unit (two pieces): same sums as one flat all-reduce
+    cuts = R._chunk_cuts([1 << 16, 1 << 16, 1 << 17], 2)
+    flat = local.to(dev)
+    side = torch.cuda.Stream(rank)
+    ev = torch.cuda.Event()
+    ev.record(torch.cuda.current_stream(rank))
+    side.wait_event(ev)
+    with torch.cuda.stream(side):
+        for (_, _, e0, e1) in cuts:
+            link.allreduce(flat[e0:e1])
+    side.synchronize()
+    torch.save({"sum": buf.cpu(), "chunked": flat.cpu(), "info": (r.value, w.value), "comm_dev": link.comm_device()},
+               os.path.join(out_dir, f"rccl{rank}.pt"))
+    link.barrier()
+    link.destroy_comm()
+
+
+def test_rccl_c_abi_world2_allreduce_when_two_gpus():
+    """tfmq_comm_init / tfmq_allreduce_sum_f32 with TWO ranks on two devices (skipped on a 1-GPU box: RCCL refuses two ranks on
+    one device) against the sum of the locals: what `bench.py --gpus N` and cali_model_multi rely on at N > 1."""
+    if not torch.cuda.is_available() or torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    world, port = 2, 32500 + (os.getpid() % 2000)
+    with tempfile.TemporaryDirectory() as d:
+        mp.start_processes(_rccl_world2_worker, args=(world, port, d), nprocs=world, join=True, start_method="spawn")
+        res = [torch.load(os.path.join(d, f"rccl{r}.pt")) for r in range(world)]
+    ref = sum(torch.randn(1 << 18, generator=torch.Generator().manual_seed(100 + r)) for r in range(world))
+    for r in range(world):
+        assert res[r]["info"] == (r, world) and res[r]["comm_dev"] == r
+        assert torch.equal(res[r]["sum"], ref) and torch.equal(res[r]["chunked"], ref)      # two addends: one rounding, order-free
+
+
+def test_side_stream_exchange_equals_in_stream_exchange(monkeypatch):
+    """engine.recon._Unit.iterate with the gradient exchange cut in two pieces on a side stream (the next piece travels while the
+    previous piece's fused AdaRound-backward + Adam kernels run) against the one-piece in-stream exchange: identical alphas after
+    five iterations.  One device: the 'all-reduce' is a stand-in that doubles the buffer on the CALLER's current stream, which is
+    exactly the ordering contract of tfmq_allreduce_sum_f32."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    _paths()
+    import tfmq_dm_amd.ops as ops
+    from tfmq_dm_amd.engine import recon as R
+    streams_seen = set()
+
+    def fake_allreduce(t):
+        streams_seen.add(torch.cuda.current_stream(0).cuda_stream)
+        ops.axpy(t, t.clone(), 1.0)           # t <- 2 t: "sum over two identical ranks"
+
+    def build(chunks):
+        monkeypatch.setenv("TFMQ_EXCHANGE_CHUNKS", str(chunks))
+        gen = torch.Generator().manual_seed(5)
+
+        def ada(cout, cin, k):
+            w = (torch.randn(cout, cin, k, k, generator=gen) * 0.05).to(DEV)
+            qp = ops.minmax_to_qparam(ops.minmax(w.reshape(cout, -1).contiguous(), cout), 16)
+            return R.AdaLayer(w, qp[:, 0].contiguous(), qp[:, 1].contiguous(), torch.zeros(cout, device=DEV))
+        c1, c2 = ada(32, 32, 3), ada(32, 32, 3)
+        x = torch.randn(4, 8, 8, 32, generator=gen).to(DEV)
+        y = torch.randn(4, 8, 8, 32, generator=gen).to(DEV)
+        gn = (torch.ones(32, device=DEV), torch.zeros(32, device=DEV))
+        return R.ResnetUnit(c1, c2, gn, gn, None, x, torch.randn(4, 32, generator=gen).to(DEV), y, eps=1e-5, iters=20, world_size=2,
+                            allreduce=fake_allreduce), (c1, c2)
+    idx = torch.arange(4, device=DEV)
+    out = {}
+    for chunks in (1, 2):
+        streams_seen.clear()
+        unit, layers = build(chunks)
+        for _ in range(5):
+            unit.iterate(idx)
+        torch.cuda.synchronize()
+        out[chunks] = [l.alpha.clone() for l in layers]
+        assert len(unit._cuts) == chunks
+        if chunks == 2:
+            assert torch.cuda.current_stream(0).cuda_stream not in streams_seen        # the exchange ran on the side stream
+    for a, b in zip(out[1], out[2]):
+        assert torch.equal(a, b)

@@ -417,8 +417,8 @@ def test_generate_cali_data_ddim_and_sample_fid_vs_reference(golden):
 
 
 def test_unsupported_bit_widths_fail_loudly(golden):
-    """--wq 8 (a README recipe of the reference) is not built on the device path: the engine must refuse it instead of
-    packing 8-bit grids into nibbles (the bit width used to be dropped silently)."""
+    """Bit widths the device path does not implement must be refused, not packed into another grid silently (the bit
+    width used to be dropped): 8-bit weights run since round 3 (tests/test_w8a8_gpu.py), 4-bit ACTIVATIONS do not."""
     import tfmq_dm_amd.ddim.models as M
     from quant.quant_layer import QMODE, Scaler
     from quant.quant_model import QuantModel
@@ -426,11 +426,11 @@ def test_unsupported_bit_widths_fail_loudly(golden):
     g8 = golden("f8_cali_tiny")
     m = M.Model(M.make_config(ch=32, ch_mult=(1, 2), num_res_blocks=1, attn_resolutions=(8,), image_size=16, dropout=0.0))
     m.load_state_dict(sd_of(g8))
-    wq = {"bits": 8, "channel_wise": True, "scaler": Scaler.MINMAX}
-    aq = {"bits": 8, "channel_wise": False, "scaler": Scaler.MINMAX, "leaf_param": True}
+    wq = {"bits": 4, "channel_wise": True, "scaler": Scaler.MINMAX}
+    aq = {"bits": 4, "channel_wise": False, "scaler": Scaler.MINMAX, "leaf_param": True}
     q = QuantModel(m.to(DEV).eval(), wq, aq, cali=False, aq_mode=[QMODE.NORMAL.value]).to(DEV).eval()
     q.set_quant_state(True, True)
-    with pytest.raises(TfmqError, match="4-bit weights"):
+    with pytest.raises(TfmqError, match="8-bit activations"):
         q(torch.randn(2, 3, 16, 16, device=DEV), torch.tensor([10.0, 500.0], device=DEV))
 
 

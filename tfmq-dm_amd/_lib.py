@@ -63,6 +63,10 @@ _SIGS = {
     "tfmq_last_error": (C.c_char_p, [c_void_p]),
     "tfmq_device_info": (c_int, [c_void_p, C.POINTER(c_int), C.POINTER(c_int), C.POINTER(c_size_t)]),
     "tfmq_quantize_act": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, QSel, c_int, c_void_p]),
+    "tfmq_fake_quant_sel": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, QSel, c_int, C.c_float, c_void_p]),
+    "tfmq_set_gemm_precision": (c_int, [c_void_p, c_int]),
+    "tfmq_bins_to_grid": (c_int, [c_void_p, c_void_p, QSel, c_void_p, c_int, c_size_t, c_void_p]),
+    "tfmq_scale_by_qdelta": (c_int, [c_void_p, c_void_p, QSel, c_void_p, c_int, c_void_p]),
     "tfmq_quantize_act_h": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, QSel, c_int, c_void_p]),
     "tfmq_fake_quant": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_size_t, c_void_p, c_void_p, c_int, c_void_p]),
     "tfmq_minmax_ws_bytes": (c_size_t, [c_size_t, c_size_t]),

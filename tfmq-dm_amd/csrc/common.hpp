@@ -25,6 +25,8 @@ struct tfmq_ctx {
   // RCCL communicator of the sharded calibration (comm.hip); opaque here so that no kernel file needs rccl.h
   void* comm = nullptr;
   int comm_rank = 0, comm_world = 0;
+  // operand precision of tfmq_gemm_f32's matrix-core path (tfmq_set_gemm_precision): 0 exact fp32, 1 bf16x3 split, 2 fp16
+  int gemm_prec = 0;
 };
 
 // strided fp32 GEMM of the reconstruction units (recon_kernels.hip, gemm_f32_mfma.hip)

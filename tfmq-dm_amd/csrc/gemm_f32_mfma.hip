@@ -178,8 +178,17 @@ struct TileLoader<R, 2, BK> : TileLoaderBase<R, BK> {
   }
 };
 
-template <int WAVES_M, int WAVES_N, int WM_TILES, int WN_TILES, int MA = 0, int MB = 0, int BK = 16>
-__global__ __launch_bounds__(256, (WM_TILES * WN_TILES > 2) ? 2 : (BK == 32 ? 3 : 5)) void k_gemm_f32_mfma(GemmP p) {
+// PREC (tfmq_set_gemm_precision; the reconstruction iterations only -- everything that must be exact keeps 0):
+//   0  v_mfma_f32_32x32x2f32: exact fp32 products (157 TFLOP/s matrix peak)
+//   1  "bf16x3": every fp32 operand value split as hi = bf16(a), lo = bf16(a - hi) while it sits in registers between the LDS read and
+//      the MFMA; a b ~ hi hi' + hi lo' + lo hi' on v_mfma_f32_32x32x16_bf16 (3 MFMAs per 16 k instead of 8 fp32 ones at twice the
+//      cycles each: 5.3x fewer matrix-pipe cycles), fp32 accumulation.  Relative error per product <= 2^-16 (the dropped lo lo' term and
+//      lo's own rounding) against 2^-24: SURVEY section 7-1's "split-bf16 operand MFMA, check loss-curve parity".
+//   2  fp16 operands (one MFMA per 16 k), relative error per product 2^-11
+typedef __bf16 v8bf __attribute__((ext_vector_type(8)));
+typedef _Float16 v8hf __attribute__((ext_vector_type(8)));
+template <int WAVES_M, int WAVES_N, int WM_TILES, int WN_TILES, int MA = 0, int MB = 0, int BK = 16, int PREC = 0>
+__global__ __launch_bounds__(256, (WM_TILES * WN_TILES > 2) ? 2 : (BK == 32 ? 3 : (PREC ? 4 : 5))) void k_gemm_f32_mfma(GemmP p) {
   constexpr int BM = WAVES_M * WM_TILES * 32, BN = WAVES_N * WN_TILES * 32;
   static_assert(WAVES_M * WAVES_N == 4, "4 waves");
   __shared__ __attribute__((aligned(128))) float sA[2][BK * (BM + 4)];
@@ -250,29 +259,32 @@ __global__ __launch_bounds__(256, (WM_TILES * WN_TILES > 2) ? 2 : (BK == 32 ? 3 
     // an MFMA multiplies the k-pair (lanes 0-31: first k, lanes 32-63: second k); any pairing is a valid order of the
     // k sum as long as A and B use the same one: MFMA j of half h takes k = 8h + j (lanes 0-31) and 8h + 4 + j
     // (lanes 32-63), so a k-contiguous operand feeds four MFMAs from one 16-byte read
+    auto frag_a = [&](int i, int half, float (&o)[4]) {
+      if constexpr (MA == 1) {
+        const float4 v = *reinterpret_cast<const float4*>(a_b + swz_rk<BK>((wm * WM_TILES + i) * 32 + l32, half * 2 + hh));
+        o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = a_l[(half * 8 + hh * 4 + j) * (BM + 4) + i * 32];
+      }
+    };
+    auto frag_b = [&](int jn, int half, float (&o)[4]) {
+      if constexpr (MB == 1) {
+        const float4 v = *reinterpret_cast<const float4*>(b_b + swz_rk<BK>((wn * WN_TILES + jn) * 32 + l32, half * 2 + hh));
+        o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = b_l[(half * 8 + hh * 4 + j) * (BN + 4) + jn * 32];
+      }
+    };
+    if constexpr (PREC == 0) {
 #pragma unroll
     for (int half = 0; half < BK / 8; ++half) {
       float af[WM_TILES][4], bf[WN_TILES][4];
 #pragma unroll
-      for (int i = 0; i < WM_TILES; ++i) {
-        if constexpr (MA == 1) {
-          const float4 v = *reinterpret_cast<const float4*>(a_b + swz_rk<BK>((wm * WM_TILES + i) * 32 + l32, half * 2 + hh));
-          af[i][0] = v.x; af[i][1] = v.y; af[i][2] = v.z; af[i][3] = v.w;
-        } else {
+      for (int i = 0; i < WM_TILES; ++i) frag_a(i, half, af[i]);
 #pragma unroll
-          for (int j = 0; j < 4; ++j) af[i][j] = a_l[(half * 8 + hh * 4 + j) * (BM + 4) + i * 32];
-        }
-      }
-#pragma unroll
-      for (int jn = 0; jn < WN_TILES; ++jn) {
-        if constexpr (MB == 1) {
-          const float4 v = *reinterpret_cast<const float4*>(b_b + swz_rk<BK>((wn * WN_TILES + jn) * 32 + l32, half * 2 + hh));
-          bf[jn][0] = v.x; bf[jn][1] = v.y; bf[jn][2] = v.z; bf[jn][3] = v.w;
-        } else {
-#pragma unroll
-          for (int j = 0; j < 4; ++j) bf[jn][j] = b_l[(half * 8 + hh * 4 + j) * (BN + 4) + jn * 32];
-        }
-      }
+      for (int jn = 0; jn < WN_TILES; ++jn) frag_b(jn, half, bf[jn]);
 #pragma unroll
       for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -288,6 +300,77 @@ __global__ __launch_bounds__(256, (WM_TILES * WN_TILES > 2) ? 2 : (BK == 32 ? 3 
         lb.template store<PAR ^ 1>(sB[buf ^ 1]);
       }
 #endif
+    }
+    } else {
+    // 16 k per MFMA: the 8 values a lane holds of two consecutive "halves" (k = 8h + 4hh + j) are ONE operand of the 16-wide MFMA --
+    // any assignment of k to operand slots is a valid order of the k sum as long as A and B use the same one
+#pragma unroll
+    for (int grp = 0; grp < BK / 16; ++grp) {
+      float a8[WM_TILES][8], b8[WN_TILES][8];
+#pragma unroll
+      for (int i = 0; i < WM_TILES; ++i) {
+        float t0[4], t1[4];
+        frag_a(i, 2 * grp, t0);
+        frag_a(i, 2 * grp + 1, t1);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { a8[i][j] = t0[j]; a8[i][4 + j] = t1[j]; }
+      }
+#pragma unroll
+      for (int jn = 0; jn < WN_TILES; ++jn) {
+        float t0[4], t1[4];
+        frag_b(jn, 2 * grp, t0);
+        frag_b(jn, 2 * grp + 1, t1);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { b8[jn][j] = t0[j]; b8[jn][4 + j] = t1[j]; }
+      }
+      if constexpr (PREC == 1) {
+        v8bf ah[WM_TILES], al[WM_TILES], bh[WN_TILES], bl[WN_TILES];
+#pragma unroll
+        for (int i = 0; i < WM_TILES; ++i)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            ah[i][e] = static_cast<__bf16>(a8[i][e]);
+            al[i][e] = static_cast<__bf16>(a8[i][e] - static_cast<float>(ah[i][e]));
+          }
+#pragma unroll
+        for (int jn = 0; jn < WN_TILES; ++jn)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            bh[jn][e] = static_cast<__bf16>(b8[jn][e]);
+            bl[jn][e] = static_cast<__bf16>(b8[jn][e] - static_cast<float>(bh[jn][e]));
+          }
+#pragma unroll
+        for (int i = 0; i < WM_TILES; ++i)
+#pragma unroll
+          for (int jn = 0; jn < WN_TILES; ++jn) {
+            // small terms first: they are not absorbed by the large partial sum's rounding
+            acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[jn], acc[i][jn], 0, 0, 0);
+            acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[jn], acc[i][jn], 0, 0, 0);
+            acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[jn], acc[i][jn], 0, 0, 0);
+          }
+      } else {
+        v8hf ah[WM_TILES], bh[WN_TILES];
+#pragma unroll
+        for (int i = 0; i < WM_TILES; ++i)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) ah[i][e] = static_cast<_Float16>(a8[i][e]);
+#pragma unroll
+        for (int jn = 0; jn < WN_TILES; ++jn)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) bh[jn][e] = static_cast<_Float16>(b8[jn][e]);
+#pragma unroll
+        for (int i = 0; i < WM_TILES; ++i)
+#pragma unroll
+          for (int jn = 0; jn < WN_TILES; ++jn)
+            acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[jn], acc[i][jn], 0, 0, 0);
+      }
+#ifndef TFMQ_DBG_GEMM_NO_STORE
+      if (grp == 0) {
+        la.template store<PAR ^ 1>(sA[buf ^ 1]);
+        lb.template store<PAR ^ 1>(sB[buf ^ 1]);
+      }
+#endif
+    }
     }
     __syncthreads();
   };
@@ -404,6 +487,17 @@ int tfmq_gemm_f32_mfma_launch(tfmq_handle h, GemmP& p, int batch, hipStream_t st
       mb = mode_of(p.B, p.sbn, p.sbk, N, batch > 1 ? (p.bsb | p.bsb2) : 0);
   if (getenv("TFMQ_GEMM_GENERIC_LOADER")) ma = mb = 0;
   const bool bk32 = getenv("TFMQ_GEMM_BK32") != nullptr;
+  const int prec = h->gemm_prec;
+  if (prec != 0 && BN == 64 && !bk32) {
+#define TFMQ_GEMM_PREC(PR)                                                                                                        \
+    if (ma == 1 && mb == 1) hipLaunchKernelGGL((k_gemm_f32_mfma<4, 1, 1, 2, 1, 1, 16, PR>), grid, dim3(256), 0, st, p);           \
+    else if (ma == 1 && mb == 2) hipLaunchKernelGGL((k_gemm_f32_mfma<4, 1, 1, 2, 1, 2, 16, PR>), grid, dim3(256), 0, st, p);      \
+    else if (ma == 2 && mb == 1) hipLaunchKernelGGL((k_gemm_f32_mfma<4, 1, 1, 2, 2, 1, 16, PR>), grid, dim3(256), 0, st, p);      \
+    else if (ma == 2 && mb == 2) hipLaunchKernelGGL((k_gemm_f32_mfma<4, 1, 1, 2, 2, 2, 16, PR>), grid, dim3(256), 0, st, p);      \
+    else hipLaunchKernelGGL((k_gemm_f32_mfma<4, 1, 1, 2, 0, 0, 16, PR>), grid, dim3(256), 0, st, p);
+    if (prec == 1) { TFMQ_GEMM_PREC(1) } else { TFMQ_GEMM_PREC(2) }
+#undef TFMQ_GEMM_PREC
+  } else
   if (BN == 128 && ma == 1 && mb == 1) hipLaunchKernelGGL((k_gemm_f32_mfma<2, 2, 2, 2, 1, 1>), grid, dim3(256), 0, st, p);
   else if (BN == 128 && ma == 1 && mb == 2) hipLaunchKernelGGL((k_gemm_f32_mfma<2, 2, 2, 2, 1, 2>), grid, dim3(256), 0, st, p);
   else if (BN == 128 && ma == 2 && mb == 2) hipLaunchKernelGGL((k_gemm_f32_mfma<2, 2, 2, 2, 2, 2>), grid, dim3(256), 0, st, p);

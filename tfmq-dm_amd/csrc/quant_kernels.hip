@@ -43,6 +43,75 @@ extern "C" int tfmq_quantize_act(tfmq_handle h, const float* x, int8_t* q, size_
   return TFMQ_OK;
 }
 
+__global__ __launch_bounds__(256) void k_fake_quant_sel(const float* __restrict__ x, float* __restrict__ y, size_t n, tfmq_qsel qs,
+                                                        float lmax, float pre) {
+  const float2 p = load_qparam(qs);
+  const size_t stride = static_cast<size_t>(gridDim.x) * blockDim.x;
+  for (size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const float v = x[i] * pre;
+    y[i] = p.x * (quant_index_f(v, p.x, p.y, lmax) - p.y);
+  }
+}
+
+extern "C" int tfmq_fake_quant_sel(tfmq_handle h, const float* x, float* y, size_t n, tfmq_qsel qs, int level, float pre, void* stream) {
+  TFMQ_CHECK_ARG(h, h && x && y && qs.qtable, "fake_quant_sel: null pointer");
+  TFMQ_CHECK_ARG(h, level >= 2 && level <= 65536, "fake_quant_sel: level must be in [2, 65536]");
+  if (n == 0) return TFMQ_OK;
+  int blocks = ceil_div(static_cast<long>(n), 256);
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(k_fake_quant_sel, dim3(blocks), dim3(256), 0, as_stream(stream), x, y, n, qs, static_cast<float>(level - 1), pre);
+  TFMQ_LAUNCH_CHECK(h);
+  return TFMQ_OK;
+}
+
+// W8A8 layers (include/tfmq_hip.h): activation bins -> their integer grid (b - z_a), exact in fp16 / fp32
+template <bool HALF>
+__global__ __launch_bounds__(256) void k_bins_to_grid(const int8_t* __restrict__ xq, tfmq_qsel qs, void* __restrict__ out, size_t n) {
+  const float zp = load_qparam(qs).y;
+  const size_t n4 = n >> 2;
+  const size_t stride = static_cast<size_t>(gridDim.x) * blockDim.x;
+  const char4* q4 = reinterpret_cast<const char4*>(xq);
+  for (size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    const char4 c = q4[i];
+    const float a = static_cast<float>(c.x + 128) - zp, b = static_cast<float>(c.y + 128) - zp;
+    const float e = static_cast<float>(c.z + 128) - zp, f = static_cast<float>(c.w + 128) - zp;
+    if constexpr (HALF) {
+      const __half2 lo = __floats2half2_rn(a, b), hi = __floats2half2_rn(e, f);
+      reinterpret_cast<uint2*>(out)[i] = make_uint2(*reinterpret_cast<const unsigned*>(&lo), *reinterpret_cast<const unsigned*>(&hi));
+    } else {
+      reinterpret_cast<float4*>(out)[i] = make_float4(a, b, e, f);
+    }
+  }
+  if (!HALF && blockIdx.x == 0)
+    for (size_t i = (n4 << 2) + threadIdx.x; i < n; i += blockDim.x) reinterpret_cast<float*>(out)[i] = static_cast<float>(xq[i] + 128) - zp;
+}
+
+extern "C" int tfmq_bins_to_grid(tfmq_handle h, const int8_t* xq, tfmq_qsel qs, void* out, int out_f16, size_t n, void* stream) {
+  TFMQ_CHECK_ARG(h, h && xq && out && qs.qtable, "bins_to_grid: null pointer");
+  TFMQ_CHECK_ARG(h, !out_f16 || n % 4 == 0, "bins_to_grid: fp16 output needs n % 4 == 0");
+  TFMQ_CHECK_ARG(h, (reinterpret_cast<uintptr_t>(xq) & 3) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0, "bins_to_grid: alignment");
+  if (n == 0) return TFMQ_OK;
+  int blocks = ceil_div(static_cast<long>((n + 3) / 4), 256);
+  if (blocks > 8192) blocks = 8192;
+  if (out_f16) hipLaunchKernelGGL(k_bins_to_grid<true>, dim3(blocks), dim3(256), 0, as_stream(stream), xq, qs, out, n);
+  else hipLaunchKernelGGL(k_bins_to_grid<false>, dim3(blocks), dim3(256), 0, as_stream(stream), xq, qs, out, n);
+  TFMQ_LAUNCH_CHECK(h);
+  return TFMQ_OK;
+}
+
+__global__ void k_scale_by_qdelta(const float* __restrict__ ws, tfmq_qsel qs, float* __restrict__ out, int n) {
+  const float d = load_qparam(qs).x;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = d * ws[i];
+}
+
+extern "C" int tfmq_scale_by_qdelta(tfmq_handle h, const float* ws, tfmq_qsel qs, float* out, int n, void* stream) {
+  TFMQ_CHECK_ARG(h, h && ws && out && qs.qtable && n > 0, "scale_by_qdelta: null pointer / empty");
+  hipLaunchKernelGGL(k_scale_by_qdelta, dim3(ceil_div(n, 256)), dim3(256), 0, as_stream(stream), ws, qs, out, n);
+  TFMQ_LAUNCH_CHECK(h);
+  return TFMQ_OK;
+}
+
 // the same on a tensor of the fp16 activation stream (n % 4 == 0)
 __global__ __launch_bounds__(256) void k_quantize_act_h(const __half* __restrict__ x, int8_t* __restrict__ q, size_t n,
                                                         tfmq_qsel qs, float lmax) {

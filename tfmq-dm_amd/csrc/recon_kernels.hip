@@ -102,6 +102,12 @@ static int gemm_f32_impl(tfmq_handle h, const float* A, const float* B, float* C
   return TFMQ_OK;
 }
 
+extern "C" int tfmq_set_gemm_precision(tfmq_handle h, int mode) {
+  TFMQ_CHECK_ARG(h, h && mode >= 0 && mode <= 2, "set_gemm_precision: mode 0 (exact fp32), 1 (bf16x3) or 2 (fp16)");
+  h->gemm_prec = mode;
+  return TFMQ_OK;
+}
+
 extern "C" int tfmq_gemm_f32(tfmq_handle h, const float* A, const float* B, float* C, int M, int N, int K, long sam,
                              long sak, long sbk, long sbn, long scm, int batch, long bsa, long bsb, long bsc, float alpha,
                              const float* bias, const float* rowadd, int rows_per_img, int rowadd_ld,

@@ -39,8 +39,12 @@ class LayerQ:
 
 
 class _Layer:
-    def __init__(self, kind, packed, aq, w32=None):
+    def __init__(self, kind, packed, aq, w32=None, wide=False):
         self.kind, self.p, self.aq = kind, packed, aq
+        # wide: a quantised-weight x 8-bit-activation layer whose weights have MORE than 16 levels (the --wq 8 recipes).  (q_w - z_w)
+        # then needs 9 bits and does not fit the int8 MFMA operand; the layer keeps kind "w4a8" (= consumes activation bins) but its
+        # packed weights are the fp16 integer grid and it runs the fp16-operand kernels on exact integers (see _run_wide).
+        self.wide = wide
         # TFMQ_EXACT_FP=1 (parity diagnostics): fp32 weights [cout, kh*kw*cin] in the im2col column order.  An un-quantised /
         # weight-only layer then runs as im2col + the exact-fp32 MFMA GEMM (the reference's fp32 F.conv2d / F.linear up to the
         # summation order) instead of the fp16-operand kernels.
@@ -74,9 +78,23 @@ class _Layer:
         y = ops.gemm(col, self.w32, trans_b=True, bias=self.p.bias, rowadd=ra, rows_per_img=Ho * Wo, residual=res)
         return y.reshape(B, Ho, Wo, cout)
 
+    def _run_wide(self, xq, **kw):
+        """W8A8: (b - z_a) and (q_w - z_w) are integers of magnitude <= 255, exact in fp16; their products are exact in the fp32
+        accumulator of the fp16 MFMA and the sums round like any fp32 accumulation -- at least as exact as the reference, which runs an
+        fp32 conv on the DEquantised values.  Output scale delta_a(step) * delta_w[c]."""
+        for k in ("out_q8", "geglu_oq", "t_col0"):
+            if kw.get(k) is not None:
+                raise TfmqError(f"W8A8 layer: the fused int8-path epilogue '{k}' is not available")
+        half = ops.f16_dma_ok(self.p.cin, self.p.kh, self.p.kw)
+        xg = ops.bins_to_grid(xq, self.aq, half=half)
+        pf = ops.PackedF16(self.p.w16, self.p.bias, self.p.cout, self.p.cin, self.p.kh, self.p.kw, wscale=ops.scale_by_qdelta(self.p.wscale, self.aq))
+        return ops.conv2d_f16(xg, pf, **kw)
+
     def run(self, x, **kw):
         kw.setdefault("want_stats", True)   # conv-epilogue GroupNorm statistics (K8 split form)
         if self.kind == "w4a8":
+            if self.wide:
+                return self._run_wide(x, **kw)
             return ops.conv2d_w4a8(x, self.p, self.aq, **kw)
         if self.w32 is not None:
             return self._run_exact(x, **kw)
@@ -114,12 +132,12 @@ class _Layer:
 
 
 def _check_w4a8_levels(name: str, q: LayerQ) -> None:
-    """The int8-MFMA path stores weights as nibbles (16 levels) and activations as 256 bins.  Another bit width (the
-    reference's --wq 8 recipe) must not be run on it silently: the deltas would have been searched for that width and the
-    packed values clamped to 4 bits."""
-    if q.level != 16 or q.act_level != 256:
-        raise TfmqError(f"{name}: the HIP engine's quantised layers are 4-bit weights x 8-bit activations; got "
-                        f"{q.level} weight levels / {q.act_level} activation levels (W8A8 is not built on the device path yet)")
+    """The int8-MFMA path stores weights as nibbles (<= 16 levels) and activations as 256 bins; weights with up to 2048 levels (the
+    reference's --wq 8 recipes: 256) run the fp16 integer-grid path (_Layer._run_wide).  Anything else must not be run silently on
+    either: the deltas would have been searched for that width."""
+    if q.act_level != 256 or not 2 <= q.level <= 2048:
+        raise TfmqError(f"{name}: the HIP engine's quantised layers are 2..2048-level weights x 8-bit activations; got "
+                        f"{q.level} weight levels / {q.act_level} activation levels")
 
 
 def ddim_resblock_names(cfg) -> List[str]:
@@ -199,12 +217,17 @@ class DdimUNetEngine:
         return [k[:-7] for k in self.sd if k.endswith(".weight") and self.sd[k].dim() == 4]
 
     def prepare(self, wq: Optional[Dict[str, LayerQ]] = None, qtable: Optional[torch.Tensor] = None,
-                step: Optional[torch.Tensor] = None):
+                step: Optional[torch.Tensor] = None, attn_q: Optional[Dict[str, dict]] = None):
         """wq: name -> LayerQ for every weight-quantised layer (absent => FP layer).  A layer with
         LayerQ.qid != None and a qtable runs w4a8; qtable: fp32 [n_steps, n_q, 2] on the device."""
         wq = wq or {}
         self.qtable = None if qtable is None else qtable.to(self.dev, torch.float32).contiguous()
         self.step = step
+        # attn_q (SURVEY section 8f-3, off unless a block's `use_aq` was switched on by hand): attention path -> {"q", "k", "v", "w": qid in
+        # the activation table, "w_level": levels of the softmax quantizer}; that attention then runs ops.attention_quant
+        self.attn_q = dict(attn_q or {})
+        if self.attn_q and self.qtable is None:
+            raise TfmqError("prepare: attention quantizers need the activation table")
         self.layers.clear()
         self.lin.clear()
         sd = self.sd
@@ -228,7 +251,10 @@ class DdimUNetEngine:
             else:
                 _check_w4a8_levels(n, q)
                 a = None if q.alpha is None else q.alpha.to(self.dev).contiguous()
-                self.layers[n] = _Layer("w4a8", ops.pack_w4(w, q.delta.to(self.dev), q.zp.to(self.dev), a, b), aq)
+                if q.level > 16:
+                    self.layers[n] = _Layer("w4a8", ops.pack_w_f16(w, b, q.delta.to(self.dev), q.zp.to(self.dev), a, level=q.level), aq, wide=True)
+                else:
+                    self.layers[n] = _Layer("w4a8", ops.pack_w4(w, q.delta.to(self.dev), q.zp.to(self.dev), a, b), aq)
         # linears of the temporal-information block
         for n in [k[:-7] for k in sd if k.endswith(".weight") and sd[k].dim() == 2]:
             w, b = sd[n + ".weight"], sd.get(n + ".bias")
@@ -238,7 +264,12 @@ class DdimUNetEngine:
             else:
                 _check_w4a8_levels(n, q)
                 a = None if q.alpha is None else q.alpha.to(self.dev).contiguous()
-                self.lin[n] = ("w4", ops.pack_w4(w, q.delta.to(self.dev), q.zp.to(self.dev), a, b), None, aq_of(q))
+                if q.level > 16:       # wide weights: dequantised fp32 weights (q - z) delta, fp32 GEMV; activations fake-quantised first
+                    pf = ops.pack_w_f16(w.reshape(w.shape[0], w.shape[1], 1, 1).contiguous(), b, q.delta.to(self.dev), q.zp.to(self.dev), a, level=q.level)
+                    w32 = (pf.w16[:, 0, :w.shape[1]].float() * pf.wscale.reshape(-1, 1)).contiguous()
+                    self.lin[n] = ("w8", w32, b, aq_of(q))
+                else:
+                    self.lin[n] = ("w4", ops.pack_w4(w, q.delta.to(self.dev), q.zp.to(self.dev), a, b), None, aq_of(q))
         # fused q/k/v GEMM where the three sibling quantizers agree at every step
         self.fused_qkv: Dict[str, _Layer] = {}
         for n in list(self.layers):
@@ -246,7 +277,7 @@ class DdimUNetEngine:
                 continue
             p = n[:-2]
             ls = [self.layers[p + s] for s in (".q", ".k", ".v")]
-            if all(l.kind == "w4a8" for l in ls):
+            if all(l.kind == "w4a8" and not l.wide for l in ls):
                 ids = [wq[p + s].qid for s in (".q", ".k", ".v")]
                 same = all(bool(torch.equal(self.qtable[:, ids[0]], self.qtable[:, i])) for i in ids[1:])
                 if same:
@@ -255,7 +286,7 @@ class DdimUNetEngine:
                                       3 * ls[0].p.cout, ls[0].p.cin, 1, 1)
                     self.fused_qkv[p] = _Layer("w4a8", pk, ls[0].aq)
                     self.fused_qkv[p].sibling_qids = tuple(ids[1:])
-            elif all(l.kind in ("fp", "w4") for l in ls) and len({l.kind for l in ls}) == 1:
+            elif all(l.kind in ("fp", "w4") for l in ls) and len({l.kind for l in ls}) == 1 and not any(l.wide for l in ls):
                 pf = ls[0].p
                 ws = None if pf.wscale is None else torch.cat([l.p.wscale for l in ls])
                 pk = ops.PackedF16(torch.cat([l.p.w16 for l in ls]), torch.cat([l.p.bias for l in ls]), 3 * pf.cout,
@@ -286,7 +317,7 @@ class DdimUNetEngine:
         if self.step is not None:
             self.step.fill_(int(k))
 
-    def _observe(self, aq, x, siblings=()):
+    def _observe(self, aq, x, siblings=(), level: int = 256, always_zero: bool = False):
         mode, k = self.calib
         qid = aq.qid
         if self.calib_mask is not None and qid not in self.calib_mask:
@@ -296,14 +327,17 @@ class DdimUNetEngine:
             for s in siblings:
                 self.observed[s] = self.observed[qid]
             return
+        x = x.contiguous()
         if mode == "init":
-            qp = ops.mse_search(x, 1, 256)
+            qp = ops.mse_search(x, 1, level, always_zero=always_zero)
             self.qtable[k, qid].copy_(qp[0])
-            ops.act_range_update(ops.minmax(x), self.act_state[qid:qid + 1], self._qp_scratch, 0.95, 256, init=True)
+            ops.act_range_update(ops.minmax(x), self.act_state[qid:qid + 1], self._qp_scratch, 0.95, level, init=True)
         elif mode == "init_minmax":  # Scaler.MINMAX init (aq_params of the non-calibrating drivers)
-            ops.act_range_update(ops.minmax(x), self.act_state[qid:qid + 1], self.qtable[k, qid], 0.95, 256, init=True)
+            ops.act_range_update(ops.minmax(x), self.act_state[qid:qid + 1], self.qtable[k, qid], 0.95, level, init=True)
         else:
-            ops.act_range_update(ops.minmax(x), self.act_state[qid:qid + 1], self.qtable[k, qid], 0.95, 256, init=False)
+            ops.act_range_update(ops.minmax(x), self.act_state[qid:qid + 1], self.qtable[k, qid], 0.95, level, init=False)
+        if always_zero and mode != "init":      # the softmax quantizer: delta = x_max / (level - 1), zero point 0 (quant_layer.py:29-30,34)
+            self.qtable[k, qid].copy_(ops.minmax_to_qparam(self.act_state[qid:qid + 1].contiguous(), level, always_zero=True)[0])
         for s in siblings:  # sibling quantizers see the identical tensor
             self.qtable[k, s].copy_(self.qtable[k, qid])
             self.act_state[s].copy_(self.act_state[qid])
@@ -314,6 +348,15 @@ class DdimUNetEngine:
         if ent[0] == "fp":
             return ops.linear_small_f32(x, ent[1], ent[2], silu_in=silu_in)
         aq = ent[3]
+        if ent[0] == "w8":
+            xs = ops.silu(x) if silu_in else x
+            if aq is not None:
+                if self.calib is not None:
+                    self._observe(aq, xs)
+                k = 0 if self.step is None else int(self.step.item())
+                qp = self.qtable[k, aq.qid]
+                xs = ops.fake_quant(xs.contiguous(), qp[0:1].contiguous(), qp[1:2].contiguous(), 256)
+            return ops.linear_small_f32(xs, ent[1], ent[2], silu_in=False)
         if aq is not None and self.calib is not None:
             xs = ops.silu(x) if silu_in else x
             self._observe(aq, xs)
@@ -392,6 +435,16 @@ class DdimUNetEngine:
     def _fp_conv_half_ok(self, layer: _Layer) -> bool:
         return (not self.exact_fp) and layer.kind != "w4a8" and ops.f16_dma_ok(layer.p.cin, layer.p.kh, layer.p.kw)
 
+    def _attention_quantised(self, key: str, q, k, v, heads: int, scale: float, pre: float = 1.0):
+        """The attention of a block whose quantizers were switched on (self.attn_q[key]): fp32 out."""
+        cfg = self.attn_q[key]
+        sel = {w: ops.qsel(self.qtable, cfg[w], self.step) for w in ("q", "k", "v", "w")}
+        obs = None
+        if self.calib is not None:
+            def obs(which, t):
+                self._observe(sel[which], t, level=cfg["w_level"] if which == "w" else 256, always_zero=which == "w")
+        return ops.attention_quant(q, k, v, heads, scale, sel["q"], sel["k"], sel["v"], sel["w"], cfg["w_level"], pre, obs)
+
     def _attention_exact(self, q, k, v, heads: int, scale: float, aq):
         """softmax(q k^T scale) v as exact-fp32 matmuls and a row softmax (three launches per head); (fp32 out, int8 bins | None)"""
         out, _ = ops._attention_wide(q, k, v, heads, scale, None, True)
@@ -427,7 +480,7 @@ class DdimUNetEngine:
         B, H, W, Cc = x.shape
         po = L[p + ".proj_out"]
         f = self.fused_qkv.get(p)
-        if (f is not None and f.kind == "w4a8" and self.calib is None and not self.exact_fp and ops.attention_f16_ok(Cc, H * W)
+        if (f is not None and f.kind == "w4a8" and self.calib is None and not self.exact_fp and p not in self.attn_q and ops.attention_f16_ok(Cc, H * W)
                 and (2 * Cc) % 128 == 0 and (H * W) % 4 == 0):
             # the fused q|k|v GEMM writes q, k as fp16 rows and v as fp16 V^T; the flash kernel reads them tile by tile
             # (what the fp32-operand kernel rounds to on load -- same products, no fp32 round trip)
@@ -454,6 +507,10 @@ class DdimUNetEngine:
         qkv = qkv.reshape(B, H * W, 3 * Cc)
         aq = po.aq if po.kind == "w4a8" else None
         attn = self._attention_exact if self.exact_fp else (lambda q, k, v, h, sc, a=None: ops.attention(q, k, v, h, sc, a, want_f32=a is None))
+        if p in self.attn_q:      # QuantAttnBlock.use_aq (quant_block.py:487-498): quantised q, k, softmax, v
+            def attn(q, k, v, h, sc, a=None):
+                o = self._attention_quantised(p, q, k, v, h, sc)
+                return o, (ops.quantize_act(o, a) if a is not None else None)
         if aq is not None and self.calib is not None:
             out, _ = attn(qkv[..., :Cc], qkv[..., Cc:2 * Cc], qkv[..., 2 * Cc:], 1, float(int(Cc) ** (-0.5)), None)
             self._observe(aq, out)

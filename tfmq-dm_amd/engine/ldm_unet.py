@@ -77,8 +77,8 @@ class LdmUNetEngine(DdimUNetEngine):
                 self.cfg["model_channels"], True)
 
     # ------------------------------------------------------------------ prepare: add fused k|v of the cross attention
-    def prepare(self, wq=None, qtable=None, step=None):
-        super().prepare(wq, qtable, step)
+    def prepare(self, wq=None, qtable=None, step=None, attn_q=None):
+        super().prepare(wq, qtable, step, attn_q)
         wq = wq or {}
         self.fused_kv: Dict[str, _Layer] = {}
         # self-attention q|k|v: the base class fuses names ending in ".q"; here the layers are to_q/to_k/to_v
@@ -105,7 +105,7 @@ class LdmUNetEngine(DdimUNetEngine):
                 continue
             l0, l2 = self.layers[n], self.layers.get(n[:-len("0.proj")] + "2")
             q = wq.get(n)
-            if l0.kind != "w4a8" or l2 is None or l2.kind != "w4a8" or q is None:
+            if l0.kind != "w4a8" or l2 is None or l2.kind != "w4a8" or q is None or l0.wide or l2.wide:
                 continue
             w, b = self.sd[n + ".weight"], self.sd.get(n + ".bias")
             inner = w.shape[0] // 2
@@ -119,7 +119,7 @@ class LdmUNetEngine(DdimUNetEngine):
 
     def _fuse(self, ls, qs):
         kinds = {l.kind for l in ls}
-        if len(kinds) != 1:
+        if len(kinds) != 1 or any(l.wide for l in ls):
             return None
         if ls[0].kind == "w4a8":
             ids = [q.qid for q in qs]
@@ -182,7 +182,7 @@ class LdmUNetEngine(DdimUNetEngine):
             sc = L[p + ".skip_connection"].run(x1, x2=x2, want_stats=False, **self._o16())
         else:
             sc = L[p + ".skip_connection"].run(xcat if xcat is not None else x1, want_stats=False, **self._o16()) if has_skip else x1
-        if out_aq is not None and cout.kind == "w4a8":
+        if out_aq is not None and cout.kind == "w4a8" and not cout.wide:
             return cout.run(h, pad=(1, 1, 1, 1), residual=sc, want_stats=False, out_q8=out_aq)
         return cout.run(h, pad=(1, 1, 1, 1), residual=sc, **self._o16())
 
@@ -192,9 +192,10 @@ class LdmUNetEngine(DdimUNetEngine):
         heads = self.cfg["num_heads"]
         to_out = L[p + ".to_out.0"]
         f = self.fused_qkv.get(p) if self_attn else None
-        if self.exact_fp:
+        aq_on = p in self.attn_q          # cross_attn_forward with use_aq (quant_block.py:226-243)
+        if self.exact_fp or aq_on:
             f = None if f is None or f.kind == "w4a8" else f      # (the w4a8 fused projection would write fp16 attention operands)
-        if f is not None and f.kind != "w4a8" and self.calib is None and not self.exact_fp:
+        if f is not None and f.kind != "w4a8" and self.calib is None and not self.exact_fp and not aq_on:
             # FP / weight-only state (calibration data passes, FP sampling of the calibration set): the same fp16-operand
             # attention, fed by the un-quantised fused projection
             B, T, Cin = xq_src.shape
@@ -222,7 +223,7 @@ class LdmUNetEngine(DdimUNetEngine):
                     o, _ = ops.attention_f16(y16[..., :Cc], y16[..., Cc:2 * Cc], vt, heads, float(d ** -0.5))
                     o = self._quant_in(to_out, o)
                 return self._tok(to_out, o, residual=x_res, **self._o16())
-        if (not self_attn) and self.calib is None and self._ctx_pad is not None and not self.exact_fp:
+        if (not self_attn) and self.calib is None and self._ctx_pad is not None and not self.exact_fp and not aq_on:
             # cross attention on fp16 operands: the context is stored padded to a multiple of 8 tokens (padding masked
             # in the kernel), to_q writes fp16 rows, to_k fp16 rows, to_v its fp16 transpose
             lq, lk, lv = L[p + ".to_q"], L[p + ".to_k"], L[p + ".to_v"]
@@ -230,7 +231,7 @@ class LdmUNetEngine(DdimUNetEngine):
             B, T, Cin = xq_src.shape
             Cc = lq.p.cout
             d = Cc // heads
-            if lq.kind == lk.kind == lv.kind == "w4a8" and ops.attention_f16_ok(d, cpad.shape[1]):
+            if lq.kind == lk.kind == lv.kind == "w4a8" and not (lq.wide or lk.wide or lv.wide) and ops.attention_f16_ok(d, cpad.shape[1]):
                 Bc, Lp, Dc = cpad.shape
                 q16 = ops.conv2d_w4a8(xq_src.reshape(B, T, 1, Cin), lq.p, lq.aq, out_f16=True).reshape(B, T, Cc)
                 k16 = ops.conv2d_w4a8(ops.quantize_act(cpad, lk.aq).reshape(Bc, Lp, 1, Dc), lk.p, lk.aq, out_f16=True)
@@ -261,7 +262,9 @@ class LdmUNetEngine(DdimUNetEngine):
                 v = self._tok(L[p + ".to_v"], self._quant_in(L[p + ".to_v"], ctx))
         d = Cc // heads
         aq = to_out.aq if to_out.kind == "w4a8" else None
-        if self.exact_fp:
+        if aq_on:
+            o = self._quant_in(to_out, self._attention_quantised(p, q, k, v, heads, float(d ** -0.5)))
+        elif self.exact_fp:
             o, oq = self._attention_exact(q, k, v, heads, float(d ** -0.5), aq if self.calib is None else None)
             o = oq if oq is not None else self._quant_in(to_out, o)
         elif aq is not None and self.calib is None:
@@ -288,7 +291,7 @@ class LdmUNetEngine(DdimUNetEngine):
         L = self.layers
         q1 = self.fused_qkv.get(p + ".attn1", L[p + ".attn1.to_q"])
         x = self._attention(p + ".attn1", self._ln(p + ".norm1", x, q1), None, x, True)
-        if (ctx is not None and ctx.shape[1] == 1 and self.calib is None and x.shape[-1] % 8 == 0 and not self.exact_fp
+        if (ctx is not None and ctx.shape[1] == 1 and self.calib is None and x.shape[-1] % 8 == 0 and not self.exact_fp and (p + ".attn2") not in self.attn_q
                 and os.environ.get("TFMQ_SINGLE_CTX_TOKEN", "1") != "0"):
             x = self._attn2_single_token(p + ".attn2", ctx, x)
         else:
@@ -321,7 +324,7 @@ class LdmUNetEngine(DdimUNetEngine):
             taps[p + ".proj_in"] = (h_in, h)
         tok = h.reshape(B, H * W, h.shape[-1])
         nblk = _n_children(self.sd, p + ".transformer_blocks")
-        fuse_q = pout.kind == "w4a8" and self.calib is None and taps is None and self.fuse_q8
+        fuse_q = pout.kind == "w4a8" and not pout.wide and self.calib is None and taps is None and self.fuse_q8
         for i in range(nblk):
             name = f"{p}.transformer_blocks.{i}"
             tin = tok
@@ -333,7 +336,7 @@ class LdmUNetEngine(DdimUNetEngine):
             # the layer's own output (its reconstruction target) excludes the residual; the data path stays the fused
             # launch, so a tapped forward is bit-identical to the sampling forward
             taps[p + ".proj_out"] = (h, pout.run(h, want_stats=False))
-        if out_aq is not None and pout.kind == "w4a8":
+        if out_aq is not None and pout.kind == "w4a8" and not pout.wide:
             return pout.run(h, residual=x, want_stats=False, out_q8=out_aq)
         return pout.run(h, residual=x, **self._o16())
 
@@ -346,7 +349,7 @@ class LdmUNetEngine(DdimUNetEngine):
         heads = self.cfg["num_heads"] if nhc in (-1, None) else Cc // nhc
         d = Cc // heads
         T = H * W
-        if (self.calib is None and not self.exact_fp and qkv_l.kind != "w4a8" and self._fp_conv_half_ok(qkv_l) and ops.attention_f16_ok(d, T)
+        if (self.calib is None and not self.exact_fp and (p + ".attention") not in self.attn_q and qkv_l.kind != "w4a8" and self._fp_conv_half_ok(qkv_l) and ops.attention_f16_ok(d, T)
                 and T % 4 == 0 and os.environ.get("TFMQ_ATTNBLOCK_F16", "1") != "0"):
             # fp16 operands end to end: the GroupNorm writes fp16, the qkv conv writes q | k as fp16 rows and v as fp16 V^T, the flash
             # kernel copies them tile by tile -- the values the fp32-operand kernel below rounds to on load (same products), without
@@ -370,7 +373,9 @@ class LdmUNetEngine(DdimUNetEngine):
             hn, _ = self._gn(p + ".norm", x, None, False, qkv_l, eps=1e-5)
         qkv = qkv_l.run(hn, want_stats=False).reshape(B, H * W, 3 * Cc)
         # q*s . k*s with s = d^-1/4 (QKMatMul) == (q . k) * d^-1/2
-        if self.exact_fp:
+        if (p + ".attention") in self.attn_q:      # QuantQKMatMul / QuantSMVMatMul with use_aq: the quantizers see q, k scaled by d^-1/4 (quant_block.py:318-323)
+            o = self._attention_quantised(p + ".attention", qkv[..., :Cc], qkv[..., Cc:2 * Cc], qkv[..., 2 * Cc:], heads, 1.0, pre=float(d ** -0.25))
+        elif self.exact_fp:
             o, _ = self._attention_exact(qkv[..., :Cc], qkv[..., Cc:2 * Cc], qkv[..., 2 * Cc:], heads, float(d ** -0.5), None)
         else:
             o, _ = ops.attention(qkv[..., :Cc], qkv[..., Cc:2 * Cc], qkv[..., 2 * Cc:], heads, float(d ** -0.5))
@@ -384,7 +389,7 @@ class LdmUNetEngine(DdimUNetEngine):
             hin = h
             # the next child is an up-sampling conv on 8-bit activations: this child's output feeds only its quantizer
             nxt = L.get(f"{p}.{j + 1}.conv") if j + 1 < nchild else None
-            out_aq = nxt.aq if (nxt is not None and nxt.kind == "w4a8" and self.calib is None and taps is None
+            out_aq = nxt.aq if (nxt is not None and nxt.kind == "w4a8" and not nxt.wide and self.calib is None and taps is None
                                 and self.fuse_q8) else None
             if (q + ".in_layers.0.weight") in self.sd:
                 h = self._res(q, h, skip if j == 0 else None, rowadd(q), out_aq=out_aq)

@@ -11,6 +11,7 @@ running one Adam iteration on the mini-batch `idx` of its cached inputs/targets:
 """
 from __future__ import annotations
 
+import os
 from typing import Dict, List, Optional, Sequence
 
 import torch
@@ -61,6 +62,21 @@ class AdaLayer:
                               w_reg, b_temp, lr, t, round_loss)
 
 
+def _chunk_cuts(sizes: Sequence[int], n_chunks: int):
+    """Cut a list of layer gradient sizes into <= n_chunks contiguous pieces of roughly equal bytes, at layer boundaries.
+    -> [(first layer, end layer, first element, end element)]"""
+    total, n = sum(sizes), len(sizes)
+    n_chunks = max(1, min(n_chunks, n))
+    cuts, l0, e0, acc, k = [], 0, 0, 0, 1
+    for i, sz in enumerate(sizes):
+        acc += sz
+        last = i == n - 1
+        if last or (k < n_chunks and acc >= total * k / n_chunks and n - 1 - i >= n_chunks - k):
+            cuts.append((l0, i + 1, e0, acc))
+            l0, e0, k = i + 1, acc, k + 1
+    return cuts
+
+
 class _Unit:
     """Shared iteration driver.  Sub-classes implement _forward_backward(idx) -> (rec_loss_tensor,
     [g_what per AdaLayer, OIHW])."""
@@ -77,35 +93,72 @@ class _Unit:
         dev = self.layers[0].w.device
         self._rl = torch.zeros(1, dtype=torch.float32, device=dev)
         self._flat = None
+        self._comm_stream = None
+        self.gemm_mode = os.environ.get("TFMQ_RECON_GEMM", "f32")
+        self.exchange_chunks = max(1, int(os.environ.get("TFMQ_EXCHANGE_CHUNKS", "2")))
 
     def iterate(self, idx: torch.Tensor):
         self.count += 1
-        rec, grads = self._forward_backward(idx)
-        if self.world_size > 1 and self.allreduce is not None:
-            # one flattened fp32 buffer per iteration instead of one all-reduce per tensor
-            # (reference reconstruction.py:193-195); the rounding regulariser is computed identically on
-            # every rank and is therefore summed world_size times by the reference's grad all-reduce.
-            if self._flat is None:
-                self._flat = torch.empty(sum(g.numel() for g in grads), dtype=torch.float32, device=grads[0].device)
-            off = 0
-            for g in grads:
-                self._flat[off:off + g.numel()].copy_(g.reshape(-1))
-                off += g.numel()
-            local = self._flat.clone() if (_Unit.trace is not None and self.count == 1) else None
-            self.allreduce(self._flat)
-            if local is not None:
-                _Unit.trace.append((type(self).__name__, local.cpu(), self._flat.cpu().clone()))
-            off, red = 0, []
-            for g in grads:
-                red.append(self._flat[off:off + g.numel()].view_as(g))
-                off += g.numel()
-            grads = red
+        # TFMQ_RECON_GEMM = f32 (default: exact fp32 products) | bf16x3 | f16: operand precision of the unit's forward / backward GEMMs
+        # on the matrix cores (ops.gemm_precision; csrc/gemm_f32_mfma.hip).  The soft-rounded weights, the loss, the AdaRound /
+        # Adam kernels and the fused attention stay fp32 in every mode.
+        if self.gemm_mode != "f32":
+            with ops.gemm_precision(self.gemm_mode, self._rl.device.index):
+                rec, grads = self._forward_backward(idx)
+        else:
+            rec, grads = self._forward_backward(idx)
         b = temp_decay(self.count, self.iters, self.warmup, self.b_range[0], self.b_range[1])
         reg_on = self.count >= self.iters * self.warmup
         self._rl.zero_()
-        w_eff = self.w_reg * (self.world_size if (self.world_size > 1 and self.allreduce is not None) else 1)
-        for layer, g in zip(self.layers, grads):
-            layer.step(g, w_eff, b if reg_on else 0.0, self.lr, self.count, self._rl)
+        dist_on = self.world_size > 1 and self.allreduce is not None
+        w_eff = self.w_reg * (self.world_size if dist_on else 1)
+        if not dist_on:
+            for layer, g in zip(self.layers, grads):
+                layer.step(g, w_eff, b if reg_on else 0.0, self.lr, self.count, self._rl)
+            return rec, self._rl
+        # One flattened fp32 buffer per iteration instead of one all-reduce per tensor (reference reconstruction.py:193-195); the
+        # rounding regulariser is computed identically on every rank and is therefore summed world_size times by the reference's
+        # grad all-reduce (w_eff).  The buffer is exchanged in `exchange_chunks` contiguous pieces cut at layer boundaries, on a SIDE
+        # stream: while piece k travels over xGMI, the fused AdaRound-backward + Adam kernels of piece k-1 run on the unit's stream
+        # (events both ways, no host synchronisation).  One piece = the plain in-stream exchange.
+        if self._flat is None:
+            self._flat = torch.empty(sum(g.numel() for g in grads), dtype=torch.float32, device=grads[0].device)
+            self._cuts = _chunk_cuts([g.numel() for g in grads], self.exchange_chunks)
+        off, views = 0, []
+        for g in grads:
+            v = self._flat[off:off + g.numel()]
+            v.copy_(g.reshape(-1))
+            views.append(v.view_as(g))
+            off += g.numel()
+        local = self._flat.clone() if (_Unit.trace is not None and self.count == 1) else None
+        side = self._flat.is_cuda and len(self._cuts) > 1
+        if not side:
+            self.allreduce(self._flat)
+            if local is not None:
+                _Unit.trace.append((type(self).__name__, local.cpu(), self._flat.cpu().clone()))
+            for layer, g in zip(self.layers, views):
+                layer.step(g, w_eff, b if reg_on else 0.0, self.lr, self.count, self._rl)
+            return rec, self._rl
+        main = torch.cuda.current_stream(self._flat.device)
+        if self._comm_stream is None:
+            self._comm_stream = torch.cuda.Stream(self._flat.device)
+            self._ev_ready = torch.cuda.Event()
+            self._ev_done = [torch.cuda.Event() for _ in self._cuts]
+            self._ev_adam = torch.cuda.Event()
+        self._ev_ready.record(main)                         # gradients are in the flat buffer
+        self._comm_stream.wait_event(self._ev_ready)
+        with torch.cuda.stream(self._comm_stream):
+            for k, (l0, l1, e0, e1) in enumerate(self._cuts):
+                self.allreduce(self._flat[e0:e1])
+                self._ev_done[k].record(self._comm_stream)
+        for k, (l0, l1, e0, e1) in enumerate(self._cuts):
+            main.wait_event(self._ev_done[k])
+            for layer, g in zip(self.layers[l0:l1], views[l0:l1]):
+                layer.step(g, w_eff, b if reg_on else 0.0, self.lr, self.count, self._rl)
+        self._ev_adam.record(main)                          # the next iteration's copies into the flat buffer are stream-ordered behind this
+        self._comm_stream.wait_event(self._ev_adam)
+        if local is not None:
+            _Unit.trace.append((type(self).__name__, local.cpu(), self._flat.cpu().clone()))
         return rec, self._rl
 
     def losses(self, rec, rl):

@@ -43,12 +43,24 @@ class DDIMSampler:
         """Opt-in (`sample(..., _graph=True)`, used by the calibration-set generators, which need neither callbacks nor
         intermediates): the same recurrence as the host loop below, replayed as captured step graphs
         (ldm/sampler.py) on the engine `model.apply_model` lowers to.  Returns None when the call does not qualify
-        (guidance-free conditional sampling, eta > 0, Finite-Set wrapper attributes set, model not lowered to an engine)."""
+        (guidance-free conditional sampling, eta > 0, PLMS with Finite-Set wrapper attributes set, model not lowered to an
+        engine).  DDIM with the drivers' Finite-Set attributes (wrapper.tot / t_max / ckpt): the group of step i is
+        k_i = t_max - (t_i - 1) // tot (ddpm.py:1402-1405); the table installed for the replay is [act_{k_0}, act_{k_1}, ...], one
+        row per executed step, indexed by the graph's device step counter."""
         from .sampler import GraphLatentDdimSampler, GraphLatentPlmsSampler
         wrapper = getattr(self.model, "model", None)
         qnn = getattr(wrapper, "diffusion_model", None)
-        if qnn is None or not hasattr(qnn, "engine") or hasattr(wrapper, "tot"):
+        if qnn is None or not hasattr(qnn, "engine"):
             return None
+        if hasattr(wrapper, "tot"):
+            if plms or not hasattr(qnn, "set_act_table"):
+                return None
+            rows = tuple(int(wrapper.t_max - (int(t) - 1) // wrapper.tot) for t in np.flip(self.ddim_timesteps))
+            mark = ("steps", id(wrapper.ckpt), rows)
+            if getattr(wrapper, "_table_of", None) != mark:
+                qnn.set_act_table(wrapper.ckpt, rows=rows)
+                wrapper._table_of = mark               # (the eager wrapper.forward re-installs the group table when it runs next)
+                qnn.__dict__.pop("_graph_samplers", None)
         dev = self.model.betas.device
         if dev.type != "cuda":
             return None

@@ -171,6 +171,69 @@ def quantize_act(x: torch.Tensor, qs: QSel, level: int = 256, out: Optional[torc
     return q
 
 
+def fake_quant_sel(x: torch.Tensor, qs: QSel, level: int = 256, pre: float = 1.0) -> torch.Tensor:
+    """delta * (clamp(rint(x * pre / delta) + zp, 0, level - 1) - zp) under the current Finite-Set group: the fake-quantised operand
+    of an attention matmul whose quantizers are enabled (tfmq_fake_quant_sel)."""
+    d = _dev(x)
+    x = x.contiguous()
+    _chk(x, torch.float32, "x")
+    y = _alloc_like(x)
+    handle(d).call("fake_quant_sel", _p(x), _p(y), x.numel(), qs, int(level), float(pre), _stream(d))
+    return y
+
+
+def attention_quant(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int, scale: float, sel_q: QSel, sel_k: QSel, sel_v: QSel,
+                    sel_w: QSel, w_level: int = 256, pre: float = 1.0, observe=None) -> torch.Tensor:
+    """softmax(q^ k^T scale) quantised to w^, times v^ -- the attention of a block whose `use_aq` is switched on (quant_block.py:226-243,
+    318-323,350-351,487-498): x^ = fake-quantised x (8 bit), w^ = the always-zero softmax quantizer (softmax_a_bit).  pre: the d^-1/4
+    factor QuantQKMatMul applies to q and k BEFORE their quantizers (then scale = 1).  Exact fp32 products of the dequantised values
+    (strided MFMA GEMMs) and an fp32 row softmax: the reference's arithmetic up to summation order.  observe(which, tensor): the
+    calibration hook, called with the tensor each quantizer is about to see ('q', 'k', 'v', 'w')."""
+    B, Tq, Cq = q.shape
+    Tk, d_ = k.shape[1], Cq // heads
+
+    def fq(which, x, sel, level, pr=1.0):
+        x = x.contiguous()
+        if pr != 1.0:        # the quantizer (and its calibration) sees the scaled tensor
+            xs = _alloc_like(x)
+            xs.zero_()
+            axpy(xs, x, pr)
+            x, pr = xs, 1.0
+        if observe is not None:
+            observe(which, x)
+        return fake_quant_sel(x, sel, level, pr)
+    qh, kh, vh = fq("q", q, sel_q, 256, pre), fq("k", k, sel_k, 256, pre), fq("v", v, sel_v, 256)
+    S = _alloc(B, heads, Tq, Tk, dtype=torch.float32, device=q.device)
+    for h in range(heads):
+        gemm_strided(qh, h * d_, Cq, 1, Tq * Cq, kh, h * d_, 1, Cq, Tk * Cq, S, h * Tq * Tk, Tk, heads * Tq * Tk, Tq, Tk, d_, B)
+    P = softmax_rows(S, float(scale))
+    Ph = fq("w", P, sel_w, w_level)
+    out = _alloc(B, Tq, Cq, dtype=torch.float32, device=q.device)
+    for h in range(heads):
+        gemm_strided(Ph, h * Tq * Tk, Tk, 1, heads * Tq * Tk, vh, h * d_, Cq, 1, Tk * Cq, out, h * d_, Cq, Tq * Cq, Tq, d_, Tk, B)
+    return out
+
+
+def bins_to_grid(xq: torch.Tensor, qs: QSel, half: bool = True) -> torch.Tensor:
+    """int8 activation bins (quantize_act) -> (b - z_a) on their integer grid, fp16 (exact: |b - z_a| <= 255) or fp32: the
+    activation operand of a W8A8 layer on the fp16-operand kernels (include/tfmq_hip.h: tfmq_bins_to_grid)."""
+    d = _dev(xq)
+    _chk(xq, torch.int8, "xq")
+    half = half and xq.numel() % 4 == 0
+    out = _alloc(*xq.shape, dtype=torch.float16 if half else torch.float32, device=xq.device)
+    handle(d).call("bins_to_grid", _p(xq), qs, _p(out), int(half), xq.numel(), _stream(d))
+    return out
+
+
+def scale_by_qdelta(ws: torch.Tensor, qs: QSel) -> torch.Tensor:
+    """[n] fp32 -> delta_a(current Finite-Set group) * ws: the per-channel output scale of a W8A8 layer."""
+    d = _dev(ws)
+    _chk(ws, torch.float32, "ws")
+    out = _alloc(ws.numel(), dtype=torch.float32, device=ws.device)
+    handle(d).call("scale_by_qdelta", _p(ws), qs, _p(out), ws.numel(), _stream(d))
+    return out
+
+
 def fake_quant(x: torch.Tensor, delta: torch.Tensor, zp: torch.Tensor, level: int, want_idx: bool = False):
     """Per-tensor (delta/zp numel 1) or per-row (first dim) fake quantisation."""
     d = _dev(x)
@@ -972,6 +1035,30 @@ def adaround_bwd_adam(w, alpha, delta, zp, g_what, m, v, level: int, w_reg: floa
 
 
 # ------------------------------------------------------------------------------ K15 (reconstruction fwd/bwd pieces)
+GEMM_PRECISIONS = {"f32": 0, "bf16x3": 1, "f16": 2}
+
+
+class gemm_precision:
+    """with ops.gemm_precision("bf16x3"): the fp32 GEMMs inside run their matrix-core path on split-bf16 operands (tfmq_set_gemm_precision);
+    restored to exact fp32 on exit.  Used by the AdaRound reconstruction iterations when TFMQ_RECON_GEMM asks for it."""
+
+    def __init__(self, mode: str, device: int = None):
+        if mode not in GEMM_PRECISIONS:
+            raise TfmqError(f"gemm_precision: {mode!r} is not one of {sorted(GEMM_PRECISIONS)}")
+        self.mode, self.dev = GEMM_PRECISIONS[mode], device
+
+    def __enter__(self):
+        self.d = torch.cuda.current_device() if self.dev is None else self.dev
+        if self.mode:
+            handle(self.d).call("set_gemm_precision", self.mode)
+        return self
+
+    def __exit__(self, *exc):
+        if self.mode:
+            handle(self.d).call("set_gemm_precision", 0)
+        return False
+
+
 def gemm(A: torch.Tensor, B: torch.Tensor, trans_a: bool = False, trans_b: bool = False, alpha: float = 1.0,
          bias=None, rowadd=None, rows_per_img: int = 1, residual=None, out=None, accumulate: bool = False) -> torch.Tensor:
     """C = alpha * op(A) @ op(B) (+bias[n]) (+rowadd[m // rows_per_img]) (+residual); A,B: contiguous fp32

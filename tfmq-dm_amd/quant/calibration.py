@@ -48,25 +48,34 @@ def _parameterise_weight_quantizers(qnn: QuantModel):
             module.delta = nn.Parameter(module.delta.detach().clone())
 
 
-def _recon_walk(qnn: QuantModel, model: nn.Module, cali_data, kwargs, rank0=True):
+ONLY_UNITS = None      # measurement aid (bench.py --cali-only): tuple of qualified-name prefixes; other units keep nearest rounding
+
+
+def _unit_wanted(path: str) -> bool:
+    return ONLY_UNITS is None or any(path.startswith(p) for p in ONLY_UNITS)
+
+
+def _recon_walk(qnn: QuantModel, model: nn.Module, cali_data, kwargs, rank0=True, prefix=""):
     """Tree walk of recon_model (reference :56-84): TIB first (at `temb`), single layers, blocks."""
     for name, module in model.named_children():
+        path = prefix + name
         if rank0:
             logger.info(f"block name: {name} quant: {isinstance(module, BaseQuantBlock)}")
         if name == "tib":
             continue
         if name in ("time_embed", "temb"):
-            tib_reconstruction(qnn.tib, cali_data=cali_data, **kwargs)
-            qnn.invalidate()
+            if _unit_wanted("tib"):
+                tib_reconstruction(qnn.tib, cali_data=cali_data, **kwargs)
+                qnn.invalidate()
             continue
         if isinstance(module, QuantLayer):
-            if not module.ignore_recon:
+            if not module.ignore_recon and _unit_wanted(path):
                 layer_reconstruction(qnn, module, cali_data=cali_data, **kwargs)
         elif isinstance(module, BaseQuantBlock):
-            if not module.ignore_recon:
+            if not module.ignore_recon and _unit_wanted(path):
                 block_reconstruction(qnn, module, cali_data=cali_data, **kwargs)
         else:
-            _recon_walk(qnn, module, cali_data, kwargs, rank0)
+            _recon_walk(qnn, module, cali_data, kwargs, rank0, path + ".")
 
 
 def _calibrate_activations(qnn: QuantModel, a_cali_data, interval: int, running_stat: bool, model_dict: dict, rank0=True,

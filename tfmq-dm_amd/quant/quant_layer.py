@@ -295,10 +295,12 @@ class QuantLayer(nn.Module):
             d, z, a = self.weight_quant_state()
             w = self.w.detach().float().contiguous()
             a = None if a is None else a.float().contiguous()
-            if mode == "w4a8" and (self.wqtizer.level != 16 or self.aqtizer.level != 256):
-                raise TfmqError(f"QuantLayer: the device path is 4-bit weights x 8-bit activations; got {self.wqtizer.level} weight "
+            if mode == "w4a8" and (not 2 <= self.wqtizer.level <= 2048 or self.aqtizer.level != 256):
+                raise TfmqError(f"QuantLayer: the device path is 2..2048-level weights x 8-bit activations; got {self.wqtizer.level} weight "
                                 f"levels / {self.aqtizer.level} activation levels")
-            pk = ops.pack_w4(w, d, z, a, b) if mode == "w4a8" else ops.pack_w_f16(w, b, d, z, a, self.wqtizer.level)
+            # more than 16 weight levels (--wq 8): the fp16 integer grid, run on the fp16-operand kernels (engine _Layer._run_wide)
+            int8_path = mode == "w4a8" and self.wqtizer.level <= 16
+            pk = ops.pack_w4(w, d, z, a, b) if int8_path else ops.pack_w_f16(w, b, d, z, a, self.wqtizer.level)
         self._packed = (key, pk)
         return pk
 
@@ -332,7 +334,12 @@ class QuantLayer(nn.Module):
             zp = zp.detach() if torch.is_tensor(zp) else torch.tensor(float(zp), device=x.device)
             qt = torch.stack([self.aqtizer.delta.detach().reshape(()), zp.reshape(())]).reshape(1, 1, 2).contiguous()
             sel = ops.qsel(qt)
-            y = ops.conv2d_w4a8(ops.quantize_act(xn, sel), pk, sel, stride=stride, pad=pad)
+            xq = ops.quantize_act(xn, sel)
+            if isinstance(pk, ops.PackedW4):
+                y = ops.conv2d_w4a8(xq, pk, sel, stride=stride, pad=pad)
+            else:       # W8A8: exact integer grids on the fp16-operand kernel, output scale delta_a * delta_w[c]
+                pf = ops.PackedF16(pk.w16, pk.bias, pk.cout, pk.cin, pk.kh, pk.kw, wscale=ops.scale_by_qdelta(pk.wscale, sel))
+                y = ops.conv2d_f16(ops.bins_to_grid(xq, sel, half=ops.f16_dma_ok(pk.cin, pk.kh, pk.kw)), pf, stride=stride, pad=pad)
         else:
             y = ops.conv2d_f16(xn, pk, stride=stride, pad=pad)
         y = ops.nhwc_to_nchw(y) if self.kind == "conv2d" else y.reshape(tuple(shape_out) + (y.shape[-1],))

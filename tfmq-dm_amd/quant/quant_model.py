@@ -136,6 +136,7 @@ class QuantModel(nn.Module):
         for n, l in self.named_quant_layers():
             key.append((n, l.use_wq, l.use_aq and not l.disable_aq, id(l.wqtizer), getattr(l.wqtizer, "_version_", 0),
                         l.w.data_ptr(), l.w._version))
+        key.append(tuple(name for _, _, name, _ in self.attn_quantizers()))
         return tuple(key)
 
     def invalidate(self):
@@ -144,6 +145,55 @@ class QuantModel(nn.Module):
 
     def act_layer_names(self) -> List[str]:
         return [n for n, l in self.named_quant_layers() if l.use_aq and not l.disable_aq]
+
+    def attn_quantizers(self):
+        """The attention-matmul quantizers of every block whose `use_aq` was switched on BY HAND (no driver of the reference does:
+        SURVEY section 0 fact 2, section 8f-3): [(engine key, role in 'qkvw', qualified quantizer name, UniformAffineQuantizer)], in
+        module order.  Engine keys: the QuantAttnBlock path (DDPM), '<transformer block>.attn1' / '.attn2' (cross_attn_forward),
+        '<AttentionBlock>.attention' (QuantQKMatMul + QuantSMVMatMul)."""
+        out = []
+        for n, m in self.model.named_modules():
+            if isinstance(m, QuantAttnBlock) and m.use_aq:
+                out += [(n, r, f"{n}.aqtizer_{r}", getattr(m, f"aqtizer_{r}")) for r in "qkvw"]
+            elif isinstance(m, QuantBasicTransformerBlock):
+                for an in ("attn1", "attn2"):
+                    a = getattr(m, an)
+                    if getattr(a, "use_aq", False):
+                        out += [(f"{n}.{an}", r, f"{n}.{an}.aqtizer_{r}", getattr(a, f"aqtizer_{r}")) for r in "qkvw"]
+            elif isinstance(m, QuantQKMatMul) and m.use_aq:
+                key = n.rsplit(".", 1)[0]
+                out += [(key, "q", f"{n}.aqtizer_q", m.aqtizer_q), (key, "k", f"{n}.aqtizer_k", m.aqtizer_k)]
+            elif isinstance(m, QuantSMVMatMul) and m.use_aq:
+                key = n.rsplit(".", 1)[0]
+                out += [(key, "v", f"{n}.aqtizer_v", m.aqtizer_v), (key, "w", f"{n}.aqtizer_w", m.aqtizer_w)]
+        return out
+
+    def calibrate_attention_quantizers(self, *inputs) -> None:
+        """What the reference's lazy initialisation does on the first forward after `use_aq` of an attention block is switched on
+        (UniformAffineQuantizer.forward, quant_layer.py:211-221): every attention quantizer is initialised on the tensor it sees in
+        this forward, upstream ones already active, with its scaler (MSE / MINMAX; the softmax quantizer `always_zero`)."""
+        aqs = self.attn_quantizers()
+        if not aqs:
+            return
+        dev = next(self.model.parameters()).device
+        eng = self.engine(dev)
+        _, act_names, _ = self._plan
+        ids = set(range(len(act_names), len(act_names) + len(aqs)))
+        scaler = getattr(aqs[0][3].scaler, "__name__", "mse")
+        eng.calib_mask = ids
+        try:
+            eng.set_calibration("init" if scaler == "mse" else "init_minmax", 0 if self._act_step is None else int(self._act_step.item()))
+            self(*inputs)
+        finally:
+            eng.set_calibration(None)
+            eng.calib_mask = None
+        k = 0 if self._act_step is None else int(self._act_step.item())
+        rows = eng.qtable[k].cpu()
+        for j, (_, _, _, q) in enumerate(aqs):
+            d, z = rows[len(act_names) + j]
+            q.delta = nn.Parameter(d.clone().to(dev)) if q.leaf_param else d.clone().to(dev)
+            q.zero_point = z.clone().to(dev)
+            q.init = True
 
     def _lower(self, device):
         from tfmq_dm_amd.engine import DdimUNetEngine, LayerQ, LdmUNetEngine
@@ -176,10 +226,19 @@ class QuantModel(nn.Module):
             self._tiles = {}
         eng.tiles = self._tiles      # measured tile shapes survive re-lowering (keys are shapes, not weights)
         n_steps = 1 if self._act_table is None else self._act_table.shape[0]
-        qtable = torch.zeros(n_steps, max(len(act_names), 1), 2, dtype=torch.float32, device=device)
+        aqs = self.attn_quantizers() if act_names else []
+        attn_q = {}
+        for j, (key, role, _, q) in enumerate(aqs):
+            attn_q.setdefault(key, {})[role] = len(act_names) + j
+            if role == "w":
+                attn_q[key]["w_level"] = int(q.level)
+        if aqs and self._act_table is not None and self._act_table.shape[1] != len(act_names) + len(aqs):
+            raise TfmqError("QuantModel: an activation table from a checkpoint holds no attention-matmul quantizers; switch `use_aq` of the "
+                            "attention blocks on only with module-held quantizer state (no table installed)")
+        qtable = torch.zeros(n_steps, max(len(act_names) + len(aqs), 1), 2, dtype=torch.float32, device=device)
         if self._act_step is None:
             self._act_step = torch.zeros(1, dtype=torch.int32, device=device)
-        eng.prepare(wq, qtable if act_names else None, self._act_step)   # the step counter also indexes the per-step TIB table
+        eng.prepare(wq, qtable if act_names else None, self._act_step, attn_q=attn_q or None)   # the step counter also indexes the per-step TIB table
         self._plan = (eng, act_names, qtable)
         self._sync_act_params()
         return eng
@@ -194,8 +253,7 @@ class QuantModel(nn.Module):
             return
         layers = dict(self.named_quant_layers())
         rows = []
-        for n in act_names:
-            q = layers[n].aqtizer
+        for q in [layers[n].aqtizer for n in act_names] + [a[3] for a in self.attn_quantizers()][:qtable.shape[1] - len(act_names)]:
             if q.delta is None:
                 rows.append([0.0, 0.0])      # not initialised yet: calibration mode fills it
             else:
@@ -216,9 +274,11 @@ class QuantModel(nn.Module):
             self._plan = plan
         return self._plan[0]
 
-    def set_act_table(self, cali_ckpt: Optional[dict]):
+    def set_act_table(self, cali_ckpt: Optional[dict], rows=None):
         """Install the whole Finite-Set-Calibration table {act_0..act_{G-1}} on the device, replacing
-        the per-step `load_state_dict(act_k)` of the reference's sampling loop."""
+        the per-step `load_state_dict(act_k)` of the reference's sampling loop.  rows: optional list of group indices --
+        the installed table is then [act_{rows[0]}, act_{rows[1]}, ...], one row per sampling step in execution order, which is
+        what a captured step graph indexes with the device step counter."""
         if cali_ckpt is None:
             self._act_table = None
         else:
@@ -230,6 +290,8 @@ class QuantModel(nn.Module):
                 for i, n in enumerate(names):
                     tab[g, i, 0] = float(act[f"model.{n}.aqtizer.delta"])
                     tab[g, i, 1] = float(act[f"model.{n}.aqtizer.zero_point"])
+            if rows is not None:
+                tab = tab[torch.as_tensor(list(rows), dtype=torch.long)].contiguous()
             self._act_table = tab.to(next(self.model.parameters()).device)
         self.invalidate()
 
