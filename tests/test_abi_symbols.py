@@ -70,4 +70,4 @@ def test_slab_kernel_launch_geometry_rule(lib):
     assert not ops.slab_ok(desc(24, 24))                                               # 576 pixels: neither 256 | HW nor HW | 256
     assert not ops.slab_ok(desc(128, 128))                                             # (2 + 2) * 130 = 520 slab rows > 512
     assert not ops.slab_ok(desc(64, 64, out_mode=2))                                   # GEGLU output is a pointwise mode
-    assert set(ops._TILE_NAMES) == {1, 2, 3, 4, 5, 6, 7, 8}
+    assert set(ops._TILE_NAMES) == {1, 2, 3, 4, 5, 6}

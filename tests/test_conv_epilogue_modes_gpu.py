@@ -372,8 +372,8 @@ def test_direct_pointwise_kernel_is_bit_identical_to_the_tile_kernels(ops, T, ci
         if mode.endswith("+stats"):      # the SpatialTransformer's proj_out: GroupNorm statistics of the consumer (DPP sums)
             kw["want_stats"] = True
     outs, stats = [], []
-    for tile in (1, 6, 7, 8):   # 7 = TFMQ_TILE_STREAM: persistent blocks, producer wave + four consumer waves (several tiles per block
-        ops.set_conv_autotune({})       # in the large cases; fewer than 3 K-steps falls back to the tile kernel)
+    for tile in (1, 6):          # the tile kernel and the register-direct pointwise kernel
+        ops.set_conv_autotune({})
         orig = _o._tune_conv
         try:
             _o._tune_conv = lambda h, name, kind, d, dsc, t=tile: t
@@ -385,8 +385,6 @@ def test_direct_pointwise_kernel_is_bit_identical_to_the_tile_kernels(ops, T, ci
             _o._tune_conv = orig
             ops.set_conv_autotune(None)
     assert torch.equal(outs[0], outs[1])
-    assert torch.equal(outs[0], outs[2])
-    assert torch.equal(outs[0], outs[3])      # 8 = TFMQ_TILE_PERSIST: symmetric waves, DMA ring across tiles, exact counted waits
     if stats:
         assert torch.equal(stats[0], stats[1])
     if mode == "geglu":     # and against the arithmetic spelled out: x * gelu(gate) of the un-fused projection, then the quantizer

@@ -144,3 +144,21 @@ def test_rccl_communicator_binds_lazily_to_the_tensors_device(tmp_path):
         assert names == ["comm_init", "allreduce_sum_f32", "allreduce_sum_f32"]          # created once, on first use
         assert res[r]["calls"][0][1:] == (r + 2, r, world)                              # device, rank, world
     assert res[0]["ident"] == res[1]["ident"] == bytes((i * 7 + 3) % 251 for i in range(128))   # rank 0's id reached rank 1 via the store
+
+
+def test_exchange_chunk_cuts_partition_the_gradient_buffer():
+    """engine.recon._chunk_cuts: contiguous pieces at layer boundaries, every layer in exactly one piece, never more pieces than asked."""
+    sys.path.insert(0, ROOT)
+    from tfmq_dm_amd.engine.recon import _chunk_cuts
+    rng = np.random.default_rng(0)
+    for _ in range(200):
+        sizes = [int(s) for s in rng.integers(1, 5000, size=int(rng.integers(1, 12)))]
+        n = int(rng.integers(1, 6))
+        cuts = _chunk_cuts(sizes, n)
+        assert 1 <= len(cuts) <= min(n, len(sizes))
+        assert cuts[0][0] == 0 and cuts[0][2] == 0 and cuts[-1][1] == len(sizes) and cuts[-1][3] == sum(sizes)
+        for (l0, l1, e0, e1), nxt in zip(cuts, cuts[1:] + [None]):
+            assert l1 > l0 and e1 - e0 == sum(sizes[l0:l1])
+            if nxt is not None:
+                assert nxt[0] == l1 and nxt[2] == e1
+    assert _chunk_cuts([10, 10, 10, 10], 2) == [(0, 2, 0, 20), (2, 4, 20, 40)]

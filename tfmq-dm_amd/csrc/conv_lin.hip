@@ -443,408 +443,20 @@ __global__ __launch_bounds__(256, 3) void k_lin_direct(ConvP p) {
 
 
 // ---------------------------------------------------------------------------------------------------------------------
-// K5r: k_lin_direct as a PERSISTENT block with symmetric waves.  scratch/phase_lin.py (TILE=6) on k_lin_direct at K = 320: a
-// block lives 3.3 us until its first DMA data, 2.8 us in the K loop, 4.8 us in the epilogue, three blocks per CU -- 3.3-4 us
-// per tile and CU whatever the arithmetic costs.  Here a block walks tiles bid, bid + G, bid + 2G, ... and its LDS-DMA ring
-// runs across tile boundaries: steps 0 and 1 of tile t+1 are requested at the last two steps of tile t, i.e. BEFORE tile t's
-// epilogue, which therefore hides their latency; nothing of a tile's life is spent waiting for a first load or for stores to
-// drain.  Every wave issues DMA *and* stores (a single producer wave cannot feed the stream: K5q), which the in-order vmcnt
-// allows only with EXACT counted waits: the first two steps of a tile wait for everything but {the next step's DMA, the
-// previous tile's stores, the constants and residual values requested behind them}, a number that is a compile-time
-// constant for full tiles (a ragged tile falls back to the conservative count for the tile after it).  The constants and
-// residual values are ordinary loads: the compiler, which cannot see the DMA instructions, waits for "everything" at their
-// first use in the epilogue -- i.e. also for the two prefetched steps of the next tile, which have been in flight since the
-// last two K-steps (inline-asm loads would avoid that wait, but any register copy the compiler places behind such an asm
-// reads the register before the data has landed).
-template <int MODE, bool RES>
-__global__ __launch_bounds__(256, 3) void k_lin_persist(ConvP p, int n_tiles) {
-  constexpr int BM = 128, BN = 128;
-  constexpr int STAGE = (BM + BN) * 64;
-  constexpr int NST = 3;
-  constexpr int NLOAD = 4;                                   // DMA pieces per wave per K-step
-  constexpr int NSTO = MODE == LIN_GEGLU ? 4 : 8;            // store instructions per wave of a full tile
-  constexpr int NC = 3, NR = RES ? 8 : 0;                    // constant / residual loads per wave per tile
-  constexpr int EXTRA = NSTO + NC + NR;
-  constexpr int CONST_OFF = NST * STAGE;
-  __shared__ __attribute__((aligned(1024))) unsigned char lds[NST * STAGE + 3 * BN * 4];
-
-  const tfmq_conv_desc& d = p.d;
-  const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5;
-  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wid >> 1, wn = wid & 1;
-  const int G = gridDim.x, bid = xcd_tile_id();
-  const int tiles_m = (p.M + BM - 1) / BM;
-  int gm = (3 << 19) / (BM * d.Cin);
-  gm = gm < 1 ? 1 : (gm > 16 ? 16 : gm);
-  if (static_cast<long>(p.cout_pad) * d.Cin < (2L << 20)) gm = 1;
-  const int per_panel = gm * p.tiles_n;
-  auto coords = [&](int t, int& m0, int& n0) {              // tile order of k_lin_direct (panels for weights beyond L2)
-    const int panel = t / per_panel, rp = t - panel * per_panel;
-    const int gml = (tiles_m - panel * gm) < gm ? (tiles_m - panel * gm) : gm;
-    const int tn = rp / gml;
-    m0 = (panel * gm + (rp - tn * gml)) * BM;
-    n0 = tn * BN;
-  };
-
-  const unsigned lds0 = static_cast<unsigned>(reinterpret_cast<uintptr_t>(lds));
-  const unsigned char* xb = static_cast<const unsigned char*>(d.x);
-  const int dcol = ((lane & 3) ^ ((lane >> 4) & 3)) * 16;
-  const unsigned char* a_ptr[2];
-  const unsigned char* b_ptr[2];
-  auto set_ptrs = [&](int m0, int n0) {
-#pragma unroll
-    for (int it = 0; it < 2; ++it) {
-      const int piece = wid * 2 + it;
-      int m = m0 + piece * 16 + (lane >> 2);
-      m = m < p.M ? m : p.M - 1;                               // rows past M: any valid row (never stored)
-      a_ptr[it] = xb + static_cast<size_t>(m) * d.Cin + dcol;
-      int n = n0 + piece * 16 + (lane >> 2);
-      n = n < p.cout_pad ? n : p.cout_pad - 1;
-      b_ptr[it] = static_cast<const unsigned char*>(d.w) + (static_cast<size_t>(n / 32) * p.nsteps * 32 + (n % 32)) * 64 + dcol;
-    }
-  };
-  auto issue = [&](int s, int stage) {
-    const unsigned sbase = lds0 + stage * STAGE;
-    glds16(a_ptr[0] + s * 64, sbase + __builtin_amdgcn_readfirstlane((wid * 2) * 1024));
-    glds16(a_ptr[1] + s * 64, sbase + __builtin_amdgcn_readfirstlane((wid * 2 + 1) * 1024));
-    glds16(b_ptr[0] + static_cast<size_t>(s) * 2048, sbase + __builtin_amdgcn_readfirstlane(BM * 64 + (wid * 2) * 1024));
-    glds16(b_ptr[1] + static_cast<size_t>(s) * 2048, sbase + __builtin_amdgcn_readfirstlane(BM * 64 + (wid * 2 + 1) * 1024));
-  };
-  auto ncol0 = [&](int j) { return MODE == LIN_GEGLU ? j * 64 + wn * 32 : (wn * 2 + j) * 32; };
-  const int fsw = (h ^ ((lane >> 2) & 3)) << 4;
-  const int brow = lin_brow(lane & 31);
-  const int bsw = (h ^ ((brow >> 2) & 3)) << 4;
-
-  // quantizer parameters: needed (and therefore complete) before anything else is requested
-  const float2 aqp = load_qparam(d.aq);
-  float2 oqp = make_float2(1.0f, 0.0f);
-  if constexpr (MODE != LIN_F16) oqp = load_qparam(d.oq);
-  const int za = static_cast<int>(aqp.y);
-  const float a_delta = aqp.x + 0.0f * oqp.x;               // (uses both: the compiler waits for them here)
-  asm volatile("" ::"v"(a_delta), "v"(za));
-
-  // per-column constants of a tile: every thread loads column tid % BN (the same instruction count in every wave)
-  const float* biasp = d.bias ? d.bias : d.wscale;
-  const float bias_on = d.bias ? 1.0f : 0.0f;
-  int c_zp, c_rs, c_ws, c_b;                                // raw bits; valid one tile later
-  auto load_consts = [&](int n0) {
-    int n = n0 + (tid & (BN - 1));
-    n = n < d.Cout ? n : d.Cout - 1;
-    const int4 m4 = reinterpret_cast<const int4*>(d.wmeta)[n];
-    c_zp = m4.x;
-    c_rs = m4.y;
-    c_ws = __float_as_int(d.wscale[n]);
-    c_b = __float_as_int(biasp[n]);
-  };
-  uint4 rres[2][2][2];
-  auto load_res = [&](int m0, int n0) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int m = m0 + (wm * 2 + i) * 32 + (lane & 31);
-      const int mc = m < p.M ? m : p.M - 1;
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          const int n = n0 + ncol0(j) + 16 * h + 8 * u;
-          const int nc = n < d.Cout ? n : 0;
-          rres[i][j][u] = *reinterpret_cast<const uint4*>(reinterpret_cast<const __half*>(d.residual) + static_cast<size_t>(mc) * d.Cout + nc);
-        }
-    }
-  };
-  float* cs = reinterpret_cast<float*>(lds + CONST_OFF);
-
-  int t = bid;
-  if (t >= n_tiles) return;
-  int m0, n0;
-  coords(t, m0, n0);
-  set_ptrs(m0, n0);
-  load_consts(n0);
-  if constexpr (RES) load_res(m0, n0);
-  issue(0, 0);
-  issue(1, 1);                                               // nsteps >= 3
-  int st_c = 0, st_i = 2;
-  bool steady = false;                                       // the counted waits of steps 0 / 1 may leave EXTRA operations in flight
-  const int ns = p.nsteps;
-
-  while (true) {
-    const int t_next = t + G;
-    const bool has_next = t_next < n_tiles;
-    int m1 = 0, n1 = 0;
-    if (has_next) coords(t_next, m1, n1);
-    v16i acc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0;
-
-    for (int s = 0; s < ns; ++s) {
-      const bool younger = (s + 1 < ns) || has_next;          // the next flat step's DMA is in flight behind this step's
-      if (!younger) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      else if (steady && s < 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLOAD + EXTRA) : "memory");
-      else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLOAD) : "memory");
-      asm volatile("s_barrier" ::: "memory");
-      const int s2 = s + 2;
-      if (s2 < ns) {
-        issue(s2, st_i);
-        st_i = st_i == NST - 1 ? 0 : st_i + 1;
-      } else if (has_next) {
-        if (s2 == ns) set_ptrs(m1, n1);
-        issue(s2 - ns, st_i);
-        st_i = st_i == NST - 1 ? 0 : st_i + 1;
-      }
-      const unsigned char* sa = lds + st_c * STAGE;
-      const unsigned char* sb = sa + BM * 64;
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        v4i af[2], bf[2];
-#pragma unroll
-        for (int i = 0; i < 2; ++i) af[i] = *reinterpret_cast<const v4i*>(sa + ((wm * 2 + i) * 32 + (lane & 31)) * 64 + (fsw ^ (ks << 5)));
-#pragma unroll
-        for (int j = 0; j < 2; ++j) bf[j] = *reinterpret_cast<const v4i*>(sb + (ncol0(j) + brow) * 64 + (bsw ^ (ks << 5)));
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(bf[j], af[i], acc[i][j], 0, 0, 0);
-      }
-      st_c = st_c == NST - 1 ? 0 : st_c + 1;
-    }
-
-    // ---- epilogue of tile t (the constants / residual values were requested a tile ago and are complete: step 2's wait)
-    if (tid < BN) {
-      cs[tid] = aqp.x * __int_as_float(c_ws);
-      reinterpret_cast<int*>(cs)[BN + tid] = (128 - za) * (c_rs - p.Ktot * c_zp);
-      cs[2 * BN + tid] = __int_as_float(c_b) * bias_on;
-    }
-    LDS_BARRIER();
-    if constexpr (RES) {
-      lin_epilogue<MODE, 1>(p, acc, cs, rres, true, m0, n0, wm, wn, lane, oqp);
-      load_res(has_next ? m1 : m0, has_next ? n1 : n0);
-      lin_epilogue<MODE, 2>(p, acc, cs, rres, true, m0, n0, wm, wn, lane, oqp);
-    } else {
-      lin_epilogue<MODE>(p, acc, cs, rres, false, m0, n0, wm, wn, lane, oqp);
-    }
-    load_consts(has_next ? n1 : n0);
-    steady = (m0 + BM <= p.M) && (n0 + BN <= d.Cout);       // exactly NSTO store instructions were issued
-    if (!has_next) break;
-    t = t_next;
-    m0 = m1;
-    n0 = n1;
-  }
-}
-
-
-// ---------------------------------------------------------------------------------------------------------------------
-// K5q: the same GEMM as a PERSISTENT, warp-specialised pipeline.  Measured on k_lin_direct (scratch/lat_lin.py): a block
-// lives ~10 us for 0.5 us of MFMA work at K = 320 -- first-DMA latency, the K loop, store issue -- and three resident
-// blocks per CU cannot hide that chain: 3-4 us per tile and CU whatever the epilogue costs (halving its VALU work moved
-// nothing).  Here a block walks a contiguous range of tiles (N fastest: the A rows stay in L1 / L2) and
-//   * wave 4 is the producer: it alone issues the LDS-DMA of every (tile, K-step) of the block's flat step sequence, two
-//     steps ahead through a three-stage ring that runs ACROSS tile boundaries -- the first stages of tile t+1 land
-//     while tile t is in its epilogue.  Its vmcnt sees nothing but its own DMA (and the per-tile column constants it
-//     fetches one tile ahead and writes to a double-buffered LDS table), so the counted waits stay exact;
-//   * waves 0-3 are consumers: one raw s_barrier per step, MFMAs, then the register epilogue.  Their stores are never
-//     waited for (the in-order vmcnt of a wave that also issued DMA would make the next tile's first wait a wait for
-//     these stores); the fp16 residual values of tile t+1 are requested right after tile t's stores.
-// All five waves execute exactly one s_barrier per step.  Same sums, same epilogue arithmetic: bit-identical output.
-// RES: the launch has an fp16 residual (the variant that keeps 32 more registers and runs two blocks per CU)
-template <int MODE, bool RES>
-__global__ __launch_bounds__(320, RES ? 3 : 4) void k_lin_stream(ConvP p, int n_tiles) {
-  constexpr int BM = 128, BN = 128;
-  constexpr int STAGE = (BM + BN) * 64;
-  constexpr int NST = 3;
-  constexpr int NP = 16;                          // DMA pieces per step (all issued by the producer wave): 8 of A, 8 of B
-  constexpr int NC = 6;                           // constant loads per tile in the producer wave
-  constexpr int CS_BYTES = 3 * BN * 4;
-  __shared__ __attribute__((aligned(1024))) unsigned char lds[NST * STAGE + 2 * CS_BYTES];
-
-  const tfmq_conv_desc& d = p.d;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int nb = gridDim.x, b = xcd_tile_id();
-  const int t_begin = static_cast<int>(static_cast<long long>(n_tiles) * b / nb);
-  const int t_end = static_cast<int>(static_cast<long long>(n_tiles) * (b + 1) / nb);
-  const int ns = p.nsteps;
-  const int G = (t_end - t_begin) * ns;
-  if (G == 0) return;
-  const unsigned lds0 = static_cast<unsigned>(reinterpret_cast<uintptr_t>(lds));
-  float* const cs_base = reinterpret_cast<float*>(lds + NST * STAGE);
-
-  if (wid == 4) {
-    // ------------------------------------------------------------------------------------------------ producer
-    const unsigned char* xb = static_cast<const unsigned char*>(d.x);
-    const unsigned char* wb = static_cast<const unsigned char*>(d.w);
-    const int dcol = ((lane & 3) ^ ((lane >> 4) & 3)) * 16;
-    const float* biasp = d.bias ? d.bias : d.wscale;       // always a valid address: the number of loads is a constant
-    const float bias_on = d.bias ? 1.0f : 0.0f;
-    const float2 aqp = load_qparam(d.aq);
-    unsigned aoff[8], boff[8];
-    auto set_tile = [&](int t) {
-      const int tm = t / p.tiles_n, tn = t - tm * p.tiles_n;
-#pragma unroll
-      for (int it = 0; it < 8; ++it) {
-        int m = tm * BM + it * 16 + (lane >> 2);
-        m = m < p.M ? m : p.M - 1;                            // rows past M: any valid row (their outputs are never stored)
-        aoff[it] = static_cast<unsigned>(m) * static_cast<unsigned>(d.Cin) + dcol;
-        int n = tn * BN + it * 16 + (lane >> 2);
-        n = n < p.cout_pad ? n : p.cout_pad - 1;
-        boff[it] = (static_cast<unsigned>(n / 32) * ns * 32 + (n % 32)) * 64 + dcol;
-      }
-    };
-    auto issue = [&](int s, int stage) {
-      const unsigned sbase = lds0 + stage * STAGE;
-      const unsigned char* xs = xb + static_cast<size_t>(s) * 64;
-      const unsigned char* ws = wb + static_cast<size_t>(s) * 2048;
-#pragma unroll
-      for (int it = 0; it < 8; ++it) glds16(xs + aoff[it], sbase + it * 1024);
-#pragma unroll
-      for (int it = 0; it < 8; ++it) glds16(ws + boff[it], sbase + BM * 64 + it * 1024);
-    };
-    // column constants of a tile: lane l owns columns l and l + 64
-    int2 c_meta[2];
-    float c_ws[2], c_b[2];
-    auto load_consts = [&](int t) {
-      const int tn = t % p.tiles_n;
-#pragma unroll
-      for (int c = 0; c < 2; ++c) {
-        int n = tn * BN + c * 64 + lane;
-        n = n < d.Cout ? n : d.Cout - 1;
-        c_meta[c] = *reinterpret_cast<const int2*>(reinterpret_cast<const int4*>(d.wmeta) + n);
-        c_ws[c] = d.wscale[n];
-        c_b[c] = biasp[n];
-      }
-    };
-    const int za = static_cast<int>(aqp.y);
-    auto write_consts = [&](int t) {
-      float* cs = cs_base + (t & 1) * (3 * BN);
-#pragma unroll
-      for (int c = 0; c < 2; ++c) {
-        const int col = c * 64 + lane;
-        cs[col] = aqp.x * c_ws[c];
-        reinterpret_cast<int*>(cs)[BN + col] = (128 - za) * (c_meta[c].y - p.Ktot * c_meta[c].x);
-        cs[2 * BN + col] = c_b[c] * bias_on;
-      }
-    };
-
-    int t = t_begin, s = 0;                  // (tile, step) of global step g
-    int ti = t_begin, si = 0;                // (tile, step) of the next step to issue
-    load_consts(t_begin);
-    set_tile(ti);
-    issue(0, 0);
-    si = 1;
-    if (G > 1) {
-      issue(1, 1);                           // ns >= 3: still tile t_begin
-      si = 2;
-    }
-    int st_i = 2;
-    TFMQ_T0();
-    for (int g = 0; g < G; ++g) {
-      if (g + 2 >= G) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      else if (s == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NP + NC) : "memory");
-      else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NP) : "memory");
-      TFMQ_TACC(0);
-      if (g == 0) write_consts(t_begin);
-      else if (s == 2) write_consts(t + 1);          // table of the NEXT tile (harmless past the last tile)
-      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-      TFMQ_TACC(1);
-      if (g + 2 < G) {
-        if (si == 0) set_tile(ti);
-        issue(si, st_i);
-        st_i = st_i == NST - 1 ? 0 : st_i + 1;
-        if (++si == ns) { si = 0; ++ti; }
-      }
-      if (s == 0) load_consts(t + 1 < t_end ? t + 1 : t);
-      if (++s == ns) { s = 0; ++t; }
-      TFMQ_TACC(2);
-    }
-    TFMQ_TDUMP(0, 3);
-    return;
-  }
-
-  // -------------------------------------------------------------------------------------------------- consumers
-  const int h = lane >> 5;
-  const int wm = wid >> 1, wn = wid & 1;
-  auto ncol0 = [&](int j) { return MODE == LIN_GEGLU ? j * 64 + wn * 32 : (wn * 2 + j) * 32; };
-  const int fsw = (h ^ ((lane >> 2) & 3)) << 4;
-  const int brow = lin_brow(lane & 31);
-  const int bsw = (h ^ ((brow >> 2) & 3)) << 4;
-  float2 oqp = make_float2(1.0f, 0.0f);
-  if constexpr (MODE != LIN_F16) oqp = load_qparam(d.oq);
-  uint4 rres[2][2][2];
-  if constexpr (RES) {
-    const int tm = t_begin / p.tiles_n, tn = t_begin - tm * p.tiles_n;
-    lin_load_res<MODE>(p, rres, tm * BM, tn * BN, wm, wn, lane);
-  }
-  int st_c = 0;
-  bool prev_full = false;
-  TFMQ_T0();
-  for (int t = t_begin; t < t_end; ++t) {
-    const int tm = t / p.tiles_n, tn = t - tm * p.tiles_n;
-    const int m0 = tm * BM, n0 = tn * BN;
-    v16i acc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0;
-    for (int s = 0; s < ns; ++s) {
-      asm volatile("s_barrier" ::: "memory");
-      TFMQ_TACC(0);
-      const unsigned char* sa = lds + st_c * STAGE;
-      const unsigned char* sb = sa + BM * 64;
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        v4i af[2], bf[2];
-#pragma unroll
-        for (int i = 0; i < 2; ++i) af[i] = *reinterpret_cast<const v4i*>(sa + ((wm * 2 + i) * 32 + (lane & 31)) * 64 + (fsw ^ (ks << 5)));
-#pragma unroll
-        for (int j = 0; j < 2; ++j) bf[j] = *reinterpret_cast<const v4i*>(sb + (ncol0(j) + brow) * 64 + (bsw ^ (ks << 5)));
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(bf[j], af[i], acc[i][j], 0, 0, 0);
-      }
-      st_c = st_c == NST - 1 ? 0 : st_c + 1;
-      TFMQ_TACC(1);
-    }
-    // the fragment reads of the last step must have left LDS before the barrier of the next step lets the producer
-    // overwrite that stage: they have -- the MFMAs above consumed them (lgkmcnt(0) is implied by the data dependence)
-    // A consumer never waits for its stores: their acknowledgement takes longer than a short-K tile's whole K loop.
-    // With a residual, the next tile's values are requested BEFORE this tile's stores (after the affine + residual phase
-    // has consumed the current ones), so the counted wait below -- everything but the youngest 8 operations, the stores
-    // of a full tile -- covers the loads and leaves the stores in flight.
-    if constexpr (!RES) {
-      lin_epilogue<MODE>(p, acc, cs_base + (t & 1) * (3 * BN), rres, false, m0, n0, wm, wn, lane, oqp);
-    } else {
-      {
-        if (prev_full) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        lin_epilogue<MODE, 1>(p, acc, cs_base + (t & 1) * (3 * BN), rres, true, m0, n0, wm, wn, lane, oqp);
-        if (t + 1 < t_end) {
-          const int t2 = t + 1, tm2 = t2 / p.tiles_n, tn2 = t2 - tm2 * p.tiles_n;
-          lin_load_res<MODE>(p, rres, tm2 * BM, tn2 * BN, wm, wn, lane);
-        }
-        lin_epilogue<MODE, 2>(p, acc, cs_base + (t & 1) * (3 * BN), rres, true, m0, n0, wm, wn, lane, oqp);
-        prev_full = m0 + BM <= p.M && n0 + BN <= d.Cout;      // all 8 store instructions of this wave were issued
-      }
-    }
-    TFMQ_TACC(2);
-  }
-  if (wid == 0) TFMQ_TDUMP(4, 3);
-}
+// (Round 2 carried two persistent variants of this kernel here -- K5q `k_lin_stream`: a producer wave streaming the LDS-DMA of consecutive
+// tiles through one ring for four consumer waves; K5r `k_lin_persist`: symmetric waves, the ring running across tile boundaries with exact
+// counted waits.  Both were bit-identical to k_lin_direct and 3-60 % slower on every SD shape (the in-order vmcnt
+// couples a wave's stores to its DMA, one producer wave cannot feed a CU's L2 -> LDS stream, the compiler waits for "everything" at the
+// first use of prefetched constants).  Negative results stay in DESIGN.md; the 420 lines were removed in round 3.)
 
 }  // namespace
 
-bool launch_conv_lin(tfmq_handle h, ConvP& p, hipStream_t st, int variant) {
-  const bool stream = variant == 1, persist = variant == 2;
+bool launch_conv_lin(tfmq_handle h, ConvP& p, hipStream_t st) {
   const tfmq_conv_desc& d = p.d;
   if (d.KH != 1 || d.KW != 1 || d.stride != 1 || d.up2x || d.pad_t != 0 || d.pad_l != 0 || d.Ho != d.H || d.Wo != d.W) return false;
   if (d.Cin % 32 != 0 || p.chunks != (d.Cin + 63) / 64 || static_cast<size_t>(d.B) * d.H * d.W * d.Cin >= (static_cast<size_t>(1) << 31)) return false;
   if (d.rowadd || (d.Cout & 7) != 0) return false;                 // a lane moves whole 8-channel octets
-  if (d.stats && (stream || d.out_mode != TFMQ_OUT_F16 || d.yt || 128 % d.stats_seg != 0)) return false;
+  if (d.stats && (d.out_mode != TFMQ_OUT_F16 || d.yt || 128 % d.stats_seg != 0)) return false;
   if (d.yt && (d.out_mode != TFMQ_OUT_F16 || d.residual)) return false;
   int mode;
   if (d.out_mode == TFMQ_OUT_F16) {
@@ -861,50 +473,6 @@ bool launch_conv_lin(tfmq_handle h, ConvP& p, hipStream_t st, int variant) {
   p.tiles_n = (d.Cout + 127) / 128;
   const int tiles_m = (p.M + 127) / 128;
   const int n_tiles = p.tiles_n * tiles_m;
-  const bool stream_ok = p.nsteps >= 3 && (!d.residual || d.res_f16) && static_cast<size_t>(p.cout_pad) * p.Ktot < (static_cast<size_t>(1) << 31);
-  if (stream && !stream_ok) return false;
-  if (persist) {
-    if (!stream_ok || d.yt || d.stats || d.B * d.H * static_cast<long>(d.W) * d.Cin >= (1L << 31)) return false;
-    const int nblk = n_tiles < h->cu_count * 3 ? n_tiles : h->cu_count * 3;
-    dim3 g3(static_cast<unsigned>(nblk));
-    const bool res = d.residual != nullptr;
-    if (mode == LIN_F16 && res) hipLaunchKernelGGL((k_lin_persist<LIN_F16, true>), g3, dim3(256), 0, st, p, n_tiles);
-    else if (mode == LIN_F16) hipLaunchKernelGGL((k_lin_persist<LIN_F16, false>), g3, dim3(256), 0, st, p, n_tiles);
-    else if (mode == LIN_Q8 && res) hipLaunchKernelGGL((k_lin_persist<LIN_Q8, true>), g3, dim3(256), 0, st, p, n_tiles);
-    else if (mode == LIN_Q8) hipLaunchKernelGGL((k_lin_persist<LIN_Q8, false>), g3, dim3(256), 0, st, p, n_tiles);
-    else hipLaunchKernelGGL((k_lin_persist<LIN_GEGLU, false>), g3, dim3(256), 0, st, p, n_tiles);
-    return true;
-  }
-  if (stream) {
-    // persistent blocks: three per CU (51 KiB of LDS, five waves each), two for the residual variants (register budget)
-    const int per_cu = d.residual ? 2 : 3;
-    const int nblk = n_tiles < h->cu_count * per_cu ? n_tiles : h->cu_count * per_cu;
-    dim3 g2(static_cast<unsigned>(nblk));
-#ifdef TFMQ_PHASE_TIMERS
-    static unsigned long long* dbuf = nullptr;
-    if (!dbuf) (void)hipMalloc(reinterpret_cast<void**>(&dbuf), sizeof(unsigned long long) * 8 * 4096);
-    p.dbg = dbuf;
-#endif
-    const bool res = d.residual != nullptr;
-    if (mode == LIN_F16 && res) hipLaunchKernelGGL((k_lin_stream<LIN_F16, true>), g2, dim3(320), 0, st, p, n_tiles);
-    else if (mode == LIN_F16) hipLaunchKernelGGL((k_lin_stream<LIN_F16, false>), g2, dim3(320), 0, st, p, n_tiles);
-    else if (mode == LIN_Q8 && res) hipLaunchKernelGGL((k_lin_stream<LIN_Q8, true>), g2, dim3(320), 0, st, p, n_tiles);
-    else if (mode == LIN_Q8) hipLaunchKernelGGL((k_lin_stream<LIN_Q8, false>), g2, dim3(320), 0, st, p, n_tiles);
-    else hipLaunchKernelGGL((k_lin_stream<LIN_GEGLU, false>), g2, dim3(320), 0, st, p, n_tiles);
-#ifdef TFMQ_PHASE_TIMERS
-    if (getenv("TFMQ_PHASE_PRINT")) {
-      (void)hipStreamSynchronize(st);
-      std::vector<unsigned long long> hb(static_cast<size_t>(nblk) * 8);
-      (void)hipMemcpy(hb.data(), dbuf, hb.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
-      double a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-      for (int i = 0; i < nblk; ++i)
-        for (int k = 0; k < 8; ++k) a[k] += double(hb[i * 8 + k]) / nblk;
-      fprintf(stderr, "[lin_stream Cin%d Cout%d mode%d] blocks %d tiles %d steps/tile %d | producer: wait %.0f barrier %.0f issue %.0f | consumer: barrier %.0f mfma %.0f epilogue %.0f  (10 ns ticks per block)\n",
-              d.Cin, d.Cout, mode, nblk, n_tiles, p.nsteps, a[0], a[1], a[2], a[4], a[5], a[6]);
-    }
-#endif
-    return true;
-  }
   dim3 grid(static_cast<unsigned>(n_tiles));
 #ifdef TFMQ_PHASE_TIMERS
   static unsigned long long* dbuf2 = nullptr;

@@ -655,6 +655,12 @@ __global__ void k_hw_selftest(unsigned* out) {
 
 extern "C" int tfmq_hw_selftest(tfmq_handle h, uint32_t* report) {
   TFMQ_CHECK_ARG(h, h != nullptr, "hw_selftest: null handle");
+  // (allocates, launches on the null stream and copies synchronously: run it before any stream capture on this device -- tfmq_create /
+  // the first handle(dev) does; the device is selected explicitly so that a handle made from another current device tests ITS GPU)
+  int prev = 0;
+  (void)hipGetDevice(&prev);
+  if (hipSetDevice(h->device) != hipSuccess) return TFMQ_ERR_HIP;
+  struct Restore { int d; ~Restore() { (void)hipSetDevice(d); } } restore{prev};
   unsigned* d = nullptr;
   if (hipMalloc(reinterpret_cast<void**>(&d), sizeof(unsigned)) != hipSuccess) return TFMQ_ERR_HIP;
   (void)hipMemset(d, 0, sizeof(unsigned));

@@ -425,7 +425,7 @@ def _attach_stats(dsc, y: torch.Tensor, B: int, hw: int, cout: int, want_stats: 
 # the launch stream; a conv is idempotent, so re-running it is harmless) and later launches -- in particular the ones
 # captured into the sampler's hipGraph -- use the winner.  The result does not depend on the tile shape.
 _AUTOTUNE = None      # None = off, else {shape key: tile id}
-_TILE_NAMES = {1: "128x128", 2: "64x64", 3: "256x128", 4: "128x64", 5: "slab 256xN (3x3)", 6: "direct 128x128 (pointwise)", 7: "stream 128x128 (pointwise, persistent producer/consumer)", 8: "persist 128x128 (pointwise, persistent symmetric)"}
+_TILE_NAMES = {1: "128x128", 2: "64x64", 3: "256x128", 4: "128x64", 5: "slab 256xN (3x3)", 6: "direct 128x128 (pointwise)"}
 
 
 def set_conv_autotune(cache) -> None:
@@ -499,8 +499,6 @@ def _tune_conv(h, name, kind, d, dsc):
     if (kind == "w4a8" and dsc.KH == 1 and dsc.KW == 1 and dsc.stride == 1 and not dsc.up2x and k64 and dsc.Cout % 4 == 0
             and dsc.out_mode in (1, 2, 3) and not dsc.rowadd and not (dsc.stats and dsc.out_mode != 1) and not (dsc.yt and dsc.residual)):
         cands.append(6)
-        # (7 = TFMQ_TILE_STREAM and 8 = TFMQ_TILE_PERSIST, the persistent variants, are selectable but not candidates: measured
-        # slower than 6 on the SD shapes -- DESIGN.md section 4)
     if (kind == "f16" and dsc.x_f16 and dsc.KH == 1 and dsc.KW == 1 and dsc.stride == 1 and not dsc.up2x and dsc.Cin % 32 == 0
             and dsc.Cout % 8 == 0 and dsc.out_mode == 1 and not dsc.rowadd and not (dsc.yt and (dsc.residual or dsc.stats))):
         cands.append(6)             # the same register-direct kernel on fp16 operands (skip-connection 1x1 convs, un-quantised q|k|v)
@@ -608,7 +606,12 @@ def conv2d_w4a8(xq: torch.Tensor, pw: PackedW4, aq: QSel, stride: int = 1, pad: 
         raise TfmqError("conv2d_w4a8: Cin must be a multiple of 32")
     dsc.w, dsc.wmeta, dsc.wscale = pw.w8.data_ptr(), pw.wmeta.data_ptr(), pw.wscale.data_ptr()
     if getattr(pw, "w8p", None) is not None:
-        dsc.w64 = pw.w8p.data_ptr()
+        # the K-padded operand makes the last K-step of a pixel read 32 bytes of the NEXT pixel (times zero weights): the buffer
+        # must own those bytes.  Tensors from _alloc / the arena carry the slack; a caller-made int8 tensor that ends at its
+        # storage's end does not -- those launches keep the register-staged 32-channel-step kernel.
+        st = xq.untyped_storage()
+        if st.nbytes() - (xq.storage_offset() + xq.numel()) * xq.element_size() >= 32:
+            dsc.w64 = pw.w8p.data_ptr()
     dsc.bias = None if pw.bias is None else pw.bias.data_ptr()
     dsc.aq = aq
     osz = 4.0
