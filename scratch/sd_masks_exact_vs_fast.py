@@ -1,0 +1,86 @@
+"""Round-2 verdict, weak item 2: calibration targets are captured on fp16-operand convs / attention where the reference captures them in
+fp32 -- does that move the LEARNED ROUNDING at SD width?  Two reconstruction units of the real SD v1 UNet (859.5 M, random init) -- the first
+quantised ResBlock (320 ch @ 64x64) and the first transformer block (T = 4096, 8 heads of 40) -- are reconstructed twice from the same
+calibration samples and the same host RNG stream: once with the engine in its fast mode, once with TFMQ_EXACT_FP=1 (every un-quantised /
+weight-only layer and the attention of the capture forwards in exact fp32).  Reported: share of identical final AdaRound masks, per layer.
+
+    python scratch/sd_masks_exact_vs_fast.py [iters] [samples per group]      -> gpurun_out/r03/sd_masks_exact_vs_fast.json"""
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tfmq-dm_amd"))
+import numpy as np
+import torch
+
+ITERS = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
+N = int(sys.argv[2]) if len(sys.argv) > 2 else 32
+UNITS = ("model.input_blocks.1.0", "model.input_blocks.1.1.transformer_blocks.0", "model.input_blocks.1.1.proj_in")
+DEV = "cuda:0"
+
+
+def run(exact: bool):
+    if exact:
+        os.environ["TFMQ_EXACT_FP"] = "1"
+    else:
+        os.environ.pop("TFMQ_EXACT_FP", None)
+    from tfmq_dm_amd.ldm.unet import UNetModel, SD_V1_UNET
+    from quant.quant_layer import QMODE, Scaler
+    from quant.quant_model import QuantModel
+    from quant.reconstruction_util import RLOSS
+    import quant.calibration as QC
+    torch.manual_seed(1234)
+    m = UNetModel(**SD_V1_UNET)
+    g = torch.Generator().manual_seed(7)
+    with torch.no_grad():
+        for p in m.parameters():
+            if p.numel() and float(p.abs().max()) == 0.0:
+                p.copy_(torch.randn(p.shape, generator=g) * 0.02)
+    m = m.to(DEV)
+    G = 2
+    xs = torch.randn(G * N, 4, 64, 64, generator=g)
+    ts = torch.cat([torch.full((N,), float(t)) for t in (981, 201)])
+    cs = torch.randn(G * N, 77, 768, generator=g)
+    wq = {"bits": 4, "channel_wise": True, "scaler": Scaler.MINMAX}
+    aq = {"bits": 8, "channel_wise": False, "scaler": Scaler.MINMAX, "leaf_param": True}
+    qnn = QuantModel(m, wq, aq, cali=True, aq_mode=[QMODE.NORMAL.value, QMODE.QDIFF.value]).eval()
+    QC.ONLY_UNITS = UNITS
+    torch.manual_seed(5)
+    np.random.seed(5)
+    t0 = time.time()
+    md = QC.cali_model(qnn, (xs, ts, cs), (xs, ts, cs), use_aq=False, path=None, running_stat=True, interval=N, iters=ITERS, batch_size=8, w=0.01,
+                       asym=True, warmup=0.2, opt_mode=RLOSS.MSE, multi_gpu=False)
+    torch.cuda.synchronize()
+    masks = {k: (v >= 0).cpu() for k, v in md["weight"].items() if k.endswith("alpha")}
+    nearest = {}
+    for k in masks:         # what rounding-to-nearest would have chosen: the mask is informative only where AdaRound departs from it
+        base = k[:-len("wqtizer.alpha")]
+        w, d = md["weight"][base + "w"].float(), md["weight"][base + "wqtizer.delta"].float()
+        r = w / d.reshape((-1,) + (1,) * (w.dim() - 1))
+        nearest[k] = ((r - torch.floor(r)) >= 0.5).cpu()
+    del qnn, m
+    torch.cuda.empty_cache()
+    return masks, nearest, time.time() - t0
+
+
+if __name__ == "__main__":
+    fast, nearest, t_fast = run(False)
+    exact, _, t_exact = run(True)
+    out = {"iters": ITERS, "samples_per_group": N, "groups": 2, "units": list(UNITS), "seconds": {"fast": round(t_fast, 1), "exact": round(t_exact, 1)},
+           "layers": {}}
+    tot_same = tot = tot_flip = tot_flip_same = 0
+    for k in sorted(fast):
+        same = (fast[k] == exact[k])
+        moved = fast[k] != nearest[k]          # weights whose learned rounding departs from nearest in the fast run
+        out["layers"][k] = {"weights": int(same.numel()), "identical_masks": round(float(same.float().mean()), 5),
+                            "share_departing_from_nearest": round(float(moved.float().mean()), 4),
+                            "identical_among_departing": round(float(same[moved].float().mean()), 5) if int(moved.sum()) else None}
+        tot_same += int(same.sum()); tot += same.numel(); tot_flip += int(moved.sum()); tot_flip_same += int(same[moved].sum())
+    out["identical_masks_overall"] = round(tot_same / tot, 5)
+    out["identical_among_departing_overall"] = round(tot_flip_same / max(tot_flip, 1), 5)
+    os.makedirs(os.path.join(ROOT, "gpurun_out", "r03"), exist_ok=True)
+    json.dump(out, open(os.path.join(ROOT, "gpurun_out", "r03", "sd_masks_exact_vs_fast.json"), "w"), indent=1)
+    print(json.dumps(out, indent=1))
