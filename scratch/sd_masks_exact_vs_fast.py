@@ -22,7 +22,7 @@ UNITS = ("model.input_blocks.1.0", "model.input_blocks.1.1.transformer_blocks.0"
 DEV = "cuda:0"
 
 
-def run(exact: bool):
+def run(exact: bool, noise: float = 0.0):
     if exact:
         os.environ["TFMQ_EXACT_FP"] = "1"
     else:
@@ -44,6 +44,8 @@ def run(exact: bool):
     xs = torch.randn(G * N, 4, 64, 64, generator=g)
     ts = torch.cat([torch.full((N,), float(t)) for t in (981, 201)])
     cs = torch.randn(G * N, 77, 768, generator=g)
+    if noise:       # control: the SAME run with rounding-level relative noise on the calibration latents
+        xs = xs * (1.0 + noise * torch.randn(xs.shape, generator=torch.Generator().manual_seed(99)))
     wq = {"bits": 4, "channel_wise": True, "scaler": Scaler.MINMAX}
     aq = {"bits": 8, "channel_wise": False, "scaler": Scaler.MINMAX, "leaf_param": True}
     qnn = QuantModel(m, wq, aq, cali=True, aq_mode=[QMODE.NORMAL.value, QMODE.QDIFF.value]).eval()
@@ -69,18 +71,26 @@ def run(exact: bool):
 if __name__ == "__main__":
     fast, nearest, t_fast = run(False)
     exact, _, t_exact = run(True)
+    ctrl, _, _ = run(False, noise=1e-6)
     out = {"iters": ITERS, "samples_per_group": N, "groups": 2, "units": list(UNITS), "seconds": {"fast": round(t_fast, 1), "exact": round(t_exact, 1)},
            "layers": {}}
-    tot_same = tot = tot_flip = tot_flip_same = 0
+    tot_same = tot = tot_flip = tot_flip_same = c_same = c_flip_same = 0
     for k in sorted(fast):
         same = (fast[k] == exact[k])
         moved = fast[k] != nearest[k]          # weights whose learned rounding departs from nearest in the fast run
+        csame = (fast[k] == ctrl[k])           # control: fast vs fast with 1e-6 relative noise on the calibration latents
+        c_same += int(csame.sum())
+        c_flip_same += int(csame[moved].sum())
         out["layers"][k] = {"weights": int(same.numel()), "identical_masks": round(float(same.float().mean()), 5),
+                            "control_identical_masks": round(float(csame.float().mean()), 5),
                             "share_departing_from_nearest": round(float(moved.float().mean()), 4),
                             "identical_among_departing": round(float(same[moved].float().mean()), 5) if int(moved.sum()) else None}
         tot_same += int(same.sum()); tot += same.numel(); tot_flip += int(moved.sum()); tot_flip_same += int(same[moved].sum())
     out["identical_masks_overall"] = round(tot_same / tot, 5)
     out["identical_among_departing_overall"] = round(tot_flip_same / max(tot_flip, 1), 5)
+    out["control_identical_masks_overall"] = round(c_same / tot, 5)
+    out["control_identical_among_departing_overall"] = round(c_flip_same / max(tot_flip, 1), 5)
+    out["control"] = "fast mode twice, the second time with 1e-6 relative noise on the calibration latents (same seeds, same mini-batches)"
     os.makedirs(os.path.join(ROOT, "gpurun_out", "r03"), exist_ok=True)
     json.dump(out, open(os.path.join(ROOT, "gpurun_out", "r03", "sd_masks_exact_vs_fast.json"), "w"), indent=1)
     print(json.dumps(out, indent=1))

@@ -83,12 +83,12 @@ def _loss_curve(golden, mode, monkeypatch):
     return rec_dev, rnd_dev, float((my_mask == ref_mask).mean())
 
 
-@pytest.mark.parametrize("mode", ["bf16x3", "f16"])
+@pytest.mark.parametrize("mode", ["f32", "bf16x3", "f16"])
 def test_reconstruction_loss_curve_under_reduced_operand_precision(golden, monkeypatch, mode):
     rec_dev, rnd_dev, agree = _loss_curve(golden, mode, monkeypatch)
     print(f"[TFMQ_RECON_GEMM={mode}] vs the reference's 400-iteration curve (F8b): worst reconstruction-loss deviation {rec_dev:.3%}, "
           f"worst rounding-loss deviation {rnd_dev:.3%}, final AdaRound masks identical {agree:.4%}")
-    if mode == "bf16x3":
+    if mode in ("f32", "bf16x3"):       # the default (bf16x3) is held to the bars of exact fp32 products
         assert rec_dev <= 0.05 and rnd_dev <= 0.02 and agree >= 0.99
     else:
         # fp16 operands: recorded, not required (DESIGN.md section 4 quotes the printed numbers); it must still converge to a sane state
