@@ -199,8 +199,10 @@ typedef struct tfmq_conv_desc {
                                     256-pixel tile once per channel chunk for all nine taps (256 x 320 / 256 / 128 tiles, 8 waves).
                                     TFMQ_TILE_DIRECT: pointwise w4a8 layers with fp16 / int8 / GEGLU-int8 output on the kernel whose
                                     epilogue runs out of the accumulator registers (swapped MFMA operands, no LDS staging).
-                                    (7 and 8 were the persistent variants of TFMQ_TILE_DIRECT of round 2 -- measured slower on every
-                                    shape and removed in round 3; the values fall back to the rule) */
+                                    TFMQ_TILE_SLAB128 (7): the slab kernel on 128-pixel tiles and four waves, two blocks per CU (one block's
+                                    epilogue runs under the other's MFMAs; twice the blocks at the 8x8 / 16x16 levels) -- same bits.
+                                    (8 was a persistent variant of TFMQ_TILE_DIRECT in round 2 -- measured slower on every shape and
+                                    removed in round 3; the value falls back to the rule) */
   int32_t res_f16;               /* != 0: `residual` is an fp16 buffer [B][Ho][Wo][Cout] (a tensor of the fp16 activation stream:
                                     the TFMQ_OUT_F16 output of an earlier launch) */
   const void* x2;                /* tfmq_conv2d_f16, pointwise, x_f16 only; NULL = one source.  Input channels [cin1, Cin) are read
@@ -217,7 +219,8 @@ typedef struct tfmq_conv_desc {
                                     bytes.  NULL: those layers run on the register-staged kernel with 32-channel K-steps */
 } tfmq_conv_desc;
 enum { TFMQ_OUT_F32 = 0, TFMQ_OUT_F16 = 1, TFMQ_OUT_GEGLU_Q8 = 2, TFMQ_OUT_Q8 = 3 };
-enum { TFMQ_TILE_AUTO = 0, TFMQ_TILE_128 = 1, TFMQ_TILE_64 = 2, TFMQ_TILE_256 = 3, TFMQ_TILE_128x64 = 4, TFMQ_TILE_SLAB = 5, TFMQ_TILE_DIRECT = 6 };
+enum { TFMQ_TILE_AUTO = 0, TFMQ_TILE_128 = 1, TFMQ_TILE_64 = 2, TFMQ_TILE_256 = 3, TFMQ_TILE_128x64 = 4, TFMQ_TILE_SLAB = 5, TFMQ_TILE_DIRECT = 6,
+       TFMQ_TILE_SLAB128 = 7 };
 int tfmq_conv2d_w4a8(tfmq_handle h, const tfmq_conv_desc* d, void* stream);
 int tfmq_conv2d_f16(tfmq_handle h, const tfmq_conv_desc* d, void* stream);
 

@@ -1,4 +1,4 @@
-"""3x3 w4a8 convolutions of the SD UNet at UNet batch 128: every tile kernel (tfmq_conv_desc.tile 1..4) vs the slab kernel (5)."""
+"""3x3 w4a8 convolutions of the SD UNet at UNet batch 128: every tile kernel (tfmq_conv_desc.tile 1..4) vs the slab kernel (5) and its 128-pixel two-blocks-per-CU form (7)."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -30,7 +30,7 @@ for (H, cin, cout, res) in shapes:
     nops = 2.0 * B * Ho * Ho * cout * 9 * cin
     line = f"{B}x{H}x{H} {cin}->{cout} res={int(res)}:"
     ref = None
-    for tile in (1, 3, 4, 5):
+    for tile in (1, 3, 4, 5, 7):
         orig = ops._tune_conv
         ops.set_conv_autotune({})
         ops._tune_conv = lambda h, name, kind, d, dsc, t=tile: t

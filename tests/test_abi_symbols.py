@@ -70,4 +70,8 @@ def test_slab_kernel_launch_geometry_rule(lib):
     assert not ops.slab_ok(desc(24, 24))                                               # 576 pixels: neither 256 | HW nor HW | 256
     assert not ops.slab_ok(desc(128, 128))                                             # (2 + 2) * 130 = 520 slab rows > 512
     assert not ops.slab_ok(desc(64, 64, out_mode=2))                                   # GEGLU output is a pointwise mode
-    assert set(ops._TILE_NAMES) == {1, 2, 3, 4, 5, 6}
+    # the 128-pixel form (TFMQ_TILE_SLAB128): slabs of at most 320 rows
+    assert all(ops.slab_ok(desc(r, r), 128) for r in (64, 32, 16, 8, 4)) and ops.slab_ok(desc(32, 32, up=1), 128)
+    assert not ops.slab_ok(desc(128, 128), 128)                                        # (1 + 2) * 130 = 390 slab rows > 320
+    assert not ops.slab_ok(desc(24, 24), 128)
+    assert set(ops._TILE_NAMES) == {1, 2, 3, 4, 5, 6, 7}

@@ -295,7 +295,7 @@ def test_f16_stream_epilogue_equals_rounded_f32_epilogue(ops, k, B, H, cin, cout
     pad = (k // 2,) * 4
     ref = ops.conv2d_w4a8(xq, pw, sel, pad=pad, residual=r16.float(), rowadd=ra, want_stats=True)
     ref_st = ref._tfmq_stats[0].clone()
-    tiles = (1, 2, 3, 4, 5) if k == 3 else (1, 2, 3, 4)
+    tiles = (1, 2, 3, 4, 5, 7) if k == 3 else (1, 2, 3, 4)
     for tile in tiles:
         ops.set_conv_autotune({})
         orig = _o._tune_conv
@@ -644,7 +644,7 @@ def test_w4a8_k_padded_operand_cin_32_mod_64(ops, B, H, W, cin, cout, k, res):
     if res:
         kw["residual"] = torch.randn(B, H, W, cout, generator=gen).to(DEV).half()
     ref = ops.conv2d_w4a8(xq, pw_ref, sel, **kw)
-    tiles = (1, 2, 4, 5) if k == 3 else (1, 2, 4, 6)
+    tiles = (1, 2, 4, 5, 7) if k == 3 else (1, 2, 4, 6)
     for tile in tiles:
         ops.set_conv_autotune({})
         orig = _o._tune_conv

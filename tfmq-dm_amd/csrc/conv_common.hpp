@@ -50,6 +50,15 @@ __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
                : "memory");
 }
 
+// The same with a uniform base (SGPR pair) and a per-lane 32-bit byte offset: half the address VGPRs of the 64-bit form.
+__device__ __forceinline__ void glds16_sv(const void* sbase, unsigned voff, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(voff), "s"(sbase), "s"(lds_dst)
+               : "memory");
+}
+
 // XCD-aware tile order (T1): the dispatcher places block b on XCD b % 8; give each XCD a contiguous
 // range of tiles so the 3x3 taps / neighbouring rows of one image hit that XCD's private L2.
 // Bijective for any grid size; placement is a speed matter only.
@@ -105,7 +114,7 @@ __device__ __forceinline__ float4 load_res4(const tfmq_conv_desc& d, int m, int 
 }
 
 // 3x3 / stride 1 / pad 1 w4a8 convolutions on the slab kernel (conv_slab.hip): true when the launch was taken
-bool launch_conv_slab(tfmq_handle h, ConvP& p, hipStream_t st, bool forced, bool f16 = false);
+bool launch_conv_slab(tfmq_handle h, ConvP& p, hipStream_t st, bool forced, bool f16 = false, bool half_m = false);
 // pointwise w4a8 layers with fp16 / int8 / GEGLU-int8 output on the register-direct-epilogue kernel (conv_lin.hip)
 bool launch_conv_lin(tfmq_handle h, ConvP& p, hipStream_t st);
 // fp16-operand pointwise layers (tfmq_conv2d_f16 with x_f16) on the same kernel

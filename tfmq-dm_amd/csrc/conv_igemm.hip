@@ -1034,12 +1034,24 @@ static int launch_conv(tfmq_handle h, const tfmq_conv_desc* dd, void* stream) {
       TFMQ_LAUNCH_CHECK(h);
       return TFMQ_OK;
     }
+    // the 128-pixel form of the same kernel (two blocks per CU): a caller's measured choice, or the rule's fallback when the
+    // 256-pixel grid would leave CUs idle (8x8 / 16x16 feature maps at small batches)
+    if ((d.tile == TFMQ_TILE_AUTO || d.tile == TFMQ_TILE_SLAB128) && dma8 &&
+        launch_conv_slab(h, p, as_stream(stream), d.tile == TFMQ_TILE_SLAB128, false, true)) {
+      TFMQ_LAUNCH_CHECK(h);
+      return TFMQ_OK;
+    }
   } else {
     // the same kernel on fp16 operands (un-quantised / weight-only 3x3 layers, fp16 input).  Its K order is (channel chunk, tap),
     // the tile kernels' (tap, channel chunk): fp32 sums differ in the last bits, so the choice must not depend on the batch size --
     // every launch whose GEOMETRY the slab kernel takes runs on it (whatever the grid size), and the tile kernels only when a
     // caller pins one (tests, A/B runs).  A UNet-batch-12 forward then equals two batch-6 forwards bit for bit as before.
-    if ((d.tile == TFMQ_TILE_AUTO || d.tile == TFMQ_TILE_SLAB) && dma16 && !d.x2 &&
+    // (TFMQ_TILE_SLAB128: the 128-pixel form -- the same K order and MFMA sequence per output, hence the same bits)
+    if (d.tile == TFMQ_TILE_SLAB128 && dma16 && !d.x2 && launch_conv_slab(h, p, as_stream(stream), true, true, true)) {
+      TFMQ_LAUNCH_CHECK(h);
+      return TFMQ_OK;
+    }
+    if ((d.tile == TFMQ_TILE_AUTO || d.tile == TFMQ_TILE_SLAB || d.tile == TFMQ_TILE_SLAB128) && dma16 && !d.x2 &&
         launch_conv_slab(h, p, as_stream(stream), true, true)) {
       TFMQ_LAUNCH_CHECK(h);
       return TFMQ_OK;

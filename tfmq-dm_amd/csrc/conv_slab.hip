@@ -8,6 +8,14 @@
 //     of the slab (rows of the byte z_a - 128 from the handle's pad table: a real zero under the activation quantizer);
 //   * the tile is 256 pixels x (64 * WN) channels on 8 waves (4 along M x 2 along N, each 64 x 32*WN), WN = 5 gives
 //     320-wide tiles: no column waste at Cout = 320 / 640 / 960 / 1280 ..., B (weight) bytes per MFMA halve against 128^2;
+//   * NWM = 2 (round 3): the same pipeline on 128 pixels x (64 * WN) channels and FOUR waves (2 along M x 2 along N), two weight
+//     stages instead of three and 320-row slab buffers -> exactly 80 KiB of LDS and <= 256 VGPRs, so that TWO blocks share a CU:
+//     one block's register-direct epilogue (a third of a block's life: scratch/phase_slab.py) and its per-K-step barrier stalls run
+//     under the other block's MFMAs, and the 8x8 / 16x16 levels get twice as many blocks to spread over 256 CUs.  Measured
+//     (scratch/bench_slab.py, UNet batch 128): +8 ... +23 % at the 8x8 level (256 blocks instead of 128), -1 ... -7 % elsewhere
+//     (twice the weight DMA per MFMA, two stages) -- the two co-resident blocks run in lockstep, and starting the second one
+//     25 / 50 / 75 % of a block time late is monotonically slower (gpurun_out/r03/bench_slab_stagger.txt): a block's life is a chain
+//     of its own latencies, not contention with its neighbour.  The engines' per-shape measurement picks the form (ops.py);
 //   * both operands travel global -> LDS by LDS-DMA with the 16-byte-slot XOR swizzle of the other kernels (on the
 //     source address and on the fragment reads), the slab double-buffered per chunk, the weights in three K-step
 //     stages, counted vmcnt and one raw s_barrier per K-step.
@@ -16,6 +24,7 @@
 // uses) stages 32 tile rows at a time through LDS and writes whole rows.
 #include "conv_common.hpp"
 #include <type_traits>
+#include <cstdlib>
 #ifdef TFMQ_PHASE_TIMERS
 #include <cstdio>
 #include <cstdlib>
@@ -36,14 +45,24 @@ struct SlabP {
   int slab_rows;  // rows of the slab that carry pixels (<= 512)
 };
 
-constexpr int SLAB_CAP = 512;                 // rows per slab buffer
-constexpr int SLAB_BYTES = SLAB_CAP * 64;     // 32 KiB, a power of two: the two buffers toggle by XOR on the offset
+// Geometry of a variant: NWM waves along M (4: 256-pixel tiles, 8 waves, one block per CU; 2: 128-pixel tiles, 4 waves, two per CU)
+template <int NWM>
+struct SlabGeo {
+  static constexpr int NW = 2 * NWM;                 // waves per block
+  static constexpr int NT = 64 * NW;                 // threads
+  static constexpr int BM = 64 * NWM;                // pixels per tile
+  static constexpr int NST = NWM == 4 ? 3 : 2;       // weight K-step stages in LDS
+  static constexpr int NIT = NWM == 4 ? 4 : 5;       // slab DMA pieces per wave and chunk (one per K-step of taps 0 .. NIT-1)
+  static constexpr int CAP = NIT * NW * 16;          // rows per slab buffer: 512 / 320
+  static constexpr int STRIDE = CAP * 64;            // 32 KiB / 20 KiB
+};
 
-template <int WN>
+template <int WN, int NWM>
 __host__ __device__ constexpr int slab_lds_bytes() {
+  using G = SlabGeo<NWM>;
   constexpr int BN = 64 * WN;
-  constexpr int main_ = 2 * SLAB_BYTES + 3 * BN * 64;
-  constexpr int epi = 32 * BN * 8 + (3 + 4) * BN * 4;      // 8-row-group partial sums + the table of per-column constants
+  constexpr int main_ = 2 * G::STRIDE + G::NST * BN * 64;
+  constexpr int epi = (G::BM / 8) * BN * 8 + (3 + 4) * BN * 4;      // 8-row-group partial sums + the table of per-column constants
   return main_ > epi ? main_ : epi;
 }
 
@@ -55,13 +74,16 @@ __device__ __forceinline__ void wait_vmcnt() {
 // F16OP: the un-quantised / weight-only 3x3 layers on the same pipeline -- fp16 activations (a 64-byte slab row = 32 channels), fp16
 // weights [cout][tap][cin_pad] row-major (tfmq_pack_w_f16), v_mfma_f32_32x32x16_f16, value = scale * acc + bias (k_conv_dma<true>'s
 // arithmetic; the K order differs from its tap-major one, so the two agree to fp32 summation noise, not bit for bit).
-template <int WN, bool F16OP = false>
-__global__ __launch_bounds__(512) void k_conv3_slab(SlabP sp) {
-  constexpr int BM = 256, BN = 64 * WN;
+template <int WN, bool F16OP = false, int NWM = 4>
+__global__ __launch_bounds__(64 * 2 * NWM, 2) void k_conv3_slab(SlabP sp) {
+  using G = SlabGeo<NWM>;
+  constexpr int NW = G::NW, NT = G::NT, NST = G::NST, NIT = G::NIT, SLAB_BYTES = G::STRIDE;
+  constexpr int BM = G::BM, BN = 64 * WN;
   constexpr int BST = BN * 64;                 // bytes of one weight K-step stage
   constexpr int BOFF = 2 * SLAB_BYTES;
   constexpr int NBP = BN / 16;                 // 1-KiB weight pieces per K-step
-  __shared__ __attribute__((aligned(1024))) unsigned char lds[slab_lds_bytes<WN>()];
+  constexpr int MAXCH = (NBP + NW - 1) / NW;   // weight pieces a wave moves per K-step
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[slab_lds_bytes<WN, NWM>()];
 
   const ConvP& p = sp.p;
   const tfmq_conv_desc& d = p.d;
@@ -95,13 +117,13 @@ __global__ __launch_bounds__(512) void k_conv3_slab(SlabP sp) {
       srow0[i] = im * sp.SI + y * SW + (q - y * W);
     }
   }
-  // slab DMA sources: piece it*8 + wid, 16 rows each, this lane's row = piece*16 + lane/4
+  // slab DMA sources: piece it*NW + wid, 16 rows each, this lane's row = piece*16 + lane/4
   const unsigned char* xb = static_cast<const unsigned char*>(d.x);
   const int dcol = ((lane & 3) ^ ((lane >> 4) & 3)) * 16;        // swizzle on the SOURCE: (row >> 2) & 3 == (lane >> 4) & 3
-  int s_off[4];
+  int s_off[NIT];
 #pragma unroll
-  for (int it = 0; it < 4; ++it) {
-    const int j = (it * 8 + wid) * 16 + (lane >> 2);
+  for (int it = 0; it < NIT; ++it) {
+    const int j = (it * NW + wid) * 16 + (lane >> 2);
     int off = -1;
     if (j < sp.slab_rows) {
       const int k = sp.imgs == 1 ? 0 : j / sp.SI;
@@ -120,21 +142,22 @@ __global__ __launch_bounds__(512) void k_conv3_slab(SlabP sp) {
 
   auto issue_slab = [&](int it, int c, int buf) {
     const unsigned char* src = s_off[it] >= 0 ? xb + static_cast<size_t>(static_cast<unsigned>(s_off[it])) * EB + c * 64 + dcol : padp;
-    glds16(src, lds0 + buf * SLAB_BYTES + __builtin_amdgcn_readfirstlane((it * 8 + wid) * 1024));
+    glds16(src, lds0 + buf * SLAB_BYTES + __builtin_amdgcn_readfirstlane((it * NW + wid) * 1024));
   };
 
-  // weight DMA sources: pieces wid, wid + 8, wid + 16 (< NBP)
-  const unsigned char* b_ptr[3];
+  // weight DMA sources: pieces wid, wid + NW, wid + 2 NW ... (< NBP): per-lane 32-bit offsets from the (uniform) weight base
+  const unsigned char* wbase = static_cast<const unsigned char*>(d.w);
+  unsigned b_off[MAXCH];
 #pragma unroll
-  for (int k = 0; k < 3; ++k) {
-    const int piece = wid + 8 * k;
+  for (int k = 0; k < MAXCH; ++k) {
+    const int piece = wid + NW * k;
     int n = n0 + piece * 16 + (lane >> 2);
     if constexpr (F16OP) {
       n = n < d.Cout ? n : d.Cout - 1;
-      b_ptr[k] = static_cast<const unsigned char*>(d.w) + static_cast<size_t>(n) * 9 * p.cin_pad * 2 + dcol;
+      b_off[k] = static_cast<unsigned>(static_cast<size_t>(n) * 9 * p.cin_pad * 2 + dcol);
     } else {
       n = n < p.cout_pad ? n : p.cout_pad - 1;
-      b_ptr[k] = static_cast<const unsigned char*>(d.w) + (static_cast<size_t>(n / 32) * p.nsteps * 32 + (n % 32)) * 64 + dcol;
+      b_off[k] = static_cast<unsigned>((static_cast<size_t>(n / 32) * p.nsteps * 32 + (n % 32)) * 64 + dcol);
     }
   }
 
@@ -162,22 +185,25 @@ __global__ __launch_bounds__(512) void k_conv3_slab(SlabP sp) {
       const size_t boff = F16OP ? static_cast<size_t>(tap * p.cin_pad + c * 32) * 2 : static_cast<size_t>(tap * p.chunks + c) * 2048;
 #pragma unroll
       for (int k = 0; k < B_CH; ++k)
-        glds16(b_ptr[k] + boff, lds0 + BOFF + stage * BST + __builtin_amdgcn_readfirstlane((wid + 8 * k) * 1024));
+        glds16_sv(wbase + boff, b_off[k], lds0 + BOFF + stage * BST + __builtin_amdgcn_readfirstlane((wid + NW * k) * 1024));
     };
     auto step = [&](int c, auto tap_tag) {
       constexpr int TAP = decltype(tap_tag)::value;
-      // slab pieces issued one / two iterations ago (taps 0..3 carry one each) are younger than this step's weights
-      constexpr int X = ((TAP >= 1 && TAP <= 4) ? 1 : 0) + ((TAP >= 2 && TAP <= 5) ? 1 : 0);
+      // Loads younger than this step's weights: the weights of the NST - 2 steps after it and the slab pieces issued in the
+      // NST - 1 steps before this one (taps 0 .. NIT-1 carry one each)
+      constexpr int X = ((TAP >= 1 && TAP <= NIT) ? 1 : 0) + ((NST == 3 && TAP >= 2 && TAP <= NIT + 1) ? 1 : 0);
       const int pos = c * 9 + TAP;
-      if (pos + 1 < p.nsteps) wait_vmcnt<B_CH + X>();
+      if (pos + 1 < p.nsteps) wait_vmcnt<(NST - 2) * B_CH + X>();
       else wait_vmcnt<0>();
       asm volatile("s_barrier" ::: "memory");
+      // stage of a K-step: NST = 3 -> tap % 3 (9 taps a chunk); NST = 2 -> parity of the step index
+      const int st_next = NST == 3 ? (TAP + 2) % 3 : ((pos + 1) & 1);
       auto issue_next = [&]() {
-        if (pos + 2 < p.nsteps) {
-          if constexpr (TAP + 2 < 9) issue_b(c, TAP + 2, (TAP + 2) % 3);
-          else issue_b(c + 1, TAP + 2 - 9, (TAP + 2) % 3);
+        if (pos + NST - 1 < p.nsteps) {
+          if constexpr (TAP + NST - 1 < 9) issue_b(c, TAP + NST - 1, st_next);
+          else issue_b(c + 1, TAP + NST - 1 - 9, st_next);
         }
-        if constexpr (TAP < 4) {
+        if constexpr (TAP < NIT) {
           // next chunk's slab into the idle buffer; the last chunk re-stages chunk 0 there (never read) so that the
           // counted waits see the same number of loads in flight in every chunk
           issue_slab(TAP, c + 1 < p.chunks ? c + 1 : 0, ((c + 1) & 1));
@@ -189,9 +215,10 @@ __global__ __launch_bounds__(512) void k_conv3_slab(SlabP sp) {
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         const int srow = srow0[i] + toff;
-        a_rel[i] = ((srow << 6) + (((h ^ (srow >> 2)) & 3) << 4)) ^ slab_toggle;
+        const int ar = (srow << 6) + (((h ^ (srow >> 2)) & 3) << 4);
+        a_rel[i] = (SLAB_BYTES & (SLAB_BYTES - 1)) == 0 ? (ar ^ slab_toggle) : (ar + slab_toggle);     // 32 KiB buffers toggle by XOR
       }
-      const unsigned char* sb = lds + BOFF + (TAP % 3) * BST;
+      const unsigned char* sb = lds + BOFF + (NST == 3 ? TAP % 3 : (pos & 1)) * BST;
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
         v4i af[2], bf[WN];
@@ -218,9 +245,9 @@ __global__ __launch_bounds__(512) void k_conv3_slab(SlabP sp) {
       }
     };
 #pragma unroll
-    for (int it = 0; it < 4; ++it) issue_slab(it, 0, 0);
+    for (int it = 0; it < NIT; ++it) issue_slab(it, 0, 0);
     issue_b(0, 0, 0);
-    issue_b(0, 1, 1);
+    if constexpr (NST == 3) issue_b(0, 1, 1);
     for (int c = 0; c < p.chunks; ++c) {
       step(c, std::integral_constant<int, 0>{});
       step(c, std::integral_constant<int, 1>{});
@@ -231,11 +258,11 @@ __global__ __launch_bounds__(512) void k_conv3_slab(SlabP sp) {
       step(c, std::integral_constant<int, 6>{});
       step(c, std::integral_constant<int, 7>{});
       step(c, std::integral_constant<int, 8>{});
-      slab_toggle ^= SLAB_BYTES;
+      slab_toggle = SLAB_BYTES - slab_toggle;
     }
   };
-  if (NBP % 8 != 0 && wid < NBP % 8) kloop(std::integral_constant<int, NBP / 8 + 1>{});
-  else kloop(std::integral_constant<int, NBP / 8>{});
+  if (NBP % NW != 0 && wid < NBP % NW) kloop(std::integral_constant<int, NBP / NW + 1>{});
+  else kloop(std::integral_constant<int, NBP / NW>{});
   SLAB_MARK(1);
 
   // ================================================================================ epilogue (out of the registers)
@@ -245,8 +272,8 @@ __global__ __launch_bounds__(512) void k_conv3_slab(SlabP sp) {
   // scratch/phase_slab.py): every lane converts its own values, 16-byte stores and residual loads, the fp16 residual
   // octets requested three channel tiles ahead, statistics by DPP sums over the 8 lanes of a pixel-row group in the
   // canonical order.
-  float2* ldsP = reinterpret_cast<float2*>(lds);                         // [32 eight-row groups][BN] (sum, sum of squares)
-  float* cs = reinterpret_cast<float*>(lds + 32 * BN * 8);               // scale[BN], corr[BN] (int), bias[BN], rowadd[imgs][BN]
+  float2* ldsP = reinterpret_cast<float2*>(lds);                         // [BM / 8 eight-row groups][BN] (sum, sum of squares)
+  float* cs = reinterpret_cast<float*>(lds + (BM / 8) * BN * 8);         // scale[BN], corr[BN] (int), bias[BN], rowadd[imgs][BN]
   const int hw = sp.HW;
   const float* rowadd = d.rowadd;
   if (rowadd && d.rowadd_step) rowadd += static_cast<size_t>(*d.rowadd_step) * d.rowadd_step_stride;
@@ -256,8 +283,8 @@ __global__ __launch_bounds__(512) void k_conv3_slab(SlabP sp) {
   if (q8) oqp = load_qparam(d.oq);
   const QuantP qP = make_quantp(oqp);
   __syncthreads();                       // every wave has left the K loop: its LDS becomes the table and the partial sums
-  if (tid < BN) {
-    const int n = n0 + tid;
+  for (int tc = tid; tc < BN; tc += NT) {
+    const int n = n0 + tc;
     float c_sc = 1.0f, c_bias = 0.0f;
     int c_corr = 0;
     if (n < d.Cout) {
@@ -270,13 +297,13 @@ __global__ __launch_bounds__(512) void k_conv3_slab(SlabP sp) {
       }
       c_bias = d.bias ? d.bias[n] : 0.0f;
     }
-    cs[tid] = c_sc;
-    reinterpret_cast<int*>(cs)[BN + tid] = c_corr;
-    cs[2 * BN + tid] = c_bias;
+    cs[tc] = c_sc;
+    reinterpret_cast<int*>(cs)[BN + tc] = c_corr;
+    cs[2 * BN + tc] = c_bias;
     if (rowadd) {
       for (int k = 0; k < sp.imgs; ++k) {
         const int b = (b0 + k) < d.B ? (b0 + k) : d.B - 1;
-        cs[(3 + k) * BN + tid] = n < d.Cout ? rowadd[static_cast<size_t>(b) * d.rowadd_ld + n] : 0.0f;
+        cs[(3 + k) * BN + tc] = n < d.Cout ? rowadd[static_cast<size_t>(b) * d.rowadd_ld + n] : 0.0f;
       }
     }
   }
@@ -379,7 +406,7 @@ __global__ __launch_bounds__(512) void k_conv3_slab(SlabP sp) {
   if (seg) {
     __syncthreads();
     const int nseg = BM / seg, gps = seg / 8;
-    for (int o = tid; o < nseg * BN; o += 512) {
+    for (int o = tid; o < nseg * BN; o += NT) {
       const int sidx = o / BN, col = o - sidx * BN;
       float2 a = make_float2(0.0f, 0.0f);
       for (int q = 0; q < gps; ++q) {            // a segment = its 8-row groups added in row order
@@ -396,7 +423,7 @@ __global__ __launch_bounds__(512) void k_conv3_slab(SlabP sp) {
 
 }  // namespace
 
-bool launch_conv_slab(tfmq_handle h, ConvP& p, hipStream_t st, bool forced, bool f16) {
+bool launch_conv_slab(tfmq_handle h, ConvP& p, hipStream_t st, bool forced, bool f16, bool half_m) {
   const tfmq_conv_desc& d = p.d;
   const int Hv = d.up2x ? 2 * d.H : d.H, Wv = d.up2x ? 2 * d.W : d.W;
   if (d.KH != 3 || d.KW != 3 || d.stride != 1 || d.pad_t != 1 || d.pad_l != 1 || d.Ho != Hv || d.Wo != Wv || p.Hv != Hv || p.Wv != Wv) return false;
@@ -405,25 +432,26 @@ bool launch_conv_slab(tfmq_handle h, ConvP& p, hipStream_t st, bool forced, bool
   if (f16 && (!d.x_f16 || p.cin_pad != d.Cin || p.chunks != d.Cin / 32 || d.out_mode == TFMQ_OUT_Q8)) return false;
   if (!(d.out_mode == TFMQ_OUT_F32 || d.out_mode == TFMQ_OUT_Q8 || (d.out_mode == TFMQ_OUT_F16 && !d.yt))) return false;
   if (((d.Cout | d.ldy | d.y_coff) & 7) != 0) return false;             // a lane moves whole 8-channel octets
-  if (d.stats && 256 % d.stats_seg != 0) return false;
+  const int BM = half_m ? 128 : 256, cap = half_m ? SlabGeo<2>::CAP : SlabGeo<4>::CAP;
+  if (d.stats && BM % d.stats_seg != 0) return false;
   SlabP sp;
   sp.HW = Hv * Wv;
   sp.SW = Wv + 2;
-  if (sp.HW % 256 == 0 && 256 % Wv == 0) {
+  if (sp.HW % BM == 0 && BM % Wv == 0) {
     sp.imgs = 1;
-    sp.slab_rows = (256 / Wv + 2) * sp.SW;
+    sp.slab_rows = (BM / Wv + 2) * sp.SW;
     sp.SI = sp.slab_rows;
-  } else if (256 % sp.HW == 0) {
-    sp.imgs = 256 / sp.HW;
+  } else if (BM % sp.HW == 0) {
+    sp.imgs = BM / sp.HW;
     sp.SI = (Hv + 2) * sp.SW;
     sp.slab_rows = sp.imgs * sp.SI;
   } else {
     return false;
   }
-  if (sp.slab_rows > SLAB_CAP) return false;
+  if (sp.slab_rows > cap) return false;
   const int WN = d.Cout % 320 == 0 ? 5 : (d.Cout > 128 ? 4 : 2);
   const int BN = 64 * WN;
-  const int tiles_n = (d.Cout + BN - 1) / BN, tiles_m = (p.M + 255) / 256;
+  const int tiles_n = (d.Cout + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
   // one 8-wave block per CU: a grid that leaves most CUs idle is better served by the small-tile kernels
   if (!forced && static_cast<long>(tiles_n) * tiles_m < h->cu_count) return false;
   p.tiles_n = tiles_n;
@@ -434,7 +462,15 @@ bool launch_conv_slab(tfmq_handle h, ConvP& p, hipStream_t st, bool forced, bool
   if (!dbuf) (void)hipMalloc(reinterpret_cast<void**>(&dbuf), sizeof(unsigned long long) * 4 * (1u << 16));
   sp.p.dbg = grid.x <= (1u << 16) ? dbuf : nullptr;
 #endif
-  if (f16) {
+  if (half_m) {
+    if (f16) {
+      if (WN == 5) hipLaunchKernelGGL((k_conv3_slab<5, true, 2>), grid, dim3(256), 0, st, sp);
+      else if (WN == 4) hipLaunchKernelGGL((k_conv3_slab<4, true, 2>), grid, dim3(256), 0, st, sp);
+      else hipLaunchKernelGGL((k_conv3_slab<2, true, 2>), grid, dim3(256), 0, st, sp);
+    } else if (WN == 5) hipLaunchKernelGGL((k_conv3_slab<5, false, 2>), grid, dim3(256), 0, st, sp);
+    else if (WN == 4) hipLaunchKernelGGL((k_conv3_slab<4, false, 2>), grid, dim3(256), 0, st, sp);
+    else hipLaunchKernelGGL((k_conv3_slab<2, false, 2>), grid, dim3(256), 0, st, sp);
+  } else if (f16) {
     if (WN == 5) hipLaunchKernelGGL((k_conv3_slab<5, true>), grid, dim3(512), 0, st, sp);
     else if (WN == 4) hipLaunchKernelGGL((k_conv3_slab<4, true>), grid, dim3(512), 0, st, sp);
     else hipLaunchKernelGGL((k_conv3_slab<2, true>), grid, dim3(512), 0, st, sp);

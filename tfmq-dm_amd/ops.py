@@ -425,7 +425,8 @@ def _attach_stats(dsc, y: torch.Tensor, B: int, hw: int, cout: int, want_stats: 
 # the launch stream; a conv is idempotent, so re-running it is harmless) and later launches -- in particular the ones
 # captured into the sampler's hipGraph -- use the winner.  The result does not depend on the tile shape.
 _AUTOTUNE = None      # None = off, else {shape key: tile id}
-_TILE_NAMES = {1: "128x128", 2: "64x64", 3: "256x128", 4: "128x64", 5: "slab 256xN (3x3)", 6: "direct 128x128 (pointwise)"}
+_TILE_NAMES = {1: "128x128", 2: "64x64", 3: "256x128", 4: "128x64", 5: "slab 256xN (3x3)", 6: "direct 128x128 (pointwise)",
+               7: "slab 128xN (3x3, two blocks per CU)"}
 
 
 def set_conv_autotune(cache) -> None:
@@ -457,9 +458,9 @@ def conv_autotune_report():
     return {} if _AUTOTUNE is None else {k: _TILE_NAMES.get(v, "auto") for k, v in _AUTOTUNE.items()}
 
 
-def slab_ok(dsc) -> bool:
-    """Launch geometry the 3x3 slab kernel (csrc/conv_slab.hip, TFMQ_TILE_SLAB) takes: 3x3 / stride 1 / pad 1, Cin % 64 == 0,
-    256-pixel tiles made of whole image rows (or whole images), a slab of at most 512 pixel rows."""
+def slab_ok(dsc, bm: int = 256) -> bool:
+    """Launch geometry the 3x3 slab kernel (csrc/conv_slab.hip, TFMQ_TILE_SLAB / _SLAB128) takes: 3x3 / stride 1 / pad 1, Cin % 64 == 0,
+    256- (128-) pixel tiles made of whole image rows (or whole images), a slab of at most 512 (320) pixel rows."""
     hv, wv = (2 * dsc.H, 2 * dsc.W) if dsc.up2x else (dsc.H, dsc.W)      # the fused nearest-2x upsample stages upsampled rows
     f16 = bool(dsc.x_f16)              # the fp16-operand form: 32 channels per 64-byte slab row, no int8 output
     if not (dsc.KH == 3 and dsc.KW == 3 and dsc.stride == 1 and dsc.pad_t == 1 and dsc.pad_l == 1
@@ -467,13 +468,13 @@ def slab_ok(dsc) -> bool:
             and dsc.out_mode in ((0, 1) if f16 else (0, 1, 3)) and dsc.Cout % 8 == 0):
         return False
     hw = hv * wv
-    if hw % 256 == 0 and 256 % wv == 0:
-        rows = (256 // wv + 2) * (wv + 2)
-    elif 256 % hw == 0:
-        rows = (256 // hw) * (hv + 2) * (wv + 2)
+    if hw % bm == 0 and bm % wv == 0:
+        rows = (bm // wv + 2) * (wv + 2)
+    elif bm % hw == 0:
+        rows = (bm // hw) * (hv + 2) * (wv + 2)
     else:
         return False
-    return rows <= 512
+    return rows <= (512 if bm == 256 else 320) and not (dsc.stats and bm % dsc.stats_seg != 0)
 
 
 def _tune_conv(h, name, kind, d, dsc):
@@ -487,21 +488,15 @@ def _tune_conv(h, name, kind, d, dsc):
     if kind == "f16" and dsc.x2:
         return 6                      # two sources: only the register-direct pointwise kernel reads them
     if kind == "f16" and dsc.x_f16 and slab_ok(dsc):
-        return 5                      # fp16 3x3: the slab kernel's K order differs from the tile kernels' -- one rule for every batch size
-    cands = [1, 2]
-    k64 = dsc.Cin % 64 == 0 or (dsc.Cin % 32 == 0 and bool(dsc.w64))      # int8 layers the LDS-DMA kernels take
-    if (kind == "w4a8" and k64) or (kind == "f16" and dsc.x_f16):
-        cands.append(4)
-        if dsc.stride == 1 and not dsc.up2x:
-            cands.append(3)
-    if kind == "w4a8" and slab_ok(dsc):
-        cands.append(5)
-    if (kind == "w4a8" and dsc.KH == 1 and dsc.KW == 1 and dsc.stride == 1 and not dsc.up2x and k64 and dsc.Cout % 4 == 0
-            and dsc.out_mode in (1, 2, 3) and not dsc.rowadd and not (dsc.stats and dsc.out_mode != 1) and not (dsc.yt and dsc.residual)):
-        cands.append(6)
-    if (kind == "f16" and dsc.x_f16 and dsc.KH == 1 and dsc.KW == 1 and dsc.stride == 1 and not dsc.up2x and dsc.Cin % 32 == 0
-            and dsc.Cout % 8 == 0 and dsc.out_mode == 1 and not dsc.rowadd and not (dsc.yt and (dsc.residual or dsc.stats))):
-        cands.append(6)             # the same register-direct kernel on fp16 operands (skip-connection 1x1 convs, un-quantised q|k|v)
+        # fp16 3x3: the slab kernel's K order differs from the tile kernels' -- one rule for every batch size; its 256- and 128-pixel
+        # forms accumulate every output in the same order (bit-identical), so THAT choice may be measured
+        cands = [5] + ([7] if slab_ok(dsc, 128) else [])
+        if len(cands) == 1:
+            return 5
+    else:
+        cands = None
+    if cands is None:
+        cands = _tile_candidates(kind, dsc)
     best, best_ms = 0, None
     e0, e1 = C.c_int(), C.c_int()
     h.call("event_create", C.byref(e0))
@@ -518,6 +513,26 @@ def _tune_conv(h, name, kind, d, dsc):
             best, best_ms = t, ms
     _AUTOTUNE[key] = best
     return best
+
+
+def _tile_candidates(kind, dsc):
+    cands = [1, 2]
+    k64 = dsc.Cin % 64 == 0 or (dsc.Cin % 32 == 0 and bool(dsc.w64))      # int8 layers the LDS-DMA kernels take
+    if (kind == "w4a8" and k64) or (kind == "f16" and dsc.x_f16):
+        cands.append(4)
+        if dsc.stride == 1 and not dsc.up2x:
+            cands.append(3)
+    if kind == "w4a8" and slab_ok(dsc):
+        cands.append(5)
+    if kind == "w4a8" and slab_ok(dsc, 128):
+        cands.append(7)
+    if (kind == "w4a8" and dsc.KH == 1 and dsc.KW == 1 and dsc.stride == 1 and not dsc.up2x and k64 and dsc.Cout % 4 == 0
+            and dsc.out_mode in (1, 2, 3) and not dsc.rowadd and not (dsc.stats and dsc.out_mode != 1) and not (dsc.yt and dsc.residual)):
+        cands.append(6)
+    if (kind == "f16" and dsc.x_f16 and dsc.KH == 1 and dsc.KW == 1 and dsc.stride == 1 and not dsc.up2x and dsc.Cin % 32 == 0
+            and dsc.Cout % 8 == 0 and dsc.out_mode == 1 and not dsc.rowadd and not (dsc.yt and (dsc.residual or dsc.stats))):
+        cands.append(6)             # the same register-direct kernel on fp16 operands (skip-connection 1x1 convs, un-quantised q|k|v)
+    return cands
 
 
 def _profiled_conv(name, kind, d, dsc, nops, nbytes=0.0):
