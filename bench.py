@@ -490,7 +490,9 @@ def run_cali_workload(args, dev, rank, local_rank, world, log):
         "metric": "w4a8 calibration wall-clock, SD-v1-4 UNet (reduced recipe, see config)", "value": round(dt, 2), "unit": "s",
         "n_gpus": world, "steps": 1, "warmup": 0, "ms_per_step": round(dt * 1e3, 1), "higher_is_better": False,
         "scaling": "strong" if world > 1 else "weak", "vs_baseline": None,
-        "dtype": "f32 (AdaRound iterations: exact fp32 GEMMs) + int8/f16 (capture forwards)", "data": "synthetic",
+        "dtype": {"f32": "f32 (AdaRound iterations: exact fp32 MFMA GEMMs)", "f16": "f32 values, fp16-operand MFMA GEMMs with fp32 accumulation (AdaRound iterations)"}.get(
+            os.environ.get("TFMQ_RECON_GEMM", "bf16x3"), "f32 values, split-bf16 (hi + lo, 3 MFMAs per product, fp32 accumulation: 2^-16 per product) GEMMs (AdaRound iterations)")
+        + " + int8/f16 (capture forwards)", "data": "synthetic",
         "config": {"workload": (f"cali_model{'_multi' if world > 1 else ''} on the SD v1-4 UNet (859.5M, random init): {G} timestep groups x {N} "
                                 f"samples, {ITERS} AdaRound iterations per unit at mini-batch 8/rank (the recipe: 25 groups x 512, 20000), "
                                 "w4 channel-wise + a8 Finite-Set, running_stat"
@@ -763,7 +765,10 @@ def main():
             cali["plms"] = info["plms"]()
             # SD calibration at the recipe's iteration count, run once with this code by `bench.py --workload cali --cali-iters 20000`
             # (a run of this length cannot sit inside the default bench; the committed lines carry their own config and phase split)
-            for key, fn in (("whole_unet", "r03_bench_line_cali_sd_full_20000.json"), ("8x8_level_units", "r03_bench_line_cali_sd_8x8level_20000.json")):
+            # (a gpurun call is limited to one hour, so the UNet was measured one resolution level per call; the levels partition the
+            # reconstruction units, and `sum_of_levels` adds their wall-clocks)
+            for key, fn in (("64x64_level_units", "r03_bench_line_cali_sd_64x64level_20000.json"), ("32x32_level_units", "r03_bench_line_cali_sd_32x32level_20000.json"),
+                            ("16x16_level_units", "r03_bench_line_cali_sd_16x16level_20000.json"), ("8x8_level_units_and_tib", "r03_bench_line_cali_sd_8x8level_20000.json")):
                 fpath = os.path.join(ROOT, "profiles", fn)
                 if os.path.exists(fpath):
                     try:
@@ -773,6 +778,12 @@ def main():
                         cali.setdefault("measured_sd_recipe_20000_iterations", {})[key] = ent
                     except Exception as e:      # a damaged record must not take the sampling line down
                         cali.setdefault("measured_sd_recipe_20000_iterations", {})[key] = {"error": repr(e)}
+            lv = cali.get("measured_sd_recipe_20000_iterations", {})
+            if len(lv) == 4 and all("wall_clock_s" in v for v in lv.values()):
+                lv["sum_of_levels"] = {"wall_clock_s": round(sum(v["wall_clock_s"] for v in lv.values()), 1),
+                                       "reconstruction_units": sum(v["reconstruction_units"] for v in lv.values()),
+                                       "note": "8 timestep groups x 128 samples, 20000 iterations per unit, 1 GPU; each level's run repeats the weight "
+                                               "initialisation and the Finite-Set pass of the whole UNet"}
             mpath = os.path.join(ROOT, "profiles", "r02_cifar_calibration_full.json")
             if os.path.exists(mpath):       # the whole CIFAR recipe, measured once end to end with this code (scratch/cifar_cali_full.py)
                 mj = json.load(open(mpath))

@@ -79,6 +79,12 @@ int tfmq_scale_by_qdelta(tfmq_handle h, const float* ws, tfmq_qsel qs, float* ou
  * or per row ([rows] arrays, the per-output-channel weight quantizer, quant_layer.py:193-204) */
 int tfmq_fake_quant(tfmq_handle h, const float* x, float* y, uint8_t* idx_or_null, size_t rows, size_t cols,
                     const float* delta, const float* zp, int level, void* stream);
+/* Backward of the per-tensor fake quantisation through the straight-through round -- the delta-learning reconstruction mode
+ * (reference quant/quant_layer.py:211-227 under autograd; quant/reconstruction.py:135-166): gx (may be NULL) = g where the bin is
+ * inside [0, level-1], else 0; part[nparts] (double) = per-block partial sums of dL/ddelta = sum g * ((q - zp) - (x/delta)[in range]),
+ * to be added in index order by the caller (deterministic).  delta, zp: device scalars. */
+int tfmq_fake_quant_bwd(tfmq_handle h, const float* x, const float* g, float* gx, size_t n, const float* delta, const float* zp,
+                        int level, double* part, int nparts, void* stream);
 
 /* ---- K2: min/max statistics (minmax, quant_layer.py:20-35; act_momentum_update :229-244) */
 /* out[r] = {min, max} of row r ([rows][cols] fp32); rows=1 => whole tensor.

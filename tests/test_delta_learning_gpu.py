@@ -1,0 +1,243 @@
+"""Delta-learning reconstruction (`use_aq=True`; reference quant/reconstruction.py:36-48 layer, :135-166 block): Adam(lr) + cosine annealing on
+the activation deltas of a unit's QuantLayers through the straight-through round, weights fixed.  No driver requests it (cali_model never
+forwards `use_aq` to the reconstruction calls); fixture F22 was produced by calling the reference's functions directly on the tiny DDPM
+UNet of F8 after loading F8's checkpoint the drivers' way.  Same state, same host RNG stream -> same mini-batches here.
+
+Checked: the fake-quant backward kernel against torch autograd of the reference's formula; dL/ddelta of every quantizer of the
+ResnetBlock / AttnBlock / BasicTransformerBlock units against autograd on the same mathematics (2e-7 ... 3e-6 of the largest gradient);
+per unit of F22 (single layer, ResnetBlock with nin_shortcut, the first AttnBlock, LDM ResBlock, BasicTransformerBlock with its ten
+deltas) the delta TRAJECTORY over 30 full-set iterations and the reconstruction-loss curve against the reference's own run.  Adam on a
+scalar turns the sign of a near-zero gradient into a full step, so a unit whose captured input sits downstream of a rounding tie (the
+mid-block attention: its first proj_out step has the other sign, scratch/delta_attn_debug.py) walks another path; the fixture uses units
+whose inputs are reproduced to rounding."""
+import os
+import sys
+import tempfile
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tfmq-dm_amd"))
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def T(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def test_fake_quant_backward_kernel_vs_autograd():
+    import tfmq_dm_amd.ops as ops
+    gen = torch.Generator().manual_seed(3)
+    x = torch.randn(4, 33, 17, generator=gen) * 2.0
+    g = torch.randn(4, 33, 17, generator=gen)
+    for level, delta, zp in ((256, 0.021, 117.0), (16, 0.3, 5.0), (256, 0.004, 0.0)):
+        d = torch.tensor(delta, requires_grad=True)
+        xr = x.clone().requires_grad_(True)
+        u = xr / d
+        xq = torch.clamp(((u.round() - u).detach() + u) + zp, 0, level - 1)       # quant_layer.py:152-160,224
+        y = d * (xq - zp)
+        y.backward(g)
+        gx, gd = ops.fake_quant_bwd(x.to(DEV), g.to(DEV), torch.tensor([delta], device=DEV), torch.tensor([zp], device=DEV), level)
+        yk = ops.fake_quant(x.to(DEV), torch.tensor([delta], device=DEV), torch.tensor([zp], device=DEV), level)
+        assert torch.equal(yk.cpu(), y.detach())
+        # autograd forms g * delta / delta (two roundings); the kernel passes g through where the bin is in range
+        assert torch.equal(gx.cpu() == 0, xr.grad == 0) and torch.allclose(gx.cpu(), xr.grad, rtol=1e-6, atol=0.0)
+        assert abs(float(gd) - float(d.grad)) <= 1e-4 * max(1.0, abs(float(d.grad))), (float(gd), float(d.grad))
+    _, gd2 = ops.fake_quant_bwd(x.to(DEV), g.to(DEV), torch.tensor([0.021], device=DEV), torch.tensor([117.0], device=DEV), 256, want_gx=False)
+    assert _ is None and torch.isfinite(gd2).all()
+
+
+def _fq(x, d, zp, level=256):
+    """UniformAffineQuantizer.forward under autograd (reference quant/quant_layer.py:152-160,211-227)"""
+    u = x / d
+    return d * (torch.clamp(((u.round() - u).detach() + u) + zp, 0, level - 1) - zp)
+
+
+def _check(unit, n, loss, deltas, what):
+    rec, grads = unit._forward_backward(torch.arange(n, device=DEV))
+    assert abs(float(rec) - float(loss)) <= 2e-4 * abs(float(loss)), (what, float(rec), float(loss))
+    ref = torch.stack([d.grad for d in deltas])
+    mine = torch.cat([g.reshape(1).cpu() for g in grads])
+    err = float((mine - ref).abs().max() / ref.abs().max())
+    print(f"[{what}] dL/ddelta vs autograd: {mine.tolist()} vs {ref.tolist()}  (max error / max |grad| = {err:.1e})")
+    # the device forward and the CPU forward may put a handful of values that sit on a rounding boundary into neighbouring bins
+    assert err <= 2e-3, (what, err)
+
+
+def test_delta_units_gradients_vs_autograd():
+    """dL/ddelta of every quantizer of the ResnetBlock, AttnBlock and BasicTransformerBlock delta-learning units against torch autograd
+    through the reference's quantizer formula on the same mathematics."""
+    import torch.nn.functional as F
+    from tfmq_dm_amd.engine import recon as R
+    gen = torch.Generator().manual_seed(11)
+
+    def rnd(*s, scale=1.0):
+        return torch.randn(*s, generator=gen) * scale
+
+    def dl(vals):
+        return [torch.tensor(v, requires_grad=True) for v in vals]
+    kw = dict(iters=10, lr=1e-3)
+    # ---- ResnetBlock with nin_shortcut
+    B, H, W, C1, C2 = 3, 8, 8, 32, 64
+    x, y, proj = rnd(B, C1, H, W), rnd(B, C2, H, W), rnd(B, C2, scale=0.3)
+    W1, b1, W2, b2 = rnd(C2, C1, 3, 3, scale=0.06), rnd(C2, scale=0.1), rnd(C2, C2, 3, 3, scale=0.04), rnd(C2, scale=0.1)
+    Ws, bs = rnd(C2, C1, 1, 1, scale=0.2), rnd(C2, scale=0.1)
+    gn1, gn2 = (rnd(C1, scale=0.2) + 1, rnd(C1, scale=0.1)), (rnd(C2, scale=0.2) + 1, rnd(C2, scale=0.1))
+    d = dl([0.031, 0.027])
+    zps = [9.0, 11.0]
+    a1 = F.silu(F.group_norm(x, 32, gn1[0], gn1[1], 1e-6))
+    c1 = F.conv2d(_fq(a1, d[0], zps[0]), W1, b1, padding=1) + proj[:, :, None, None]
+    a2 = F.silu(F.group_norm(c1, 32, gn2[0], gn2[1], 1e-6))
+    out = F.conv2d(_fq(a2, d[1], zps[1]), W2, b2, padding=1) + F.conv2d(x, Ws, bs)
+    loss = ((out - y) ** 2).sum(1).mean()
+    loss.backward()
+    nhwc = lambda t: t.permute(0, 2, 3, 1).contiguous().to(DEV)
+    unit = R.DeltaResnetUnit(R.FixedLayer(W1.to(DEV), b1.to(DEV), 0), R.FixedLayer(W2.to(DEV), b2.to(DEV), 1), tuple(t.to(DEV) for t in gn1),
+                             tuple(t.to(DEV) for t in gn2), (Ws.reshape(C2, C1).to(DEV), bs.to(DEV)), nhwc(x), proj.to(DEV), nhwc(y),
+                             deltas=[t.detach().to(DEV) for t in d], zps=[torch.tensor(z) for z in zps], levels=[256, 256], **kw)
+    _check(unit, B, loss, d, "ResnetBlock")
+    # ---- AttnBlock
+    B, H, W, Cc = 3, 8, 8, 64
+    x, y = rnd(B, Cc, H, W), rnd(B, Cc, H, W)
+    Wq, Wk, Wv, Wp = (rnd(Cc, Cc, 1, 1, scale=0.12) for _ in range(4))
+    bq, bk, bv, bp = (rnd(Cc, scale=0.1) for _ in range(4))
+    gn = (rnd(Cc, scale=0.2) + 1, rnd(Cc, scale=0.1))
+    d = dl([0.03, 0.028, 0.033, 0.012])
+    zps = [120.0, 131.0, 127.0, 100.0]
+    hn = F.group_norm(x, 32, gn[0], gn[1], 1e-6)
+    q = F.conv2d(_fq(hn, d[0], zps[0]), Wq, bq).reshape(B, Cc, H * W).permute(0, 2, 1)
+    k = F.conv2d(_fq(hn, d[1], zps[1]), Wk, bk).reshape(B, Cc, H * W)
+    v = F.conv2d(_fq(hn, d[2], zps[2]), Wv, bv).reshape(B, Cc, H * W)
+    w_ = torch.softmax(torch.bmm(q, k) * (int(Cc) ** (-0.5)), dim=2)
+    h_ = torch.bmm(v, w_.permute(0, 2, 1)).reshape(B, Cc, H, W)
+    out = x + F.conv2d(_fq(h_, d[3], zps[3]), Wp, bp)
+    loss = ((out - y) ** 2).sum(1).mean()
+    loss.backward()
+    fl = [R.FixedLayer(w.to(DEV), b.to(DEV), i) for i, (w, b) in enumerate(((Wq, bq), (Wk, bk), (Wv, bv), (Wp, bp)))]
+    unit = R.DeltaAttnUnit(fl[0], fl[1], fl[2], fl[3], tuple(t.to(DEV) for t in gn), nhwc(x), nhwc(y),
+                           deltas=[t.detach().to(DEV) for t in d], zps=[torch.tensor(z) for z in zps], levels=[256] * 4, **kw)
+    _check(unit, B, loss, d, "AttnBlock")
+    # ---- BasicTransformerBlock
+    B, Tn, Cc, L, Dc, Hh, I = 3, 16, 32, 5, 24, 2, 128
+
+    def w(*s):
+        return rnd(*s, scale=1.0 / s[-1] ** 0.5)
+    Wq1, Wk1, Wv1, Wo1, Wf0, Wf2 = w(Cc, Cc), w(Cc, Cc), w(Cc, Cc), w(Cc, Cc), w(2 * I, Cc), w(Cc, I)
+    Wq2, Wk2, Wv2, Wo2 = w(Cc, Cc), w(Cc, Dc), w(Cc, Dc), w(Cc, Cc)
+    bo1, bf0, bf2, bo2 = (rnd(n, scale=0.1) for n in (Cc, 2 * I, Cc, Cc))
+    norms = [(rnd(Cc, scale=0.2) + 1, rnd(Cc, scale=0.1)) for _ in range(3)]
+    x, ctx, y = rnd(B, Tn, Cc), rnd(B, L, Dc), rnd(B, Tn, Cc)
+    d = dl([0.03, 0.027, 0.033, 0.011, 0.035, 0.02, 0.031, 0.029, 0.026, 0.009])
+    zps = [125.0, 128.0, 120.0, 118.0, 122.0, 9.0, 127.0, 126.0, 131.0, 124.0]
+
+    def attn(q, k, v):
+        dd = Cc // Hh
+        qh, kh, vh = (t.reshape(t.shape[0], t.shape[1], Hh, dd).permute(0, 2, 1, 3) for t in (q, k, v))
+        p = torch.softmax(qh @ kh.transpose(-1, -2) * dd ** -0.5, -1)
+        return (p @ vh).permute(0, 2, 1, 3).reshape(q.shape)
+    Q = lambda i, t: _fq(t, d[i], zps[i])
+    n1 = F.layer_norm(x, (Cc,), *norms[0], 1e-5)
+    x1 = Q(3, attn(Q(0, n1) @ Wq1.T, Q(1, n1) @ Wk1.T, Q(2, n1) @ Wv1.T)) @ Wo1.T + bo1 + x
+    n2 = F.layer_norm(x1, (Cc,), *norms[1], 1e-5)
+    x2 = Q(9, attn(Q(6, n2) @ Wq2.T, Q(7, ctx) @ Wk2.T, Q(8, ctx) @ Wv2.T)) @ Wo2.T + bo2 + x1
+    n3 = F.layer_norm(x2, (Cc,), *norms[2], 1e-5)
+    hc = Q(4, n3) @ Wf0.T + bf0
+    a, gate = hc.chunk(2, dim=-1)
+    out = Q(5, a * F.gelu(gate)) @ Wf2.T + bf2 + x2
+    loss = ((out - y) ** 2).sum(1).mean()
+    loss.backward()
+    ws = [Wq1, Wk1, Wv1, Wo1, Wf0, Wf2, Wq2, Wk2, Wv2, Wo2]
+    bs_ = [None, None, None, bo1, bf0, bf2, None, None, None, bo2]
+    fl = [R.FixedLayer(wt.to(DEV), None if bt is None else bt.to(DEV), i) for i, (wt, bt) in enumerate(zip(ws, bs_))]
+    unit = R.DeltaTransformerUnit(fl, [(g_.to(DEV), b_.to(DEV)) for g_, b_ in norms], Hh, x.to(DEV), ctx.to(DEV), y.to(DEV),
+                                  deltas=[t.detach().to(DEV) for t in d], zps=[torch.tensor(z) for z in zps], levels=[256] * 10, **kw)
+    _check(unit, B, loss, d, "BasicTransformerBlock")
+
+
+def _state(golden, ldm=False):
+    """QuantModel(cali=False) -> load_cali_model(F8's / F12's checkpoint) -> act_1: hard AdaRound weights + initialised activation quantizers"""
+    from test_calibration_gpu import build
+    from test_quant_mirror_ldm import tiny_qnn
+    from quant.calibration import load_cali_model
+    g8, g = golden("f12_ldm_cali_tiny" if ldm else "f8_cali_tiny"), golden("f22_delta_learning")
+    pre = "ldm/" if ldm else ""
+    ck = {"weight": {str(k): T(g8["ck/weight/" + str(k)]) for k in g8["weight_keys"]}}
+    akeys = [str(k) for k in g8["act_keys"]]
+    dk, zk = [k for k in akeys if k.endswith("delta")], [k for k in akeys if k.endswith("zero_point")]
+    for gi in range(3):
+        d, z = T(g8[f"ck/act_{gi}/delta"]), T(g8[f"ck/act_{gi}/zp"])
+        ck[f"act_{gi}"] = {**{k: d[i].clone() for i, k in enumerate(dk)}, **{k: z[i].clone() for i, k in enumerate(zk)}}
+    path = os.path.join(tempfile.mkdtemp(), "c.pth")
+    torch.save(ck, path)
+    qnn = tiny_qnn(g8, cali=False, device=DEV).to(DEV) if ldm else build(g8, cali=False)
+    init = (T(g[pre + "init_x"]), T(g[pre + "init_t"]).float()) + ((T(g[pre + "init_c"]),) if ldm else ())
+    load_cali_model(qnn, init, use_aq=True, path=path)
+    qnn.load_state_dict(ck["act_1"], strict=False)
+    return qnn, g8, g
+
+
+@pytest.mark.parametrize("kind,name,ldm", [("layer", "up.1.upsample.conv", False), ("block", "down.1.block.0", False), ("block", "down.1.attn.0", False),
+                                           ("block", "input_blocks.1.0", True), ("block", "input_blocks.1.1.transformer_blocks.0", True)])
+def test_delta_learning_matches_reference_run(golden, monkeypatch, kind, name, ldm):
+    import quant.reconstruction as REC
+    from quant.quant_layer import QuantLayer
+    from quant.reconstruction_util import RLOSS
+    monkeypatch.setenv("TFMQ_RECON_GEMM", "f32")
+    if os.environ.get("DELTA_TEST_EXACT", "1") == "1":
+        monkeypatch.setenv("TFMQ_EXACT_FP", "1")      # unit inputs captured with fp32 operands upstream, as the reference captures them
+    qnn, g8, g = _state(golden, ldm)
+    unit = dict(qnn.model.named_modules())[name]
+    fname = ("ldm/" if ldm else "") + name
+    names = [str(n) for n in g[f"{fname}/names"]]
+    mods = dict(qnn.model.named_modules())
+    before = torch.stack([mods[n].aqtizer.delta.detach().reshape(()).cpu() for n in names])
+    assert torch.equal(before, T(g[f"{fname}/before"]))                      # the same starting state as the reference's run
+    data = (T(g8["cali_x"]), T(g8["cali_t"])) + ((T(g8["cali_c"]),) if ldm else ())
+    iters = int(g["iters"])
+    trace = {"counts": tuple(range(1, iters + 1)), "rows": [], "unit": 0}
+    REC.LOSS_TRACE = trace
+    from tfmq_dm_amd.engine import recon as R
+    traj, orig_iterate = [], R._DeltaUnit.iterate
+
+    def rec_iterate(self, idx):
+        r = orig_iterate(self, idx)
+        traj.append(self.delta.detach().cpu().clone())
+        return r
+    monkeypatch.setattr(R._DeltaUnit, "iterate", rec_iterate)
+    torch.manual_seed(77)
+    np.random.seed(77)
+    try:
+        kw = dict(cali_data=data, batch_size=int(g["batch_size"]), iters=iters, w=0.01, opt_mode=RLOSS.MSE, asym=True, warmup=0.2,
+                  use_aq=True, lr=float(g["lr"]), multi_gpu=False)
+        (REC.layer_reconstruction if kind == "layer" else REC.block_reconstruction)(qnn, unit, **kw)
+    finally:
+        REC.LOSS_TRACE = None
+    after = torch.stack([mods[n].aqtizer.delta.detach().reshape(()).cpu() for n in names])
+    ref_after, ref_loss = T(g[f"{fname}/after"]), g[f"{fname}/loss"]
+    loss = np.array([r[2] for r in trace["rows"]])
+    moved = (ref_after - before).abs()
+    err = (after - ref_after).abs()
+    print(f"[{name}] deltas {before.tolist()} -> {after.tolist()} (reference {ref_after.tolist()}); loss {loss[0]:.5f} -> {loss[-1]:.5f} "
+          f"(reference {ref_loss[0]:.5f} -> {ref_loss[-1]:.5f}); worst loss deviation {np.max(np.abs(loss - ref_loss) / ref_loss):.2%}")
+    assert len(loss) == iters
+    # full-set batches: a deterministic gradient per iteration.  The loss curve agrees to the capture's precision, every delta that moved by
+    # more than a tenth of the unit's largest move went the reference's way and ended within 15 % of the distance it travelled, the
+    # rest (gradients that hover around zero: Adam on a scalar turns their sign into full steps) within 15 % of the largest move.
+    assert np.max(np.abs(loss - ref_loss) / ref_loss) <= 0.02
+    mine_tr, ref_tr = torch.stack(traj), T(g[f"{fname}/trajectory"])
+    assert mine_tr.shape == ref_tr.shape and torch.equal(mine_tr[-1], after)
+    travel = float(g["lr"]) * iters * 0.5                     # what Adam + cosine annealing can move a scalar in `iters` steps
+    dev_t = (mine_tr - ref_tr).abs().max(dim=1).values / travel
+    print(f"[{name}] trajectory deviation / possible travel, per iteration: " + " ".join(f"{float(v):.3f}" for v in dev_t))
+    # measured: <= 0.049 at every iteration of every unit, <= 0.009 at the end
+    assert float(dev_t.max()) <= 0.08, dev_t.tolist()
+    assert float(dev_t[-1]) <= 0.02, dev_t.tolist()
+    # only the unit's own deltas changed
+    others = [n for n, m in mods.items() if isinstance(m, QuantLayer) and m.aqtizer.delta is not None and n not in names]
+    ck1 = {str(k): v for k, v in zip([k for k in map(str, g8["act_keys"]) if k.endswith("delta")], T(g8["ck/act_1/delta"]))}
+    for n in others:
+        assert float(mods[n].aqtizer.delta) == float(ck1["model." + n + ".aqtizer.delta"]), n

@@ -69,6 +69,7 @@ _SIGS = {
     "tfmq_scale_by_qdelta": (c_int, [c_void_p, c_void_p, QSel, c_void_p, c_int, c_void_p]),
     "tfmq_quantize_act_h": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, QSel, c_int, c_void_p]),
     "tfmq_fake_quant": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_size_t, c_void_p, c_void_p, c_int, c_void_p]),
+    "tfmq_fake_quant_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p]),
     "tfmq_minmax_ws_bytes": (c_size_t, [c_size_t, c_size_t]),
     "tfmq_minmax": (c_int, [c_void_p, c_void_p, c_size_t, c_size_t, c_void_p, c_void_p, c_void_p]),
     "tfmq_minmax_to_qparam": (c_int, [c_void_p, c_void_p, c_size_t, c_int, c_int, c_void_p, c_void_p]),

@@ -175,6 +175,43 @@ extern "C" int tfmq_fake_quant(tfmq_handle h, const float* x, float* y, uint8_t*
   return TFMQ_OK;
 }
 
+// Backward of the per-tensor fake quantisation through the straight-through round (the delta-learning reconstruction mode,
+// reference quant/quant_layer.py:211-227 under autograd, quant/reconstruction.py:135-166):
+//   y = delta * (clamp(rint(x / delta) + zp, 0, L-1) - zp);  d round(u)/du := 1
+//   dL/dx     = g            where 0 <= rint(x/delta) + zp <= L-1, else 0
+//   dL/ddelta = sum g * ((q - zp) - (x / delta) [in range])
+// gx may be NULL.  part[gridDim.x]: per-block partial sums of dL/ddelta in double (the caller adds them in order: deterministic).
+__global__ __launch_bounds__(256) void k_fake_quant_bwd(const float* __restrict__ x, const float* __restrict__ g, float* __restrict__ gx,
+                                                        size_t n, const float* __restrict__ delta, const float* __restrict__ zp,
+                                                        float lmax, double* __restrict__ part) {
+  const float d = delta[0], z = zp[0];
+  const size_t stride = static_cast<size_t>(gridDim.x) * blockDim.x;
+  double acc = 0.0;
+  for (size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const float u = x[i] / d;
+    const float xi = rintf(u) + z;
+    const bool in = xi >= 0.0f && xi <= lmax;
+    const float q = fminf(fmaxf(xi, 0.0f), lmax);
+    const float gi = g[i];
+    if (gx) gx[i] = in ? gi : 0.0f;
+    acc += static_cast<double>(gi) * static_cast<double>((q - z) - (in ? u : 0.0f));
+  }
+  acc = wave_reduce_sum_d(acc);
+  __shared__ double sh[4];
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) part[blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+
+extern "C" int tfmq_fake_quant_bwd(tfmq_handle h, const float* x, const float* g, float* gx, size_t n, const float* delta,
+                                   const float* zp, int level, double* part, int nparts, void* stream) {
+  TFMQ_CHECK_ARG(h, h && x && g && delta && zp && part, "fake_quant_bwd: null pointer");
+  TFMQ_CHECK_ARG(h, level >= 2 && level <= 65536 && nparts >= 1 && nparts <= 4096, "fake_quant_bwd: level in [2,65536], 1..4096 partial sums");
+  hipLaunchKernelGGL(k_fake_quant_bwd, dim3(nparts), dim3(256), 0, as_stream(stream), x, g, gx, n, delta, zp, static_cast<float>(level - 1), part);
+  TFMQ_LAUNCH_CHECK(h);
+  return TFMQ_OK;
+}
+
 // ------------------------------------------------------------------------------ K2
 // grid = (bpr, rows): block (j, r) reduces a contiguous slice of row r.
 static inline int blocks_per_row(size_t rows, size_t cols, int cu) {

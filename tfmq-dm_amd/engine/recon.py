@@ -414,3 +414,260 @@ class TibUnit(_Unit):
         g_temb = ops.silu_bwd(temb, g_s1)
         grads[0] = ops.gemm(g_temb, s0, trans_a=True).reshape(d1.w.shape)
         return total, grads
+
+
+# ============================================================================================ delta learning (use_aq = True)
+class FixedLayer:
+    """A layer of a delta-learning unit: fixed (hard-rounded / fake-quantised) weights in the GEMM layout, bias, shape, and the index
+    of its activation quantizer in the unit's delta vector (None: the layer's input is not quantised -- `disable_aq`)."""
+
+    def __init__(self, w_hat: torch.Tensor, bias: Optional[torch.Tensor], qi: Optional[int]):
+        w_hat = w_hat.detach().float().contiguous()
+        self.cout, self.cin = w_hat.shape[0], w_hat.shape[1]
+        self.kh, self.kw = (w_hat.shape[2], w_hat.shape[3]) if w_hat.dim() == 4 else (1, 1)
+        self.wg = w_hat.reshape(self.cout, self.cin) if self.kh * self.kw == 1 else ops.w_relayout(w_hat, self.cout, self.cin, self.kh, self.kw, to_gemm=True)
+        self.bias = None if bias is None else bias.detach().float().contiguous()
+        self.qi = qi
+
+
+class _DeltaUnit:
+    """Reconstruction with `use_aq=True` (reference quant/reconstruction.py:36-48,135-166): the unit's weights are FIXED, the trainable
+    parameters are the scalar deltas of its activation quantizers; the quantizer is differentiated through the straight-through
+    round (quant_layer.py:152-160,211-227: d round(u)/du = 1, clamp passes gradients inside [0, L-1]); Adam(lr) with
+    CosineAnnealingLR(T_max=iters, eta_min=0); the loss is the reconstruction term alone (round_loss NONE).  Multi-GPU: the
+    reference SUMs `param.grad` over the ranks (not an average), so does this.
+
+    Sub-classes implement _forward_backward(idx) -> (rec loss tensor, [dL/ddelta_i (fp32 [1]) or None per quantizer])."""
+
+    def __init__(self, deltas: Sequence[torch.Tensor], zps: Sequence[torch.Tensor], levels: Sequence[int], iters: int, lr: float = 4e-5,
+                 world_size: int = 1, allreduce=None):
+        dev = deltas[0].device
+        self.delta = torch.stack([d.detach().reshape(()).float() for d in deltas]).to(dev).contiguous()      # [n], trained in place
+        self.zp = torch.stack([torch.as_tensor(z).detach().reshape(()).float().to(dev) for z in zps]).contiguous()
+        self.levels = [int(l) for l in levels]
+        self.iters, self.lr0 = int(iters), float(lr)
+        self.world_size, self.allreduce = world_size, allreduce
+        self.m, self.v = torch.zeros_like(self.delta), torch.zeros_like(self.delta)
+        self.count = 0
+        self._zero = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.gemm_mode = os.environ.get("TFMQ_RECON_GEMM", "bf16x3")
+
+    # quantizer i on a tensor (forward) / its backward
+    def q(self, i: int, x: torch.Tensor) -> torch.Tensor:
+        return ops.fake_quant(x.contiguous(), self.delta[i:i + 1], self.zp[i:i + 1], self.levels[i])
+
+    def q_bwd(self, i: int, x: torch.Tensor, g: torch.Tensor, want_gx: bool = True):
+        return ops.fake_quant_bwd(x.contiguous(), g.contiguous(), self.delta[i:i + 1], self.zp[i:i + 1], self.levels[i], want_gx)
+
+    def iterate(self, idx: torch.Tensor):
+        import math
+        self.count += 1
+        if self.gemm_mode != "f32":
+            with ops.gemm_precision(self.gemm_mode, self.delta.device.index):
+                rec, grads = self._forward_backward(idx)
+        else:
+            rec, grads = self._forward_backward(idx)
+        g = torch.cat([self._zero if gi is None else gi.reshape(1) for gi in grads]).contiguous()
+        if self.world_size > 1 and self.allreduce is not None:
+            self.allreduce(g)
+        t = self.count
+        lr_t = self.lr0 * 0.5 * (1.0 + math.cos(math.pi * (t - 1) / self.iters))       # CosineAnnealingLR, eta_min = 0, after t-1 steps
+        b1, b2, eps = 0.9, 0.999, 1e-8
+        self.m.mul_(b1).add_(g, alpha=1.0 - b1)
+        self.v.mul_(b2).addcmul_(g, g, value=1.0 - b2)
+        denom = (self.v.sqrt() / math.sqrt(1.0 - b2 ** t)).add_(eps)
+        self.delta.addcdiv_(self.m, denom, value=-lr_t / (1.0 - b1 ** t))
+        return rec, self._zero
+
+    def losses(self, rec, rl):
+        r = float(rec)
+        return r, r, 0.0
+
+
+def _fixed_conv_fwd(x, L: FixedLayer, pad, rowadd=None, residual=None):
+    B, H, W, _ = x.shape
+    col = x.reshape(B * H * W, L.cin) if L.kh * L.kw == 1 else ops.im2col(x, L.kh, L.kw, 1, pad)
+    y = ops.gemm(col, L.wg, trans_b=True, bias=L.bias, rowadd=rowadd, rows_per_img=H * W,
+                 residual=None if residual is None else residual.reshape(B * H * W, -1))
+    return y.reshape(B, H, W, L.cout)
+
+
+def _fixed_conv_bwd_input(g, L: FixedLayer, shape, pad):
+    """dL/d(input) of a fixed conv / linear: g [B,H,W,cout] -> [B,H,W,cin]"""
+    B, H, W, _ = shape
+    dcol = ops.gemm(g.reshape(B * H * W, L.cout), L.wg)
+    return dcol.reshape(B, H, W, L.cin) if L.kh * L.kw == 1 else ops.col2im(dcol, (B, H, W, L.cin), L.kh, L.kw, 1, pad)
+
+
+class DeltaLayerUnit(_DeltaUnit):
+    """layer_reconstruction(use_aq=True) (reference :36-48): one delta."""
+
+    def __init__(self, layer: FixedLayer, x, y, pad=(1, 1, 1, 1), **kw):
+        super().__init__(**kw)
+        self.layer, self.x, self.y, self.pad = layer, x, y, pad
+
+    def _forward_backward(self, idx):
+        L = self.layer
+        x, y = self.x.index_select(0, idx), self.y.index_select(0, idx)
+        xq = self.q(L.qi, x) if L.qi is not None else x
+        out = _fixed_conv_fwd(xq, L, self.pad)
+        loss, g = ops.recon_loss(out, y, denom=out.numel() // out.shape[-1])
+        if L.qi is None:
+            return loss, []
+        g_xq = _fixed_conv_bwd_input(g, L, x.shape, self.pad)
+        _, gd = self.q_bwd(L.qi, x, g_xq, want_gx=False)
+        return loss, [gd]
+
+
+class DeltaResnetUnit(_DeltaUnit):
+    """QuantResnetBlock / QuantResBlock under use_aq=True: the deltas of conv1 and conv2 (temb_proj / emb_layers.1 is `quant_emb`: its
+    input IS quantised in the forward -- the caller passes the projection computed that way -- but its delta is not trained)."""
+
+    def __init__(self, conv1: FixedLayer, conv2: FixedLayer, gn1, gn2, shortcut, x, proj, y, eps: float = 1e-6, **kw):
+        super().__init__(**kw)
+        self.c1, self.c2, self.gn1, self.gn2, self.shortcut, self.eps = conv1, conv2, gn1, gn2, shortcut, eps
+        self.x, self.proj, self.y = x, proj, y
+
+    def _forward_backward(self, idx):
+        c1l, c2l = self.c1, self.c2
+        x, proj, y = self.x.index_select(0, idx), self.proj.index_select(0, idx), self.y.index_select(0, idx)
+        B, H, W, cin = x.shape
+        _, a1, _ = ops.groupnorm(x, self.gn1[0], self.gn1[1], self.eps, True, want_f32=True)
+        a1q = self.q(c1l.qi, a1) if c1l.qi is not None else a1
+        c1 = _fixed_conv_fwd(a1q, c1l, (1, 1, 1, 1), rowadd=proj)
+        _, a2, _ = ops.groupnorm(c1, self.gn2[0], self.gn2[1], self.eps, True, want_f32=True)
+        a2q = self.q(c2l.qi, a2) if c2l.qi is not None else a2
+        if self.shortcut is not None:
+            sc = ops.gemm(x.reshape(B * H * W, cin), self.shortcut[0], trans_b=True, bias=self.shortcut[1]).reshape(B, H, W, -1)
+        else:
+            sc = x
+        out = _fixed_conv_fwd(a2q, c2l, (1, 1, 1, 1), residual=sc)
+        loss, g = ops.recon_loss(out, y, denom=B * H * W)
+        grads = [None] * self.delta.numel()
+        g_a2q = _fixed_conv_bwd_input(g, c2l, a2.shape, (1, 1, 1, 1))
+        if c2l.qi is not None:
+            g_a2, grads[c2l.qi] = self.q_bwd(c2l.qi, a2, g_a2q)
+        else:
+            g_a2 = g_a2q
+        if c1l.qi is not None:
+            g_c1 = ops.groupnorm_bwd(c1, g_a2, self.gn2[0], self.gn2[1], self.eps, True)
+            g_a1q = _fixed_conv_bwd_input(g_c1, c1l, a1.shape, (1, 1, 1, 1))
+            _, grads[c1l.qi] = self.q_bwd(c1l.qi, a1, g_a1q, want_gx=False)
+        return loss, grads
+
+
+class DeltaAttnUnit(_DeltaUnit):
+    """QuantAttnBlock under use_aq=True with the attention-matmul quantizers off (the state every driver leaves them in): the deltas
+    of q, k, v (three quantizers on the same normalised input) and proj_out."""
+
+    def __init__(self, q: FixedLayer, k: FixedLayer, v: FixedLayer, po: FixedLayer, gn, x, y, **kw):
+        super().__init__(**kw)
+        self.ls, self.gn, self.x, self.y = (q, k, v, po), gn, x, y
+
+    def _forward_backward(self, idx):
+        ql, kl, vl, pl = self.ls
+        x, y = self.x.index_select(0, idx), self.y.index_select(0, idx)
+        B, H, W, Cc = x.shape
+        T = H * W
+        scale = float(int(Cc) ** (-0.5))
+        _, hn, _ = ops.groupnorm(x, self.gn[0], self.gn[1], 1e-6, False, want_f32=True)
+        hf = hn.reshape(B * T, Cc)
+
+        def lin(L, inp):
+            return ops.gemm(self.q(L.qi, inp) if L.qi is not None else inp, L.wg, trans_b=True, bias=L.bias)
+        q, k, v = (lin(L, hf).reshape(B, T, Cc) for L in (ql, kl, vl))
+        S = ops.gemm(q, k, trans_b=True)
+        P = ops.softmax_rows(S, scale)
+        o = ops.gemm(P, v).reshape(B * T, Cc)
+        oq = self.q(pl.qi, o) if pl.qi is not None else o
+        out = ops.gemm(oq, pl.wg, trans_b=True, bias=pl.bias, residual=x.reshape(B * T, Cc)).reshape(B, H, W, Cc)
+        loss, g = ops.recon_loss(out, y, denom=B * T)
+        grads = [None] * self.delta.numel()
+        g_oq = ops.gemm(g.reshape(B * T, Cc), pl.wg)
+        if pl.qi is not None:
+            g_o, grads[pl.qi] = self.q_bwd(pl.qi, o, g_oq)
+        else:
+            g_o = g_oq
+        g_o = g_o.reshape(B, T, Cc)
+        dV = ops.gemm(P, g_o, trans_a=True)
+        dP = ops.gemm(g_o, v, trans_b=True)
+        dS = ops.softmax_bwd_rows(P, dP, scale)
+        dQ = ops.gemm(dS, k)
+        dK = ops.gemm(dS, q, trans_a=True)
+        for L, dd in ((ql, dQ), (kl, dK), (vl, dV)):
+            if L.qi is not None:
+                g_in = ops.gemm(dd.reshape(B * T, Cc), L.wg)           # dL/d(quantised input of this projection)
+                _, grads[L.qi] = self.q_bwd(L.qi, hf, g_in, want_gx=False)
+        return loss, grads
+
+
+class DeltaTransformerUnit(_DeltaUnit):
+    """QuantBasicTransformerBlock under use_aq=True with the attention-matmul quantizers off: the deltas of its ten QuantLayers
+    (module order: attn1.{to_q,to_k,to_v,to_out.0}, ff.net.0.proj, ff.net.2, attn2.{to_q,to_k,to_v,to_out.0}); same dataflow and
+    fused exact-fp32 attention as TransformerUnit, gradients taken w.r.t. the layers' (quantised) inputs instead of their weights."""
+
+    _attn_fwd = TransformerUnit._attn_fwd
+    _attn_bwd = TransformerUnit._attn_bwd
+    use_flash = True
+
+    def __init__(self, layers: Sequence[FixedLayer], norms, heads: int, x, ctx, y, **kw):
+        super().__init__(**kw)
+        assert len(layers) == 10
+        self.ls, self.norms, self.heads = list(layers), norms, heads
+        self.x, self.ctx, self.y = x, ctx, y
+
+    def _forward_backward(self, idx):
+        (q1l, k1l, v1l, o1l, f0l, f2l, q2l, k2l, v2l, o2l) = self.ls
+        x, ctx, y = self.x.index_select(0, idx), self.ctx.index_select(0, idx), self.y.index_select(0, idx)
+        B, T, Cc = x.shape
+        L, Dc = ctx.shape[1], ctx.shape[2]
+        (g1, b1), (g2, b2), (g3, b3) = self.norms
+        grads = [None] * self.delta.numel()
+
+        def lin(Ly, inp, residual=None):
+            return ops.gemm(self.q(Ly.qi, inp) if Ly.qi is not None else inp, Ly.wg, trans_b=True, bias=Ly.bias, residual=residual)
+
+        def back(Ly, inp, g, want_gx=True):
+            """g = dL/d(layer output) -> dL/d(layer input before its quantizer); records the layer's delta gradient"""
+            g_in = ops.gemm(g, Ly.wg)
+            if Ly.qi is None:
+                return g_in
+            gx, grads[Ly.qi] = self.q_bwd(Ly.qi, inp, g_in, want_gx)
+            return gx
+        x2d, c2d = x.reshape(B * T, Cc), ctx.reshape(B * L, Dc).contiguous()
+        # ---- forward
+        n1 = ops.layernorm(x, g1, b1, 1e-5, None)[1].reshape(B * T, Cc)
+        q1, k1, v1 = (lin(Ly, n1).reshape(B, T, Cc) for Ly in (q1l, k1l, v1l))
+        o1, P1 = self._attn_fwd(q1, k1, v1)
+        o1 = o1.reshape(B * T, Cc)
+        x1 = lin(o1l, o1, residual=x2d)
+        n2 = ops.layernorm(x1.reshape(B, T, Cc), g2, b2, 1e-5, None)[1].reshape(B * T, Cc)
+        q2 = lin(q2l, n2).reshape(B, T, Cc)
+        k2, v2 = lin(k2l, c2d).reshape(B, L, Cc), lin(v2l, c2d).reshape(B, L, Cc)
+        o2, P2 = self._attn_fwd(q2, k2, v2)
+        o2 = o2.reshape(B * T, Cc)
+        x2 = lin(o2l, o2, residual=x1)
+        n3 = ops.layernorm(x2.reshape(B, T, Cc), g3, b3, 1e-5, None)[1].reshape(B * T, Cc)
+        hcat = lin(f0l, n3)
+        gg = ops.geglu(hcat, None)[1]
+        out = lin(f2l, gg, residual=x2)
+        loss, g = ops.recon_loss(out.reshape(B, T, Cc), y, denom=B * Cc)
+        # ---- backward to the quantizer inputs
+        g_out = g.reshape(B * T, Cc)
+        d_gg = back(f2l, gg, g_out)
+        d_hcat = ops.geglu_bwd(hcat, d_gg)
+        d_n3 = back(f0l, n3, d_hcat)
+        d_x2 = ops.layernorm_bwd(x2.reshape(B, T, Cc), d_n3.reshape(B, T, Cc), g3, 1e-5).reshape(B * T, Cc)
+        ops.axpy(d_x2, g_out, 1.0)
+        g_o2 = back(o2l, o2, d_x2).reshape(B, T, Cc)
+        dQ2, dK2, dV2 = self._attn_bwd(g_o2, q2, k2, v2, P2)
+        d_n2 = back(q2l, n2, dQ2.reshape(B * T, Cc))
+        back(k2l, c2d, dK2.reshape(B * L, Cc), want_gx=False)
+        back(v2l, c2d, dV2.reshape(B * L, Cc), want_gx=False)
+        d_x1 = ops.layernorm_bwd(x1.reshape(B, T, Cc), d_n2.reshape(B, T, Cc), g2, 1e-5).reshape(B * T, Cc)
+        ops.axpy(d_x1, d_x2, 1.0)
+        g_o1 = back(o1l, o1, d_x1).reshape(B, T, Cc)
+        dQ1, dK1, dV1 = self._attn_bwd(g_o1, q1, k1, v1, P1)
+        for Ly, dd in ((q1l, dQ1), (k1l, dK1), (v1l, dV1)):
+            back(Ly, n1, dd.reshape(B * T, Cc), want_gx=False)
+        return loss, grads

@@ -248,6 +248,21 @@ def fake_quant(x: torch.Tensor, delta: torch.Tensor, zp: torch.Tensor, level: in
     return (y, idx) if want_idx else y
 
 
+def fake_quant_bwd(x: torch.Tensor, g: torch.Tensor, delta: torch.Tensor, zp: torch.Tensor, level: int, want_gx: bool = True):
+    """Backward of per-tensor fake_quant through the straight-through round (tfmq_fake_quant_bwd): -> (dL/dx | None, dL/ddelta [1] fp32)."""
+    d = _dev(x)
+    _chk(x, torch.float32, "x")
+    _chk(g, torch.float32, "g")
+    if g.numel() != x.numel() or delta.numel() != 1 or zp.numel() != 1:
+        raise TfmqError("fake_quant_bwd: g like x, scalar delta / zero point")
+    gx = _alloc_like(x) if want_gx else None
+    nparts = max(1, min(1024, (x.numel() + 4095) // 4096))
+    part = _alloc(nparts, dtype=torch.float64, device=x.device)
+    handle(d).call("fake_quant_bwd", _p(x), _p(g), _p(gx), x.numel(), _p(delta.reshape(1).float().contiguous()), _p(zp.reshape(1).float().contiguous()),
+                   int(level), _p(part), nparts, _stream(d))
+    return gx, part.sum().float().reshape(1)
+
+
 def minmax(x: torch.Tensor, rows: int = 1) -> torch.Tensor:
     """-> float32 [rows, 2] = {min, max} per row of x viewed as [rows, -1]."""
     d = _dev(x)

@@ -57,6 +57,57 @@ def _commit(layer: QuantLayer, ada: R.AdaLayer):
     q._version_ += 1
 
 
+def _hard_weight(layer: QuantLayer) -> torch.Tensor:
+    """The layer's weight as its CURRENT weight quantizer produces it (hard AdaRound or nearest), fp32, the module's layout."""
+    d, z, a = layer.weight_quant_state()
+    w = layer.w.data.float().contiguous()
+    if a is not None:
+        return ops.adaround_soft_fwd(w, a.float().contiguous(), d, z, layer.wqtizer.level, hard=True)
+    return ops.fake_quant(w, d.reshape(-1), z.reshape(-1), layer.wqtizer.level)
+
+
+class _DeltaSet:
+    """The trainable activation deltas of a unit under use_aq=True (reference reconstruction.py:36-48,135-166): every QuantLayer that
+    is not `quant_emb`, quantises its input (use_aq and not disable_aq) and has an initialised, non-zero delta."""
+
+    def __init__(self):
+        self.layers, self.deltas, self.zps, self.levels = [], [], [], []
+
+    def fixed(self, layer: QuantLayer) -> R.FixedLayer:
+        q, qi = layer.aqtizer, None
+        if layer.use_aq and not layer.disable_aq:
+            if q.delta is None:
+                raise TfmqError("delta-learning reconstruction: run a forward with use_aq=True first (an activation quantizer of the unit is uninitialised)")
+            if not layer.quant_emb and bool(q.delta != 0):
+                qi = len(self.layers)
+                self.layers.append(layer)
+                self.deltas.append(q.delta.data)
+                zp = q.zero_point
+                self.zps.append(zp.detach() if torch.is_tensor(zp) else torch.tensor(float(zp), device=q.delta.device))
+                self.levels.append(q.level)
+        return R.FixedLayer(_hard_weight(layer), None if layer.b is None else layer.b.data, qi)
+
+    def kw(self, iters, lr, multi_gpu):
+        return dict(deltas=self.deltas, zps=self.zps, levels=self.levels, iters=iters, lr=lr, **_dist_kw(multi_gpu))
+
+    def commit(self, unit: R._DeltaUnit):
+        for i, layer in enumerate(self.layers):
+            layer.aqtizer.delta.data.copy_(unit.delta[i].reshape(layer.aqtizer.delta.shape))
+
+
+def _quant_emb_projection(layer: QuantLayer, emb: torch.Tensor) -> torch.Tensor:
+    """temb_proj / emb_layers.1 of a ResBlock under the block's quant state, input silu(emb) (its own activation quantizer applied when
+    live -- the layer is `quant_emb`, so its delta is used but never trained here)."""
+    s_ = ops.silu(emb.float().contiguous())
+    q = layer.aqtizer
+    if layer.use_aq and not layer.disable_aq and q.delta is not None:
+        zp = q.zero_point
+        zp = zp.detach() if torch.is_tensor(zp) else torch.tensor(float(zp), device=emb.device)
+        s_ = ops.fake_quant(s_, q.delta.data.reshape(1), zp.reshape(1), q.level)
+    w = _hard_weight(layer).reshape(layer.w.shape[0], -1).contiguous()
+    return ops.gemm(s_, w, trans_b=True, bias=None if layer.b is None else layer.b.data.float().contiguous())
+
+
 LOSS_TRACE = None     # tests: {"counts": (...), "rows": [], "unit": 0} -> rows of (unit index, count, rec, round) at those counts
 
 
@@ -80,10 +131,25 @@ def layer_reconstruction(model, layer: QuantLayer, cali_data: Tuple[torch.Tensor
                          include_act_func: bool = True, b_range: tuple = (20, 2), warmup: float = 0.0,
                          use_aq: bool = False, lr: float = 4e-5, p: float = 2.0, multi_gpu: bool = False,
                          keep_gpu=True) -> None:
-    if use_aq:
-        raise NotImplementedError("delta-learning reconstruction (use_aq=True) is never requested by the drivers (SURVEY §8f-3)")
     model.set_quant_state(use_wq=False, use_aq=False)
     layer.set_quant_state(use_wq=True, use_aq=use_aq)
+    if use_aq:
+        # delta learning (reference :36-48): the layer's activation delta under Adam(lr) + cosine annealing, weights fixed
+        if opt_mode != RLOSS.MSE:
+            raise NotImplementedError("Fisher-weighted reconstruction losses are not built (DESIGN.md section 7)")
+        ds = _DeltaSet()
+        fl = ds.fixed(layer)
+        loss_func = LossFunc(o=layer, round_loss=RLOSS.NONE, w=w, max_count=iters, rec_loss=opt_mode, b_range=b_range,
+                             decay_start=0.0, warmup=warmup, p=p)
+        cached_inputs, cached_outputs = save_inout(model, layer, cali_data, asym, use_aq, batch_size, keep_gpu)
+        if not ds.layers:
+            return                      # `disable_aq` layer: the reference's optimiser has an un-used parameter and nothing moves
+        ph, pw = layer.fwd_kwargs.get("padding", (0, 0))
+        unit = R.DeltaLayerUnit(fl, cached_inputs[0], cached_outputs, pad=(ph, pw, ph, pw), **ds.kw(iters, lr, multi_gpu))
+        _run(unit, cached_inputs[0].size(0), batch_size, iters, loss_func, cached_outputs.device)
+        ds.commit(unit)
+        model.invalidate()
+        return
     ada = _ada_layer(layer)
     loss_func = LossFunc(o=layer, round_loss=RLOSS.RELAXATION, w=w, max_count=iters, rec_loss=opt_mode, b_range=b_range,
                          decay_start=0.0, warmup=warmup, p=p)
@@ -101,10 +167,10 @@ def block_reconstruction(model, block: BaseQuantBlock, cali_data: torch.Tensor, 
                          include_act_func: bool = True, b_range: tuple = (20, 2), warmup: float = 0.0,
                          use_aq: bool = False, lr: float = 4e-5, p: float = 2.0, multi_gpu: bool = True,
                          keep_gpu=True) -> None:
-    if use_aq:
-        raise NotImplementedError("delta-learning reconstruction (use_aq=True) is never requested by the drivers (SURVEY §8f-3)")
     model.set_quant_state(use_wq=False, use_aq=False)
     block.set_quant_state(use_wq=True, use_aq=use_aq)
+    if use_aq:
+        return _block_delta_learning(model, block, cali_data, batch_size, iters, w, opt_mode, asym, b_range, warmup, lr, p, multi_gpu, keep_gpu)
     if not any(isinstance(m, QuantLayer) and not m.quant_emb for m in block.modules()):
         return      # QuantAttentionBlock / QuantQKMatMul / QuantSMVMatMul: nothing to optimise (reference :130-131)
     loss_func = LossFunc(o=block, round_loss=RLOSS.RELAXATION, w=w, max_count=iters, rec_loss=opt_mode, b_range=b_range,
@@ -166,6 +232,58 @@ def block_reconstruction(model, block: BaseQuantBlock, cali_data: torch.Tensor, 
     _run(unit, cached_inputs[0].size(0), batch_size, iters, loss_func, dev)
     for layer, ada in layers:
         _commit(layer, ada)
+    model.invalidate()
+
+
+def _block_delta_learning(model, block, cali_data, batch_size, iters, w, opt_mode, asym, b_range, warmup, lr, p, multi_gpu, keep_gpu):
+    """block_reconstruction(use_aq=True) (reference :135-166): Adam(lr) + CosineAnnealingLR on the activation deltas of the block's
+    QuantLayers, weights fixed.  Built for QuantResnetBlock, QuantResBlock, QuantAttnBlock, QuantBasicTransformerBlock
+    with the attention-matmul quantizers off (the state every driver leaves them in); live attention quantizers raise NotImplementedError
+    (DESIGN.md section 7)."""
+    if opt_mode != RLOSS.MSE:
+        raise NotImplementedError("Fisher-weighted reconstruction losses are not built (DESIGN.md section 7)")
+    if getattr(block, "use_aq", False) or any(getattr(m, "delta", None) is not None for n, m in block.named_modules()
+                                                    if n.split(".")[-1] in ("aqtizer_q", "aqtizer_k", "aqtizer_v", "aqtizer_w")):
+        raise NotImplementedError("delta learning with live attention-matmul quantizers is not built (DESIGN.md section 7)")
+    loss_func = LossFunc(o=block, round_loss=RLOSS.NONE, w=w, max_count=iters, rec_loss=opt_mode, b_range=b_range,
+                         decay_start=0.0, warmup=warmup, p=p)
+    dev = next(block.parameters()).device
+    ds = _DeltaSet()
+    if isinstance(block, (QuantResnetBlock, QuantResBlock)):
+        ddpm = isinstance(block, QuantResnetBlock)
+        conv1, conv2 = (block.conv1, block.conv2) if ddpm else (block.in_layers[2], block.out_layers[3])
+        f1, f2 = ds.fixed(conv1), ds.fixed(conv2)
+        cached_inputs, cached_outputs = save_inout(model, block, cali_data, asym, True, batch_size, keep_gpu)
+        x, emb = cached_inputs
+        proj = _quant_emb_projection(block.temb_proj if ddpm else block.emb_layers[1], emb)
+        ns = getattr(block, "nin_shortcut", None) if ddpm else (block.skip_connection if isinstance(block.skip_connection, torch.nn.Conv2d) else None)
+        sc = None if ns is None else (ns.weight.data.reshape(ns.weight.shape[0], -1).float().contiguous(), ns.bias.data.float().contiguous())
+        n1, n2 = (block.norm1, block.norm2) if ddpm else (block.in_layers[0], block.out_layers[0])
+        if not ds.layers:
+            return
+        unit = R.DeltaResnetUnit(f1, f2, (n1.weight.data.float(), n1.bias.data.float()), (n2.weight.data.float(), n2.bias.data.float()),
+                                 sc, x, proj, cached_outputs, eps=n1.eps, **ds.kw(iters, lr, multi_gpu))
+    elif isinstance(block, QuantAttnBlock):
+        fl = [ds.fixed(getattr(block, n)) for n in ("q", "k", "v", "proj_out")]
+        cached_inputs, cached_outputs = save_inout(model, block, cali_data, asym, True, batch_size, keep_gpu)
+        if not ds.layers:
+            return
+        unit = R.DeltaAttnUnit(fl[0], fl[1], fl[2], fl[3], (block.norm.weight.data.float(), block.norm.bias.data.float()),
+                               cached_inputs[0], cached_outputs, **ds.kw(iters, lr, multi_gpu))
+    elif isinstance(block, QuantBasicTransformerBlock):
+        mods = [block.attn1.to_q, block.attn1.to_k, block.attn1.to_v, block.attn1.to_out[0], block.ff.net[0].proj,
+                block.ff.net[2], block.attn2.to_q, block.attn2.to_k, block.attn2.to_v, block.attn2.to_out[0]]
+        fl = [ds.fixed(m) for m in mods]
+        cached_inputs, cached_outputs = save_inout(model, block, cali_data, asym, True, batch_size, keep_gpu)
+        if not ds.layers:
+            return
+        x, ctx = cached_inputs
+        norms = [(n.weight.data.float().contiguous(), n.bias.data.float().contiguous()) for n in (block.norm1, block.norm2, block.norm3)]
+        unit = R.DeltaTransformerUnit(fl, norms, block.attn1.heads, x, ctx, cached_outputs, **ds.kw(iters, lr, multi_gpu))
+    else:
+        raise NotImplementedError(f"delta-learning reconstruction of {type(block).__name__} is not built (DESIGN.md section 7)")
+    _run(unit, cached_inputs[0].size(0), batch_size, iters, loss_func, dev)
+    ds.commit(unit)
     model.invalidate()
 
 
