@@ -1,6 +1,9 @@
 """Reconstruction units (hand-written fwd/bwd + fused AdaRound/Adam on the device) vs the CPU oracle
 running the reference's algorithm with torch autograd + torch.optim.Adam (quant/reconstruction.py).
-Tolerances: losses 1e-4 relative, alpha 1e-4 absolute after 6 iterations, masks >= 99.9 %."""
+Tolerances: losses 1e-4 relative, alpha 1e-4 absolute after 6 iterations, masks >= 99.9 %, with the units' GEMMs on exact fp32
+operands (TFMQ_RECON_GEMM=f32); with the default bf16x3 split operands (2^-16 per product) the losses keep their bar and alpha gets
+5e-4: Adam normalises every element's step to <= lr = 1e-3 whatever the gradient's size, so an element whose gradient is of the size
+of the operand noise moves by a different fraction of lr (measured: 2.0e-4 on one element of test_layer_unit)."""
 import numpy as np
 import pytest
 import torch
@@ -10,6 +13,15 @@ import tfmq_oracle as O
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
+ALPHA_TOL = {"f32": 1e-4, "bf16x3": 5e-4}
+_MODE = ["bf16x3"]
+
+
+@pytest.fixture(autouse=True, params=["f32", "bf16x3"])
+def gemm_mode(request, monkeypatch):
+    monkeypatch.setenv("TFMQ_RECON_GEMM", request.param)
+    _MODE[0] = request.param
+    return request.param
 
 
 def nhwc(x):
@@ -65,7 +77,7 @@ def check(unit, dev_layers, ref_alphas, ref_hist, idxs):
         assert abs(tot - ref_hist[it]) <= 1e-4 * abs(ref_hist[it]) + 1e-7, (it, tot, ref_hist[it])
     for L, ra in zip(dev_layers, ref_alphas):
         a = L.alpha.cpu()
-        assert float((a - ra).abs().max()) <= 1e-4
+        assert float((a - ra).abs().max()) <= ALPHA_TOL[_MODE[0]], _MODE[0]
         assert float(((a >= 0) == (ra >= 0)).float().mean()) >= 0.999
 
 
@@ -176,4 +188,4 @@ def test_flat_allreduce_path_matches_single_rank_emulation(R):
     tot = 2 * (O.lp_loss(out, y) + O.round_loss([alpha], O.temp_decay(1, 2, 0.0), 0.01))
     tot.backward()
     opt.step()
-    assert float((a.alpha.cpu() - alpha.detach()).abs().max()) <= 1e-4
+    assert float((a.alpha.cpu() - alpha.detach()).abs().max()) <= ALPHA_TOL[_MODE[0]]
