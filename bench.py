@@ -200,8 +200,33 @@ def setup_sd(args, dev, rank, log, preset="sd"):
     def fwd():
         if CTX is None:
             eng.forward(sampler.x, None)
+        elif sampler.pair_prefix:
+            eng.forward(sampler.x, None, sampler.ctx2, pair_prefix=True)
         else:
             eng.forward(sampler.x2, None, sampler.ctx2)
+
+    def materialised():
+        """The same sampling with the guidance pair materialised as a 2B batch in front of the UNet (TFMQ_PAIR_PREFIX=0: the two
+        members' shared prefix -- conv_in ... first self attention -- computed twice, as the reference's cat([x] * 2) does); the
+        metric's run computes it once per pair, bit-identical output (tests/test_engine_ldm_gpu.py)."""
+        old = os.environ.get("TFMQ_PAIR_PREFIX")
+        os.environ["TFMQ_PAIR_PREFIX"] = "0"
+        try:
+            ms = GraphLatentDdimSampler(eng, S, batch, LAT, CTX, scale=scale, alphas_cumprod=alphas_cumprod_linear()).capture()
+        finally:
+            if old is None:
+                del os.environ["TFMQ_PAIR_PREFIX"]
+            else:
+                os.environ["TFMQ_PAIR_PREFIX"] = old
+        ms.sample_nhwc(x_T, cond, uncond)
+        ms.stream.synchronize()
+        t0 = time.perf_counter()
+        out = ms.sample_nhwc(x_T, cond, uncond)
+        ms.stream.synchronize()
+        dt = time.perf_counter() - t0
+        same = bool(torch.equal(out, sampler.x)) if sampler.gid is not None else None
+        return {"images_per_s": round(batch / dt, 3), "final_latents_equal_to_the_metric_run": same,
+                "note": "guidance pair materialised as a 2B batch (TFMQ_PAIR_PREFIX=0); the metric's run shares the pair's common prefix"}
 
     def cpu():
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -267,13 +292,15 @@ def setup_sd(args, dev, rank, log, preset="sd"):
         return out
 
     info = dict(batch=batch, sync=sampler.stream.synchronize, finite=lambda: bool(torch.isfinite(sampler.x).all().item()),
-                stream=sampler.stream, step=eng.step, plms=plms, sweep=sweep,
+                stream=sampler.stream, step=eng.step, plms=plms, sweep=sweep, materialised=materialised if CTX is not None and sampler.pair_prefix else None,
                 oracle_state=dict(sd=sd, wq=wq, act_names=act_names, cfg=cfg, eng=eng),     # scratch/sd_parity_full.py
                 workload=(f"{P['name']} ({n_params:.1f}M) w4a8 on MI355X: {LH}x{LW}x{LC} latents, DDIM-{S} eta=0, "
                           + (f"CFG {scale} (UNet batch 2x{batch}), {CTX[0]}x{CTX[1]} context, " if CTX is not None else "unconditional, ")
                           + f"{batch} images per GPU ({P['tail']})"),
                 preset=preset,
-                extra={"batch_per_gpu": batch, "ddim_steps": S, "unet_evals_per_step": S, "unet_batch": NB, "guidance_scale": scale})
+                extra={"batch_per_gpu": batch, "ddim_steps": S, "unet_evals_per_step": S, "unet_batch": NB, "guidance_scale": scale,
+                       "guidance_pair": ("shared prefix computed once per pair (conv_in ... first self attention; bit-identical to the materialised 2B batch)"
+                                         if (CTX is not None and sampler.pair_prefix) else ("materialised 2B batch" if CTX is not None else None))})
     return run, fwd, cpu, info
 
 
@@ -803,6 +830,8 @@ def main():
             "data": "synthetic: N(0,1) latents / context, random-init weights (zero params re-drawn N(0,0.02^2)), synthetic FSC tables",
             "config": cfgd, "finite": finite, "roofline": roof, "cpu_baseline": cpu_b, "calibration": cali,
         }
+        if world == 1 and not args.no_cpu_baseline and info.get("materialised") is not None:
+            out["guidance_pair_materialised"] = info["materialised"]()
         if world == 1 and args.workload == "sd" and not args.no_cpu_baseline and args.batch in (0, 64) and "sweep" in info:
             out["batch_sweep"] = info["sweep"]()
         emit(out)

@@ -106,6 +106,45 @@ def test_ldm_w4a8_and_cfg_ddim(env):
     assert torch.equal(out2, first)
 
 
+def test_guidance_pair_prefix_is_bit_identical(env, monkeypatch):
+    """Classifier-free guidance runs the UNet on cat([x] * 2), cat([t] * 2), cat([uc, c]) (ldm/models/diffusion/ddim.py:180-186).  Both
+    members of a pair share everything in front of the first cross attention; `pair_prefix` computes that part once per pair.  Per-item
+    arithmetic is batch independent, so eps equals the forward of the materialised pair BIT FOR BIT -- eager with host timesteps, in
+    the FP / weight-only state, and through the captured sampler graphs (TFMQ_PAIR_PREFIX=0 = the materialised pair)."""
+    g, sd, Engine, LayerQ = env
+    x, t, ctx, uc = T(g["x"]), T(g["t"]).float(), T(g["ctx"]), T(g["traj_uc"])
+    B = x.shape[0]
+    t = t[:1].repeat(B)                       # one timestep for the batch, like a sampler step
+    x2, t2, c2 = torch.cat([x, x]), torch.cat([t, t]).to(DEV), torch.cat([uc, ctx]).to(DEV)
+    wq, qtable = layerq(g, LayerQ, True)
+    step = torch.zeros(1, dtype=torch.int32, device=DEV)
+    eng = Engine(sd, CFG, DEV)
+    for state in ("fp", "w4a8"):
+        if state == "fp":
+            eng.prepare()
+        else:
+            eng.prepare(wq, qtable.repeat(4, 1, 1).contiguous().to(DEV), step)
+        full = eng.forward(nhwc(x2), t2, c2)
+        pair = eng.forward(nhwc(x), t2, c2, pair_prefix=True)
+        assert pair.shape == full.shape and torch.equal(pair, full), state
+        assert not torch.equal(full[:B], full[B:])          # the members do differ behind the cross attention
+    from tfmq_dm_amd._lib import TfmqError
+    with pytest.raises(TfmqError):
+        eng.forward(nhwc(x), t2, c2[:B], pair_prefix=True)
+    from tfmq_dm_amd.ldm.sampler import GraphLatentDdimSampler, GraphLatentPlmsSampler, alphas_cumprod_linear
+    ac = alphas_cumprod_linear()
+    for cls in (GraphLatentDdimSampler, GraphLatentPlmsSampler):
+        outs = []
+        for flag in ("0", "1"):
+            monkeypatch.setenv("TFMQ_PAIR_PREFIX", flag)
+            sampler = cls(eng, 4, 2, (4, 8, 8), (5, 64), scale=7.5, alphas_cumprod=ac)
+            assert sampler.pair_prefix == (flag == "1")
+            out = sampler.sample_nhwc(nhwc(T(g["traj_xT"])), ctx.to(DEV), uc.to(DEV))
+            sampler.stream.synchronize()
+            outs.append(out.clone())
+        assert torch.equal(outs[0], outs[1]), cls.__name__
+
+
 def test_layernorm_geglu_kernels(env):
     import torch.nn.functional as F
     import tfmq_dm_amd.ops as ops

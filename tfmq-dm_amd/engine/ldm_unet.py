@@ -70,6 +70,7 @@ class LdmUNetEngine(DdimUNetEngine):
         super().__init__(sd2, dict(cfg), device)
         self.res_names = ldm_resblock_paths(self.sd)
         self._ctx_pad = None
+        self._pair_half = False
         self.fuse_q8 = os.environ.get("TFMQ_NO_Q8") is None
 
     def tib_layout(self):
@@ -287,15 +288,35 @@ class LdmUNetEngine(DdimUNetEngine):
         r = self._tok(to_out, self._quant_in(to_out, v))           # [B, 1, C] fp32: to_out(v) + bias
         return ops.row_broadcast_add(x, r.reshape(B, Cc))
 
+    @staticmethod
+    def _dup(h: torch.Tensor) -> torch.Tensor:
+        """[B, ...] -> [2B, ...] = cat(h, h): the guidance pair of `_forward(pair_prefix=True)` from its shared prefix (device copies)."""
+        B = h.shape[0]
+        out = ops._alloc(2 * B, *h.shape[1:], dtype=h.dtype, device=h.device)
+        out[:B].copy_(h)
+        out[B:].copy_(h)
+        st = getattr(h, "_tfmq_stats", None)
+        if st is not None:      # the producing epilogue's GroupNorm statistics ([image][segment] rows, taken before the fp16 rounding) travel along
+            out._tfmq_stats = (LdmUNetEngine._dup(st[0]), st[1])
+        return out
+
     def _tblock(self, p, x, ctx, out_aq=None):
         L = self.layers
         q1 = self.fused_qkv.get(p + ".attn1", L[p + ".attn1.to_q"])
         x = self._attention(p + ".attn1", self._ln(p + ".norm1", x, q1), None, x, True)
+        # pair_prefix: everything up to here saw only (x, t) -- identical for the two members of a guidance pair -- and ran once per
+        # pair; the first cross attention is where the members part (norm2 / to_q's quantizer still see the shared tensor)
+        pend = self._pair_half
         if (ctx is not None and ctx.shape[1] == 1 and self.calib is None and x.shape[-1] % 8 == 0 and not self.exact_fp and (p + ".attn2") not in self.attn_q
                 and os.environ.get("TFMQ_SINGLE_CTX_TOKEN", "1") != "0"):
+            if pend:
+                x, self._pair_half = self._dup(x), False
             x = self._attn2_single_token(p + ".attn2", ctx, x)
         else:
-            x = self._attention(p + ".attn2", self._ln(p + ".norm2", x, L[p + ".attn2.to_q"]), ctx, x, False)
+            xq2 = self._ln(p + ".norm2", x, L[p + ".attn2.to_q"])
+            if pend:
+                x, xq2, self._pair_half = self._dup(x), self._dup(xq2), False
+            x = self._attention(p + ".attn2", xq2, ctx, x, False)
         ff0, ff2 = L[p + ".ff.net.0.proj"], L[p + ".ff.net.2"]
         gp = self.geglu_fused.get(p + ".ff.net.0.proj")
         if gp is not None and self.calib is None:
@@ -331,6 +352,8 @@ class LdmUNetEngine(DdimUNetEngine):
             tok = self._tblock(name, tok, ctx, out_aq=pout.aq if (fuse_q and i == nblk - 1) else None)
             if taps is not None:
                 taps[name] = ((tin, ctx), tok)
+        if tok.shape[0] != B:       # pair_prefix: the guidance pair parted inside this transformer; the residual is the shared tensor
+            x, B = self._dup(x), tok.shape[0]
         h = tok.reshape(B, H, W, -1) if tok.dtype == torch.int8 else self._quant_in(pout, tok.reshape(B, H, W, -1))
         if taps is not None:
             # the layer's own output (its reconstruction target) excludes the residual; the data path stays the fused
@@ -432,14 +455,28 @@ class LdmUNetEngine(DdimUNetEngine):
             return None
 
     def _forward(self, x: torch.Tensor, t: Optional[torch.Tensor] = None, context: Optional[torch.Tensor] = None,
-                taps: Optional[dict] = None) -> torch.Tensor:
-        """x: fp32 NHWC latents [B,H,W,C]; t: [B] timesteps (or None -> per-step TIB table); context: fp32 [B,L,D]."""
+                taps: Optional[dict] = None, pair_prefix: bool = False) -> torch.Tensor:
+        """x: fp32 NHWC latents [B,H,W,C]; t: [B] timesteps (or None -> per-step TIB table); context: fp32 [B,L,D].
+
+        pair_prefix (classifier-free guidance, ldm/models/diffusion/ddim.py:180-186: x_in = cat([x] * 2), t_in = cat([t] * 2),
+        c_in = cat([uc, c])): `x` holds the B latents ONCE, `context` the 2B rows cat(uc, c); returns eps of the 2B-item batch.
+        The two members of a pair share (x, t), so every tensor in front of the first cross attention -- conv_in, the first
+        ResBlock, the first SpatialTransformer's norm / proj_in / norm1 / self attention / norm2 -- is the same for both: it is
+        computed once per pair and copied where the members part.  Per-item arithmetic is batch independent, so the result
+        equals the forward of the materialised 2B batch bit for bit (tests/test_engine_ldm_gpu.py)."""
         if not self.prepared:
             raise TfmqError("LdmUNetEngine.forward before prepare()")
         if context is None and any(k.endswith(".attn2.to_k.weight") for k in self.sd):
             raise TfmqError("LdmUNetEngine: SpatialTransformer UNets need a context tensor")
         L = self.layers
         self._h16 = self.stream_f16 and self.calib is None and taps is None and self._stream_f16_possible()
+        self._pair_half = False
+        if pair_prefix:
+            if context is None or context.shape[0] != 2 * x.shape[0] or self.calib is not None or taps is not None:
+                raise TfmqError("LdmUNetEngine: pair_prefix needs B latents with 2B context rows, outside calibration / taps")
+            if t is not None and (t.shape[0] != 2 * x.shape[0] or not bool(torch.equal(t[:x.shape[0]], t[x.shape[0]:]))):
+                raise TfmqError("LdmUNetEngine: pair_prefix needs t = cat([t] * 2)")
+            self._pair_half = True
         if t is not None:
             projs = dict(zip(self.res_names, self.tib(t)))
             if taps is not None:
@@ -469,8 +506,13 @@ class LdmUNetEngine(DdimUNetEngine):
         hs = []
         h = x
         for i in range(_n_children(self.sd, "input_blocks")):
+            was_half = self._pair_half
             h = self._seq(f"input_blocks.{i}", h, None, ctx, rowadd, taps)
+            if was_half and not self._pair_half:        # the pair parted inside this block: the skips taken before it are shared
+                hs = [self._dup(e) for e in hs]
             hs.append(h)
+        if self._pair_half:
+            raise TfmqError("LdmUNetEngine: pair_prefix found no cross attention in the down path")
         h = self._seq("middle_block", h, None, ctx, rowadd, taps)
         for i in range(_n_children(self.sd, "output_blocks")):
             h = self._seq(f"output_blocks.{i}", h, hs.pop(), ctx, rowadd, taps)

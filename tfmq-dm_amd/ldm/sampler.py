@@ -68,6 +68,7 @@ class GraphLatentDdimSampler:
         self.uncond = context_shape is None
         self.x2 = None if self.uncond else torch.empty(2 * batch, H, W, Cc, device=self.dev)
         self.ctx2 = None if self.uncond else torch.empty((2 * batch,) + tuple(context_shape), device=self.dev)
+        self.pair_prefix = (not self.uncond) and os.environ.get("TFMQ_PAIR_PREFIX", "1") != "0" and hasattr(engine, "_dup")
         self.stream = torch.cuda.Stream(self.dev)
         self.arena = ops.Arena()
         self.h = handle(self.dev.index or 0)
@@ -80,11 +81,19 @@ class GraphLatentDdimSampler:
             ops.ddim_update(self.x, eps, self.coef, self.step, None, out=self.x)
             ops.step_advance(self.step, 1)
             return
-        self.x2[:B].copy_(self.x)
-        self.x2[B:].copy_(self.x)
-        eps2 = self.eng.forward(self.x2, None, self.ctx2)
+        eps2 = self._eps_pair(self.x)
         ops.ddim_update_cfg(self.x, eps2[:B], eps2[B:], self.scale, self.coef, self.step, out=self.x)
         ops.step_advance(self.step, 1)
+
+    def _eps_pair(self, xin):
+        """eps of the guidance pair cat([x] * 2) under cat([uc, c]) (ddim.py:180-186).  The engine computes what the two members share
+        -- everything in front of the first cross attention -- once (`pair_prefix`, TFMQ_PAIR_PREFIX=0: the materialised 2B batch)."""
+        B = self.batch
+        if self.pair_prefix:
+            return self.eng.forward(xin, None, self.ctx2, pair_prefix=True)
+        self.x2[:B].copy_(xin)
+        self.x2[B:].copy_(xin)
+        return self.eng.forward(self.x2, None, self.ctx2)
 
     def capture(self):
         sp = C.c_void_p(self.stream.cuda_stream)
@@ -166,10 +175,8 @@ class GraphLatentPlmsSampler(GraphLatentDdimSampler):
 
     def _eps(self, xin, dst):
         B = self.batch
-        self.x2[:B].copy_(xin)
-        self.x2[B:].copy_(xin)
         with ops.use_arena(self.arena):           # every UNet call replays the same allocation log
-            eps2 = self.eng.forward(self.x2, None, self.ctx2)
+            eps2 = self._eps_pair(xin)
             ops.cfg_combine(eps2[:B], eps2[B:], self.scale, out=dst)
 
     def _rotate(self):
