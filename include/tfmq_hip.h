@@ -432,6 +432,21 @@ int tfmq_softmax_bwd_rows(tfmq_handle h, const float* P, const float* dP, float*
                           void* stream);
 /* nearest-neighbour x2 (F.interpolate(scale_factor=2, mode="nearest"), ddim/models/diffusion.py:47-48) */
 int tfmq_upsample2x(tfmq_handle h, const float* x, float* y, int B, int H, int W, int C, void* stream);
+/* backward of tfmq_upsample2x: gx[b][h][w][c] = sum of the four g[b][2h+i][2w+j][c]  (autograd through Upsample.forward's
+ * F.interpolate in the FP tail of GetLayerGrad, quant/data_utill.py:191-256) */
+int tfmq_upsample2x_bwd(tfmq_handle h, const float* g, float* gx, int B, int H, int W, int C, void* stream);
+/* GetLayerGrad's loss (reference quant/data_utill.py:246-247): F.kl_div(F.log_softmax(out_q, dim=1), F.softmax(out_fp, dim=1),
+ * reduction='batchmean') on NHWC rows [n_rows][C] (channel softmax, C <= 64):  g = dL/d out_q = (softmax(out_q) - softmax(out_fp)) / batch;
+ * loss_or_null accumulates the loss value (one device float, atomically). */
+int tfmq_kl_softmax_grad(tfmq_handle h, const float* out_q, const float* out_fp, float* g, long n_rows, int C, int batch,
+                         float* loss_or_null, void* stream);
+/* LossFunc's Fisher-weighted reconstruction terms (reference quant/reconstruction_util.py:53-59), fgrad = save_grad's cached
+ * |dL/d out| + 1 of the mini-batch (quant/data_utill.py:54-73), tensors [n_samples][per_sample]:
+ *   mode 1 (RLOSS.FISHER_DIAG): rec = ((pred - tgt)^2 * fgrad^2).sum(1).mean() = sum(...) / denom, denom = numel / size(1)
+ *   mode 2 (RLOSS.FISHER_FULL): a = |pred - tgt|, w = |fgrad|, s_b = sum_sample(a w); rec = (s_b a w).mean() / 100 (denom unused)
+ * g_or_null = d rec / d pred; loss: one device float, accumulated; dot_scratch: n_samples doubles (mode 2). */
+int tfmq_fisher_loss(tfmq_handle h, const float* pred, const float* tgt, const float* fgrad, float* g_or_null, size_t n_samples,
+                     size_t per_sample, int mode, size_t denom, double* dot_scratch, float* loss, void* stream);
 /* y += a*x */
 int tfmq_axpy(tfmq_handle h, float* y, const float* x, float a, size_t n, void* stream);
 

@@ -514,6 +514,135 @@ extern "C" int tfmq_upsample2x(tfmq_handle h, const float* x, float* y, int B, i
   return TFMQ_OK;
 }
 
+// ------------------------------------------------------------------ Fisher-weighted reconstruction
+// backward of the nearest 2x upsample: gx[b][h][w][c] = sum of the four g[b][2h+i][2w+j][c] (fixed order)
+__global__ __launch_bounds__(256) void k_upsample2x_bwd(const float* __restrict__ g, float* __restrict__ gx, int B, int H, int W,
+                                                        int Cc) {
+  const long total = static_cast<long>(B) * H * W * Cc;
+  for (long i = static_cast<long>(blockIdx.x) * blockDim.x + threadIdx.x; i < total;
+       i += static_cast<long>(gridDim.x) * blockDim.x) {
+    const int c = i % Cc;
+    long r = i / Cc;
+    const int w = r % W; r /= W;
+    const int hh = r % H;
+    const int b = r / H;
+    const long row0 = ((static_cast<long>(b) * 2 * H + 2 * hh) * 2 * W + 2 * w) * Cc + c;
+    const long row1 = row0 + static_cast<long>(2 * W) * Cc;
+    gx[i] = (g[row0] + g[row0 + Cc]) + (g[row1] + g[row1 + Cc]);
+  }
+}
+extern "C" int tfmq_upsample2x_bwd(tfmq_handle h, const float* g, float* gx, int B, int H, int W, int C, void* stream) {
+  TFMQ_CHECK_ARG(h, h && g && gx && B > 0 && H > 0 && W > 0 && C > 0, "upsample2x_bwd: bad argument");
+  const long total = static_cast<long>(B) * H * W * C;
+  int blocks = ceil_div(total, 256);
+  if (blocks > h->cu_count * 16) blocks = h->cu_count * 16;
+  hipLaunchKernelGGL(k_upsample2x_bwd, dim3(blocks), dim3(256), 0, as_stream(stream), g, gx, B, H, W, C);
+  TFMQ_LAUNCH_CHECK(h);
+  return TFMQ_OK;
+}
+
+// GetLayerGrad's loss (reference quant/data_utill.py:246-247): F.kl_div(log_softmax(out_q, 1), softmax(out_fp, 1), 'batchmean') over the
+// channel dimension of NHWC rows [n][C]; g = dL/d out_q = (softmax(out_q) - softmax(out_fp)) / batch; loss (optional) accumulates
+// sum p_fp (log p_fp - log p_q) / batch.  One thread per pixel, C <= 64.
+__global__ __launch_bounds__(256) void k_kl_softmax_grad(const float* __restrict__ q, const float* __restrict__ f, float* __restrict__ g,
+                                                         long n, int Cc, float inv_batch, float* __restrict__ loss) {
+  double acc = 0.0;
+  for (long i = static_cast<long>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += static_cast<long>(gridDim.x) * blockDim.x) {
+    const float* qr = q + i * Cc;
+    const float* fr = f + i * Cc;
+    float mq = qr[0], mf = fr[0];
+    for (int c = 1; c < Cc; ++c) { mq = fmaxf(mq, qr[c]); mf = fmaxf(mf, fr[c]); }
+    float sq = 0.0f, sf = 0.0f;
+    for (int c = 0; c < Cc; ++c) { sq += expf(qr[c] - mq); sf += expf(fr[c] - mf); }
+    const float lq = logf(sq), lf = logf(sf);
+    for (int c = 0; c < Cc; ++c) {
+      const float lpq = qr[c] - mq - lq, lpf = fr[c] - mf - lf;
+      const float pq = expf(lpq), pf = expf(lpf);
+      g[i * Cc + c] = (pq - pf) * inv_batch;
+      acc += static_cast<double>(pf) * (lpf - lpq);
+    }
+  }
+  if (loss) {
+    __shared__ double part[4];
+    acc = wave_reduce_sum_d(acc);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(loss, static_cast<float>(((part[0] + part[1]) + (part[2] + part[3])) * inv_batch));
+  }
+}
+extern "C" int tfmq_kl_softmax_grad(tfmq_handle h, const float* out_q, const float* out_fp, float* g, long n_rows, int C, int batch,
+                                    float* loss_or_null, void* stream) {
+  TFMQ_CHECK_ARG(h, h && out_q && out_fp && g && n_rows > 0 && C > 0 && C <= 64 && batch > 0, "kl_softmax_grad: bad argument (C <= 64)");
+  int blocks = ceil_div(n_rows, 256);
+  if (blocks > h->cu_count * 8) blocks = h->cu_count * 8;
+  hipLaunchKernelGGL(k_kl_softmax_grad, dim3(blocks), dim3(256), 0, as_stream(stream), out_q, out_fp, g, n_rows, C,
+                     1.0f / static_cast<float>(batch), loss_or_null);
+  TFMQ_LAUNCH_CHECK(h);
+  return TFMQ_OK;
+}
+
+// LossFunc's Fisher modes (reference quant/reconstruction_util.py:53-59); fg = the cached |dL/d out| + 1 of save_grad.
+//   DIAG: rec = ((pred - tgt)^2 * fg^2).sum(1).mean()            = sum d^2 fg^2 / denom,           g = 2 d fg^2 / denom
+//   FULL: a = |pred - tgt|, w = |fg|, s_b = sum_{chw} a w;  rec = (s_b * a * w).mean() / 100 = sum_b s_b^2 / (100 n),
+//         g = 2 s_b w sign(d) / (100 n)   (autograd differentiates both occurrences of a; sign(0) = 0 like torch's abs)
+// k_fisher_dot: per-sample s_b in double (one block per sample, fixed order).  k_fisher_loss: loss + gradient.
+__global__ __launch_bounds__(256) void k_fisher_dot(const float* __restrict__ pred, const float* __restrict__ tgt, const float* __restrict__ fg,
+                                                    size_t per_sample, double* __restrict__ dot) {
+  const size_t base = static_cast<size_t>(blockIdx.x) * per_sample;
+  double acc = 0.0;
+  for (size_t i = threadIdx.x; i < per_sample; i += blockDim.x)
+    acc += static_cast<double>(fabsf(pred[base + i] - tgt[base + i])) * fabsf(fg[base + i]);
+  __shared__ double part[4];
+  acc = wave_reduce_sum_d(acc);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) dot[blockIdx.x] = (part[0] + part[1]) + (part[2] + part[3]);
+}
+__global__ __launch_bounds__(256) void k_fisher_loss(const float* __restrict__ pred, const float* __restrict__ tgt, const float* __restrict__ fg,
+                                                     float* __restrict__ g, size_t n, size_t per_sample, int mode, float inv_denom,
+                                                     const double* __restrict__ dot, float* __restrict__ loss) {
+  const size_t stride = static_cast<size_t>(gridDim.x) * blockDim.x;
+  double acc = 0.0;
+  for (size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const float d = pred[i] - tgt[i], w = fg[i];
+    if (mode == 1) {
+      const float dw = d * d * (w * w);
+      acc += static_cast<double>(dw);
+      if (g) g[i] = 2.0f * d * (w * w) * inv_denom;
+    } else {
+      const float sb = static_cast<float>(dot[i / per_sample]);
+      const float aw = fabsf(d) * fabsf(w);
+      acc += static_cast<double>(sb) * aw;
+      if (g) g[i] = 2.0f * sb * fabsf(w) * (d > 0.0f ? 1.0f : (d < 0.0f ? -1.0f : 0.0f)) * inv_denom;
+    }
+  }
+  __shared__ double part[4];
+  acc = wave_reduce_sum_d(acc);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(loss, static_cast<float>(((part[0] + part[1]) + (part[2] + part[3])) * inv_denom));
+}
+extern "C" int tfmq_fisher_loss(tfmq_handle h, const float* pred, const float* tgt, const float* fgrad, float* g, size_t n_samples,
+                                size_t per_sample, int mode, size_t denom, double* dot_scratch, float* loss, void* stream) {
+  TFMQ_CHECK_ARG(h, h && pred && tgt && fgrad && loss && n_samples > 0 && per_sample > 0 && (mode == 1 || mode == 2) && denom > 0,
+                 "fisher_loss: bad argument (mode 1 = FISHER_DIAG, 2 = FISHER_FULL)");
+  TFMQ_CHECK_ARG(h, mode == 1 || (dot_scratch && n_samples < 2147483647UL), "fisher_loss: FISHER_FULL needs n_samples doubles of scratch");
+  const size_t n = n_samples * per_sample;
+  // FULL: mean over all n elements, / 100
+  const double inv = mode == 1 ? 1.0 / static_cast<double>(denom) : 1.0 / (100.0 * static_cast<double>(n));
+  if (mode == 2) {
+    hipLaunchKernelGGL(k_fisher_dot, dim3(static_cast<unsigned>(n_samples)), dim3(256), 0, as_stream(stream), pred, tgt, fgrad, per_sample,
+                       dot_scratch);
+    TFMQ_LAUNCH_CHECK(h);
+  }
+  int blocks = ceil_div(static_cast<long>(n), 1024);
+  if (blocks > h->cu_count * 4) blocks = h->cu_count * 4;
+  hipLaunchKernelGGL(k_fisher_loss, dim3(blocks), dim3(256), 0, as_stream(stream), pred, tgt, fgrad, g, n, per_sample, mode,
+                     static_cast<float>(inv), dot_scratch, loss);
+  TFMQ_LAUNCH_CHECK(h);
+  return TFMQ_OK;
+}
+
 // ------------------------------------------------------------------ flat gradient buffer helpers (K16: one all-reduce per iteration)
 __global__ void k_scale_add(float* __restrict__ y, const float* __restrict__ x, float a, size_t n) {
   const size_t stride = static_cast<size_t>(gridDim.x) * blockDim.x;

@@ -1324,3 +1324,48 @@ def recon_loss(pred, tgt, denom: int, want_grad: bool = True):
     g = _alloc_like(pred) if want_grad else None
     handle(d).call("recon_loss", _p(pred), _p(tgt), _p(g), pred.numel(), int(denom), _p(loss), _stream(d))
     return loss, g
+
+
+# ------------------------------------------------------------------------------ Fisher-weighted reconstruction
+def upsample2x_bwd(g: torch.Tensor) -> torch.Tensor:
+    """Backward of upsample2x: g [B,2H,2W,C] -> [B,H,W,C]."""
+    d = _dev(g)
+    _chk(g, torch.float32, "g")
+    B, H2, W2, Cc = g.shape
+    gx = _alloc(B, H2 // 2, W2 // 2, Cc, dtype=torch.float32, device=g.device)
+    handle(d).call("upsample2x_bwd", _p(g), _p(gx), B, H2 // 2, W2 // 2, Cc, _stream(d))
+    return gx
+
+
+def kl_softmax_grad(out_q: torch.Tensor, out_fp: torch.Tensor, want_loss: bool = False):
+    """GetLayerGrad's loss (reference quant/data_utill.py:246-247) on NHWC model outputs [B,H,W,C]: kl_div(log_softmax(out_q, C),
+    softmax(out_fp, C), 'batchmean').  -> (dL/d out_q, loss [1] | None)."""
+    d = _dev(out_q)
+    _chk(out_q, torch.float32, "out_q")
+    _chk(out_fp, torch.float32, "out_fp")
+    if out_q.shape != out_fp.shape:
+        raise TfmqError("kl_softmax_grad: shape mismatch")
+    g = _alloc_like(out_q)
+    loss = torch.zeros(1, dtype=torch.float32, device=out_q.device) if want_loss else None
+    Cc = out_q.shape[-1]
+    handle(d).call("kl_softmax_grad", _p(out_q), _p(out_fp), _p(g), out_q.numel() // Cc, Cc, out_q.shape[0], _p(loss), _stream(d))
+    return g, loss
+
+
+FISHER_DIAG, FISHER_FULL = 1, 2
+
+
+def fisher_loss(pred: torch.Tensor, tgt: torch.Tensor, fgrad: torch.Tensor, mode: int, denom: int, want_grad: bool = True):
+    """LossFunc's RLOSS.FISHER_DIAG / FISHER_FULL (reference quant/reconstruction_util.py:53-59) on [N, ...] tensors with the cached
+    Fisher weights `fgrad` (|dL/d out| + 1).  -> (loss [1], d loss / d pred | None)."""
+    d = _dev(pred)
+    for t, n in ((pred, "pred"), (tgt, "tgt"), (fgrad, "fgrad")):
+        _chk(t, torch.float32, n)
+    if pred.shape != tgt.shape or pred.shape != fgrad.shape:
+        raise TfmqError("fisher_loss: pred / tgt / fgrad shapes differ")
+    N = pred.shape[0]
+    loss = torch.zeros(1, dtype=torch.float32, device=pred.device)
+    g = _alloc_like(pred) if want_grad else None
+    dot = torch.empty(N, dtype=torch.float64, device=pred.device) if mode == FISHER_FULL else None
+    handle(d).call("fisher_loss", _p(pred), _p(tgt), _p(fgrad), _p(g), N, pred.numel() // N, int(mode), int(denom), _p(dot), _p(loss), _stream(d))
+    return loss, g
