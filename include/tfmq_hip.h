@@ -436,10 +436,14 @@ int tfmq_upsample2x(tfmq_handle h, const float* x, float* y, int B, int H, int W
  * F.interpolate in the FP tail of GetLayerGrad, quant/data_utill.py:191-256) */
 int tfmq_upsample2x_bwd(tfmq_handle h, const float* g, float* gx, int B, int H, int W, int C, void* stream);
 /* GetLayerGrad's loss (reference quant/data_utill.py:246-247): F.kl_div(F.log_softmax(out_q, dim=1), F.softmax(out_fp, dim=1),
- * reduction='batchmean') on NHWC rows [n_rows][C] (channel softmax, C <= 64):  g = dL/d out_q = (softmax(out_q) - softmax(out_fp)) / batch;
+ * reduction='batchmean') on NHWC rows [n_rows][C] (channel softmax, C <= 64).
+ *   wrt_target = 0: g = dL/d out_q  = (softmax(out_q) - softmax(out_fp)) / batch
+ *   wrt_target = 1: g = dL/d out_fp = p (l - sum_c p l) / batch with p = softmax(out_fp), l = log p - log_softmax(out_q): the
+ *                   reference does not detach the target, and GradSaverHook (:170-188) keeps the gradient of the pass the backward
+ *                   reaches last, which is the FP pass -- so THIS is what save_grad caches (tests/test_fisher_gpu.py).
  * loss_or_null accumulates the loss value (one device float, atomically). */
 int tfmq_kl_softmax_grad(tfmq_handle h, const float* out_q, const float* out_fp, float* g, long n_rows, int C, int batch,
-                         float* loss_or_null, void* stream);
+                         int wrt_target, float* loss_or_null, void* stream);
 /* LossFunc's Fisher-weighted reconstruction terms (reference quant/reconstruction_util.py:53-59), fgrad = save_grad's cached
  * |dL/d out| + 1 of the mini-batch (quant/data_utill.py:54-73), tensors [n_samples][per_sample]:
  *   mode 1 (RLOSS.FISHER_DIAG): rec = ((pred - tgt)^2 * fgrad^2).sum(1).mean() = sum(...) / denom, denom = numel / size(1)

@@ -1,0 +1,183 @@
+"""Fisher-weighted reconstruction (`opt_mode=RLOSS.FISHER_DIAG / FISHER_FULL`; reference quant/reconstruction.py:58-61,177-180,
+quant/data_utill.py:54-73,191-256 `save_grad` / `GetLayerGrad`, quant/reconstruction_util.py:53-59).  No driver passes
+a Fisher `opt_mode`; fixture F23 was produced by calling the reference's layer_ / block_reconstruction with it on the tiny DDPM UNet of
+F8 and the tiny SD-style UNet of F12 (checkpoints loaded the drivers' way).
+
+Checked: the loss kernel (value + gradient) against LossFunc's two formulas under autograd; the KL-gradient and the up-sampling
+backward kernels against torch; per unit of F23 -- ResnetBlock, AttnBlock, up-sampling conv, up-path block with a concatenated
+input, LDM ResBlock, BasicTransformerBlock, SpatialTransformer.proj_out, LDM up-path ResBlock -- GetLayerGrad's dL/d(unit output)
+against the reference's autograd through the whole FP tail of the UNet, the total-loss curve of 20 Fisher-weighted AdaRound iterations
+and the final alphas against the reference's own run (same host RNG stream -> same mini-batches).
+
+WHICH gradient: the reference does not detach softmax(out_fp) and its backward hook fires once per forward pass of the unit, keeping
+the last call -- the FP pass's.  save_grad therefore caches dL/d(unit output of the FP forward) through the target branch of the KL term
+(to first order the negative of the out_q branch; the first version of this test measured cosine = -1.00 against the fixture for every
+unit).  GetLayerGrad reproduces that, as released.
+
+Tolerances (engine in its exact-fp32 mode, exact-fp32 reconstruction GEMMs; measured in brackets).  dL/d(unit output): max error and
+rel-L2 <= 1e-3 of the gradient [<= 1.0e-4], cosine >= 0.9999; total-loss curve of the 20 iterations <= 1e-4 relative [<= 6e-7]; AdaRound
+masks >= 99.9 % equal per layer [100 %]; alphas: mean deviation <= 1e-5 [<= 4e-6], any element <= 2e-3 [9.8e-4: Adam turns the sign of a
+gradient that is zero to rounding into a full lr step per iteration].  (A first version of this test kept the checkpoint's learned alphas
+where the reference re-wraps every layer in a fresh AdaRoundQuantizer: 6e-3 mean alpha deviation, 3 % on the gradient -- which is how
+the unconditional re-wrap of reconstruction.py:49-52,113-128 was found.)
+"""
+import os
+import sys
+import tempfile
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tfmq-dm_amd"))
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def T(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def test_fisher_loss_kernel_vs_reference_formulas(golden):
+    import tfmq_dm_amd.ops as ops
+    g = golden("f23_fisher")
+    for tag in ("a", "b"):
+        pred, tgt, fg = (T(g[f"loss/{tag}/{k}"]).to(DEV) for k in ("pred", "tgt", "fg"))
+        for mode, m in (("FISHER_DIAG", ops.FISHER_DIAG), ("FISHER_FULL", ops.FISHER_FULL)):
+            if f"loss/{tag}/{mode}/value" not in g.files:
+                continue
+            denom = pred.numel() // pred.shape[1]
+            loss, gr = ops.fisher_loss(pred, tgt, fg, m, denom)
+            ref_v, ref_g = float(g[f"loss/{tag}/{mode}/value"]), T(g[f"loss/{tag}/{mode}/grad"])
+            assert abs(float(loss) - ref_v) <= 2e-6 * abs(ref_v), (tag, mode, float(loss), ref_v)
+            assert float((gr.cpu() - ref_g).abs().max()) <= 2e-6 * float(ref_g.abs().max()), (tag, mode)
+            loss2, none = ops.fisher_loss(pred, tgt, fg, m, denom, want_grad=False)
+            assert none is None and float(loss2) == float(loss)
+
+
+def test_kl_gradient_and_upsample_backward_kernels():
+    import torch.nn.functional as F
+    import tfmq_dm_amd.ops as ops
+    gen = torch.Generator().manual_seed(9)
+    for Cc in (3, 4):
+        q = (torch.randn(5, Cc, 6, 7, generator=gen) * 2).requires_grad_(True)
+        f = (torch.randn(5, Cc, 6, 7, generator=gen) * 2).requires_grad_(True)
+        loss = F.kl_div(F.log_softmax(q, dim=1), F.softmax(f, dim=1), reduction="batchmean")
+        loss.backward()
+        qd, fd = q.detach().permute(0, 2, 3, 1).contiguous().to(DEV), f.detach().permute(0, 2, 3, 1).contiguous().to(DEV)
+        gk, lk = ops.kl_softmax_grad(qd, fd, want_loss=True)
+        assert abs(float(lk) - float(loss.detach())) <= 1e-5 * abs(float(loss.detach()))
+        assert float((gk.cpu().permute(0, 3, 1, 2) - q.grad).abs().max()) <= 1e-6 * float(q.grad.abs().max()) + 1e-9
+        gt, _ = ops.kl_softmax_grad(qd, fd, wrt_target=True)        # the branch the reference's hook ends up storing
+        assert float((gt.cpu().permute(0, 3, 1, 2) - f.grad).abs().max()) <= 2e-6 * float(f.grad.abs().max()) + 1e-9
+    x = torch.randn(3, 5, 4, 6, generator=gen).requires_grad_(True)
+    gy = torch.randn(3, 5, 8, 12, generator=gen)
+    F.interpolate(x, scale_factor=2.0, mode="nearest").backward(gy)
+    gx = ops.upsample2x_bwd(gy.permute(0, 2, 3, 1).contiguous().to(DEV)).cpu().permute(0, 3, 1, 2)
+    assert float((gx - x.grad).abs().max()) <= 1e-6
+
+
+def _state(golden, ldm):
+    from test_calibration_gpu import build
+    from test_quant_mirror_ldm import tiny_qnn
+    from quant.calibration import load_cali_model
+    g8, g = golden("f12_ldm_cali_tiny" if ldm else "f8_cali_tiny"), golden("f23_fisher")
+    pre = "ldm/" if ldm else ""
+    ck = {"weight": {str(k): T(g8["ck/weight/" + str(k)]) for k in g8["weight_keys"]}}
+    akeys = [str(k) for k in g8["act_keys"]]
+    dk, zk = [k for k in akeys if k.endswith("delta")], [k for k in akeys if k.endswith("zero_point")]
+    for gi in range(3):
+        d, z = T(g8[f"ck/act_{gi}/delta"]), T(g8[f"ck/act_{gi}/zp"])
+        ck[f"act_{gi}"] = {**{k: d[i].clone() for i, k in enumerate(dk)}, **{k: z[i].clone() for i, k in enumerate(zk)}}
+    path = os.path.join(tempfile.mkdtemp(), "c.pth")
+    torch.save(ck, path)
+    qnn = tiny_qnn(g8, cali=False, device=DEV).to(DEV) if ldm else build(g8, cali=False)
+    init = (T(g[pre + "init_x"]), T(g[pre + "init_t"]).float()) + ((T(g[pre + "init_c"]),) if ldm else ())
+    load_cali_model(qnn, init, use_aq=False, path=path)
+    return qnn, g8, g
+
+
+UNITS = [("block", "down.1.block.0", False), ("block", "mid.attn_1", False), ("layer", "up.1.upsample.conv", False), ("block", "up.0.block.1", False),
+         ("block", "input_blocks.1.0", True), ("block", "input_blocks.1.1.transformer_blocks.0", True), ("layer", "input_blocks.1.1.proj_out", True),
+         ("block", "output_blocks.1.0", True)]
+
+
+@pytest.mark.parametrize("kind,name,ldm", UNITS)
+def test_fisher_reconstruction_matches_reference_run(golden, monkeypatch, kind, name, ldm):
+    import quant.reconstruction as REC
+    import quant.data_utill as DU
+    from quant.reconstruction_util import RLOSS
+    monkeypatch.setenv("TFMQ_RECON_GEMM", "f32")
+    monkeypatch.setenv("TFMQ_EXACT_FP", "1")      # unit inputs / targets captured with fp32 operands upstream, as the reference captures them
+    qnn, g8, g = _state(golden, ldm)
+    unit = dict(qnn.model.named_modules())[name]
+    fname = ("ldm/" if ldm else "") + name
+    mode = str(g[f"{fname}/mode"])
+    data = (T(g8["cali_x"]), T(g8["cali_t"])) + ((T(g8["cali_c"]),) if ldm else ())
+    iters, bs = int(g["iters"]), int(g["batch_size"])
+    raw, orig = [], DU.GetLayerGrad.__call__
+
+    def rec_grad(self, *a, **k):
+        gg = orig(self, *a, **k)
+        raw.append(gg.detach().cpu().clone())
+        return gg
+    monkeypatch.setattr(DU.GetLayerGrad, "__call__", rec_grad)
+    trace = {"counts": tuple(range(1, iters + 1)), "rows": [], "unit": 0}
+    REC.LOSS_TRACE = trace
+    torch.manual_seed(78)
+    np.random.seed(78)
+    try:
+        kw = dict(cali_data=data, batch_size=bs, iters=iters, w=0.01, opt_mode=RLOSS[mode], asym=True, warmup=0.2, use_aq=False, multi_gpu=False)
+        (REC.layer_reconstruction if kind == "layer" else REC.block_reconstruction)(qnn, unit, **kw)
+    finally:
+        REC.LOSS_TRACE = None
+    # ---- dL/d(unit output) of the first calibration batch vs the reference's autograd through the FP tail
+    ref = T(g[f"{fname}/raw_grad"])
+    mine = raw[0]
+    mine = mine.permute(0, 3, 1, 2) if ref.dim() == 4 else mine
+    assert mine.shape == ref.shape, (mine.shape, ref.shape)
+    err = float((mine - ref).abs().max() / ref.abs().max())
+    rel = float((mine - ref).norm() / ref.norm())
+    cos = float((mine * ref).sum() / (mine.norm() * ref.norm()))
+    print(f"[{name}] {mode}: dL/d(unit output) vs the reference: max error / max |g| = {err:.2e}, rel-L2 = {rel:.2e}, cosine = {cos:.4f} "
+          f"(max |g| = {float(ref.abs().max()):.2e}, mine {float(mine.abs().max()):.2e})")
+    assert err <= 1e-3 and rel <= 1e-3 and cos >= 0.9999, (name, err, rel, cos)
+    # ---- the loss curve of the Fisher-weighted AdaRound iterations (total = reconstruction + rounding regulariser)
+    ref_loss = g[f"{fname}/loss"]
+    loss = np.array([r[2] + r[3] for r in trace["rows"]])
+    assert len(loss) == iters
+    dev = np.max(np.abs(loss - ref_loss) / ref_loss)
+    print(f"[{name}] total loss {loss[0]:.5f} ... {loss[-1]:.3f} (reference {ref_loss[0]:.5f} ... {ref_loss[-1]:.3f}); worst deviation {dev:.2e}")
+    assert dev <= 1e-4, (name, dev)
+    # ---- final alphas
+    mods = dict(qnn.model.named_modules())
+    # Adam moves an element by lr = 1e-3 per iteration whatever the size of its gradient: an element whose gradient is zero to rounding
+    # can sit one step away; the bulk (mean deviation) and the rounding decisions must agree
+    for full in [str(n) for n in g[f"{fname}/alpha_names"]]:
+        a, ra = mods[full].wqtizer.alpha.detach().cpu(), T(g[f"{fname}/alpha/{full}"])
+        assert a.shape == ra.shape
+        mask, dmax, dmean = float(((a >= 0) == (ra >= 0)).float().mean()), float((a - ra).abs().max()), float((a - ra).abs().mean())
+        print(f"[{name}] {full}: masks equal {mask:.4%}, |alpha - reference| max {dmax:.2e} mean {dmean:.2e}")
+        assert mask >= 0.999 and dmax <= 2e-3 and dmean <= 1e-5, (full, mask, dmax, dmean)
+
+
+def test_save_grad_weights_and_state_restore(golden, monkeypatch):
+    """save_grad = |dL/d out| + 1 for the whole set; the model's quant state afterwards is the reference's (everything off, the unit on)."""
+    import quant.data_utill as DU
+    from quant.quant_layer import QuantLayer
+    monkeypatch.setenv("TFMQ_EXACT_FP", "1")
+    qnn, g8, g = _state(golden, False)
+    unit = dict(qnn.model.named_modules())["down.1.block.0"]
+    data = (T(g8["cali_x"])[:24], T(g8["cali_t"])[:24])
+    w = DU.save_grad(qnn, unit, data, 1.0, False, 16, True)
+    assert w.shape[0] == 24 and float(w.min()) >= 1.0 and float(w.max()) > 1.0
+    raw = DU.GetLayerGrad(qnn, unit, DEV, False)(data[0][:16], data[1][:16])
+    assert torch.equal(w[:16], raw.abs() + 1.0)
+    raw2 = DU.GetLayerGrad(qnn, unit, DEV, False)(data[0][16:], data[1][16:])
+    assert torch.equal(w[16:], raw2.abs() + 1.0)
+    for n, m in qnn.model.named_modules():
+        if isinstance(m, QuantLayer):
+            inside = n.startswith("down.1.block.0.")
+            assert m.use_wq == inside and not m.use_aq, n

@@ -139,7 +139,7 @@ _SIGS = {
     "tfmq_axpy": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_size_t, c_void_p]),
     "tfmq_upsample2x": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "tfmq_upsample2x_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
-    "tfmq_kl_softmax_grad": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, C.c_long, c_int, c_int, c_void_p, c_void_p]),
+    "tfmq_kl_softmax_grad": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, C.c_long, c_int, c_int, c_int, c_void_p, c_void_p]),
     "tfmq_fisher_loss": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_size_t, c_int, c_size_t, c_void_p, c_void_p, c_void_p]),
     "tfmq_graph_begin": (c_int, [c_void_p, c_void_p]),
     "tfmq_graph_end": (c_int, [c_void_p, c_void_p, C.POINTER(c_int)]),

@@ -542,10 +542,12 @@ extern "C" int tfmq_upsample2x_bwd(tfmq_handle h, const float* g, float* gx, int
 }
 
 // GetLayerGrad's loss (reference quant/data_utill.py:246-247): F.kl_div(log_softmax(out_q, 1), softmax(out_fp, 1), 'batchmean') over the
-// channel dimension of NHWC rows [n][C]; g = dL/d out_q = (softmax(out_q) - softmax(out_fp)) / batch; loss (optional) accumulates
-// sum p_fp (log p_fp - log p_q) / batch.  One thread per pixel, C <= 64.
+// channel dimension of NHWC rows [n][C]; loss (optional) accumulates sum p_fp (log p_fp - log p_q) / batch.  One thread per pixel, C <= 64.
+//   wrt_target = 0: g = dL/d out_q  = (softmax(out_q) - softmax(out_fp)) / batch
+//   wrt_target = 1: g = dL/d out_fp = p_fp (l - sum_c p_fp l) / batch, l = log p_fp - log p_q   (the target branch: the reference does
+//                   not detach softmax(out_fp), and its backward hook keeps the gradient of the pass autograd reaches LAST -- the FP one)
 __global__ __launch_bounds__(256) void k_kl_softmax_grad(const float* __restrict__ q, const float* __restrict__ f, float* __restrict__ g,
-                                                         long n, int Cc, float inv_batch, float* __restrict__ loss) {
+                                                         long n, int Cc, float inv_batch, int wrt_target, float* __restrict__ loss) {
   double acc = 0.0;
   for (long i = static_cast<long>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += static_cast<long>(gridDim.x) * blockDim.x) {
     const float* qr = q + i * Cc;
@@ -555,12 +557,17 @@ __global__ __launch_bounds__(256) void k_kl_softmax_grad(const float* __restrict
     float sq = 0.0f, sf = 0.0f;
     for (int c = 0; c < Cc; ++c) { sq += expf(qr[c] - mq); sf += expf(fr[c] - mf); }
     const float lq = logf(sq), lf = logf(sf);
+    float kl = 0.0f;
+    for (int c = 0; c < Cc; ++c) {
+      const float lpq = qr[c] - mq - lq, lpf = fr[c] - mf - lf;
+      kl += expf(lpf) * (lpf - lpq);
+    }
     for (int c = 0; c < Cc; ++c) {
       const float lpq = qr[c] - mq - lq, lpf = fr[c] - mf - lf;
       const float pq = expf(lpq), pf = expf(lpf);
-      g[i * Cc + c] = (pq - pf) * inv_batch;
-      acc += static_cast<double>(pf) * (lpf - lpq);
+      g[i * Cc + c] = (wrt_target ? pf * ((lpf - lpq) - kl) : (pq - pf)) * inv_batch;
     }
+    acc += static_cast<double>(kl);
   }
   if (loss) {
     __shared__ double part[4];
@@ -571,12 +578,12 @@ __global__ __launch_bounds__(256) void k_kl_softmax_grad(const float* __restrict
   }
 }
 extern "C" int tfmq_kl_softmax_grad(tfmq_handle h, const float* out_q, const float* out_fp, float* g, long n_rows, int C, int batch,
-                                    float* loss_or_null, void* stream) {
+                                    int wrt_target, float* loss_or_null, void* stream) {
   TFMQ_CHECK_ARG(h, h && out_q && out_fp && g && n_rows > 0 && C > 0 && C <= 64 && batch > 0, "kl_softmax_grad: bad argument (C <= 64)");
   int blocks = ceil_div(n_rows, 256);
   if (blocks > h->cu_count * 8) blocks = h->cu_count * 8;
   hipLaunchKernelGGL(k_kl_softmax_grad, dim3(blocks), dim3(256), 0, as_stream(stream), out_q, out_fp, g, n_rows, C,
-                     1.0f / static_cast<float>(batch), loss_or_null);
+                     1.0f / static_cast<float>(batch), wrt_target, loss_or_null);
   TFMQ_LAUNCH_CHECK(h);
   return TFMQ_OK;
 }

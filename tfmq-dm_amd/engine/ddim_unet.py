@@ -38,6 +38,13 @@ class LayerQ:
         self.level, self.act_level = int(level), int(act_level)      # 2 ** bits of the weight / activation quantizer
 
 
+TAPE = None       # engine/fisher.py: GradTape of the running forward (Fisher-weighted reconstruction), else None
+
+
+def _tape():
+    return TAPE if (TAPE is not None and TAPE.recording) else None
+
+
 class _Layer:
     def __init__(self, kind, packed, aq, w32=None, wide=False):
         self.kind, self.p, self.aq = kind, packed, aq
@@ -54,6 +61,7 @@ class _Layer:
                    rowadd_ld=None, rowadd_step=None, rowadd_step_stride=0, x2=None, **_):
         if out is not None or x2 is not None or x.dtype != torch.float32:
             raise TfmqError("exact-fp32 layer: fp32 NHWC input, own output buffer, no virtual concat")
+        x_in = x
         if up2x:
             x = ops.upsample2x(x)
         B, H, W, cin = x.shape
@@ -76,7 +84,22 @@ class _Layer:
         if res is not None and res.dtype != torch.float32:
             raise TfmqError("exact-fp32 layer: fp32 residual expected (fp32 stream)")
         y = ops.gemm(col, self.w32, trans_b=True, bias=self.p.bias, rowadd=ra, rows_per_img=Ho * Wo, residual=res)
-        return y.reshape(B, Ho, Wo, cout)
+        y = y.reshape(B, Ho, Wo, cout)
+        tp = _tape()
+        if tp is not None and tp.depends(x_in, residual):
+            w32, pointwise = self.w32, col.data_ptr() == x.data_ptr()
+
+            def bwd(gouts):
+                g = gouts[0].reshape(B * Ho * Wo, cout)
+                gx = None
+                if tp.depends(x_in):
+                    dcol = ops.gemm(g, w32)                                  # dL/d(im2col rows) = g W
+                    gx = dcol.reshape(B, H, W, cin) if pointwise else ops.col2im(dcol, (B, H, W, cin), kh, kw, stride, pad)
+                    if up2x:
+                        gx = ops.upsample2x_bwd(gx)
+                return [gx, gouts[0] if residual is not None else None]
+            tp.rec([x_in, residual], [y], bwd)
+        return y
 
     def _run_wide(self, xq, **kw):
         """W8A8: (b - z_a) and (q_w - z_w) are integers of magnitude <= 255, exact in fp16; their products are exact in the fp32
@@ -418,8 +441,26 @@ class DdimUNetEngine:
         if aq is None and layer is not None:
             main_ok = half_main and self._fp_conv_half_ok(layer)
             half = main_ok and (half or not want_cat)
+        tp = _tape()
+        if tp is not None and tp.depends(x1, x2):
+            if aq is not None or half or x1.dtype != torch.float32:
+                raise TfmqError("GradTape: the differentiated tail must be un-quantised fp32 (exact mode)")
+            want_cat = want_cat or x2 is not None           # the backward needs the concatenated input
         yq, yf, xcat = ops.groupnorm(x1, self.sd[name + ".weight"], self.sd[name + ".bias"], eps, silu, aq, x2=x2,
                                      want_cat=want_cat, half_out=half)
+        if tp is not None and tp.depends(x1, x2):
+            gamma, beta, c1 = self.sd[name + ".weight"], self.sd[name + ".bias"], x1.shape[-1]
+            xin = xcat if x2 is not None else x1
+
+            def bwd(gouts):
+                gy, gcat = gouts[0], (gouts[1] if len(gouts) > 1 else None)
+                gx = ops.groupnorm_bwd(xin, gy.contiguous(), gamma, beta, eps, silu) if gy is not None else None
+                if gcat is not None:                     # the shortcut conv read the concat copy
+                    gx = gcat.contiguous().clone() if gx is None else ops.axpy(gx, gcat.contiguous(), 1.0)
+                if x2 is None:
+                    return [gx, None]
+                return [gx[..., :c1].contiguous(), gx[..., c1:].contiguous()]
+            tp.rec([x1, x2], [yf] + ([xcat] if xcat is not None else []), bwd)
         return (yq if aq is not None else yf), xcat
 
     def _o16(self) -> dict:
@@ -447,7 +488,12 @@ class DdimUNetEngine:
 
     def _attention_exact(self, q, k, v, heads: int, scale: float, aq):
         """softmax(q k^T scale) v as exact-fp32 matmuls and a row softmax (three launches per head); (fp32 out, int8 bins | None)"""
-        out, _ = ops._attention_wide(q, k, v, heads, scale, None, True)
+        tp = _tape()
+        if tp is not None and tp.depends(q, k, v):
+            from .fisher import attention_taped
+            out = attention_taped(tp, q, k, v, heads, scale)
+        else:
+            out, _ = ops._attention_wide(q, k, v, heads, scale, None, True)
         return out, (ops.quantize_act(out, aq) if aq is not None else None)
 
     def _virtual_cat_ok(self, layer: _Layer, x1, x2) -> bool:

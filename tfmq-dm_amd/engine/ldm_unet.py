@@ -19,7 +19,7 @@ import torch
 
 from .. import ops
 from .._lib import TfmqError
-from .ddim_unet import UnitReached, StopAt, DdimUNetEngine, LayerQ, _Layer
+from .ddim_unet import UnitReached, StopAt, DdimUNetEngine, LayerQ, _Layer, _tape
 
 
 def _n_children(sd, prefix):
@@ -152,6 +152,9 @@ class LdmUNetEngine(DdimUNetEngine):
         if layer.kind == "w4a8" and self.calib is None:
             return ops.layernorm(x, g, b, 1e-5, layer.aq)[0]
         yf = ops.layernorm(x, g, b, 1e-5, None)[1]
+        tp = _tape()
+        if tp is not None and tp.depends(x):
+            tp.rec([x], [yf], lambda gouts: [ops.layernorm_bwd(x.contiguous(), gouts[0].reshape(x.shape).contiguous(), g, 1e-5)])
         return self._quant_in(layer, yf, getattr(layer, "sibling_qids", ()))
 
     def _tok(self, layer: _Layer, x, **kw):
@@ -330,7 +333,11 @@ class LdmUNetEngine(DdimUNetEngine):
         if ff2.kind == "w4a8" and self.calib is None:
             g = ops.geglu(h, ff2.aq)[0]
         else:
-            g = self._quant_in(ff2, ops.geglu(h, None)[1])
+            gg = ops.geglu(h, None)[1]
+            tp = _tape()
+            if tp is not None and tp.depends(h):
+                tp.rec([h], [gg], lambda gouts: [ops.geglu_bwd(h.contiguous(), gouts[0].reshape(gg.shape).contiguous())])
+            g = self._quant_in(ff2, gg)
         return self._tok(ff2, g, residual=x, **self._o16())
 
     def _st(self, p, x, ctx, taps=None, out_aq=None):
@@ -355,6 +362,11 @@ class LdmUNetEngine(DdimUNetEngine):
         if tok.shape[0] != B:       # pair_prefix: the guidance pair parted inside this transformer; the residual is the shared tensor
             x, B = self._dup(x), tok.shape[0]
         h = tok.reshape(B, H, W, -1) if tok.dtype == torch.int8 else self._quant_in(pout, tok.reshape(B, H, W, -1))
+        if taps is not None and getattr(taps, "name", None) == p + ".proj_out":
+            # Fisher tape (engine/fisher.py): d(out + x) / d out = I, so the fused launch's output stands for the layer's own output
+            y = pout.run(h, residual=x, **self._o16())
+            taps[p + ".proj_out"] = (h, y)
+            return y
         if taps is not None:
             # the layer's own output (its reconstruction target) excludes the residual; the data path stays the fused
             # launch, so a tapped forward is bit-identical to the sampling forward

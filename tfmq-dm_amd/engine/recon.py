@@ -17,6 +17,7 @@ from typing import Dict, List, Optional, Sequence
 import torch
 
 from .. import ops
+from .._lib import TfmqError
 
 
 def temp_decay(count: int, t_max: int, warmup: float, start_b: float = 20.0, end_b: float = 2.0) -> float:
@@ -75,6 +76,19 @@ def _chunk_cuts(sizes: Sequence[int], n_chunks: int):
             cuts.append((l0, i + 1, e0, acc))
             l0, e0, k = i + 1, acc, k + 1
     return cuts
+
+
+
+def _rec_loss(unit, out, y, denom, idx):
+    """The unit's reconstruction term and its gradient: lp_loss (p = 2), or -- `unit.fisher = (mode, cached |dL/d out| + 1 of the whole
+    calibration set)` -- LossFunc's FISHER_DIAG / FISHER_FULL (reference quant/reconstruction_util.py:49-59)."""
+    fisher = getattr(unit, "fisher", None)
+    if fisher is None:
+        return ops.recon_loss(out, y, denom=denom)
+    mode, fg = fisher
+    if mode == ops.FISHER_FULL and out.dim() != 4:
+        raise TfmqError("RLOSS.FISHER_FULL sums over dims (1, 2, 3): 4-D unit outputs only (the reference raises on token tensors too)")
+    return ops.fisher_loss(out.contiguous(), y.contiguous(), fg.index_select(0, idx).contiguous(), mode, denom)
 
 
 class _Unit:
@@ -168,6 +182,9 @@ class _Unit:
         r, q = float(rec), float(rl) / (self.world_size if (self.world_size > 1 and self.allreduce is not None) else 1)
         return r + q, r, q
 
+    fisher = None       # (ops.FISHER_DIAG | FISHER_FULL, cached Fisher weights [N, ...]) or None = MSE
+    _loss = _rec_loss
+
 
 def _conv_fwd(x, layer: AdaLayer, w_gemm, pad, rowadd=None, residual=None):
     """x NHWC -> (y NHWC, col) via im2col + exact fp32 GEMM."""
@@ -193,7 +210,7 @@ class LayerUnit(_Unit):
         x, y = self.x.index_select(0, idx), self.y.index_select(0, idx)
         wg = L.soft_weight_gemm()
         out, col = _conv_fwd(x, L, wg, self.pad)
-        loss, g = ops.recon_loss(out, y, denom=out.numel() // out.shape[-1])
+        loss, g = self._loss(out, y, out.numel() // out.shape[-1], idx)
         gw = ops.gemm(g.reshape(-1, L.cout), col, trans_a=True)
         return loss, [L.grad_to_oihw(gw)]
 
@@ -225,7 +242,7 @@ class ResnetUnit(_Unit):
         else:
             sc = x
         out, col2 = _conv_fwd(a2, c2l, w2, (1, 1, 1, 1), residual=sc)
-        loss, g = ops.recon_loss(out, y, denom=B * H * W)
+        loss, g = self._loss(out, y, B * H * W, idx)
         g2 = g.reshape(B * H * W, c2l.cout)
         gw2 = ops.gemm(g2, col2, trans_a=True)
         dcol2 = ops.gemm(g2, w2)
@@ -258,7 +275,7 @@ class AttnUnit(_Unit):
         P = ops.softmax_rows(S, scale)
         o = ops.gemm(P, v)                                      # [B,T,C]
         out = ops.gemm(o.reshape(B * T, Cc), wp, trans_b=True, bias=pl.bias, residual=x.reshape(B * T, Cc)).reshape(B, H, W, Cc)
-        loss, g = ops.recon_loss(out, y, denom=B * T)
+        loss, g = self._loss(out, y, B * T, idx)
         g2 = g.reshape(B * T, Cc)
         gwp = ops.gemm(g2, o.reshape(B * T, Cc), trans_a=True)
         g_o = ops.gemm(g2, wp).reshape(B, T, Cc)
@@ -354,7 +371,7 @@ class TransformerUnit(_Unit):
         gg = ops.geglu(hcat, None)[1]                                                                  # [B*T, I]
         out = ops.gemm(gg, wf2, trans_b=True, bias=f2l.bias, residual=x2)
         # lp_loss on a [B, T, C] tensor sums over dim 1 = the tokens and averages over B * C (quant_layer.py:152-153)
-        loss, g = ops.recon_loss(out.reshape(B, T, Cc), y, denom=B * Cc)
+        loss, g = self._loss(out.reshape(B, T, Cc), y, B * Cc, idx)
         # ---- backward (weight gradients only; d/dx of the block input is not needed)
         g_out = g.reshape(B * T, Cc)
         gwf2 = ops.gemm(g_out, gg, trans_a=True)
@@ -483,6 +500,9 @@ class _DeltaUnit:
         r = float(rec)
         return r, r, 0.0
 
+    fisher = None
+    _loss = _rec_loss
+
 
 def _fixed_conv_fwd(x, L: FixedLayer, pad, rowadd=None, residual=None):
     B, H, W, _ = x.shape
@@ -511,7 +531,7 @@ class DeltaLayerUnit(_DeltaUnit):
         x, y = self.x.index_select(0, idx), self.y.index_select(0, idx)
         xq = self.q(L.qi, x) if L.qi is not None else x
         out = _fixed_conv_fwd(xq, L, self.pad)
-        loss, g = ops.recon_loss(out, y, denom=out.numel() // out.shape[-1])
+        loss, g = self._loss(out, y, out.numel() // out.shape[-1], idx)
         if L.qi is None:
             return loss, []
         g_xq = _fixed_conv_bwd_input(g, L, x.shape, self.pad)
@@ -542,7 +562,7 @@ class DeltaResnetUnit(_DeltaUnit):
         else:
             sc = x
         out = _fixed_conv_fwd(a2q, c2l, (1, 1, 1, 1), residual=sc)
-        loss, g = ops.recon_loss(out, y, denom=B * H * W)
+        loss, g = self._loss(out, y, B * H * W, idx)
         grads = [None] * self.delta.numel()
         g_a2q = _fixed_conv_bwd_input(g, c2l, a2.shape, (1, 1, 1, 1))
         if c2l.qi is not None:
@@ -581,7 +601,7 @@ class DeltaAttnUnit(_DeltaUnit):
         o = ops.gemm(P, v).reshape(B * T, Cc)
         oq = self.q(pl.qi, o) if pl.qi is not None else o
         out = ops.gemm(oq, pl.wg, trans_b=True, bias=pl.bias, residual=x.reshape(B * T, Cc)).reshape(B, H, W, Cc)
-        loss, g = ops.recon_loss(out, y, denom=B * T)
+        loss, g = self._loss(out, y, B * T, idx)
         grads = [None] * self.delta.numel()
         g_oq = ops.gemm(g.reshape(B * T, Cc), pl.wg)
         if pl.qi is not None:
@@ -651,7 +671,7 @@ class DeltaTransformerUnit(_DeltaUnit):
         hcat = lin(f0l, n3)
         gg = ops.geglu(hcat, None)[1]
         out = lin(f2l, gg, residual=x2)
-        loss, g = ops.recon_loss(out.reshape(B, T, Cc), y, denom=B * Cc)
+        loss, g = self._loss(out.reshape(B, T, Cc), y, B * Cc, idx)
         # ---- backward to the quantizer inputs
         g_out = g.reshape(B * T, Cc)
         d_gg = back(f2l, gg, g_out)

@@ -1337,9 +1337,9 @@ def upsample2x_bwd(g: torch.Tensor) -> torch.Tensor:
     return gx
 
 
-def kl_softmax_grad(out_q: torch.Tensor, out_fp: torch.Tensor, want_loss: bool = False):
+def kl_softmax_grad(out_q: torch.Tensor, out_fp: torch.Tensor, want_loss: bool = False, wrt_target: bool = False):
     """GetLayerGrad's loss (reference quant/data_utill.py:246-247) on NHWC model outputs [B,H,W,C]: kl_div(log_softmax(out_q, C),
-    softmax(out_fp, C), 'batchmean').  -> (dL/d out_q, loss [1] | None)."""
+    softmax(out_fp, C), 'batchmean').  -> (dL/d out_q -- or, wrt_target, dL/d out_fp through the un-detached target --, loss [1] | None)."""
     d = _dev(out_q)
     _chk(out_q, torch.float32, "out_q")
     _chk(out_fp, torch.float32, "out_fp")
@@ -1348,7 +1348,7 @@ def kl_softmax_grad(out_q: torch.Tensor, out_fp: torch.Tensor, want_loss: bool =
     g = _alloc_like(out_q)
     loss = torch.zeros(1, dtype=torch.float32, device=out_q.device) if want_loss else None
     Cc = out_q.shape[-1]
-    handle(d).call("kl_softmax_grad", _p(out_q), _p(out_fp), _p(g), out_q.numel() // Cc, Cc, out_q.shape[0], _p(loss), _stream(d))
+    handle(d).call("kl_softmax_grad", _p(out_q), _p(out_fp), _p(g), out_q.numel() // Cc, Cc, out_q.shape[0], int(wrt_target), _p(loss), _stream(d))
     return g, loss
 
 

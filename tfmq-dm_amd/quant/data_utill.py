@@ -85,3 +85,75 @@ def save_inout(model, layer, cali_data: Tuple[torch.Tensor], asym: bool = False,
     cached_in = (torch.cat(ins),) + ((torch.cat(tembs),) if tembs else ()) + ((torch.cat(ctxs),) if ctxs else ())
     logger.info(f"input shapes: {[tuple(c.shape) for c in cached_in]} output shape: {tuple(cached_out.shape)}")
     return cached_in, cached_out
+
+
+class GetLayerGrad:
+    """dL/d(unit output) for a batch of calibration samples (reference quant/data_utill.py:191-256): FP forward, forward of the model
+    "quantised till" the unit, loss = F.kl_div(F.log_softmax(out_q, 1), F.softmax(out_fp, 1), 'batchmean'), backward to the unit's
+    output (of the FP forward: see __call__).  The reference hooks autograd; here the engine's exact-fp32 forward records the
+    hand-written backward of every launch downstream of the unit on a tape (engine/fisher.py) and replays it.  Returns the gradient in the unit's device layout: NHWC for
+    conv-type units, [N, T, C] for transformer blocks (the layout of save_inout's cached output, which the loss kernel weights)."""
+
+    def __init__(self, model, layer, device=None, use_aq: bool = False) -> None:
+        self.model, self.layer, self.use_aq = model, layer, use_aq
+        self.device = device or next(model.model.parameters()).device
+
+    def _quantize_model_till(self):
+        """Modules are visited in definition order; every QuantLayer / quant block up to and including the unit is switched on
+        (reference :219-231)."""
+        from .quant_block import BaseQuantBlock
+        from .quant_layer import QuantLayer
+        self.model.set_quant_state(False, False)
+        for _, module in self.model.named_modules():
+            if isinstance(module, (QuantLayer, BaseQuantBlock)):
+                module.set_quant_state(True, self.use_aq)
+            if module is self.layer:
+                break
+
+    def __call__(self, xs: torch.Tensor, ts: torch.Tensor, cs: torch.Tensor = None) -> torch.Tensor:
+        from tfmq_dm_amd.engine import ddim_unet as E
+        from tfmq_dm_amd.engine.fisher import GradTape
+        model, dev = self.model, self.device
+        name = unit_name(model, self.layer)
+        x = ops.nchw_to_nhwc(xs.to(dev).float().contiguous())
+        t = ts.to(dev).float().contiguous()
+        c = None if cs is None else cs.to(dev).float().contiguous()
+        args = (x, t) if c is None else (x, t, c)
+        old = (getattr(model, "_exact_fp", False), getattr(model, "_soft_targets", False))
+        model._exact_fp, model._soft_targets = True, True
+        try:
+            model.set_quant_state(False, False)
+            tape = GradTape(name)
+            E.TAPE = tape
+            try:
+                out_fp = model.engine(dev).forward(*args, taps=tape)
+            finally:
+                E.TAPE = None
+            if out_fp is None or tape.leaf is None:
+                raise KeyError(f"GetLayerGrad: the engine exposes no tap for unit '{name}'")
+            self._quantize_model_till()
+            out_q = model.engine(dev).forward(*args)
+            # WHICH gradient the reference caches: softmax(out_fp) is not detached, so loss.backward() runs through BOTH forwards, the
+            # unit's backward hook fires once per forward and GradSaverHook keeps the last call -- autograd reaches the earlier (FP)
+            # forward last.  What save_grad caches is therefore dL/d(unit output of the FP pass) through the TARGET branch of the KL
+            # term (to first order the negative of the out_q branch; Fisher weights use |g| and g^2).  Reproduced as released.
+            g_out, _ = ops.kl_softmax_grad(out_q.contiguous(), out_fp.contiguous(), wrt_target=True)
+            grad = tape.backward(out_fp, g_out)
+        finally:
+            model._exact_fp, model._soft_targets = old
+            model.set_quant_state(False, False)
+            self.layer.set_quant_state(True, self.use_aq)
+        return grad
+
+
+def save_grad(model, layer, cali_data: Tuple[torch.Tensor], damping: float = 1., use_aq: bool = False, batch_size: int = 32,
+              keep_gpu: bool = True) -> torch.Tensor:
+    """Fisher weights of a unit for the whole calibration set: |dL/d(unit output)| + 1.0 (reference :54-73), on the device, in the
+    unit's device layout (see GetLayerGrad)."""
+    dev = next(model.model.parameters()).device
+    get_grad = GetLayerGrad(model, layer, dev, use_aq)
+    grads = []
+    for i in range(0, cali_data[0].size(0), batch_size):
+        grads.append(get_grad(*(_[i: i + batch_size] for _ in cali_data)))
+    g = torch.cat(grads)
+    return g.abs_().add_(1.0)

@@ -135,8 +135,9 @@ class QuantModel(nn.Module):
         key = []
         for n, l in self.named_quant_layers():
             key.append((n, l.use_wq, l.use_aq and not l.disable_aq, id(l.wqtizer), getattr(l.wqtizer, "_version_", 0),
-                        l.w.data_ptr(), l.w._version))
+                        l.w.data_ptr(), l.w._version, bool(getattr(self, "_soft_targets", False) and getattr(l.wqtizer, "soft_tgt", False))))
         key.append(tuple(name for _, _, name, _ in self.attn_quantizers()))
+        key.append(bool(getattr(self, "_exact_fp", False)))
         return tuple(key)
 
     def invalidate(self):
@@ -208,7 +209,17 @@ class QuantModel(nn.Module):
         qid = {n: i for i, n in enumerate(act_names)}
         for n, mod in self.model.named_modules():
             if isinstance(mod, QuantLayer):
-                if mod.use_wq:
+                if mod.use_wq and getattr(self, "_soft_targets", False) and getattr(mod.wqtizer, "soft_tgt", False):
+                    # GetLayerGrad runs the unit under reconstruction with its AdaRound quantizers in the SOFT state (reference
+                    # adaptive_rounding.py:54-58: floor(w / delta) + h(alpha), not rounded): an un-quantised layer with those weights
+                    if mod.use_aq and not mod.disable_aq:
+                        raise TfmqError("QuantModel: soft-target weights together with a live activation quantizer have no engine plan")
+                    q = mod.wqtizer
+                    sd[n + ".weight"] = ops.adaround_soft_fwd(mod.w.detach().float().contiguous(), q.alpha.detach().float().contiguous(),
+                                                              q.delta.detach(), q.zero_point.detach(), q.level, hard=False)
+                    if mod.b is not None:
+                        sd[n + ".bias"] = mod.b.detach()
+                elif mod.use_wq:
                     d, z, a = mod.weight_quant_state()
                     sd[n + ".weight"] = mod.w.detach()
                     if mod.b is not None:
@@ -222,6 +233,8 @@ class QuantModel(nn.Module):
                 for pn, p in mod.named_parameters(recurse=False):
                     sd[f"{n}.{pn}"] = p.detach()
         eng = engine_cls(sd, self.model.engine_cfg(), device)
+        if getattr(self, "_exact_fp", False):     # save_grad / GetLayerGrad: the differentiated forward runs in the exact-fp32 mode
+            eng.exact_fp, eng.stream_f16 = True, False
         if not hasattr(self, "_tiles"):
             self._tiles = {}
         eng.tiles = self._tiles      # measured tile shapes survive re-lowering (keys are shapes, not weights)

@@ -18,11 +18,11 @@ from tfmq_dm_amd import ops
 from tfmq_dm_amd._lib import TfmqError
 from tfmq_dm_amd.engine import recon as R
 from .adaptive_rounding import AdaRoundQuantizer, RMODE
-from .data_utill import save_inout
+from .data_utill import save_inout, save_grad
 from .quant_block import (BaseQuantBlock, QuantAttnBlock, QuantBasicTransformerBlock, QuantResBlock, QuantResnetBlock,
                           QuantTemporalInformationBlock, QuantTemporalInformationBlockDDIM)
 from .quant_layer import QuantLayer, StraightThrough
-from .reconstruction_util import RLOSS, LossFunc, LossFuncTimeEmbedding
+from .reconstruction_util import RLOSS, LossFunc, LossFuncTimeEmbedding, fisher_mode
 
 logger = logging.getLogger(__name__)
 
@@ -37,9 +37,10 @@ def _dist_kw(multi_gpu: bool):
 def _to_adaround(layer: QuantLayer) -> AdaRoundQuantizer:
     """module.wqtizer = AdaRoundQuantizer(uaqtizer=..., w=original_w) with soft targets on."""
     d, z, _ = layer.weight_quant_state()
-    if not isinstance(layer.wqtizer, AdaRoundQuantizer):
-        layer.wqtizer = AdaRoundQuantizer(uaqtizer=layer.wqtizer, rmode=RMODE.LEARNED_HARD_SIGMOID,
-                                          w=layer.original_w.data.to(layer.w.device))
+    # the reference wraps unconditionally (reconstruction.py:49-52,113-128): a layer that already carries a learned AdaRoundQuantizer
+    # (a checkpoint loaded with load_cali_model, then reconstructed again) starts over from the soft initialisation of original_w
+    layer.wqtizer = AdaRoundQuantizer(uaqtizer=layer.wqtizer, rmode=RMODE.LEARNED_HARD_SIGMOID,
+                                      w=layer.original_w.data.to(layer.w.device))
     layer.wqtizer.soft_tgt = True
     return layer.wqtizer
 
@@ -108,6 +109,14 @@ def _quant_emb_projection(layer: QuantLayer, emb: torch.Tensor) -> torch.Tensor:
     return ops.gemm(s_, w, trans_b=True, bias=None if layer.b is None else layer.b.data.float().contiguous())
 
 
+def _attach_fisher(unit, model, layer, cali_data, opt_mode, asym, use_aq, batch_size, keep_gpu):
+    """opt_mode != MSE (reference :58-61,177-180): cache |dL/d(unit output)| + 1 of the whole calibration set (save_grad) and let the
+    unit's loss kernel weight the reconstruction error with it."""
+    if opt_mode == RLOSS.MSE:
+        return
+    unit.fisher = (fisher_mode(opt_mode), save_grad(model, layer, cali_data, asym, use_aq, batch_size, keep_gpu))
+
+
 LOSS_TRACE = None     # tests: {"counts": (...), "rows": [], "unit": 0} -> rows of (unit index, count, rec, round) at those counts
 
 
@@ -135,8 +144,6 @@ def layer_reconstruction(model, layer: QuantLayer, cali_data: Tuple[torch.Tensor
     layer.set_quant_state(use_wq=True, use_aq=use_aq)
     if use_aq:
         # delta learning (reference :36-48): the layer's activation delta under Adam(lr) + cosine annealing, weights fixed
-        if opt_mode != RLOSS.MSE:
-            raise NotImplementedError("Fisher-weighted reconstruction losses are not built (DESIGN.md section 7)")
         ds = _DeltaSet()
         fl = ds.fixed(layer)
         loss_func = LossFunc(o=layer, round_loss=RLOSS.NONE, w=w, max_count=iters, rec_loss=opt_mode, b_range=b_range,
@@ -146,6 +153,7 @@ def layer_reconstruction(model, layer: QuantLayer, cali_data: Tuple[torch.Tensor
             return                      # `disable_aq` layer: the reference's optimiser has an un-used parameter and nothing moves
         ph, pw = layer.fwd_kwargs.get("padding", (0, 0))
         unit = R.DeltaLayerUnit(fl, cached_inputs[0], cached_outputs, pad=(ph, pw, ph, pw), **ds.kw(iters, lr, multi_gpu))
+        _attach_fisher(unit, model, layer, cali_data, opt_mode, asym, use_aq, batch_size, keep_gpu)
         _run(unit, cached_inputs[0].size(0), batch_size, iters, loss_func, cached_outputs.device)
         ds.commit(unit)
         model.invalidate()
@@ -157,6 +165,7 @@ def layer_reconstruction(model, layer: QuantLayer, cali_data: Tuple[torch.Tensor
     ph, pw = layer.fwd_kwargs.get("padding", (0, 0))
     unit = R.LayerUnit(ada, cached_inputs[0], cached_outputs, pad=(ph, pw, ph, pw), iters=iters, w=w, warmup=warmup, b_range=b_range,
                        **_dist_kw(multi_gpu))
+    _attach_fisher(unit, model, layer, cali_data, opt_mode, asym, use_aq, batch_size, keep_gpu)
     _run(unit, cached_inputs[0].size(0), batch_size, iters, loss_func, cached_outputs.device)
     _commit(layer, ada)
     model.invalidate()
@@ -229,6 +238,7 @@ def block_reconstruction(model, block: BaseQuantBlock, cali_data: torch.Tensor, 
         layers = list(zip(mods, adal))
     else:
         raise TfmqError(f"block_reconstruction: no reconstruction unit for {type(block).__name__} yet")
+    _attach_fisher(unit, model, block, cali_data, opt_mode, asym, use_aq, batch_size, keep_gpu)
     _run(unit, cached_inputs[0].size(0), batch_size, iters, loss_func, dev)
     for layer, ada in layers:
         _commit(layer, ada)
@@ -240,8 +250,6 @@ def _block_delta_learning(model, block, cali_data, batch_size, iters, w, opt_mod
     QuantLayers, weights fixed.  Built for QuantResnetBlock, QuantResBlock, QuantAttnBlock, QuantBasicTransformerBlock
     with the attention-matmul quantizers off (the state every driver leaves them in); live attention quantizers raise NotImplementedError
     (DESIGN.md section 7)."""
-    if opt_mode != RLOSS.MSE:
-        raise NotImplementedError("Fisher-weighted reconstruction losses are not built (DESIGN.md section 7)")
     if getattr(block, "use_aq", False) or any(getattr(m, "delta", None) is not None for n, m in block.named_modules()
                                                     if n.split(".")[-1] in ("aqtizer_q", "aqtizer_k", "aqtizer_v", "aqtizer_w")):
         raise NotImplementedError("delta learning with live attention-matmul quantizers is not built (DESIGN.md section 7)")
@@ -282,6 +290,7 @@ def _block_delta_learning(model, block, cali_data, batch_size, iters, w, opt_mod
         unit = R.DeltaTransformerUnit(fl, norms, block.attn1.heads, x, ctx, cached_outputs, **ds.kw(iters, lr, multi_gpu))
     else:
         raise NotImplementedError(f"delta-learning reconstruction of {type(block).__name__} is not built (DESIGN.md section 7)")
+    _attach_fisher(unit, model, block, cali_data, opt_mode, asym, True, batch_size, keep_gpu)
     _run(unit, cached_inputs[0].size(0), batch_size, iters, loss_func, dev)
     ds.commit(unit)
     model.invalidate()

@@ -37,8 +37,8 @@ class LossFunc:
     def __init__(self, o, round_loss: RLOSS = RLOSS.RELAXATION, w: float = 1.0, rec_loss: RLOSS = RLOSS.MSE,
                  max_count: int = 2000, b_range: tuple = (10, 2), decay_start: float = 0.0, warmup: float = 0.0,
                  p: float = 2.0) -> None:
-        if rec_loss != RLOSS.MSE:
-            raise NotImplementedError("Fisher-weighted reconstruction is never selected by the drivers (SURVEY §8f-4)")
+        if rec_loss not in (RLOSS.MSE, RLOSS.FISHER_DIAG, RLOSS.FISHER_FULL):
+            raise ValueError("Not supported reconstruction loss function: {}".format(rec_loss))
         if p != 2.0:
             raise NotImplementedError("lp_loss with p != 2 is not on the hot path")
         self.o, self.round_loss, self.w, self.rec_loss, self.p = o, round_loss, w, rec_loss, p
@@ -58,6 +58,12 @@ class LossFunc:
         if self.count % print_freq == 0 and rank0:
             logger.info("Total loss:\t{:.8f} (rec:{:.8f}, round:{:.8f})\tb={:.2f}\tcount={}".format(
                 float(total), float(rec), float(rnd), b, self.count))
+
+
+def fisher_mode(rec_loss: RLOSS):
+    """RLOSS -> the device loss kernel's mode (ops.FISHER_DIAG / FISHER_FULL), None for the plain lp_loss."""
+    from tfmq_dm_amd import ops
+    return {RLOSS.MSE: None, RLOSS.FISHER_DIAG: ops.FISHER_DIAG, RLOSS.FISHER_FULL: ops.FISHER_FULL}[rec_loss]
 
 
 class LossFuncTimeEmbedding(LossFunc):
