@@ -32,6 +32,13 @@ def uaq2adar(model: nn.Module):
             if not child.ignore_recon:
                 for sub in child.modules():
                     if isinstance(sub, QuantLayer):
+                        if hasattr(sub, "wqtizer1"):        # QDIFF-split layer: one AdaRound quantizer per input-channel half (reference :35-40)
+                            ow, sp = sub.original_w.data.to(sub.w.device), sub.split
+                            sub._wq_state(sub.wqtizer, sub.w.data[:, :sp])
+                            sub._wq_state(sub.wqtizer1, sub.w.data[:, sp:])
+                            sub.wqtizer = AdaRoundQuantizer(sub.wqtizer, rmode=RMODE.LEARNED_HARD_SIGMOID, w=ow[:, :sp, ...])
+                            sub.wqtizer1 = AdaRoundQuantizer(sub.wqtizer1, rmode=RMODE.LEARNED_HARD_SIGMOID, w=ow[:, sp:, ...])
+                            continue
                         sub.weight_quant_state()
                         sub.wqtizer = AdaRoundQuantizer(sub.wqtizer, rmode=RMODE.LEARNED_HARD_SIGMOID,
                                                         w=sub.original_w.data.to(sub.w.device))

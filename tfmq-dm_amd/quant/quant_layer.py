@@ -275,45 +275,90 @@ class QuantLayer(nn.Module):
     def weight_quant_state(self):
         """(delta, zero_point, alpha|None) of the weight quantizer, initialising it lazily exactly
         like `self.wqtizer(self.w)` would (reference :330-333)."""
-        q = self.wqtizer
+        if self.split != 0 and QMODE.QDIFF.value in self.aq_mode:
+            raise TfmqError("QuantLayer: a QDIFF-split layer (two quantizer pairs, reference :310-329) runs through its own forward; the "
+                            "fused engine plan and the block reconstruction units take un-split layers only (the tree rewrite never "
+                            "produces a split one: quant_model.py:57-58 keeps skip / shortcut convs un-quantised)")
+        return self._wq_state(self.wqtizer, self.w.data)
+
+    @staticmethod
+    def _wq_state(q, w):
         if isinstance(q, UniformAffineQuantizer):
             if not q.init:
-                q.delta, q.zero_point = q._init_quantization_param(self.w.data, q.channel_wise)
+                q.delta, q.zero_point = q._init_quantization_param(w, q.channel_wise)
                 q.init = True
             return q.delta.detach(), q.zero_point.detach(), None
         return q.delta.detach(), q.zero_point.detach(), q.alpha.detach()  # AdaRoundQuantizer (hard rounding)
 
-    def _pack(self, mode: str):
-        key = (mode, self.w.data_ptr(), id(self.wqtizer), getattr(self.wqtizer, "_version_", 0))
-        if self._packed is not None and self._packed[0] == key:
-            return self._packed[1]
+    def _pack(self, mode: str, part: int = 0):
+        """part 0: the whole layer; 1 / 2: the input-channel halves [:split] / [split:] of a QDIFF-split layer with their own weight
+        quantizers (reference :325-329); the bias rides with part 1."""
+        wq = self.wqtizer if part < 2 else self.wqtizer1
+        aq = self.aqtizer if part < 2 else self.aqtizer1
+        key = (mode, part, self.split, self.w.data_ptr(), id(wq), getattr(wq, "_version_", 0))
+        hit = self._packed.get(part) if isinstance(self._packed, dict) else None
+        if hit is not None and hit[0] == key:
+            return hit[1]
+        if not isinstance(self._packed, dict):
+            self._packed = {}
         dev = self.w.device
-        b = None if self.b is None else (self.b if mode != "fp" else self.original_b.to(dev)).detach().float().contiguous()
+        sl = slice(None) if part == 0 else (slice(0, self.split) if part == 1 else slice(self.split, None))
+        b = None if (self.b is None or part == 2) else (self.b if mode != "fp" else self.original_b.to(dev)).detach().float().contiguous()
         if mode == "fp":
-            pk = ops.pack_w_f16(self.original_w.to(dev).float().contiguous(), b)
+            pk = ops.pack_w_f16(self.original_w.to(dev)[:, sl].float().contiguous(), b)
         else:
-            d, z, a = self.weight_quant_state()
-            w = self.w.detach().float().contiguous()
+            w = self.w.detach()[:, sl].float().contiguous()
+            d, z, a = self._wq_state(wq, w)
             a = None if a is None else a.float().contiguous()
-            if mode == "w4a8" and (not 2 <= self.wqtizer.level <= 2048 or self.aqtizer.level != 256):
-                raise TfmqError(f"QuantLayer: the device path is 2..2048-level weights x 8-bit activations; got {self.wqtizer.level} weight "
-                                f"levels / {self.aqtizer.level} activation levels")
+            if mode == "w4a8" and (not 2 <= wq.level <= 2048 or aq.level != 256):
+                raise TfmqError(f"QuantLayer: the device path is 2..2048-level weights x 8-bit activations; got {wq.level} weight "
+                                f"levels / {aq.level} activation levels")
             # more than 16 weight levels (--wq 8): the fp16 integer grid, run on the fp16-operand kernels (engine _Layer._run_wide)
-            int8_path = mode == "w4a8" and self.wqtizer.level <= 16
-            pk = ops.pack_w4(w, d, z, a, b) if int8_path else ops.pack_w_f16(w, b, d, z, a, self.wqtizer.level)
-        self._packed = (key, pk)
+            int8_path = mode == "w4a8" and wq.level <= 16
+            pk = ops.pack_w4(w, d, z, a, b) if int8_path else ops.pack_w_f16(w, b, d, z, a, wq.level)
+        self._packed[part] = (key, pk)
         return pk
+
+    def _run(self, xn, mode: str, part: int, stride: int, pad, residual=None):
+        """One launch on NHWC input `xn` (fp32): the layer, or one input-channel half of a split layer (its output accumulates onto
+        `residual`, the other half's)."""
+        aqt = self.aqtizer if part < 2 else self.aqtizer1
+        pk = self._pack(mode, part)
+        if mode == "w4a8":
+            if not aqt.init:
+                aqt(xn)  # lazy init on this tensor (mse / minmax), reference :211-221
+            elif aqt.running_stat:
+                aqt.act_momentum_update(xn)
+            zp = aqt.zero_point
+            zp = zp.detach() if torch.is_tensor(zp) else torch.tensor(float(zp), device=xn.device)
+            qt = torch.stack([aqt.delta.detach().reshape(()), zp.reshape(())]).reshape(1, 1, 2).contiguous()
+            sel = ops.qsel(qt)
+            xq = ops.quantize_act(xn, sel)
+            if isinstance(pk, ops.PackedW4):
+                return ops.conv2d_w4a8(xq, pk, sel, stride=stride, pad=pad, residual=residual)
+            # W8A8: exact integer grids on the fp16-operand kernel, output scale delta_a * delta_w[c]
+            pf = ops.PackedF16(pk.w16, pk.bias, pk.cout, pk.cin, pk.kh, pk.kw, wscale=ops.scale_by_qdelta(pk.wscale, sel))
+            return ops.conv2d_f16(ops.bins_to_grid(xq, sel, half=ops.f16_dma_ok(pk.cin, pk.kh, pk.kw)), pf, stride=stride, pad=pad, residual=residual)
+        return ops.conv2d_f16(xn, pk, stride=stride, pad=pad, residual=residual)
 
     def forward(self, x: torch.Tensor, split: int = 0) -> torch.Tensor:
         if split != 0 and self.split == 0:
-            self.split = split  # QDIFF split bookkeeping only: shortcuts are never QuantLayers (SURVEY §0-1)
+            # reference :310-316: the first call with a split records it and, under QMODE.QDIFF, creates the second quantizer pair
+            # (input channels [split:] of the concatenated input of an up-path shortcut get quantizers of their own).  In the released
+            # tree the tree rewrite never wraps skip / shortcut convs (quant_model.py:57-58), so only a hand-built QuantLayer gets here.
+            self.split = split
+            if QMODE.QDIFF.value in self.aq_mode:
+                self.aqtizer1 = UniformAffineQuantizer(**self.aq_params)
+                self.wqtizer1 = UniformAffineQuantizer(**self.wq_params)
         if not x.is_cuda:
             raise TfmqError("QuantLayer.forward: CPU tensor (the HIP kernels are the only implementation)")
         quant_act = self.use_aq and not self.disable_aq
         mode = "fp" if not self.use_wq else ("w4a8" if quant_act else "w4")
+        qdiff = self.split != 0 and QMODE.QDIFF.value in self.aq_mode
         x = x.float()
         if quant_act and not self.use_wq:
-            x = self.aqtizer(x)  # act-only fake quant then FP weights (never used by the drivers)
+            # act-only fake quant then FP weights (never used by the drivers)
+            x = torch.cat([self.aqtizer(x[:, :self.split].contiguous()), self.aqtizer1(x[:, self.split:].contiguous())], dim=1) if qdiff else self.aqtizer(x)
         if self.kind == "conv2d":
             xn = ops.nchw_to_nhwc(x.contiguous())
             ph, pw_ = self.fwd_kwargs["padding"]
@@ -324,24 +369,13 @@ class QuantLayer(nn.Module):
             shape_out = x.shape[:-1]
             xn = x.reshape(-1, 1, 1, x.shape[-1]).contiguous()
             stride, pad = 1, (0, 0, 0, 0)
-        pk = self._pack(mode)
-        if mode == "w4a8":
-            if not self.aqtizer.init:
-                self.aqtizer(xn)  # lazy init on this tensor (mse / minmax), reference :211-221
-            elif self.aqtizer.running_stat:
-                self.aqtizer.act_momentum_update(xn)
-            zp = self.aqtizer.zero_point
-            zp = zp.detach() if torch.is_tensor(zp) else torch.tensor(float(zp), device=x.device)
-            qt = torch.stack([self.aqtizer.delta.detach().reshape(()), zp.reshape(())]).reshape(1, 1, 2).contiguous()
-            sel = ops.qsel(qt)
-            xq = ops.quantize_act(xn, sel)
-            if isinstance(pk, ops.PackedW4):
-                y = ops.conv2d_w4a8(xq, pk, sel, stride=stride, pad=pad)
-            else:       # W8A8: exact integer grids on the fp16-operand kernel, output scale delta_a * delta_w[c]
-                pf = ops.PackedF16(pk.w16, pk.bias, pk.cout, pk.cin, pk.kh, pk.kw, wscale=ops.scale_by_qdelta(pk.wscale, sel))
-                y = ops.conv2d_f16(ops.bins_to_grid(xq, sel, half=ops.f16_dma_ok(pk.cin, pk.kh, pk.kw)), pf, stride=stride, pad=pad)
+        if qdiff and mode != "fp":
+            # y = conv(cat(q(x1), q1(x2)), cat(Q(w1), Q1(w2))) + b = [conv(q(x1), Q(w1)) + b] + conv(q1(x2), Q1(w2)): two launches, the
+            # second accumulating onto the first (integer sums per half, one fp32 affine map each)
+            y = self._run(xn[..., :self.split].contiguous(), mode, 1, stride, pad)
+            y = self._run(xn[..., self.split:].contiguous(), mode, 2, stride, pad, residual=y)
         else:
-            y = ops.conv2d_f16(xn, pk, stride=stride, pad=pad)
+            y = self._run(xn, mode, 0, stride, pad)
         y = ops.nhwc_to_nchw(y) if self.kind == "conv2d" else y.reshape(tuple(shape_out) + (y.shape[-1],))
         return self.act_func(y)
 
@@ -351,3 +385,5 @@ class QuantLayer(nn.Module):
 
     def set_running_stat(self, running_stat: bool) -> None:
         self.aqtizer.running_stat = running_stat
+        if self.split != 0 and QMODE.QDIFF.value in self.aq_mode:
+            self.aqtizer1.running_stat = running_stat
