@@ -223,6 +223,16 @@ typedef struct tfmq_conv_desc {
                                     pointwise, DMA tile kernels) then take such layers too: their last K-step of a pixel reads 32 bytes
                                     past its channel row (the next pixel's, times zero weights), so x must be followed by >= 32 readable
                                     bytes.  NULL: those layers run on the register-staged kernel with 32-channel K-steps */
+  int32_t ksplit;                /* tfmq_conv2d_w4a8 on the LDS-DMA tile kernels (tile = TFMQ_TILE_128 / _64 / _128x64 / _256 or the rule's
+                                    choice of one of them), 0 / 1 = off.  k > 1: every output tile is computed by k workgroups, each over
+                                    a contiguous 1/k of the K-steps; they publish their int32 partial sums to a slab of the handle's
+                                    workspace and take a ticket, and the last arriver adds the slabs and runs the epilogue.  Integer sums:
+                                    the result is bit-identical to the unsplit launch.  For launches whose M x Cout grid has fewer tiles
+                                    than the chip has CUs and whose K is long -- the 1280-channel 3x3 convs at 8x8 / 16x16 of a
+                                    UNet(2) forward (1 image under guidance) stream 14.7 MB of weights through 10 ... 40 CUs otherwise.
+                                    Needs tiles * k * tile elements <= 16 Mi (the handle's 64 MiB of slabs) and k <= K-steps, else
+                                    TFMQ_ERR_ARG; split-K launches of one handle must be stream-ordered.  Ignored by the slab /
+                                    register-direct kernels (pin a tile shape together with ksplit). */
 } tfmq_conv_desc;
 enum { TFMQ_OUT_F32 = 0, TFMQ_OUT_F16 = 1, TFMQ_OUT_GEGLU_Q8 = 2, TFMQ_OUT_Q8 = 3 };
 enum { TFMQ_TILE_AUTO = 0, TFMQ_TILE_128 = 1, TFMQ_TILE_64 = 2, TFMQ_TILE_256 = 3, TFMQ_TILE_128x64 = 4, TFMQ_TILE_SLAB = 5, TFMQ_TILE_DIRECT = 6,

@@ -16,4 +16,4 @@ eng = info["oracle_state"]["eng"] if "oracle_state" in info else info["eng"]
 names = ops._TILE_NAMES
 keys = ("kind", "B", "H", "W", "Cin", "Cout", "KH", "stride", "up2x", "out_mode", "res", "stats", "seg", "x_f16", "yt")
 for k, v in sorted(eng.tiles.items(), key=lambda kv: str(kv[0])):
-    print(names.get(v, "auto"), "|", " ".join(f"{a}={b}" for a, b in zip(keys, k)))
+    print(ops.tile_name(v), "|", " ".join(f"{a}={b}" for a, b in zip(keys, k)))

@@ -29,7 +29,7 @@ def test_header_symbols_all_exported(lib):
     l = lib.load()
     for name in declared:
         assert hasattr(l, name), name
-    assert l.tfmq_abi_version() == 6
+    assert l.tfmq_abi_version() == 7
 
 
 def test_struct_layouts_match_header(lib):

@@ -151,7 +151,14 @@ def test_tile_variants_are_bit_identical(ops, k, res, mode, B, H):
     else:
         kw["want_stats"] = True
     outs = []
-    for tile in (1, 2, 3, 4):
+    # codes >= 256: the split-K form of a tile kernel, ksplit = code >> 8 workgroups per output tile (tfmq_conv_desc.ksplit); K-steps: 18
+    # for the 3x3 layers here, 2 for the pointwise ones
+    splits = (1 | 2 << 8, 1 | 5 << 8, 2 | 9 << 8, 4 | 18 << 8, 3 | 3 << 8) if k == 3 else (1 | 2 << 8, 2 | 2 << 8)
+    def fits(code):       # the handle's slab workspace: tiles * ksplit * tile elements <= 16 Mi (else TFMQ_ERR_ARG, by design)
+        bm, bn = {1: (128, 128), 2: (128, 128), 3: (256, 128), 4: (128, 64)}[code & 0xff]
+        return -(-B * H * W // bm) * -(-cout // bn) * bm * bn * (code >> 8) <= (16 << 20)
+    splits = tuple(c for c in splits if fits(c))
+    for tile in (1, 2, 3, 4) + splits + splits[:1]:          # (a split form twice: the arrival tickets are zero again after a launch)
         ops.set_conv_autotune({})
         try:
             import tfmq_dm_amd.ops as _o
@@ -173,8 +180,58 @@ def test_tile_variants_are_bit_identical(ops, k, res, mode, B, H):
         y = ops.conv2d_w4a8(xq, pw, sel, **kw)
     finally:
         ops.set_conv_autotune(None)
-    assert len(cache) == 1 and list(cache.values())[0] in (1, 2, 3, 4, 5, 6, 7, 8)
+    assert len(cache) == 1 and (list(cache.values())[0] & 0xff) in (1, 2, 3, 4, 5, 6, 7, 8)
     assert torch.equal(y, outs[0][0])
+
+
+def test_split_k_small_batch_shapes_are_bit_identical(ops):
+    """The launches split-K is for: the 1280-channel 3x3 convs at 8x8 / 16x16 of a UNet(2) forward (1 image under guidance) -- one or four
+    128-pixel row tiles, 180 / 360 K-steps.  Every split form, launched repeatedly (slab workspace and tickets are reused), equals the
+    unsplit tile kernel bit for bit: fp16-stream output with residual and GroupNorm statistics, and the int8 output mode."""
+    import tfmq_dm_amd.ops as _o
+    g = torch.Generator().manual_seed(31)
+    for (B, H, cin, cout, mode) in ((2, 8, 1280, 1280, "f16"), (2, 16, 2560, 1280, "f16"), (2, 8, 1280, 1280, "q8"), (3, 8, 640, 320, "f32")):
+        x = torch.randn(B, H, H, cin, generator=g) * 1.3 - 0.2
+        w = torch.randn(cout, cin, 3, 3, generator=g) * (2.0 / (cin * 9) ** 0.5)
+        b = torch.randn(cout, generator=g) * 0.2
+        wd, wz = O.init_channelwise(w, 16, "minmax")
+        ad, az = O.minmax(x, 256)
+        sel = ops.qsel(qtab(ad, az))
+        xq = ops.quantize_act(x.to(DEV), sel)
+        pw = ops.pack_w4(w.to(DEV), wd.to(DEV), wz.to(DEV), bias=b.to(DEV))
+        r = torch.randn(B, H, H, cout, generator=g).to(DEV)
+        kw = dict(pad=(1, 1, 1, 1))
+        if mode == "f16":
+            kw.update(out_f16=True, residual=r.half(), want_stats=True)
+        elif mode == "q8":
+            kw.update(out_q8=ops.qsel(qtab(0.03, 117.0)), residual=r)
+        else:
+            kw.update(residual=r, want_stats=True)
+        ref = None
+        for code in (1, 1 | 16 << 8, 2 | 6 << 8, 4 | 12 << 8, 1 | 16 << 8, 1 | 7 << 8, 1 | 16 << 8):
+            ops.set_conv_autotune({})
+            try:
+                orig = _o._tune_conv
+                _o._tune_conv = lambda h, name, kind, d, dsc, t=code: t
+                y = ops.conv2d_w4a8(xq, pw, sel, **kw)
+                st = y._tfmq_stats[0].clone() if hasattr(y, "_tfmq_stats") else None
+            finally:
+                _o._tune_conv = orig
+                ops.set_conv_autotune(None)
+            if ref is None:
+                ref = (y.clone(), st)
+            else:
+                assert torch.equal(y, ref[0]), (B, H, cin, mode, code)
+                assert st is None or torch.equal(st, ref[1]), (B, H, cin, mode, code)
+    # the measured selection may now return a split form; it must still be the same bits
+    cache = {}
+    ops.set_conv_autotune(cache)
+    try:
+        y = ops.conv2d_w4a8(xq, pw, sel, **kw)
+    finally:
+        ops.set_conv_autotune(None)
+    assert torch.equal(y, ref[0])
+    print("selected for", (B, H, cin, cout), ":", _o.tile_name(list(cache.values())[0]))
 
 
 @pytest.mark.parametrize("B,H,cin,cout,res,mode", [

@@ -39,7 +39,7 @@ class ConvDesc(C.Structure):
         ("ldy", C.c_int32), ("y_coff", C.c_int32),
         ("stats", c_void_p), ("stats_seg", C.c_int32), ("out_mode", C.c_int32),
         ("oq", QSel), ("yq", c_void_p), ("yt", c_void_p), ("t_col0", C.c_int32), ("x_f16", C.c_int32), ("tile", C.c_int32), ("res_f16", C.c_int32),
-        ("x2", c_void_p), ("cin1", C.c_int32), ("w64", c_void_p),
+        ("x2", c_void_p), ("cin1", C.c_int32), ("w64", c_void_p), ("ksplit", C.c_int32),
     ]
 
 

@@ -25,6 +25,13 @@ struct tfmq_ctx {
   // RCCL communicator of the sharded calibration (comm.hip); opaque here so that no kernel file needs rccl.h
   void* comm = nullptr;
   int comm_rank = 0, comm_world = 0;
+  // split-K of the w4a8 tile kernel (tfmq_conv_desc.ksplit): int32 partial slabs [tile][slice][BM * BN] and one arrival ticket per
+  // tile (zero between launches: the last arriver resets it).  Allocated with the handle; split-K launches of one handle are
+  // stream-ordered (one stream at a time), like gemm_ws.
+  int* ksplit_ws = nullptr;
+  int* ksplit_cnt = nullptr;
+  static constexpr size_t KSPLIT_WS_INTS = static_cast<size_t>(16) << 20;      // 64 MiB: 1024 slabs of 128 x 128
+  static constexpr int KSPLIT_MAX_TILES = 65536;
   // operand precision of tfmq_gemm_f32's matrix-core path (tfmq_set_gemm_precision): 0 exact fp32, 1 bf16x3 split, 2 fp16
   int gemm_prec = 0;
 };

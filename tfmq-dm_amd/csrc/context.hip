@@ -1,7 +1,7 @@
 // Handle, device query, hipGraph capture helpers and HIP-event timing.
 #include "common.hpp"
 
-extern "C" int tfmq_abi_version(void) { return 6; }   // 6: + Fisher-weighted reconstruction (upsample2x_bwd, kl_softmax_grad, fisher_loss); 3: tfmq_conv_desc grew x2 / cin1; 4: + w64 (round 2); 5: + W8A8 / attention-quantizer / GEMM-precision entry points, TFMQ_TILE_SLAB128 (round 3)
+extern "C" int tfmq_abi_version(void) { return 7; }   // 7: tfmq_conv_desc.ksplit (split-K of the w4a8 tile kernel); 6: + Fisher-weighted reconstruction (upsample2x_bwd, kl_softmax_grad, fisher_loss); 3: tfmq_conv_desc grew x2 / cin1; 4: + w64 (round 2); 5: + W8A8 / attention-quantizer / GEMM-precision entry points, TFMQ_TILE_SLAB128 (round 3)
 
 extern "C" int tfmq_create(int device, tfmq_handle* out) {
   if (!out) return TFMQ_ERR_ARG;
@@ -26,6 +26,15 @@ extern "C" int tfmq_create(int device, tfmq_handle* out) {
       return TFMQ_ERR_HIP;
     }
   }
+  if (hipMalloc(reinterpret_cast<void**>(&c->ksplit_ws), tfmq_ctx::KSPLIT_WS_INTS * sizeof(int)) != hipSuccess ||
+      hipMalloc(reinterpret_cast<void**>(&c->ksplit_cnt), tfmq_ctx::KSPLIT_MAX_TILES * sizeof(int)) != hipSuccess ||
+      hipMemset(c->ksplit_cnt, 0, tfmq_ctx::KSPLIT_MAX_TILES * sizeof(int)) != hipSuccess) {
+    if (c->ksplit_ws) (void)hipFree(c->ksplit_ws);
+    if (c->ksplit_cnt) (void)hipFree(c->ksplit_cnt);
+    (void)hipFree(c->pad_table);
+    delete c;
+    return TFMQ_ERR_HIP;
+  }
   *out = c;
   return TFMQ_OK;
 }
@@ -39,6 +48,8 @@ extern "C" int tfmq_destroy(tfmq_handle h) {
     if (e) (void)hipEventDestroy(e);
   if (h->pad_table) (void)hipFree(h->pad_table);
   if (h->gemm_ws) (void)hipFree(h->gemm_ws);
+  if (h->ksplit_ws) (void)hipFree(h->ksplit_ws);
+  if (h->ksplit_cnt) (void)hipFree(h->ksplit_cnt);
   delete h;
   return TFMQ_OK;
 }

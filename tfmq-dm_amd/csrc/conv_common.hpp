@@ -21,6 +21,9 @@ struct ConvP {
   int tiles_n;
   int cout_pad;                    // w4a8: rows of the expanded weight operand (multiple of 32)
   const unsigned char* pad_table;  // 256 x 64 B, row v = byte v (tfmq_ctx::pad_table)
+  int ksplit;                      // >= 1: workgroups per output tile (k_conv_dma, w4a8)
+  int* ks_ws;                      // tfmq_ctx::ksplit_ws: [tile][slice][BM * BN] int32 partial sums
+  int* ks_cnt;                     // tfmq_ctx::ksplit_cnt: arrival tickets, zero between launches
 #ifdef TFMQ_PHASE_TIMERS
   unsigned long long* dbg;         // [blocks][4] shader-clock stamps: start, loop start, loop end, end
 #endif

@@ -479,7 +479,14 @@ __global__ __launch_bounds__(256, (WM_TILES * WN_TILES > 4 || NST > 3) ? 2 : 3) 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wid / WAVES_N, wn = wid % WAVES_N;
-  const int bid = xcd_tile_id();
+  // split-K (tfmq_conv_desc.ksplit, w4a8 only): `ksplit` consecutive block ids -- neighbours on one XCD under the tile order --
+  // share an output tile, slice z multiplying K-steps [nsteps z / k, nsteps (z + 1) / k)
+  const int bid0 = xcd_tile_id();
+  const int ksp = F16 ? 1 : p.ksplit;
+  const int bid = ksp > 1 ? bid0 / ksp : bid0;
+  const int kslice = bid0 - bid * ksp;
+  const int s_begin = ksp > 1 ? static_cast<int>(static_cast<long>(p.nsteps) * kslice / ksp) : 0;
+  const int n_my = (ksp > 1 ? static_cast<int>(static_cast<long>(p.nsteps) * (kslice + 1) / ksp) : p.nsteps) - s_begin;
   const int tile_n = bid % p.tiles_n, tile_m = bid / p.tiles_n;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
 
@@ -571,9 +578,11 @@ __global__ __launch_bounds__(256, (WM_TILES * WN_TILES > 4 || NST > 3) ? 2 : 3) 
   const unsigned char* padp = p.pad_table;
   if (!pointwise && !F16) padp += (static_cast<unsigned>(static_cast<int>(aqp.y) - 128) & 0xffu) * 64;
 
-  int i_tap = 0, i_chunk = 0;
+  int i_tap = s_begin / p.chunks, i_chunk = s_begin - (s_begin / p.chunks) * p.chunks;
+  bool tap_fresh = true;          // (a K slice may start inside a tap)
   auto issue = [&](int s, int stage) {
-    if (i_chunk == 0 && !pointwise) {
+    if ((i_chunk == 0 || tap_fresh) && !pointwise) {
+      tap_fresh = false;
       if constexpr (COMPACT) {
         const int tapoff = ((i_tap / d.KW) * d.W + (i_tap % d.KW)) * d.Cin * (F16 ? 2 : 1);
 #pragma unroll
@@ -641,7 +650,7 @@ __global__ __launch_bounds__(256, (WM_TILES * WN_TILES > 4 || NST > 3) ? 2 : 3) 
   TFMQ_MARK(1);
 #pragma unroll
   for (int s0 = 0; s0 < NST - 1; ++s0)
-    if (s0 < p.nsteps) issue(s0, s0);
+    if (s0 < n_my) issue(s_begin + s0, s0);
   // requested behind the first DMA pieces, consumed in the epilogue (the counted waits of the loop only become more
   // conservative on its first step: these loads are younger than the pieces they must not overtake)
   if constexpr (!F16) {
@@ -649,9 +658,9 @@ __global__ __launch_bounds__(256, (WM_TILES * WN_TILES > 4 || NST > 3) ? 2 : 3) 
   }
   const EpiCols<WN_TILES> ec = load_epi_cols<!F16, WAVES_N, WN_TILES>(p, n0);
   int st_c = 0, st_i = NST - 1;
-  for (int s = 0; s < p.nsteps; ++s) {
+  for (int s = 0; s < n_my; ++s) {
     // this wave's pieces of K-step s have landed (those of the up to NST-2 later steps may still be in flight) ...
-    const int ahead = p.nsteps - 1 - s;
+    const int ahead = n_my - 1 - s;
     if (ahead >= NST - 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * NLOAD) : "memory");
     else if (NST > 3 && ahead == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NLOAD) : "memory");
     else if (NST > 3 && ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLOAD) : "memory");
@@ -661,9 +670,9 @@ __global__ __launch_bounds__(256, (WM_TILES * WN_TILES > 4 || NST > 3) ? 2 : 3) 
     // diagnostics builds (-DTFMQ_DBG_NO_DMA / -DTFMQ_DBG_NO_MFMA, results are garbage): the K loop without its
     // L2 -> LDS traffic, or without its fragment reads and MFMAs -- DESIGN.md section 4 quotes both
 #ifdef TFMQ_DBG_NO_DMA
-    if (s + NST - 1 < p.nsteps && s < 1) issue(s + NST - 1, st_i);
+    if (s + NST - 1 < n_my && s < 1) issue(s_begin + s + NST - 1, st_i);
 #else
-    if (s + NST - 1 < p.nsteps) issue(s + NST - 1, st_i);
+    if (s + NST - 1 < n_my) issue(s_begin + s + NST - 1, st_i);
 #endif
 #ifndef TFMQ_DBG_NO_MFMA
     compute(st_c);
@@ -673,6 +682,46 @@ __global__ __launch_bounds__(256, (WM_TILES * WN_TILES > 4 || NST > 3) ? 2 : 3) 
   }
 
   TFMQ_MARK(2);
+  if constexpr (!F16) {
+    if (ksp > 1) {
+      // Publish this slice's int32 partial sums, take a ticket; the tile's last arriver adds the other slabs to its registers and
+      // runs the epilogue (integer sums: any order gives the bits of the unsplit launch).  Hand-off per
+      // cdna_hip_programming.md section 5 (in-launch split-K): write-through (sc1) slab stores at the accumulators' natural 4-byte
+      // width = relaxed agent-scope atomic stores, every wave drains its stores, workgroup barrier, ONE relaxed agent-scope ticket;
+      // the reducer reads the slabs with sc1 (relaxed agent-scope) loads -- correct for any placement of the slices over XCDs / CUs.
+      // Slab layout: lane-linear ([wave][mfma tile][register][lane]): every store / load instruction moves 256 contiguous bytes.
+      constexpr int TILE_INTS = BM * BN;
+      int* slab0 = p.ks_ws + static_cast<size_t>(bid) * ksp * TILE_INTS + (wid * WM_TILES * WN_TILES) * 16 * 64 + lane;
+      int* mine = slab0 + static_cast<size_t>(kslice) * TILE_INTS;
+#pragma unroll
+      for (int i = 0; i < WM_TILES; ++i)
+#pragma unroll
+        for (int j = 0; j < WN_TILES; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            __hip_atomic_store(mine + ((i * WN_TILES + j) * 16 + r) * 64, acc[i][j][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();                       // every wave's slab stores are out; nobody reads the pipeline stages any more
+      int* flag = reinterpret_cast<int*>(lds);
+      if (tid == 0) *flag = __hip_atomic_fetch_add(p.ks_cnt + bid, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __syncthreads();
+      const int ticket = *flag;
+      __syncthreads();                       // (the epilogue stages through the same LDS)
+      if (ticket != ksp - 1) return;
+      if (tid == 0) __hip_atomic_store(p.ks_cnt + bid, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // zero again for the next launch
+      for (int z = 0; z < ksp; ++z) {
+        if (z == kslice) continue;
+        const int* other = slab0 + static_cast<size_t>(z) * TILE_INTS;
+#pragma unroll
+        for (int i = 0; i < WM_TILES; ++i)
+#pragma unroll
+          for (int j = 0; j < WN_TILES; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+              acc[i][j][r] += __hip_atomic_load(other + ((i * WN_TILES + j) * 16 + r) * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+  }
   conv_epilogue<!F16, WAVES_M, WAVES_N, WM_TILES, WN_TILES, RES_PRE>(p, lds, acc, m0, n0, aqp, static_cast<int>(aqp.y), ec);
   TFMQ_MARK(3);
 }
@@ -1065,9 +1114,20 @@ static int launch_conv(tfmq_handle h, const tfmq_conv_desc* dd, void* stream) {
   const int tiles_m = (p.M + BM - 1) / BM;
   dim3 grid(static_cast<unsigned>(p.tiles_n) * tiles_m);
   hipStream_t st = as_stream(stream);
+  p.ksplit = 1;
+  p.ks_ws = h->ksplit_ws;
+  p.ks_cnt = h->ksplit_cnt;
   if constexpr (INT8) {
     const bool dma = p.chunks == (d.Cin + 63) / 64 && d.KH * d.KW <= 9 &&
                      static_cast<size_t>(d.B) * d.H * d.W * d.Cin < (static_cast<size_t>(1) << 31);
+    if (d.ksplit > 1) {
+      const size_t tiles = static_cast<size_t>(p.tiles_n) * tiles_m;
+      TFMQ_CHECK_ARG(h, dma && d.ksplit <= p.nsteps && tiles <= static_cast<size_t>(tfmq_ctx::KSPLIT_MAX_TILES) &&
+                            tiles * d.ksplit * BM * BN <= tfmq_ctx::KSPLIT_WS_INTS,
+                     "conv_w4a8: ksplit needs the LDS-DMA tile kernel, ksplit <= K-steps and tiles * ksplit * tile elements <= 16 Mi");
+      p.ksplit = d.ksplit;
+      grid.x *= static_cast<unsigned>(d.ksplit);
+    }
     if (dma) {
 #ifdef TFMQ_PHASE_TIMERS
       static unsigned long long* dbuf = nullptr;

@@ -142,11 +142,11 @@ class GraphDdimSampler:
             self.gid = gid.value
             if os.environ.get("TFMQ_TUNE_REPORT"):
                 import collections, sys
-                print("[tfmq] tile selection:", dict(collections.Counter(ops._TILE_NAMES.get(v, "rule") for v in self.tiles.values())),
+                print("[tfmq] tile selection:", dict(collections.Counter(ops.tile_name(v) for v in self.tiles.values())),
                       file=sys.stderr)
                 if os.environ["TFMQ_TUNE_REPORT"] == "2":
                     for k, v in self.tiles.items():
-                        print("   ", k, ops._TILE_NAMES.get(v, "rule"), file=sys.stderr)
+                        print("   ", k, ops.tile_name(v), file=sys.stderr)
         return self
 
     def sample_nhwc(self, x_T: torch.Tensor, steps: Optional[int] = None) -> torch.Tensor:

@@ -469,8 +469,12 @@ class autotuned:
         return False
 
 
+def tile_name(v: int) -> str:
+    return _TILE_NAMES.get(v & 0xff, "rule") + (f", split-K {v >> 8}" if v >> 8 else "")
+
+
 def conv_autotune_report():
-    return {} if _AUTOTUNE is None else {k: _TILE_NAMES.get(v, "auto") for k, v in _AUTOTUNE.items()}
+    return {} if _AUTOTUNE is None else {k: tile_name(v) for k, v in _AUTOTUNE.items()}
 
 
 def slab_ok(dsc, bm: int = 256) -> bool:
@@ -512,12 +516,13 @@ def _tune_conv(h, name, kind, d, dsc):
         cands = None
     if cands is None:
         cands = _tile_candidates(kind, dsc)
+    cands = list(cands) + _ksplit_candidates(kind, dsc)
     best, best_ms = 0, None
     e0, e1 = C.c_int(), C.c_int()
     h.call("event_create", C.byref(e0))
     h.call("event_create", C.byref(e1))
     for t in cands:
-        dsc.tile = t
+        dsc.tile, dsc.ksplit = t & 0xff, t >> 8
         h.call(name, C.byref(dsc), _stream(d))          # warm (instruction cache, clocks)
         h.call("event_record", e0.value, _stream(d))
         for _ in range(3):
@@ -528,6 +533,28 @@ def _tune_conv(h, name, kind, d, dsc):
             best, best_ms = t, ms
     _AUTOTUNE[key] = best
     return best
+
+
+def _ksplit_candidates(kind, dsc):
+    """Split-K forms of the w4a8 tile kernels (tfmq_conv_desc.ksplit) for launches whose output grid leaves CUs idle while K is long
+    (the 8x8 / 16x16 / 32x32 levels of a small-batch forward): (tile | ksplit << 8) codes.  Integer partial sums: same bits."""
+    if os.environ.get("TFMQ_KSPLIT", "1") == "0" or kind != "w4a8" or dsc.out_mode == 2:
+        return []
+    if not (dsc.Cin % 64 == 0 or (dsc.Cin % 32 == 0 and bool(dsc.w64))) or dsc.KH * dsc.KW > 9:
+        return []
+    M, N = dsc.B * dsc.Ho * dsc.Wo, dsc.Cout
+    nsteps = dsc.KH * dsc.KW * ((dsc.Cin + 63) // 64)
+    out = []
+    for tile, bm, bn in ((1, 128, 128), (4, 128, 64), (2, 64, 64)):
+        if tile == 2 and dsc.stats and dsc.stats_seg > 64:
+            continue
+        nb = ((M + bm - 1) // bm) * ((N + bn - 1) // bn)
+        if nb >= 384:
+            continue
+        for ks in (2, 3, 4, 6, 8, 12, 16):
+            if nsteps // ks >= 3 and 160 <= nb * ks <= 1280 and nb * ks * bm * bn <= (16 << 20):
+                out.append(tile | (ks << 8))
+    return out
 
 
 def _tile_candidates(kind, dsc):
@@ -553,7 +580,8 @@ def _tile_candidates(kind, dsc):
 def _profiled_conv(name, kind, d, dsc, nops, nbytes=0.0):
     h = handle(d)
     if _AUTOTUNE is not None:
-        dsc.tile = _tune_conv(h, name, kind, d, dsc)
+        t = _tune_conv(h, name, kind, d, dsc)
+        dsc.tile, dsc.ksplit = t & 0xff, t >> 8
     if _conv_prof is None:
         h.call(name, C.byref(dsc), _stream(d))
         return
