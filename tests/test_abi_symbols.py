@@ -36,7 +36,7 @@ def test_struct_layouts_match_header(lib):
     import ctypes as C
     # tfmq_qsel: 2 pointers + 2 int32; tfmq_conv_desc / tfmq_gn_desc sizes as laid out by the C compiler
     assert C.sizeof(lib.QSel) == 24
-    assert C.sizeof(lib.ConvDesc) == 13 * 4 + 4 + 5 * 8 + 24 + 2 * 8 + 8 + 2 * 8 + 8 + 16 + 24 + 8 + 8 + 8 + 8 + 8 + 8 + 8   # ... + x2 + cin1 (padded) + w64
+    assert C.sizeof(lib.ConvDesc) == 13 * 4 + 4 + 5 * 8 + 24 + 2 * 8 + 8 + 2 * 8 + 8 + 16 + 24 + 8 + 8 + 8 + 8 + 8 + 8 + 8 + 8   # ... + x2 + cin1 (padded) + w64 + ksplit (padded)
     assert C.sizeof(lib.GnDesc) == 16 + 32 + 12 + 4 + 24 + 24 + 8
 
 
