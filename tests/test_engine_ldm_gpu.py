@@ -145,6 +145,37 @@ def test_guidance_pair_prefix_is_bit_identical(env, monkeypatch):
         assert torch.equal(outs[0], outs[1]), cls.__name__
 
 
+def test_fp16_stream_overflow_falls_back_to_the_fp32_stream(env, monkeypatch):
+    """A checkpoint whose residual stream leaves the fp16 range (here: conv_in's bias + 1e5) must not produce inf / NaN silently: the first
+    sampling of a graph sampler is checked, the engine falls back to the fp32 activation stream (what the reference keeps) and samples
+    again -- the result equals a sampler that was told to use the fp32 stream from the start."""
+    import warnings
+    g, sd, Engine, LayerQ = env
+    sd2 = dict(sd)
+    sd2["input_blocks.0.0.bias"] = sd["input_blocks.0.0.bias"] + 1.0e5
+    ctx, uc = T(g["ctx"]), T(g["traj_uc"])
+    wq, qtable = layerq(g, LayerQ, True)
+    from tfmq_dm_amd.ldm.sampler import GraphLatentDdimSampler, alphas_cumprod_linear
+    ac = alphas_cumprod_linear()
+    outs = []
+    for f32_first in (False, True):
+        if f32_first:
+            monkeypatch.setenv("TFMQ_STREAM_F32", "1")
+        step = torch.zeros(1, dtype=torch.int32, device=DEV)
+        eng = Engine(sd2, CFG, DEV)
+        eng.prepare(wq, qtable.repeat(4, 1, 1).contiguous().to(DEV), step)
+        assert eng.stream_f16 == (not f32_first)
+        sampler = GraphLatentDdimSampler(eng, 4, 2, (4, 8, 8), (5, 64), scale=7.5, alphas_cumprod=ac)
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            out = sampler.sample_nhwc(nhwc(T(g["traj_xT"])), ctx.to(DEV), uc.to(DEV))
+            sampler.stream.synchronize()
+        assert bool(torch.isfinite(out).all()) and not eng.stream_f16
+        assert any("fp16 activation stream" in str(x.message) for x in w) == (not f32_first)
+        outs.append(out.clone())
+    assert torch.equal(outs[0], outs[1])
+
+
 def test_layernorm_geglu_kernels(env):
     import torch.nn.functional as F
     import tfmq_dm_amd.ops as ops

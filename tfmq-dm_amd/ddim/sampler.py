@@ -91,6 +91,31 @@ def check_fsc_rows(engine, n_steps: int, who: str) -> None:
                         "(calibrate with one group per sampling step, or install a matching table)")
 
 
+def fp16_stream_overflowed(sampler) -> bool:
+    """The fp16 activation stream stores the tensors that travel between blocks as fp16: a checkpoint whose
+    residual stream exceeds 65504 somewhere would turn into inf / NaN, where the reference's fp32 stream does not.  The FIRST sampling of
+    a graph sampler is therefore checked once it has finished (one host synchronisation, one reduction): a non-finite result with the
+    fp16 stream on switches the engine to the fp32 stream, drops the captured graphs and tells the caller to sample again.  Later
+    samplings are not checked (overflow is a property of the weights, not of the noise).  TFMQ_STREAM_GUARD=0 switches the check off."""
+    if getattr(sampler, "_stream_checked", False) or os.environ.get("TFMQ_STREAM_GUARD", "1") == "0":
+        return False
+    sampler._stream_checked = True
+    eng = sampler.eng
+    if not getattr(eng, "stream_f16", False):
+        return False
+    sampler.stream.synchronize()
+    if bool(torch.isfinite(sampler.x).all()):
+        return False
+    import warnings
+    warnings.warn("tfmq: non-finite latents with the fp16 activation stream -- falling back to the fp32 stream (TFMQ_STREAM_F32=1 selects it up front)")
+    eng.stream_f16 = False
+    sampler.arena = ops.Arena()
+    sampler.gid = None
+    if hasattr(sampler, "gids"):
+        sampler.gids = None
+    return True
+
+
 class GraphDdimSampler:
     """DDIM loop over a prepared DdimUNetEngine, one hipGraph replay per step."""
 
@@ -162,6 +187,8 @@ class GraphDdimSampler:
                 self.h.call("graph_launch", self.gid, sp)
                 if sync_every and (i + 1) % sync_every == 0:
                     self.stream.synchronize()
+        if fp16_stream_overflowed(self):
+            return self.sample_nhwc(x_T, steps)
         return self.x
 
     def sample(self, x_T_nchw: torch.Tensor) -> torch.Tensor:

@@ -18,7 +18,7 @@ import torch
 
 from .. import ops
 from .._lib import TfmqError, handle
-from ..ddim.sampler import check_fsc_rows
+from ..ddim.sampler import check_fsc_rows, fp16_stream_overflowed
 
 
 def alphas_cumprod_linear(linear_start: float = 0.00085, linear_end: float = 0.012, n: int = 1000) -> torch.Tensor:
@@ -146,6 +146,8 @@ class GraphLatentDdimSampler:
                 self.h.call("graph_launch", self.gid, sp)
                 if sync_every and (i + 1) % sync_every == 0:
                     self.stream.synchronize()
+        if fp16_stream_overflowed(self):
+            return self.sample_nhwc(x_T, cond, uncond, steps)
         return self.x
 
 
@@ -247,4 +249,6 @@ class GraphLatentPlmsSampler(GraphLatentDdimSampler):
                 self.h.call("graph_launch", self.gids[min(i, 3)], sp)
                 if sync_every and (i + 1) % sync_every == 0:
                     self.stream.synchronize()
+        if fp16_stream_overflowed(self):
+            return self.sample_nhwc(x_T, cond, uncond, steps)
         return self.x
