@@ -146,13 +146,15 @@ def test_guidance_pair_prefix_is_bit_identical(env, monkeypatch):
 
 
 def test_fp16_stream_overflow_falls_back_to_the_fp32_stream(env, monkeypatch):
-    """A checkpoint whose residual stream leaves the fp16 range (here: conv_in's bias + 1e5) must not produce inf / NaN silently: the first
-    sampling of a graph sampler is checked, the engine falls back to the fp32 activation stream (what the reference keeps) and samples
-    again -- the result equals a sampler that was told to use the fp32 stream from the start."""
+    """A checkpoint whose residual stream leaves the fp16 range (here: + 1e5 on the bias of a ResBlock's first conv, whose output feeds a
+    GroupNorm) must not produce inf / NaN silently: the first sampling of a graph sampler is checked, the engine falls back to the fp32
+    activation stream (what the reference keeps) and samples again -- the result equals a sampler that was told to use the fp32 stream from
+    the start.  Where even that is not enough (conv_in's output also feeds an un-quantised shortcut conv, which rounds its INPUT to fp16)
+    the sampler raises instead of returning NaN."""
     import warnings
     g, sd, Engine, LayerQ = env
     sd2 = dict(sd)
-    sd2["input_blocks.0.0.bias"] = sd["input_blocks.0.0.bias"] + 1.0e5
+    sd2["input_blocks.1.0.in_layers.2.bias"] = sd["input_blocks.1.0.in_layers.2.bias"] + 1.0e5
     ctx, uc = T(g["ctx"]), T(g["traj_uc"])
     wq, qtable = layerq(g, LayerQ, True)
     from tfmq_dm_amd.ldm.sampler import GraphLatentDdimSampler, alphas_cumprod_linear
@@ -174,6 +176,16 @@ def test_fp16_stream_overflow_falls_back_to_the_fp32_stream(env, monkeypatch):
         assert any("fp16 activation stream" in str(x.message) for x in w) == (not f32_first)
         outs.append(out.clone())
     assert torch.equal(outs[0], outs[1])
+    from tfmq_dm_amd._lib import TfmqError
+    sd3 = dict(sd)
+    sd3["input_blocks.0.0.bias"] = sd["input_blocks.0.0.bias"] + 1.0e5
+    eng = Engine(sd3, CFG, DEV)
+    eng.prepare(wq, qtable.repeat(4, 1, 1).contiguous().to(DEV), torch.zeros(1, dtype=torch.int32, device=DEV))
+    sampler = GraphLatentDdimSampler(eng, 4, 2, (4, 8, 8), (5, 64), scale=7.5, alphas_cumprod=ac)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        with pytest.raises(TfmqError, match="fp16 operand range"):
+            sampler.sample_nhwc(nhwc(T(g["traj_xT"])), ctx.to(DEV), uc.to(DEV))
 
 
 def test_layernorm_geglu_kernels(env):

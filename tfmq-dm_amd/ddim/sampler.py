@@ -91,23 +91,44 @@ def check_fsc_rows(engine, n_steps: int, who: str) -> None:
                         "(calibrate with one group per sampling step, or install a matching table)")
 
 
-def fp16_stream_overflowed(sampler) -> bool:
+def fp16_stream_overflowed(sampler, probe) -> bool:
     """The fp16 activation stream stores the tensors that travel between blocks as fp16: a checkpoint whose
-    residual stream exceeds 65504 somewhere would turn into inf / NaN, where the reference's fp32 stream does not.  The FIRST sampling of
-    a graph sampler is therefore checked once it has finished (one host synchronisation, one reduction): a non-finite result with the
-    fp16 stream on switches the engine to the fp32 stream, drops the captured graphs and tells the caller to sample again.  Later
-    samplings are not checked (overflow is a property of the weights, not of the noise).  TFMQ_STREAM_GUARD=0 switches the check off."""
+    residual stream exceeds 65504 somewhere turns into inf there -- and an inf that meets an activation quantizer is clamped to the top
+    bin, i.e. the result can be finite and wrong -- where the reference's fp32 stream is fine.  After the FIRST sampling of a graph
+    sampler, `probe()` (one eager UNet evaluation of the sampler's first step) is therefore run with the fp16 and with the fp32 stream:
+    non-finite latents, or eps further apart than 25 % rel-L2 (bin flips alone put them 2 ... 3 % apart), switch the engine to the fp32
+    stream, drop the captured graphs and tell the caller to sample again.  Later samplings are not checked (overflow is a property of the
+    weights, not of the noise).  TFMQ_STREAM_GUARD=0 switches the check off."""
     if getattr(sampler, "_stream_checked", False) or os.environ.get("TFMQ_STREAM_GUARD", "1") == "0":
         return False
     sampler._stream_checked = True
     eng = sampler.eng
-    if not getattr(eng, "stream_f16", False):
-        return False
     sampler.stream.synchronize()
-    if bool(torch.isfinite(sampler.x).all()):
-        return False
+    finite = bool(torch.isfinite(sampler.x).all())
+    if not getattr(eng, "stream_f16", False):
+        if finite:
+            return False
+        # the fp32 stream is already on: what overflows is an fp16 OPERAND of an un-quantised conv / attention (they round their inputs
+        # to fp16 for the matrix cores).  Loud, not silent; the exact-fp32 engine mode runs those layers in fp32.
+        raise TfmqError("non-finite latents with the fp32 activation stream: an un-quantised layer's input exceeds the fp16 operand range "
+                        "(or the model itself diverges); TFMQ_EXACT_FP=1 runs the un-quantised layers on exact-fp32 GEMMs")
+    if finite:
+        with torch.cuda.stream(sampler.stream), ops.use_arena(None):
+            step_after = sampler.step.clone()
+            sampler.step.zero_()
+            e16 = probe().float().clone()
+            eng.stream_f16 = False
+            try:
+                e32 = probe().float()
+            finally:
+                eng.stream_f16 = True
+            sampler.step.copy_(step_after)          # (callers read the device step counter after a sampling)
+            sampler.stream.synchronize()
+        apart = float((e16 - e32).norm() / e32.norm().clamp_min(1e-30)) if bool(torch.isfinite(e32).all()) else 0.0
+        if bool(torch.isfinite(e16).all()) and apart <= 0.25:
+            return False
     import warnings
-    warnings.warn("tfmq: non-finite latents with the fp16 activation stream -- falling back to the fp32 stream (TFMQ_STREAM_F32=1 selects it up front)")
+    warnings.warn("tfmq: the fp16 activation stream overflows on this checkpoint -- falling back to the fp32 stream (TFMQ_STREAM_F32=1 selects it up front)")
     eng.stream_f16 = False
     sampler.arena = ops.Arena()
     sampler.gid = None
@@ -187,7 +208,7 @@ class GraphDdimSampler:
                 self.h.call("graph_launch", self.gid, sp)
                 if sync_every and (i + 1) % sync_every == 0:
                     self.stream.synchronize()
-        if fp16_stream_overflowed(self):
+        if fp16_stream_overflowed(self, lambda: self.eng.forward(x_T.float().contiguous(), None)):
             return self.sample_nhwc(x_T, steps)
         return self.x
 

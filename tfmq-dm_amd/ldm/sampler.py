@@ -146,7 +146,8 @@ class GraphLatentDdimSampler:
                 self.h.call("graph_launch", self.gid, sp)
                 if sync_every and (i + 1) % sync_every == 0:
                     self.stream.synchronize()
-        if fp16_stream_overflowed(self):
+        if fp16_stream_overflowed(self, lambda: (self.eng.forward(x_T.float().contiguous(), None, None) if self.uncond
+                                                 else self._eps_pair(x_T.float().contiguous()))):
             return self.sample_nhwc(x_T, cond, uncond, steps)
         return self.x
 
@@ -249,6 +250,7 @@ class GraphLatentPlmsSampler(GraphLatentDdimSampler):
                 self.h.call("graph_launch", self.gids[min(i, 3)], sp)
                 if sync_every and (i + 1) % sync_every == 0:
                     self.stream.synchronize()
-        if fp16_stream_overflowed(self):
+        if fp16_stream_overflowed(self, lambda: (self.eng.forward(x_T.float().contiguous(), None, None) if self.uncond
+                                                 else self._eps_pair(x_T.float().contiguous()))):
             return self.sample_nhwc(x_T, cond, uncond, steps)
         return self.x
