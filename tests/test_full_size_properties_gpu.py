@@ -94,6 +94,44 @@ def test_sd_batch_independent_across_tile_choices(sd):
     assert torch.equal(e[:6], a) and torch.equal(e[6:], b)
 
 
+def test_sd_guidance_pair_prefix_is_bit_identical_at_full_size(sd):
+    """The full SD v1 UNet on a guidance batch: 6 latents under cat([uc, c]) -- `pair_prefix` (the pair's shared prefix computed once, at
+    batch 6, copied where the members part) against the materialised 12-item batch the reference feeds its UNet.  Bit for bit, although
+    the two forms run different tile kernels on the prefix's shapes."""
+    run, fwd, info = sd
+    eng = _engine_of(fwd)
+    g = torch.Generator().manual_seed(12)
+    x = torch.randn(6, 64, 64, 4, generator=g).to(DEV)
+    ctx = torch.randn(12, 77, 768, generator=g).to(DEV)
+    t = torch.full((12,), 301.0, device=DEV)
+    with torch.cuda.stream(info["stream"]):
+        info["step"].zero_()
+        full = eng.forward(torch.cat([x, x]).contiguous(), t, ctx).clone()
+        pair = eng.forward(x, t, ctx, pair_prefix=True).clone()
+        info["stream"].synchronize()
+    assert torch.isfinite(full).all() and torch.equal(pair, full)
+    assert not torch.equal(full[:6], full[6:])
+
+
+def test_sd_fused_context_kv_projection_is_bit_identical(sd, monkeypatch):
+    """Cross attention at 640 / 1280 channels: to_k | to_v as ONE quantise pass + ONE GEMM (k as fp16 rows, v transposed) when their
+    quantizers agree at every step, against the two separate projections (TFMQ_FUSED_KV=0)."""
+    run, fwd, info = sd
+    eng = _engine_of(fwd)
+    assert any(f.kind == "w4a8" for f in eng.fused_kv.values())          # the synthetic tables do give to_k / to_v equal rows
+    g = torch.Generator().manual_seed(14)
+    x = torch.randn(4, 64, 64, 4, generator=g).to(DEV)
+    ctx = torch.randn(4, 77, 768, generator=g).to(DEV)
+    outs = []
+    with torch.cuda.stream(info["stream"]):
+        for flag in ("1", "0"):
+            monkeypatch.setenv("TFMQ_FUSED_KV", flag)
+            info["step"].zero_()
+            outs.append(eng.forward(x, None, ctx).clone())
+        info["stream"].synchronize()
+    assert torch.isfinite(outs[0]).all() and torch.equal(outs[0], outs[1])
+
+
 def test_sd_full_size_eps_vs_oracle(sd):
     """The full SD v1 UNet (859.5 M, w4a8, synthetic Finite-Set table) against the CPU oracle -- the reference's
     fake-quant forward restated on torch-CPU, pinned to the reference at tiny sizes by F11-F13 -- on one CFG pair:

@@ -238,14 +238,20 @@ class LdmUNetEngine(DdimUNetEngine):
             if lq.kind == lk.kind == lv.kind == "w4a8" and not (lq.wide or lk.wide or lv.wide) and ops.attention_f16_ok(d, cpad.shape[1]):
                 Bc, Lp, Dc = cpad.shape
                 q16 = ops.conv2d_w4a8(xq_src.reshape(B, T, 1, Cin), lq.p, lq.aq, out_f16=True).reshape(B, T, Cc)
-                k16 = ops.conv2d_w4a8(ops.quantize_act(cpad, lk.aq).reshape(Bc, Lp, 1, Dc), lk.p, lk.aq, out_f16=True)
-                _, vt = ops.conv2d_w4a8(ops.quantize_act(cpad, lv.aq).reshape(Bc, Lp, 1, Dc), lv.p, lv.aq, out_f16=True, t_col0=0)
+                fkv = self.fused_kv.get(p)
+                if fkv is not None and fkv.kind == "w4a8" and Cc % 128 == 0 and os.environ.get("TFMQ_FUSED_KV", "1") != "0":
+                    # to_k and to_v quantise the same context with quantizers that agree at every step (prepare()): one quantise pass and
+                    # one GEMM write k as fp16 rows and v as its fp16 transpose (the transposed region starts at a multiple of 128 channels)
+                    kv, vt = ops.conv2d_w4a8(ops.quantize_act(cpad, fkv.aq).reshape(Bc, Lp, 1, Dc), fkv.p, fkv.aq, out_f16=True, t_col0=Cc)
+                    k16 = kv.reshape(Bc, Lp, 2 * Cc)[..., :Cc]
+                else:
+                    k16 = ops.conv2d_w4a8(ops.quantize_act(cpad, lk.aq).reshape(Bc, Lp, 1, Dc), lk.p, lk.aq, out_f16=True).reshape(Bc, Lp, Cc)
+                    _, vt = ops.conv2d_w4a8(ops.quantize_act(cpad, lv.aq).reshape(Bc, Lp, 1, Dc), lv.p, lv.aq, out_f16=True, t_col0=0)
                 aq = to_out.aq if to_out.kind == "w4a8" else None
                 if aq is not None:
-                    _, o = ops.attention_f16(q16, k16.reshape(Bc, Lp, Cc), vt, heads, float(d ** -0.5), aq, want_f32=False,
-                                             n_keys=n_ctx)
+                    _, o = ops.attention_f16(q16, k16, vt, heads, float(d ** -0.5), aq, want_f32=False, n_keys=n_ctx)
                 else:
-                    o, _ = ops.attention_f16(q16, k16.reshape(Bc, Lp, Cc), vt, heads, float(d ** -0.5), n_keys=n_ctx)
+                    o, _ = ops.attention_f16(q16, k16, vt, heads, float(d ** -0.5), n_keys=n_ctx)
                 return self._tok(to_out, o, residual=x_res, **self._o16())
         if self_attn and p in self.fused_qkv:
             qkv = self._tok(self.fused_qkv[p], xq_src)
