@@ -59,6 +59,40 @@ def test_backward_vs_float64_autograd(ops, B, heads, T, L, d):
         assert float((mine.cpu().double() - ref).abs().max()) <= 5e-6 * max(1.0, float(ref.abs().max()))
 
 
+@pytest.mark.parametrize("B,heads,T,L,d", [(2, 8, 256, 256, 40), (1, 2, 128, 96, 64), (2, 3, 64, 160, 32), (1, 8, 1024, 1024, 40),
+                                             (2, 8, 128, 77, 40), (1, 2, 96, 200, 80), (2, 1, 64, 5, 32)])
+def test_bf16x3_operand_form_vs_float64(ops, B, heads, T, L, d):
+    """The same kernels' bf16x3 operand form (tfmq_set_gemm_precision(1): the default of the reconstruction iterations): every fp32
+    operand split hi + lo in bf16, three MFMAs per product, fp32 accumulation -- 2^-16 per product.  Forward and backward against
+    float64 at 5e-5 of the largest element (the exact-fp32 form: 2e-6 / 5e-6), run-to-run identical."""
+    g = torch.Generator().manual_seed(11 * T + d)
+    C = heads * d
+    q, k, v = (torch.randn(B, n, C, generator=g) for n in (T, L, L))
+    go = torch.randn(B, T, C, generator=g)
+    scale = d ** -0.5
+    q64, k64, v64 = (t.double().requires_grad_(True) for t in (q, k, v))
+    qh, kh, vh = (t.reshape(B, -1, heads, d).permute(0, 2, 1, 3) for t in (q64, k64, v64))
+    o64 = (torch.softmax(qh @ kh.transpose(-1, -2) * scale, -1) @ vh).permute(0, 2, 1, 3).reshape(B, T, C)
+    o64.backward(go.double())
+    qd, kd, vd = q.to(DEV), k.to(DEV), v.to(DEV)
+    with ops.gemm_precision("bf16x3", 0):
+        o, lse = ops.attention_f32_fwd(qd, kd, vd, heads, scale)
+        dq, dk, dv = ops.attention_f32_bwd(qd, kd, vd, o, lse, go.to(DEV), heads, scale)
+        o2, _ = ops.attention_f32_fwd(qd, kd, vd, heads, scale)
+        dq2, dk2, dv2 = ops.attention_f32_bwd(qd, kd, vd, o, lse, go.to(DEV), heads, scale)
+    oe, _ = ops.attention_f32_fwd(qd, kd, vd, heads, scale)           # exact form outside the context
+    ro, rl = ref_attn(q, k, v, heads, scale)
+    err = float((o.cpu().double() - ro).abs().max()) / max(1.0, float(ro.abs().max()))
+    print(f"[bf16x3 d={d} T={T} L={L}] forward error {err:.2e} (exact form {float((oe.cpu().double() - ro).abs().max()):.2e}), "
+          f"lse {float((lse.cpu().double() - rl).abs().max()):.2e}")
+    assert torch.equal(o, o2) and err <= 5e-5 and float((lse.cpu().double() - rl).abs().max()) <= 1e-4
+    for name, mine, again, ref in (("dq", dq, dq2, q64.grad), ("dk", dk, dk2, k64.grad), ("dv", dv, dv2, v64.grad)):
+        assert torch.equal(mine, again)
+        e = float((mine.cpu().double() - ref).abs().max()) / max(1.0, float(ref.abs().max()))
+        print(f"    {name} error {e:.2e}")
+        assert e <= 5e-5, (name, e)
+
+
 def test_transformer_unit_fused_vs_gemm_path(ops):
     """One AdaRound iteration of a TransformerUnit (heads of 40 channels, 64 tokens) with the fused fp32 attention and
     with the GEMM path: same reconstruction loss and weight gradients (both exact fp32, different summation orders)."""
