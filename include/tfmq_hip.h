@@ -312,7 +312,10 @@ int tfmq_attention_f16(tfmq_handle h, const uint16_t* q, const uint16_t* k, cons
  * 86-209 on quant_block.py:248-299; the reference runs einsum / softmax / einsum under autograd).  fp32 operands on
  * the fp32 matrix cores, nothing of size Tq x Tk is written: the forward returns O and the per-row log-sum-exp in the
  * exp2 domain (lse[b][h][q] = m + log2(sum_k exp2(scale*log2(e)*s_qk - m))), the backward recomputes the probabilities.
- * q [B][Tq][ldq], k / v [B][Tk][ldk], head h at channels h*d..; d in {32, 40, 64, 80}; Tq a multiple of 32, any Tk. */
+ * q [B][Tq][ldq], k / v [B][Tk][ldk], head h at channels h*d..; d in {32, 40, 64, 80}; Tq a multiple of 32, any Tk.
+ * Under tfmq_set_gemm_precision(h, 1) (bf16x3: the AdaRound iterations' default) forward and backward run the same decomposition with
+ * every fp32 operand split hi + lo in bf16 and three v_mfma_f32_32x32x16_bf16 per product (fp32 accumulation, 2^-16 per product:
+ * 1e-5 of float64 instead of 1e-6; 2.0 -> 0.83 ms forward, 6.4 -> 3.2 ms backward at T = 4096, d = 40, 64 (batch, head) pairs). */
 int tfmq_attention_f32_fwd(tfmq_handle h, const float* q, const float* k, const float* v, int ldq, int ldk, float* out,
                            int ldo, float* lse, int B, int heads, int Tq, int Tk, int d, float scale, void* stream);
 /* backward of the above: dq [B][Tq][ldq], dk / dv [B][Tk][ldk] from dout [B][Tq][ldo], the forward's out and lse.
