@@ -27,6 +27,8 @@ struct AttnF32P {
   float *dq, *dk, *dv;   // bwd outputs (dq uses ldq, dk / dv use ldk)
   int B, heads, Tq, Tk, d;
   float scale;
+  int qsplit = 1;        // k_attn_bx3_bwd_kv: query-range slices per key block (short key sequences: cross attention on 77 tokens)
+  float* part = nullptr; // [2][qsplit][B][Tk][heads * d] partial dV | dK (unscaled) of the slices, summed in slice order afterwards
 };
 
 // floats per LDS row: odd -> column-wise fragment reads are conflict free (65 for d <= 64, 97 for d <= 96)
@@ -630,7 +632,8 @@ __global__ __launch_bounds__(256) void k_attn_bx3_bwd_kv(AttnF32P p) {
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int j = lane & 31, half = lane >> 5;
   const int nkb = (p.Tk + 127) / 128;
-  const int bh = blockIdx.x / nkb, kbk = blockIdx.x - bh * nkb;
+  const int nz = p.qsplit, zq = blockIdx.x % nz, bx = blockIdx.x / nz;
+  const int bh = bx / nkb, kbk = bx - bh * nkb;
   const int b = bh / p.heads, h = bh - b * p.heads;
   const int d = p.d;
   const int key = kbk * 128 + wid * 32 + j;
@@ -662,7 +665,8 @@ __global__ __launch_bounds__(256) void k_attn_bx3_bwd_kv(AttnF32P p) {
   const float* ob = p.dout + static_cast<long>(b) * p.Tq * p.ldo + h * d;
   const float* lb = p.lse + (static_cast<long>(b) * p.heads + h) * p.Tq;
   const float* db = p.dsum + (static_cast<long>(b) * p.heads + h) * p.Tq;
-  const int ntile = p.Tq / 32;
+  const int ntile_all = p.Tq / 32;
+  const int qt0 = static_cast<int>(static_cast<long>(ntile_all) * zq / nz), ntile = static_cast<int>(static_cast<long>(ntile_all) * (zq + 1) / nz);
   TileStage<KD, 1> tq, to;
   tq.init(qb, p.ldq, static_cast<long>(p.Tq - 1) * p.ldq + d);
   to.init(ob, p.ldo, static_cast<long>(p.Tq - 1) * p.ldo + d);
@@ -682,13 +686,14 @@ __global__ __launch_bounds__(256) void k_attn_bx3_bwd_kv(AttnF32P p) {
     if (tid < 32) sL[buf][tid] = l_reg;
     else if (tid < 64) sD[buf][tid - 32] = d_reg;
   };
-  load(0);
+  load(qt0);
   __syncthreads();
   store(0);
   __syncthreads();
-  for (int qt = 0; qt < ntile; ++qt) {
-    const int buf = qt & 1;
-    load(qt + 1);
+  for (int qt = qt0; qt < ntile; ++qt) {
+    const int buf = (qt - qt0) & 1;
+    if (qt + 1 < ntile) load(qt + 1);
+    else load(ntile_all);                    // past the extent: zeros
     __builtin_amdgcn_sched_barrier(0);
     v16f_ s, dp;
 #pragma unroll
@@ -724,6 +729,21 @@ __global__ __launch_bounds__(256) void k_attn_bx3_bwd_kv(AttnF32P p) {
     __syncthreads();
   }
   if (!k_ok) return;
+  if (nz > 1) {        // partial sums of this query slice: [dV | dK][slice][b][key][heads * d], reduced in slice order by k_attn_qsplit_reduce
+    const long cc = static_cast<long>(p.heads) * d, plane = static_cast<long>(p.B) * p.Tk * cc;
+    float* pv_ = p.part + zq * plane + (static_cast<long>(b) * p.Tk + key) * cc + h * d;
+    float* pk_ = pv_ + nz * plane;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int dd = t * 32 + 8 * g + 4 * half;
+        if (dd >= d) continue;
+        *reinterpret_cast<float4*>(pv_ + dd) = make_float4(dv[t][4 * g], dv[t][4 * g + 1], dv[t][4 * g + 2], dv[t][4 * g + 3]);
+        *reinterpret_cast<float4*>(pk_ + dd) = make_float4(dk[t][4 * g], dk[t][4 * g + 1], dk[t][4 * g + 2], dk[t][4 * g + 3]);
+      }
+    return;
+  }
   const long off = (static_cast<long>(b) * p.Tk + key) * p.ldk + h * d;
 #pragma unroll
   for (int t = 0; t < NT; ++t)
@@ -735,6 +755,21 @@ __global__ __launch_bounds__(256) void k_attn_bx3_bwd_kv(AttnF32P p) {
       *reinterpret_cast<float4*>(p.dk + off + dd) = make_float4(dk[t][4 * g] * p.scale, dk[t][4 * g + 1] * p.scale, dk[t][4 * g + 2] * p.scale,
                                                                 dk[t][4 * g + 3] * p.scale);
     }
+}
+
+// dV, dK = sums of the query slices' partials in slice order (deterministic), dK times `scale`
+__global__ void k_attn_qsplit_reduce(AttnF32P p) {
+  const long cc = static_cast<long>(p.heads) * p.d, plane = static_cast<long>(p.B) * p.Tk * cc;
+  for (long i = static_cast<long>(blockIdx.x) * blockDim.x + threadIdx.x; i < plane; i += static_cast<long>(gridDim.x) * blockDim.x) {
+    float a = 0.0f, c = 0.0f;
+    for (int z = 0; z < p.qsplit; ++z) {
+      a += p.part[z * plane + i];
+      c += p.part[(p.qsplit + z) * plane + i];
+    }
+    const long row = i / cc, col = i - row * cc;
+    p.dv[row * p.ldk + col] = a;
+    p.dk[row * p.ldk + col] = c * p.scale;
+  }
 }
 
 template <int KD, int NS, int NT>
@@ -852,10 +887,42 @@ extern "C" int tfmq_attention_f32_bwd(tfmq_handle h, const float* q, const float
     hipLaunchKernelGGL((k_attn_bx3_bwd_q<KD_, NS_, NT_>), gq, dim3(256), 0, st, p);     \
   } while (0)
   if (h->gemm_prec == 1 && !getenv("TFMQ_ATTN_F32_EXACT")) {
+    // short key sequences (cross attention: 77 keys = ONE key block per (batch, head)) leave most CUs idle in the key-block kernel:
+    // slice its query loop over several workgroups, partial dK / dV summed in slice order afterwards
+    const long kv_blocks = static_cast<long>(gkv.x);
+    int nz = 1;
+    if (kv_blocks < h->cu_count && Tq / 32 >= 8 && !getenv("TFMQ_ATTN_NO_QSPLIT")) {
+      nz = static_cast<int>((2L * h->cu_count + kv_blocks - 1) / kv_blocks);
+      if (nz > Tq / 32 / 4) nz = Tq / 32 / 4;
+      if (nz > 16) nz = 16;
+      if (nz < 1) nz = 1;
+    }
+    if (nz > 1) {
+      const size_t need = static_cast<size_t>(2) * nz * B * Tk * heads * d * sizeof(float);
+      if (need > h->gemm_ws_bytes) {
+        if (h->gemm_ws) (void)hipFree(h->gemm_ws);
+        h->gemm_ws = nullptr;
+        h->gemm_ws_bytes = 0;
+        if (hipMalloc(reinterpret_cast<void**>(&h->gemm_ws), need) != hipSuccess) {
+          h->err = "attention_f32_bwd: workspace allocation failed";
+          return TFMQ_ERR_HIP;
+        }
+        h->gemm_ws_bytes = need;
+      }
+      p.qsplit = nz;
+      p.part = h->gemm_ws;
+      gkv.x *= static_cast<unsigned>(nz);
+    }
     if (d == 40) TFMQ_BWD3(20, 3, 2);
     else if (d == 32) TFMQ_BWD3(16, 2, 1);
     else if (d == 64) TFMQ_BWD3(32, 4, 2);
     else TFMQ_BWD3(40, 5, 3);
+    if (nz > 1) {
+      const long plane = static_cast<long>(B) * Tk * heads * d;
+      int rb = ceil_div(plane, 256);
+      if (rb > h->cu_count * 8) rb = h->cu_count * 8;
+      hipLaunchKernelGGL(k_attn_qsplit_reduce, dim3(rb), dim3(256), 0, st, p);
+    }
     TFMQ_LAUNCH_CHECK(h);
     return TFMQ_OK;
   }
