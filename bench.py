@@ -811,12 +811,14 @@ def main():
                                        "reconstruction_units": sum(v["reconstruction_units"] for v in lv.values()),
                                        "note": "8 timestep groups x 128 samples, 20000 iterations per unit, 1 GPU; each level's run repeats the weight "
                                                "initialisation and the Finite-Set pass of the whole UNet"}
-            mpath = os.path.join(ROOT, "profiles", "r02_cifar_calibration_full.json")
+            mname = next((n for n in ("r03_cifar_calibration_full.json", "r02_cifar_calibration_full.json")
+                          if os.path.exists(os.path.join(ROOT, "profiles", n))), "r02_cifar_calibration_full.json")
+            mpath = os.path.join(ROOT, "profiles", mname)
             if os.path.exists(mpath):       # the whole CIFAR recipe, measured once end to end with this code (scratch/cifar_cali_full.py)
                 mj = json.load(open(mpath))
                 cali["measured_full_recipe_cifar"] = {k: mj[k] for k in ("recipe", "wall_clock_s", "phases_s", "reconstruction_units",
                                                                        "iterations_per_unit", "ms_per_iteration_all_units") if k in mj}
-                cali["measured_full_recipe_cifar"]["source"] = "profiles/r02_cifar_calibration_full.json"
+                cali["measured_full_recipe_cifar"]["source"] = "profiles/" + mname
         cfgd = {"workload": info["workload"], "parallelism": f"replicas x{world} (no data-path collective)"}
         cfgd.update(info["extra"])
         out = {
