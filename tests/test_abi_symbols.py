@@ -75,3 +75,29 @@ def test_slab_kernel_launch_geometry_rule(lib):
     assert not ops.slab_ok(desc(128, 128), 128)                                        # (1 + 2) * 130 = 390 slab rows > 320
     assert not ops.slab_ok(desc(24, 24), 128)
     assert set(ops._TILE_NAMES) == {1, 2, 3, 4, 5, 6, 7}
+
+
+def test_split_k_candidate_rule(lib):
+    """Host-side rule that offers split-K forms of the w4a8 tile kernels to the per-shape measurement (ops._ksplit_candidates): only
+    launches whose output grid leaves CUs idle, at least three K-steps per slice, between 160 and 1280 workgroups, and never more slab
+    elements than the handle's 64 MiB workspace holds (the launcher would answer TFMQ_ERR_ARG)."""
+    import tfmq_dm_amd.ops as ops
+
+    def desc(B, H, cin, cout, k=3, out_mode=1):
+        d = lib.ConvDesc()
+        d.B, d.H, d.W, d.Ho, d.Wo, d.Cin, d.Cout, d.KH, d.KW, d.stride, d.out_mode = B, H, H, H, H, cin, cout, k, k, 1, out_mode
+        return d
+    tiles = {1: (128, 128), 4: (128, 64), 2: (64, 64)}
+    for d in (desc(2, 8, 1280, 1280), desc(2, 16, 2560, 1280), desc(2, 32, 640, 640), desc(2, 64, 320, 320), desc(2, 16, 1280, 1280, k=1)):
+        cands = ops._ksplit_candidates("w4a8", d)
+        assert cands, (d.H, d.Cin)
+        M, nsteps = d.B * d.Ho * d.Wo, d.KH * d.KW * ((d.Cin + 63) // 64)
+        for c in cands:
+            bm, bn = tiles[c & 0xff]
+            ks = c >> 8
+            nb = -(-M // bm) * -(-d.Cout // bn)
+            assert ks >= 2 and nsteps // ks >= 3 and 160 <= nb * ks <= 1280 and nb * ks * bm * bn <= (16 << 20)
+    assert ops._ksplit_candidates("w4a8", desc(128, 64, 320, 320)) == []          # the metric batch: the grid fills the chip
+    assert ops._ksplit_candidates("f16", desc(2, 8, 1280, 1280)) == []            # fp32 sums: the K order is part of the result
+    assert ops._ksplit_candidates("w4a8", desc(2, 8, 1280, 2560, k=1, out_mode=2)) == []      # fused GEGLU epilogue pairs columns inside a tile
+    assert ops.tile_name(2 | 12 << 8) == "64x64, split-K 12" and ops.tile_name(5).startswith("slab")
