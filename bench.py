@@ -88,6 +88,14 @@ def setup_cifar(args, dev, rank, log):
     def run():
         sampler.sample_nhwc(x_T)
 
+    # the sampler's first sampling carries its one-off fp16-stream check (ddim/sampler.py: fp16_stream_overflowed): here, outside
+    # the timed region whatever --warmup is
+    if getattr(args, "first_sampling", True):      # (scratch/pmc_forward.py: counter collection cannot take a graph replay)
+        t0 = time.time()
+        run()
+        sampler.stream.synchronize()
+        log(f"first sampling (graph upload + fp16-stream check): {time.time() - t0:.2f}s, fp16 stream {'on' if eng.stream_f16 else 'OFF (fallback)'}")
+
     def fwd():
         eng.forward(sampler.x, None)
 
@@ -196,6 +204,12 @@ def setup_sd(args, dev, rank, log, preset="sd"):
             sampler.sample_nhwc(x_T)
         else:
             sampler.sample_nhwc(x_T, cond, uncond)
+
+    if getattr(args, "first_sampling", True):      # (scratch/pmc_forward.py: counter collection cannot take a graph replay)
+        t0 = time.time()
+        run()        # one-off fp16-stream check of the sampler's first sampling: outside the timed region whatever --warmup is
+        sampler.stream.synchronize()
+        log(f"first sampling (graph upload + fp16-stream check): {time.time() - t0:.2f}s, fp16 stream {'on' if eng.stream_f16 else 'OFF (fallback)'}")
 
     def fwd():
         if CTX is None:

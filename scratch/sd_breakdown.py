@@ -6,7 +6,7 @@ import torch
 import bench
 import tfmq_dm_amd.ops as ops
 dev = torch.device("cuda", 0)
-args = argparse.Namespace(batch=int(os.environ.get("SD_BATCH", "8")), ddim_steps=int(os.environ.get("SD_STEPS", "4")))
+args = argparse.Namespace(batch=int(os.environ.get("SD_BATCH", "8")), ddim_steps=int(os.environ.get("SD_STEPS", "4")), first_sampling=False)
 run, fwd, cpu, info = bench.setup_sd(args, dev, 0, lambda *a: print(*a, file=sys.stderr))
 rec, shapes = [], []
 orig = ops._profiled_conv

@@ -7,7 +7,7 @@ import torch, bench
 import tfmq_dm_amd.ops as ops
 wl = sys.argv[1] if len(sys.argv) > 1 else "sd"
 dev = torch.device("cuda", 0)
-args = argparse.Namespace(batch=0, ddim_steps=4)
+args = argparse.Namespace(batch=0, ddim_steps=4, first_sampling=False)
 if wl == "cifar":
     run, fwd, cpu, info = bench.setup_cifar(args, dev, 0, lambda *a: None)
 else:
