@@ -354,6 +354,10 @@ int tfmq_step_advance(tfmq_handle h, int32_t* step, int delta, void* stream);
  * correction, values outside [edges[0], edges[bins]] dropped.  For Scaler.KL / Scaler.HIST (quant/quant_layer.py:67-133). */
 int tfmq_np_histogram(tfmq_handle h, const float* x, size_t n, int f64, int do_clip, double clip_lo, double clip_hi,
                       const void* edges, int bins, uint32_t* counts, void* stream);
+/* The same for `rows` tensors of n values at once (x [rows][n]; edges [rows][bins + 1]; clip_lo / clip_hi [rows] device doubles; counts
+ * [rows][bins]): the per-output-channel loop of the KL / HIST weight scalers (quant/quant_layer.py:193-204) as 51 launches in all. */
+int tfmq_np_histogram_rows(tfmq_handle h, const float* x, size_t rows, size_t n, int f64, int do_clip, const double* clip_lo,
+                           const double* clip_hi, const void* edges, int bins, uint32_t* counts, void* stream);
 /* Device self-test of instruction semantics the kernels rely on (v_cvt_pk_u8_f32 saturation to [0, 255], DPP lane
  * selection of the statistics sums).  0 = all hold; otherwise an error with *report = failing-check bit mask.  Synchronous,
  * allocates 4 bytes for the duration of the call; not for use under stream capture. */

@@ -442,3 +442,30 @@ def test_histogram_scalers_kl_and_hist_vs_reference(golden):
     qc(w)
     d0, z0 = hist(w[0], False, 16, False)
     assert qc.delta.shape == (2, 1) and float(qc.delta[0]) == float(d0) and float(qc.zero_point[0]) == float(z0)
+
+
+@pytest.mark.gpu
+def test_channel_wise_histogram_scalers_batched_equal_the_channel_loop(monkeypatch):
+    """Channel-wise Scaler.KL / Scaler.HIST (the reference loops the output channels through the scaler, quant_layer.py:193-204): all
+    channels per launch (kl_rows / hist_rows: 51 launches in all, the bin bookkeeping vectorised over the rows) against the channel loop
+    over the per-tensor functions that F18 pins to the reference -- delta and zero point bit for bit."""
+    from quant.quant_layer import Scaler, UniformAffineQuantizer
+    g = torch.Generator().manual_seed(18)
+    w = torch.randn(24, 16, 3, 3, generator=g) * 0.1
+    w[3] *= 4.0
+    w[7, 0, 0, 0] = 2.5                 # an outlier channel: the clip search has something to find
+    w[11] = w[11].abs()                 # a one-sided channel
+    for scaler in (Scaler.KL, Scaler.HIST):
+        for bits, az in ((4, False), (8, False), (8, True)):
+            res = []
+            for loop in (False, True):
+                if loop:
+                    monkeypatch.setenv("TFMQ_SCALER_ROW_LOOP", "1")
+                else:
+                    monkeypatch.delenv("TFMQ_SCALER_ROW_LOOP", raising=False)
+                q = UniformAffineQuantizer(bits=bits, channel_wise=True, scaler=scaler, always_zero=az)
+                d, z = q._init_quantization_param(w.to(DEV), True)
+                res.append((d.cpu(), z.cpu()))
+            assert res[0][0].shape == (24, 1, 1, 1)
+            assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1]), (scaler.__name__, bits, az)
+            assert len(torch.unique(res[0][0])) > 4

@@ -106,6 +106,7 @@ _SIGS = {
     "tfmq_row_broadcast_add": (c_int, [c_void_p, c_void_p, c_void_p, c_int, C.c_long, c_int, c_int, c_void_p, c_void_p]),
     "tfmq_hw_selftest": (c_int, [c_void_p, c_void_p]),
     "tfmq_np_histogram": (c_int, [c_void_p, c_void_p, c_size_t, c_int, c_int, C.c_double, C.c_double, c_void_p, c_int, c_void_p, c_void_p]),
+    "tfmq_np_histogram_rows": (c_int, [c_void_p, c_void_p, c_size_t, c_size_t, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     "tfmq_silu": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "tfmq_nchw_to_nhwc": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "tfmq_nhwc_to_nchw": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),

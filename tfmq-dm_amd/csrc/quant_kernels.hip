@@ -748,6 +748,56 @@ __global__ __launch_bounds__(256) void k_np_histogram(const float* __restrict__ 
     if (sh[i]) atomicAdd(&counts[i], sh[i]);
 }
 
+// the same for `rows` tensors of n values at once (the per-output-channel loop of the KL / HIST weight scalers, quant_layer.py:193-204):
+// row r has its own edge table edges[r][bins + 1] and clip bounds; blockIdx.y = row
+template <typename T>
+__global__ __launch_bounds__(256) void k_np_histogram_rows(const float* __restrict__ x, size_t n, int do_clip, const double* __restrict__ clip_lo,
+                                                           const double* __restrict__ clip_hi, const T* __restrict__ edges_all, int bins,
+                                                           unsigned* __restrict__ counts_all) {
+  extern __shared__ unsigned sh[];
+  const int row = blockIdx.y;
+  const float* xr = x + static_cast<size_t>(row) * n;
+  const T* edges = edges_all + static_cast<size_t>(row) * (bins + 1);
+  unsigned* counts = counts_all + static_cast<size_t>(row) * bins;
+  for (int i = threadIdx.x; i < bins; i += blockDim.x) sh[i] = 0;
+  __syncthreads();
+  const T first = edges[0], last = edges[bins];
+  const T denom = last - first;
+  const double lo = do_clip ? clip_lo[row] : 0.0, hi = do_clip ? clip_hi[row] : 0.0;
+  const size_t stride = static_cast<size_t>(gridDim.x) * blockDim.x;
+  for (size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) {
+    T v = static_cast<T>(xr[i]);
+    if (do_clip) v = static_cast<T>(fmin(fmax(static_cast<double>(xr[i]), lo), hi));
+    if (!(v >= first) || !(v <= last)) continue;
+    int idx = static_cast<int>(((v - first) / denom) * static_cast<T>(bins));
+    if (idx == bins) idx -= 1;
+    if (v < edges[idx]) idx -= 1;
+    if (idx != bins - 1 && v >= edges[idx + 1]) idx += 1;
+    atomicAdd(&sh[idx], 1u);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < bins; i += blockDim.x)
+    if (sh[i]) atomicAdd(&counts[i], sh[i]);
+}
+
+extern "C" int tfmq_np_histogram_rows(tfmq_handle h, const float* x, size_t rows, size_t n, int f64, int do_clip, const double* clip_lo,
+                                      const double* clip_hi, const void* edges, int bins, uint32_t* counts, void* stream) {
+  TFMQ_CHECK_ARG(h, h && x && edges && counts && rows > 0 && rows <= 65535 && n > 0 && bins > 0 && bins <= 4096 && (!do_clip || (clip_lo && clip_hi)),
+                 "np_histogram_rows: bad argument");
+  TFMQ_HIP(h, hipMemsetAsync(counts, 0, sizeof(uint32_t) * bins * rows, as_stream(stream)));
+  int blocks = ceil_div(static_cast<long>(n), 256 * 8);
+  if (blocks > 64) blocks = 64;
+  if (blocks < 1) blocks = 1;
+  const size_t shm = sizeof(unsigned) * bins;
+  dim3 grid(blocks, static_cast<unsigned>(rows));
+  if (f64) hipLaunchKernelGGL(k_np_histogram_rows<double>, grid, dim3(256), shm, as_stream(stream), x, n, do_clip, clip_lo, clip_hi,
+                              static_cast<const double*>(edges), bins, counts);
+  else hipLaunchKernelGGL(k_np_histogram_rows<float>, grid, dim3(256), shm, as_stream(stream), x, n, do_clip, clip_lo, clip_hi,
+                          static_cast<const float*>(edges), bins, counts);
+  TFMQ_LAUNCH_CHECK(h);
+  return TFMQ_OK;
+}
+
 extern "C" int tfmq_np_histogram(tfmq_handle h, const float* x, size_t n, int f64, int do_clip, double clip_lo, double clip_hi,
                                  const void* edges, int bins, uint32_t* counts, void* stream) {
   TFMQ_CHECK_ARG(h, h && x && edges && counts && n > 0 && bins > 0 && bins <= 4096, "np_histogram: bad argument");

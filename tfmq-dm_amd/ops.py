@@ -301,6 +301,28 @@ def np_histogram(x: torch.Tensor, edges, clip=None):
     return counts.cpu().numpy().astype(np.int64)
 
 
+def np_histogram_rows(x: torch.Tensor, edges, clip=None):
+    """np_histogram for every row of x [rows, n] at once: edges numpy [rows, bins + 1] (float32 or float64), clip = (lo [rows], hi [rows])
+    numpy float64 or None.  -> numpy int64 [rows, bins]."""
+    import numpy as np
+    d = _dev(x)
+    _chk(x, torch.float32, "x")
+    rows, n = x.shape
+    edges = np.ascontiguousarray(edges)
+    if edges.dtype not in (np.float32, np.float64) or edges.shape[0] != rows:
+        raise TfmqError("np_histogram_rows: edges must be float32 or float64 [rows, bins + 1]")
+    bins = edges.shape[1] - 1
+    ed = torch.from_numpy(edges).to(x.device)
+    counts = _alloc(rows, bins, dtype=torch.int32, device=x.device)
+    lo = hi = None
+    if clip is not None:
+        lo = torch.from_numpy(np.ascontiguousarray(clip[0], dtype=np.float64)).to(x.device)
+        hi = torch.from_numpy(np.ascontiguousarray(clip[1], dtype=np.float64)).to(x.device)
+    handle(d).call("np_histogram_rows", _p(x), rows, n, int(edges.dtype == np.float64), int(clip is not None), _p(lo), _p(hi), _p(ed), bins,
+                   _p(counts), _stream(d))
+    return counts.cpu().numpy().astype(np.int64)
+
+
 def act_range_update(mm: torch.Tensor, state: torch.Tensor, qparam: torch.Tensor, momentum: float, level: int, init: bool):
     d = _dev(mm)
     handle(d).call("act_range_update", _p(mm), _p(state), _p(qparam), float(momentum), level, int(init), _stream(d))

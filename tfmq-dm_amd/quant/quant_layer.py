@@ -9,6 +9,8 @@ from __future__ import annotations
 from enum import Enum
 from typing import List, Optional, Union
 
+import os
+
 import torch
 import torch.nn as nn
 
@@ -126,6 +128,86 @@ def hist(x: torch.Tensor, symmetric: bool = False, level: int = 256, always_zero
     return _clipped_qparam(xf, xmin, xmax, float(lo), float(hi), level, always_zero)
 
 
+def _clipped_qparam_rows(x2: torch.Tensor, xmin, xmax, lo, hi, level: int, always_zero: bool):
+    """_clipped_qparam for every row (numpy arrays xmin / xmax float32, lo / hi float64) -> device [rows, 2] {delta, zero_point}"""
+    import numpy as np
+    lo32, hi32 = lo.astype(np.float32), hi.astype(np.float32)
+    cmin = np.where(xmin.astype(np.float64) < lo, lo32, xmin)
+    cmax = np.where(xmax.astype(np.float64) > hi, hi32, xmax)
+    cmin = np.where(cmin > hi32, hi32, cmin)
+    mm = torch.from_numpy(np.stack([cmin, cmax], axis=1).astype(np.float32)).to(x2.device)
+    return ops.minmax_to_qparam(mm.contiguous(), level, always_zero)
+
+
+def kl_rows(x2: torch.Tensor, level: int = 256, always_zero: bool = False) -> torch.Tensor:
+    """`kl` for every row of x2 [rows, n] (the per-output-channel loop of the reference, quant_layer.py:193-204) with the 51 histograms of
+    ALL rows in 51 launches and the 256-bin bookkeeping vectorised over the rows -- the same numpy operations in the same precisions per
+    row as `kl`, so delta / zero point are those of the loop bit for bit (tests/test_hip_kernels.py) instead of ~51 launches and host
+    synchronisations per channel.  -> device [rows, 2]."""
+    import numpy as np
+    xf = x2.detach().contiguous().float()
+    R = xf.shape[0]
+    mm = ops.minmax(xf, R).cpu().numpy()
+    xmin, xmax = mm[:, 0].astype(np.float32), mm[:, 1].astype(np.float32)
+    ref_edges = np.linspace(xmin, xmax, level + 1, endpoint=True, dtype=np.float32, axis=-1)
+    ref_cnt = ops.np_histogram_rows(xf, ref_edges)
+    ref_hist = ref_cnt / np.diff(ref_edges, axis=-1) / ref_cnt.sum(axis=-1, keepdims=True)
+    width = np.sum(np.diff(ref_edges, axis=-1), axis=-1)
+    p = (ref_hist + 1e-5) / (1.0 + width * 1e-5)[:, None]
+    best, best_r = np.full(R, 1e5), np.full(R, 1.0)
+    xmin64, xmax64 = xmin.astype(np.float64), xmax.astype(np.float64)
+    rows = np.arange(R)
+    for r in np.linspace(0.5, 1.0, 50):
+        lo, hi = xmin * r, xmax * r                                   # float64 (float32 array * np.float64)
+        first, last = np.minimum(np.maximum(xmin64, lo), hi), np.minimum(np.maximum(xmax64, lo), hi)
+        q_edges = np.linspace(first, last, level + 1, endpoint=True, dtype=np.float64, axis=-1)
+        q_cnt = ops.np_histogram_rows(xf, q_edges, clip=(lo, hi))
+        q_hist = q_cnt / np.diff(q_edges, axis=-1) / q_cnt.sum(axis=-1, keepdims=True)
+        out = np.zeros((R, level), dtype=q_hist.dtype)
+        v = np.zeros(R, dtype=np.float64)
+        j = np.zeros(R, dtype=np.int64)
+        edge = q_edges[:, 0].copy()
+        for i in range(level):
+            left = ref_edges[:, i]
+            step = edge <= left
+            take = step & (j < level)
+            over = step & ~(j < level)
+            jt = np.minimum(j, level - 1)
+            v = np.where(take, q_hist[rows, jt], np.where(over, 0.0, v))
+            j = np.where(take, j + 1, j)
+            edge = np.where(take, q_edges[rows, np.minimum(j, level)], np.where(over, (left + np.float32(1.0)).astype(np.float64), edge))
+            out[:, i] = v
+        q = (out + 1e-5) / (1.0 + width * 1e-5)[:, None]
+        dkl = np.sum(p * np.log(p / q), axis=-1)
+        better = dkl < best
+        best, best_r = np.where(better, dkl, best), np.where(better, r, best_r)
+    return _clipped_qparam_rows(xf, xmin, xmax, xmin * best_r, xmax * best_r, level, always_zero)
+
+
+def hist_rows(x2: torch.Tensor, level: int = 256, always_zero: bool = False) -> torch.Tensor:
+    """`hist` for every row of x2 [rows, n] with one histogram launch for all rows (see kl_rows).  -> device [rows, 2]."""
+    import numpy as np
+    xf = x2.detach().contiguous().float()
+    R = xf.shape[0]
+    mm = ops.minmax(xf, R).cpu().numpy()
+    xmin, xmax = mm[:, 0].astype(np.float32), mm[:, 1].astype(np.float32)
+    amax = np.maximum(-xmin, xmax)
+    edges = np.linspace(np.zeros(R, dtype=np.float64), amax, level + 1, endpoint=True, dtype=np.float32, axis=-1)     # (`hist` starts at the int 0: float64 arithmetic)
+    cnt = ops.np_histogram_rows(xf, edges)
+    h = cnt / np.diff(edges, axis=-1) / cnt.sum(axis=-1, keepdims=True)
+    h = h.astype(np.float32) / h.sum(axis=-1, keepdims=True)
+    lo, hi = np.zeros(R, dtype=np.float64), np.zeros(R, dtype=np.float64)
+    for rr in range(R):          # a 256-step running sum per row: host arithmetic in `hist`'s own order
+        acc = 0
+        for i in range(level):
+            acc += h[rr, i]
+            if acc >= 0.9996:
+                c = (i + 0.5) * (amax[rr] / level)
+                lo[rr], hi[rr] = max(-c, xmin[rr]), min(c, xmax[rr])
+                break
+    return _clipped_qparam_rows(xf, xmin, xmax, lo, hi, level, always_zero)
+
+
 class Scaler:
     """Namespace of scaler functions (the reference's Enum of plain functions is just that)."""
     MINMAX = staticmethod(minmax)
@@ -184,8 +266,11 @@ class UniformAffineQuantizer(nn.Module):
             # the histogram scalers work on one tensor at a time (reference :193-204 loops the channels through the scaler)
             fn = kl if kind == "kl" else hist
             if channel_wise:
-                pairs = [fn(x[c], False, self.level, self.always_zero) for c in range(rows)]
                 shape = (-1,) + (1,) * (x.dim() - 1)
+                if os.environ.get("TFMQ_SCALER_ROW_LOOP") is None:       # all channels per launch (kl_rows / hist_rows); the loop is kept for the test
+                    qp = (kl_rows if kind == "kl" else hist_rows)(x.reshape(rows, -1), self.level, self.always_zero)
+                    return qp[:, 0].clone().view(shape), qp[:, 1].clone().view(shape)
+                pairs = [fn(x[c], False, self.level, self.always_zero) for c in range(rows)]
                 return torch.stack([p[0] for p in pairs]).view(shape), torch.stack([p[1] for p in pairs]).view(shape)
             if self.leaf_param:
                 mm = ops.minmax(x, 1)
