@@ -185,6 +185,13 @@ typedef struct tfmq_conv_desc {
                                     TFMQ_OUT_Q8: yq[m][c] = quant_oq(conv + bias (+ rowadd) (+ residual)) - 128, int8
                                       [M][Cout]: for an output whose ONLY consumer is the next QuantLayer's
                                       activation quantizer (quant_layer.py:312-313); y is unused.
+                                    TFMQ_OUT_GEGLU_Q8_FAST (4; round 4): TFMQ_OUT_GEGLU_Q8 with the epilogue arithmetic sized for its
+                                      consumer -- the value is rounded to one of 256 bins next instruction: Phi(g) as a logistic of an
+                                      odd quintic (|g Phi(g) - gelu(g)| <= 2.8e-5), the output delta folded into the value's scale, the
+                                      zero-point corrections into the biases: 13.75 instead of 22.75 VALU issue slots per output.
+                                      Bins within 1 of TFMQ_OUT_GEGLU_Q8's, < 2e-3 of them moved (tests/test_geglu_fast_gpu.py).
+                                      Only the register-direct pointwise kernel (tile AUTO / DIRECT) takes it; otherwise
+                                      TFMQ_ERR_UNSUPPORTED.  The sampling path's default (TFMQ_GELU_EXACT=1 restores mode 2).
                                     rowadd / residual are defined for TFMQ_OUT_F32 and TFMQ_OUT_Q8, stats for F32. */
   tfmq_qsel oq;                  /* TFMQ_OUT_GEGLU_Q8 / TFMQ_OUT_Q8: activation quantizer of the consumer */
   int8_t* yq;                    /* TFMQ_OUT_GEGLU_Q8 / TFMQ_OUT_Q8: int8 output */
@@ -234,7 +241,7 @@ typedef struct tfmq_conv_desc {
                                     TFMQ_ERR_ARG; split-K launches of one handle must be stream-ordered.  Ignored by the slab /
                                     register-direct kernels (pin a tile shape together with ksplit). */
 } tfmq_conv_desc;
-enum { TFMQ_OUT_F32 = 0, TFMQ_OUT_F16 = 1, TFMQ_OUT_GEGLU_Q8 = 2, TFMQ_OUT_Q8 = 3 };
+enum { TFMQ_OUT_F32 = 0, TFMQ_OUT_F16 = 1, TFMQ_OUT_GEGLU_Q8 = 2, TFMQ_OUT_Q8 = 3, TFMQ_OUT_GEGLU_Q8_FAST = 4 };
 enum { TFMQ_TILE_AUTO = 0, TFMQ_TILE_128 = 1, TFMQ_TILE_64 = 2, TFMQ_TILE_256 = 3, TFMQ_TILE_128x64 = 4, TFMQ_TILE_SLAB = 5, TFMQ_TILE_DIRECT = 6,
        TFMQ_TILE_SLAB128 = 7 };
 int tfmq_conv2d_w4a8(tfmq_handle h, const tfmq_conv_desc* d, void* stream);

@@ -64,7 +64,7 @@ def test_geglu_epilogue_bit_exact(ops, B, T, cin, inner):
     perm = ops.geglu_perm(inner)
     pwp = ops.pack_w4(w[perm].contiguous().to(DEV), wd.reshape(-1)[perm].contiguous().to(DEV),
                       wz.reshape(-1)[perm].contiguous().to(DEV), bias=b[perm].contiguous().to(DEV))
-    got = ops.conv2d_w4a8(xq, pwp, sel, geglu_oq=osel)
+    got = ops.conv2d_w4a8(xq, pwp, sel, geglu_oq=osel, geglu_exact=True)
     assert got.dtype == torch.int8 and got.shape == (B, T, 1, inner)
     assert torch.equal(got.reshape(B, T, inner), want)
     # and against the oracle's arithmetic on the same fake-quantised operands (bins may differ only where the
@@ -418,6 +418,7 @@ def test_direct_pointwise_kernel_is_bit_identical_to_the_tile_kernels(ops, T, ci
         pw = ops.pack_w4(w.to(DEV)[perm].contiguous(), wd.to(DEV).reshape(-1)[perm].contiguous(), wz.to(DEV).reshape(-1)[perm].contiguous(),
                          bias=b.to(DEV)[perm].contiguous())
         kw["geglu_oq"] = oq
+        kw["geglu_exact"] = True          # (the consumer-sized GELU of round 4 lives on the register-direct kernel only: tests/test_geglu_fast_gpu.py)
     else:
         pw = ops.pack_w4(w.to(DEV), wd.to(DEV), wz.to(DEV), bias=b.to(DEV))
         if mode.startswith("f16"):

@@ -242,6 +242,37 @@ __device__ __forceinline__ f2 gelu2(f2 g) {
   return f2{fmaxf(g.x, 0.0f), fmaxf(g.y, 0.0f)} - ag * (pl * e);
 }
 
+// ---- GELU sized for its consumer (round 4).  In the fused GEGLU epilogues value * gelu(gate) is rounded to one of 256 activation bins by
+// the next instruction, and the epilogue is VALU-bound (the 7.1.26 form above: ~11.5 issue slots per value counting v_rcp / v_exp twice).
+// Phi(g) ~= 1 / (1 + exp2(g (c1 + c3 g^2 + c5 g^4))) with the minimax coefficients below (fitted against 0.5 (1 + erf(g / sqrt 2)) in
+// float64, -log2(e) folded in): |g Phi(g) - gelu(g)| <= 2.8e-5 absolute over the whole line -- 8 issue slots, no abs / max / select.  The
+// argument of the polynomial is clamped to [-9, 9] (c5 < 0: the quartic turns over at |g| ~ 11; beyond 9 the logistic is 0 or 1 to 1e-11),
+// the final product uses the unclamped g.  Used by TFMQ_OUT_GEGLU_Q8_FAST only; the calibration path (k_geglu) and TFMQ_OUT_GEGLU_Q8 keep
+// the 5e-7 form.  tests/test_geglu_fast_gpu.py: bins within 1 of the exact epilogue's, < 2e-3 of them moved.
+__device__ __forceinline__ f2 gelu_fast2(f2 g) {
+  const f2 gc = {__builtin_amdgcn_fmed3f(g.x, -9.0f, 9.0f), __builtin_amdgcn_fmed3f(g.y, -9.0f, 9.0f)};
+  const f2 x2 = gc * gc;
+  f2 pl = pk_fma(f2{1.02381220e-3f, 1.02381220e-3f}, x2, f2{-1.06834617e-1f, -1.06834617e-1f});
+  pl = pk_fma(pl, x2, f2{-2.30105644f, -2.30105644f});
+  const f2 u = pl * gc;
+  const f2 dn = f2{__builtin_amdgcn_exp2f(u.x), __builtin_amdgcn_exp2f(u.y)} + f2{1.0f, 1.0f};
+  return g * f2{__builtin_amdgcn_rcpf(dn.x), __builtin_amdgcn_rcpf(dn.y)};
+}
+__device__ __forceinline__ float gelu_fast_f(float g) {
+  const f2 r = gelu_fast2(f2{g, g});
+  return r.x;
+}
+// four (value / delta) and gelu(gate) pairs -> bins - 128: q = value' * G + zp in one packed FMA, round-half-even, saturating byte pack
+__device__ __forceinline__ unsigned geglu_fast_pack4(f2 a0, f2 G0, f2 a1, f2 G1, float zp) {
+  const f2 z = {zp, zp};
+  const f2 q0 = pk_fma(a0, G0, z), q1 = pk_fma(a1, G1, z);
+  unsigned w = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_rintf(q0.x), 0, 0u);
+  w = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_rintf(q0.y), 1, w);
+  w = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_rintf(q1.x), 2, w);
+  w = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_rintf(q1.y), 3, w);
+  return w ^ 0x80808080u;
+}
+
 static inline int ceil_div(long a, long b) { return static_cast<int>((a + b - 1) / b); }
 
 // ---------------------------------------------------------------- packed int4 weight layout

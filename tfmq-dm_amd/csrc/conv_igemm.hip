@@ -990,7 +990,7 @@ template <bool INT8>
 static int launch_conv(tfmq_handle h, const tfmq_conv_desc* dd, void* stream) {
   TFMQ_CHECK_ARG(h, h && dd, "conv: null pointer");
   const tfmq_conv_desc& d = *dd;
-  TFMQ_CHECK_ARG(h, d.x && d.w && (d.y || d.out_mode == TFMQ_OUT_GEGLU_Q8 || d.out_mode == TFMQ_OUT_Q8), "conv: null operand");
+  TFMQ_CHECK_ARG(h, d.x && d.w && (d.y || d.out_mode == TFMQ_OUT_GEGLU_Q8 || d.out_mode == TFMQ_OUT_GEGLU_Q8_FAST || d.out_mode == TFMQ_OUT_Q8), "conv: null operand");
   TFMQ_CHECK_ARG(h, d.B > 0 && d.H > 0 && d.W > 0 && d.Cin > 0 && d.Cout > 0 && d.KH > 0 && d.KW > 0 && d.stride > 0,
                  "conv: bad geometry");
   TFMQ_CHECK_ARG(h, d.Ho > 0 && d.Wo > 0 && d.ldy >= d.Cout + d.y_coff, "conv: bad output geometry");
@@ -999,10 +999,10 @@ static int launch_conv(tfmq_handle h, const tfmq_conv_desc* dd, void* stream) {
   TFMQ_CHECK_ARG(h, d.out_mode == TFMQ_OUT_F32 || d.out_mode == TFMQ_OUT_F16 || !d.stats, "conv: stats need out_mode F32 or F16");
   TFMQ_CHECK_ARG(h, d.out_mode != TFMQ_OUT_Q8 || (d.yq && d.oq.qtable && d.Cout % 4 == 0 && (!d.rowadd || d.rowadd_ld % 4 == 0)),
                  "conv: Q8 output needs yq, oq and Cout % 4 == 0");
-  TFMQ_CHECK_ARG(h, d.out_mode != TFMQ_OUT_GEGLU_Q8 ||
+  TFMQ_CHECK_ARG(h, (d.out_mode != TFMQ_OUT_GEGLU_Q8 && d.out_mode != TFMQ_OUT_GEGLU_Q8_FAST) ||
                         (INT8 && d.yq && d.oq.qtable && d.KH == 1 && d.KW == 1 && d.Cout % 128 == 0 && d.Cout / 2 % 4 == 0),
                  "conv: GEGLU epilogue needs a w4a8 Linear with Cout % 128 == 0, yq and oq");
-  TFMQ_CHECK_ARG(h, d.out_mode >= 0 && d.out_mode <= 3, "conv: bad out_mode");
+  TFMQ_CHECK_ARG(h, d.out_mode >= 0 && d.out_mode <= 4, "conv: bad out_mode");
   TFMQ_CHECK_ARG(h, !d.yt || (d.out_mode == TFMQ_OUT_F16 && d.t_col0 >= 0 && d.t_col0 % 128 == 0 && d.t_col0 < d.Cout &&
                               (d.Ho * d.Wo) % 4 == 0),
                  "conv: transposed region needs out_mode F16, t_col0 % 128 == 0 and Ho*Wo % 4 == 0");
@@ -1073,6 +1073,10 @@ static int launch_conv(tfmq_handle h, const tfmq_conv_desc* dd, void* stream) {
         launch_conv_lin(h, p, as_stream(stream))) {
       TFMQ_LAUNCH_CHECK(h);
       return TFMQ_OK;
+    }
+    if (d.out_mode == TFMQ_OUT_GEGLU_Q8_FAST) {      // only the register-direct kernel carries the consumer-sized GELU
+      h->err = "conv_w4a8: TFMQ_OUT_GEGLU_Q8_FAST needs a launch the register-direct pointwise kernel takes (tile AUTO / DIRECT, Cin % 32 == 0)";
+      return TFMQ_ERR_UNSUPPORTED;
     }
   }
   if constexpr (INT8) {

@@ -24,7 +24,8 @@
 
 namespace {
 
-enum { LIN_F16 = 0, LIN_Q8 = 1, LIN_GEGLU = 2 };
+enum { LIN_F16 = 0, LIN_Q8 = 1, LIN_GEGLU = 2, LIN_GEGLU_FAST = 3 };
+template <int MODE> constexpr bool lin_is_geglu = MODE == LIN_GEGLU || MODE == LIN_GEGLU_FAST;
 
 // diagnostics build (-DTFMQ_PHASE_TIMERS): cycles a wave of k_lin_stream spends in each phase of its loop, per block
 #ifdef TFMQ_PHASE_TIMERS
@@ -55,7 +56,7 @@ __device__ __forceinline__ void lin_epilogue(const ConvP& p, v16i (&acc)[2][2], 
   constexpr int BN = 128;
   const tfmq_conv_desc& d = p.d;
   const int h = lane >> 5;
-  auto ncol0 = [&](int j) { return MODE == LIN_GEGLU ? j * 64 + wn * 32 : (wn * 2 + j) * 32; };
+  auto ncol0 = [&](int j) { return lin_is_geglu<MODE> ? j * 64 + wn * 32 : (wn * 2 + j) * 32; };
   auto affine2 = [&](int a0, int a1, float sx, float sy, int kx, int ky, float bx, float by) -> f2 {
     return f2{sx, sy} * f2{static_cast<float>(a0 + kx), static_cast<float>(a1 + ky)} + f2{bx, by};
   };
@@ -85,7 +86,32 @@ __device__ __forceinline__ void lin_epilogue(const ConvP& p, v16i (&acc)[2][2], 
       const bool mok = m < p.M;
       const int thw = d.Ho * d.Wo;
       const int tb = transposed ? m / thw : 0, tt = m - tb * thw;
-      if constexpr (MODE == LIN_GEGLU) {
+      if constexpr (MODE == LIN_GEGLU_FAST) {
+        // value' = (scale / delta_o) float(acc) + bias', gate = scale float(acc) + bias'' (zero-point corrections folded into the biases
+        // by the table), G = gelu_fast2(gate), bin = rint(value' G + zp): 13.75 issue slots per output instead of 22.75
+        const int inner = d.Cout >> 1;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int co = 16 * h + 8 * u;
+          f2 a[4], g[4];
+#pragma unroll
+          for (int e = 0; e < 2; ++e) {
+            const float4 sa = *reinterpret_cast<const float4*>(cs + ncol0(0) + co + 4 * e), ba = *reinterpret_cast<const float4*>(cs + 2 * BN + ncol0(0) + co + 4 * e);
+            const float4 sg = *reinterpret_cast<const float4*>(cs + ncol0(1) + co + 4 * e), bg = *reinterpret_cast<const float4*>(cs + 2 * BN + ncol0(1) + co + 4 * e);
+            const v16i& av = acc[i][0];
+            const v16i& gv = acc[i][1];
+            a[2 * e] = pk_fma(f2{sa.x, sa.y}, f2{static_cast<float>(av[8 * u + 4 * e]), static_cast<float>(av[8 * u + 4 * e + 1])}, f2{ba.x, ba.y});
+            a[2 * e + 1] = pk_fma(f2{sa.z, sa.w}, f2{static_cast<float>(av[8 * u + 4 * e + 2]), static_cast<float>(av[8 * u + 4 * e + 3])}, f2{ba.z, ba.w});
+            g[2 * e] = pk_fma(f2{sg.x, sg.y}, f2{static_cast<float>(gv[8 * u + 4 * e]), static_cast<float>(gv[8 * u + 4 * e + 1])}, f2{bg.x, bg.y});
+            g[2 * e + 1] = pk_fma(f2{sg.z, sg.w}, f2{static_cast<float>(gv[8 * u + 4 * e + 2]), static_cast<float>(gv[8 * u + 4 * e + 3])}, f2{bg.z, bg.w});
+          }
+          const unsigned w0 = geglu_fast_pack4(a[0], gelu_fast2(g[0]), a[1], gelu_fast2(g[1]), oqp.y);
+          const unsigned w1 = geglu_fast_pack4(a[2], gelu_fast2(g[2]), a[3], gelu_fast2(g[3]), oqp.y);
+          const int oc = (n0 >> 1) + wn * 32 + co;
+          if (mok && oc < inner) *reinterpret_cast<uint2*>(d.yq + static_cast<size_t>(m) * inner + oc) = make_uint2(w0, w1);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      } else if constexpr (MODE == LIN_GEGLU) {
         const int inner = d.Cout >> 1;
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
@@ -220,7 +246,7 @@ __device__ __forceinline__ void lin_epilogue(const ConvP& p, v16i (&acc)[2][2], 
       }
     }
   };
-  if constexpr (MODE == LIN_F16) {
+  if constexpr (MODE == LIN_F16 || MODE == LIN_GEGLU_FAST) {
     epi(std::false_type{});
   } else {
     if (__builtin_expect((__float_as_uint(oqp.x) & 0x7fffffu) == 0x7fffffu, 0)) epi(std::true_type{});
@@ -241,7 +267,7 @@ __device__ __forceinline__ void lin_load_res(const ConvP& p, uint4 (&rres)[2][2]
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
-        const int n = n0 + (MODE == LIN_GEGLU ? j * 64 + wn * 32 : (wn * 2 + j) * 32) + 16 * h + 8 * u;
+        const int n = n0 + (lin_is_geglu<MODE> ? j * 64 + wn * 32 : (wn * 2 + j) * 32) + 16 * h + 8 * u;
         const int nc = n < d.Cout ? n : 0;
         rres[i][j][u] = *reinterpret_cast<const uint4*>(reinterpret_cast<const __half*>(d.residual) + static_cast<size_t>(mc) * d.Cout + nc);
       }
@@ -322,7 +348,7 @@ __global__ __launch_bounds__(256, 3) void k_lin_direct(ConvP p) {
 
   // fragment rows: pixels (wm * 2 + i) * 32 + lane % 32; channels of N-tile j: plain (wn * 2 + j) * 32, GEGLU j * 64 + wn * 32
   // (tile columns [0, 64) = value, [64, 128) = gate of the same 64 output channels)
-  auto ncol0 = [&](int j) { return MODE == LIN_GEGLU ? j * 64 + wn * 32 : (wn * 2 + j) * 32; };
+  auto ncol0 = [&](int j) { return lin_is_geglu<MODE> ? j * 64 + wn * 32 : (wn * 2 + j) * 32; };
   const int fsw = (h ^ ((lane >> 2) & 3)) << 4;           // physical 16-byte slot of k-slot h in this lane's row
   const int brow = lin_brow(lane & 31);                    // weight rows in the permuted order (see lin_brow)
   const int bsw = (h ^ ((brow >> 2) & 3)) << 4;
@@ -366,7 +392,7 @@ __global__ __launch_bounds__(256, 3) void k_lin_direct(ConvP p) {
   float2 oqp = make_float2(1.0f, 0.0f);
   if constexpr (MODE != LIN_F16) oqp = load_qparam(d.oq);
   uint4 rres[2][2][2];                     // MODE F16 / Q8 with a residual: 8 channels x fp16 per (i, j, register octet)
-  const bool has_res = MODE != LIN_GEGLU && d.residual != nullptr;
+  const bool has_res = !lin_is_geglu<MODE> && d.residual != nullptr;
   if (has_res && d.res_f16) lin_load_res<MODE>(p, rres, m0, n0, wm, wn, lane);
 
   int st_c = 0, st_i = 2;
@@ -409,9 +435,18 @@ __global__ __launch_bounds__(256, 3) void k_lin_direct(ConvP p) {
   float* cs = reinterpret_cast<float*>(lds + CONST_OFF);
   const int za = static_cast<int>(aqp.y);
   if (tid < BN) {
-    cs[tid] = aqp.x * c_ws;
-    reinterpret_cast<int*>(cs)[BN + tid] = (128 - za) * (c_rs - p.Ktot * c_zp);
-    cs[2 * BN + tid] = c_bias;
+    const float sc = aqp.x * c_ws;
+    const int kc = (128 - za) * (c_rs - p.Ktot * c_zp);
+    if constexpr (MODE == LIN_GEGLU_FAST) {      // zero-point correction folded into the bias; value columns pre-divided by the output delta
+      const float bf = sc * static_cast<float>(kc) + c_bias;
+      const bool val = (tid & 64) == 0;
+      cs[tid] = val ? sc / oqp.x : sc;
+      cs[2 * BN + tid] = val ? bf / oqp.x : bf;
+    } else {
+      cs[tid] = sc;
+      reinterpret_cast<int*>(cs)[BN + tid] = kc;
+      cs[2 * BN + tid] = c_bias;
+    }
   }
   __syncthreads();
 
@@ -464,9 +499,9 @@ bool launch_conv_lin(tfmq_handle h, ConvP& p, hipStream_t st) {
     mode = LIN_F16;
   } else if (d.out_mode == TFMQ_OUT_Q8) {
     mode = LIN_Q8;
-  } else if (d.out_mode == TFMQ_OUT_GEGLU_Q8) {
+  } else if (d.out_mode == TFMQ_OUT_GEGLU_Q8 || d.out_mode == TFMQ_OUT_GEGLU_Q8_FAST) {
     if (d.residual || d.Cout % 128 != 0 || (d.Cout >> 1) % 8 != 0) return false;
-    mode = LIN_GEGLU;
+    mode = d.out_mode == TFMQ_OUT_GEGLU_Q8 ? LIN_GEGLU : LIN_GEGLU_FAST;
   } else {
     return false;
   }
@@ -481,7 +516,8 @@ bool launch_conv_lin(tfmq_handle h, ConvP& p, hipStream_t st) {
 #endif
   if (mode == LIN_F16) hipLaunchKernelGGL((k_lin_direct<LIN_F16>), grid, dim3(256), 0, st, p);
   else if (mode == LIN_Q8) hipLaunchKernelGGL((k_lin_direct<LIN_Q8>), grid, dim3(256), 0, st, p);
-  else hipLaunchKernelGGL((k_lin_direct<LIN_GEGLU>), grid, dim3(256), 0, st, p);
+  else if (mode == LIN_GEGLU) hipLaunchKernelGGL((k_lin_direct<LIN_GEGLU>), grid, dim3(256), 0, st, p);
+  else hipLaunchKernelGGL((k_lin_direct<LIN_GEGLU_FAST>), grid, dim3(256), 0, st, p);
 #ifdef TFMQ_PHASE_TIMERS
   if (p.dbg && getenv("TFMQ_PHASE_PRINT")) {
     (void)hipStreamSynchronize(st);

@@ -528,6 +528,8 @@ def _tune_conv(h, name, kind, d, dsc):
         return 0                      # cannot time inside a capture / nothing to choose / not idempotent
     if kind == "f16" and dsc.x2:
         return 6                      # two sources: only the register-direct pointwise kernel reads them
+    if dsc.out_mode == 4:
+        return 6                      # TFMQ_OUT_GEGLU_Q8_FAST: only the register-direct pointwise kernel carries that epilogue
     if kind == "f16" and dsc.x_f16 and slab_ok(dsc):
         # fp16 3x3: the slab kernel's K order differs from the tile kernels' -- one rule for every batch size; its 256- and 128-pixel
         # forms accumulate every output in the same order (bit-identical), so THAT choice may be measured
@@ -652,7 +654,8 @@ def conv2d_w4a8(xq: torch.Tensor, pw: PackedW4, aq: QSel, stride: int = 1, pad: 
                 up2x: bool = False, rowadd: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
                 out: Optional[torch.Tensor] = None, y_coff: int = 0, rowadd_ld=None, rowadd_step=None,
                 rowadd_step_stride: int = 0, want_stats: bool = False, out_f16: bool = False,
-                geglu_oq: Optional[QSel] = None, t_col0: Optional[int] = None, out_q8: Optional[QSel] = None):
+                geglu_oq: Optional[QSel] = None, t_col0: Optional[int] = None, out_q8: Optional[QSel] = None,
+                geglu_exact: bool = False):
     """xq: int8 NHWC [B,H,W,Cin] (bin-128).  pad = (top, left, bottom, right).  -> fp32 NHWC.
     out_f16: fp16 output (operands of the attention kernel).  geglu_oq: `pw` is a geglu_perm-ordered GEGLU projection;
     returns int8 [B,Ho,Wo,Cout/2] = quant_geglu_oq(value * gelu(gate)) - 128.
@@ -696,7 +699,10 @@ def conv2d_w4a8(xq: torch.Tensor, pw: PackedW4, aq: QSel, stride: int = 1, pad: 
     dsc.aq = aq
     osz = 4.0
     if geglu_oq is not None:
-        dsc.out_mode, dsc.oq, dsc.yq, dsc.y = 2, geglu_oq, y.data_ptr(), None
+        # consumer-sized GELU (TFMQ_OUT_GEGLU_Q8_FAST, round 4) where the register-direct kernel takes the launch; TFMQ_GELU_EXACT=1 or
+        # geglu_exact=True keep the 5e-7 form (TFMQ_OUT_GEGLU_Q8, bit-identical to the un-fused geglu + quantise)
+        fast = (not geglu_exact) and os.environ.get("TFMQ_GELU_EXACT", "0") != "1" and cin % 64 == 0 and pw.cout % 128 == 0
+        dsc.out_mode, dsc.oq, dsc.yq, dsc.y = (4 if fast else 2), geglu_oq, y.data_ptr(), None
         osz = 0.5
     elif out_q8 is not None:
         dsc.out_mode, dsc.oq, dsc.yq, dsc.y = 3, out_q8, y.data_ptr(), None
