@@ -247,6 +247,36 @@ enum { TFMQ_TILE_AUTO = 0, TFMQ_TILE_128 = 1, TFMQ_TILE_64 = 2, TFMQ_TILE_256 = 
 int tfmq_conv2d_w4a8(tfmq_handle h, const tfmq_conv_desc* d, void* stream);
 int tfmq_conv2d_f16(tfmq_handle h, const tfmq_conv_desc* d, void* stream);
 
+/* ---- K5f (round 4): the feed-forward half of a BasicTransformerBlock as one launch:
+ *   y = ff.net.2( quant_aq2( value * gelu(gate) ) ) + x,   value | gate = ff.net.0.proj( quant_aq0( LayerNorm(x) ) )
+ * (`x = self.ff(self.norm3(x)) + x`, ldm/modules/attention.py:37-64,152-215 under QuantBasicTransformerBlock, quant/quant_block.py:248-299;
+ * both Linears are w4a8 QuantLayers, quant/quant_layer.py:306-340).  Replaces tfmq_layernorm_h + tfmq_conv2d_w4a8(TFMQ_OUT_GEGLU_Q8_FAST) +
+ * tfmq_conv2d_w4a8(TFMQ_OUT_F16 | TFMQ_OUT_Q8, residual) and agrees with that chain bit for bit; HBM sees the fp16 row once in, once out.
+ * A workgroup owns 256 tokens, a lane one token; the GEGLU bins go from the accumulators straight into the second GEMM's MFMA operand. */
+typedef struct tfmq_ff_desc {
+  int32_t M, C, inner;           /* tokens, token width (320), hidden width of the GEGLU (ff.net.0.proj has 2 * inner outputs; % 64 == 0) */
+  const uint16_t* x;             /* fp16 [M][C]: the LayerNorm's input and the residual */
+  const float* gamma;            /* LayerNorm weight / bias [C], eps */
+  const float* beta;
+  float eps;
+  tfmq_qsel aq0;                 /* activation quantizer of ff.net.0.proj (consumes the LayerNorm output) */
+  const int8_t* w1;              /* ff.net.0.proj: tfmq_expand_w4 of the rows in ops.geglu_perm order ([64 value | 64 gate] per 128 rows) */
+  const int32_t* wmeta1;         /* [2 * inner][4], wscale1 / bias1 [2 * inner], in the same row order */
+  const float* wscale1;
+  const float* bias1;            /* or NULL */
+  tfmq_qsel aq2;                 /* activation quantizer of ff.net.2 (consumes value * gelu(gate)) */
+  const int8_t* w2;              /* ff.net.2: tfmq_expand_w4, [C][inner] */
+  const int32_t* wmeta2;
+  const float* wscale2;
+  const float* bias2;            /* or NULL */
+  uint16_t* y;                   /* fp16 [M][C] output (oq.qtable == NULL) */
+  tfmq_qsel oq;                  /* qtable != NULL: the output's only consumer is this activation quantizer: int8 bins to yq */
+  int8_t* yq;
+  float* ws;                     /* scratch, 4 * inner floats: the GEGLU projection's folded per-channel constants (written per call) */
+} tfmq_ff_desc;
+/* TFMQ_ERR_UNSUPPORTED for a token width other than 320 (callers keep the three-launch chain). */
+int tfmq_ff_fused(tfmq_handle h, const tfmq_ff_desc* d, void* stream);
+
 /* ---- K7: temporal-information block GEMVs (QuantTemporalInformationBlockDDIM.forward,
  * quant_block.py:52-64; ddim/models/diffusion.py:6-24,310-313) -------------------------- */
 /* emb[m][dim] = [sin(t f_i), cos(t f_i)] (DDIM order, denominator half-1) or

@@ -29,7 +29,7 @@ def test_header_symbols_all_exported(lib):
     l = lib.load()
     for name in declared:
         assert hasattr(l, name), name
-    assert l.tfmq_abi_version() == 7
+    assert l.tfmq_abi_version() == 8
 
 
 def test_struct_layouts_match_header(lib):
@@ -38,6 +38,7 @@ def test_struct_layouts_match_header(lib):
     assert C.sizeof(lib.QSel) == 24
     assert C.sizeof(lib.ConvDesc) == 13 * 4 + 4 + 5 * 8 + 24 + 2 * 8 + 8 + 2 * 8 + 8 + 16 + 24 + 8 + 8 + 8 + 8 + 8 + 8 + 8 + 8   # ... + x2 + cin1 (padded) + w64 + ksplit (padded)
     assert C.sizeof(lib.GnDesc) == 16 + 32 + 12 + 4 + 24 + 24 + 8
+    assert C.sizeof(lib.FfDesc) == 16 + 3 * 8 + 8 + 24 + 4 * 8 + 24 + 4 * 8 + 8 + 24 + 8 + 8      # tfmq_ff_desc (round 4)
 
 
 def test_cpu_tensor_is_refused_loudly(lib):

@@ -55,6 +55,19 @@ class GnDesc(C.Structure):
     ]
 
 
+class FfDesc(C.Structure):
+    """tfmq_ff_desc"""
+    _fields_ = [
+        ("M", C.c_int32), ("C", C.c_int32), ("inner", C.c_int32),
+        ("x", c_void_p), ("gamma", c_void_p), ("beta", c_void_p), ("eps", c_float),
+        ("aq0", QSel),
+        ("w1", c_void_p), ("wmeta1", c_void_p), ("wscale1", c_void_p), ("bias1", c_void_p),
+        ("aq2", QSel),
+        ("w2", c_void_p), ("wmeta2", c_void_p), ("wscale2", c_void_p), ("bias2", c_void_p),
+        ("y", c_void_p), ("oq", QSel), ("yq", c_void_p), ("ws", c_void_p),
+    ]
+
+
 # name -> (restype, argtypes); every symbol declared in include/tfmq_hip.h
 _SIGS = {
     "tfmq_abi_version": (c_int, []),
@@ -83,6 +96,7 @@ _SIGS = {
     "tfmq_pack_w_f16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "tfmq_conv2d_w4a8": (c_int, [c_void_p, C.POINTER(ConvDesc), c_void_p]),
     "tfmq_conv2d_f16": (c_int, [c_void_p, C.POINTER(ConvDesc), c_void_p]),
+    "tfmq_ff_fused": (c_int, [c_void_p, C.POINTER(FfDesc), c_void_p]),
     "tfmq_timestep_embedding": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "tfmq_linear_small_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "tfmq_linear_small_w4": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, QSel, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),

@@ -329,6 +329,11 @@ class LdmUNetEngine(DdimUNetEngine):
         ff0, ff2 = L[p + ".ff.net.0.proj"], L[p + ".ff.net.2"]
         gp = self.geglu_fused.get(p + ".ff.net.0.proj")
         if gp is not None and self.calib is None:
+            if (x.dtype == torch.float16 and ff2.kind == "w4a8" and not ff2.wide and ops.ff_fused_ok(x.shape[-1], gp.cout // 2, gp, ff2.p)
+                    and (out_aq is not None or self._h16)):
+                # round 4: norm3 -> ff.net.0.proj -> GEGLU -> quantise -> ff.net.2 (+ x) as ONE launch, a token per lane; the GEGLU bins
+                # go from the accumulators into the second GEMM's MFMA operand.  Bit-identical to the three launches below.
+                return ops.ff_fused(x, self.sd[p + ".norm3.weight"], self.sd[p + ".norm3.bias"], 1e-5, ff0.aq, gp, ff2.aq, ff2.p, out_q8=out_aq)
             xq = self._ln(p + ".norm3", x, ff0)
             B, T, Cc = xq.shape
             g = ops.conv2d_w4a8(xq.reshape(B, T, 1, Cc), gp, ff0.aq, geglu_oq=ff2.aq).reshape(B, T, -1)

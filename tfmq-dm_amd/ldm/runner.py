@@ -155,7 +155,7 @@ class LatentRunner:
                 raise TfmqError("LatentRunner.quantize: the text-guided calibration needs prompts")
             cali = DG.generate_cali_text_guided_data(self.model, self.sampler, T=self.steps, c=1, batch_size=1, prompts=tuple(prompts),
                                                      shape=shape)
-            w_cali, interval, bs = cali, int(_get(o, "cali_interval", 256)), 32
+            w_cali, interval, bs = cali, int(_get(o, "cali_interval", 256)), 8       # txt2img.py:473-486 (32 only in its mp.spawn kwargs)
         logger.info("Calibration data generated.")
         torch.cuda.empty_cache()
         setattr(unet, "split", True)
@@ -174,6 +174,10 @@ class LatentRunner:
                        interval=interval, w_cali_data=w_cali, a_cali_data=cali, iters=iters, batch_size=bs, w=0.01, asym=o.asym,
                        warmup=0.2, opt_mode=RLOSS.MSE, multi_gpu=False)
         return "calibrated"
+
+    #: (interval, single-GPU AdaRound mini-batch) of cali_model per driver flow: sample_diffusion_ldm.py:534-546 (256, 32),
+    #: latent_imagenet_diffusion.py:275-287 (512, 8), txt2img.py:473-486 (256, 8); the multi-GPU kwargs use 32 in all three
+    CALI_RECIPE = {"uncond": (256, 32), "class": (512, 8), "text": (256, 8)}
 
     # ------------------------------------------------------------------ sampling
     @torch.no_grad()

@@ -12,7 +12,7 @@ from typing import Optional, Tuple
 
 import torch
 
-from ._lib import ConvDesc, GnDesc, QSel, TfmqError, handle
+from ._lib import ConvDesc, FfDesc, GnDesc, QSel, TfmqError, handle
 
 NULL = None
 
@@ -919,6 +919,58 @@ def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: flo
     handle(d).call("layernorm_h" if xh else "layernorm", _p(x), _p(gamma), _p(beta), float(eps), rows, Cc,
                    aq if quant else QSel(None, None, 0, 0), _p(yq), _p(yf), _stream(d))
     return yq, yf
+
+
+def ff_fused_ok(C_: int, inner: int, pw1, pw2) -> bool:
+    """Launches tfmq_ff_fused takes: token width 320 (the 64 x 64 level of SD v1), inner % 64 == 0, both Linears with their
+    int8-expanded operands (tfmq_expand_w4).  TFMQ_FF_FUSED=0 keeps the three-launch chain (A/B runs)."""
+    return (os.environ.get("TFMQ_FF_FUSED", "1") != "0" and os.environ.get("TFMQ_GELU_EXACT", "0") != "1" and C_ == 320 and inner % 64 == 0
+            and pw1.w8 is not None and pw2.w8 is not None and pw1.cin == C_ and pw1.cout == 2 * inner and pw2.cin == inner and pw2.cout == C_
+            and pw1.kh == pw1.kw == pw2.kh == pw2.kw == 1)
+
+
+def ff_fused(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float, aq0: QSel, pw1: "PackedW4", aq2: QSel, pw2: "PackedW4",
+             out_q8: Optional[QSel] = None) -> torch.Tensor:
+    """x: fp16 [..., C] tokens of the fp16 activation stream.  ff.net.2(quant(value * gelu(gate))) + x with value | gate =
+    ff.net.0.proj(quant(LayerNorm(x))) in one launch (tfmq_ff_fused; `x = self.ff(self.norm3(x)) + x`, ldm/modules/attention.py:37-64,
+    152-215).  pw1: the GEGLU projection packed in ops.geglu_perm row order; pw2: ff.net.2.  Returns fp16 [..., C], or with out_q8 the
+    consumer quantizer's int8 bins.  Bit-identical to layernorm -> conv2d_w4a8(geglu_oq) -> conv2d_w4a8(residual=x)."""
+    d = _dev(x)
+    _chk(x, torch.float16, "x")
+    Cc = x.shape[-1]
+    inner = pw1.cout // 2
+    if not ff_fused_ok(Cc, inner, pw1, pw2):
+        raise TfmqError("ff_fused: unsupported shape (token width 320, inner % 64 == 0, w4a8 Linears)")
+    M = x.numel() // Cc
+    y = _alloc(x.shape, dtype=torch.int8 if out_q8 is not None else torch.float16, device=x.device)
+    ws = _alloc(4 * inner, dtype=torch.float32, device=x.device)
+    dsc = FfDesc()
+    dsc.M, dsc.C, dsc.inner = M, Cc, inner
+    dsc.x, dsc.gamma, dsc.beta, dsc.eps = x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), float(eps)
+    dsc.aq0, dsc.aq2 = aq0, aq2
+    dsc.w1, dsc.wmeta1, dsc.wscale1 = pw1.w8.data_ptr(), pw1.wmeta.data_ptr(), pw1.wscale.data_ptr()
+    dsc.bias1 = None if pw1.bias is None else pw1.bias.data_ptr()
+    dsc.w2, dsc.wmeta2, dsc.wscale2 = pw2.w8.data_ptr(), pw2.wmeta.data_ptr(), pw2.wscale.data_ptr()
+    dsc.bias2 = None if pw2.bias is None else pw2.bias.data_ptr()
+    if out_q8 is not None:
+        dsc.oq, dsc.yq, dsc.y = out_q8, y.data_ptr(), None
+    else:
+        dsc.oq, dsc.yq, dsc.y = QSel(None, None, 0, 0), None, y.data_ptr()
+    dsc.ws = ws.data_ptr()
+    h = handle(d)
+    if _conv_prof is None:
+        h.call("ff_fused", C.byref(dsc), _stream(d))
+        return y
+    e0, e1 = C.c_int(), C.c_int()
+    h.call("event_create", C.byref(e0))
+    h.call("event_create", C.byref(e1))
+    h.call("event_record", e0.value, _stream(d))
+    h.call("ff_fused", C.byref(dsc), _stream(d))
+    h.call("event_record", e1.value, _stream(d))
+    # algorithmic bytes: the fp16 row in and out (or int8 out), both weight operands
+    _conv_prof.append((e0.value, e1.value, 2.0 * M * (2 * inner * Cc + inner * Cc), "w4a8",
+                       M * Cc * (2.0 + (1.0 if out_q8 is not None else 2.0)) + 3.0 * inner * Cc))
+    return y
 
 
 def geglu(hin: torch.Tensor, aq: Optional[QSel] = None, want_f32: bool = False):
