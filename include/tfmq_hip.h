@@ -277,6 +277,47 @@ typedef struct tfmq_ff_desc {
 /* TFMQ_ERR_UNSUPPORTED for a token width other than 320 (callers keep the three-launch chain). */
 int tfmq_ff_fused(tfmq_handle h, const tfmq_ff_desc* d, void* stream);
 
+/* ---- K5c (round 4): chains of w4a8 token Linears (K = C = 320) around the attention of a BasicTransformerBlock as one launch, a token
+ * per lane (the layout of tfmq_ff_fused): an input stage, up to three GEMMs over the resident token tile, optionally ONE LayerNorm +
+ * quantise between a C-wide GEMM and its successor.  Replaces, bit for bit,
+ *   in_mode 2: tfmq_groupnorm_from_stats (apply pass) -> tfmq_conv2d_w4a8 (proj_in, fp16 out) -> tfmq_layernorm_h -> tfmq_conv2d_w4a8
+ *              (fused to_q | to_k | to_v: fp16 rows + transposed V)       SpatialTransformer.forward / BasicTransformerBlock._forward /
+ *              CrossAttention.forward, ldm/modules/attention.py:238-261, :212, :168-177
+ *   in_mode 0: tfmq_conv2d_w4a8 (to_out + residual, on the attention kernel's int8 output) -> tfmq_layernorm_h -> tfmq_conv2d_w4a8 (to_q)
+ *              ldm/modules/attention.py:194, :212-213
+ * under the quantised blocks of quant/quant_block.py:178-299 (QuantLayers: quant/quant_layer.py:306-340). */
+typedef struct tfmq_chain_gemm {
+  const int8_t* w;               /* tfmq_expand_w4 operand of the layer, [N][C] */
+  const int32_t* wmeta;          /* [N][4] */
+  const float* wscale;           /* [N] */
+  const float* bias;             /* [N] or NULL */
+  int32_t N;                     /* outputs, multiple of 64 */
+  tfmq_qsel aq;                  /* activation quantizer of the layer's input (the bins resident in LDS) */
+  const uint16_t* residual;      /* fp16 [M][N] added before the rounding to fp16, or NULL */
+  uint16_t* y;                   /* fp16 rows [M][ldy]: output columns < t_col0 (all of them without yt) */
+  int32_t ldy;
+  uint16_t* yt;                  /* optional: columns >= t_col0 transposed, fp16 yt[b][n - t_col0][t] (b = token / T): the V^T operand of
+                                    tfmq_attention_f16 */
+  int32_t t_col0;                /* multiple of 64 */
+  int32_t next;                  /* != 0 (N == C, not the last GEMM): LayerNorm(ln_gamma, ln_beta, ln_eps) of the output row + the next
+                                    GEMM's quantizer produce the next GEMM's input */
+} tfmq_chain_gemm;
+typedef struct tfmq_chain_desc {
+  int32_t M, C, T;               /* tokens (multiple of 256), token width (320), tokens per image */
+  int32_t in_mode;               /* 0: x = int8 bins [M][C] of g[0].aq.  2: x = fp16 [M][C]; y = gn_a[b][c] * x + gn_b[b][c] (the GroupNorm's
+                                    per-(image, channel) affine, e.g. from tfmq_gn_finalize), then g[0]'s quantizer; T % 256 == 0 */
+  const void* x;
+  const float* gn_a;             /* [M / T][C] */
+  const float* gn_b;
+  const float* ln_gamma;         /* the chain's LayerNorm (at most one) */
+  const float* ln_beta;
+  float ln_eps;
+  int32_t n_gemm;                /* 1 .. 3 */
+  tfmq_chain_gemm g[3];
+  float* ws;                     /* scratch: 4 * (sum of N) floats (per-column constants, rebuilt per call from the current Finite-Set row) */
+} tfmq_chain_desc;
+int tfmq_row_chain(tfmq_handle h, const tfmq_chain_desc* d, void* stream);
+
 /* ---- K7: temporal-information block GEMVs (QuantTemporalInformationBlockDDIM.forward,
  * quant_block.py:52-64; ddim/models/diffusion.py:6-24,310-313) -------------------------- */
 /* emb[m][dim] = [sin(t f_i), cos(t f_i)] (DDIM order, denominator half-1) or
@@ -317,6 +358,9 @@ int tfmq_groupnorm(tfmq_handle h, const tfmq_gn_desc* d, void* stream);
  * stats2 pairs with d->x2 (channel concat).  ws: 2 * B * (C1+C2) floats. */
 int tfmq_groupnorm_from_stats(tfmq_handle h, const tfmq_gn_desc* d, const float* stats1, const float* stats2, int seg,
                               float* ws, void* stream);
+/* The GroupNorm statistics pass of tfmq_groupnorm_from_stats on its own: a[b][c] = rstd * gamma[c], bsh[b][c] = beta[c] - a * mean from the
+ * producing conv's per-segment {sum, sum of squares} (tfmq_conv_desc.stats); a, bsh: [B][C1 + C2] floats. */
+int tfmq_gn_finalize(tfmq_handle h, const tfmq_gn_desc* d, const float* stats1, const float* stats2, int seg, float* a, float* bsh, void* stream);
 
 /* ---- K9: LayerNorm (+quantise) and GEGLU (+quantise) of the SpatialTransformer blocks
  * (nn.LayerNorm ldm/modules/attention.py:203-205 eps 1e-5; GEGLU :37-44 exact erf GELU) ------------ */

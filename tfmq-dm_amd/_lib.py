@@ -68,6 +68,23 @@ class FfDesc(C.Structure):
     ]
 
 
+class ChainGemm(C.Structure):
+    """tfmq_chain_gemm"""
+    _fields_ = [
+        ("w", c_void_p), ("wmeta", c_void_p), ("wscale", c_void_p), ("bias", c_void_p), ("N", C.c_int32),
+        ("aq", QSel), ("residual", c_void_p), ("y", c_void_p), ("ldy", C.c_int32), ("yt", c_void_p), ("t_col0", C.c_int32), ("next", C.c_int32),
+    ]
+
+
+class ChainDesc(C.Structure):
+    """tfmq_chain_desc"""
+    _fields_ = [
+        ("M", C.c_int32), ("C", C.c_int32), ("T", C.c_int32), ("in_mode", C.c_int32),
+        ("x", c_void_p), ("gn_a", c_void_p), ("gn_b", c_void_p), ("ln_gamma", c_void_p), ("ln_beta", c_void_p), ("ln_eps", c_float),
+        ("n_gemm", C.c_int32), ("g", ChainGemm * 3), ("ws", c_void_p),
+    ]
+
+
 # name -> (restype, argtypes); every symbol declared in include/tfmq_hip.h
 _SIGS = {
     "tfmq_abi_version": (c_int, []),
@@ -97,6 +114,8 @@ _SIGS = {
     "tfmq_conv2d_w4a8": (c_int, [c_void_p, C.POINTER(ConvDesc), c_void_p]),
     "tfmq_conv2d_f16": (c_int, [c_void_p, C.POINTER(ConvDesc), c_void_p]),
     "tfmq_ff_fused": (c_int, [c_void_p, C.POINTER(FfDesc), c_void_p]),
+    "tfmq_row_chain": (c_int, [c_void_p, C.POINTER(ChainDesc), c_void_p]),
+    "tfmq_gn_finalize": (c_int, [c_void_p, C.POINTER(GnDesc), c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     "tfmq_timestep_embedding": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "tfmq_linear_small_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "tfmq_linear_small_w4": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, QSel, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),

@@ -92,7 +92,7 @@ __global__ __launch_bounds__(512, 2) void k_ff_fused(FfP p) {
   const int m = m0 + wid * 32 + pl;
   const int mc = m < d.M ? m : d.M - 1;
   const bool mok = m < d.M;
-  const int npairs = d.inner >> 6, nphase = 3 * npairs, nsteps2 = npairs;
+  const int npairs = d.inner >> 6, nsteps2 = npairs;
 
   // ---- weight stream: phase ph = 3 q + kind; kind 0 / 1: value | gate tiles of hidden tile 2 q + kind (+ the pair's constants), kind 2:
   // ff.net.2's K-step q for all C / 32 output tiles.  Piece pi of a phase = 16 weight rows x 64 B, lane-linear in LDS, swizzled on the source.
@@ -100,9 +100,8 @@ __global__ __launch_bounds__(512, 2) void k_ff_fused(FfP p) {
   const unsigned voff = static_cast<unsigned>((lane >> 2) * 64 + (((lane & 3) ^ ((lane >> 4) & 3)) * 16));
   const unsigned char* w1 = reinterpret_cast<const unsigned char*>(d.w1);
   const unsigned char* w2 = reinterpret_cast<const unsigned char*>(d.w2);
-  auto issue = [&](int ph) {
-    const int q = ph / 3, kind = ph - 3 * q;
-    const unsigned sbase = lds0 + G::RING_OFF + (ph % 3) * G::SLOT;
+  auto issue = [&](int kind, int q) {
+    const unsigned sbase = lds0 + G::RING_OFF + kind * G::SLOT;
 #pragma unroll
     for (int it = 0; it < PPW; ++it) {
       int pi = wid + 8 * it;
@@ -125,8 +124,9 @@ __global__ __launch_bounds__(512, 2) void k_ff_fused(FfP p) {
       glds16_sv(src, voff, sbase + __builtin_amdgcn_readfirstlane(pi * 1024));
     }
   };
-  issue(0);
-  issue(1);
+  issue(0, 0);
+  issue(1, 0);
+  issue(2, 0);
 
   // ---- per-column constants of ff.net.2 {scale, zero-point correction, bias} and the LayerNorm's gamma | beta -> LDS
   const float2 aqp0 = load_qparam(d.aq0), aqp2 = load_qparam(d.aq2);
@@ -247,59 +247,100 @@ __global__ __launch_bounds__(512, 2) void k_ff_fused(FfP p) {
     for (int r = 0; r < 16; ++r) acc2[t][r] = 0;
   v4i hb[2];
 
-  for (int q = 0; q < npairs; ++q) {
-#pragma unroll
-    for (int kind = 0; kind < 3; ++kind) {
-      const int ph = 3 * q + kind;
-      if (ph + 1 < nphase) ff_wait_vmcnt<PPW>();
+  v16i av, ag;
+  // ---- the five steps of a pair of hidden tiles: A0 (value | gate MFMAs of tile 2q), E0 (their bins), A1, E1, C (ff.net.2's K-step q).
+  // Waves 0-3 (one per SIMD) run them at the global intervals 5q .. 5q + 4, waves 4-7 ONE INTERVAL LATER: the two waves of a SIMD are
+  // then in complementary steps -- one issues MFMAs while the other does the GELU arithmetic -- in four of five intervals (in lockstep
+  // the SIMD alternated between two waves of MFMAs and two waves of VALU work: 1014 us; staggered: see DESIGN.md).  One barrier per
+  // interval; the weight stages are re-filled as soon as BOTH groups are through with them (stage kind lives in slot kind):
+  //   interval 5q (+0): wait A0(q) | issue A1(q)   (+1): issue C(q)   (+2): wait A1(q)   (+3): issue A0(q+1)   (+4): wait C(q)
+  auto sync = [&](auto r_tag, int qi) {
+    constexpr int R = decltype(r_tag)::value;
+    if constexpr (R == 0) ff_wait_vmcnt<0>();
+    if constexpr (R == 2) ff_wait_vmcnt<PPW>();
+    if constexpr (R == 4) {
+      if (qi + 1 < npairs) ff_wait_vmcnt<PPW>();
       else ff_wait_vmcnt<0>();
-      asm volatile("s_barrier" ::: "memory");
-      if (ph + 2 < nphase) issue(ph + 2);
-      const unsigned char* slot = lds + G::RING_OFF + (ph % 3) * G::SLOT;
-      if (kind < 2) {
-        v16i av, ag;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) av[r] = ag[r] = 0;
-#pragma unroll
-        for (int sidx = 0; sidx < NCH; ++sidx)
-#pragma unroll
-          for (int ks = 0; ks < 2; ++ks) {
-            const v4i xf = *reinterpret_cast<const v4i*>(xfr + sidx * 2048 + (fsw ^ (ks << 5)));
-            const v4i vf = *reinterpret_cast<const v4i*>(slot + sidx * 2048 + brow * 64 + (bsw ^ (ks << 5)));
-            const v4i gf = *reinterpret_cast<const v4i*>(slot + NCH * 2048 + sidx * 2048 + brow * 64 + (bsw ^ (ks << 5)));
-            av = __builtin_amdgcn_mfma_i32_32x32x32_i8(vf, xf, av, 0, 0, 0);
-            ag = __builtin_amdgcn_mfma_i32_32x32x32_i8(gf, xf, ag, 0, 0, 0);
-          }
-        __builtin_amdgcn_sched_barrier(0);
-        // value' * gelu(gate) -> bins: TFMQ_OUT_GEGLU_Q8_FAST's arithmetic (conv_lin.hip), constants {sv, bv, sg, bg}[32] of this tile
-        const float* cst = reinterpret_cast<const float*>(slot + G::NPIECE * 1024) + kind * 128 + 16 * h;
-        unsigned w[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const float4 sv = *reinterpret_cast<const float4*>(cst + 4 * i), bv = *reinterpret_cast<const float4*>(cst + 32 + 4 * i);
-          const float4 sg = *reinterpret_cast<const float4*>(cst + 64 + 4 * i), bg = *reinterpret_cast<const float4*>(cst + 96 + 4 * i);
-          const f2 a0 = pk_fma(f2{sv.x, sv.y}, f2{static_cast<float>(av[4 * i]), static_cast<float>(av[4 * i + 1])}, f2{bv.x, bv.y});
-          const f2 a1 = pk_fma(f2{sv.z, sv.w}, f2{static_cast<float>(av[4 * i + 2]), static_cast<float>(av[4 * i + 3])}, f2{bv.z, bv.w});
-          const f2 g0 = pk_fma(f2{sg.x, sg.y}, f2{static_cast<float>(ag[4 * i]), static_cast<float>(ag[4 * i + 1])}, f2{bg.x, bg.y});
-          const f2 g1 = pk_fma(f2{sg.z, sg.w}, f2{static_cast<float>(ag[4 * i + 2]), static_cast<float>(ag[4 * i + 3])}, f2{bg.z, bg.w});
-          w[i] = geglu_fast_pack4(a0, gelu_fast2(g0), a1, gelu_fast2(g1), zp2);
-          __builtin_amdgcn_sched_barrier(0);        // four outputs at a time: interleaving the groups spilled the accumulators
-        }
-        // (pin the bins here: without it the compiler sinks this phase's arithmetic below the next phase's MFMAs and keeps both
-        // phases' accumulators and constants alive -- 180 spilled registers)
-        asm volatile("" : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]));
-        hb[kind] = v4i{static_cast<int>(w[0]), static_cast<int>(w[1]), static_cast<int>(w[2]), static_cast<int>(w[3])};
-      } else {
-#pragma unroll
-        for (int t = 0; t < NT; ++t)
-#pragma unroll
-          for (int ks = 0; ks < 2; ++ks) {
-            const v4i wf = *reinterpret_cast<const v4i*>(slot + t * 2048 + brow * 64 + (bsw ^ (ks << 5)));
-            acc2[t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf, hb[ks], acc2[t], 0, 0, 0);
-          }
-      }
     }
-  }
+    asm volatile("s_barrier" ::: "memory");
+    if constexpr (R == 0) {
+      if (qi >= 1 && qi < npairs) issue(1, qi);
+    }
+    if constexpr (R == 1) {
+      if (qi >= 1 && qi < npairs) issue(2, qi);
+    }
+    if constexpr (R == 3) {
+      if (qi + 1 < npairs) issue(0, qi + 1);
+    }
+  };
+  auto step_a = [&](auto kind_tag) {
+    constexpr int kind = decltype(kind_tag)::value;
+    const unsigned char* slot = lds + G::RING_OFF + kind * G::SLOT;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) av[r] = ag[r] = 0;
+#pragma unroll
+    for (int sidx = 0; sidx < NCH; ++sidx)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const v4i xf = *reinterpret_cast<const v4i*>(xfr + sidx * 2048 + (fsw ^ (ks << 5)));
+        const v4i vf = *reinterpret_cast<const v4i*>(slot + sidx * 2048 + brow * 64 + (bsw ^ (ks << 5)));
+        const v4i gf = *reinterpret_cast<const v4i*>(slot + NCH * 2048 + sidx * 2048 + brow * 64 + (bsw ^ (ks << 5)));
+        av = __builtin_amdgcn_mfma_i32_32x32x32_i8(vf, xf, av, 0, 0, 0);
+        ag = __builtin_amdgcn_mfma_i32_32x32x32_i8(gf, xf, ag, 0, 0, 0);
+      }
+    // (pin the accumulators: the interval ends here)
+    asm volatile("" : "+v"(av), "+v"(ag));
+  };
+  auto step_e = [&](auto kind_tag) {
+    constexpr int kind = decltype(kind_tag)::value;
+    // value' * gelu(gate) -> bins: TFMQ_OUT_GEGLU_Q8_FAST's arithmetic (conv_lin.hip), constants {sv, bv, sg, bg}[32] of this tile
+    const float* cst = reinterpret_cast<const float*>(lds + G::RING_OFF + kind * G::SLOT + G::NPIECE * 1024) + kind * 128 + 16 * h;
+    unsigned w[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float4 sv = *reinterpret_cast<const float4*>(cst + 4 * i), bv = *reinterpret_cast<const float4*>(cst + 32 + 4 * i);
+      const float4 sg = *reinterpret_cast<const float4*>(cst + 64 + 4 * i), bg = *reinterpret_cast<const float4*>(cst + 96 + 4 * i);
+      const f2 a0 = pk_fma(f2{sv.x, sv.y}, f2{static_cast<float>(av[4 * i]), static_cast<float>(av[4 * i + 1])}, f2{bv.x, bv.y});
+      const f2 a1 = pk_fma(f2{sv.z, sv.w}, f2{static_cast<float>(av[4 * i + 2]), static_cast<float>(av[4 * i + 3])}, f2{bv.z, bv.w});
+      const f2 g0 = pk_fma(f2{sg.x, sg.y}, f2{static_cast<float>(ag[4 * i]), static_cast<float>(ag[4 * i + 1])}, f2{bg.x, bg.y});
+      const f2 g1 = pk_fma(f2{sg.z, sg.w}, f2{static_cast<float>(ag[4 * i + 2]), static_cast<float>(ag[4 * i + 3])}, f2{bg.z, bg.w});
+      w[i] = geglu_fast_pack4(a0, gelu_fast2(g0), a1, gelu_fast2(g1), zp2);
+      __builtin_amdgcn_sched_barrier(0);        // four outputs at a time: interleaving the groups spilled the accumulators
+    }
+    // (pin the bins here: without it the compiler sinks this step's arithmetic below the next step's MFMAs and keeps both
+    // steps' accumulators and constants alive -- 180 spilled registers)
+    asm volatile("" : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]));
+    hb[kind] = v4i{static_cast<int>(w[0]), static_cast<int>(w[1]), static_cast<int>(w[2]), static_cast<int>(w[3])};
+  };
+  auto step_c = [&]() {
+    const unsigned char* slot = lds + G::RING_OFF + 2 * G::SLOT;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const v4i wf = *reinterpret_cast<const v4i*>(slot + t * 2048 + brow * 64 + (bsw ^ (ks << 5)));
+        acc2[t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf, hb[ks], acc2[t], 0, 0, 0);
+      }
+  };
+  auto run = [&](auto g_tag) {
+    constexpr int GR = decltype(g_tag)::value;
+    if constexpr (GR == 1) sync(std::integral_constant<int, 0>{}, 0);
+    for (int q = 0; q < npairs; ++q) {
+      sync(std::integral_constant<int, (0 + GR) % 5>{}, q + (0 + GR) / 5);
+      step_a(std::integral_constant<int, 0>{});
+      sync(std::integral_constant<int, (1 + GR) % 5>{}, q + (1 + GR) / 5);
+      step_e(std::integral_constant<int, 0>{});
+      sync(std::integral_constant<int, (2 + GR) % 5>{}, q + (2 + GR) / 5);
+      step_a(std::integral_constant<int, 1>{});
+      sync(std::integral_constant<int, (3 + GR) % 5>{}, q + (3 + GR) / 5);
+      step_e(std::integral_constant<int, 1>{});
+      sync(std::integral_constant<int, (4 + GR) % 5>{}, q + (4 + GR) / 5);
+      step_c();
+    }
+    if constexpr (GR == 0) sync(std::integral_constant<int, 0>{}, npairs);
+  };
+  if (wid < 4) run(std::integral_constant<int, 0>{});
+  else run(std::integral_constant<int, 1>{});
 
   // ---- epilogue: scale * float(acc + kc) + bias + x -> fp16 rows / int8 bins (k_lin_direct's operations); the ring is idle: staging
   asm volatile("s_barrier" ::: "memory");

@@ -614,6 +614,18 @@ extern "C" int tfmq_groupnorm_from_stats(tfmq_handle h, const tfmq_gn_desc* dd, 
   return TFMQ_OK;
 }
 
+extern "C" int tfmq_gn_finalize(tfmq_handle h, const tfmq_gn_desc* dd, const float* stats1, const float* stats2, int seg, float* a, float* bsh,
+                                void* stream) {
+  TFMQ_CHECK_ARG(h, h && dd && stats1 && a && bsh, "gn_finalize: null pointer");
+  const tfmq_gn_desc& d = *dd;
+  TFMQ_CHECK_ARG(h, d.gamma && d.beta && d.B > 0 && d.HW > 0 && d.C1 > 0 && d.C2 >= 0 && (d.C2 == 0 || stats2) && d.groups > 0 && d.groups <= 64 &&
+                        (d.C1 + d.C2) % d.groups == 0 && seg > 0 && d.HW % seg == 0, "gn_finalize: bad shape");
+  hipLaunchKernelGGL(k_gn_finalize, dim3(d.B, (d.groups + 7) / 8), dim3(256), 0, as_stream(stream), reinterpret_cast<const float2*>(stats1), d.C1,
+                     reinterpret_cast<const float2*>(stats2), d.C2, d.HW, seg, d.groups, d.eps, d.gamma, d.beta, a, bsh);
+  TFMQ_LAUNCH_CHECK(h);
+  return TFMQ_OK;
+}
+
 extern "C" int tfmq_groupnorm(tfmq_handle h, const tfmq_gn_desc* dd, void* stream) {
   TFMQ_CHECK_ARG(h, h && dd, "groupnorm: null pointer");
   const tfmq_gn_desc& d = *dd;

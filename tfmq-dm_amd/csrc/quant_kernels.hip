@@ -666,6 +666,7 @@ extern "C" int tfmq_pack_w_f16(tfmq_handle h, const float* w, const float* alpha
 // (tfmq_hw_selftest; the Python layer calls it when it creates a handle and refuses to run otherwise):
 //   * v_cvt_pk_u8_f32 SATURATES to [0, 255] (quant_pack4 leaves the clamp of clamp(rint(x / delta) + zp, 0, 255) to it), converts
 //     integers exactly and keeps the other three bytes of the destination;
+//   * v_cvt_pk_u8_f32 rounds to nearest-even (the consumer-sized GEGLU epilogue converts without a v_rndne_f32);
 //   * DPP quad_perm / row_shl source lanes as group8_sum (conv_common.hpp) assumes them.
 __global__ void k_hw_selftest(unsigned* out) {
   const int lane = threadIdx.x;
@@ -680,6 +681,15 @@ __global__ void k_hw_selftest(unsigned* out) {
   for (int k = 0; k < 4; ++k) {                       // every integer 0..255
     const unsigned v = lane * 4 + k;
     if ((__builtin_amdgcn_cvt_pk_u8_f32(static_cast<float>(v), 0, 0u) & 0xffu) != v) fail |= 2u;
+  }
+  for (int k = 0; k < 4; ++k) {                       // round-half-even on its own (geglu_fast_pack4 has no v_rndne_f32 in front of it)
+    const float v = static_cast<float>(lane * 4 + k);
+    const float probes[5] = {v + 0.5f, v + 0.25f, v + 0.75f, __uint_as_float(__float_as_uint(v + 0.5f) + 1u), __uint_as_float(__float_as_uint(v + 0.5f) - 1u)};
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+      const float r = fminf(__builtin_rintf(probes[i]), 255.0f);
+      if ((__builtin_amdgcn_cvt_pk_u8_f32(probes[i], 0, 0u) & 0xffu) != static_cast<unsigned>(r)) fail |= 16u;
+    }
   }
   const float x = static_cast<float>(lane);
   const float q1 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x55, 0xf, 0xf, true));
@@ -708,7 +718,7 @@ extern "C" int tfmq_hw_selftest(tfmq_handle h, uint32_t* report) {
   if (e != hipSuccess) return TFMQ_ERR_HIP;
   if (report) *report = r;
   if (r != 0) {
-    h->err = "hardware self-test failed (bit 0/1: v_cvt_pk_u8_f32 saturation / exactness, bit 2/3: DPP lane selection): mask " + std::to_string(r);
+    h->err = "hardware self-test failed (bit 0/1: v_cvt_pk_u8_f32 saturation / exactness, bit 2/3: DPP lane selection, bit 4: v_cvt_pk_u8_f32 round-half-even): mask " + std::to_string(r);
     return TFMQ_ERR_HIP;
   }
   return TFMQ_OK;
