@@ -251,22 +251,89 @@ def setup_sd(args, dev, rank, log, preset="sd"):
         def shp(n, v):
             return v.cpu().reshape((-1,) + (1,) * (sdc[n + ".weight"].dim() - 1))
         wqc = {n: {"delta": shp(n, q.delta), "zp": shp(n, q.zp), "alpha": None} for n, q in wq.items()}
-        cs, ci = 2, 2          # 2 DDIM steps of 2 images (UNet batch 4 with guidance): bounded sample, host cores busy
-        xc = torch.randn(ci, LC, LH, LW)
+        cs, ci = int(os.environ.get("TFMQ_BENCH_CPU_STEPS", "4")), int(os.environ.get("TFMQ_BENCH_CPU_IMAGES", "1"))   # 4 DDIM steps of 1 image (UNet batch 2 with guidance): bounded sample (~70 s), host cores busy
+        gcpu = torch.Generator().manual_seed(4242)
+        xc = torch.randn(ci, LC, LH, LW, generator=gcpu)
         tsn, _, _ = O.ldm_ddim_schedule(O.ldm_alphas_cumprod(), S)
+        eps_ref, inputs = [], []
         with torch.no_grad():
             t0 = time.time()
             for i, stp in enumerate(list(np.flip(tsn))[:cs]):
                 aq = {n: (qt[i, j, 0], qt[i, j, 1]) for j, n in enumerate(act_names)}
+                tt = torch.full((ci * (1 if CTX is None else 2),), int(stp), dtype=torch.long)
                 if CTX is None:
-                    O.ldm_unet_forward(sdc, dict(cfg), xc, torch.full((ci,), int(stp), dtype=torch.long), None, O.QuantSpec(wq=wqc, aq=aq))
+                    xin, cin_ = xc, None
                 else:
-                    c1, u1 = torch.randn(ci, CTX[0], CTX[1]), torch.randn(ci, CTX[0], CTX[1])
-                    O.ldm_unet_forward(sdc, dict(cfg), torch.cat([xc] * 2), torch.full((2 * ci,), int(stp), dtype=torch.long), torch.cat([u1, c1]),
-                                       O.QuantSpec(wq=wqc, aq=aq))
+                    c1, u1 = torch.randn(ci, CTX[0], CTX[1], generator=gcpu), torch.randn(ci, CTX[0], CTX[1], generator=gcpu)
+                    xin, cin_ = torch.cat([xc] * 2), torch.cat([u1, c1])
+                e = O.ldm_unet_forward(sdc, dict(cfg), xin, tt, cin_, O.QuantSpec(wq=wqc, aq=aq))
+                if i < 2:
+                    eps_ref.append(e)
+                    inputs.append((xin, tt, cin_))
             dt = time.time() - t0
+        info["parity_inputs"] = (inputs, eps_ref)          # the engine is evaluated on the same inputs / rows (parity leg below)
         return ci / (dt / cs * S), (f"{ci} images (UNet batch {ci * (1 if CTX is None else 2)}) x {cs} of the {S} DDIM steps = {dt:.1f}s on "
                                     f"{torch.get_num_threads()} threads, extrapolated to the full schedule")
+
+    def parity():
+        """eps of the HIP engine against the CPU oracle (the reference's fp32 fake-quant arithmetic) on the inputs the cpu_baseline leg just
+        evaluated: the benchmarked fast mode (fp16 activation stream, fp16-operand attention / un-quantised convs, consumer-sized GELU) and
+        the exact mode (TFMQ_EXACT_FP=1: fp32 stream, exact-fp32 MFMA for every un-quantised product) built on the same weights and
+        tables, plus the exact mode's forward time.  rel-L2 over the first two DDIM steps' UNet calls."""
+        inputs, eps_ref = info.get("parity_inputs", (None, None))
+        if not inputs:
+            return None
+
+        def rel(e_, r_):
+            return float((e_ - r_).norm() / r_.norm())
+
+        def run_engine(e_):
+            out = []
+            with torch.cuda.stream(sampler.stream):
+                for i, (xin, tt, cin_) in enumerate(inputs):
+                    e_.step.fill_(i)
+                    y = e_.forward(xin.permute(0, 2, 3, 1).contiguous().to(dev), tt.float().to(dev), None if cin_ is None else cin_.to(dev))
+                    out.append(y.permute(0, 3, 1, 2).float().cpu())
+                e_.step.zero_()
+                sampler.stream.synchronize()
+            return out
+        res = {"inputs": f"UNet batch {inputs[0][0].shape[0]}, the first {len(inputs)} DDIM steps' tables", "reference": "oracle/tfmq_oracle.py on the host (fp32 fake-quant path)"}
+        fast = run_engine(eng)
+        res["eps_rel_l2_fast"] = [round(rel(a, b), 5) for a, b in zip(fast, eps_ref)]
+        old = os.environ.get("TFMQ_EXACT_FP")
+        os.environ["TFMQ_EXACT_FP"] = "1"
+        try:
+            ex = LdmUNetEngine(sd, cfg, dev)
+            ex.prepare(wq, eng.qtable, torch.zeros(1, dtype=torch.int32, device=dev))
+            exact = run_engine(ex)
+            res["eps_rel_l2_exact"] = [round(rel(a, b), 5) for a, b in zip(exact, eps_ref)]
+            xin, tt, cin_ = inputs[0]
+            nb = 16
+            xb = torch.randn(nb, LH, LW, LC, device=dev)
+            cb = None if cin_ is None else torch.randn(nb, CTX[0], CTX[1], device=dev)
+            tb = torch.full((nb,), float(tt[0]), device=dev)
+            ex.forward(xb, tb, cb)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(2):
+                ex.forward(xb, tb, cb)
+            torch.cuda.synchronize()
+            ms = (time.perf_counter() - t0) / 2 * 1e3
+            per_img = nb // (1 if CTX is None else 2)
+            res["exact_fp"] = {"ms_per_unet_forward": round(ms, 1), "unet_batch": nb,
+                               "images_per_s_equivalent": round(per_img / (S * ms * 1e-3), 3),
+                               "note": (f"TFMQ_EXACT_FP=1 engine, eager forwards at UNet batch {nb} ({per_img} images): images/s = images / ({S} steps x forward time); "
+                                        "the sampler update is negligible beside it.  Diagnostics mode, not the metric")}
+            del ex
+        except Exception as e_:       # noqa: BLE001 -- a diagnostics leg must not take the line down
+            res["exact_error"] = f"{type(e_).__name__}: {e_}"
+        finally:
+            if old is None:
+                del os.environ["TFMQ_EXACT_FP"]
+            else:
+                os.environ["TFMQ_EXACT_FP"] = old
+            torch.cuda.empty_cache()
+        return res
 
     def plms():
         """The README's SD recipe samples with PLMS (S + 1 UNet calls): reported beside the metric, one
@@ -306,7 +373,7 @@ def setup_sd(args, dev, rank, log, preset="sd"):
         return out
 
     info = dict(batch=batch, sync=sampler.stream.synchronize, finite=lambda: bool(torch.isfinite(sampler.x).all().item()),
-                stream=sampler.stream, step=eng.step, plms=plms, sweep=sweep, materialised=materialised if CTX is not None and sampler.pair_prefix else None,
+                stream=sampler.stream, step=eng.step, plms=plms, sweep=sweep, parity=parity, materialised=materialised if CTX is not None and sampler.pair_prefix else None,
                 oracle_state=dict(sd=sd, wq=wq, act_names=act_names, cfg=cfg, eng=eng),     # scratch/sd_parity_full.py
                 workload=(f"{P['name']} ({n_params:.1f}M) w4a8 on MI355X: {LH}x{LW}x{LC} latents, DDIM-{S} eta=0, "
                           + (f"CFG {scale} (UNet batch 2x{batch}), {CTX[0]}x{CTX[1]} context, " if CTX is not None else "unconditional, ")
@@ -846,6 +913,11 @@ def main():
             "data": "synthetic: N(0,1) latents / context, random-init weights (zero params re-drawn N(0,0.02^2)), synthetic FSC tables",
             "config": cfgd, "finite": finite, "roofline": roof, "cpu_baseline": cpu_b, "calibration": cali,
         }
+        if cpu_b is not None and "parity" in info:
+            try:
+                out["parity"] = info["parity"]()
+            except Exception as e:      # noqa: BLE001
+                out["parity"] = {"error": f"{type(e).__name__}: {e}"}
         if world == 1 and not args.no_cpu_baseline and info.get("materialised") is not None:
             out["guidance_pair_materialised"] = info["materialised"]()
         if world == 1 and args.workload == "sd" and not args.no_cpu_baseline and args.batch in (0, 64) and "sweep" in info:

@@ -132,6 +132,30 @@ def test_sd_fused_context_kv_projection_is_bit_identical(sd, monkeypatch):
     assert torch.isfinite(outs[0]).all() and torch.equal(outs[0], outs[1])
 
 
+def test_sd_row_chains_and_fused_ff_are_bit_identical_at_full_size(sd, monkeypatch):
+    """Round 4: at the 64 x 64 level the transformer blocks run as three token-per-lane launches around the attentions -- tfmq_row_chain
+    [norm + proj_in + norm1 + q|k|v], tfmq_row_chain [attn1.to_out + residual + norm2 + attn2.to_q], tfmq_ff_fused [norm3 + GEGLU + ff.net.2
+    + residual] -- against the separate launches (TFMQ_ROW_CHAIN=0, TFMQ_FF_FUSED=0): eps bit for bit, plain batch and guidance pair."""
+    run, fwd, info = sd
+    eng = _engine_of(fwd)
+    g = torch.Generator().manual_seed(15)
+    x = torch.randn(3, 64, 64, 4, generator=g).to(DEV)
+    ctx = torch.randn(6, 77, 768, generator=g).to(DEV)
+    outs = {}
+    with torch.cuda.stream(info["stream"]):
+        for chain, ff in (("1", "1"), ("0", "0"), ("1", "0"), ("0", "1")):
+            monkeypatch.setenv("TFMQ_ROW_CHAIN", chain)
+            monkeypatch.setenv("TFMQ_FF_FUSED", ff)
+            info["step"].zero_()
+            outs[(chain, ff, "plain")] = eng.forward(x, None, ctx[:3].contiguous()).clone()
+            outs[(chain, ff, "pair")] = eng.forward(x, None, ctx, pair_prefix=True).clone()
+        info["stream"].synchronize()
+    ref_plain, ref_pair = outs[("0", "0", "plain")], outs[("0", "0", "pair")]
+    assert torch.isfinite(ref_plain).all() and torch.isfinite(ref_pair).all()
+    for k, v in outs.items():
+        assert torch.equal(v, ref_plain if k[2] == "plain" else ref_pair), k
+
+
 def test_sd_full_size_eps_vs_oracle(sd):
     """The full SD v1 UNet (859.5 M, w4a8, synthetic Finite-Set table) against the CPU oracle -- the reference's
     fake-quant forward restated on torch-CPU, pinned to the reference at tiny sizes by F11-F13 -- on one CFG pair:

@@ -163,17 +163,15 @@ __global__ __launch_bounds__(512, 2) void k_row_chain(ChainP p) {
   uint4 kept[RC_NT][2];                               // the fp16 row of a GEMM whose output a LayerNorm consumes (N = C)
 
   int s_prev = -1;                                    // stores of the previous phase: 4 (row tiles) or 32 (transposed tiles); -1 = first phase
-  for (int ph = 0; ph < p.nphase; ++ph) {
+  // one phase: two output tiles (64 columns) of GEMM g.  KEEP >= 0: they are tiles 2 KEEP, 2 KEEP + 1 of a row a LayerNorm will consume
+  auto phase = [&](auto keep_tag, int ph, int g, int pr) {
+    constexpr int KEEP = decltype(keep_tag)::value;
     if (s_prev == 4) rc_wait_vmcnt<4>();
     else if (s_prev == 32) rc_wait_vmcnt<32>();
     else rc_wait_vmcnt<0>();
     asm volatile("s_barrier" ::: "memory");
     if (ph + 1 < p.nphase) issue(ph + 1);
-    const int g = gemm_of(ph);
     const tfmq_chain_gemm& L = d.g[g];
-    const int pr = ph - p.ph0[g];
-    auto body = [&](auto keep_tag) {
-    constexpr int KEEP = decltype(keep_tag)::value;      // >= 0: this phase's tiles 2 KEEP, 2 KEEP + 1 of a row a LayerNorm will consume
     const unsigned char* slot = lds + RC_RING_OFF + (ph & 1) * RC_SLOT;
     const float* cs = reinterpret_cast<const float*>(slot + RC_NPIECE * 1024);
     const bool transposed = L.yt != nullptr && 64 * pr >= L.t_col0;
@@ -256,15 +254,22 @@ __global__ __launch_bounds__(512, 2) void k_row_chain(ChainP p) {
       }
     }
     s_prev = transposed ? 32 : 4;
-    };
-    if (!L.next) body(std::integral_constant<int, -1>{});
-    else if (pr == 0) body(std::integral_constant<int, 0>{});
-    else if (pr == 1) body(std::integral_constant<int, 1>{});
-    else if (pr == 2) body(std::integral_constant<int, 2>{});
-    else if (pr == 3) body(std::integral_constant<int, 3>{});
-    else body(std::integral_constant<int, 4>{});
+  };
 
-    if (L.next && ph + 1 == p.ph0[g + 1]) {
+  int ph = 0;
+  for (int g = 0; g < d.n_gemm; ++g) {
+    const tfmq_chain_gemm& L = d.g[g];
+    if (!L.next) {
+      for (int pr = 0; pr < (L.N >> 6); ++pr, ++ph) phase(std::integral_constant<int, -1>{}, ph, g, pr);
+      continue;
+    }
+    phase(std::integral_constant<int, 0>{}, ph, g, 0);
+    phase(std::integral_constant<int, 1>{}, ph + 1, g, 1);
+    phase(std::integral_constant<int, 2>{}, ph + 2, g, 2);
+    phase(std::integral_constant<int, 3>{}, ph + 3, g, 3);
+    phase(std::integral_constant<int, 4>{}, ph + 4, g, 4);
+    ph += 5;
+    {
       // LayerNorm of the row this lane just finished (its fp16-rounded values, as the stand-alone kernel reads them back) in
       // k_layernorm_hs<8>'s summation order (ff_fused.hip), then the next GEMM's quantizer: the bins replace the wave's X rows
       // (the row stays packed: 80 registers; every pass widens a tile's 16 values when it needs them)

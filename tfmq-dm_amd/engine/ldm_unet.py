@@ -236,23 +236,53 @@ class LdmUNetEngine(DdimUNetEngine):
             Cc = lq.p.cout
             d = Cc // heads
             if lq.kind == lk.kind == lv.kind == "w4a8" and not (lq.wide or lk.wide or lv.wide) and ops.attention_f16_ok(d, cpad.shape[1]):
-                Bc, Lp, Dc = cpad.shape
                 q16 = ops.conv2d_w4a8(xq_src.reshape(B, T, 1, Cin), lq.p, lq.aq, out_f16=True).reshape(B, T, Cc)
-                fkv = self.fused_kv.get(p)
-                if fkv is not None and fkv.kind == "w4a8" and Cc % 128 == 0 and os.environ.get("TFMQ_FUSED_KV", "1") != "0":
-                    # to_k and to_v quantise the same context with quantizers that agree at every step (prepare()): one quantise pass and
-                    # one GEMM write k as fp16 rows and v as its fp16 transpose (the transposed region starts at a multiple of 128 channels)
-                    kv, vt = ops.conv2d_w4a8(ops.quantize_act(cpad, fkv.aq).reshape(Bc, Lp, 1, Dc), fkv.p, fkv.aq, out_f16=True, t_col0=Cc)
-                    k16 = kv.reshape(Bc, Lp, 2 * Cc)[..., :Cc]
-                else:
-                    k16 = ops.conv2d_w4a8(ops.quantize_act(cpad, lk.aq).reshape(Bc, Lp, 1, Dc), lk.p, lk.aq, out_f16=True).reshape(Bc, Lp, Cc)
-                    _, vt = ops.conv2d_w4a8(ops.quantize_act(cpad, lv.aq).reshape(Bc, Lp, 1, Dc), lv.p, lv.aq, out_f16=True, t_col0=0)
-                aq = to_out.aq if to_out.kind == "w4a8" else None
-                if aq is not None:
-                    _, o = ops.attention_f16(q16, k16, vt, heads, float(d ** -0.5), aq, want_f32=False, n_keys=n_ctx)
-                else:
-                    o, _ = ops.attention_f16(q16, k16, vt, heads, float(d ** -0.5), n_keys=n_ctx)
-                return self._tok(to_out, o, residual=x_res, **self._o16())
+                return self._cross_core(p, q16, x_res)
+        return self._attention_rest(p, xq_src, ctx, x_res, self_attn)
+
+    def _cross_ok(self, p) -> bool:
+        """The fp16-operand cross attention of the sampling path (context padded to a multiple of 8 keys) applies to block p."""
+        L = self.layers
+        lq, lk, lv = L[p + ".to_q"], L[p + ".to_k"], L[p + ".to_v"]
+        if self.calib is not None or self._ctx_pad is None or self.exact_fp or p in self.attn_q:
+            return False
+        d = lq.p.cout // self.cfg["num_heads"]
+        return (lq.kind == lk.kind == lv.kind == "w4a8" and not (lq.wide or lk.wide or lv.wide) and ops.attention_f16_ok(d, self._ctx_pad[0].shape[1]))
+
+    def _cross_core(self, p, q16, x_res, defer_out=False):
+        """k | v projections of the padded context + the fp16 attention (+ to_out and the residual unless defer_out: then the int8 bins
+        of to_out's quantizer are returned).  q16: fp16 [B, T, C] queries."""
+        L = self.layers
+        heads = self.cfg["num_heads"]
+        lq, lk, lv, to_out = L[p + ".to_q"], L[p + ".to_k"], L[p + ".to_v"], L[p + ".to_out.0"]
+        cpad, n_ctx = self._ctx_pad
+        B, T, Cc = q16.shape
+        d = Cc // heads
+        Bc, Lp, Dc = cpad.shape
+        fkv = self.fused_kv.get(p)
+        if fkv is not None and fkv.kind == "w4a8" and Cc % 128 == 0 and os.environ.get("TFMQ_FUSED_KV", "1") != "0":
+            # to_k and to_v quantise the same context with quantizers that agree at every step (prepare()): one quantise pass and
+            # one GEMM write k as fp16 rows and v as its fp16 transpose (the transposed region starts at a multiple of 128 channels)
+            kv, vt = ops.conv2d_w4a8(ops.quantize_act(cpad, fkv.aq).reshape(Bc, Lp, 1, Dc), fkv.p, fkv.aq, out_f16=True, t_col0=Cc)
+            k16 = kv.reshape(Bc, Lp, 2 * Cc)[..., :Cc]
+        else:
+            k16 = ops.conv2d_w4a8(ops.quantize_act(cpad, lk.aq).reshape(Bc, Lp, 1, Dc), lk.p, lk.aq, out_f16=True).reshape(Bc, Lp, Cc)
+            _, vt = ops.conv2d_w4a8(ops.quantize_act(cpad, lv.aq).reshape(Bc, Lp, 1, Dc), lv.p, lv.aq, out_f16=True, t_col0=0)
+        aq = to_out.aq if to_out.kind == "w4a8" else None
+        if aq is not None:
+            _, o = ops.attention_f16(q16, k16, vt, heads, float(d ** -0.5), aq, want_f32=False, n_keys=n_ctx)
+        else:
+            o, _ = ops.attention_f16(q16, k16, vt, heads, float(d ** -0.5), n_keys=n_ctx)
+        if defer_out:
+            return o
+        return self._tok(to_out, o, residual=x_res, **self._o16())
+
+    def _attention_rest(self, p, xq_src, ctx, x_res, self_attn: bool):
+        """_attention's generic forms (fp32 operands, calibration observation, exact / quantised attention)."""
+        L = self.layers
+        heads = self.cfg["num_heads"]
+        to_out = L[p + ".to_out.0"]
+        aq_on = p in self.attn_q
         if self_attn and p in self.fused_qkv:
             qkv = self._tok(self.fused_qkv[p], xq_src)
             Cc = qkv.shape[-1] // 3
@@ -309,10 +339,60 @@ class LdmUNetEngine(DdimUNetEngine):
             out._tfmq_stats = (LdmUNetEngine._dup(st[0]), st[1])
         return out
 
+    def _chain_ok(self, p, x, taps) -> bool:
+        """SpatialTransformer p (depth 1) at token width 320 in the fp16-stream sampling state: its Linears around the two attentions run as
+        row chains (tfmq_row_chain) -- [norm + proj_in + norm1 + q|k|v] and [attn1.to_out + residual + norm2 + attn2.to_q]."""
+        L = self.layers
+        B, H, W, Cc = x.shape
+        T = H * W
+        tb = p + ".transformer_blocks.0"
+        f = self.fused_qkv.get(tb + ".attn1")
+        pin = L[p + ".proj_in"]
+        heads = self.cfg["num_heads"]
+        return (self._h16 and self.calib is None and taps is None and not self.exact_fp and x.dtype == torch.float16 and ops.row_chain_ok(Cc, B * T, T, True)
+                and _n_children(self.sd, p + ".transformer_blocks") == 1 and pin.kind == "w4a8" and not pin.wide and pin.p.cout == Cc
+                and f is not None and f.kind == "w4a8" and not f.wide and f.p.cout == 3 * Cc and (tb + ".attn1") not in self.attn_q
+                and ops.attention_f16_ok(Cc // heads, T) and getattr(x, "_tfmq_stats", None) is not None and T % x._tfmq_stats[1] == 0
+                and L[tb + ".attn1.to_out.0"].kind == "w4a8" and not L[tb + ".attn1.to_out.0"].wide)
+
+    def _tblock_chained(self, sp, x_img, ctx, out_aq=None):
+        """_st's norm / proj_in and the transformer block of SpatialTransformer sp with the row chains (see _chain_ok).  Returns the block's
+        output tokens (fp16, or proj_out's int8 bins with out_aq) -- what _tblock returns -- bit-identical to the separate launches."""
+        L = self.layers
+        B, H, W, Cc = x_img.shape
+        T, heads = H * W, self.cfg["num_heads"]
+        p = sp + ".transformer_blocks.0"
+        pin, f = L[sp + ".proj_in"], self.fused_qkv[p + ".attn1"]
+        ab = ops.gn_affine_from_stats(x_img, self.sd[sp + ".norm.weight"], self.sd[sp + ".norm.bias"], 1e-6)
+        pre = ops.row_chain(x_img.reshape(B * T, Cc), T, [dict(pw=pin.p, aq=pin.aq, ln=True), dict(pw=f.p, aq=f.aq, t_col0=2 * Cc)], gn=ab,
+                            ln=(self.sd[p + ".norm1.weight"], self.sd[p + ".norm1.bias"], 1e-5))
+        h, y16, vt = pre[0][0].reshape(B, T, Cc), pre[1][0].reshape(B, T, 3 * Cc), pre[1][1]
+        to_out = L[p + ".attn1.to_out.0"]
+        _, o = ops.attention_f16(y16[..., :Cc], y16[..., Cc:2 * Cc], vt, heads, float((Cc // heads) ** -0.5), to_out.aq, want_f32=False)
+        pend = self._pair_half
+        lq = L[p + ".attn2.to_q"]
+        single = ctx is not None and ctx.shape[1] == 1 and os.environ.get("TFMQ_SINGLE_CTX_TOKEN", "1") != "0"
+        if (not single) and self._cross_ok(p + ".attn2") and lq.p.cout == Cc:
+            mid = ops.row_chain(o.reshape(B * T, Cc), T, [dict(pw=to_out.p, aq=to_out.aq, residual=h.reshape(B * T, Cc), ln=True), dict(pw=lq.p, aq=lq.aq)],
+                                ln=(self.sd[p + ".norm2.weight"], self.sd[p + ".norm2.bias"], 1e-5))
+            x, q16 = mid[0][0].reshape(B, T, Cc), mid[1][0].reshape(B, T, Cc)
+            if pend:      # the guidance pair parts here (norm2 / to_q saw the shared tensor: per-item arithmetic, same bits)
+                x, q16, self._pair_half = self._dup(x), self._dup(q16), False
+            x = self._cross_core(p + ".attn2", q16, x)
+        else:
+            x = self._tok(to_out, o, residual=h, **self._o16())
+            x = self._tblock_after_attn1(p, x, ctx)
+        return self._ff(p, x, out_aq)
+
     def _tblock(self, p, x, ctx, out_aq=None):
         L = self.layers
         q1 = self.fused_qkv.get(p + ".attn1", L[p + ".attn1.to_q"])
         x = self._attention(p + ".attn1", self._ln(p + ".norm1", x, q1), None, x, True)
+        x = self._tblock_after_attn1(p, x, ctx)
+        return self._ff(p, x, out_aq)
+
+    def _tblock_after_attn1(self, p, x, ctx):
+        L = self.layers
         # pair_prefix: everything up to here saw only (x, t) -- identical for the two members of a guidance pair -- and ran once per
         # pair; the first cross attention is where the members part (norm2 / to_q's quantizer still see the shared tensor)
         pend = self._pair_half
@@ -326,6 +406,10 @@ class LdmUNetEngine(DdimUNetEngine):
             if pend:
                 x, xq2, self._pair_half = self._dup(x), self._dup(xq2), False
             x = self._attention(p + ".attn2", xq2, ctx, x, False)
+        return x
+
+    def _ff(self, p, x, out_aq=None):
+        L = self.layers
         ff0, ff2 = L[p + ".ff.net.0.proj"], L[p + ".ff.net.2"]
         gp = self.geglu_fused.get(p + ".ff.net.0.proj")
         if gp is not None and self.calib is None:
@@ -357,6 +441,15 @@ class LdmUNetEngine(DdimUNetEngine):
         L = self.layers
         B, H, W, Cc = x.shape
         pin, pout = L[p + ".proj_in"], L[p + ".proj_out"]
+        if self._chain_ok(p, x, taps):
+            fuse_q = pout.kind == "w4a8" and not pout.wide and self.fuse_q8
+            tok = self._tblock_chained(p, x, ctx, out_aq=pout.aq if fuse_q else None)
+            if tok.shape[0] != B:       # pair_prefix: the guidance pair parted inside this transformer; the residual is the shared tensor
+                x, B = self._dup(x), tok.shape[0]
+            h = tok.reshape(B, H, W, -1) if tok.dtype == torch.int8 else self._quant_in(pout, tok.reshape(B, H, W, -1))
+            if out_aq is not None and pout.kind == "w4a8" and not pout.wide:
+                return pout.run(h, residual=x, want_stats=False, out_q8=out_aq)
+            return pout.run(h, residual=x, **self._o16())
         h_in, _ = self._gn(p + ".norm", x, None, False, pin, eps=1e-6)
         h = pin.run(h_in, want_stats=False, **self._o16())
         if taps is not None:

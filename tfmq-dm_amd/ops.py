@@ -12,7 +12,7 @@ from typing import Optional, Tuple
 
 import torch
 
-from ._lib import ConvDesc, FfDesc, GnDesc, QSel, TfmqError, handle
+from ._lib import ChainDesc, ConvDesc, FfDesc, GnDesc, QSel, TfmqError, handle
 
 NULL = None
 
@@ -919,6 +919,90 @@ def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: flo
     handle(d).call("layernorm_h" if xh else "layernorm", _p(x), _p(gamma), _p(beta), float(eps), rows, Cc,
                    aq if quant else QSel(None, None, 0, 0), _p(yq), _p(yf), _stream(d))
     return yq, yf
+
+
+def gn_affine_from_stats(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float, groups: int = 32):
+    """The statistics half of groupnorm() on its own (tfmq_gn_finalize): per-(image, channel) a, b with GroupNorm(x) = a * x + b, from the
+    {sum, sum of squares} segments the producing conv's epilogue attached to x (x._tfmq_stats); None when x carries none."""
+    st = getattr(x, "_tfmq_stats", None)
+    B, Cc = x.shape[0], x.shape[-1]
+    HW = x.numel() // (B * Cc)
+    if st is None or HW % st[1] != 0:
+        return None
+    d = _dev(x)
+    g = GnDesc()
+    g.B, g.HW, g.C1, g.C2 = B, HW, Cc, 0
+    g.gamma, g.beta, g.eps, g.groups = gamma.data_ptr(), beta.data_ptr(), float(eps), groups
+    ab = _alloc(2, B, Cc, dtype=torch.float32, device=x.device)
+    handle(d).call("gn_finalize", C.byref(g), _p(st[0]), None, st[1], _p(ab[0]), _p(ab[1]), _stream(d))
+    return ab[0], ab[1]
+
+
+def row_chain_ok(C_: int, M: int, T: int, gn_in: bool) -> bool:
+    """Launches tfmq_row_chain takes (TFMQ_ROW_CHAIN=0: the separate launches, A/B runs)."""
+    return os.environ.get("TFMQ_ROW_CHAIN", "1") != "0" and C_ == 320 and M % 256 == 0 and (not gn_in or T % 256 == 0)
+
+
+def row_chain(x: torch.Tensor, T: int, gemms, gn=None, ln=None):
+    """Token Linears (K = C = 320) chained over resident token tiles in ONE launch (tfmq_row_chain), a token per lane.
+    x: [M, C] int8 bins of gemms[0]'s quantizer, or -- with gn = (a, b) per-(image, channel) GroupNorm affine [M / T, C] -- fp16 rows.
+    gemms: up to 3 dicts {pw: PackedW4, aq: QSel, residual: fp16 [M, N] | None, t_col0: int | None, ln: bool}; `ln` (one at most,
+    on a C-wide GEMM that is not the last) puts LayerNorm(ln = (gamma, beta, eps)) + the next GEMM's quantizer between the two.
+    Returns [(y fp16 [M, N], yt fp16 [M / T, N - t_col0, T] | None), ...]; with t_col0, y's columns >= t_col0 stay unwritten."""
+    d = _dev(x)
+    M, Cc = x.shape
+    _chk(x, torch.float16 if gn is not None else torch.int8, "x")
+    if not row_chain_ok(Cc, M, T, gn is not None) or not 1 <= len(gemms) <= 3:
+        raise TfmqError("row_chain: unsupported shape (token width 320, M % 256 == 0, 1-3 GEMMs)")
+    dsc = ChainDesc()
+    dsc.M, dsc.C, dsc.T, dsc.in_mode = M, Cc, int(T), (2 if gn is not None else 0)
+    dsc.x = x.data_ptr()
+    if gn is not None:
+        dsc.gn_a, dsc.gn_b = gn[0].data_ptr(), gn[1].data_ptr()
+    if ln is not None:
+        dsc.ln_gamma, dsc.ln_beta, dsc.ln_eps = ln[0].data_ptr(), ln[1].data_ptr(), float(ln[2])
+    dsc.n_gemm = len(gemms)
+    outs, keep, ncol, nops, nbytes = [], [x, gn, ln], 0, 0.0, float(x.numel() * x.element_size())
+    for i, gm in enumerate(gemms):
+        pw = gm["pw"]
+        if pw.w8 is None or pw.cin != Cc or pw.kh != 1 or pw.kw != 1 or pw.cout % 64:
+            raise TfmqError("row_chain: every GEMM is a w4a8 Linear with Cin = 320 and Cout % 64 == 0")
+        L = dsc.g[i]
+        L.w, L.wmeta, L.wscale = pw.w8.data_ptr(), pw.wmeta.data_ptr(), pw.wscale.data_ptr()
+        L.bias = None if pw.bias is None else pw.bias.data_ptr()
+        L.N, L.aq = pw.cout, gm["aq"]
+        res = gm.get("residual")
+        if res is not None:
+            _chk(res, torch.float16, "residual")
+            L.residual = res.data_ptr()
+            nbytes += 2.0 * M * pw.cout
+        y = _alloc(M, pw.cout, dtype=torch.float16, device=x.device)
+        L.y, L.ldy = y.data_ptr(), pw.cout
+        yt = None
+        if gm.get("t_col0") is not None:
+            yt = _alloc(M // T, pw.cout - gm["t_col0"], T, dtype=torch.float16, device=x.device)
+            L.yt, L.t_col0 = yt.data_ptr(), int(gm["t_col0"])
+        L.next = int(bool(gm.get("ln")))
+        outs.append((y, yt))
+        keep += [pw, res, gm["aq"]]
+        ncol += pw.cout
+        nops += 2.0 * M * pw.cout * Cc
+        nbytes += 2.0 * M * pw.cout + pw.cout * Cc
+    ws = _alloc(4 * ncol, dtype=torch.float32, device=x.device)
+    dsc.ws = ws.data_ptr()
+    dsc._keep = keep
+    h = handle(d)
+    if _conv_prof is None:
+        h.call("row_chain", C.byref(dsc), _stream(d))
+        return outs
+    e0, e1 = C.c_int(), C.c_int()
+    h.call("event_create", C.byref(e0))
+    h.call("event_create", C.byref(e1))
+    h.call("event_record", e0.value, _stream(d))
+    h.call("row_chain", C.byref(dsc), _stream(d))
+    h.call("event_record", e1.value, _stream(d))
+    _conv_prof.append((e0.value, e1.value, nops, "w4a8", nbytes))
+    return outs
 
 
 def ff_fused_ok(C_: int, inner: int, pw1, pw2) -> bool:
