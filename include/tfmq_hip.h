@@ -272,7 +272,31 @@ typedef struct tfmq_ff_desc {
   uint16_t* y;                   /* fp16 [M][C] output (oq.qtable == NULL) */
   tfmq_qsel oq;                  /* qtable != NULL: the output's only consumer is this activation quantizer: int8 bins to yq */
   int8_t* yq;
-  float* ws;                     /* scratch, 4 * inner floats: the GEGLU projection's folded per-channel constants (written per call) */
+  float* ws;                     /* scratch, 4 * inner + 2560 floats: folded per-channel constants (written per call) */
+  /* optional (ABI 8, round 4): a C -> C w4a8 Linear IN FRONT of the feed-forward, w0 != NULL -- attn2.to_out of the block
+   * (`x = self.attn2(self.norm2(x), context=context) + x`, ldm/modules/attention.py:213, to_out :194): the rows x_pre = to_out(xq_pre) + bias0 +
+   * res_pre are written to y_pre (fp16 [M][C]) and take the place of `x` (LayerNorm input and residual).  xq_pre: int8 bins [M][C] of
+   * aq_pre (the cross attention kernel's output).  M % 256 == 0. */
+  const int8_t* xq_pre;
+  const int8_t* w0;
+  const int32_t* wmeta0;
+  const float* wscale0;
+  const float* bias0;
+  tfmq_qsel aq_pre;
+  const uint16_t* res_pre;
+  uint16_t* y_pre;
+  /* optional: a C -> C w4a8 Linear BEHIND it, w3 != NULL -- the SpatialTransformer's proj_out (+ x_in, ldm/modules/attention.py:259-261): the
+   * feed-forward's output is quantised with oq (proj_out's activation quantizer; yq / y unused) and y_post = proj_out(bins) + bias3 + res_post
+   * is written as fp16 [M][C]; stats (optional): the consumer GroupNorm's per-segment {sum, sum of squares}, [M / stats_seg][C][2], as
+   * tfmq_conv_desc.stats.  M % 256 == 0. */
+  const int8_t* w3;
+  const int32_t* wmeta3;
+  const float* wscale3;
+  const float* bias3;
+  const uint16_t* res_post;
+  uint16_t* y_post;
+  float* stats;
+  int32_t stats_seg;
 } tfmq_ff_desc;
 /* TFMQ_ERR_UNSUPPORTED for a token width other than 320 (callers keep the three-launch chain). */
 int tfmq_ff_fused(tfmq_handle h, const tfmq_ff_desc* d, void* stream);

@@ -38,7 +38,7 @@ def test_struct_layouts_match_header(lib):
     assert C.sizeof(lib.QSel) == 24
     assert C.sizeof(lib.ConvDesc) == 13 * 4 + 4 + 5 * 8 + 24 + 2 * 8 + 8 + 2 * 8 + 8 + 16 + 24 + 8 + 8 + 8 + 8 + 8 + 8 + 8 + 8   # ... + x2 + cin1 (padded) + w64 + ksplit (padded)
     assert C.sizeof(lib.GnDesc) == 16 + 32 + 12 + 4 + 24 + 24 + 8
-    assert C.sizeof(lib.FfDesc) == 16 + 3 * 8 + 8 + 24 + 4 * 8 + 24 + 4 * 8 + 8 + 24 + 8 + 8      # tfmq_ff_desc (round 4)
+    assert C.sizeof(lib.FfDesc) == 16 + 3 * 8 + 8 + 24 + 4 * 8 + 24 + 4 * 8 + 8 + 24 + 8 + 8 + (5 * 8 + 24 + 2 * 8) + (7 * 8 + 8)      # tfmq_ff_desc (round 4): + the Linears in front / behind
     assert C.sizeof(lib.ChainGemm) == 104 and C.sizeof(lib.ChainDesc) == 384      # tfmq_chain_gemm / tfmq_chain_desc as g++ lays them out
 
 

@@ -112,3 +112,47 @@ def test_ff_fused_refuses_other_widths(ops):
     assert not ops.ff_fused_ok(128, 256, pw1, pw2)
     with pytest.raises(TfmqError):
         ops.ff_fused(ref["x"][:64].half().to(DEV), ref["gamma"].to(DEV), ref["beta"].to(DEV), 1e-5, ops.qsel(qt, 0), pw1, ops.qsel(qt, 1), pw2)
+
+
+@pytest.mark.parametrize("M,with_pre,with_post", [(512, True, False), (512, False, True), (4096 * 2, True, True), (256, True, True)])
+def test_ff_fused_with_the_linears_in_front_and_behind(ops, M, with_pre, with_post):
+    """attn2.to_out (+ residual) in front and proj_out (+ the SpatialTransformer's input, + the next GroupNorm's statistics) behind the
+    feed-forward, in the same launch (ldm/modules/attention.py:194, :213, :259-261): every stored tensor and the statistics equal the
+    separate launches bit for bit."""
+    C, inner, T = 320, 1280, 256
+    qt, pw1, pw2, ref = _layers(ops, C, inner, 21)
+    g = torch.Generator().manual_seed(33 + M)
+    qt2 = torch.tensor([[[0.04, 119.0]]], dtype=torch.float32, device=DEV)
+    sel0, sel2, selo, selp = ops.qsel(qt, 0), ops.qsel(qt, 1), ops.qsel(qt, 2), ops.qsel(qt2, 0)
+    gamma, beta = ref["gamma"].to(DEV), ref["beta"].to(DEV)
+
+    def lin(bias=True):
+        w = torch.randn(C, C, 1, 1, generator=g) * (2.0 / C ** 0.5)
+        wd, wz = O.init_channelwise(w, 16, "minmax")
+        return ops.pack_w4(w.to(DEV), wd.to(DEV), wz.to(DEV), bias=(torch.randn(C, generator=g) * 0.2).to(DEV) if bias else None)
+    to_out2, proj_out = lin(), lin()
+    xres = (torch.randn(M, C, generator=g) * 1.4).half().to(DEV)           # the stream before attn2's residual add
+    x_in = (torch.randn(M, C, generator=g) * 1.1).half().to(DEV)           # the SpatialTransformer's input
+    o2 = torch.randint(-128, 128, (M, C), generator=g, dtype=torch.int8).to(DEV)
+    # the separate launches
+    if with_pre:
+        x2 = ops.conv2d_w4a8(o2.reshape(1, M, 1, C), to_out2, selp, residual=xres.reshape(1, M, 1, C), out_f16=True, want_stats=False).reshape(M, C)
+    else:
+        x2 = xres
+    if with_post:
+        bins = _chain(ops, x2, gamma, beta, sel0, pw1, sel2, pw2, selo)
+        want = ops.conv2d_w4a8(bins.reshape(M // T, T, 1, C), proj_out, selo, residual=x_in.reshape(M // T, T, 1, C), out_f16=True, want_stats=True)
+        want_stats = want._tfmq_stats
+        want = want.reshape(M, C)
+    else:
+        want = _chain(ops, x2, gamma, beta, sel0, pw1, sel2, pw2, None)
+    # one launch
+    pre = dict(xq=o2, pw=to_out2, aq=selp, residual=xres) if with_pre else None
+    post = dict(pw=proj_out, residual=x_in, stats=True, hw=T) if with_post else None
+    got = ops.ff_fused(None if with_pre else x2, gamma, beta, 1e-5, sel0, pw1, sel2, pw2, out_q8=selo if with_post else None, pre=pre, post=post)
+    if with_pre:
+        assert torch.equal(got[0], x2)
+        got = got[1]
+    assert got.dtype == want.dtype and torch.equal(got, want)
+    if with_post:
+        assert got._tfmq_stats[1] == want_stats[1] and torch.equal(got._tfmq_stats[0], want_stats[0])

@@ -143,14 +143,15 @@ def test_sd_row_chains_and_fused_ff_are_bit_identical_at_full_size(sd, monkeypat
     ctx = torch.randn(6, 77, 768, generator=g).to(DEV)
     outs = {}
     with torch.cuda.stream(info["stream"]):
-        for chain, ff in (("1", "1"), ("0", "0"), ("1", "0"), ("0", "1")):
+        for chain, ff, ffc in (("1", "1", "1"), ("0", "0", "1"), ("1", "0", "1"), ("0", "1", "1"), ("1", "1", "0")):
             monkeypatch.setenv("TFMQ_ROW_CHAIN", chain)
             monkeypatch.setenv("TFMQ_FF_FUSED", ff)
+            monkeypatch.setenv("TFMQ_FF_CHAIN", ffc)        # attn2.to_out in front of / proj_out behind the feed-forward, in its launch
             info["step"].zero_()
-            outs[(chain, ff, "plain")] = eng.forward(x, None, ctx[:3].contiguous()).clone()
-            outs[(chain, ff, "pair")] = eng.forward(x, None, ctx, pair_prefix=True).clone()
+            outs[(chain, ff, "plain", ffc)] = eng.forward(x, None, ctx[:3].contiguous()).clone()
+            outs[(chain, ff, "pair", ffc)] = eng.forward(x, None, ctx, pair_prefix=True).clone()
         info["stream"].synchronize()
-    ref_plain, ref_pair = outs[("0", "0", "plain")], outs[("0", "0", "pair")]
+    ref_plain, ref_pair = outs[("0", "0", "plain", "1")], outs[("0", "0", "pair", "1")]
     assert torch.isfinite(ref_plain).all() and torch.isfinite(ref_pair).all()
     for k, v in outs.items():
         assert torch.equal(v, ref_plain if k[2] == "plain" else ref_pair), k

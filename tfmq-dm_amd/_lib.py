@@ -65,6 +65,10 @@ class FfDesc(C.Structure):
         ("aq2", QSel),
         ("w2", c_void_p), ("wmeta2", c_void_p), ("wscale2", c_void_p), ("bias2", c_void_p),
         ("y", c_void_p), ("oq", QSel), ("yq", c_void_p), ("ws", c_void_p),
+        ("xq_pre", c_void_p), ("w0", c_void_p), ("wmeta0", c_void_p), ("wscale0", c_void_p), ("bias0", c_void_p), ("aq_pre", QSel),
+        ("res_pre", c_void_p), ("y_pre", c_void_p),
+        ("w3", c_void_p), ("wmeta3", c_void_p), ("wscale3", c_void_p), ("bias3", c_void_p), ("res_post", c_void_p), ("y_post", c_void_p),
+        ("stats", c_void_p), ("stats_seg", C.c_int32),
     ]
 
 

@@ -27,6 +27,12 @@
 #include "conv_common.hpp"
 #include <type_traits>
 
+// Timing-only ablations (scratch/r04_ff_abl.sh builds one library per mask with -DFF_ABLATE=<mask>; results are garbage, times are not):
+// 1 no GELU / quantise arithmetic, 2 no projection MFMAs, 4 no ff.net.2 MFMAs, 8 no constant reads, 16 no LayerNorm arithmetic, 32 no fragment reads
+#ifndef FF_ABLATE
+#define FF_ABLATE 0
+#endif
+
 namespace {
 
 struct FfP {
@@ -61,6 +67,23 @@ __global__ __launch_bounds__(256) void k_ff_fold(tfmq_ff_desc d) {
   }
 }
 
+// the optional Linears in front of / behind the feed-forward (K = C): per phase (64 columns) {scale[64], kc[64] (int bits), bias[64], pad[64]}
+// (k_lin_direct's table) behind the GEGLU constants: ws + 4 * inner + (5 * which + phase) * 256
+__global__ __launch_bounds__(256) void k_ff_fold_lin(tfmq_ff_desc d) {
+  const int which = blockIdx.y, n = blockIdx.x * 256 + threadIdx.x;
+  if (n >= d.C) return;
+  const int32_t* wmeta = which ? d.wmeta3 : d.wmeta0;
+  const float* wscale = which ? d.wscale3 : d.wscale0;
+  const float* bias = which ? d.bias3 : d.bias0;
+  if (!wmeta) return;
+  const float2 aqp = load_qparam(which ? d.oq : d.aq_pre);
+  const int4 wmv = reinterpret_cast<const int4*>(wmeta)[n];
+  float* out = d.ws + 4 * static_cast<size_t>(d.inner) + static_cast<size_t>(5 * which + (n >> 6)) * 256 + (n & 63);
+  out[0] = aqp.x * wscale[n];
+  reinterpret_cast<int*>(out)[64] = (128 - static_cast<int>(aqp.y)) * (wmv.y - d.C * wmv.x);
+  out[128] = bias ? bias[n] : 0.0f;
+}
+
 constexpr int FF_STG_ROW = 144;         // output staging: 64 fp16 + 16 bytes per token row (conv_lin.hip)
 constexpr int FF_STG_ROW_Q8 = 80;
 
@@ -74,13 +97,17 @@ struct FfGeo {
   static constexpr int X_OFF = 3 * SLOT;
   static constexpr int CS2_OFF = X_OFF + 8 * XW;
   static constexpr int LNGB_OFF = CS2_OFF + 3 * C * 4;
-  static constexpr int TOTAL = LNGB_OFF + 2 * C * 4;
+  static constexpr int TOTAL = (LNGB_OFF + 2 * C * 4) > (CS2_OFF + 16384) ? (LNGB_OFF + 2 * C * 4) : (CS2_OFF + 16384);   // (POST: statistics partials alias the tables)
   static constexpr int NPIECE = 2 * NCH * 2;         // 1-KiB DMA pieces of a phase (value + gate tiles; = NT * 2 for ff.net.2's K-step)
   static_assert(NT * 2 == NPIECE, "");
   static constexpr int PPW = (NPIECE + 1 + 7) / 8;   // pieces a wave issues per phase (uniform: surplus slots re-load a piece)
 };
 
-template <int C>
+// PRE: a C -> C Linear (+ bias, + fp16 residual) on int8 input rows in front (attn2.to_out: its output row is stored, normalised in place and
+// becomes the residual of the feed-forward).  POST: a C -> C Linear on the feed-forward's output bins behind it (proj_out: + bias, + fp16
+// residual, fp16 rows out, GroupNorm statistics of the consumer).  Both on the chain phases of row_chain.hip (two output tiles per phase,
+// slots 0 / 1 of the ring).  M % 256 == 0 with either.
+template <int C, bool PRE, bool POST>
 __global__ __launch_bounds__(512, 2) void k_ff_fused(FfP p) {
   using G = FfGeo<C>;
   constexpr int NCH = G::NCH, NT = G::NT, PPW = G::PPW;
@@ -124,6 +151,154 @@ __global__ __launch_bounds__(512, 2) void k_ff_fused(FfP p) {
       glds16_sv(src, voff, sbase + __builtin_amdgcn_readfirstlane(pi * 1024));
     }
   };
+  // ---- chain phases of the optional Linears (row_chain.hip): phase ph of `which` (0 = PRE, 1 = POST) = output tiles 2 ph, 2 ph + 1
+  auto issue_lin = [&](int which, int ph) {
+    const unsigned char* w = reinterpret_cast<const unsigned char*>(which ? d.w3 : d.w0);
+    const unsigned sbase = lds0 + G::RING_OFF + (ph & 1) * G::SLOT;
+#pragma unroll
+    for (int it = 0; it < PPW; ++it) {
+      int pi = wid + 8 * it;
+      if (pi == G::NPIECE) {
+        glds16_sv(reinterpret_cast<const unsigned char*>(d.ws + 4 * static_cast<size_t>(d.inner)) + static_cast<size_t>(5 * which + ph) * 1024,
+                  static_cast<unsigned>(lane * 16), sbase + __builtin_amdgcn_readfirstlane(G::NPIECE * 1024));
+        continue;
+      }
+      if (pi >= G::NPIECE) pi -= 8;
+      const int tile = pi / (2 * NCH), rem = pi - tile * 2 * NCH, sI = rem >> 1, j = rem & 1;
+      const unsigned char* src = w + ((static_cast<size_t>(2 * ph + tile) * NCH + sI) * 32 + j * 16) * 64;
+      glds16_sv(src, voff, sbase + __builtin_amdgcn_readfirstlane(pi * 1024));
+    }
+  };
+  unsigned char* Xw = lds + G::X_OFF + wid * G::XW;
+  const int fsw = (h ^ ((pl >> 2) & 3)) << 4;
+  const int brow = lin_brow(pl);
+  const int bsw = (h ^ ((brow >> 2) & 3)) << 4;
+  const unsigned char* xfr = Xw + pl * 64;
+  const int swz_x = (pl >> 2) & 3;
+  auto x_store = [&](int t, unsigned w0, unsigned w1_, unsigned w2_, unsigned w3_) {
+    *reinterpret_cast<uint4*>(Xw + (t >> 1) * 2048 + pl * 64 + (((2 * (t & 1) + h) ^ swz_x) << 4)) = make_uint4(w0, w1_, w2_, w3_);
+  };
+  // one phase: scale * float(acc + kc) + bias + residual -> fp16 (k_lin_direct's operations); rows out through the wave's staging in slot 2;
+  // KEEP: the packed row stays in `keep` (PRE); STATS: the consumer GroupNorm's {sum, sum of squares} partials of the fp32 values (POST)
+  auto lin_phase = [&](auto ph_tag, auto which_tag, uint4 (&keep)[NT][2], const __half* res, __half* yout, bool first) {
+    constexpr int PH = decltype(ph_tag)::value, WHICH = decltype(which_tag)::value;
+    if (first) ff_wait_vmcnt<0>();
+    else ff_wait_vmcnt<4>();
+    asm volatile("s_barrier" ::: "memory");
+    if (PH + 1 < NT / 2) issue_lin(WHICH, PH + 1);
+    const unsigned char* slot = lds + G::RING_OFF + (PH & 1) * G::SLOT;
+    const float* cs = reinterpret_cast<const float*>(slot + G::NPIECE * 1024);
+    unsigned char* stgl = lds + G::RING_OFF + 2 * G::SLOT + wid * (32 * 80);
+    float2* part = reinterpret_cast<float2*>(lds + G::CS2_OFF);
+    uint4 rr[2][2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int u = 0; u < 2; ++u) rr[j][u] = *reinterpret_cast<const uint4*>(res + static_cast<size_t>(m) * C + 64 * PH + 32 * j + 16 * h + 8 * u);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      v16i acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0;
+#pragma unroll
+      for (int sidx = 0; sidx < NCH; ++sidx)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          const v4i xf = *reinterpret_cast<const v4i*>(xfr + sidx * 2048 + (fsw ^ (ks << 5)));
+          const v4i wf = *reinterpret_cast<const v4i*>(slot + (j * NCH + sidx) * 2048 + brow * 64 + (bsw ^ (ks << 5)));
+          acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf, xf, acc, 0, 0, 0);
+        }
+      unsigned hw[8];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int ct = 32 * j + 16 * h + 8 * u;
+        f2 vv[4];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          const float4 sc = *reinterpret_cast<const float4*>(cs + ct + 4 * e);
+          const int4 kc = *reinterpret_cast<const int4*>(reinterpret_cast<const int*>(cs) + 64 + ct + 4 * e);
+          const float4 bb = *reinterpret_cast<const float4*>(cs + 128 + ct + 4 * e);
+          vv[2 * e] = f2{sc.x, sc.y} * f2{static_cast<float>(acc[8 * u + 4 * e] + kc.x), static_cast<float>(acc[8 * u + 4 * e + 1] + kc.y)} + f2{bb.x, bb.y};
+          vv[2 * e + 1] = f2{sc.z, sc.w} * f2{static_cast<float>(acc[8 * u + 4 * e + 2] + kc.z), static_cast<float>(acc[8 * u + 4 * e + 3] + kc.w)} + f2{bb.z, bb.w};
+        }
+        const uint4 rw = rr[j][u];
+        const float2 r0 = __half22float2(*reinterpret_cast<const __half2*>(&rw.x)), r1 = __half22float2(*reinterpret_cast<const __half2*>(&rw.y));
+        const float2 r2 = __half22float2(*reinterpret_cast<const __half2*>(&rw.z)), r3 = __half22float2(*reinterpret_cast<const __half2*>(&rw.w));
+        vv[0] += f2{r0.x, r0.y};
+        vv[1] += f2{r1.x, r1.y};
+        vv[2] += f2{r2.x, r2.y};
+        vv[3] += f2{r3.x, r3.y};
+        if constexpr (WHICH == 1) {
+          if (d.stats) {       // k_lin_direct's statistics: DPP sums over the 8 lanes (token rows) of a group, canonical order (group8_sum)
+            const int grp = wid * 4 + (pl >> 3);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float x0 = vv[e].x, x1 = vv[e].y;
+              const float s0 = group8_sum(x0), s1 = group8_sum(x1);
+              const float q0 = group8_sum(x0 * x0), q1 = group8_sum(x1 * x1);
+              if ((lane & 7) == 0) *reinterpret_cast<float4*>(part + grp * 64 + ct + 2 * e) = make_float4(s0, q0, s1, q1);
+            }
+          }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) hw[4 * u + e] = pack_h2(vv[e].x, vv[e].y);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if constexpr (WHICH == 0) {
+        keep[2 * PH + j][0] = make_uint4(hw[0], hw[1], hw[2], hw[3]);
+        keep[2 * PH + j][1] = make_uint4(hw[4], hw[5], hw[6], hw[7]);
+      }
+      *reinterpret_cast<uint4*>(stgl + pl * 80 + 32 * h) = make_uint4(hw[0], hw[1], hw[2], hw[3]);
+      *reinterpret_cast<uint4*>(stgl + pl * 80 + 32 * h + 16) = make_uint4(hw[4], hw[5], hw[6], hw[7]);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+#pragma unroll
+      for (int it = 0; it < 2; ++it) {
+        const int row = it * 16 + (lane >> 2), pc = lane & 3;
+        const uint4 w = *reinterpret_cast<const uint4*>(stgl + row * 80 + pc * 16);
+        *reinterpret_cast<uint4*>(yout + static_cast<size_t>(m0 + wid * 32 + row) * C + 64 * PH + 32 * j + pc * 8) = w;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    if constexpr (WHICH == 1) {
+      if (d.stats) {
+        LDS_BARRIER();
+        const int seg = d.stats_seg, nseg = 256 / seg, gps = seg / 8;
+        for (int o = tid; o < nseg * 64; o += 512) {
+          const int sidx = o >> 6, col = o & 63;
+          float2 a = make_float2(0.0f, 0.0f);
+          for (int q = 0; q < gps; ++q) {            // a segment = its 8-row groups added in row order
+            const float2 b = part[(sidx * gps + q) * 64 + col];
+            a.x += b.x;
+            a.y += b.y;
+          }
+          reinterpret_cast<float2*>(d.stats)[static_cast<size_t>((m0 + sidx * seg) / seg) * C + 64 * PH + col] = a;
+        }
+      }
+    }
+  };
+  auto lin_all = [&](auto which_tag, uint4 (&keep)[NT][2], const __half* res, __half* yout) {
+    lin_phase(std::integral_constant<int, 0>{}, which_tag, keep, res, yout, true);
+    lin_phase(std::integral_constant<int, 1>{}, which_tag, keep, res, yout, false);
+    lin_phase(std::integral_constant<int, 2>{}, which_tag, keep, res, yout, false);
+    lin_phase(std::integral_constant<int, 3>{}, which_tag, keep, res, yout, false);
+    lin_phase(std::integral_constant<int, 4>{}, which_tag, keep, res, yout, false);
+  };
+  static_assert(NT == 10, "the chain phases are written for C = 320");
+
+  uint4 raw[NT][2];
+  if constexpr (PRE) {
+    // int8 input rows (the cross attention's output bins): 10 pieces per wave straight into the wave's X region, then the Linear
+    const unsigned char* xb = reinterpret_cast<const unsigned char*>(d.xq_pre) + static_cast<size_t>(m0 + wid * 32) * C;
+#pragma unroll
+    for (int sI = 0; sI < NCH; ++sI)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        glds16_sv(xb + static_cast<size_t>(j * 16) * C + sI * 64, static_cast<unsigned>((lane >> 2) * C + (((lane & 3) ^ ((lane >> 4) & 3)) * 16)),
+                  lds0 + G::X_OFF + __builtin_amdgcn_readfirstlane(wid * G::XW + sI * 2048 + j * 1024));
+    issue_lin(0, 0);
+    lin_all(std::integral_constant<int, 0>{}, raw, reinterpret_cast<const __half*>(d.res_pre), reinterpret_cast<__half*>(d.y_pre));
+    asm volatile("s_barrier" ::: "memory");          // slots 0 / 1 and the staging in slot 2 are free
+  }
   issue(0, 0);
   issue(1, 0);
   issue(2, 0);
@@ -142,14 +317,14 @@ __global__ __launch_bounds__(512, 2) void k_ff_fused(FfP p) {
   }
 
   // ---- this lane's half of its token's row: channels 32 t + 16 h .. + 15 of every tile t
-  const __half* xrow = reinterpret_cast<const __half*>(d.x) + static_cast<size_t>(mc) * C + 16 * h;
-  unsigned char* Xw = lds + G::X_OFF + wid * G::XW;
+  const __half* xrow = reinterpret_cast<const __half*>(PRE ? d.y_pre : d.x) + static_cast<size_t>(mc) * C + 16 * h;
   {
-    uint4 raw[NT][2];
+    if constexpr (!PRE) {
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      raw[t][0] = *reinterpret_cast<const uint4*>(xrow + 32 * t);
-      raw[t][1] = *reinterpret_cast<const uint4*>(xrow + 32 * t + 8);
+      for (int t = 0; t < NT; ++t) {
+        raw[t][0] = *reinterpret_cast<const uint4*>(xrow + 32 * t);
+        raw[t][1] = *reinterpret_cast<const uint4*>(xrow + 32 * t + 8);
+      }
     }
     LDS_BARRIER();                    // the tables above
     // LayerNorm in k_layernorm_hs<C / 40>'s order: a row's 8-channel pieces idx = 4 t + 2 h + e belong to sub-lane j = idx % LPR and are
@@ -234,10 +409,6 @@ __global__ __launch_bounds__(512, 2) void k_ff_fused(FfP p) {
   }
 
   // ---- fragment addressing (conv_lin.hip): activation rows by token, weight rows in the permuted order that makes register r = channel 16 h + r
-  const int fsw = (h ^ ((pl >> 2) & 3)) << 4;
-  const int brow = lin_brow(pl);
-  const int bsw = (h ^ ((brow >> 2) & 3)) << 4;
-  const unsigned char* xfr = Xw + pl * 64;
   const float zp2 = aqp2.y;
 
   v16i acc2[NT];
@@ -282,11 +453,21 @@ __global__ __launch_bounds__(512, 2) void k_ff_fused(FfP p) {
     for (int sidx = 0; sidx < NCH; ++sidx)
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
-        const v4i xf = *reinterpret_cast<const v4i*>(xfr + sidx * 2048 + (fsw ^ (ks << 5)));
-        const v4i vf = *reinterpret_cast<const v4i*>(slot + sidx * 2048 + brow * 64 + (bsw ^ (ks << 5)));
-        const v4i gf = *reinterpret_cast<const v4i*>(slot + NCH * 2048 + sidx * 2048 + brow * 64 + (bsw ^ (ks << 5)));
-        av = __builtin_amdgcn_mfma_i32_32x32x32_i8(vf, xf, av, 0, 0, 0);
-        ag = __builtin_amdgcn_mfma_i32_32x32x32_i8(gf, xf, ag, 0, 0, 0);
+        v4i xf, vf, gf;
+        if constexpr (FF_ABLATE & 32) {
+          xf = vf = gf = v4i{sidx, ks, lane, 1};
+        } else {
+          xf = *reinterpret_cast<const v4i*>(xfr + sidx * 2048 + (fsw ^ (ks << 5)));
+          vf = *reinterpret_cast<const v4i*>(slot + sidx * 2048 + brow * 64 + (bsw ^ (ks << 5)));
+          gf = *reinterpret_cast<const v4i*>(slot + NCH * 2048 + sidx * 2048 + brow * 64 + (bsw ^ (ks << 5)));
+        }
+        if constexpr (FF_ABLATE & 2) {
+          av[ks] += vf[0] + xf[1];
+          ag[ks] += gf[0];
+        } else {
+          av = __builtin_amdgcn_mfma_i32_32x32x32_i8(vf, xf, av, 0, 0, 0);
+          ag = __builtin_amdgcn_mfma_i32_32x32x32_i8(gf, xf, ag, 0, 0, 0);
+        }
       }
     // (pin the accumulators: the interval ends here)
     asm volatile("" : "+v"(av), "+v"(ag));
@@ -298,8 +479,17 @@ __global__ __launch_bounds__(512, 2) void k_ff_fused(FfP p) {
     unsigned w[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const float4 sv = *reinterpret_cast<const float4*>(cst + 4 * i), bv = *reinterpret_cast<const float4*>(cst + 32 + 4 * i);
-      const float4 sg = *reinterpret_cast<const float4*>(cst + 64 + 4 * i), bg = *reinterpret_cast<const float4*>(cst + 96 + 4 * i);
+      float4 sv, bv, sg, bg;
+      if constexpr (FF_ABLATE & 8) {
+        sv = bv = sg = bg = make_float4(zp2, 1.0f, 0.5f, 0.25f);
+      } else {
+        sv = *reinterpret_cast<const float4*>(cst + 4 * i), bv = *reinterpret_cast<const float4*>(cst + 32 + 4 * i);
+        sg = *reinterpret_cast<const float4*>(cst + 64 + 4 * i), bg = *reinterpret_cast<const float4*>(cst + 96 + 4 * i);
+      }
+      if constexpr (FF_ABLATE & 1) {
+        w[i] = static_cast<unsigned>(av[4 * i] + ag[4 * i + 1]) ^ __float_as_uint(sv.x + bg.y);
+        continue;
+      }
       const f2 a0 = pk_fma(f2{sv.x, sv.y}, f2{static_cast<float>(av[4 * i]), static_cast<float>(av[4 * i + 1])}, f2{bv.x, bv.y});
       const f2 a1 = pk_fma(f2{sv.z, sv.w}, f2{static_cast<float>(av[4 * i + 2]), static_cast<float>(av[4 * i + 3])}, f2{bv.z, bv.w});
       const f2 g0 = pk_fma(f2{sg.x, sg.y}, f2{static_cast<float>(ag[4 * i]), static_cast<float>(ag[4 * i + 1])}, f2{bg.x, bg.y});
@@ -318,8 +508,11 @@ __global__ __launch_bounds__(512, 2) void k_ff_fused(FfP p) {
     for (int t = 0; t < NT; ++t)
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
-        const v4i wf = *reinterpret_cast<const v4i*>(slot + t * 2048 + brow * 64 + (bsw ^ (ks << 5)));
-        acc2[t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf, hb[ks], acc2[t], 0, 0, 0);
+        v4i wf;
+        if constexpr (FF_ABLATE & 32) wf = v4i{t, ks, lane, 1};
+        else wf = *reinterpret_cast<const v4i*>(slot + t * 2048 + brow * 64 + (bsw ^ (ks << 5)));
+        if constexpr (FF_ABLATE & 4) acc2[t][ks] += wf[0] + hb[ks][1];
+        else acc2[t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf, hb[ks], acc2[t], 0, 0, 0);
       }
   };
   auto run = [&](auto g_tag) {
@@ -382,7 +575,11 @@ __global__ __launch_bounds__(512, 2) void k_ff_fused(FfP p) {
         vv[3] += f2{r3.x, r3.y};
         if constexpr (Q8) {
           const unsigned q0 = quant_pack4_t<EX>(vv[0], vv[1], qP), q1 = quant_pack4_t<EX>(vv[2], vv[3], qP);
-          *reinterpret_cast<uint2*>(stg + pl * FF_STG_ROW_Q8 + j * 32 + 16 * h + 8 * u) = make_uint2(q0, q1);
+          if constexpr (POST) {        // the bins are the next Linear's operand: this lane's 16 channels of tile t, 8 bytes at a time
+            *reinterpret_cast<uint2*>(Xw + (t >> 1) * 2048 + pl * 64 + (((2 * (t & 1) + h) ^ swz_x) << 4) + 8 * u) = make_uint2(q0, q1);
+          } else {
+            *reinterpret_cast<uint2*>(stg + pl * FF_STG_ROW_Q8 + j * 32 + 16 * h + 8 * u) = make_uint2(q0, q1);
+          }
         } else {
           *reinterpret_cast<uint4*>(stg + pl * FF_STG_ROW + (j * 32 + 16 * h + 8 * u) * 2) =
               make_uint4(pack_h2(vv[0].x, vv[0].y), pack_h2(vv[1].x, vv[1].y), pack_h2(vv[2].x, vv[2].y), pack_h2(vv[3].x, vv[3].y));
@@ -390,6 +587,7 @@ __global__ __launch_bounds__(512, 2) void k_ff_fused(FfP p) {
         __builtin_amdgcn_sched_barrier(0);
       }
     }
+    if constexpr (POST) continue;
     // wave-private transpose: whole row segments out (8 lanes x 16 B per fp16 row of 64 channels; 4 lanes per int8 row)
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     if constexpr (Q8) {
@@ -412,9 +610,17 @@ __global__ __launch_bounds__(512, 2) void k_ff_fused(FfP p) {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   }
   };
-  if (!q8) epilogue(std::false_type{}, std::false_type{});
-  else if (__builtin_expect(qP.bad, 0)) epilogue(std::true_type{}, std::true_type{});
-  else epilogue(std::true_type{}, std::false_type{});
+  if constexpr (POST) {
+    issue_lin(1, 0);                  // (slots 0 / 1 are idle since the barrier above)
+    if (__builtin_expect(qP.bad, 0)) epilogue(std::true_type{}, std::true_type{});
+    else epilogue(std::true_type{}, std::false_type{});
+    // proj_out on the bins just written: + bias + the SpatialTransformer's input -> fp16 rows + the consumer GroupNorm's statistics
+    lin_all(std::integral_constant<int, 1>{}, raw, reinterpret_cast<const __half*>(d.res_post), reinterpret_cast<__half*>(d.y_post));
+  } else {
+    if (!q8) epilogue(std::false_type{}, std::false_type{});
+    else if (__builtin_expect(qP.bad, 0)) epilogue(std::true_type{}, std::true_type{});
+    else epilogue(std::true_type{}, std::false_type{});
+  }
   (void)mok;
 }
 
@@ -423,10 +629,19 @@ __global__ __launch_bounds__(512, 2) void k_ff_fused(FfP p) {
 extern "C" int tfmq_ff_fused(tfmq_handle h, const tfmq_ff_desc* dd, void* stream) {
   TFMQ_CHECK_ARG(h, h && dd, "ff_fused: null pointer");
   const tfmq_ff_desc& d = *dd;
-  TFMQ_CHECK_ARG(h, d.M > 0 && d.x && d.gamma && d.beta && d.w1 && d.wmeta1 && d.wscale1 && d.w2 && d.wmeta2 && d.wscale2 && d.ws,
+  const bool pre = d.w0 != nullptr, post = d.w3 != nullptr;
+  TFMQ_CHECK_ARG(h, d.M > 0 && (d.x || pre) && d.gamma && d.beta && d.w1 && d.wmeta1 && d.wscale1 && d.w2 && d.wmeta2 && d.wscale2 && d.ws,
                  "ff_fused: null operand");
   TFMQ_CHECK_ARG(h, d.aq0.qtable && d.aq2.qtable, "ff_fused: both activation quantizers are required");
-  TFMQ_CHECK_ARG(h, (d.oq.qtable && d.yq) || (!d.oq.qtable && d.y), "ff_fused: fp16 output y, or oq with the int8 output yq");
+  TFMQ_CHECK_ARG(h, post || (d.oq.qtable && d.yq) || (!d.oq.qtable && d.y), "ff_fused: fp16 output y, or oq with the int8 output yq");
+  TFMQ_CHECK_ARG(h, !pre || (d.xq_pre && d.wmeta0 && d.wscale0 && d.aq_pre.qtable && d.res_pre && d.y_pre), "ff_fused: the Linear in front needs xq_pre, w0 / wmeta0 / wscale0, aq_pre, res_pre and y_pre");
+  TFMQ_CHECK_ARG(h, !post || (d.wmeta3 && d.wscale3 && d.oq.qtable && d.res_post && d.y_post &&
+                              (!d.stats || ((d.stats_seg == 16 || d.stats_seg == 32 || d.stats_seg == 64 || d.stats_seg == 128)))),
+                 "ff_fused: the Linear behind needs w3 / wmeta3 / wscale3, oq (its activation quantizer), res_post, y_post (and stats_seg 16 ... 128 with stats)");
+  if ((pre || post) && d.M % 256 != 0) {
+    h->err = "ff_fused: the Linears in front of / behind the feed-forward need M % 256 == 0";
+    return TFMQ_ERR_UNSUPPORTED;
+  }
   if (d.C != 320 || d.inner % 64 != 0 || d.inner <= 0) {
     h->err = "ff_fused: token width 320 and inner % 64 == 0 only";
     return TFMQ_ERR_UNSUPPORTED;
@@ -437,7 +652,12 @@ extern "C" int tfmq_ff_fused(tfmq_handle h, const tfmq_ff_desc* dd, void* stream
   p.d = d;
   p.pad_table = h->pad_table;
   hipLaunchKernelGGL(k_ff_fold, dim3((d.inner + 255) / 256), dim3(256), 0, st, d);
-  hipLaunchKernelGGL((k_ff_fused<320>), dim3((d.M + 255) / 256), dim3(512), 0, st, p);
+  if (pre || post) hipLaunchKernelGGL(k_ff_fold_lin, dim3((d.C + 255) / 256, 2), dim3(256), 0, st, d);
+  const dim3 grid((d.M + 255) / 256);
+  if (pre && post) hipLaunchKernelGGL((k_ff_fused<320, true, true>), grid, dim3(512), 0, st, p);
+  else if (pre) hipLaunchKernelGGL((k_ff_fused<320, true, false>), grid, dim3(512), 0, st, p);
+  else if (post) hipLaunchKernelGGL((k_ff_fused<320, false, true>), grid, dim3(512), 0, st, p);
+  else hipLaunchKernelGGL((k_ff_fused<320, false, false>), grid, dim3(512), 0, st, p);
   TFMQ_LAUNCH_CHECK(h);
   return TFMQ_OK;
 }

@@ -355,9 +355,11 @@ class LdmUNetEngine(DdimUNetEngine):
                 and ops.attention_f16_ok(Cc // heads, T) and getattr(x, "_tfmq_stats", None) is not None and T % x._tfmq_stats[1] == 0
                 and L[tb + ".attn1.to_out.0"].kind == "w4a8" and not L[tb + ".attn1.to_out.0"].wide)
 
-    def _tblock_chained(self, sp, x_img, ctx, out_aq=None):
+    def _tblock_chained(self, sp, x_img, ctx, out_aq=None, final_ok=False):
         """_st's norm / proj_in and the transformer block of SpatialTransformer sp with the row chains (see _chain_ok).  Returns the block's
-        output tokens (fp16, or proj_out's int8 bins with out_aq) -- what _tblock returns -- bit-identical to the separate launches."""
+        output tokens (fp16, or proj_out's int8 bins with out_aq) -- what _tblock returns -- and False; or, with final_ok and proj_out fused
+        behind the feed-forward, the SpatialTransformer's OUTPUT image (proj_out + x_img, with its GroupNorm statistics) and True.
+        Bit-identical to the separate launches."""
         L = self.layers
         B, H, W, Cc = x_img.shape
         T, heads = H * W, self.cfg["num_heads"]
@@ -378,11 +380,33 @@ class LdmUNetEngine(DdimUNetEngine):
             x, q16 = mid[0][0].reshape(B, T, Cc), mid[1][0].reshape(B, T, Cc)
             if pend:      # the guidance pair parts here (norm2 / to_q saw the shared tensor: per-item arithmetic, same bits)
                 x, q16, self._pair_half = self._dup(x), self._dup(q16), False
+            to_out2, pout = L[p + ".attn2.to_out.0"], L[sp + ".proj_out"]
+            ff0, ff2 = L[p + ".ff.net.0.proj"], L[p + ".ff.net.2"]
+            gp = self.geglu_fused.get(p + ".ff.net.0.proj")
+            Bx = x.shape[0]
+            if (os.environ.get("TFMQ_FF_CHAIN", "1") != "0" and to_out2.kind == "w4a8" and not to_out2.wide and gp is not None and ff2.kind == "w4a8" and not ff2.wide
+                    and ops.ff_fused_ok(Cc, gp.cout // 2, gp, ff2.p) and (Bx * T) % 256 == 0 and to_out2.p.cout == Cc):
+                # round 4: attn2.to_out + residual, norm3, the feed-forward and (when the tokens feed nothing else) proj_out + the SpatialTransformer's
+                # input + the next GroupNorm's statistics as ONE launch (tfmq_ff_fused with the Linears in front / behind)
+                o2 = self._cross_core(p + ".attn2", q16, x, defer_out=True)
+                pre = dict(xq=o2.reshape(Bx, T, Cc), pw=to_out2.p, aq=to_out2.aq, residual=x)
+                post = None
+                if final_ok and pout.kind == "w4a8" and not pout.wide and self.fuse_q8 and pout.p.cout == Cc:
+                    xin = x_img if x_img.shape[0] == Bx else self._dup(x_img)
+                    post = dict(pw=pout.p, residual=xin.reshape(Bx, T, Cc), stats=True, hw=T)
+                _, y = ops.ff_fused(None, self.sd[p + ".norm3.weight"], self.sd[p + ".norm3.bias"], 1e-5, ff0.aq, gp, ff2.aq, ff2.p,
+                                    out_q8=pout.aq if (post is not None or out_aq is not None) else None, pre=pre, post=post)
+                if post is not None:
+                    y4 = y.reshape(Bx, H, W, Cc)
+                    if getattr(y, "_tfmq_stats", None) is not None:      # (the attribute lives on the tensor object, not on its views)
+                        y4._tfmq_stats = y._tfmq_stats
+                    return y4, True
+                return y, False
             x = self._cross_core(p + ".attn2", q16, x)
         else:
             x = self._tok(to_out, o, residual=h, **self._o16())
             x = self._tblock_after_attn1(p, x, ctx)
-        return self._ff(p, x, out_aq)
+        return self._ff(p, x, out_aq), False
 
     def _tblock(self, p, x, ctx, out_aq=None):
         L = self.layers
@@ -443,7 +467,9 @@ class LdmUNetEngine(DdimUNetEngine):
         pin, pout = L[p + ".proj_in"], L[p + ".proj_out"]
         if self._chain_ok(p, x, taps):
             fuse_q = pout.kind == "w4a8" and not pout.wide and self.fuse_q8
-            tok = self._tblock_chained(p, x, ctx, out_aq=pout.aq if fuse_q else None)
+            tok, final = self._tblock_chained(p, x, ctx, out_aq=pout.aq if fuse_q else None, final_ok=out_aq is None and self._h16)
+            if final:
+                return tok
             if tok.shape[0] != B:       # pair_prefix: the guidance pair parted inside this transformer; the residual is the shared tensor
                 x, B = self._dup(x), tok.shape[0]
             h = tok.reshape(B, H, W, -1) if tok.dtype == torch.int8 else self._quant_in(pout, tok.reshape(B, H, W, -1))

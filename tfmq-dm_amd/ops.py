@@ -1013,38 +1013,76 @@ def ff_fused_ok(C_: int, inner: int, pw1, pw2) -> bool:
             and pw1.kh == pw1.kw == pw2.kh == pw2.kw == 1)
 
 
-def ff_fused(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float, aq0: QSel, pw1: "PackedW4", aq2: QSel, pw2: "PackedW4",
-             out_q8: Optional[QSel] = None) -> torch.Tensor:
+def ff_fused(x: Optional[torch.Tensor], gamma: torch.Tensor, beta: torch.Tensor, eps: float, aq0: QSel, pw1: "PackedW4", aq2: QSel, pw2: "PackedW4",
+             out_q8: Optional[QSel] = None, pre: Optional[dict] = None, post: Optional[dict] = None):
     """x: fp16 [..., C] tokens of the fp16 activation stream.  ff.net.2(quant(value * gelu(gate))) + x with value | gate =
     ff.net.0.proj(quant(LayerNorm(x))) in one launch (tfmq_ff_fused; `x = self.ff(self.norm3(x)) + x`, ldm/modules/attention.py:37-64,
     152-215).  pw1: the GEGLU projection packed in ops.geglu_perm row order; pw2: ff.net.2.  Returns fp16 [..., C], or with out_q8 the
-    consumer quantizer's int8 bins.  Bit-identical to layernorm -> conv2d_w4a8(geglu_oq) -> conv2d_w4a8(residual=x)."""
-    d = _dev(x)
-    _chk(x, torch.float16, "x")
-    Cc = x.shape[-1]
+    consumer quantizer's int8 bins.  Bit-identical to layernorm -> conv2d_w4a8(geglu_oq) -> conv2d_w4a8(residual=x).
+    pre = {xq: int8 [..., C] bins, pw, aq, residual: fp16}: a C -> C Linear in front (attn2.to_out + residual): its fp16 output takes x's place
+    (x = None) and is returned as well.  post = {pw, residual: fp16, stats: bool}: a C -> C Linear behind (proj_out + residual) on the
+    feed-forward's bins under out_q8 (= that Linear's quantizer): returns its fp16 output (with `_tfmq_stats` when stats).  Both need
+    M % 256 == 0.  Returns y, or (y_pre, y) with pre."""
+    src = x if pre is None else pre["xq"]
+    d = _dev(src)
+    _chk(src, torch.float16 if pre is None else torch.int8, "x")
+    Cc = src.shape[-1]
     inner = pw1.cout // 2
     if not ff_fused_ok(Cc, inner, pw1, pw2):
         raise TfmqError("ff_fused: unsupported shape (token width 320, inner % 64 == 0, w4a8 Linears)")
-    M = x.numel() // Cc
-    y = _alloc(x.shape, dtype=torch.int8 if out_q8 is not None else torch.float16, device=x.device)
-    ws = _alloc(4 * inner, dtype=torch.float32, device=x.device)
+    M = src.numel() // Cc
+    if (pre is not None or post is not None) and M % 256:
+        raise TfmqError("ff_fused: pre / post need M % 256 == 0")
+    if post is not None and out_q8 is None:
+        raise TfmqError("ff_fused: post needs out_q8 (the Linear's activation quantizer)")
+    y = _alloc(src.shape, dtype=torch.int8 if (out_q8 is not None and post is None) else torch.float16, device=src.device)
+    ws = _alloc(4 * inner + 2560, dtype=torch.float32, device=src.device)
     dsc = FfDesc()
     dsc.M, dsc.C, dsc.inner = M, Cc, inner
-    dsc.x, dsc.gamma, dsc.beta, dsc.eps = x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), float(eps)
+    dsc.x = None if x is None else x.data_ptr()
+    dsc.gamma, dsc.beta, dsc.eps = gamma.data_ptr(), beta.data_ptr(), float(eps)
+    y_pre = None
+    if pre is not None:
+        pw0 = pre["pw"]
+        if pw0.w8 is None or pw0.cin != Cc or pw0.cout != Cc or pw0.kh != 1 or pw0.kw != 1:
+            raise TfmqError("ff_fused: pre is a C -> C w4a8 Linear")
+        _chk(pre["residual"], torch.float16, "pre residual")
+        y_pre = _alloc(src.shape, dtype=torch.float16, device=src.device)
+        dsc.xq_pre, dsc.w0, dsc.wmeta0, dsc.wscale0 = src.data_ptr(), pw0.w8.data_ptr(), pw0.wmeta.data_ptr(), pw0.wscale.data_ptr()
+        dsc.bias0 = None if pw0.bias is None else pw0.bias.data_ptr()
+        dsc.aq_pre, dsc.res_pre, dsc.y_pre = pre["aq"], pre["residual"].data_ptr(), y_pre.data_ptr()
+    if post is not None:
+        pw3 = post["pw"]
+        if pw3.w8 is None or pw3.cin != Cc or pw3.cout != Cc or pw3.kh != 1 or pw3.kw != 1:
+            raise TfmqError("ff_fused: post is a C -> C w4a8 Linear")
+        _chk(post["residual"], torch.float16, "post residual")
+        dsc.w3, dsc.wmeta3, dsc.wscale3 = pw3.w8.data_ptr(), pw3.wmeta.data_ptr(), pw3.wscale.data_ptr()
+        dsc.bias3 = None if pw3.bias is None else pw3.bias.data_ptr()
+        dsc.res_post, dsc.y_post = post["residual"].data_ptr(), y.data_ptr()
+        if post.get("stats"):
+            hw = int(post["hw"])
+            seg = stats_segment(hw)
+            if seg and 256 % seg == 0:
+                st = _alloc(M // seg, Cc, 2, dtype=torch.float32, device=src.device)
+                dsc.stats, dsc.stats_seg = st.data_ptr(), seg
+                y._tfmq_stats = (st, seg)
     dsc.aq0, dsc.aq2 = aq0, aq2
     dsc.w1, dsc.wmeta1, dsc.wscale1 = pw1.w8.data_ptr(), pw1.wmeta.data_ptr(), pw1.wscale.data_ptr()
     dsc.bias1 = None if pw1.bias is None else pw1.bias.data_ptr()
     dsc.w2, dsc.wmeta2, dsc.wscale2 = pw2.w8.data_ptr(), pw2.wmeta.data_ptr(), pw2.wscale.data_ptr()
     dsc.bias2 = None if pw2.bias is None else pw2.bias.data_ptr()
-    if out_q8 is not None:
+    if post is not None:
+        dsc.oq, dsc.yq, dsc.y = out_q8, None, None
+    elif out_q8 is not None:
         dsc.oq, dsc.yq, dsc.y = out_q8, y.data_ptr(), None
     else:
         dsc.oq, dsc.yq, dsc.y = QSel(None, None, 0, 0), None, y.data_ptr()
     dsc.ws = ws.data_ptr()
     h = handle(d)
+    ret = y if pre is None else (y_pre, y)
     if _conv_prof is None:
         h.call("ff_fused", C.byref(dsc), _stream(d))
-        return y
+        return ret
     e0, e1 = C.c_int(), C.c_int()
     h.call("event_create", C.byref(e0))
     h.call("event_create", C.byref(e1))
@@ -1052,9 +1090,11 @@ def ff_fused(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: floa
     h.call("ff_fused", C.byref(dsc), _stream(d))
     h.call("event_record", e1.value, _stream(d))
     # algorithmic bytes: the fp16 row in and out (or int8 out), both weight operands
-    _conv_prof.append((e0.value, e1.value, 2.0 * M * (2 * inner * Cc + inner * Cc), "w4a8",
-                       M * Cc * (2.0 + (1.0 if out_q8 is not None else 2.0)) + 3.0 * inner * Cc))
-    return y
+    nl = (pre is not None) + (post is not None)
+    _conv_prof.append((e0.value, e1.value, 2.0 * M * (2 * inner * Cc + inner * Cc + nl * Cc * Cc), "w4a8",
+                       M * Cc * (2.0 + (1.0 if (out_q8 is not None and post is None) else 2.0) + 3.0 * (pre is not None) + 2.0 * (post is not None))
+                       + 3.0 * inner * Cc + nl * Cc * Cc))
+    return ret
 
 
 def geglu(hin: torch.Tensor, aq: Optional[QSel] = None, want_f32: bool = False):
