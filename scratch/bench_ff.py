@@ -52,3 +52,25 @@ uf, yf = t(fused)
 nops = 2.0 * M * (2 * inner * C + inner * C)
 print(f"UNet batch {B} x {T} tokens, C {C}, inner {inner}, {'int8' if q8 else 'fp16'} out: three launches {uc:8.1f} us ({nops / uc / 1e6:6.0f} TOP/s)   "
       f"fused {uf:8.1f} us ({nops / uf / 1e6:6.0f} TOP/s)   {'bit-identical' if torch.equal(yc, yf) else 'MISMATCH'}", flush=True)
+
+# ---- the Linears in front of / behind the feed-forward in the same launch (attn2.to_out + residual; proj_out + x_in + statistics)
+if os.environ.get("CHAIN", "1") == "1":
+    w0 = (torch.randn(C, C, generator=g) * 0.08).to(dev)
+    w3 = (torch.randn(C, C, generator=g) * 0.08).to(dev)
+    q0, q3 = ops.minmax_to_qparam(ops.minmax(w0, C), 16), ops.minmax_to_qparam(ops.minmax(w3, C), 16)
+    pw0 = ops.pack_w4(w0, q0[:, 0].contiguous(), q0[:, 1].contiguous(), None, torch.zeros(C, device=dev))
+    pw3 = ops.pack_w4(w3, q3[:, 0].contiguous(), q3[:, 1].contiguous(), None, torch.zeros(C, device=dev))
+    o2 = torch.randint(-128, 128, (M, C), dtype=torch.int8, device=dev)
+    xin = (torch.randn(M, C, device=dev)).half()
+
+    def launches():
+        x2 = ops.conv2d_w4a8(o2.reshape(1, M, 1, C), pw0, so, residual=x16.reshape(1, M, 1, C), out_f16=True, want_stats=False).reshape(M, C)
+        b = ops.ff_fused(x2, gamma, beta, 1e-5, s0, pw1, s2, pw2, out_q8=so)
+        return ops.conv2d_w4a8(b.reshape(B, T, 1, C), pw3, so, residual=xin.reshape(B, T, 1, C), out_f16=True, want_stats=True).reshape(M, C)
+
+    def one():
+        return ops.ff_fused(None, gamma, beta, 1e-5, s0, pw1, s2, pw2, out_q8=so, pre=dict(xq=o2, pw=pw0, aq=so, residual=x16),
+                            post=dict(pw=pw3, residual=xin, stats=True, hw=T))[1]
+    ul, yl = t(launches)
+    uo, yo = t(one)
+    print(f"to_out + FF + proj_out: three launches {ul:8.1f} us   one launch {uo:8.1f} us   {'bit-identical' if torch.equal(yl, yo) else 'MISMATCH'}", flush=True)

@@ -249,3 +249,42 @@ def test_attention_d40_pipelined_kernel_is_deterministic(ops):
             o1, _ = ops.attention_f16(q, k, vt, heads, d ** -0.5)
             o2, _ = ops.attention_f16(qk[..., :C], qk[..., C:], vt, heads, d ** -0.5)
             assert torch.equal(o1, ref) and torch.equal(o2, ref)
+
+
+@pytest.mark.parametrize("B,heads,Tq,d", [(2, 8, 256, 40), (3, 8, 1024, 80), (1, 8, 128, 40), (2, 4, 384, 80)])
+def test_context_attention_all_heads_per_workgroup(ops, B, heads, Tq, d, monkeypatch):
+    monkeypatch.setenv("TFMQ_ATTN_CTX", "2")          # (d = 80 is only taken on request)
+    """Round 4, k_attention_ctx (csrc/attention_ctx.hip): cross attention over the 77 CLIP tokens (stored padded to 80 keys, padding
+    poisoned) with the int8 output of to_out's quantizer -- a workgroup keeps its 128 queries for all heads, one exact softmax over the
+    <= 96 keys.  Taken when only the int8 output is asked for; compared with the quantised fp32 reference and with k_attention_h's bins
+    (the same operand precision; the softmax denominator is summed differently): within one bin, a few per mille moved."""
+    gen = torch.Generator().manual_seed(d + Tq)
+    Tk, C = 77, heads * d
+    q = torch.randn(B, Tq, C, generator=gen)
+    k = torch.randn(B, Tk, C, generator=gen)
+    v = torch.randn(B, Tk, C, generator=gen)
+    scale = d ** -0.5
+    qh = q.half().float().reshape(B, Tq, heads, d).permute(0, 2, 1, 3)
+    kh = k.half().float().reshape(B, Tk, heads, d).permute(0, 2, 1, 3)
+    vh = v.half().float().reshape(B, Tk, heads, d).permute(0, 2, 1, 3)
+    ref = (torch.softmax(qh @ kh.transpose(-1, -2) * scale, -1) @ vh).permute(0, 2, 1, 3).reshape(B, Tq, C)
+    od, oz = O.minmax(ref, 256)
+    sel = ops.qsel(qtab(od, oz))
+    kp = torch.zeros(B, 80, C)
+    kp[:, :Tk] = k
+    kp[:, Tk:] = 50.0
+    vp = torch.zeros(B, 80, C)
+    vp[:, :Tk] = v
+    vp[:, Tk:] = 1e4
+    args = (q.half().to(DEV), kp.half().to(DEV), vp.transpose(1, 2).contiguous().half().to(DEV), heads, scale)
+    out_old, yq_old = ops.attention_f16(*args, sel, want_f32=True, n_keys=Tk)           # k_attention_h (fp32 + int8 outputs)
+    _, yq_new = ops.attention_f16(*args, sel, want_f32=False, n_keys=Tk)                # k_attention_ctx
+    assert yq_new.dtype == torch.int8 and yq_new.shape == (B, Tq, C)
+    assert maxnorm(out_old.cpu(), ref) <= 3e-3
+    d_old = (yq_new.int() - yq_old.int()).abs()
+    assert int(d_old.max()) <= 1 and float((d_old > 0).float().mean()) < 1e-2
+    bins = O.quant_index(ref, od, oz, 256)
+    d_ref = (yq_new.cpu().float() + 128 - bins).abs()
+    assert float(d_ref.max()) <= 1 and float((d_ref > 0).float().mean()) < 3e-2
+    _, again = ops.attention_f16(*args, sel, want_f32=False, n_keys=Tk)
+    assert torch.equal(again, yq_new)

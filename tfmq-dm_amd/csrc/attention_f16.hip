@@ -16,6 +16,9 @@
 typedef float v16f __attribute__((ext_vector_type(16)));
 typedef _Float16 v8h __attribute__((ext_vector_type(8)));
 
+int launch_attention_ctx(tfmq_handle h, const uint16_t* q, const uint16_t* k, const uint16_t* vt, int ldq, int ldk, int8_t* yq, tfmq_qsel aq, int B,
+                         int heads, int Tq, int Tk, int Tks, int d, float scale, void* stream, bool* taken);
+
 struct AttnHP {
   const __half *q, *k, *vt;
   int ldq, ldk;
@@ -791,6 +794,11 @@ extern "C" int tfmq_attention_f16(tfmq_handle h, const uint16_t* q, const uint16
   TFMQ_CHECK_ARG(h, !yq || aq.qtable, "attention_f16: quantised output needs a qparam");
   AttnHP p{reinterpret_cast<const __half*>(q), reinterpret_cast<const __half*>(k), reinterpret_cast<const __half*>(vt),
            ldq, ldk, out, ldo, yq, aq, B, heads, Tq, Tk, Tk_stride, d, scale, 1};
+  if (!out && yq) {       // a short context (cross attention over the 77 CLIP tokens) with int8 output: all heads per workgroup (attention_ctx.hip)
+    bool taken = false;
+    const int rc = launch_attention_ctx(h, q, k, vt, ldq, ldk, yq, aq, B, heads, Tq, Tk, Tk_stride, d, scale, stream, &taken);
+    if (taken) return rc;
+  }
   if (d <= 32) return launch_attn_h<2, 1>(h, p, stream);
   if (d == 40) {   // SD v1 at 64x64
     static const bool pipe = !(getenv("TFMQ_ATTN_PIPE") && atoi(getenv("TFMQ_ATTN_PIPE")) == 0);
