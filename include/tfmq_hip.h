@@ -301,7 +301,7 @@ typedef struct tfmq_ff_desc {
 /* TFMQ_ERR_UNSUPPORTED for a token width other than 320 (callers keep the three-launch chain). */
 int tfmq_ff_fused(tfmq_handle h, const tfmq_ff_desc* d, void* stream);
 
-/* ---- K5c (round 4): chains of w4a8 token Linears (K = C = 320) around the attention of a BasicTransformerBlock as one launch, a token
+/* ---- K5c (round 4): chains of w4a8 token Linears (K = C = 320 or 640) around the attention of a BasicTransformerBlock as one launch, a token
  * per lane (the layout of tfmq_ff_fused): an input stage, up to three GEMMs over the resident token tile, optionally ONE LayerNorm +
  * quantise between a C-wide GEMM and its successor.  Replaces, bit for bit,
  *   in_mode 2: tfmq_groupnorm_from_stats (apply pass) -> tfmq_conv2d_w4a8 (proj_in, fp16 out) -> tfmq_layernorm_h -> tfmq_conv2d_w4a8
@@ -327,9 +327,9 @@ typedef struct tfmq_chain_gemm {
                                     GEMM's quantizer produce the next GEMM's input */
 } tfmq_chain_gemm;
 typedef struct tfmq_chain_desc {
-  int32_t M, C, T;               /* tokens (multiple of 256), token width (320), tokens per image */
+  int32_t M, C, T;               /* tokens (multiple of 81920 / C), token width (320 or 640), tokens per image */
   int32_t in_mode;               /* 0: x = int8 bins [M][C] of g[0].aq.  2: x = fp16 [M][C]; y = gn_a[b][c] * x + gn_b[b][c] (the GroupNorm's
-                                    per-(image, channel) affine, e.g. from tfmq_gn_finalize), then g[0]'s quantizer; T % 256 == 0 */
+                                    per-(image, channel) affine, e.g. from tfmq_gn_finalize), then g[0]'s quantizer; T % (81920 / C) == 0 */
   const void* x;
   const float* gn_a;             /* [M / T][C] */
   const float* gn_b;
@@ -338,7 +338,7 @@ typedef struct tfmq_chain_desc {
   float ln_eps;
   int32_t n_gemm;                /* 1 .. 3 */
   tfmq_chain_gemm g[3];
-  float* ws;                     /* scratch: 4 * (sum of N) floats (per-column constants, rebuilt per call from the current Finite-Set row) */
+  float* ws;                     /* scratch: 4 * (sum of N) * (C / 320) floats (per-column constants, rebuilt per call from the current Finite-Set row) */
 } tfmq_chain_desc;
 int tfmq_row_chain(tfmq_handle h, const tfmq_chain_desc* d, void* stream);
 

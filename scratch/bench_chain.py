@@ -8,7 +8,8 @@ import torch
 import tfmq_dm_amd.ops as ops
 dev = torch.device("cuda", 0)
 B = int(os.environ.get("BATCH", "128"))
-C, T = 320, 4096
+C = int(os.environ.get("CH", "320"))
+T = 4096 * 320 * 320 // (C * C)       # 4096 tokens at C = 320, 1024 at C = 640
 M = B * T
 g = torch.Generator().manual_seed(0)
 

@@ -19,7 +19,6 @@ import tfmq_oracle as O
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
-C = 320
 
 
 @pytest.fixture(scope="module")
@@ -35,9 +34,11 @@ def _lin(ops, g, cout, cin, bias=True, scale=1.0):
     return ops.pack_w4(w.to(DEV), wd.to(DEV), wz.to(DEV), bias=None if b is None else b.to(DEV))
 
 
-@pytest.mark.parametrize("B,T", [(2, 256), (1, 4096), (3, 1024)])
-def test_pre_chain_equals_the_four_launches(ops, B, T):
-    g = torch.Generator().manual_seed(100 + T)
+@pytest.mark.parametrize("B,T,C", [(2, 256, 320), (1, 4096, 320), (3, 1024, 320), (2, 128, 640), (3, 1024, 640), (1, 256, 640)])
+def test_pre_chain_equals_the_four_launches(ops, B, T, C):
+    """C = 640 (the 32 x 32 level): two waves share a 32-token group -- one output tile each, half of K per phase, the LayerNorm's row
+    statistics cross the pair through LDS in k_layernorm_hs<16>'s summation order."""
+    g = torch.Generator().manual_seed(100 + T + C)
     # the stream tensor with its producer's GroupNorm statistics: the fp16 output of a w4a8 pointwise layer
     xin = torch.randn(B, T, 1, 64, generator=g)
     ad, az = O.minmax(xin, 256)
@@ -56,7 +57,7 @@ def test_pre_chain_equals_the_four_launches(ops, B, T):
     y16, vt = ops.conv2d_w4a8(hq.reshape(B, T, 1, C), qkv, sel[2], out_f16=True, t_col0=2 * C)
     # the chain
     ab = ops.gn_affine_from_stats(x, gn_g, gn_b, 1e-6)
-    assert ab is not None and ops.row_chain_ok(C, B * T, T, True)
+    assert ab is not None and ops.row_chain_supported(C, B * T, T, True)
     outs = ops.row_chain(x.reshape(B * T, C), T, [dict(pw=pin, aq=sel[1], ln=True), dict(pw=qkv, aq=sel[2], t_col0=2 * C)], gn=ab, ln=(ln_g, ln_b, 1e-5))
     assert torch.equal(outs[0][0], h.reshape(B * T, C))
     assert torch.equal(outs[1][0][:, :2 * C], y16.reshape(B * T, 3 * C)[:, :2 * C])
@@ -65,9 +66,9 @@ def test_pre_chain_equals_the_four_launches(ops, B, T):
     assert torch.equal(again[1][1], vt) and torch.equal(again[0][0], outs[0][0])
 
 
-@pytest.mark.parametrize("M", [256, 4096 * 2, 1024 * 3])
-def test_mid_chain_equals_the_three_launches(ops, M):
-    g = torch.Generator().manual_seed(7 + M)
+@pytest.mark.parametrize("M,C", [(256, 320), (4096 * 2, 320), (1024 * 3, 320), (128, 640), (1024 * 5, 640)])
+def test_mid_chain_equals_the_three_launches(ops, M, C):
+    g = torch.Generator().manual_seed(7 + M + C)
     qt = torch.tensor([[[0.04, 117.0], [0.033, 129.0]]], dtype=torch.float32, device=DEV)
     sel = [ops.qsel(qt, i) for i in range(2)]
     o = torch.randint(-128, 128, (M, C), generator=g, dtype=torch.int8).to(DEV)          # the attention kernel's output bins
@@ -84,6 +85,9 @@ def test_mid_chain_equals_the_three_launches(ops, M):
 
 def test_row_chain_refuses_what_it_cannot_take(ops):
     from tfmq_dm_amd._lib import TfmqError
-    assert not ops.row_chain_ok(C, 255, 255, False) and not ops.row_chain_ok(640, 1024, 1024, False) and not ops.row_chain_ok(C, 256, 64, True)
+    C = 320
+    assert not ops.row_chain_ok(C, 255, 255, False) and not ops.row_chain_ok(1280, 1024, 1024, False) and not ops.row_chain_ok(C, 256, 64, True)
+    assert ops.row_chain_supported(640, 128, 128, True) and not ops.row_chain_supported(640, 192, 192, False)
+    assert not ops.row_chain_ok(640, 128, 128, True)          # (the engine's policy: C = 640 measured not faster than the launches)
     with pytest.raises(TfmqError):
         ops.row_chain(torch.zeros(100, C, dtype=torch.int8, device=DEV), 100, [dict(pw=None, aq=None)])

@@ -940,11 +940,24 @@ def gn_affine_from_stats(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tenso
 
 def row_chain_ok(C_: int, M: int, T: int, gn_in: bool) -> bool:
     """Launches tfmq_row_chain takes (TFMQ_ROW_CHAIN=0: the separate launches, A/B runs)."""
-    return os.environ.get("TFMQ_ROW_CHAIN", "1") != "0" and C_ == 320 and M % 256 == 0 and (not gn_in or T % 256 == 0)
+    # C = 640 (two waves per 32-token group, half of K per phase): bit-identical and measured NOT faster than the launches at the 32 x 32
+    # level of SD (pre chain 575 vs 572 us, mid chain 368 vs 298 us at UNet batch 128: 1.6 MB of weights streamed per 128 tokens, ten-MFMA
+    # phases between barriers) -- off unless TFMQ_ROW_CHAIN_640=1
+    if os.environ.get("TFMQ_ROW_CHAIN", "1") == "0" or (C_ == 640 and os.environ.get("TFMQ_ROW_CHAIN_640", "0") != "1"):
+        return False
+    return row_chain_supported(C_, M, T, gn_in)
+
+
+def row_chain_supported(C_: int, M: int, T: int, gn_in: bool) -> bool:
+    """Shapes tfmq_row_chain takes (the policy -- which of them the engine uses -- is row_chain_ok)."""
+    if C_ not in (320, 640):
+        return False
+    bt = 81920 // C_             # tokens per workgroup: 256 (C = 320), 128 (C = 640: two waves per 32-token group)
+    return M % bt == 0 and (not gn_in or T % bt == 0)
 
 
 def row_chain(x: torch.Tensor, T: int, gemms, gn=None, ln=None):
-    """Token Linears (K = C = 320) chained over resident token tiles in ONE launch (tfmq_row_chain), a token per lane.
+    """Token Linears (K = C = 320 or 640) chained over resident token tiles in ONE launch (tfmq_row_chain), a token per lane.
     x: [M, C] int8 bins of gemms[0]'s quantizer, or -- with gn = (a, b) per-(image, channel) GroupNorm affine [M / T, C] -- fp16 rows.
     gemms: up to 3 dicts {pw: PackedW4, aq: QSel, residual: fp16 [M, N] | None, t_col0: int | None, ln: bool}; `ln` (one at most,
     on a C-wide GEMM that is not the last) puts LayerNorm(ln = (gamma, beta, eps)) + the next GEMM's quantizer between the two.
@@ -952,8 +965,8 @@ def row_chain(x: torch.Tensor, T: int, gemms, gn=None, ln=None):
     d = _dev(x)
     M, Cc = x.shape
     _chk(x, torch.float16 if gn is not None else torch.int8, "x")
-    if not row_chain_ok(Cc, M, T, gn is not None) or not 1 <= len(gemms) <= 3:
-        raise TfmqError("row_chain: unsupported shape (token width 320, M % 256 == 0, 1-3 GEMMs)")
+    if not row_chain_supported(Cc, M, T, gn is not None) or not 1 <= len(gemms) <= 3:
+        raise TfmqError("row_chain: unsupported shape (token width 320 / 640, M % (81920 / C) == 0, 1-3 GEMMs)")
     dsc = ChainDesc()
     dsc.M, dsc.C, dsc.T, dsc.in_mode = M, Cc, int(T), (2 if gn is not None else 0)
     dsc.x = x.data_ptr()
@@ -966,7 +979,7 @@ def row_chain(x: torch.Tensor, T: int, gemms, gn=None, ln=None):
     for i, gm in enumerate(gemms):
         pw = gm["pw"]
         if pw.w8 is None or pw.cin != Cc or pw.kh != 1 or pw.kw != 1 or pw.cout % 64:
-            raise TfmqError("row_chain: every GEMM is a w4a8 Linear with Cin = 320 and Cout % 64 == 0")
+            raise TfmqError("row_chain: every GEMM is a w4a8 Linear with Cin = C and Cout % 64 == 0")
         L = dsc.g[i]
         L.w, L.wmeta, L.wscale = pw.w8.data_ptr(), pw.wmeta.data_ptr(), pw.wscale.data_ptr()
         L.bias = None if pw.bias is None else pw.bias.data_ptr()
@@ -988,7 +1001,7 @@ def row_chain(x: torch.Tensor, T: int, gemms, gn=None, ln=None):
         ncol += pw.cout
         nops += 2.0 * M * pw.cout * Cc
         nbytes += 2.0 * M * pw.cout + pw.cout * Cc
-    ws = _alloc(4 * ncol, dtype=torch.float32, device=x.device)
+    ws = _alloc(4 * ncol * (Cc // 320), dtype=torch.float32, device=x.device)
     dsc.ws = ws.data_ptr()
     dsc._keep = keep
     h = handle(d)
