@@ -840,18 +840,20 @@ def main():
             tot_ops, tot_ms, n_launch, tot_bytes, n_fwd = conv_roofline(fwd, info["stream"])
         achieved = tot_ops / (tot_ms * 1e-3) / 1e12 if tot_ms > 0 else 0.0
         traffic, traffic_src = None, None
-        tname = next((f"r{r:02d}_traffic_{args.workload}.json" for r in (3, 2, 1)
+        tname = next((f"r{r:02d}_traffic_{args.workload}.json" for r in (4, 3, 2, 1)
                       if os.path.exists(os.path.join(ROOT, "profiles", f"r{r:02d}_traffic_{args.workload}.json"))), None)
         if tname is not None:
             tj = json.load(open(os.path.join(ROOT, "profiles", tname)))["kernels"]
             ks = [v for k, v in tj.items() if ("k_conv_dma<false" in k or "k_conv_igemm<true" in k or "k_conv3_slab" in k
-                                                or "k_lin_direct" in k)]
+                                                or "k_lin_direct" in k or "k_ff_fused" in k or "k_row_chain" in k)]
             if ks:
                 traffic = sum(v["hbm_bytes_per_launch"] * v["launches"] for v in ks) / sum(v["launches"] for v in ks)
                 traffic_src = (f"profiles/{tname} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, "
                                "separate passes, eager forwards of the same workload)")
         roof = {"bound": "mfma", "kernel": ("the w4a8 implicit-GEMM family: k_conv3_slab<WN> (3x3, activation slab staged once per channel chunk), "
-                                            "k_lin_direct<mode> (pointwise, register-direct epilogue), k_conv_dma<false,...> (tile kernels)"),
+                                            "k_lin_direct<mode> (pointwise, register-direct epilogue), k_conv_dma<false,...> (tile kernels), and the token-per-lane "
+                                            "launches of round 4 -- k_ff_fused (attn2.to_out + norm3 + GEGLU feed-forward + proj_out) and k_row_chain (the Linears "
+                                            "around the attentions), counted with the int8 ops of all their GEMMs"),
                 "achieved": round(achieved, 2), "peak": INT8_PEAK_TOPS, "unit": "TOP/s",
                 "frac": round(achieved / INT8_PEAK_TOPS, 4), "traffic": traffic, "traffic_unit": "bytes/launch (PMC)",
                 "traffic_source": traffic_src,
