@@ -384,7 +384,8 @@ class TransformerUnit(_Unit):
         # cross attention
         gwo2 = ops.gemm(d_x2, o2.reshape(B * T, Cc), trans_a=True)
         g_o2 = ops.gemm(d_x2, wo2).reshape(B, T, Cc)
-        dQ2, dK2, dV2 = self._attn_bwd(g_o2, q2, k2, v2, P2)
+        dQ2, dK2, dV2 = (self._attn_bwd(g_o2, q2, k2, v2, P2) if self.attn_q2 is None
+                         else self._attn_bwd_quant(g_o2, q2, k2, v2, P2, self.attn_q2, self.heads, grads))
         gwq2 = ops.gemm(dQ2.reshape(B * T, Cc), n2, trans_a=True)
         gwk2 = ops.gemm(dK2.reshape(B * L, Cc), c2d, trans_a=True)
         gwv2 = ops.gemm(dV2.reshape(B * L, Cc), c2d, trans_a=True)
@@ -394,7 +395,8 @@ class TransformerUnit(_Unit):
         # self attention
         gwo1 = ops.gemm(d_x1, o1.reshape(B * T, Cc), trans_a=True)
         g_o1 = ops.gemm(d_x1, wo1).reshape(B, T, Cc)
-        dQ1, dK1, dV1 = self._attn_bwd(g_o1, q1, k1, v1, P1)
+        dQ1, dK1, dV1 = (self._attn_bwd(g_o1, q1, k1, v1, P1) if self.attn_q1 is None
+                         else self._attn_bwd_quant(g_o1, q1, k1, v1, P1, self.attn_q1, self.heads, grads))
         gwq1 = ops.gemm(dQ1.reshape(B * T, Cc), n1, trans_a=True)
         gwk1 = ops.gemm(dK1.reshape(B * T, Cc), n1, trans_a=True)
         gwv1 = ops.gemm(dV1.reshape(B * T, Cc), n1, trans_a=True)
@@ -475,6 +477,47 @@ class _DeltaUnit:
 
     def q_bwd(self, i: int, x: torch.Tensor, g: torch.Tensor, want_gx: bool = True):
         return ops.fake_quant_bwd(x.contiguous(), g.contiguous(), self.delta[i:i + 1], self.zp[i:i + 1], self.levels[i], want_gx)
+
+    # ---- attention with LIVE matmul quantizers (aqtizer_q / _k / _v / _w of QuantAttnBlock, cross_attn_forward,
+    # reference quant/quant_block.py:226-243,483-500; trained through the `A` lists of reconstruction.py:145-163).  aq = indices of
+    # (q, k, v, w) in the unit's delta vector (w None: a 16-bit softmax quantizer is left out, as the reference does).  Functional path:
+    # fake-quantised operands, per-head strided fp32 GEMMs, row softmax, straight-through backward for every quantizer.
+    def _attn_fwd_quant(self, q, k, v, aq, heads: int):
+        B, T, Cc = q.shape
+        L, H = k.shape[1], heads
+        d = Cc // H
+        qh, kh, vh = self.q(aq[0], q).reshape(B, T, Cc), self.q(aq[1], k).reshape(B, L, Cc), self.q(aq[2], v).reshape(B, L, Cc)
+        S = torch.empty(B, H, T, L, dtype=torch.float32, device=q.device)
+        ops.gemm_strided(qh, 0, Cc, 1, T * Cc, kh, 0, 1, Cc, L * Cc, S, 0, L, H * T * L, T, L, d, B, hsa=d, hsb=d, hsc=T * L, heads=H)
+        P = ops.softmax_rows(S, float(d ** -0.5))
+        Ph = self.q(aq[3], P).reshape(B, H, T, L) if aq[3] is not None else P
+        o = torch.empty(B, T, Cc, dtype=torch.float32, device=q.device)
+        ops.gemm_strided(Ph, 0, L, 1, H * T * L, vh, 0, Cc, 1, L * Cc, o, 0, Cc, T * Cc, T, d, L, B, hsa=T * L, hsb=d, hsc=d, heads=H)
+        return o, ("quant", P, Ph, qh, kh, vh)
+
+    def _attn_bwd_quant(self, g_o, q, k, v, saved, aq, heads: int, grads):
+        """-> dQ, dK, dV w.r.t. the UN-quantised q, k, v; the four deltas' gradients are written into `grads`."""
+        _, P, Ph, qh, kh, vh = saved
+        B, T, Cc = q.shape
+        L, H = k.shape[1], heads
+        d = Cc // H
+        g_o = g_o.contiguous()
+        dVh, dKh, dQh = torch.empty_like(vh), torch.empty_like(kh), torch.empty_like(qh)
+        dPh = torch.empty_like(P)
+        ops.gemm_strided(Ph, 0, 1, L, H * T * L, g_o, 0, Cc, 1, T * Cc, dVh, 0, Cc, L * Cc, L, d, T, B, hsa=T * L, hsb=d, hsc=d, heads=H)
+        ops.gemm_strided(g_o, 0, Cc, 1, T * Cc, vh, 0, 1, Cc, L * Cc, dPh, 0, L, H * T * L, T, L, d, B, hsa=d, hsb=d, hsc=T * L, heads=H)
+        if aq[3] is not None:
+            dP, grads[aq[3]] = self.q_bwd(aq[3], P, dPh)
+            dP = dP.reshape(P.shape)
+        else:
+            dP = dPh
+        dS = ops.softmax_bwd_rows(P, dP.contiguous(), float(d ** -0.5))
+        ops.gemm_strided(dS, 0, L, 1, H * T * L, kh, 0, Cc, 1, L * Cc, dQh, 0, Cc, T * Cc, T, d, L, B, hsa=T * L, hsb=d, hsc=d, heads=H)
+        ops.gemm_strided(dS, 0, 1, L, H * T * L, qh, 0, Cc, 1, T * Cc, dKh, 0, Cc, L * Cc, L, d, T, B, hsa=T * L, hsb=d, hsc=d, heads=H)
+        dQ, grads[aq[0]] = self.q_bwd(aq[0], q, dQh)
+        dK, grads[aq[1]] = self.q_bwd(aq[1], k, dKh)
+        dV, grads[aq[2]] = self.q_bwd(aq[2], v, dVh)
+        return dQ.reshape(q.shape), dK.reshape(k.shape), dV.reshape(v.shape)
 
     def iterate(self, idx: torch.Tensor):
         import math
@@ -580,11 +623,14 @@ class DeltaAttnUnit(_DeltaUnit):
     """QuantAttnBlock under use_aq=True with the attention-matmul quantizers off (the state every driver leaves them in): the deltas
     of q, k, v (three quantizers on the same normalised input) and proj_out."""
 
-    def __init__(self, q: FixedLayer, k: FixedLayer, v: FixedLayer, po: FixedLayer, gn, x, y, **kw):
+    def __init__(self, q: FixedLayer, k: FixedLayer, v: FixedLayer, po: FixedLayer, gn, x, y, attn_q=None, **kw):
         super().__init__(**kw)
         self.ls, self.gn, self.x, self.y = (q, k, v, po), gn, x, y
+        self.attn_q = attn_q          # (iq, ik, iv, iw | None): the block's own matmul quantizers are live (use_aq set by hand)
 
     def _forward_backward(self, idx):
+        if self.attn_q is not None:
+            return self._forward_backward_quant(idx)
         ql, kl, vl, pl = self.ls
         x, y = self.x.index_select(0, idx), self.y.index_select(0, idx)
         B, H, W, Cc = x.shape
@@ -621,6 +667,38 @@ class DeltaAttnUnit(_DeltaUnit):
         return loss, grads
 
 
+    def _forward_backward_quant(self, idx):
+        """QuantAttnBlock.forward with use_aq (quant_block.py:483-500): q^, k^ quantised before the score product, v^ and the softmax
+        (zero point 0) before the second; one head of C channels, scale C^-1/2."""
+        ql, kl, vl, pl = self.ls
+        x, y = self.x.index_select(0, idx), self.y.index_select(0, idx)
+        B, H, W, Cc = x.shape
+        T = H * W
+        _, hn, _ = ops.groupnorm(x, self.gn[0], self.gn[1], 1e-6, False, want_f32=True)
+        hf = hn.reshape(B * T, Cc)
+
+        def lin(L, inp):
+            return ops.gemm(self.q(L.qi, inp) if L.qi is not None else inp, L.wg, trans_b=True, bias=L.bias)
+        q, k, v = (lin(L, hf).reshape(B, T, Cc) for L in (ql, kl, vl))
+        o, saved = self._attn_fwd_quant(q, k, v, self.attn_q, 1)
+        o = o.reshape(B * T, Cc)
+        oq = self.q(pl.qi, o) if pl.qi is not None else o
+        out = ops.gemm(oq, pl.wg, trans_b=True, bias=pl.bias, residual=x.reshape(B * T, Cc)).reshape(B, H, W, Cc)
+        loss, g = self._loss(out, y, B * T, idx)
+        grads = [None] * self.delta.numel()
+        g_oq = ops.gemm(g.reshape(B * T, Cc), pl.wg)
+        if pl.qi is not None:
+            g_o, grads[pl.qi] = self.q_bwd(pl.qi, o, g_oq)
+        else:
+            g_o = g_oq
+        dQ, dK, dV = self._attn_bwd_quant(g_o.reshape(B, T, Cc), q, k, v, saved, self.attn_q, 1, grads)
+        for L, dd in ((ql, dQ), (kl, dK), (vl, dV)):
+            if L.qi is not None:
+                g_in = ops.gemm(dd.reshape(B * T, Cc), L.wg)
+                _, grads[L.qi] = self.q_bwd(L.qi, hf, g_in, want_gx=False)
+        return loss, grads
+
+
 class DeltaTransformerUnit(_DeltaUnit):
     """QuantBasicTransformerBlock under use_aq=True with the attention-matmul quantizers off: the deltas of its ten QuantLayers
     (module order: attn1.{to_q,to_k,to_v,to_out.0}, ff.net.0.proj, ff.net.2, attn2.{to_q,to_k,to_v,to_out.0}); same dataflow and
@@ -630,11 +708,12 @@ class DeltaTransformerUnit(_DeltaUnit):
     _attn_bwd = TransformerUnit._attn_bwd
     use_flash = True
 
-    def __init__(self, layers: Sequence[FixedLayer], norms, heads: int, x, ctx, y, **kw):
+    def __init__(self, layers: Sequence[FixedLayer], norms, heads: int, x, ctx, y, attn_q1=None, attn_q2=None, **kw):
         super().__init__(**kw)
         assert len(layers) == 10
         self.ls, self.norms, self.heads = list(layers), norms, heads
         self.x, self.ctx, self.y = x, ctx, y
+        self.attn_q1, self.attn_q2 = attn_q1, attn_q2      # (iq, ik, iv, iw | None) of attn1 / attn2 when their use_aq was set by hand
 
     def _forward_backward(self, idx):
         (q1l, k1l, v1l, o1l, f0l, f2l, q2l, k2l, v2l, o2l) = self.ls
@@ -658,13 +737,13 @@ class DeltaTransformerUnit(_DeltaUnit):
         # ---- forward
         n1 = ops.layernorm(x, g1, b1, 1e-5, None)[1].reshape(B * T, Cc)
         q1, k1, v1 = (lin(Ly, n1).reshape(B, T, Cc) for Ly in (q1l, k1l, v1l))
-        o1, P1 = self._attn_fwd(q1, k1, v1)
+        o1, P1 = self._attn_fwd(q1, k1, v1) if self.attn_q1 is None else self._attn_fwd_quant(q1, k1, v1, self.attn_q1, self.heads)
         o1 = o1.reshape(B * T, Cc)
         x1 = lin(o1l, o1, residual=x2d)
         n2 = ops.layernorm(x1.reshape(B, T, Cc), g2, b2, 1e-5, None)[1].reshape(B * T, Cc)
         q2 = lin(q2l, n2).reshape(B, T, Cc)
         k2, v2 = lin(k2l, c2d).reshape(B, L, Cc), lin(v2l, c2d).reshape(B, L, Cc)
-        o2, P2 = self._attn_fwd(q2, k2, v2)
+        o2, P2 = self._attn_fwd(q2, k2, v2) if self.attn_q2 is None else self._attn_fwd_quant(q2, k2, v2, self.attn_q2, self.heads)
         o2 = o2.reshape(B * T, Cc)
         x2 = lin(o2l, o2, residual=x1)
         n3 = ops.layernorm(x2.reshape(B, T, Cc), g3, b3, 1e-5, None)[1].reshape(B * T, Cc)

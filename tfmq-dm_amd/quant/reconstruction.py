@@ -10,7 +10,7 @@ quantizers to hard rounding.
 from __future__ import annotations
 
 import logging
-from typing import Tuple
+from typing import Optional, Tuple
 
 import torch
 
@@ -73,6 +73,7 @@ class _DeltaSet:
 
     def __init__(self):
         self.layers, self.deltas, self.zps, self.levels = [], [], [], []
+        self.extra = []          # (index, attention-matmul quantizer)
 
     def fixed(self, layer: QuantLayer) -> R.FixedLayer:
         q, qi = layer.aqtizer, None
@@ -88,12 +89,38 @@ class _DeltaSet:
                 self.levels.append(q.level)
         return R.FixedLayer(_hard_weight(layer), None if layer.b is None else layer.b.data, qi)
 
+    def attn(self, owner) -> Optional[tuple]:
+        """The live attention-matmul quantizers of `owner` (a QuantAttnBlock, or attn1 / attn2 of a QuantBasicTransformerBlock whose
+        `use_aq` was set by hand) as trainable deltas -- the reference's `A` lists (reconstruction.py:145-163): aqtizer_q, _k, _v, and
+        aqtizer_w unless it is a 16-bit quantizer.  -> (iq, ik, iv, iw | None) indices into the unit's delta vector, or None."""
+        if not getattr(owner, "use_aq", False):
+            return None
+        idx = []
+        for r in "qkvw":
+            q = getattr(owner, f"aqtizer_{r}")
+            if r == "w" and q.level == 2 ** 16:
+                idx.append(None)
+                continue
+            if q.delta is None or not bool(q.delta != 0):
+                raise TfmqError("delta-learning reconstruction: an attention-matmul quantizer is live but uninitialised (run a forward with its use_aq set first)")
+            idx.append(len(self.deltas))
+            self.layers.append(None)
+            self.extra.append((len(self.deltas), q))
+            self.deltas.append(q.delta.data)
+            zp = q.zero_point
+            self.zps.append(zp.detach() if torch.is_tensor(zp) else torch.tensor(float(zp), device=q.delta.device))
+            self.levels.append(q.level)
+        return tuple(idx)
+
     def kw(self, iters, lr, multi_gpu):
         return dict(deltas=self.deltas, zps=self.zps, levels=self.levels, iters=iters, lr=lr, **_dist_kw(multi_gpu))
 
     def commit(self, unit: R._DeltaUnit):
         for i, layer in enumerate(self.layers):
-            layer.aqtizer.delta.data.copy_(unit.delta[i].reshape(layer.aqtizer.delta.shape))
+            if layer is not None:
+                layer.aqtizer.delta.data.copy_(unit.delta[i].reshape(layer.aqtizer.delta.shape))
+        for i, q in self.extra:
+            q.delta.data.copy_(unit.delta[i].reshape(q.delta.shape))
 
 
 def _quant_emb_projection(layer: QuantLayer, emb: torch.Tensor) -> torch.Tensor:
@@ -247,12 +274,9 @@ def block_reconstruction(model, block: BaseQuantBlock, cali_data: torch.Tensor, 
 
 def _block_delta_learning(model, block, cali_data, batch_size, iters, w, opt_mode, asym, b_range, warmup, lr, p, multi_gpu, keep_gpu):
     """block_reconstruction(use_aq=True) (reference :135-166): Adam(lr) + CosineAnnealingLR on the activation deltas of the block's
-    QuantLayers, weights fixed.  Built for QuantResnetBlock, QuantResBlock, QuantAttnBlock, QuantBasicTransformerBlock
-    with the attention-matmul quantizers off (the state every driver leaves them in); live attention quantizers raise NotImplementedError
-    (DESIGN.md section 7)."""
-    if getattr(block, "use_aq", False) or any(getattr(m, "delta", None) is not None for n, m in block.named_modules()
-                                                    if n.split(".")[-1] in ("aqtizer_q", "aqtizer_k", "aqtizer_v", "aqtizer_w")):
-        raise NotImplementedError("delta learning with live attention-matmul quantizers is not built (DESIGN.md section 7)")
+    QuantLayers, weights fixed.  Built for QuantResnetBlock, QuantResBlock, QuantAttnBlock, QuantBasicTransformerBlock; round 4: with the
+    attention-matmul quantizers live (use_aq of the attention set by hand -- no driver does) their deltas are trained too, the
+    reference's `A` lists (:145-163; fixture F25)."""
     loss_func = LossFunc(o=block, round_loss=RLOSS.NONE, w=w, max_count=iters, rec_loss=opt_mode, b_range=b_range,
                          decay_start=0.0, warmup=warmup, p=p)
     dev = next(block.parameters()).device
@@ -274,20 +298,22 @@ def _block_delta_learning(model, block, cali_data, batch_size, iters, w, opt_mod
     elif isinstance(block, QuantAttnBlock):
         fl = [ds.fixed(getattr(block, n)) for n in ("q", "k", "v", "proj_out")]
         cached_inputs, cached_outputs = save_inout(model, block, cali_data, asym, True, batch_size, keep_gpu)
+        aq_live = ds.attn(block)            # round 4: the block's own matmul quantizers (use_aq set by hand) join the trained deltas
         if not ds.layers:
             return
         unit = R.DeltaAttnUnit(fl[0], fl[1], fl[2], fl[3], (block.norm.weight.data.float(), block.norm.bias.data.float()),
-                               cached_inputs[0], cached_outputs, **ds.kw(iters, lr, multi_gpu))
+                               cached_inputs[0], cached_outputs, attn_q=aq_live, **ds.kw(iters, lr, multi_gpu))
     elif isinstance(block, QuantBasicTransformerBlock):
         mods = [block.attn1.to_q, block.attn1.to_k, block.attn1.to_v, block.attn1.to_out[0], block.ff.net[0].proj,
                 block.ff.net[2], block.attn2.to_q, block.attn2.to_k, block.attn2.to_v, block.attn2.to_out[0]]
         fl = [ds.fixed(m) for m in mods]
         cached_inputs, cached_outputs = save_inout(model, block, cali_data, asym, True, batch_size, keep_gpu)
+        a1, a2 = ds.attn(block.attn1), ds.attn(block.attn2)
         if not ds.layers:
             return
         x, ctx = cached_inputs
         norms = [(n.weight.data.float().contiguous(), n.bias.data.float().contiguous()) for n in (block.norm1, block.norm2, block.norm3)]
-        unit = R.DeltaTransformerUnit(fl, norms, block.attn1.heads, x, ctx, cached_outputs, **ds.kw(iters, lr, multi_gpu))
+        unit = R.DeltaTransformerUnit(fl, norms, block.attn1.heads, x, ctx, cached_outputs, attn_q1=a1, attn_q2=a2, **ds.kw(iters, lr, multi_gpu))
     else:
         raise NotImplementedError(f"delta-learning reconstruction of {type(block).__name__} is not built (DESIGN.md section 7)")
     _attach_fisher(unit, model, block, cali_data, opt_mode, asym, True, batch_size, keep_gpu)
