@@ -241,3 +241,107 @@ def test_delta_learning_matches_reference_run(golden, monkeypatch, kind, name, l
     ck1 = {str(k): v for k, v in zip([k for k in map(str, g8["act_keys"]) if k.endswith("delta")], T(g8["ck/act_1/delta"]))}
     for n in others:
         assert float(mods[n].aqtizer.delta) == float(ck1["model." + n + ".aqtizer.delta"]), n
+
+
+def _state_f25(golden, ldm):
+    """As _state, from fixture F25's initial tuple; then the unit's ATTENTION-MATMUL quantizers switched on by hand with the reference's
+    lazily initialised (delta, zero point, level) -- what F25's generator did through `use_aq = True` + one forward over the calibration set."""
+    from test_calibration_gpu import build
+    from test_quant_mirror_ldm import tiny_qnn
+    from quant.calibration import load_cali_model
+    g8, g = golden("f12_ldm_cali_tiny" if ldm else "f8_cali_tiny"), golden("f25_delta_learning_attention")
+    pre = "ldm/" if ldm else ""
+    ck = {"weight": {str(k): T(g8["ck/weight/" + str(k)]) for k in g8["weight_keys"]}}
+    akeys = [str(k) for k in g8["act_keys"]]
+    dk, zk = [k for k in akeys if k.endswith("delta")], [k for k in akeys if k.endswith("zero_point")]
+    for gi in range(3):
+        d, z = T(g8[f"ck/act_{gi}/delta"]), T(g8[f"ck/act_{gi}/zp"])
+        ck[f"act_{gi}"] = {**{k: d[i].clone() for i, k in enumerate(dk)}, **{k: z[i].clone() for i, k in enumerate(zk)}}
+    path = os.path.join(tempfile.mkdtemp(), "c.pth")
+    torch.save(ck, path)
+    qnn = tiny_qnn(g8, cali=False, device=DEV).to(DEV) if ldm else build(g8, cali=False)
+    init = (T(g[pre + "init_x"]), T(g[pre + "init_t"]).float()) + ((T(g[pre + "init_c"]),) if ldm else ())
+    load_cali_model(qnn, init, use_aq=True, path=path)
+    qnn.load_state_dict(ck["act_1"], strict=False)
+    return qnn, g8, g
+
+
+@pytest.mark.parametrize("name,ldm", [("down.1.attn.0", False), ("input_blocks.1.1.transformer_blocks.0", True)])
+def test_delta_learning_through_live_attention_quantizers(golden, monkeypatch, name, ldm):
+    """SURVEY section 8f-3, second half (round 4): block_reconstruction(use_aq=True) of a QuantAttnBlock / QuantBasicTransformerBlock whose
+    attention-matmul quantizers are LIVE -- the reference's `A` lists (quant/reconstruction.py:145-163) join the trained deltas.  Fixture
+    F25 = the reference's own run (tests/golden/gen_golden_r04.py).  DDPM AttnBlock: the whole 30-step trajectory of its 8 deltas and the
+    loss curve.  SD-style transformer block: Adam's first step (5e-4) is larger than attn1's softmax delta (2.3e-4), which turns NEGATIVE
+    in the reference -- every softmax bin clamps to 0, the attention output vanishes and the loss jumps from 0.159 to a 0.708 plateau; the
+    mirror must do exactly that (first loss, the jump, the plateau, the sign of that delta), and follow the other 17 deltas."""
+    import quant.reconstruction as REC
+    from quant.reconstruction_util import RLOSS
+    monkeypatch.setenv("TFMQ_RECON_GEMM", "f32")
+    monkeypatch.setenv("TFMQ_EXACT_FP", "1")
+    qnn, g8, g = _state_f25(golden, ldm)
+    mods = dict(qnn.model.named_modules())
+    unit = mods[name]
+    fname = ("ldm/" if ldm else "") + name
+    names = [str(n) for n in g[f"{fname}/names"]]
+    anames = [str(n) for n in g[f"{fname}/attn_names"]]
+    # switch the unit's attention quantizers on, with the reference's initial parameters
+    owners = [unit.attn1, unit.attn2] if ldm else [unit]
+    for o in owners:
+        o.use_aq = True
+    quantizers = {}
+    for an in anames:
+        q = unit
+        for part in an.split("."):
+            q = getattr(q, part)
+        q.delta = torch.nn.Parameter(T(g[f"{fname}/attn_q/{an}/delta"]).reshape(()).clone().to(DEV))
+        q.zero_point = torch.tensor(float(g[f"{fname}/attn_q/{an}/zp"]), device=DEV)
+        assert q.level == int(g[f"{fname}/attn_q/{an}/level"])
+        q.init = True
+        quantizers[name + "." + an] = q
+    if hasattr(qnn, "invalidate"):
+        qnn.invalidate()
+
+    def delta_of(n):
+        return (quantizers[n].delta if n in quantizers else mods[n].aqtizer.delta).detach().reshape(()).cpu()
+    before = torch.stack([delta_of(n) for n in names])
+    assert torch.equal(before, T(g[f"{fname}/before"]))
+    data = (T(g8["cali_x"]), T(g8["cali_t"])) + ((T(g8["cali_c"]),) if ldm else ())
+    iters = int(g["iters"])
+    trace = {"counts": tuple(range(1, iters + 1)), "rows": [], "unit": 0}
+    REC.LOSS_TRACE = trace
+    from tfmq_dm_amd.engine import recon as R
+    traj, orig_iterate = [], R._DeltaUnit.iterate
+
+    def rec_iterate(self, idx):
+        r = orig_iterate(self, idx)
+        traj.append(self.delta.detach().cpu().clone())
+        return r
+    monkeypatch.setattr(R._DeltaUnit, "iterate", rec_iterate)
+    torch.manual_seed(77)
+    np.random.seed(77)
+    try:
+        REC.block_reconstruction(qnn, unit, cali_data=data, batch_size=int(g["batch_size"]), iters=iters, w=0.01, opt_mode=RLOSS.MSE, asym=True,
+                                 warmup=0.2, use_aq=True, lr=float(g["lr"]), multi_gpu=False)
+    finally:
+        REC.LOSS_TRACE = None
+    after = torch.stack([delta_of(n) for n in names])
+    ref_after, ref_loss, ref_tr = T(g[f"{fname}/after"]), g[f"{fname}/loss"], T(g[f"{fname}/trajectory"])
+    loss = np.array([r[2] for r in trace["rows"]])
+    mine_tr = torch.stack(traj)
+    assert len(loss) == iters and mine_tr.shape == ref_tr.shape
+    # the unit's own delta order may differ from the optimiser's (layers, then the A list): compare by name through the committed values
+    print(f"[{name}] loss {loss[0]:.5f} -> {loss[-1]:.5f} (reference {ref_loss[0]:.5f} -> {ref_loss[-1]:.5f}); deltas after: {after.tolist()} (reference {ref_after.tolist()})")
+    travel = float(g["lr"]) * iters * 0.5
+    if not ldm:
+        assert np.max(np.abs(loss - ref_loss) / ref_loss) <= 0.02
+        assert float((after - ref_after).abs().max()) / travel <= 0.05, ((after - ref_after).abs() / travel).tolist()
+        assert not torch.equal(before[4:], after[4:])                    # the four attention deltas moved
+    else:
+        iw1 = names.index(name + ".attn1.aqtizer_w")
+        assert abs(loss[0] - ref_loss[0]) / ref_loss[0] <= 0.02          # the same starting loss
+        assert float(ref_after[iw1]) < 0 and float(after[iw1]) < 0       # Adam's first step takes attn1's softmax delta through zero, here as there
+        assert np.max(np.abs(loss[1:] - ref_loss[1:]) / ref_loss[1:]) <= 0.02      # ... and the loss sits on the reference's plateau from then on
+        others = [i for i in range(len(names)) if i != iw1]
+        dev = (after[others] - ref_after[others]).abs() / travel
+        print(f"[{name}] deviation / possible travel of the other 17 deltas: " + " ".join(f"{float(v):.3f}" for v in dev))
+        assert float(dev.max()) <= 0.15
