@@ -384,8 +384,7 @@ class TransformerUnit(_Unit):
         # cross attention
         gwo2 = ops.gemm(d_x2, o2.reshape(B * T, Cc), trans_a=True)
         g_o2 = ops.gemm(d_x2, wo2).reshape(B, T, Cc)
-        dQ2, dK2, dV2 = (self._attn_bwd(g_o2, q2, k2, v2, P2) if self.attn_q2 is None
-                         else self._attn_bwd_quant(g_o2, q2, k2, v2, P2, self.attn_q2, self.heads, grads))
+        dQ2, dK2, dV2 = self._attn_bwd(g_o2, q2, k2, v2, P2)
         gwq2 = ops.gemm(dQ2.reshape(B * T, Cc), n2, trans_a=True)
         gwk2 = ops.gemm(dK2.reshape(B * L, Cc), c2d, trans_a=True)
         gwv2 = ops.gemm(dV2.reshape(B * L, Cc), c2d, trans_a=True)
@@ -395,8 +394,7 @@ class TransformerUnit(_Unit):
         # self attention
         gwo1 = ops.gemm(d_x1, o1.reshape(B * T, Cc), trans_a=True)
         g_o1 = ops.gemm(d_x1, wo1).reshape(B, T, Cc)
-        dQ1, dK1, dV1 = (self._attn_bwd(g_o1, q1, k1, v1, P1) if self.attn_q1 is None
-                         else self._attn_bwd_quant(g_o1, q1, k1, v1, P1, self.attn_q1, self.heads, grads))
+        dQ1, dK1, dV1 = self._attn_bwd(g_o1, q1, k1, v1, P1)
         gwq1 = ops.gemm(dQ1.reshape(B * T, Cc), n1, trans_a=True)
         gwk1 = ops.gemm(dK1.reshape(B * T, Cc), n1, trans_a=True)
         gwv1 = ops.gemm(dV1.reshape(B * T, Cc), n1, trans_a=True)
@@ -759,14 +757,16 @@ class DeltaTransformerUnit(_DeltaUnit):
         d_x2 = ops.layernorm_bwd(x2.reshape(B, T, Cc), d_n3.reshape(B, T, Cc), g3, 1e-5).reshape(B * T, Cc)
         ops.axpy(d_x2, g_out, 1.0)
         g_o2 = back(o2l, o2, d_x2).reshape(B, T, Cc)
-        dQ2, dK2, dV2 = self._attn_bwd(g_o2, q2, k2, v2, P2)
+        dQ2, dK2, dV2 = (self._attn_bwd(g_o2, q2, k2, v2, P2) if self.attn_q2 is None
+                         else self._attn_bwd_quant(g_o2, q2, k2, v2, P2, self.attn_q2, self.heads, grads))
         d_n2 = back(q2l, n2, dQ2.reshape(B * T, Cc))
         back(k2l, c2d, dK2.reshape(B * L, Cc), want_gx=False)
         back(v2l, c2d, dV2.reshape(B * L, Cc), want_gx=False)
         d_x1 = ops.layernorm_bwd(x1.reshape(B, T, Cc), d_n2.reshape(B, T, Cc), g2, 1e-5).reshape(B * T, Cc)
         ops.axpy(d_x1, d_x2, 1.0)
         g_o1 = back(o1l, o1, d_x1).reshape(B, T, Cc)
-        dQ1, dK1, dV1 = self._attn_bwd(g_o1, q1, k1, v1, P1)
+        dQ1, dK1, dV1 = (self._attn_bwd(g_o1, q1, k1, v1, P1) if self.attn_q1 is None
+                         else self._attn_bwd_quant(g_o1, q1, k1, v1, P1, self.attn_q1, self.heads, grads))
         for Ly, dd in ((q1l, dQ1), (k1l, dK1), (v1l, dV1)):
             back(Ly, n1, dd.reshape(B * T, Cc), want_gx=False)
         return loss, grads
