@@ -413,6 +413,21 @@ int tfmq_attention_f16(tfmq_handle h, const uint16_t* q, const uint16_t* k, cons
                        float* out, int ldo, int8_t* yq, tfmq_qsel aq, int B, int heads, int Tq, int Tk, int Tk_stride,
                        int d, float scale, void* stream);
 
+/* ---- K10q8 (section 8f-3): the attention of a block whose matmul quantizers are LIVE (aqtizer_q / _k / _v / _w with use_aq:
+ * cross_attn_forward quant_block.py:226-243, QuantAttnBlock.forward :483-500, QuantQKMatMul / QuantSMVMatMul :318-323, :350-351), both
+ * products on the int8 matrix cores over the quantizers' BINS.  q / k: int8 bins - 128 of tfmq_quantize_act under aq_q / aq_k
+ * ([B][Tq][ldq], [B][Tk][ldk], head h at channels h*d ..); vt: the bins - 128 of v under aq_v TRANSPOSED, [B][heads*d][Tk_stride]
+ * (tfmq_transpose_i8; keys Tk .. Tk_stride zero).  sum (b_q - z_q)(b_k - z_k) and sum b_w (b_v - z_v) are exact int32 (zero points as
+ * rank-one corrections); the softmax in fp32 over delta_q delta_k scale * (integer score), two passes over the keys (the bins need the
+ * row's final normaliser); b_w = clamp(rint(p / delta_w), 0, w_level - 1) (the always-zero quantizer: zero point 0), w_level <= 256;
+ * out = delta_w delta_v * (integer sum), fp32 [B][Tq][ldo].  d % 8 == 0, d <= 160, ldq / ldk / Tk_stride % 8 == 0, ldo % 4 == 0.
+ * Against the fp32 products of the dequantised values (ops.attention_quant) only values on a rounding boundary of aq_w differ. */
+int tfmq_attention_q8(tfmq_handle h, const int8_t* q, const int8_t* k, const int8_t* vt, int ldq, int ldk, tfmq_qsel aq_q, tfmq_qsel aq_k,
+                      tfmq_qsel aq_v, tfmq_qsel aq_w, int w_level, float* out, int ldo, int B, int heads, int Tq, int Tk, int Tk_stride,
+                      int d, float scale, void* stream);
+/* y[b][c][t] = x[b][t][c] (int8), t < T; zero for T <= t < Tp: the V^T operand of tfmq_attention_q8 */
+int tfmq_transpose_i8(tfmq_handle h, const int8_t* x, int8_t* y, int B, int T, int C, int Tp, void* stream);
+
 /* ---- K15: exact-fp32 fused attention for the reconstruction of BasicTransformerBlock units (quant/reconstruction.py:
  * 86-209 on quant_block.py:248-299; the reference runs einsum / softmax / einsum under autograd).  fp32 operands on
  * the fp32 matrix cores, nothing of size Tq x Tk is written: the forward returns O and the per-row log-sum-exp in the

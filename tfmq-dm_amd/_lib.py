@@ -131,6 +131,9 @@ _SIGS = {
     "tfmq_attention": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p, QSel,
                                c_int, c_int, c_int, c_int, c_int, c_float, c_void_p]),
     "tfmq_attention_f16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, QSel, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p]),
+    "tfmq_attention_q8": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, QSel, QSel, QSel, QSel, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+                                  c_float, c_void_p]),
+    "tfmq_transpose_i8": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "tfmq_ddim_update": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p]),
     "tfmq_dpm_x0": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_float, c_void_p, c_size_t, c_void_p]),
     "tfmq_dpm_update": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_float, c_float, c_float, c_float, c_void_p, c_size_t, c_void_p]),

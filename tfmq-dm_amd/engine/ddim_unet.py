@@ -484,6 +484,10 @@ class DdimUNetEngine:
         if self.calib is not None:
             def obs(which, t):
                 self._observe(sel[which], t, level=cfg["w_level"] if which == "w" else 256, always_zero=which == "w")
+        if obs is None and os.environ.get("TFMQ_ATTN_Q8", "0") == "1" and ops.attention_q8_ok(q.shape[-1] // heads, cfg["w_level"]) and _tape() is None:
+            # both products on the int8 matrix cores over the quantizers' bins (tfmq_attention_q8); off by default: ops.attention_quant's fp32
+            # products of the dequantised values are what the fixtures (F21) were pinned with
+            return ops.attention_q8(q, k, v, heads, scale, sel["q"], sel["k"], sel["v"], sel["w"], cfg["w_level"], pre)
         return ops.attention_quant(q, k, v, heads, scale, sel["q"], sel["k"], sel["v"], sel["w"], cfg["w_level"], pre, obs)
 
     def _attention_exact(self, q, k, v, heads: int, scale: float, aq):

@@ -214,6 +214,41 @@ def attention_quant(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: in
     return out
 
 
+def attention_q8_ok(d: int, w_level: int) -> bool:
+    """tfmq_attention_q8's envelope (include/tfmq_hip.h): head dim a multiple of 8 up to 160, a softmax quantizer of at most 8 bits."""
+    return d % 8 == 0 and d <= 160 and 2 <= w_level <= 256
+
+
+def attention_q8(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int, scale: float, sel_q: QSel, sel_k: QSel, sel_v: QSel,
+                 sel_w: QSel, w_level: int = 256, pre: float = 1.0) -> torch.Tensor:
+    """attention_quant on the int8 matrix cores (tfmq_attention_q8, csrc/attention_q8.hip): q, k, v -> their quantizers' bins
+    (tfmq_quantize_act), v's transposed, both products as exact int32 sums of (bin - zero point) pairs, softmax bins from an fp32 two-pass
+    softmax over the integer scores.  Same quantizers, same reference lines as attention_quant (quant_block.py:226-243, 318-323, 350-351,
+    487-498); results differ from it only where a softmax value sits on a rounding boundary (tests/test_attention_q8_gpu.py)."""
+    B, Tq, C = q.shape
+    Tk, d_ = k.shape[1], C // heads
+    dv = _dev(q)
+    if not attention_q8_ok(d_, w_level):
+        raise TfmqError(f"attention_q8: head dim {d_} / softmax levels {w_level} outside the kernel's envelope (ops.attention_quant takes them)")
+
+    def bins(x, sel):
+        x = x.contiguous()
+        if pre != 1.0 and sel is not sel_v:
+            xs = _alloc_like(x)
+            xs.zero_()
+            axpy(xs, x, pre)
+            x = xs
+        return quantize_act(x, sel)
+    qb, kb, vb = bins(q, sel_q), bins(k, sel_k), bins(v, sel_v)
+    Tks = (Tk + 7) // 8 * 8
+    vt = _alloc(B, C, Tks, dtype=torch.int8, device=q.device)
+    handle(dv).call("transpose_i8", _p(vb), _p(vt), B, Tk, C, Tks, _stream(dv))
+    out = _alloc(B, Tq, C, dtype=torch.float32, device=q.device)
+    handle(dv).call("attention_q8", _p(qb), _p(kb), _p(vt), C, C, sel_q, sel_k, sel_v, sel_w, int(w_level), _p(out), C, B, heads, Tq, Tk, Tks, d_,
+                    float(scale), _stream(dv))
+    return out
+
+
 def bins_to_grid(xq: torch.Tensor, qs: QSel, half: bool = True) -> torch.Tensor:
     """int8 activation bins (quantize_act) -> (b - z_a) on their integer grid, fp16 (exact: |b - z_a| <= 255) or fp32: the
     activation operand of a W8A8 layer on the fp16-operand kernels (include/tfmq_hip.h: tfmq_bins_to_grid)."""
