@@ -541,11 +541,41 @@ def run_cali_workload(args, dev, rank, local_rank, world, log):
     m = m.to(dev)
     wq = {"bits": 4, "channel_wise": True, "scaler": Scaler.MINMAX}
     aq = {"bits": 8, "channel_wise": False, "scaler": Scaler.MINMAX, "leaf_param": True}
-    xs = torch.randn(G * N, 4, 64, 64, generator=g)
-    ts = torch.cat([torch.full((N,), float(t)) for t in np.linspace(981, 1, G).astype(int)])
-    cs = torch.randn(G * N, 77, 768, generator=g)
     path = os.path.join(tempfile.mkdtemp(), "sd_w4a8.pth")
     acc, calls = collections.defaultdict(float), collections.Counter()
+    qnn, gen_note = None, "calibration set: synthetic normal latents / contexts at fixed timesteps"
+    if getattr(args, "cali_generate", False):
+        # The set as the reference's driver makes it (txt2img.py:421-487 -> quant/data_generate.py:13-49, generate_cali_text_guided_data): for every
+        # c-th of the T = 50 sampler steps and every prompt, CFG-7.5 sampling with the FULL-PRECISION model from fresh noise until that step;
+        # (x_t, t, c) and (x_t, t, uc) both enter.  The text encoder is outside this package: a fixed table of random embeddings stands in.
+        if world > 1:
+            raise SystemExit("--cali-generate: single-GPU job (the reference generates the set before it spawns the workers)")
+        from tfmq_dm_amd.ldm.ddpm import LatentDiffusion
+        from tfmq_dm_amd.ldm.ddim import DDIMSampler
+        from quant.quant_model import QuantModel
+        from quant.data_generate import generate_cali_text_guided_data
+        T_, c_ = 50, 50 // G
+        if 50 // c_ != G or N % 2:
+            raise SystemExit(f"--cali-generate: {G} groups do not divide the 50 sampler steps evenly / odd group size {N}")
+        qnn = QuantModel(m, wq, aq, cali=True, aq_mode=[QMODE.NORMAL.value, QMODE.QDIFF.value]).eval()
+        qnn.set_quant_state(False, False)
+        ld = LatentDiffusion(qnn, conditioning_key="crossattn").to(dev)
+        table = {}
+        ld.get_learned_conditioning = lambda prompts: torch.stack([table.setdefault(p_, torch.randn(77, 768, generator=g)) for p_ in prompts]).to(dev)
+        torch.cuda.synchronize()
+        tg = time.perf_counter()
+        xs, ts, cs = generate_cali_text_guided_data(ld, DDIMSampler(ld), T_, c_, 1, tuple(f"prompt {i}" for i in range(N // 2)), [4, 64, 64])
+        torch.cuda.synchronize()
+        acc["generate_cali_text_guided_data"] = time.perf_counter() - tg
+        xs, ts, cs = xs.float().cpu(), ts.float().cpu(), cs.float().cpu()
+        assert xs.shape[0] == G * N, (xs.shape, G, N)
+        gen_note = (f"calibration set GENERATED inside the timed run (generate_cali_text_guided_data: DDIM-50, CFG 7.5, full-precision UNet, {N // 2} prompts "
+                    f"x every {c_}th step; random text embeddings stand in for the text encoder)")
+        del ld
+    else:
+        xs = torch.randn(G * N, 4, 64, 64, generator=g)
+        ts = torch.cat([torch.full((N,), float(t)) for t in np.linspace(981, 1, G).astype(int)])
+        cs = torch.randn(G * N, 77, 768, generator=g)
 
     def timed(mod, name):
         f = getattr(mod, name)
@@ -578,12 +608,14 @@ def run_cali_workload(args, dev, rank, local_rank, world, log):
                             (xs, ts, cs), (xs, ts, cs), N, True, kw)
     else:
         from quant.quant_model import QuantModel
-        qnn = QuantModel(m, wq, aq, cali=True, aq_mode=[QMODE.NORMAL.value, QMODE.QDIFF.value]).eval()
+        if qnn is None:
+            qnn = QuantModel(m, wq, aq, cali=True, aq_mode=[QMODE.NORMAL.value, QMODE.QDIFF.value]).eval()
         md = QC.cali_model(qnn, (xs, ts, cs), (xs, ts, cs), use_aq=True, path=path, running_stat=True, interval=N, multi_gpu=False, **kw)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
-    dt = time.perf_counter() - t0
+    dt = time.perf_counter() - t0 + acc.get("generate_cali_text_guided_data", 0.0)
+    QC.ONLY_UNITS = None
     if world > 1:
         tt = torch.tensor([dt], device="cpu" if ONE_DEVICE else dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -603,13 +635,14 @@ def run_cali_workload(args, dev, rank, local_rank, world, log):
         + " + int8/f16 (capture forwards)", "data": "synthetic",
         "config": {"workload": (f"cali_model{'_multi' if world > 1 else ''} on the SD v1-4 UNet (859.5M, random init): {G} timestep groups x {N} "
                                 f"samples, {ITERS} AdaRound iterations per unit at mini-batch 8/rank (the recipe: 25 groups x 512, 20000), "
-                                "w4 channel-wise + a8 Finite-Set, running_stat"
+                                "w4 channel-wise + a8 Finite-Set, running_stat; " + gen_note
                                 + (f"; reconstruction restricted to the units under {args.cali_only}" if args.cali_only else "")),
                    "parallelism": "single GPU" if world == 1 else f"timestep-group shards x{world}, one RCCL SUM all-reduce per iteration"},
         "finite": finite,
         "calibration": {"measured": True, "wall_clock_s": round(dt, 2), "reconstruction_units": n_units,
                         "iterations_per_unit": ITERS, "adaround_iterations_per_s": round(n_units * ITERS / max(rec_s, 1e-9), 1),
-                        "phases_s": {"tib_reconstruction": round(acc["tib_reconstruction"], 2),
+                        "phases_s": {**({"generate_cali_text_guided_data": round(acc["generate_cali_text_guided_data"], 2)} if "generate_cali_text_guided_data" in acc else {}),
+                                     "tib_reconstruction": round(acc["tib_reconstruction"], 2),
                                      "block_reconstruction (incl. input/target capture)": round(acc["block_reconstruction"], 2),
                                      "layer_reconstruction (incl. capture)": round(acc["layer_reconstruction"], 2),
                                      "finite_set_activation_calibration": round(acc["_calibrate_activations"], 2)},
@@ -721,6 +754,8 @@ def main():
     ap.add_argument("--cali-iters", type=int, default=100, help="--workload cali: AdaRound iterations per unit (recipe: 20000)")
     ap.add_argument("--cali-samples", type=int, default=32, help="--workload cali: samples per timestep group (recipe: 512)")
     ap.add_argument("--cali-groups", type=int, default=2, help="--workload cali: timestep groups (recipe: 25)")
+    ap.add_argument("--cali-generate", action="store_true", help="--workload cali: build the calibration set with generate_cali_text_guided_data (FP sampling) "
+                    "inside the timed run instead of drawing synthetic latents")
     ap.add_argument("--cali-only", default="", help="--workload cali: comma-separated unit-name prefixes (e.g. model.middle_block,model.input_blocks.10); "
                     "only these reconstruction units run (at --cali-iters), the others keep nearest rounding -- for measuring a resolution level at the recipe's length")
     ap.add_argument("--batch", type=int, default=0, help="images per GPU (default 64 for sd, 256 for cifar)")
@@ -871,6 +906,17 @@ def main():
             cali = {"sharded": sharded}
         if world == 1 and args.workload == "sd" and not args.no_cpu_baseline:
             cali.update(calibration_sample(dev))
+            # LIVE slice of the calibration job itself, timed inside this run: cali_model end to end on the SD UNet -- calibration-set generation
+            # (FP DDIM sampling), weight-scale search, the reconstruction units under two prefixes (a ResBlock, a SpatialTransformer with its
+            # BasicTransformerBlock, the middle attention) with input / target capture, Finite-Set activation calibration, checkpoint.
+            # The full-length runs below are RECORDED (run once with `--workload cali`, committed under profiles/).
+            try:
+                lj = run_cali_workload(argparse.Namespace(cali_samples=16, cali_groups=2, cali_iters=int(os.environ.get("TFMQ_BENCH_LIVE_CALI_ITERS", "500")),
+                                                          cali_only="model.input_blocks.1,model.middle_block.1", cali_generate=True), dev, 0, 0, 1, log)
+                cali["live_slice"] = {"live": True, "workload": lj["config"]["workload"], "finite": lj["finite"], **lj["calibration"]}
+            except Exception as e:          # the slice must not take the sampling line down
+                cali["live_slice"] = {"live": True, "error": repr(e)}
+            torch.cuda.empty_cache()
             cali["first_stage_decode"] = first_stage_sample(dev)
             cali["plms"] = info["plms"]()
             # SD calibration at the recipe's iteration count, run once with this code by `bench.py --workload cali --cali-iters 20000`
