@@ -214,7 +214,29 @@ def _rccl_world2_worker(rank, world, port, out_dir):
         for (_, _, e0, e1) in cuts:
             link.allreduce(flat[e0:e1])
     side.synchronize()
-    torch.save({"sum": buf.cpu(), "chunked": flat.cpu(), "info": (r.value, w.value), "comm_dev": link.comm_device()},
+    # a reconstruction unit's own iterations over RCCL: engine.recon's chunked side-stream exchange (two pieces), each rank on its own shard
+    # of the cached inputs; the all-reduced gradients make every rank take the same Adam steps
+    import tfmq_dm_amd.ops as ops
+    os.environ["TFMQ_EXCHANGE_CHUNKS"] = "2"
+    gw = torch.Generator().manual_seed(5)                   # the same weights on every rank
+
+    def ada(cout, cin, k):
+        wgt = (torch.randn(cout, cin, k, k, generator=gw) * 0.05).to(dev)
+        qp = ops.minmax_to_qparam(ops.minmax(wgt.reshape(cout, -1).contiguous(), cout), 16)
+        return R.AdaLayer(wgt, qp[:, 0].contiguous(), qp[:, 1].contiguous(), torch.zeros(cout, device=dev))
+    c1, c2 = ada(32, 32, 3), ada(32, 32, 3)
+    gd = torch.Generator().manual_seed(200 + rank)          # a different data shard per rank
+    x, y = torch.randn(4, 8, 8, 32, generator=gd).to(dev), torch.randn(4, 8, 8, 32, generator=gd).to(dev)
+    gn = (torch.ones(32, device=dev), torch.zeros(32, device=dev))
+    unit = R.ResnetUnit(c1, c2, gn, gn, None, x, torch.randn(4, 32, generator=gd).to(dev), y, eps=1e-5, iters=20, world_size=world,
+                        allreduce=link.allreduce)
+    a0 = [l.alpha.clone() for l in (c1, c2)]
+    idx = torch.arange(4, device=dev)
+    for _ in range(5):
+        unit.iterate(idx)
+    torch.cuda.synchronize(rank)
+    torch.save({"sum": buf.cpu(), "chunked": flat.cpu(), "info": (r.value, w.value), "comm_dev": link.comm_device(),
+                "alpha": [l.alpha.cpu() for l in (c1, c2)], "alpha0": [a.cpu() for a in a0], "cuts": len(unit._cuts)},
                os.path.join(out_dir, f"rccl{rank}.pt"))
     link.barrier()
     link.destroy_comm()
@@ -233,6 +255,10 @@ def test_rccl_c_abi_world2_allreduce_when_two_gpus():
     for r in range(world):
         assert res[r]["info"] == (r, world) and res[r]["comm_dev"] == r
         assert torch.equal(res[r]["sum"], ref) and torch.equal(res[r]["chunked"], ref)      # two addends: one rounding, order-free
+        assert res[r]["cuts"] == 2
+        for a_, a0_, b_ in zip(res[r]["alpha"], res[r]["alpha0"], res[0]["alpha"]):
+            assert torch.isfinite(a_).all() and not torch.equal(a_, a0_)                    # the unit trained ...
+            assert torch.equal(a_, b_)                                                      # ... and every rank took the same steps
 
 
 def test_side_stream_exchange_equals_in_stream_exchange(monkeypatch):

@@ -180,13 +180,25 @@ def _state(golden, ldm=False):
     return qnn, g8, g
 
 
-@pytest.mark.parametrize("kind,name,ldm", [("layer", "up.1.upsample.conv", False), ("block", "down.1.block.0", False), ("block", "down.1.attn.0", False),
-                                           ("block", "input_blocks.1.0", True), ("block", "input_blocks.1.1.transformer_blocks.0", True)])
-def test_delta_learning_matches_reference_run(golden, monkeypatch, kind, name, ldm):
+# mode "f32": exact fp32 GEMM operands, the bars the fixture was pinned with.  mode "default": whatever TFMQ_RECON_GEMM defaults to (split-bf16
+# operands, 2^-16 per product) -- the SHIPPED configuration against the same reference run, with its own stated bars.
+_BARS = {"f32": (0.02, 0.08, 0.02), "default": (0.03, 0.12, 0.05)}
+
+
+@pytest.mark.parametrize("kind,name,ldm,mode", [("layer", "up.1.upsample.conv", False, "f32"), ("block", "down.1.block.0", False, "f32"),
+                                                ("block", "down.1.attn.0", False, "f32"), ("block", "input_blocks.1.0", True, "f32"),
+                                                ("block", "input_blocks.1.1.transformer_blocks.0", True, "f32"),
+                                                ("block", "down.1.block.0", False, "default"), ("block", "down.1.attn.0", False, "default"),
+                                                ("block", "input_blocks.1.1.transformer_blocks.0", True, "default")])
+def test_delta_learning_matches_reference_run(golden, monkeypatch, kind, name, ldm, mode):
     import quant.reconstruction as REC
     from quant.quant_layer import QuantLayer
     from quant.reconstruction_util import RLOSS
-    monkeypatch.setenv("TFMQ_RECON_GEMM", "f32")
+    if mode == "f32":
+        monkeypatch.setenv("TFMQ_RECON_GEMM", "f32")
+    else:
+        monkeypatch.delenv("TFMQ_RECON_GEMM", raising=False)
+    bar_loss, bar_traj, bar_end = _BARS[mode]
     if os.environ.get("DELTA_TEST_EXACT", "1") == "1":
         monkeypatch.setenv("TFMQ_EXACT_FP", "1")      # unit inputs captured with fp32 operands upstream, as the reference captures them
     qnn, g8, g = _state(golden, ldm)
@@ -221,21 +233,21 @@ def test_delta_learning_matches_reference_run(golden, monkeypatch, kind, name, l
     loss = np.array([r[2] for r in trace["rows"]])
     moved = (ref_after - before).abs()
     err = (after - ref_after).abs()
-    print(f"[{name}] deltas {before.tolist()} -> {after.tolist()} (reference {ref_after.tolist()}); loss {loss[0]:.5f} -> {loss[-1]:.5f} "
+    print(f"[{name}, GEMM operands {mode}] deltas {before.tolist()} -> {after.tolist()} (reference {ref_after.tolist()}); loss {loss[0]:.5f} -> {loss[-1]:.5f} "
           f"(reference {ref_loss[0]:.5f} -> {ref_loss[-1]:.5f}); worst loss deviation {np.max(np.abs(loss - ref_loss) / ref_loss):.2%}")
     assert len(loss) == iters
     # full-set batches: a deterministic gradient per iteration.  The loss curve agrees to the capture's precision, every delta that moved by
     # more than a tenth of the unit's largest move went the reference's way and ended within 15 % of the distance it travelled, the
     # rest (gradients that hover around zero: Adam on a scalar turns their sign into full steps) within 15 % of the largest move.
-    assert np.max(np.abs(loss - ref_loss) / ref_loss) <= 0.02
+    assert np.max(np.abs(loss - ref_loss) / ref_loss) <= bar_loss
     mine_tr, ref_tr = torch.stack(traj), T(g[f"{fname}/trajectory"])
     assert mine_tr.shape == ref_tr.shape and torch.equal(mine_tr[-1], after)
     travel = float(g["lr"]) * iters * 0.5                     # what Adam + cosine annealing can move a scalar in `iters` steps
     dev_t = (mine_tr - ref_tr).abs().max(dim=1).values / travel
     print(f"[{name}] trajectory deviation / possible travel, per iteration: " + " ".join(f"{float(v):.3f}" for v in dev_t))
     # measured: <= 0.049 at every iteration of every unit, <= 0.009 at the end
-    assert float(dev_t.max()) <= 0.08, dev_t.tolist()
-    assert float(dev_t[-1]) <= 0.02, dev_t.tolist()
+    assert float(dev_t.max()) <= bar_traj, dev_t.tolist()
+    assert float(dev_t[-1]) <= bar_end, dev_t.tolist()
     # only the unit's own deltas changed
     others = [n for n, m in mods.items() if isinstance(m, QuantLayer) and m.aqtizer.delta is not None and n not in names]
     ck1 = {str(k): v for k, v in zip([k for k in map(str, g8["act_keys"]) if k.endswith("delta")], T(g8["ck/act_1/delta"]))}

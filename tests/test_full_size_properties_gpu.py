@@ -142,6 +142,7 @@ def test_sd_row_chains_and_fused_ff_are_bit_identical_at_full_size(sd, monkeypat
     x = torch.randn(3, 64, 64, 4, generator=g).to(DEV)
     ctx = torch.randn(6, 77, 768, generator=g).to(DEV)
     outs = {}
+    monkeypatch.setenv("TFMQ_CHAIN_MIN_TOKENS", "0")       # (the engine's size policy keeps the chains for >= 32768 tokens: ops.chain_tokens_ok)
     with torch.cuda.stream(info["stream"]):
         for chain, ff, ffc in (("1", "1", "1"), ("0", "0", "1"), ("1", "0", "1"), ("0", "1", "1"), ("1", "1", "0")):
             monkeypatch.setenv("TFMQ_ROW_CHAIN", chain)

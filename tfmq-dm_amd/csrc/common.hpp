@@ -30,6 +30,12 @@ struct tfmq_ctx {
   // stream-ordered (one stream at a time), like gemm_ws.
   int* ksplit_ws = nullptr;
   int* ksplit_cnt = nullptr;
+  // the stream that issued the last split-K launch and an event behind that launch (recorded outside stream capture): a split-K launch on
+  // ANOTHER stream first waits for it, so that launches of one handle that are ordered on the host are ordered on the device as well.  Two
+  // streams replaying captured split-K launches of one handle CONCURRENTLY remain the caller's to order (use one handle per such stream).
+  void* ksplit_owner = nullptr;
+  bool ksplit_owner_set = false, ksplit_ev_valid = false;
+  hipEvent_t ksplit_ev = nullptr;
   static constexpr size_t KSPLIT_WS_INTS = static_cast<size_t>(16) << 20;      // 64 MiB: 1024 slabs of 128 x 128
   static constexpr int KSPLIT_MAX_TILES = 65536;
   // operand precision of tfmq_gemm_f32's matrix-core path (tfmq_set_gemm_precision): 0 exact fp32, 1 bf16x3 split, 2 fp16

@@ -50,6 +50,7 @@ extern "C" int tfmq_destroy(tfmq_handle h) {
   if (h->gemm_ws) (void)hipFree(h->gemm_ws);
   if (h->ksplit_ws) (void)hipFree(h->ksplit_ws);
   if (h->ksplit_cnt) (void)hipFree(h->ksplit_cnt);
+  if (h->ksplit_ev) (void)hipEventDestroy(h->ksplit_ev);
   delete h;
   return TFMQ_OK;
 }
@@ -66,6 +67,8 @@ extern "C" int tfmq_device_info(tfmq_handle h, int* cu_count, int* clock_khz, si
 
 extern "C" int tfmq_graph_begin(tfmq_handle h, void* stream) {
   TFMQ_CHECK_ARG(h, h && stream, "graph_begin: capture needs a non-default stream");
+  // the split-K arrival tickets are zero between launches; a launch that aborted would leave some set: clear them ahead of a capture
+  TFMQ_HIP(h, hipMemsetAsync(h->ksplit_cnt, 0, tfmq_ctx::KSPLIT_MAX_TILES * sizeof(int), as_stream(stream)));
   TFMQ_HIP(h, hipStreamBeginCapture(as_stream(stream), hipStreamCaptureModeThreadLocal));
   return TFMQ_OK;
 }

@@ -1119,6 +1119,7 @@ static int launch_conv(tfmq_handle h, const tfmq_conv_desc* dd, void* stream) {
   dim3 grid(static_cast<unsigned>(p.tiles_n) * tiles_m);
   hipStream_t st = as_stream(stream);
   p.ksplit = 1;
+  bool ks_record = false;
   p.ks_ws = h->ksplit_ws;
   p.ks_cnt = h->ksplit_cnt;
   if constexpr (INT8) {
@@ -1131,6 +1132,14 @@ static int launch_conv(tfmq_handle h, const tfmq_conv_desc* dd, void* stream) {
                      "conv_w4a8: ksplit needs the LDS-DMA tile kernel, ksplit <= K-steps and tiles * ksplit * tile elements <= 16 Mi");
       p.ksplit = d.ksplit;
       grid.x *= static_cast<unsigned>(d.ksplit);
+      // one workspace / ticket array per handle: order this launch behind the last split-K launch of another stream (common.hpp)
+      hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+      (void)hipStreamIsCapturing(st, &cap);
+      if (h->ksplit_owner_set && h->ksplit_owner != stream && h->ksplit_ev_valid && cap == hipStreamCaptureStatusNone)
+        TFMQ_HIP(h, hipStreamWaitEvent(st, h->ksplit_ev, 0));
+      h->ksplit_owner = stream;
+      h->ksplit_owner_set = true;
+      ks_record = cap == hipStreamCaptureStatusNone;
     }
     if (dma) {
 #ifdef TFMQ_PHASE_TIMERS
@@ -1202,6 +1211,11 @@ static int launch_conv(tfmq_handle h, const tfmq_conv_desc* dd, void* stream) {
 #undef TFMQ_LAUNCH
   }
   TFMQ_LAUNCH_CHECK(h);
+  if (ks_record) {
+    if (!h->ksplit_ev) TFMQ_HIP(h, hipEventCreateWithFlags(&h->ksplit_ev, hipEventDisableTiming));
+    TFMQ_HIP(h, hipEventRecord(h->ksplit_ev, st));
+    h->ksplit_ev_valid = true;
+  }
   return TFMQ_OK;
 }
 

@@ -33,6 +33,11 @@ def _root(t: torch.Tensor):
         return t, 0, t.shape[-1]
     if not b.is_contiguous() or t.stride(-1) != 1:
         raise TfmqError("GradTape: only column slices of contiguous tensors are differentiable views")
+    if t.is_contiguous():
+        # a contiguous view that is SMALLER than its base: a slice of leading (batch) rows, base[:B] or base[B:].  Its gradient has the
+        # slice's shape, not the base's -- recording it under the base's key would mis-accumulate when the producer is replayed.
+        raise TfmqError("GradTape: a batch (leading-dimension) slice of a taped tensor is not a differentiable view here; tape the un-sliced "
+                        "tensor (the guidance-pair prefix is switched off while taps are recorded)")
     rowlen = t.stride(-2) if t.dim() >= 2 else b.shape[-1]
     off = (t.data_ptr() - b.data_ptr()) // t.element_size()
     if off >= rowlen:

@@ -349,7 +349,7 @@ class LdmUNetEngine(DdimUNetEngine):
         f = self.fused_qkv.get(tb + ".attn1")
         pin = L[p + ".proj_in"]
         heads = self.cfg["num_heads"]
-        return (self._h16 and self.calib is None and taps is None and not self.exact_fp and x.dtype == torch.float16 and ops.row_chain_ok(Cc, B * T, T, True)
+        return (self._h16 and self.calib is None and taps is None and not self.exact_fp and x.dtype == torch.float16 and ops.row_chain_ok(Cc, B * T, T, True) and ops.chain_tokens_ok(B * T)
                 and _n_children(self.sd, p + ".transformer_blocks") == 1 and pin.kind == "w4a8" and not pin.wide and pin.p.cout == Cc
                 and f is not None and f.kind == "w4a8" and not f.wide and f.p.cout == 3 * Cc and (tb + ".attn1") not in self.attn_q
                 and ops.attention_f16_ok(Cc // heads, T) and getattr(x, "_tfmq_stats", None) is not None and T % x._tfmq_stats[1] == 0
@@ -438,7 +438,7 @@ class LdmUNetEngine(DdimUNetEngine):
         gp = self.geglu_fused.get(p + ".ff.net.0.proj")
         if gp is not None and self.calib is None:
             if (x.dtype == torch.float16 and ff2.kind == "w4a8" and not ff2.wide and ops.ff_fused_ok(x.shape[-1], gp.cout // 2, gp, ff2.p)
-                    and (out_aq is not None or self._h16)):
+                    and (out_aq is not None or self._h16) and ops.chain_tokens_ok(x.numel() // x.shape[-1])):
                 # round 4: norm3 -> ff.net.0.proj -> GEGLU -> quantise -> ff.net.2 (+ x) as ONE launch, a token per lane; the GEGLU bins
                 # go from the accumulators into the second GEMM's MFMA operand.  Bit-identical to the three launches below.
                 return ops.ff_fused(x, self.sd[p + ".norm3.weight"], self.sd[p + ".norm3.bias"], 1e-5, ff0.aq, gp, ff2.aq, ff2.p, out_q8=out_aq)

@@ -983,6 +983,14 @@ def row_chain_ok(C_: int, M: int, T: int, gn_in: bool) -> bool:
     return row_chain_supported(C_, M, T, gn_in)
 
 
+def chain_tokens_ok(M: int) -> bool:
+    """The engine's size policy for the token-per-lane launches (tfmq_row_chain, tfmq_ff_fused): a workgroup owns 256 tokens and walks the
+    whole chain over them, so below ~half a chip's worth of workgroups the separate launches (128 x 128 tiles, split-K) spread the same
+    work over more CUs -- SD at 1 image / GPU (8192 tokens, 32 workgroups): 6.66 ms per forward with the chains against 5.9 without.
+    TFMQ_CHAIN_MIN_TOKENS overrides the threshold (default 32768 = 128 workgroups)."""
+    return M >= int(os.environ.get("TFMQ_CHAIN_MIN_TOKENS", "32768"))
+
+
 def row_chain_supported(C_: int, M: int, T: int, gn_in: bool) -> bool:
     """Shapes tfmq_row_chain takes (the policy -- which of them the engine uses -- is row_chain_ok)."""
     if C_ not in (320, 640):

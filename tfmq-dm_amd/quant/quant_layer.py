@@ -117,7 +117,9 @@ def hist(x: torch.Tensor, symmetric: bool = False, level: int = 256, always_zero
     amax = max(-xmin, xmax)
     edges = np.linspace(0, amax, level + 1, endpoint=True, dtype=np.float32)
     h = _np_density(ops.np_histogram(xf, edges), edges)
-    h = h.astype(np.float32) / h.sum()
+    # float32-rounded densities divided in float64: what `hist.astype(np.float32) / hist.sum()` evaluates to under NumPy >= 2 (NEP 50: a
+    # float64 SCALAR is not value-cast any more), the NumPy the fixtures were generated with; explicit so that NumPy 1.x gives the same bits
+    h = h.astype(np.float32).astype(np.float64) / np.float64(h.sum())
     acc, lo, hi = 0, None, None
     for i in range(level):
         acc += h[i]
@@ -195,7 +197,7 @@ def hist_rows(x2: torch.Tensor, level: int = 256, always_zero: bool = False) -> 
     edges = np.linspace(np.zeros(R, dtype=np.float64), amax, level + 1, endpoint=True, dtype=np.float32, axis=-1)     # (`hist` starts at the int 0: float64 arithmetic)
     cnt = ops.np_histogram_rows(xf, edges)
     h = cnt / np.diff(edges, axis=-1) / cnt.sum(axis=-1, keepdims=True)
-    h = h.astype(np.float32) / h.sum(axis=-1, keepdims=True)
+    h = h.astype(np.float32).astype(np.float64) / h.sum(axis=-1, keepdims=True).astype(np.float64)      # (as in `hist`: explicit float64)
     lo, hi = np.zeros(R, dtype=np.float64), np.zeros(R, dtype=np.float64)
     for rr in range(R):          # a 256-step running sum per row: host arithmetic in `hist`'s own order
         acc = 0
