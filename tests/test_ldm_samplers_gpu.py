@@ -193,6 +193,18 @@ def test_graph_fast_path_of_the_dropin_samplers(ldm):
             assert hasattr(q, "_graph_samplers") and len(q._graph_samplers) == 1          # the fast path was taken
             assert float((fast - ref).abs().max()) <= 1e-5 * float(ref.abs().max()), (cls.__name__, until)
             assert len(inter["x_inter"]) == 2
+    # eta > 0 (ddim.py:173-212: sigma_t * noise): the step graphs read a noise buffer refilled before every replay in the host loop's order
+    # of draws -- same generator state, same trajectory
+    kw = dict(S=4, conditioning=ctx, batch_size=2, shape=[4, 8, 8], verbose=False, unconditional_guidance_scale=7.5,
+              unconditional_conditioning=uc, eta=0.7, x_T=x_T)
+    torch.manual_seed(5)
+    ref, _ = DDIMSampler(m).sample(**kw)
+    torch.manual_seed(5)
+    fast, _ = DDIMSampler(m).sample(_graph=True, **kw)
+    det, _ = DDIMSampler(m).sample(_graph=True, **{**kw, "eta": 0.0})
+    assert len(q._graph_samplers) == 1 and next(iter(q._graph_samplers.values())).eta == 0.0
+    assert float((fast - ref).abs().max()) <= 1e-5 * float(ref.abs().max())
+    assert float((fast - det).abs().max()) > 1e-2 * float(ref.abs().max())              # (the noise term is there)
     # a call with a callback keeps the host loop
     seen = []
     DDIMSampler(m).sample(S=4, conditioning=ctx, batch_size=2, shape=[4, 8, 8], verbose=False, unconditional_guidance_scale=7.5,

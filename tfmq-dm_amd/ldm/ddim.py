@@ -39,12 +39,12 @@ class DDIMSampler:
         return ops.cfg_combine(e2[:b].contiguous(), e2[b:].contiguous(), scale)
 
     # -------------------------------------------------------------------------------------------- graph fast path
-    def _graph_sample(self, plms: bool, S: int, cond, shape, x_T, scale: float, uc, untill_fake_t):
+    def _graph_sample(self, plms: bool, S: int, cond, shape, x_T, scale: float, uc, untill_fake_t, eta: float = 0.0):
         """Opt-in (`sample(..., _graph=True)`, used by the calibration-set generators, which need neither callbacks nor
         intermediates): the same recurrence as the host loop below, replayed as captured step graphs
         (ldm/sampler.py) on the engine `model.apply_model` lowers to.  Returns None when the call does not qualify
-        (guidance-free conditional sampling, eta > 0, PLMS with Finite-Set wrapper attributes set, model not lowered to an
-        engine).  DDIM with the drivers' Finite-Set attributes (wrapper.tot / t_max / ckpt): the group of step i is
+        (guidance-free conditional sampling, PLMS with Finite-Set wrapper attributes set, model not lowered to an engine).  eta > 0
+        (DDIM only): the noise of every step is drawn on the sampler's stream right before its replay, in the host loop's order.  DDIM with the drivers' Finite-Set attributes (wrapper.tot / t_max / ckpt): the group of step i is
         k_i = t_max - (t_i - 1) // tot (ddpm.py:1402-1405); the table installed for the replay is [act_{k_0}, act_{k_1}, ...], one
         row per executed step, indexed by the graph's device step counter."""
         from .sampler import GraphLatentDdimSampler, GraphLatentPlmsSampler
@@ -74,7 +74,7 @@ class DDIMSampler:
             return None
         b, Cc, H, W = shape
         ctx_shape = None if cond is None else tuple(cond.shape[1:])
-        key = (id(eng), plms, int(S), b, (Cc, H, W), ctx_shape, float(scale))
+        key = (id(eng), plms, int(S), b, (Cc, H, W), ctx_shape, float(scale), float(eta))
         cache = qnn.__dict__.setdefault("_graph_samplers", {})
         smp = cache.get(key)
         if smp is None:
@@ -83,7 +83,7 @@ class DDIMSampler:
             if plms:
                 smp = GraphLatentPlmsSampler(eng, S, b, (Cc, H, W), ctx_shape, scale=scale, alphas_cumprod=ac)
             else:
-                smp = GraphLatentDdimSampler(eng, S, b, (Cc, H, W), ctx_shape, scale=scale, alphas_cumprod=ac)
+                smp = GraphLatentDdimSampler(eng, S, b, (Cc, H, W), ctx_shape, scale=scale, alphas_cumprod=ac, eta=eta)
             smp.capture()
             cache[key] = smp
         img = (torch.randn(shape, device=dev) if x_T is None else x_T.to(dev)).float().contiguous()
@@ -111,9 +111,9 @@ class DDIMSampler:
         if not untill_fake_t:
             untill_fake_t = float("inf")
         Cc, H, W = shape
-        if kwargs.get("_graph") and eta == 0.0 and callback is None and img_callback is None:
+        if kwargs.get("_graph") and callback is None and img_callback is None:
             r = self._graph_sample(False, S, conditioning, (batch_size, Cc, H, W), x_T, float(unconditional_guidance_scale),
-                                   unconditional_conditioning, untill_fake_t)
+                                   unconditional_conditioning, untill_fake_t, float(eta))
             if r is not None:
                 return r
         return self.ddim_sampling(conditioning, (batch_size, Cc, H, W), x_T=x_T, callback=callback, img_callback=img_callback,

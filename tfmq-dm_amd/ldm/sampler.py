@@ -50,9 +50,8 @@ def ddim_coef_table(alphas_cumprod: torch.Tensor, S: int, eta: float = 0.0) -> t
 class GraphLatentDdimSampler:
     def __init__(self, engine, S: int, batch: int, latent_shape, context_shape, scale: float = 7.5,
                  alphas_cumprod: Optional[torch.Tensor] = None, eta: float = 0.0):
-        if eta != 0.0:
-            raise TfmqError("GraphLatentDdimSampler: eta != 0 needs a device RNG stream (not wired yet)")
         self.eng, self.S, self.batch, self.scale = engine, S, batch, float(scale)
+        self.eta = float(eta)
         self.dev = engine.dev
         ac = alphas_cumprod if alphas_cumprod is not None else alphas_cumprod_linear()
         self.coef = ddim_coef_table(ac, S, eta).to(self.dev)
@@ -63,6 +62,10 @@ class GraphLatentDdimSampler:
         engine.build_tib_table([float(t) for t in np.flip(ddim_timesteps(S, ac.shape[0]))])
         Cc, H, W = latent_shape
         self.x = torch.empty(batch, H, W, Cc, device=self.dev)
+        # eta > 0 (p_sample_ddim's sigma_t * noise term, ddim.py:173-212): the captured update reads this buffer; every replay is preceded by a
+        # fresh draw into it on the sampler's stream, in the host loop's order (one torch.randn of the NCHW shape per step)
+        self.noise = torch.empty(batch, H, W, Cc, device=self.dev) if self.eta > 0.0 else None
+        self.nchw = (batch, Cc, H, W)
         # context_shape None: unconditional LDM (CelebA-HQ / LSUN configs, sample_diffusion_ldm.py): one UNet call on the
         # batch itself per step, plain DDIM update -- no guidance pair
         self.uncond = context_shape is None
@@ -78,11 +81,11 @@ class GraphLatentDdimSampler:
         B = self.batch
         if self.uncond:
             eps = self.eng.forward(self.x, None, None)
-            ops.ddim_update(self.x, eps, self.coef, self.step, None, out=self.x)
+            ops.ddim_update(self.x, eps, self.coef, self.step, self.noise, out=self.x)
             ops.step_advance(self.step, 1)
             return
         eps2 = self._eps_pair(self.x)
-        ops.ddim_update_cfg(self.x, eps2[:B], eps2[B:], self.scale, self.coef, self.step, out=self.x)
+        ops.ddim_update_cfg(self.x, eps2[:B], eps2[B:], self.scale, self.coef, self.step, noise=self.noise, out=self.x)
         ops.step_advance(self.step, 1)
 
     def _eps_pair(self, xin):
@@ -143,6 +146,8 @@ class GraphLatentDdimSampler:
             # the host buys nothing and overflows rocprofv3's dispatch records at large batches
             sync_every = int(os.environ.get("TFMQ_GRAPH_SYNC_EVERY", "8"))
             for i in range(self.coef.shape[0] if steps is None else steps):
+                if self.noise is not None:
+                    self.noise.copy_(ops.nchw_to_nhwc(torch.randn(self.nchw, device=self.dev)))
                 self.h.call("graph_launch", self.gid, sp)
                 if sync_every and (i + 1) % sync_every == 0:
                     self.stream.synchronize()
