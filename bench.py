@@ -934,6 +934,15 @@ def main():
                         cali.setdefault("measured_sd_recipe_20000_iterations", {})[key] = ent
                     except Exception as e:      # a damaged record must not take the sampling line down
                         cali.setdefault("measured_sd_recipe_20000_iterations", {})[key] = {"error": repr(e)}
+            # round 4: ONE job over all 74 units with the calibration set generated inside it (`--workload cali --cali-generate`)
+            fpath = os.path.join(ROOT, "profiles", "r04_bench_line_cali_sd_full_20000.json")
+            if os.path.exists(fpath):
+                try:
+                    mj = json.loads(open(fpath).read().strip().splitlines()[-1])
+                    cali["measured_sd_recipe_20000_iterations_one_job"] = {**mj["calibration"], "workload": mj["config"]["workload"],
+                                                                           "source": "profiles/r04_bench_line_cali_sd_full_20000.json", "recorded_run": True}
+                except Exception as e:
+                    cali["measured_sd_recipe_20000_iterations_one_job"] = {"error": repr(e)}
             lv = cali.get("measured_sd_recipe_20000_iterations", {})
             if len(lv) == 4 and all("wall_clock_s" in v for v in lv.values()):
                 lv["sum_of_levels"] = {"wall_clock_s": round(sum(v["wall_clock_s"] for v in lv.values()), 1),
