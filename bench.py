@@ -239,6 +239,10 @@ def setup_sd(args, dev, rank, log, preset="sd"):
         ms.stream.synchronize()
         dt = time.perf_counter() - t0
         same = bool(torch.equal(out, sampler.x)) if sampler.gid is not None else None
+        if same is False:
+            df = (out - sampler.x).abs()
+            log(f"materialised pair vs metric run: {int((df > 0).sum())} of {df.numel()} latent values differ, max abs {float(df.max()):.3e}, "
+                f"images touched {int((df.reshape(df.shape[0], -1).amax(dim=1) > 0).sum())} of {df.shape[0]}")
         return {"images_per_s": round(batch / dt, 3), "final_latents_equal_to_the_metric_run": same,
                 "note": "guidance pair materialised as a 2B batch (TFMQ_PAIR_PREFIX=0); the metric's run shares the pair's common prefix"}
 
@@ -373,7 +377,8 @@ def setup_sd(args, dev, rank, log, preset="sd"):
         return out
 
     info = dict(batch=batch, sync=sampler.stream.synchronize, finite=lambda: bool(torch.isfinite(sampler.x).all().item()),
-                stream=sampler.stream, step=eng.step, plms=plms, sweep=sweep, parity=parity, materialised=materialised if CTX is not None and sampler.pair_prefix else None,
+                stream=sampler.stream, step=eng.step, sampler=sampler, inputs=(x_T, cond, uncond),
+                new_sampler=lambda: GraphLatentDdimSampler(eng, S, batch, LAT, CTX, scale=scale, alphas_cumprod=alphas_cumprod_linear()), plms=plms, sweep=sweep, parity=parity, materialised=materialised if CTX is not None and sampler.pair_prefix else None,
                 oracle_state=dict(sd=sd, wq=wq, act_names=act_names, cfg=cfg, eng=eng),     # scratch/sd_parity_full.py
                 workload=(f"{P['name']} ({n_params:.1f}M) w4a8 on MI355X: {LH}x{LW}x{LC} latents, DDIM-{S} eta=0, "
                           + (f"CFG {scale} (UNet batch 2x{batch}), {CTX[0]}x{CTX[1]} context, " if CTX is not None else "unconditional, ")
@@ -911,6 +916,8 @@ def main():
             # BasicTransformerBlock, the middle attention) with input / target capture, Finite-Set activation calibration, checkpoint.
             # The full-length runs below are RECORDED (run once with `--workload cali`, committed under profiles/).
             try:
+                if os.environ.get("TFMQ_BENCH_NO_LIVE_CALI") == "1":
+                    raise RuntimeError("skipped (TFMQ_BENCH_NO_LIVE_CALI=1)")
                 lj = run_cali_workload(argparse.Namespace(cali_samples=16, cali_groups=2, cali_iters=int(os.environ.get("TFMQ_BENCH_LIVE_CALI_ITERS", "500")),
                                                           cali_only="model.input_blocks.1,model.middle_block.1", cali_generate=True), dev, 0, 0, 1, log)
                 cali["live_slice"] = {"live": True, "workload": lj["config"]["workload"], "finite": lj["finite"], **lj["calibration"]}

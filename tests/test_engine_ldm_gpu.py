@@ -367,3 +367,40 @@ def test_ldm_w4a8_bin_flip_rate_per_layer(env):
     assert overall <= 0.40 and max(rates.values()) <= 0.75     # measured 0.30 / 0.62 (a narrow-range attn2.to_q input deep in the net)
     assert big / tot_n <= 6e-2                                  # measured 3.3e-2
     assert max(l2.values()) <= 7e-2                             # measured 4.7e-2
+
+
+def test_graph_sampler_is_ordered_behind_the_callers_stream(env):
+    """A graph sampler built and started while the CALLER's stream is still busy (long fills queued in front of its constructor, the
+    start latent produced by a kernel behind them): the TIB table the constructor builds through the shared device step counter, the
+    inputs and the sampler's own (non-blocking) stream must be ordered -- the result equals that of a sampler built on an idle device.
+    Round 4: a bench leg that left the default stream busy exposed a race between build_tib_table (caller's stream, drives the step
+    counter through every step) and the sampler stream's first step.zero_() / forward."""
+    g, sd, Engine, LayerQ = env
+    from tfmq_dm_amd.ldm.sampler import GraphLatentDdimSampler, alphas_cumprod_linear
+    ctx, uc, x_T = T(g["ctx"]).to(DEV), T(g["traj_uc"]).to(DEV), nhwc(T(g["traj_xT"])).to(DEV)
+    wq, qtable = layerq(g, LayerQ, True)
+    S, n_exec = 8, 8
+    step = torch.zeros(1, dtype=torch.int32, device=DEV)
+    qt = torch.stack([qtable[0] * torch.tensor([1.0 + 0.02 * k, 1.0]) for k in range(n_exec)]).contiguous()     # a table row per step
+    eng = Engine(sd, CFG, DEV)
+    eng.prepare(wq, qt.to(DEV), step)
+    torch.cuda.synchronize()
+    quiet = GraphLatentDdimSampler(eng, S, 2, (4, 8, 8), (5, 64), scale=7.5, alphas_cumprod=alphas_cumprod_linear()).capture()
+    ref = quiet.sample_nhwc(x_T, ctx, uc)
+    quiet.stream.synchronize()
+    ref, tib_ref = ref.clone(), eng.tib_table.clone()
+    del quiet
+    big = torch.empty(1 << 28, dtype=torch.int32, device=DEV)            # 1 GiB: each fill keeps the caller's stream busy for a while
+    for rep in range(3):
+        for _ in range(3000):                                             # the better part of a second of queued work in front of the constructor
+            big.fill_(rep)
+        x_late = x_T + 0.0                                               # produced BEHIND the fills on the caller's stream
+        busy = GraphLatentDdimSampler(eng, S, 2, (4, 8, 8), (5, 64), scale=7.5, alphas_cumprod=alphas_cumprod_linear())
+        out = busy.sample_nhwc(x_late, ctx, uc)                          # (captures on first use)
+        with torch.cuda.stream(busy.stream):
+            seen = eng.tib_table.clone()                                 # the table as the SAMPLER's stream sees it when it is done
+        busy.stream.synchronize()
+        assert torch.equal(seen, tib_ref), rep
+        assert torch.equal(eng.tib_table, tib_ref), rep
+        assert torch.equal(out, ref), rep
+        del busy

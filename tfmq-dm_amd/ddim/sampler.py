@@ -166,6 +166,7 @@ class GraphDdimSampler:
 
     def capture(self):
         sp = C.c_void_p(self.stream.cuda_stream)
+        self.stream.wait_stream(torch.cuda.current_stream(self.dev))      # inputs / set-up produced on the caller's stream
         with torch.cuda.stream(self.stream):
             self.step.zero_()
             # the warm-up pass allocates every intermediate once and times the tile variants of every conv / linear shape
@@ -200,6 +201,7 @@ class GraphDdimSampler:
         if self.gid is None:
             self.capture()
         sp = C.c_void_p(self.stream.cuda_stream)
+        self.stream.wait_stream(torch.cuda.current_stream(self.dev))      # inputs / set-up produced on the caller's stream
         with torch.cuda.stream(self.stream):
             self.x.copy_(x_T, non_blocking=True)
             self.step.zero_()
@@ -213,9 +215,11 @@ class GraphDdimSampler:
         return self.x
 
     def sample(self, x_T_nchw: torch.Tensor) -> torch.Tensor:
+        self.stream.wait_stream(torch.cuda.current_stream(self.dev))      # inputs / set-up produced on the caller's stream
         with torch.cuda.stream(self.stream):
             xin = ops.nchw_to_nhwc(x_T_nchw.contiguous())
         out = self.sample_nhwc(xin)
+        self.stream.wait_stream(torch.cuda.current_stream(self.dev))      # inputs / set-up produced on the caller's stream
         with torch.cuda.stream(self.stream):
             y = ops.nhwc_to_nchw(out)
         self.stream.synchronize()

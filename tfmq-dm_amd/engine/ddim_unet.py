@@ -409,6 +409,12 @@ class DdimUNetEngine:
         index it with the device-side step counter (K7)."""
         if self.step is None and self.qtable is not None and self.qtable.shape[0] > 1:
             raise TfmqError("build_tib_table: a multi-step qtable needs a device step counter")
+        # Set-up work on the CALLER's current stream that drives the shared device step counter through every step: nothing on another
+        # stream may touch the counter meanwhile, and no stream may read the table before it is complete.  Samplers run on their own
+        # (non-blocking) streams, which do not order themselves against this one -- a sampler that started right behind its constructor
+        # used to race the loop below (its step.zero_() between a fill_ and the TIB kernels: rows computed under the wrong Finite-Set
+        # group; found in round 4 through a bench leg that left the default stream busy).  Device-wide synchronisation on both sides.
+        torch.cuda.synchronize(self.dev)
         rows = []
         for s, tv in enumerate(t_values):
             if self.step is not None:
@@ -422,6 +428,7 @@ class DdimUNetEngine:
             off += wdt
         if self.step is not None:
             self.step.zero_()
+        torch.cuda.synchronize(self.dev)
         return self.tib_table
 
     # ------------------------------------------------------------------ blocks

@@ -100,6 +100,7 @@ class GraphLatentDdimSampler:
 
     def capture(self):
         sp = C.c_void_p(self.stream.cuda_stream)
+        self.stream.wait_stream(torch.cuda.current_stream(self.dev))      # inputs / set-up produced on the caller's stream
         with torch.cuda.stream(self.stream):
             self.step.zero_()
             # the warm-up pass allocates every intermediate once and times the tile variants of every conv / linear shape
@@ -136,6 +137,7 @@ class GraphLatentDdimSampler:
         if self.gid is None:
             self.capture()
         sp = C.c_void_p(self.stream.cuda_stream)
+        self.stream.wait_stream(torch.cuda.current_stream(self.dev))      # inputs / set-up produced on the caller's stream
         with torch.cuda.stream(self.stream):
             self.x.copy_(x_T, non_blocking=True)
             if not self.uncond:
@@ -217,6 +219,7 @@ class GraphLatentPlmsSampler(GraphLatentDdimSampler):
 
     def capture(self):
         sp = C.c_void_p(self.stream.cuda_stream)
+        self.stream.wait_stream(torch.cuda.current_stream(self.dev))      # inputs / set-up produced on the caller's stream
         with torch.cuda.stream(self.stream):
             self.step.zero_()
             if not hasattr(self.eng, "tiles"):
@@ -245,6 +248,7 @@ class GraphLatentPlmsSampler(GraphLatentDdimSampler):
             self.capture()
         sp = C.c_void_p(self.stream.cuda_stream)
         n = self.coef.shape[0] if steps is None else int(steps)
+        self.stream.wait_stream(torch.cuda.current_stream(self.dev))      # inputs / set-up produced on the caller's stream
         with torch.cuda.stream(self.stream):
             self.x.copy_(x_T, non_blocking=True)
             self.ctx2[:self.batch].copy_(uncond, non_blocking=True)

@@ -36,7 +36,7 @@ class Arena:
         self.frozen = False
         # liveness needs torch's storage use count (the hook CUDA-graph trees use); without it every allocation keeps
         # its own block, which is correct and merely larger
-        self.reuse = reuse and hasattr(torch._C, "_storage_Use_Count")
+        self.reuse = reuse and hasattr(torch._C, "_storage_Use_Count") and os.environ.get("TFMQ_ARENA_REUSE", "1") != "0"      # (=0: diagnostics)
         self._by_size = {}        # nbytes -> [block indices]
 
     def rewind(self):
