@@ -24,6 +24,9 @@
 
 namespace {
 
+#ifndef LIN_PREFETCH
+#define LIN_PREFETCH 1
+#endif
 enum { LIN_F16 = 0, LIN_Q8 = 1, LIN_GEGLU = 2, LIN_GEGLU_FAST = 3 };
 template <int MODE> constexpr bool lin_is_geglu = MODE == LIN_GEGLU || MODE == LIN_GEGLU_FAST;
 
@@ -404,13 +407,24 @@ __global__ __launch_bounds__(256, 3) void k_lin_direct(ConvP p) {
     if (s + 2 < p.nsteps) issue(s + 2, st_i);
     const unsigned char* sa = lds + st_c * STAGE;
     const unsigned char* sb = sa + BM * 64;
+    // GEGLU modes (round 4): both K halves' fragments are requested up front, the second half's reads travel under the first half's MFMAs
+    // (same-box A/B, gpurun_out/r04/lin_prefetch_ab.txt: GEGLU 640 -> 5120 and 1280 -> 10240 -6.5 %; the fp16 / int8-output modes
+    // -2 ... +7 %: they keep the read-then-multiply order per half)
+    constexpr bool PF = LIN_PREFETCH && lin_is_geglu<MODE>;
+    v4i af[2][2], bf[2][2];
+    auto read_frags = [&](int ks) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) af[ks][i] = *reinterpret_cast<const v4i*>(sa + ((wm * 2 + i) * 32 + (lane & 31)) * 64 + (fsw ^ (ks << 5)));
+#pragma unroll
+      for (int j = 0; j < 2; ++j) bf[ks][j] = *reinterpret_cast<const v4i*>(sb + (ncol0(j) + brow) * 64 + (bsw ^ (ks << 5)));
+    };
+    read_frags(0);
+    if constexpr (PF) read_frags(1);
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      v4i af[2], bf[2];
-#pragma unroll
-      for (int i = 0; i < 2; ++i) af[i] = *reinterpret_cast<const v4i*>(sa + ((wm * 2 + i) * 32 + (lane & 31)) * 64 + (fsw ^ (ks << 5)));
-#pragma unroll
-      for (int j = 0; j < 2; ++j) bf[j] = *reinterpret_cast<const v4i*>(sb + (ncol0(j) + brow) * 64 + (bsw ^ (ks << 5)));
+      if constexpr (!PF) {
+        if (ks == 1) read_frags(1);
+      }
       // operands swapped: the accumulator tile is (channels x pixels) -- lane = pixel, register quad = 4 consecutive channels
 #pragma unroll
       for (int i = 0; i < 2; ++i)
@@ -420,9 +434,9 @@ __global__ __launch_bounds__(256, 3) void k_lin_direct(ConvP p) {
             typedef _Float16 v8h_t __attribute__((ext_vector_type(8)));
             typedef float v16f_t __attribute__((ext_vector_type(16)));
             v16f_t& af32 = *reinterpret_cast<v16f_t*>(&acc[i][j]);
-            af32 = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<v8h_t*>(&bf[j]), *reinterpret_cast<v8h_t*>(&af[i]), af32, 0, 0, 0);
+            af32 = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<v8h_t*>(&bf[ks][j]), *reinterpret_cast<v8h_t*>(&af[ks][i]), af32, 0, 0, 0);
           } else {
-            acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(bf[j], af[i], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(bf[ks][j], af[ks][i], acc[i][j], 0, 0, 0);
           }
         }
     }

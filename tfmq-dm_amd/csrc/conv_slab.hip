@@ -34,6 +34,15 @@
 #define SLAB_MARK(i) do { } while (0)
 #endif
 
+// Timing-only ablations of the K loop (scratch/r04_slab_abl.sh builds one library per mask with -DSLAB_ABLATE=<mask>; results are garbage):
+// 1 no DMA issue after the first chunk's, 2 no MFMAs, 4 no fragment reads (operands from registers), 8 no per-K-step barrier / waits
+#ifndef SLAB_ABLATE
+#define SLAB_ABLATE 0
+#endif
+#ifndef SLAB_PREFETCH
+#define SLAB_PREFETCH 1
+#endif
+
 namespace {
 
 struct SlabP {
@@ -193,12 +202,16 @@ __global__ __launch_bounds__(64 * 2 * NWM, 2) void k_conv3_slab(SlabP sp) {
       // NST - 1 steps before this one (taps 0 .. NIT-1 carry one each)
       constexpr int X = ((TAP >= 1 && TAP <= NIT) ? 1 : 0) + ((NST == 3 && TAP >= 2 && TAP <= NIT + 1) ? 1 : 0);
       const int pos = c * 9 + TAP;
-      if (pos + 1 < p.nsteps) wait_vmcnt<(NST - 2) * B_CH + X>();
-      else wait_vmcnt<0>();
-      asm volatile("s_barrier" ::: "memory");
+      if constexpr (!(SLAB_ABLATE & 8)) {
+        if constexpr (SLAB_ABLATE & 1) wait_vmcnt<0>();
+        else if (pos + 1 < p.nsteps) wait_vmcnt<(NST - 2) * B_CH + X>();
+        else wait_vmcnt<0>();
+        asm volatile("s_barrier" ::: "memory");
+      }
       // stage of a K-step: NST = 3 -> tap % 3 (9 taps a chunk); NST = 2 -> parity of the step index
       const int st_next = NST == 3 ? (TAP + 2) % 3 : ((pos + 1) & 1);
       auto issue_next = [&]() {
+        if constexpr (SLAB_ABLATE & 1) return;
         if (pos + NST - 1 < p.nsteps) {
           if constexpr (TAP + NST - 1 < 9) issue_b(c, TAP + NST - 1, st_next);
           else issue_b(c + 1, TAP + NST - 1 - 9, st_next);
@@ -219,13 +232,29 @@ __global__ __launch_bounds__(64 * 2 * NWM, 2) void k_conv3_slab(SlabP sp) {
         a_rel[i] = (SLAB_BYTES & (SLAB_BYTES - 1)) == 0 ? (ar ^ slab_toggle) : (ar + slab_toggle);     // 32 KiB buffers toggle by XOR
       }
       const unsigned char* sb = lds + BOFF + (NST == 3 ? TAP % 3 : (pos & 1)) * BST;
+      // Both halves' fragments are requested up front (SLAB_PREFETCH, round 4): the ks = 1 reads then travel under the ks = 0 MFMAs instead
+      // of standing between the two halves (timing ablation: the fragment reads were 16 ... 28 % of the launch, scratch/r04_slab_abl.sh).
+      // 28 more live registers inside the loop, which the epilogue's budget of 256 covers.
+      v4i af[2][2], bf[2][WN];
+      auto read_frags = [&](int ks) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          if constexpr (SLAB_ABLATE & 4) af[ks][i] = v4i{a_rel[i], ks, i, lane};
+          else af[ks][i] = *reinterpret_cast<const v4i*>(lds + (a_rel[i] ^ (ks << 5)));
+        }
+#pragma unroll
+        for (int j = 0; j < WN; ++j) {
+          if constexpr (SLAB_ABLATE & 4) bf[ks][j] = v4i{b_rel, ks, j, lane};
+          else bf[ks][j] = *reinterpret_cast<const v4i*>(sb + ((b_rel ^ (ks << 5)) + j * 2048));
+        }
+      };
+      read_frags(0);
+      if constexpr (SLAB_PREFETCH) read_frags(1);
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
-        v4i af[2], bf[WN];
-#pragma unroll
-        for (int i = 0; i < 2; ++i) af[i] = *reinterpret_cast<const v4i*>(lds + (a_rel[i] ^ (ks << 5)));
-#pragma unroll
-        for (int j = 0; j < WN; ++j) bf[j] = *reinterpret_cast<const v4i*>(sb + ((b_rel ^ (ks << 5)) + j * 2048));
+        if constexpr (!SLAB_PREFETCH) {
+          if (ks == 1) read_frags(1);
+        }
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -234,9 +263,11 @@ __global__ __launch_bounds__(64 * 2 * NWM, 2) void k_conv3_slab(SlabP sp) {
               typedef _Float16 v8h_t __attribute__((ext_vector_type(8)));
               typedef float v16f_t __attribute__((ext_vector_type(16)));
               v16f_t& af32 = *reinterpret_cast<v16f_t*>(&acc[i][j]);
-              af32 = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<v8h_t*>(&bf[j]), *reinterpret_cast<v8h_t*>(&af[i]), af32, 0, 0, 0);
+              af32 = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<v8h_t*>(&bf[ks][j]), *reinterpret_cast<v8h_t*>(&af[ks][i]), af32, 0, 0, 0);
+            } else if constexpr (SLAB_ABLATE & 2) {
+              acc[i][j][(ks * 2 + i) & 15] += bf[ks][j][0] ^ af[ks][i][1];
             } else {
-              acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(bf[j], af[i], acc[i][j], 0, 0, 0);      // (channels x pixels): lane = pixel
+              acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(bf[ks][j], af[ks][i], acc[i][j], 0, 0, 0);      // (channels x pixels): lane = pixel
             }
           }
         // the DMA issue of the next K-steps (SALU M0 moves + VMEM, ~100 clk a piece) sits behind the first half's MFMAs:
