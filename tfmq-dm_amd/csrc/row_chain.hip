@@ -222,21 +222,28 @@ __global__ __launch_bounds__(512, 2) void k_row_chain(ChainP p) {
         for (int u = 0; u < 2; ++u)
           rr[j][u] = *reinterpret_cast<const uint4*>(reinterpret_cast<const __half*>(L.residual) + static_cast<size_t>(m) * L.N + 64 * tp + 32 * (part * TPW + j) + 16 * h + 8 * u);
     }
+    if (kp == 0) {
 #pragma unroll
-    for (int j = 0; j < TPW; ++j) {
-      const int tl = part * TPW + j;                   // tile of the pair
-      if (kp == 0) {
+      for (int j = 0; j < TPW; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[j][r] = 0;
-      }
+    }
+    // the token fragment of a K slice is read ONCE for the wave's TPW tiles (with the tile loop outside, the stores of tile 0's epilogue
+    // stood between the two reads of the same fragment and the compiler kept both: 2 ds_read_b128 per MFMA instead of 1.5)
 #pragma unroll
-      for (int sidx = 0; sidx < 5; ++sidx)
+    for (int sidx = 0; sidx < 5; ++sidx)
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-          const v4i xf = *reinterpret_cast<const v4i*>(xk + sidx * 2048 + (fsw ^ (ks << 5)));
+      for (int ks = 0; ks < 2; ++ks) {
+        const v4i xf = *reinterpret_cast<const v4i*>(xk + sidx * 2048 + (fsw ^ (ks << 5)));
+#pragma unroll
+        for (int j = 0; j < TPW; ++j) {
           const v4i wf = *reinterpret_cast<const v4i*>(wslot + ((W == 1 ? j : 0) * 5 + sidx) * 2048 + (bsw ^ (ks << 5)));
           acc[j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf, xf, acc[j], 0, 0, 0);
         }
+      }
+#pragma unroll
+    for (int j = 0; j < TPW; ++j) {
+      const int tl = part * TPW + j;                   // tile of the pair
       if (!last) continue;
       // epilogue of this lane's 16 channels: scale * float(acc + kc) + bias (+ residual), k_lin_direct's operations
       unsigned hw[8];
