@@ -47,13 +47,26 @@ def f25():
     save("f25_delta_learning_attention", **out)
 
 
+def _wb_of(m):
+    """{<layer>.w / <layer>.b: tensor} of an FP model's conv / linear layers under the names QuantLayer gives them"""
+    d = {}
+    for n, mod in m.named_modules():
+        if isinstance(mod, (torch.nn.Conv2d, torch.nn.Linear)):
+            d[n + ".w"] = mod.weight
+            if mod.bias is not None:
+                d[n + ".b"] = mod.bias
+    return d
+
+
 def _family(out, pre, fixture, build, units, seed, xshape, cshape):
     import quant.reconstruction as REC
     from quant.calibration import load_cali_model
-    from quant.quant_block import QuantAttnBlock, QuantBasicTransformerBlock
+    from quant.quant_block import QuantAttnBlock, QuantBasicTransformerBlock, QuantQKMatMul, QuantSMVMatMul
     from quant.reconstruction_util import LossFunc, RLOSS
     f8 = np.load(os.path.join(HERE, fixture), allow_pickle=False)
-    ck = {"weight": {str(k): torch.from_numpy(f8["ck/weight/" + str(k)]) for k in f8["weight_keys"]}}
+    ck = {"weight": {str(k): torch.from_numpy(f8["ck/weight/" + str(k)]) for k in f8["weight_keys"] if "ck/weight/" + str(k) in f8.files}}
+    if len(ck["weight"]) < len(f8["weight_keys"]):           # F16 keeps the quantizer entries only: .w / .b are the model's own parameters
+        ck["weight"].update({"model." + k_: v_.detach().clone() for k_, v_ in _wb_of(build()).items() if "model." + k_ in set(map(str, f8["weight_keys"]))})
     akeys = [str(k) for k in f8["act_keys"]]
     dk, zk = [k for k in akeys if k.endswith("delta")], [k for k in akeys if k.endswith("zero_point")]
     for gi in range(3):
@@ -92,6 +105,12 @@ def _family(out, pre, fixture, build, units, seed, xshape, cshape):
                 A.append(("attn1.aqtizer_w", unit.attn1.aqtizer_w))
             if unit.attn2.aqtizer_w.level != (2 ** 16):
                 A.append(("attn2.aqtizer_w", unit.attn2.aqtizer_w))
+        elif isinstance(unit, QuantQKMatMul):                # reference quant/reconstruction.py:155-156
+            A = [("aqtizer_q", unit.aqtizer_q), ("aqtizer_k", unit.aqtizer_k)]
+        elif isinstance(unit, QuantSMVMatMul):               # :157-160
+            A = [("aqtizer_v", unit.aqtizer_v)]
+            if unit.aqtizer_w.level != (2 ** 16):
+                A.append(("aqtizer_w", unit.aqtizer_w))
         else:
             assert isinstance(unit, QuantAttnBlock)
             A = [("aqtizer_q", unit.aqtizer_q), ("aqtizer_k", unit.aqtizer_k), ("aqtizer_v", unit.aqtizer_v)]
@@ -138,5 +157,27 @@ def _family(out, pre, fixture, build, units, seed, xshape, cshape):
         print(pre + name, names, "\n  before", before.tolist(), "\n  after ", after.tolist(), "\n  loss", losses[0], losses[9], losses[19], losses[-1])
 
 
+def f26():
+    """f26  the same for the stand-alone matmul modules of the LDM AttentionBlock (QKVAttentionLegacy's seams): block_reconstruction(use_aq=True)
+    called on a QuantQKMatMul (A = [aqtizer_q, aqtizer_k]) and on a QuantSMVMatMul (A = [aqtizer_v, aqtizer_w]) of the tiny AttentionBlock UNet of
+    F13 / F16 -- reference quant/reconstruction.py:155-160.  Reachable only by a direct call (recon_model stops at the enclosing block)."""
+    from gen_golden_r03 import ATTN_UNET_KW
+    from ldm.modules.diffusionmodules.openaimodel import UNetModel
+    f13 = np.load(os.path.join(HERE, "f13_ldm_attnblock_tiny.npz"), allow_pickle=False)
+
+    def build_attn():
+        m = UNetModel(**ATTN_UNET_KW).eval()
+        m.load_state_dict({k[3:]: torch.from_numpy(f13[k]) for k in f13.files if k.startswith("sd/")})
+        return m
+    out = {"iters": np.array(ITERS), "lr": np.array(LR), "batch_size": np.array(BS)}
+    _family(out, "attnblock/", "f16_attnblock_cali_tiny.npz", build_attn,
+            ("middle_block.1.attention.qkv_matmul", "middle_block.1.attention.smv_matmul", "input_blocks.1.1.attention.qkv_matmul"), 2227, (3, 8, 8), None)
+    save("f26_delta_learning_qk_smv", **out)
+
+
 if __name__ == "__main__":
-    f25()
+    which = sys.argv[1:] or ["f25", "f26"]
+    if "f25" in which:
+        f25()
+    if "f26" in which:
+        f26()

@@ -505,7 +505,7 @@ class LdmUNetEngine(DdimUNetEngine):
             return pout.run(h, residual=x, want_stats=False, out_q8=out_aq)
         return pout.run(h, residual=x, **self._o16())
 
-    def _attn_block(self, p, x):
+    def _attn_block(self, p, x, taps=None):
         """AttentionBlock._forward (openaimodel.py:317-326): un-quantised (Conv1d is not a QuantLayer type)."""
         L = self.layers
         B, H, W, Cc = x.shape
@@ -514,7 +514,10 @@ class LdmUNetEngine(DdimUNetEngine):
         heads = self.cfg["num_heads"] if nhc in (-1, None) else Cc // nhc
         d = Cc // heads
         T = H * W
-        if (self.calib is None and not self.exact_fp and (p + ".attention") not in self.attn_q and qkv_l.kind != "w4a8" and self._fp_conv_half_ok(qkv_l) and ops.attention_f16_ok(d, T)
+        # the matmul seams of QKVAttentionLegacy as reconstruction units (QuantQKMatMul / QuantSMVMatMul, quant_block.py:303-354): their inputs
+        # and outputs exist only in the explicit form below
+        seam = taps is not None and getattr(taps, "stop", None) in (p + ".attention.qkv_matmul", p + ".attention.smv_matmul")
+        if (self.calib is None and not self.exact_fp and not seam and (p + ".attention") not in self.attn_q and qkv_l.kind != "w4a8" and self._fp_conv_half_ok(qkv_l) and ops.attention_f16_ok(d, T)
                 and T % 4 == 0 and os.environ.get("TFMQ_ATTNBLOCK_F16", "1") != "0"):
             # fp16 operands end to end: the GroupNorm writes fp16, the qkv conv writes q | k as fp16 rows and v as fp16 V^T, the flash
             # kernel copies them tile by tile -- the values the fp32-operand kernel below rounds to on load (same products), without
@@ -537,6 +540,8 @@ class LdmUNetEngine(DdimUNetEngine):
         else:
             hn, _ = self._gn(p + ".norm", x, None, False, qkv_l, eps=1e-5)
         qkv = qkv_l.run(hn, want_stats=False).reshape(B, H * W, 3 * Cc)
+        if seam:
+            self._attn_seam_taps(p, qkv, heads, taps)          # (ends the forward: the StopAt dictionary raises at the requested seam)
         # q*s . k*s with s = d^-1/4 (QKMatMul) == (q . k) * d^-1/2
         if (p + ".attention") in self.attn_q:      # QuantQKMatMul / QuantSMVMatMul with use_aq: the quantizers see q, k scaled by d^-1/4 (quant_block.py:318-323)
             o = self._attention_quantised(p + ".attention", qkv[..., :Cc], qkv[..., Cc:2 * Cc], qkv[..., 2 * Cc:], heads, 1.0, pre=float(d ** -0.25))
@@ -545,6 +550,40 @@ class LdmUNetEngine(DdimUNetEngine):
         else:
             o, _ = ops.attention(qkv[..., :Cc], qkv[..., Cc:2 * Cc], qkv[..., 2 * Cc:], heads, float(d ** -0.5))
         return po.run(o.reshape(B, H, W, Cc), residual=x, want_stats=True, **self._o16())
+
+    def _attn_seam_taps(self, p, qkv, heads: int, taps):
+        """taps of the two matmul modules of an AttentionBlock: `<p>.attention.qkv_matmul` = ((q, k), weight) with weight = (q s)(k s)^T,
+        s = d^-1/4 (QuantQKMatMul.forward, quant_block.py:313-328), and `<p>.attention.smv_matmul` = ((softmax(weight), v), a)
+        (QuantSMVMatMul.forward :345-354) -- under the block's live matmul quantizers when the engine was prepared with them.  Layouts:
+        q, k, v [B, T, heads d] (head-major channels), weight [B, heads, T, T], a [B, T, heads d]."""
+        B, T, C3 = qkv.shape
+        Cc = C3 // 3
+        d = Cc // heads
+        pre = float(d ** -0.25)
+        q, k, v = (qkv[..., i * Cc:(i + 1) * Cc].contiguous() for i in range(3))
+        cfg = self.attn_q.get(p + ".attention") or {}            # (one of the two modules may be live alone: q, k or v, w)
+        sel = {w: ops.qsel(self.qtable, cfg[w], self.step) for w in ("q", "k", "v", "w") if w in cfg}
+
+        def scaled(x):
+            xs = ops._alloc_like(x)
+            xs.zero_()
+            ops.axpy(xs, x, pre)
+            return xs
+        qs, ks = scaled(q), scaled(k)
+        if "q" in sel and "k" in sel:
+            qs, ks = ops.fake_quant_sel(qs, sel["q"], 256), ops.fake_quant_sel(ks, sel["k"], 256)
+        S = ops._alloc(B, heads, T, T, dtype=torch.float32, device=qkv.device)
+        ops.gemm_strided(qs, 0, Cc, 1, T * Cc, ks, 0, 1, Cc, T * Cc, S, 0, T, heads * T * T, T, T, d, B, hsa=d, hsb=d, hsc=T * T, heads=heads)
+        taps[p + ".attention.qkv_matmul"] = ((q, k), S)
+        P = ops.softmax_rows(S, 1.0)
+        Ph, vh = P, v
+        if "v" in sel:
+            vh = ops.fake_quant_sel(v, sel["v"], 256)
+        if "w" in sel:
+            Ph = ops.fake_quant_sel(P, sel["w"], cfg["w_level"])
+        o = ops._alloc(B, T, Cc, dtype=torch.float32, device=qkv.device)
+        ops.gemm_strided(Ph, 0, T, 1, heads * T * T, vh, 0, Cc, 1, T * Cc, o, 0, Cc, T * Cc, T, d, T, B, hsa=T * T, hsb=d, hsc=d, heads=heads)
+        taps[p + ".attention.smv_matmul"] = ((P, v), o)
 
     def _seq(self, p, h, skip, ctx, rowadd, taps):
         L = self.layers
@@ -565,7 +604,7 @@ class LdmUNetEngine(DdimUNetEngine):
                 if taps is not None:
                     taps[q] = (hin, h)
             elif (q + ".qkv") in L:
-                h = self._attn_block(q, h)
+                h = self._attn_block(q, h, taps)
                 if taps is not None:
                     taps[q] = (hin, h)
             elif (q + ".op") in L:

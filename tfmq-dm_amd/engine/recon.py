@@ -697,6 +697,73 @@ class DeltaAttnUnit(_DeltaUnit):
         return loss, grads
 
 
+class DeltaQKUnit(_DeltaUnit):
+    """block_reconstruction(use_aq=True) on a QuantQKMatMul (reference quant/reconstruction.py:155-156 on quant_block.py:303-328):
+    weight = aqtizer_q(q s) aqtizer_k(k s)^T with s = d^-1/4; the two deltas are the only parameters.  q, k [N, T, heads d] (head-major
+    channels), target [N, heads, T, T].  The reference's loss sums over dim 1 of [(b h), T, T] and averages the rest: sum / (N heads T)."""
+
+    def __init__(self, q, k, y, heads: int, pre: Optional[float] = None, **kw):
+        super().__init__(**kw)
+        d = q.shape[-1] // heads
+        pre = float(d ** -0.25) if pre is None else float(pre)
+        self.heads = heads
+
+        def scaled(x):
+            xs = torch.zeros_like(x, dtype=torch.float32)
+            ops.axpy(xs, x.float().contiguous(), pre)
+            return xs
+        self.qs, self.ks, self.y = scaled(q), scaled(k), y        # the quantizers see the SCALED tensors (quant_block.py:318-319)
+
+    def _forward_backward(self, idx):
+        qs, ks, y = self.qs.index_select(0, idx), self.ks.index_select(0, idx), self.y.index_select(0, idx)
+        B, T, Cc = qs.shape
+        H, L = self.heads, ks.shape[1]
+        d = Cc // H
+        qh, kh = self.q(0, qs).reshape(B, T, Cc), self.q(1, ks).reshape(B, L, Cc)
+        S = torch.empty(B, H, T, L, dtype=torch.float32, device=qs.device)
+        ops.gemm_strided(qh, 0, Cc, 1, T * Cc, kh, 0, 1, Cc, L * Cc, S, 0, L, H * T * L, T, L, d, B, hsa=d, hsb=d, hsc=T * L, heads=H)
+        loss, g = self._loss(S, y, B * H * L, idx)
+        g = g.contiguous()
+        dQh, dKh = torch.empty_like(qh), torch.empty_like(kh)
+        ops.gemm_strided(g, 0, L, 1, H * T * L, kh, 0, Cc, 1, L * Cc, dQh, 0, Cc, T * Cc, T, d, L, B, hsa=T * L, hsb=d, hsc=d, heads=H)
+        ops.gemm_strided(g, 0, 1, L, H * T * L, qh, 0, Cc, 1, T * Cc, dKh, 0, Cc, L * Cc, L, d, T, B, hsa=T * L, hsb=d, hsc=d, heads=H)
+        grads = [None, None]
+        _, grads[0] = self.q_bwd(0, qs, dQh, want_gx=False)
+        _, grads[1] = self.q_bwd(1, ks, dKh, want_gx=False)
+        return loss, grads
+
+
+class DeltaSMVUnit(_DeltaUnit):
+    """block_reconstruction(use_aq=True) on a QuantSMVMatMul (reference quant/reconstruction.py:157-160 on quant_block.py:331-354):
+    a = aqtizer_w(weight) aqtizer_v(v); deltas [v, w] (w left out when it is a 16-bit quantizer).  weight [N, heads, T, L] (softmax rows),
+    v [N, L, heads d], target [N, T, heads d]; loss = sum / (N heads T) (dim 1 of the reference's [(b h), ch, T] is the channel)."""
+
+    def __init__(self, w, v, y, heads: int, has_w: bool, **kw):
+        super().__init__(**kw)
+        self.wt, self.val, self.y, self.heads, self.has_w = w, v, y, heads, has_w        # (self.v / self.m are Adam's moments)
+
+    def _forward_backward(self, idx):
+        w, v, y = self.wt.index_select(0, idx), self.val.index_select(0, idx).contiguous(), self.y.index_select(0, idx)
+        B, H, T, L = w.shape
+        Cc = v.shape[-1]
+        d = Cc // H
+        vh = self.q(0, v).reshape(B, L, Cc)
+        wh = self.q(1, w).reshape(B, H, T, L) if self.has_w else w.contiguous()
+        o = torch.empty(B, T, Cc, dtype=torch.float32, device=v.device)
+        ops.gemm_strided(wh, 0, L, 1, H * T * L, vh, 0, Cc, 1, L * Cc, o, 0, Cc, T * Cc, T, d, L, B, hsa=T * L, hsb=d, hsc=d, heads=H)
+        loss, g = self._loss(o, y, B * H * T, idx)
+        g = g.contiguous()
+        dVh = torch.empty_like(vh)
+        ops.gemm_strided(wh, 0, 1, L, H * T * L, g, 0, Cc, 1, T * Cc, dVh, 0, Cc, L * Cc, L, d, T, B, hsa=T * L, hsb=d, hsc=d, heads=H)
+        grads = [None] * (2 if self.has_w else 1)
+        _, grads[0] = self.q_bwd(0, v, dVh, want_gx=False)
+        if self.has_w:
+            dWh = torch.empty_like(wh)
+            ops.gemm_strided(g, 0, Cc, 1, T * Cc, vh, 0, 1, Cc, L * Cc, dWh, 0, L, H * T * L, T, L, d, B, hsa=d, hsb=d, hsc=T * L, heads=H)
+            _, grads[1] = self.q_bwd(1, w.contiguous(), dWh, want_gx=False)
+        return loss, grads
+
+
 class DeltaTransformerUnit(_DeltaUnit):
     """QuantBasicTransformerBlock under use_aq=True with the attention-matmul quantizers off: the deltas of its ten QuantLayers
     (module order: attn1.{to_q,to_k,to_v,to_out.0}, ff.net.0.proj, ff.net.2, attn2.{to_q,to_k,to_v,to_out.0}); same dataflow and

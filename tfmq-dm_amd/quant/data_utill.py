@@ -37,7 +37,7 @@ def save_inout(model, layer, cali_data: Tuple[torch.Tensor], asym: bool = False,
     attention block / single layer (x,).  cali_data = (xs, ts) or (xs, ts, cs) for context-conditioned UNets.
     Everything stays on the device (288 GB HBM; the reference spills to host RAM for the largest units,
     calibration.py:62-67)."""
-    from .quant_block import QuantBasicTransformerBlock, QuantResBlock, QuantResnetBlock
+    from .quant_block import QuantBasicTransformerBlock, QuantQKMatMul, QuantResBlock, QuantResnetBlock, QuantSMVMatMul
     name = unit_name(model, layer)
     dev = next(model.model.parameters()).device
     xs, ts = cali_data[0], cali_data[1]
@@ -70,7 +70,7 @@ def save_inout(model, layer, cali_data: Tuple[torch.Tensor], asym: bool = False,
             model.set_quant_state(True, use_act)
             fwd(x, t, c, taps)
         tin = taps[name][0]
-        if isinstance(layer, QuantBasicTransformerBlock):
+        if isinstance(layer, (QuantBasicTransformerBlock, QuantQKMatMul, QuantSMVMatMul)):      # two-input units: (tokens, context) / (q, k) / (weight, v)
             ins.append(tin[0])
             ctxs.append(tin[1])
             continue

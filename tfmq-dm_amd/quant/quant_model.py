@@ -239,7 +239,9 @@ class QuantModel(nn.Module):
             self._tiles = {}
         eng.tiles = self._tiles      # measured tile shapes survive re-lowering (keys are shapes, not weights)
         n_steps = 1 if self._act_table is None else self._act_table.shape[0]
-        aqs = self.attn_quantizers() if act_names else []
+        # (an attention block's matmul quantizers follow the block's OWN hand-set `use_aq`, not the model's quant state: the reference's
+        # set_quant_state only walks QuantLayers, quant_block.py:20-26 -- so they stay live in the FP passes of save_inout too)
+        aqs = self.attn_quantizers()
         attn_q = {}
         for j, (key, role, _, q) in enumerate(aqs):
             attn_q.setdefault(key, {})[role] = len(act_names) + j
@@ -251,7 +253,7 @@ class QuantModel(nn.Module):
         qtable = torch.zeros(n_steps, max(len(act_names) + len(aqs), 1), 2, dtype=torch.float32, device=device)
         if self._act_step is None:
             self._act_step = torch.zeros(1, dtype=torch.int32, device=device)
-        eng.prepare(wq, qtable if act_names else None, self._act_step, attn_q=attn_q or None)   # the step counter also indexes the per-step TIB table
+        eng.prepare(wq, qtable if (act_names or aqs) else None, self._act_step, attn_q=attn_q or None)   # the step counter also indexes the per-step TIB table
         self._plan = (eng, act_names, qtable)
         self._sync_act_params()
         return eng
@@ -259,7 +261,7 @@ class QuantModel(nn.Module):
     def _sync_act_params(self):
         """Module quantizer state (aqtizer.delta / zero_point) -> row(s) of the device table."""
         eng, act_names, qtable = self._plan
-        if not act_names:
+        if not act_names and qtable.shape[1] <= 1 and not self.attn_quantizers():
             return
         if self._act_table is not None:
             qtable.copy_(self._act_table)

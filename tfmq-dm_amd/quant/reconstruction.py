@@ -19,8 +19,8 @@ from tfmq_dm_amd._lib import TfmqError
 from tfmq_dm_amd.engine import recon as R
 from .adaptive_rounding import AdaRoundQuantizer, RMODE
 from .data_utill import save_inout, save_grad
-from .quant_block import (BaseQuantBlock, QuantAttnBlock, QuantBasicTransformerBlock, QuantResBlock, QuantResnetBlock,
-                          QuantTemporalInformationBlock, QuantTemporalInformationBlockDDIM)
+from .quant_block import (BaseQuantBlock, QuantAttnBlock, QuantBasicTransformerBlock, QuantQKMatMul, QuantResBlock, QuantResnetBlock,
+                          QuantSMVMatMul, QuantTemporalInformationBlock, QuantTemporalInformationBlockDDIM)
 from .quant_layer import QuantLayer, StraightThrough
 from .reconstruction_util import RLOSS, LossFunc, LossFuncTimeEmbedding, fisher_mode
 
@@ -111,6 +111,25 @@ class _DeltaSet:
             self.zps.append(zp.detach() if torch.is_tensor(zp) else torch.tensor(float(zp), device=q.delta.device))
             self.levels.append(q.level)
         return tuple(idx)
+
+    def quantizers(self, owner, roles: str) -> int:
+        """aqtizer_<r> of a stand-alone matmul module (QuantQKMatMul: "qk", QuantSMVMatMul: "vw") as trainable deltas, in the reference's
+        order (reconstruction.py:155-160); a 16-bit aqtizer_w is left out.  -> how many were registered."""
+        n = 0
+        for r in roles:
+            q = getattr(owner, f"aqtizer_{r}")
+            if r == "w" and q.level == 2 ** 16:
+                continue
+            if q.delta is None or not bool(q.delta != 0):
+                raise TfmqError("delta-learning reconstruction: a matmul quantizer of the unit is uninitialised (run a forward with its use_aq set first)")
+            self.layers.append(None)
+            self.extra.append((len(self.deltas), q))
+            self.deltas.append(q.delta.data)
+            zp = q.zero_point
+            self.zps.append(zp.detach() if torch.is_tensor(zp) else torch.tensor(float(zp), device=q.delta.device))
+            self.levels.append(q.level)
+            n += 1
+        return n
 
     def kw(self, iters, lr, multi_gpu):
         return dict(deltas=self.deltas, zps=self.zps, levels=self.levels, iters=iters, lr=lr, **_dist_kw(multi_gpu))
@@ -314,6 +333,31 @@ def _block_delta_learning(model, block, cali_data, batch_size, iters, w, opt_mod
         x, ctx = cached_inputs
         norms = [(n.weight.data.float().contiguous(), n.bias.data.float().contiguous()) for n in (block.norm1, block.norm2, block.norm3)]
         unit = R.DeltaTransformerUnit(fl, norms, block.attn1.heads, x, ctx, cached_outputs, attn_q1=a1, attn_q2=a2, **ds.kw(iters, lr, multi_gpu))
+    elif isinstance(block, (QuantQKMatMul, QuantSMVMatMul)):
+        # the matmul seams of the LDM AttentionBlock as units of their own (reference :155-160; reachable by a direct call only): the
+        # deltas of their quantizers are the only parameters.  Fixture F26.
+        qk = isinstance(block, QuantQKMatMul)
+        n = ds.quantizers(block, "qk" if qk else "vw")
+        cached_inputs, cached_outputs = save_inout(model, block, cali_data, asym, True, batch_size, keep_gpu)
+        # The reference's tensors at these seams are [(b h), ...]: its mini-batches draw (sample, head) ROWS, `batch_size` of N * heads
+        # (reconstruction.py:185-189).  The engine's taps are [N, T, heads d] / [N, heads, T, T]: split the heads into rows, in the
+        # reference's row order b * heads + h, and run the units with one head per row.
+        def rows(x, heads):         # [N, T, heads d] -> [N heads, T, d]
+            N_, T_, C_ = x.shape
+            return x.reshape(N_, T_, heads, C_ // heads).permute(0, 2, 1, 3).reshape(N_ * heads, T_, C_ // heads).contiguous()
+        if qk:
+            Hh = cached_outputs.shape[1]
+            S = cached_outputs.reshape(-1, 1, cached_outputs.shape[2], cached_outputs.shape[3]).contiguous()
+            cached_inputs = (rows(cached_inputs[0], Hh), rows(cached_inputs[1], Hh))
+            cached_outputs = S
+            d_head = cached_inputs[0].shape[-1]
+            unit = R.DeltaQKUnit(cached_inputs[0], cached_inputs[1], cached_outputs, 1, pre=float(d_head ** -0.25), **ds.kw(iters, lr, multi_gpu))
+        else:
+            Hh = cached_inputs[0].shape[1]
+            Wt = cached_inputs[0].reshape(-1, 1, cached_inputs[0].shape[2], cached_inputs[0].shape[3]).contiguous()
+            cached_inputs = (Wt, rows(cached_inputs[1], Hh))
+            cached_outputs = rows(cached_outputs, Hh)
+            unit = R.DeltaSMVUnit(cached_inputs[0], cached_inputs[1], cached_outputs, 1, n == 2, **ds.kw(iters, lr, multi_gpu))
     else:
         raise NotImplementedError(f"delta-learning reconstruction of {type(block).__name__} is not built (DESIGN.md section 7)")
     _attach_fisher(unit, model, block, cali_data, opt_mode, asym, True, batch_size, keep_gpu)
