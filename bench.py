@@ -956,7 +956,7 @@ def main():
                                        "reconstruction_units": sum(v["reconstruction_units"] for v in lv.values()),
                                        "note": "8 timestep groups x 128 samples, 20000 iterations per unit, 1 GPU; each level's run repeats the weight "
                                                "initialisation and the Finite-Set pass of the whole UNet"}
-            mname = next((n for n in ("r03_cifar_calibration_full.json", "r02_cifar_calibration_full.json")
+            mname = next((n for n in ("r04_cifar_calibration_full.json", "r03_cifar_calibration_full.json", "r02_cifar_calibration_full.json")
                           if os.path.exists(os.path.join(ROOT, "profiles", n))), "r02_cifar_calibration_full.json")
             mpath = os.path.join(ROOT, "profiles", mname)
             if os.path.exists(mpath):       # the whole CIFAR recipe, measured once end to end with this code (scratch/cifar_cali_full.py)
