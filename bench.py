@@ -99,6 +99,31 @@ def setup_cifar(args, dev, rank, log):
     def fwd():
         eng.forward(sampler.x, None)
 
+    def gelu_exact():
+        """The same sampling with the 5e-7 erf GELU in every fused GEGLU epilogue (TFMQ_GELU_EXACT=1: out_mode 2 of the pointwise kernel, the
+        feed-forward as three launches) instead of the consumer-sized form the metric's run uses (TFMQ_OUT_GEGLU_Q8_FAST: |dPhi| <= 2.8e-5,
+        bins within 1, < 2e-3 of them moved on identical inputs -- tests/test_geglu_fast_gpu.py).  Reported beside `value`."""
+        old = os.environ.get("TFMQ_GELU_EXACT")
+        os.environ["TFMQ_GELU_EXACT"] = "1"
+        try:
+            ms = GraphLatentDdimSampler(eng, S, batch, LAT, CTX, scale=scale, alphas_cumprod=alphas_cumprod_linear()).capture()
+        finally:
+            if old is None:
+                del os.environ["TFMQ_GELU_EXACT"]
+            else:
+                os.environ["TFMQ_GELU_EXACT"] = old
+        args_ = (x_T,) if CTX is None else (x_T, cond, uncond)
+        ms.sample_nhwc(*args_)
+        ms.stream.synchronize()
+        t0 = time.perf_counter()
+        out = ms.sample_nhwc(*args_)
+        ms.stream.synchronize()
+        dt = time.perf_counter() - t0
+        ref = sampler.x.float()
+        rel = float((out.float() - ref).norm() / ref.norm()) if sampler.gid is not None else None
+        return {"images_per_s": round(batch / dt, 3), "final_latents_rel_l2_vs_metric_run": None if rel is None else round(rel, 5),
+                "note": "TFMQ_GELU_EXACT=1: erf-form GELU (|error| <= 5e-7) in the GEGLU epilogues, feed-forward as three launches; one sampling after a warm one"}
+
     def cpu():
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         import tfmq_oracle as O
@@ -311,6 +336,8 @@ def setup_sd(args, dev, rank, log, preset="sd"):
             ex.prepare(wq, eng.qtable, torch.zeros(1, dtype=torch.int32, device=dev))
             exact = run_engine(ex)
             res["eps_rel_l2_exact"] = [round(rel(a, b), 5) for a, b in zip(exact, eps_ref)]
+            res["gelu"] = {"fast_leg": "consumer-sized GELU (TFMQ_OUT_GEGLU_Q8_FAST), as in the timed region",
+                           "exact_leg": "erf form, |error| <= 5e-7 (the exact-fp engine passes geglu_exact; round 5)"}
             xin, tt, cin_ = inputs[0]
             nb = 16
             xb = torch.randn(nb, LH, LW, LC, device=dev)
@@ -378,7 +405,7 @@ def setup_sd(args, dev, rank, log, preset="sd"):
 
     info = dict(batch=batch, sync=sampler.stream.synchronize, finite=lambda: bool(torch.isfinite(sampler.x).all().item()),
                 stream=sampler.stream, step=eng.step, sampler=sampler, inputs=(x_T, cond, uncond),
-                new_sampler=lambda: GraphLatentDdimSampler(eng, S, batch, LAT, CTX, scale=scale, alphas_cumprod=alphas_cumprod_linear()), plms=plms, sweep=sweep, parity=parity, materialised=materialised if CTX is not None and sampler.pair_prefix else None,
+                new_sampler=lambda: GraphLatentDdimSampler(eng, S, batch, LAT, CTX, scale=scale, alphas_cumprod=alphas_cumprod_linear()), plms=plms, sweep=sweep, parity=parity, gelu_exact=gelu_exact, materialised=materialised if CTX is not None and sampler.pair_prefix else None,
                 oracle_state=dict(sd=sd, wq=wq, act_names=act_names, cfg=cfg, eng=eng),     # scratch/sd_parity_full.py
                 workload=(f"{P['name']} ({n_params:.1f}M) w4a8 on MI355X: {LH}x{LW}x{LC} latents, DDIM-{S} eta=0, "
                           + (f"CFG {scale} (UNet batch 2x{batch}), {CTX[0]}x{CTX[1]} context, " if CTX is not None else "unconditional, ")
@@ -599,6 +626,11 @@ def run_cali_workload(args, dev, rank, local_rank, world, log):
     kw = dict(iters=ITERS, batch_size=8, w=0.01, asym=True, warmup=0.2, opt_mode=RLOSS.MSE)
     if args.cali_only:
         QC.ONLY_UNITS = tuple(p for p in args.cali_only.split(",") if p)
+    # roofline of the calibration half: HIP events around a bounded SAMPLE of the tfmq_gemm_f32 launches of the job (every
+    # n-th launch, at most 2048 -- reconstruction forwards / backwards and the capture passes' exact-fp32 GEMMs alike), on their launch stream
+    import tfmq_dm_amd.ops as ops
+    gemm_rec = []
+    ops.set_gemm_profile(gemm_rec, every=max(1, (74 if not args.cali_only else 8) * ITERS * 20 // 2048), cap=2048)
     torch.cuda.synchronize()
     if world > 1:
         import torch.distributed as dist
@@ -621,6 +653,7 @@ def run_cali_workload(args, dev, rank, local_rank, world, log):
         dist.barrier()
     dt = time.perf_counter() - t0 + acc.get("generate_cali_text_guided_data", 0.0)
     QC.ONLY_UNITS = None
+    ops.set_gemm_profile(None)
     if world > 1:
         tt = torch.tensor([dt], device="cpu" if ONE_DEVICE else dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -631,7 +664,27 @@ def run_cali_workload(args, dev, rank, local_rank, world, log):
     n_units = calls["tib_reconstruction"] + calls["block_reconstruction"] + calls["layer_reconstruction"]
     rec_s = acc["tib_reconstruction"] + acc["block_reconstruction"] + acc["layer_reconstruction"]
     finite = all(bool(torch.isfinite(v).all()) for v in ck["weight"].values() if torch.is_tensor(v) and v.is_floating_point())
+    mode = os.environ.get("TFMQ_RECON_GEMM", "bf16x3")
+    # 2.5 PFLOP/s dense bf16 / f16 MFMA (MI355X_MICROARCH.md); bf16x3 spends three MFMAs per fp32 product; exact fp32 products run at the vector rate
+    peak = {"bf16x3": 2500.0 / 3.0, "f16": 2500.0, "f32": 157.3}.get(mode, 2500.0 / 3.0)
+    big = [(ops.event_elapsed_ms(e0, e1, dev.index or 0), fl, sh) for (e0, e1, fl, sh) in gemm_rec]
+    roof = None
+    if big:
+        tot_ms, tot_fl = sum(b[0] for b in big), sum(b[1] for b in big)
+        lg = [b for b in big if b[1] >= 2e9]           # the conv / Linear products of the units (per-head attention products are far smaller)
+        lg_ms, lg_fl = sum(b[0] for b in lg), sum(b[1] for b in lg)
+        ach = tot_fl / (tot_ms * 1e-3) / 1e12 if tot_ms > 0 else 0.0
+        roof = {"bound": "mfma", "kernel": ("tfmq_gemm_f32 (csrc/gemm_f32_mfma.hip: k_gemm_bx3 -- bf16x3 operands split once per block into LDS, 128 x 128 tiles -- for "
+                                            "the reconstruction iterations; k_gemm_f32_mfma for exact-fp32 products and skinny shapes)"),
+                "achieved": round(ach, 1), "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None,
+                "peak_note": ("2.5 PFLOP/s dense bf16 MFMA / 3 MFMAs per fp32 product (hi hi' + hi lo' + lo hi')" if mode == "bf16x3" else f"operand mode {mode}"),
+                "launches_timed": len(big), "sampled": "every n-th tfmq_gemm_f32 launch of the whole job (capture passes included), HIP events on the launch stream",
+                "avg_launch_us": round(tot_ms * 1e3 / len(big), 2),
+                "launches_of_2_GFLOP_or_more": {"n": len(lg), "achieved": round(lg_fl / (lg_ms * 1e-3) / 1e12, 1) if lg_ms > 0 else None,
+                                                "frac": round(lg_fl / (lg_ms * 1e-3) / 1e12 / peak, 4) if lg_ms > 0 else None,
+                                                "share_of_sampled_gemm_time": round(lg_ms / tot_ms, 3) if tot_ms > 0 else None}}
     return {
+        "roofline": roof,
         "metric": "w4a8 calibration wall-clock, SD-v1-4 UNet (reduced recipe, see config)", "value": round(dt, 2), "unit": "s",
         "n_gpus": world, "steps": 1, "warmup": 0, "ms_per_step": round(dt * 1e3, 1), "higher_is_better": False,
         "scaling": "strong" if world > 1 else "weak", "vs_baseline": None,
@@ -984,6 +1037,13 @@ def main():
                 out["parity"] = {"error": f"{type(e).__name__}: {e}"}
         if world == 1 and not args.no_cpu_baseline and info.get("materialised") is not None:
             out["guidance_pair_materialised"] = info["materialised"]()
+        if world == 1 and not args.no_cpu_baseline and info.get("gelu_exact") is not None:
+            try:
+                ge = info["gelu_exact"]()
+                out["value_gelu_exact"] = ge["images_per_s"]
+                out["gelu_exact"] = ge
+            except Exception as e:      # noqa: BLE001 -- a side leg must not take the line down
+                out["gelu_exact"] = {"error": f"{type(e).__name__}: {e}"}
         if world == 1 and args.workload == "sd" and not args.no_cpu_baseline and args.batch in (0, 64) and "sweep" in info:
             out["batch_sweep"] = info["sweep"]()
         emit(out)

@@ -378,6 +378,12 @@ __device__ __forceinline__ float vmax3(float a, float b, float c) {
   asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
   return r;
 }
+// (volatile: keeps its place behind the volatile s_nop padding that separates it from the MFMAs whose results it reads)
+__device__ __forceinline__ float vmax3v(float a, float b, float c) {
+  float r;
+  asm volatile("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
 __device__ __forceinline__ void glds16_s(const void* sbase, unsigned voff, unsigned lds_dst) {
   // lane l: 16 bytes from sbase + voff(l) -> LDS byte lds_dst + 16 l
   unsigned keep;
@@ -393,7 +399,30 @@ __device__ __forceinline__ void glds16_s(const void* sbase, unsigned voff, unsig
 // DBG (timing-only ablations, results are garbage): 1 no exp2, 2 no PV MFMAs, 4 no score MFMAs, 8 no fragment reads, 16 no max tree,
 // 32 no fp16 packing, 64 no DMA, 128 no sched_group_barrier, 256 no barrier / waits
 // NW = waves per block (32 queries each): 4, or 8 -- half the DMA instructions and L2 -> LDS bytes per query, one barrier for both waves of a SIMD
-template <int NW, int DBG = 0, int OCC = 2>
+// ACC (round 5): the P V accumulators live in AccVGPRs, o[0] = a[0:15], o[1] = a[16:31] BY NAME (physical-register constraints on
+// non-volatile inline-asm MFMAs, so the scheduler still moves them and no copy is ever made: with "+a" the register allocator kept the
+// loop-carried value in arch VGPRs and moved 32 registers in and out per key tile; in round 3 it split the budget 128 : 128 and spilled).
+// The score accumulators -- which the softmax reads with VALU instructions -- stay in arch VGPRs.  scratch/ubench/mfma_valu_overlap.hip:
+// six plain VALU instructions hide beside an MFMA whose accumulator is an AccVGPR tuple, four beside the arch-VGPR form.
+template <bool ACC, int TT>
+__device__ __forceinline__ void pv_mfma(v16f& o, const v8h& a, const v8h& b) {
+  if constexpr (!ACC) o = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, o, 0, 0, 0);
+  else if constexpr (TT == 0) asm("v_mfma_f32_32x32x16_f16 a[0:15], %1, %2, a[0:15]" : "+{a[0:15]}"(o) : "v"(a), "v"(b));
+  else asm("v_mfma_f32_32x32x16_f16 a[16:31], %1, %2, a[16:31]" : "+{a[16:31]}"(o) : "v"(a), "v"(b));
+}
+// O *= alpha on the named AccVGPRs (the rare rescale branch); wait states around it by hand: the compiler does not know the producers are MFMAs
+#define TFMQ_ACC_SCALE1(R) "v_accvgpr_read_b32 %2, a" #R "\n\tv_mul_f32 %2, %2, %3\n\tv_accvgpr_write_b32 a" #R ", %2\n\t"
+#define TFMQ_ACC_SCALE4(A, B, C, D) TFMQ_ACC_SCALE1(A) TFMQ_ACC_SCALE1(B) TFMQ_ACC_SCALE1(C) TFMQ_ACC_SCALE1(D)
+__device__ __forceinline__ void acc_scale32(v16f& o0, v16f& o1, float alpha) {
+  float tmp;
+  asm volatile("s_nop 15\n\ts_nop 3\n\t"
+               TFMQ_ACC_SCALE4(0, 1, 2, 3) TFMQ_ACC_SCALE4(4, 5, 6, 7) TFMQ_ACC_SCALE4(8, 9, 10, 11) TFMQ_ACC_SCALE4(12, 13, 14, 15)
+               TFMQ_ACC_SCALE4(16, 17, 18, 19) TFMQ_ACC_SCALE4(20, 21, 22, 23) TFMQ_ACC_SCALE4(24, 25, 26, 27) TFMQ_ACC_SCALE4(28, 29, 30, 31)
+               "s_nop 7"
+               : "+{a[0:15]}"(o0), "+{a[16:31]}"(o1), "=&v"(tmp)
+               : "v"(alpha));
+}
+template <int NW, int DBG = 0, int OCC = 2, bool ACC = false>
 __global__ __launch_bounds__(64 * NW, OCC) void k_attention_d40(AttnHP p) {
   constexpr int NTH = 64 * NW, QB = 32 * NW;
   constexpr int NSLOT = (10 + NW - 1) / NW, NFULL = 10 % NW;      // DMA wave-instructions per wave: NSLOT for waves < NFULL, else NSLOT - 1
@@ -513,6 +542,7 @@ __global__ __launch_bounds__(64 * NW, OCC) void k_attention_d40(AttnHP p) {
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
 
   auto row_max = [&](const v16f (&s)[2]) {
+    auto vmax3 = [](float a, float b, float c) { return ACC ? vmax3v(a, b, c) : ::vmax3(a, b, c); };
     float m0 = vmax3(s[0][0], s[0][1], s[0][2]), m1 = vmax3(s[0][3], s[0][4], s[0][5]);
     float m2 = vmax3(s[1][0], s[1][1], s[1][2]), m3 = vmax3(s[1][3], s[1][4], s[1][5]);
     m0 = vmax3(m0, s[0][6], s[0][7]);   m1 = vmax3(m1, s[0][8], s[0][9]);
@@ -573,6 +603,70 @@ __global__ __launch_bounds__(64 * NW, OCC) void k_attention_d40(AttnHP p) {
       }
     }
     // ---- block 1: P V of tile t-1  ||  row maximum of tile t, its first NE1 exponentials
+    float mx;
+    float pe[32];                          // P in fp32
+    if constexpr (ACC) {
+      // The inline-asm MFMAs are opaque to the scheduler (it clumps them): the interleave is written out, one MFMA per group with ~7-8
+      // issue slots of VALU work behind it (an exponential takes two), groups fenced by sched_barrier.  The first exponentials are ordinary
+      // instructions -- the compiler counts their distance to the score MFMAs of the previous iteration itself -- and the asm maximum tree
+      // sits behind them, so it needs no s_nop padding of its own.
+      auto bfrag = [&](int u) {
+        v8h bp;
+        unsigned* bw = reinterpret_cast<unsigned*>(&bp);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) bw[e] = pp[4 * u + e];
+        return bp;
+      };
+      auto ex = [&](int i) { pe[i] = __builtin_amdgcn_exp2f(sc[i >> 4][i & 15]); };
+      float m0, m1, m2, m3;
+      pv_mfma<true, 0>(o[0], vf[0][0], bfrag(0));
+      __builtin_amdgcn_sched_barrier(0);
+      ex(0); ex(1);
+      __builtin_amdgcn_sched_barrier(0);
+      m0 = vmax3v(sc[0][0], sc[0][1], sc[0][2]); m1 = vmax3v(sc[0][3], sc[0][4], sc[0][5]);
+      m2 = vmax3v(sc[1][0], sc[1][1], sc[1][2]); m3 = vmax3v(sc[1][3], sc[1][4], sc[1][5]);
+      __builtin_amdgcn_sched_barrier(0);
+      pv_mfma<true, 1>(o[1], vf[0][1], bfrag(0));
+      __builtin_amdgcn_sched_barrier(0);
+      m0 = vmax3v(m0, sc[0][6], sc[0][7]); m1 = vmax3v(m1, sc[0][8], sc[0][9]);
+      m2 = vmax3v(m2, sc[1][6], sc[1][7]); m3 = vmax3v(m3, sc[1][8], sc[1][9]);
+      ex(2);
+      __builtin_amdgcn_sched_barrier(0);
+      pv_mfma<true, 0>(o[0], vf[1][0], bfrag(1));
+      __builtin_amdgcn_sched_barrier(0);
+      m0 = vmax3v(m0, sc[0][10], sc[0][11]); m1 = vmax3v(m1, sc[0][12], sc[0][13]);
+      m2 = vmax3v(m2, sc[1][10], sc[1][11]); m3 = vmax3v(m3, sc[1][12], sc[1][13]);
+      ex(3); ex(4);
+      __builtin_amdgcn_sched_barrier(0);
+      pv_mfma<true, 1>(o[1], vf[1][1], bfrag(1));
+      __builtin_amdgcn_sched_barrier(0);
+      m0 = vmax3v(m0, sc[0][14], sc[0][15]); m2 = vmax3v(m2, sc[1][14], sc[1][15]);
+      m0 = vmax3v(m0, m1, m2);
+      ex(5); ex(6);
+      __builtin_amdgcn_sched_barrier(0);
+      pv_mfma<true, 0>(o[0], vf[2][0], bfrag(2));
+      __builtin_amdgcn_sched_barrier(0);
+      m0 = vmax3v(m0, m3, m3);
+      {
+        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(m0), __float_as_uint(m0), false, false);
+        mx = vmax3v(__uint_as_float(sw[0]), __uint_as_float(sw[1]), __uint_as_float(sw[1]));
+      }
+      ex(7); ex(8);
+      __builtin_amdgcn_sched_barrier(0);
+      pv_mfma<true, 1>(o[1], vf[2][1], bfrag(2));
+      __builtin_amdgcn_sched_barrier(0);
+      ex(9); ex(10); ex(11); ex(12);
+      __builtin_amdgcn_sched_barrier(0);
+      pv_mfma<true, 0>(o[0], vf[3][0], bfrag(3));
+      __builtin_amdgcn_sched_barrier(0);
+      ex(13); ex(14); ex(15); ex(16);
+      __builtin_amdgcn_sched_barrier(0);
+      pv_mfma<true, 1>(o[1], vf[3][1], bfrag(3));
+      __builtin_amdgcn_sched_barrier(0);
+      ex(17); ex(18); ex(19);
+      __builtin_amdgcn_sched_barrier(0);
+      static_assert(NE1 == 20, "the written-out interleave takes 20 exponentials in front of the rescale decision");
+    } else {
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       v8h bp;
@@ -585,18 +679,17 @@ __global__ __launch_bounds__(64 * NW, OCC) void k_attention_d40(AttnHP p) {
         else o[tt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[u][tt], bp, o[tt], 0, 0, 0);
       }
     }
-    float mx;
     // The maximum tree is inline asm (v_max3_f32 without the compiler's canonicalising v_max): the compiler's hazard recogniser does not
     // know that these statements READ registers an MFMA wrote (11 wait states after an 8-pass MFMA).  The barrier and the DMA issue lie
     // in between, except in the last iterations, which issue no DMA: pad.
     asm volatile("s_nop 7");
     if constexpr (DBG & 16) mx = sc[0][3] + sc[1][5];
     else mx = row_max(sc);
-    float pe[32];                          // P in fp32
 #pragma unroll
     for (int i = 0; i < NE1; ++i) {
       if constexpr (DBG & 1) pe[i] = sc[i >> 4][i & 15];
       else pe[i] = __builtin_amdgcn_exp2f(sc[i >> 4][i & 15]);
+    }
     }
     if constexpr (DBG & 128) {
       // interleave: the K fragment reads first, then per MFMA two exponentials and three plain VALU instructions of the maximum tree
@@ -616,10 +709,13 @@ __global__ __launch_bounds__(64 * NW, OCC) void k_attention_d40(AttnHP p) {
       for (int i = 0; i < 32; ++i) sc[i >> 4][i & 15] -= delta;
 #pragma unroll
       for (int i = 0; i < NE1; ++i) pe[i] = __builtin_amdgcn_exp2f(sc[i >> 4][i & 15]);
+      if constexpr (ACC) acc_scale32(o[0], o[1], alpha);
+      else {
 #pragma unroll
-      for (int tt = 0; tt < 2; ++tt)
+        for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) o[tt][r] *= alpha;
+          for (int r = 0; r < 16; ++r) o[tt][r] *= alpha;
+      }
       m_run = m_new;
       if (hh) qf[ksb][qe] = static_cast<_Float16>(-m_run);
     }
@@ -705,9 +801,10 @@ __global__ __launch_bounds__(64 * NW, OCC) void k_attention_d40(AttnHP p) {
     unsigned* bw = reinterpret_cast<unsigned*>(&bp);
 #pragma unroll
     for (int e = 0; e < 4; ++e) bw[e] = pp[4 * u + e];
-#pragma unroll
-    for (int tt = 0; tt < 2; ++tt) o[tt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[u][tt], bp, o[tt], 0, 0, 0);
+    pv_mfma<ACC, 0>(o[0], vf[u][0], bp);
+    pv_mfma<ACC, 1>(o[1], vf[u][1], bp);
   }
+  if constexpr (ACC) asm volatile("s_nop 15\n\ts_nop 3" : "+{a[0:15]}"(o[0]), "+{a[16:31]}"(o[1]));
 
   // ---- normalise and store (as k_attention_h): lane (query j, half hh) owns channels t*32 + (r&3) + 8*(r>>2) + 4*hh;
   // the denominator sits in output row 40 = tile 1, lanes of the lower half, register 4
@@ -760,7 +857,9 @@ static int launch_attn_d40(tfmq_handle h, const AttnHP& p, void* stream) {
   TFMQ_ABL(1) TFMQ_ABL(2) TFMQ_ABL(4) TFMQ_ABL(6) TFMQ_ABL(8) TFMQ_ABL(16) TFMQ_ABL(32) TFMQ_ABL(64) TFMQ_ABL(49) TFMQ_ABL(14) TFMQ_ABL(78) TFMQ_ABL(128) TFMQ_ABL(328) TFMQ_ABL(456) TFMQ_ABL(320) TFMQ_ABL(256) TFMQ_ABL(72) TFMQ_ABL(2048) TFMQ_ABL(4096) TFMQ_ABL(6144)
   if (dbg == 1000) { hipLaunchKernelGGL((k_attention_d40<4, 0, 3>), grid, dim3(256), 0, as_stream(stream), p); TFMQ_LAUNCH_CHECK(h); return TFMQ_OK; }
 #endif
-  hipLaunchKernelGGL((k_attention_d40<4>), grid, dim3(256), 0, as_stream(stream), p);
+  static const int acc = getenv("TFMQ_ATTN_ACC") ? atoi(getenv("TFMQ_ATTN_ACC")) : 0;
+  if (acc) hipLaunchKernelGGL((k_attention_d40<4, 0, 1, true>), grid, dim3(256), 0, as_stream(stream), p);
+  else hipLaunchKernelGGL((k_attention_d40<4>), grid, dim3(256), 0, as_stream(stream), p);
   TFMQ_LAUNCH_CHECK(h);
   return TFMQ_OK;
 }

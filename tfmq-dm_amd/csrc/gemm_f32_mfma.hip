@@ -406,6 +406,243 @@ __global__ __launch_bounds__(256, (WM_TILES * WN_TILES > 2) ? 2 : (BK == 32 ? 3 
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// K15b (round 5): the bf16x3 GEMM with the hi / lo split done ONCE PER BLOCK, on the way into LDS.
+//
+// k_gemm_f32_mfma<..., PREC = 1> keeps fp32 tiles in LDS and splits every fragment in registers in front of its MFMAs: with 1 x 2 MFMA tiles per
+// wave that is 72 conversion instructions beside 6 MFMAs per K-step -- 12 VALU per MFMA where about four hide -- and the
+// kernel ran at 165-195 TFLOP/s = 0.20-0.23 of the 833 TFLOP/s three bf16 MFMAs per product allow.  Here
+//   * a 128 x 128 tile on 4 waves, 2 x 2 MFMA tiles per wave, K-step 32 (two MFMA k-steps): 24 MFMAs per wave and step;
+//   * the loading thread splits its 16 values per operand and step (hi = bf16(a), lo = bf16(a - hi): v_cvt_pk_bf16_f32, shift, subtract,
+//     v_cvt_pk_bf16_f32 = 3 instructions per value, 96 per thread and step beside the 24 MFMAs) and stores the two planes of a row side by
+//     side: LDS row = [hi k0..31 | lo k0..31] = 128 bytes, the eight 16-byte slots XOR-swizzled with row bits 0-2 (swz_rk<32>'s scheme);
+//   * a fragment is one ds_read_b128 per plane (8 bf16 = the k-octet lane half hh owes the 16-wide MFMA): 16 reads per 24 MFMAs, no VALU;
+//   * loads as in the kernel above: 16-byte buffer loads two K-steps ahead in two register sets (out-of-range items read zeros), along k
+//     (MODE 1: a thread owns two k-octets of a row -> two ds_write_b128 per plane) or along rows (MODE 2: a thread owns 4 rows x 4 k, the
+//     4 x 4 transpose is register naming -> four ds_write_b64 per plane).
+// Same split, same three products per k-octet (small terms first), fp32 accumulation: the error bound of PREC = 1 (2^-16 per product);
+// the k order inside a 16-wide MFMA differs from the kernel above, so results agree to fp32 rounding, not bit for bit.
+typedef __bf16 v2bf __attribute__((ext_vector_type(2)));
+typedef float v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void bx3_split2(float x0, float x1, unsigned& hi, unsigned& lo) {
+  const v2bf h = __builtin_convertvector(v2f{x0, x1}, v2bf);
+  hi = __builtin_bit_cast(unsigned, h);
+  const float h0 = __uint_as_float(hi << 16), h1 = __uint_as_float(hi & 0xffff0000u);
+  const v2bf l = __builtin_convertvector(v2f{x0 - h0, x1 - h1}, v2bf);
+  lo = __builtin_bit_cast(unsigned, l);
+}
+// byte offset of 16-byte slot `slot` (0-3 hi octets, 4-7 lo octets) of row `row` in a [128 rows][128 B] bx3 tile
+__device__ __forceinline__ int bx3_off(int row, int slot) { return row * 128 + ((slot ^ (row & 7)) << 4); }
+
+template <int MODE>
+struct Bx3Loader {
+  static constexpr int NU = MODE == 1 ? 2 : 1;     // units per thread: MODE 1 (row, k-octet) x 2, MODE 2 (row quad, k quad) x 1
+  float4 reg[2][4];
+  __amdgpu_buffer_rsrc_t rsrc;
+  unsigned off[NU];                                // byte offset of the unit at the slice's first K-step; 0x80000000 (out of range: zeros) for rows past the operand
+  unsigned kstep, kone;                            // bytes per K-step; MODE 2: bytes per k
+  __device__ __forceinline__ void init(const float* b, long rs, long ks, int r0, int kb, int rows, int K) {
+    const int tid = threadIdx.x;
+    if constexpr (MODE == 1) {
+      rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(b), 0, static_cast<int>(((rows - 1) * rs + K) * 4), 0x00020000);
+      kstep = 32 * 4;
+      kone = 4;
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int e = tid + 256 * u, gr = r0 + (e >> 2);
+        off[u] = gr < rows ? static_cast<unsigned>(gr * rs + kb + (e & 3) * 8) * 4u : 0x80000000u;
+      }
+    } else {
+      rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(b), 0, static_cast<int>(((K - 1) * ks + rows) * 4), 0x00020000);
+      kstep = static_cast<unsigned>(32 * ks) * 4u;
+      kone = static_cast<unsigned>(ks) * 4u;
+      const int gr = r0 + (tid & 31) * 4;
+      off[0] = gr < rows ? static_cast<unsigned>((kb + (tid >> 5) * 4) * ks + gr) * 4u : 0x80000000u;
+    }
+  }
+  // k (relative to the K-step's first k) of the first value of item j
+  __device__ __forceinline__ int item_k(int j) const {
+    if constexpr (MODE == 1) return (threadIdx.x & 3) * 8 + (j & 1) * 4;
+    else return (threadIdx.x >> 5) * 4 + j;
+  }
+  // K-step `step` of the slice.  CHECKED = false: every k of the step is inside the slice -- the per-thread offsets never change, the step
+  // rides in the SCALAR offset of the buffer instruction (no VALU address arithmetic in the loop; with it the compiler put the temporaries
+  // into the destination registers of the loads still in flight and waited vmcnt(0) at the top of every step).  CHECKED = true (the last
+  // steps of a slice and the prefetches past it): items whose k lies outside get the out-of-range offset and read zeros.
+  template <int S, bool CHECKED>
+  __device__ __forceinline__ void load(int step, int klen) {
+    const unsigned sb = static_cast<unsigned>(step) * kstep;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int u = MODE == 1 ? (j >> 1) : 0;
+      const unsigned o = off[u] + (MODE == 1 ? static_cast<unsigned>((j & 1) * 16) : static_cast<unsigned>(j) * kone);
+      v4i32 v;
+      if constexpr (CHECKED) {
+        const bool ok = step * 32 + item_k(j) < klen;
+        v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, ok ? o + sb : 0x80000000u, 0, 0);
+      } else {
+        v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, o, static_cast<int>(sb), 0);
+      }
+      reg[S][j] = __builtin_bit_cast(float4, v);
+    }
+  }
+  template <int S>
+  __device__ __forceinline__ void store(unsigned char* lds) {
+    const int tid = threadIdx.x;
+    if constexpr (MODE == 1) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int e = tid + 256 * u, row = e >> 2, oct = e & 3;
+        const float4 a = reg[S][2 * u], b = reg[S][2 * u + 1];
+        uint4 hi, lo;
+        bx3_split2(a.x, a.y, hi.x, lo.x);
+        bx3_split2(a.z, a.w, hi.y, lo.y);
+        bx3_split2(b.x, b.y, hi.z, lo.z);
+        bx3_split2(b.z, b.w, hi.w, lo.w);
+        *reinterpret_cast<uint4*>(lds + bx3_off(row, oct)) = hi;
+        *reinterpret_cast<uint4*>(lds + bx3_off(row, 4 + oct)) = lo;
+      }
+    } else {
+      const int rq = tid & 31, kq4 = tid >> 5;
+      const float r[4][4] = {{reg[S][0].x, reg[S][1].x, reg[S][2].x, reg[S][3].x}, {reg[S][0].y, reg[S][1].y, reg[S][2].y, reg[S][3].y},
+                             {reg[S][0].z, reg[S][1].z, reg[S][2].z, reg[S][3].z}, {reg[S][0].w, reg[S][1].w, reg[S][2].w, reg[S][3].w}};
+#pragma unroll
+      for (int ri = 0; ri < 4; ++ri) {
+        const int row = rq * 4 + ri;
+        uint2 hi, lo;
+        bx3_split2(r[ri][0], r[ri][1], hi.x, lo.x);
+        bx3_split2(r[ri][2], r[ri][3], hi.y, lo.y);
+        *reinterpret_cast<uint2*>(lds + bx3_off(row, kq4 >> 1) + (kq4 & 1) * 8) = hi;
+        *reinterpret_cast<uint2*>(lds + bx3_off(row, 4 + (kq4 >> 1)) + (kq4 & 1) * 8) = lo;
+      }
+    }
+  }
+};
+
+template <int MA, int MB>
+__global__ __launch_bounds__(256, 2) void k_gemm_bx3(GemmP p) {
+  constexpr int BM = 128, BN = 128, BK = 32, TILE = 128 * 128;
+  __shared__ __attribute__((aligned(128))) unsigned char smem[4 * TILE];      // A[2] | B[2]: 64 KiB, two blocks per CU
+  int bz = blockIdx.z, kb = 0, ke = p.K;
+  if (p.ksplit > 1) {
+    const int sp = bz % p.ksplit;
+    bz /= p.ksplit;
+    kb = sp * p.kchunk;
+    ke = kb + p.kchunk < p.K ? kb + p.kchunk : p.K;
+  }
+  const float* A = p.A + p.off_a(bz);
+  const float* B = p.B + p.off_b(bz);
+  float* C = p.C + p.off_c(bz);
+  int tile = blockIdx.x;
+  if (p.tiles_n > 0) {      // XCD-aware tile order (as above)
+    const int nb = gridDim.x, xcd = tile & 7, q = nb >> 3, r = nb & 7;
+    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (tile >> 3);
+  }
+  const int tn = p.tiles_n > 0 ? p.tiles_n : -p.tiles_n;
+  const int m0 = (tile / tn) * BM, n0 = (tile % tn) * BN;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid >> 1, wn = wid & 1;
+  const int l32 = lane & 31, hh = lane >> 5;
+
+  Bx3Loader<MA> la;
+  Bx3Loader<MB> lb;
+  la.init(A, p.sam, p.sak, m0, kb, p.M, p.K);
+  lb.init(B, p.sbn, p.sbk, n0, kb, p.N, p.K);
+
+  v16f acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+  const int klen = ke - kb, nk = (klen + BK - 1) / BK, nfull = klen / BK;
+  la.template load<0, true>(0, klen);
+  lb.template load<0, true>(0, klen);
+  la.template load<1, true>(1, klen);
+  lb.template load<1, true>(1, klen);
+  la.template store<0>(smem);
+  lb.template store<0>(smem + 2 * TILE);
+  __syncthreads();
+  // fragment rows of this lane (row bits 0-2 = l32 bits 0-2 for every tile: one swizzle term)
+  const int ra = (wm * 2) * 32 + l32, rb = (wn * 2) * 32 + l32;
+  auto step = [&](int s, auto par_tag, auto chk_tag) {
+    constexpr int PAR = decltype(par_tag)::value;
+    constexpr bool CHK = decltype(chk_tag)::value;
+#ifndef TFMQ_DBG_GEMM_NO_LOAD
+    la.template load<PAR, CHK>(s + 2, klen);
+    lb.template load<PAR, CHK>(s + 2, klen);
+    __builtin_amdgcn_sched_barrier(0);   // the loads stay first in the step
+#endif
+    const unsigned char* a_b = smem + PAR * TILE;
+    const unsigned char* b_b = smem + (2 + PAR) * TILE;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      v8bf ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        ah[i] = *reinterpret_cast<const v8bf*>(a_b + bx3_off(ra + 32 * i, 2 * ks + hh));
+        al[i] = *reinterpret_cast<const v8bf*>(a_b + bx3_off(ra + 32 * i, 4 + 2 * ks + hh));
+        bh[i] = *reinterpret_cast<const v8bf*>(b_b + bx3_off(rb + 32 * i, 2 * ks + hh));
+        bl[i] = *reinterpret_cast<const v8bf*>(b_b + bx3_off(rb + 32 * i, 4 + 2 * ks + hh));
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          // small terms first: they are not absorbed by the large partial sum's rounding
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+        }
+#ifndef TFMQ_DBG_GEMM_NO_STORE
+      // the next K-step's tile (loaded one step ago) is split and stored to the other buffer under the second half's MFMAs
+      if (ks == 0) {
+        la.template store<PAR ^ 1>(smem + (PAR ^ 1) * TILE);
+        lb.template store<PAR ^ 1>(smem + (2 + (PAR ^ 1)) * TILE);
+      }
+#endif
+    }
+    __syncthreads();
+  };
+  int s = 0;
+  for (; s + 3 < nfull; s += 2) {        // both steps' prefetches (s + 2, s + 3) are whole K-steps of the slice
+    step(s, std::integral_constant<int, 0>{}, std::false_type{});
+    step(s + 1, std::integral_constant<int, 1>{}, std::false_type{});
+  }
+  for (; s < nk; s += 2) {
+    step(s, std::integral_constant<int, 0>{}, std::true_type{});
+    if (s + 1 < nk) step(s + 1, std::integral_constant<int, 1>{}, std::true_type{});
+  }
+
+  // C/D layout: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)   (the epilogue of k_gemm_f32_mfma)
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int n = n0 + (wn * 2 + j) * 32 + l32;
+      if (n >= p.N) continue;
+      const float bv = p.bias ? p.bias[n] : 0.0f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + (wm * 2 + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+        if (m >= p.M) continue;
+        if (p.ksplit > 1) {
+          p.partial[(static_cast<size_t>(blockIdx.z % p.ksplit) * gridDim.z / p.ksplit + bz) * p.M * p.N +
+                    static_cast<size_t>(m) * p.N + n] = acc[i][j][r];
+          continue;
+        }
+        float v = p.alpha * acc[i][j][r];
+        if (p.bias) v += bv;
+        if (p.rowadd) v += p.rowadd[static_cast<long>(m / p.rows_per_img) * p.rowadd_ld + n];
+        if (p.residual) v += p.residual[p.off_c(bz) + m * p.scm + n];
+        float* c = C + m * p.scm + n;
+        *c = p.accumulate ? *c + v : v;
+      }
+    }
+}
+
 // C(bz, m, n) = alpha * sum_s partial[s][bz][m][n]  (+ bias / rowadd / residual, accumulate) -- the epilogue of the slices
 __global__ void k_gemm_splitk_reduce(GemmP p, int batch) {
   const size_t per = static_cast<size_t>(p.M) * p.N, total = per * batch;
@@ -428,9 +665,28 @@ __global__ void k_gemm_splitk_reduce(GemmP p, int batch) {
 // called from tfmq_gemm_f32 (recon_kernels.hip) when the problem is large enough for 128-row tiles
 int tfmq_gemm_f32_mfma_launch(tfmq_handle h, GemmP& p, int batch, hipStream_t st) {
   const int M = p.M, N = p.N;
+  // loader modes (the rules of the generic loader, evaluated once here; batch / split offsets keep the alignment
+  // only if the strides do, which the rules check through bsa / bsb and kchunk % 16 == 0)
+  auto mode_of = [&](const float* base, long rs, long ks, int rows, long bs) {
+    // (+ buffer addressing of the fast loaders: one batch item's extent below 2^31 bytes, offsets in 32 bits)
+    const bool al = (reinterpret_cast<uintptr_t>(base) & 15) == 0 && (bs & 3) == 0 && rs >= 0 && ks >= 0 &&
+                    ((rows - 1) * rs + (static_cast<long>(p.K) - 1) * ks + 1) * 4 + 64L * (rs > ks ? rs : ks) < (1L << 31);
+    if (ks == 1 && al && (rs & 3) == 0 && (p.K & 3) == 0) return 1;
+    if (rs == 1 && al && (ks & 3) == 0 && (rows & 3) == 0) return 2;
+    return 0;
+  };
+  int ma = mode_of(p.A, p.sam, p.sak, M, batch > 1 ? (p.bsa | p.bsa2) : 0),
+      mb = mode_of(p.B, p.sbn, p.sbk, N, batch > 1 ? (p.bsb | p.bsb2) : 0);
+  if (getenv("TFMQ_GEMM_GENERIC_LOADER")) ma = mb = 0;
+  const int prec = h->gemm_prec;
+  // round 5: bf16x3 operands with 16-byte loads on both sides take k_gemm_bx3 (hi / lo split once per block, 128 x 128 tiles);
+  // TFMQ_GEMM_BX3=0 keeps the in-register split of k_gemm_f32_mfma<PREC = 1> (A/B runs, tests).  Skinny outputs (N <= 64: the per-head
+  // attention products) stay on the 128 x 64 tiles.
+  static const bool bx3_on = !(getenv("TFMQ_GEMM_BX3") && atoi(getenv("TFMQ_GEMM_BX3")) == 0);
+  const bool bx3 = bx3_on && prec == 1 && ma >= 1 && mb >= 1 && N > 64 && M > 64 && p.K >= 64;
   // 128 x 64 tiles (4 waves along M) measured faster than 128 x 128 at every SD unit shape (no column waste at
   // N = 320 / 640, twice the blocks for the mid-sized problems); TFMQ_GEMM_BN128 keeps the wide tile for A/B runs
-  const int BN = (N > 64 && getenv("TFMQ_GEMM_BN128")) ? 128 : 64;
+  const int BN = bx3 ? 128 : ((N > 64 && getenv("TFMQ_GEMM_BN128")) ? 128 : 64);
   // tiles of ONE batch item: the slicing (hence the summation order) must not depend on how many items share the
   // launch -- results stay bit-identical whatever else is in the batch
   const long tiles = static_cast<long>((N + BN - 1) / BN) * ((M + 127) / 128);
@@ -473,21 +729,24 @@ int tfmq_gemm_f32_mfma_launch(tfmq_handle h, GemmP& p, int batch, hipStream_t st
   p.tiles_n = (N + BN - 1) / BN;
   if (getenv("TFMQ_GEMM_NO_XCD")) p.tiles_n = -p.tiles_n;     // A/B runs: plain row-major tile order
   dim3 grid(((N + BN - 1) / BN) * ((M + 127) / 128), 1, batch * (ks > 1 ? ks : 1));
-  // loader modes (the rules of the generic loader, evaluated once here; batch / split offsets keep the alignment
-  // only if the strides do, which the rules check through bsa / bsb and kchunk % 16 == 0)
-  auto mode_of = [&](const float* base, long rs, long ks, int rows, long bs) {
-    // (+ buffer addressing of the fast loaders: one batch item's extent below 2^31 bytes, offsets in 32 bits)
-    const bool al = (reinterpret_cast<uintptr_t>(base) & 15) == 0 && (bs & 3) == 0 && rs >= 0 && ks >= 0 &&
-                    ((rows - 1) * rs + (static_cast<long>(p.K) - 1) * ks + 1) * 4 + 64L * (rs > ks ? rs : ks) < (1L << 31);
-    if (ks == 1 && al && (rs & 3) == 0 && (p.K & 3) == 0) return 1;
-    if (rs == 1 && al && (ks & 3) == 0 && (rows & 3) == 0) return 2;
-    return 0;
-  };
-  int ma = mode_of(p.A, p.sam, p.sak, M, batch > 1 ? (p.bsa | p.bsa2) : 0),
-      mb = mode_of(p.B, p.sbn, p.sbk, N, batch > 1 ? (p.bsb | p.bsb2) : 0);
-  if (getenv("TFMQ_GEMM_GENERIC_LOADER")) ma = mb = 0;
   const bool bk32 = getenv("TFMQ_GEMM_BK32") != nullptr;
-  const int prec = h->gemm_prec;
+  if (bx3) {
+    if (ma == 1 && mb == 1) hipLaunchKernelGGL((k_gemm_bx3<1, 1>), grid, dim3(256), 0, st, p);
+    else if (ma == 1 && mb == 2) hipLaunchKernelGGL((k_gemm_bx3<1, 2>), grid, dim3(256), 0, st, p);
+    else if (ma == 2 && mb == 1) hipLaunchKernelGGL((k_gemm_bx3<2, 1>), grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((k_gemm_bx3<2, 2>), grid, dim3(256), 0, st, p);
+  } else
+  if (prec != 0 && BN == 128 && !bk32) {
+    // (A/B runs, TFMQ_GEMM_BN128=1) 128 x 128 tiles, 2 x 2 MFMA tiles per wave: half the hi / lo splitting work per MFMA of the 1 x 2 form
+#define TFMQ_GEMM_PREC_W(PR)                                                                                                      \
+    if (ma == 1 && mb == 1) hipLaunchKernelGGL((k_gemm_f32_mfma<2, 2, 2, 2, 1, 1, 16, PR>), grid, dim3(256), 0, st, p);           \
+    else if (ma == 1 && mb == 2) hipLaunchKernelGGL((k_gemm_f32_mfma<2, 2, 2, 2, 1, 2, 16, PR>), grid, dim3(256), 0, st, p);      \
+    else if (ma == 2 && mb == 1) hipLaunchKernelGGL((k_gemm_f32_mfma<2, 2, 2, 2, 2, 1, 16, PR>), grid, dim3(256), 0, st, p);      \
+    else if (ma == 2 && mb == 2) hipLaunchKernelGGL((k_gemm_f32_mfma<2, 2, 2, 2, 2, 2, 16, PR>), grid, dim3(256), 0, st, p);      \
+    else hipLaunchKernelGGL((k_gemm_f32_mfma<2, 2, 2, 2, 0, 0, 16, PR>), grid, dim3(256), 0, st, p);
+    if (prec == 1) { TFMQ_GEMM_PREC_W(1) } else { TFMQ_GEMM_PREC_W(2) }
+#undef TFMQ_GEMM_PREC_W
+  } else
   if (prec != 0 && BN == 64 && !bk32) {
 #define TFMQ_GEMM_PREC(PR)                                                                                                        \
     if (ma == 1 && mb == 1) hipLaunchKernelGGL((k_gemm_f32_mfma<4, 1, 1, 2, 1, 1, 16, PR>), grid, dim3(256), 0, st, p);           \

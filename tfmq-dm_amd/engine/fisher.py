@@ -33,12 +33,14 @@ def _root(t: torch.Tensor):
         return t, 0, t.shape[-1]
     if not b.is_contiguous() or t.stride(-1) != 1:
         raise TfmqError("GradTape: only column slices of contiguous tensors are differentiable views")
-    if t.is_contiguous():
+    if t.is_contiguous() and t.shape[-1] == b.shape[-1]:
+        # (is_contiguous() ignores size-1 dimensions: kv[..., :C] of a [1, 1, 2C] fused k|v row is "contiguous and smaller than its base"
+        # too -- that one is a column slice and falls through; what is refused is a slice that keeps the base's row width)
         # a contiguous view that is SMALLER than its base: a slice of leading (batch) rows, base[:B] or base[B:].  Its gradient has the
         # slice's shape, not the base's -- recording it under the base's key would mis-accumulate when the producer is replayed.
         raise TfmqError("GradTape: a batch (leading-dimension) slice of a taped tensor is not a differentiable view here; tape the un-sliced "
                         "tensor (the guidance-pair prefix is switched off while taps are recorded)")
-    rowlen = t.stride(-2) if t.dim() >= 2 else b.shape[-1]
+    rowlen = t.stride(-2) if (t.dim() >= 2 and t.shape[-2] > 1) else b.shape[-1]      # (a single row's stride is arbitrary: take the base's width)
     off = (t.data_ptr() - b.data_ptr()) // t.element_size()
     if off >= rowlen:
         raise TfmqError("GradTape: unsupported view")

@@ -444,7 +444,8 @@ class LdmUNetEngine(DdimUNetEngine):
                 return ops.ff_fused(x, self.sd[p + ".norm3.weight"], self.sd[p + ".norm3.bias"], 1e-5, ff0.aq, gp, ff2.aq, ff2.p, out_q8=out_aq)
             xq = self._ln(p + ".norm3", x, ff0)
             B, T, Cc = xq.shape
-            g = ops.conv2d_w4a8(xq.reshape(B, T, 1, Cc), gp, ff0.aq, geglu_oq=ff2.aq).reshape(B, T, -1)
+            # (exact_fp: the diagnostics mode keeps the 5e-7 GELU -- the consumer-sized form moves bins)
+            g = ops.conv2d_w4a8(xq.reshape(B, T, 1, Cc), gp, ff0.aq, geglu_oq=ff2.aq, geglu_exact=self.exact_fp).reshape(B, T, -1)
             if out_aq is not None:      # tokens feed only proj_out's quantizer: int8 straight from the epilogue
                 return self._tok(ff2, g, residual=x, out_q8=out_aq)
             return self._tok(ff2, g, residual=x, **self._o16())

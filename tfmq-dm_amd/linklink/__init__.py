@@ -57,6 +57,50 @@ def _exchange_id(ident):
     return bytes(store.get(key))           # blocks until rank 0 has set it
 
 
+def _device_identity(dev):
+    """A string that is equal for two ranks exactly when they sit on the same physical GPU (host name + the device's uuid / PCI address)."""
+    import socket
+    p = _torch.cuda.get_device_properties(dev)
+    pci = tuple(getattr(p, k, None) for k in ("pci_domain_id", "pci_bus_id", "pci_device_id"))
+    return f"{socket.gethostname()}|{getattr(p, 'uuid', None)}|{pci}"
+
+
+def duplicate_devices(identities):
+    """[(rank_a, rank_b), ...] of ranks that named the same device (pure function: unit-tested without a GPU)."""
+    seen, dup = {}, []
+    for r, ident in enumerate(identities):
+        if ident in seen:
+            dup.append((seen[ident], r))
+        else:
+            seen[ident] = r
+    return dup
+
+
+def _refuse_duplicate_devices(mine):
+    """Every rank publishes its device identity through the rendezvous store and reads the others': two ranks on one GPU would sit in
+    ncclCommInitRank until its bootstrap times out (or for ever), so the mismatch is refused HERE, on every rank at once, before any
+    RCCL call.  TFMQ_COMM_ALLOW_SHARED_DEVICE=1 skips the check (never useful with RCCL; kept for experiments)."""
+    import os
+    from tfmq_dm_amd._lib import TfmqError
+    world, rank = dist.get_world_size(), dist.get_rank()
+    if world == 1 or os.environ.get("TFMQ_COMM_ALLOW_SHARED_DEVICE") == "1":
+        return
+    try:
+        store = dist.distributed_c10d._get_default_store()
+    except Exception:
+        store = None
+    if store is not None:
+        store.set(f"tfmq_comm_dev_{_comm_epoch}_{rank}", mine.encode())
+        ids = [bytes(store.get(f"tfmq_comm_dev_{_comm_epoch}_{r}")).decode() for r in range(world)]
+    else:
+        ids = [None] * world
+        dist.all_gather_object(ids, mine)
+    dup = duplicate_devices(ids)
+    if dup:
+        raise TfmqError(f"tfmq_comm_init: ranks {dup} share a GPU ({ids[dup[0][0]]}); RCCL needs one device per rank "
+                        "(set the device before the first device all-reduce: quant/calibration.py:241-245)")
+
+
 def init_comm(device=None):
     """Create the C-ABI RCCL communicator of this process over the ranks of the default process group (collective: every
     rank calls it, each with ITS device).  Called lazily by the first device all-reduce after an "nccl" rendezvous;
@@ -68,6 +112,7 @@ def init_comm(device=None):
     dev = _torch.cuda.current_device() if device is None else int(device)
     lib = load()
     world, rank = dist.get_world_size(), dist.get_rank()
+    _refuse_duplicate_devices(_device_identity(dev))
     ident = None
     if rank == 0:
         buf = (_C.c_uint8 * 128)()

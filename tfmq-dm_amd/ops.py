@@ -736,7 +736,10 @@ def conv2d_w4a8(xq: torch.Tensor, pw: PackedW4, aq: QSel, stride: int = 1, pad: 
     if geglu_oq is not None:
         # consumer-sized GELU (TFMQ_OUT_GEGLU_Q8_FAST, round 4) where the register-direct kernel takes the launch; TFMQ_GELU_EXACT=1 or
         # geglu_exact=True keep the 5e-7 form (TFMQ_OUT_GEGLU_Q8, bit-identical to the un-fused geglu + quantise)
-        fast = (not geglu_exact) and os.environ.get("TFMQ_GELU_EXACT", "0") != "1" and cin % 64 == 0 and pw.cout % 128 == 0
+        # (the predicate mirrors launch_conv_lin's acceptance test, csrc/conv_lin.hip: out_mode 4 exists on the register-direct kernel only,
+        # a launch it declines must keep out_mode 2, which the tile kernels complete -- ADVICE r4)
+        fast = ((not geglu_exact) and os.environ.get("TFMQ_GELU_EXACT", "0") != "1" and cin % 64 == 0 and pw.cout % 128 == 0
+                and pw.kh == 1 and pw.kw == 1 and stride == 1 and not up2x and tuple(pad) == (0, 0, 0, 0) and B * H * W * cin < 2 ** 31)
         dsc.out_mode, dsc.oq, dsc.yq, dsc.y = (4 if fast else 2), geglu_oq, y.data_ptr(), None
         osz = 0.5
     elif out_q8 is not None:
@@ -1380,6 +1383,35 @@ class gemm_precision:
         return False
 
 
+_gemm_prof = None  # {"rec": [(start_event, stop_event, flops, (M, N, K, batch))], "every", "cap", "n"}: bench.py's calibration roofline
+
+
+def set_gemm_profile(rec, every: int = 1, cap: int = 2048):
+    """bench.py `--workload cali`: bracket every `every`-th tfmq_gemm_f32 launch (at most `cap` of them: the handle keeps its events) with HIP
+    events on the launch stream.  rec = None switches it off."""
+    global _gemm_prof
+    _gemm_prof = None if rec is None else {"rec": rec, "every": max(1, int(every)), "cap": int(cap), "n": 0}
+
+
+def _gemm_call(d, name, flops, shape, *args):
+    h = handle(d)
+    P = _gemm_prof
+    if P is None:
+        h.call(name, *args)
+        return
+    P["n"] += 1
+    if P["n"] % P["every"] or len(P["rec"]) >= P["cap"]:
+        h.call(name, *args)
+        return
+    e0, e1 = C.c_int(), C.c_int()
+    h.call("event_create", C.byref(e0))
+    h.call("event_create", C.byref(e1))
+    h.call("event_record", e0.value, args[-1])
+    h.call(name, *args)
+    h.call("event_record", e1.value, args[-1])
+    P["rec"].append((e0.value, e1.value, flops, shape))
+
+
 def gemm(A: torch.Tensor, B: torch.Tensor, trans_a: bool = False, trans_b: bool = False, alpha: float = 1.0,
          bias=None, rowadd=None, rows_per_img: int = 1, residual=None, out=None, accumulate: bool = False) -> torch.Tensor:
     """C = alpha * op(A) @ op(B) (+bias[n]) (+rowadd[m // rows_per_img]) (+residual); A,B: contiguous fp32
@@ -1398,9 +1430,9 @@ def gemm(A: torch.Tensor, B: torch.Tensor, trans_a: bool = False, trans_b: bool 
     sbk, sbn = (1, b2[1]) if trans_b else (b2[1], 1)
     shape = (nb, M, N) if batched else (M, N)
     Cm = out if out is not None else _alloc(shape, dtype=torch.float32, device=A.device)
-    handle(d).call("gemm_f32", _p(A), _p(B), _p(Cm), M, N, K, sam, sak, sbk, sbn, N, nb, a2[0] * a2[1] if batched else 0,
-                   (b2[0] * b2[1] if B.dim() == 3 else 0), M * N if batched else 0, float(alpha), _p(bias), _p(rowadd),
-                   int(rows_per_img), 0 if rowadd is None else rowadd.shape[-1], _p(residual), int(accumulate), _stream(d))
+    _gemm_call(d, "gemm_f32", 2.0 * M * N * K * nb, (M, N, K, nb), _p(A), _p(B), _p(Cm), M, N, K, sam, sak, sbk, sbn, N, nb, a2[0] * a2[1] if batched else 0,
+               (b2[0] * b2[1] if B.dim() == 3 else 0), M * N if batched else 0, float(alpha), _p(bias), _p(rowadd),
+               int(rows_per_img), 0 if rowadd is None else rowadd.shape[-1], _p(residual), int(accumulate), _stream(d))
     return Cm
 
 
@@ -1418,13 +1450,13 @@ def gemm_strided(A: torch.Tensor, a_off: int, sam: int, sak: int, bsa: int, B: t
         if not t.is_cuda or t.dtype != torch.float32:
             raise TfmqError("gemm_strided: operands must be fp32 device tensors")
     if heads > 1:
-        handle(d).call("gemm_f32_heads", A.data_ptr() + 4 * a_off, B.data_ptr() + 4 * b_off, Cm.data_ptr() + 4 * c_off, M, N, K,
-                       sam, sak, sbk, sbn, scm, batch, bsa, bsb, bsc, heads, hsa, hsb, hsc, float(alpha), int(accumulate),
-                       _stream(d))
+        _gemm_call(d, "gemm_f32_heads", 2.0 * M * N * K * batch * heads, (M, N, K, batch * heads), A.data_ptr() + 4 * a_off, B.data_ptr() + 4 * b_off,
+                   Cm.data_ptr() + 4 * c_off, M, N, K, sam, sak, sbk, sbn, scm, batch, bsa, bsb, bsc, heads, hsa, hsb, hsc, float(alpha),
+                   int(accumulate), _stream(d))
         return Cm
-    handle(d).call("gemm_f32", A.data_ptr() + 4 * a_off, B.data_ptr() + 4 * b_off, Cm.data_ptr() + 4 * c_off, M, N, K,
-                   sam, sak, sbk, sbn, scm, batch, bsa, bsb, bsc, float(alpha), None, None, 1, 0, None, int(accumulate),
-                   _stream(d))
+    _gemm_call(d, "gemm_f32", 2.0 * M * N * K * batch, (M, N, K, batch), A.data_ptr() + 4 * a_off, B.data_ptr() + 4 * b_off, Cm.data_ptr() + 4 * c_off,
+               M, N, K, sam, sak, sbk, sbn, scm, batch, bsa, bsb, bsc, float(alpha), None, None, 1, 0, None, int(accumulate),
+               _stream(d))
     return Cm
 
 
