@@ -70,7 +70,7 @@ def test_gloo_world2_allreduce_matches_single_process_emulation(tmp_path):
         assert abs(float(res["delta"]) - 1.5) < 1e-6       # (1 + 2) / 2
 
 
-def _lazy_comm_worker(rank, world, port, out_dir):
+def _lazy_comm_worker(rank, world, port, out_dir, same_device=False):
     """What a spawned calibration rank does in the reference's order (quant/calibration.py:241-245): rendezvous FIRST, device
     chosen afterwards.  The RCCL communicator of the C ABI must not be bound at the rendezvous (every rank would still be on
     device 0: 'Duplicate GPU detected' / a hang) but at the first device all-reduce, to that tensor's device, with the id
@@ -108,11 +108,12 @@ def _lazy_comm_worker(rank, world, port, out_dir):
         return _lib._handles[dev]
     _lib.handle, _lib.load = fake_handle, (lambda: FakeLib)
     torch.cuda.is_available = lambda: True
+    link._device_identity = lambda d: f"fake-host|fake-gpu-{d}"      # (no GPU here: the identity the ranks publish before ncclCommInitRank)
     real_init = link.dist.init_process_group
     link.dist.init_process_group = lambda backend=None, **kw: real_init(backend="gloo", **kw)    # "nccl" asked for, gloo underneath
     link.init_process_group(backend="nccl", init_method=f"tcp://127.0.0.1:{port}", world_size=world, rank=rank)
     assert calls == [] and link.comm_device() is None          # nothing bound at the rendezvous
-    dev = rank + 2                                             # the device this rank picks afterwards
+    dev = 2 if same_device else rank + 2                       # the device this rank picks afterwards
 
     class FakeDevTensor:
         is_cuda, dtype = True, torch.float32
@@ -127,6 +128,17 @@ def _lazy_comm_worker(rank, world, port, out_dir):
         def numel(self):
             return 8
     torch.cuda.current_stream = lambda d=None: types.SimpleNamespace(cuda_stream=0)
+    if same_device:
+        # two ranks on ONE GPU: refused on every rank before any RCCL call (ncclCommInitRank would sit in its bootstrap)
+        from tfmq_dm_amd._lib import TfmqError
+        try:
+            link.allreduce(FakeDevTensor())
+            err = None
+        except TfmqError as e:
+            err = str(e)
+        torch.save({"calls": calls, "err": err}, os.path.join(out_dir, f"dup{rank}.pt"))
+        link.barrier()
+        return
     link.allreduce(FakeDevTensor())
     link.allreduce(FakeDevTensor())
     h = _lib._handles[dev]
@@ -162,3 +174,21 @@ def test_exchange_chunk_cuts_partition_the_gradient_buffer():
             if nxt is not None:
                 assert nxt[0] == l1 and nxt[2] == e1
     assert _chunk_cuts([10, 10, 10, 10], 2) == [(0, 2, 0, 20), (2, 4, 20, 40)]
+
+
+def test_rccl_communicator_refuses_two_ranks_on_one_gpu(tmp_path):
+    """tfmq_comm_init at world > 1 with a duplicate device fails loudly on every rank instead of hanging -- the ranks
+    compare device identities through the rendezvous store before librccl is entered (linklink.init_comm)."""
+    world, port = 2, 33000 + (os.getpid() % 2000)
+    mp.start_processes(_lazy_comm_worker, args=(world, port, str(tmp_path), True), nprocs=world, join=True, start_method="spawn")
+    for r in range(world):
+        res = torch.load(os.path.join(str(tmp_path), f"dup{r}.pt"))
+        assert res["err"] is not None and "share a GPU" in res["err"] and "(0, 1)" in res["err"], res
+        assert not any(c[0] == "comm_init" for c in res["calls"])           # librccl was never entered
+
+
+def test_duplicate_devices_is_a_pure_function():
+    sys.path.insert(0, os.path.join(ROOT, "tfmq-dm_amd"))
+    import linklink as link
+    assert link.duplicate_devices(["a", "b", "c"]) == []
+    assert link.duplicate_devices(["a", "b", "a", "b"]) == [(0, 2), (1, 3)]
