@@ -99,31 +99,6 @@ def setup_cifar(args, dev, rank, log):
     def fwd():
         eng.forward(sampler.x, None)
 
-    def gelu_exact():
-        """The same sampling with the 5e-7 erf GELU in every fused GEGLU epilogue (TFMQ_GELU_EXACT=1: out_mode 2 of the pointwise kernel, the
-        feed-forward as three launches) instead of the consumer-sized form the metric's run uses (TFMQ_OUT_GEGLU_Q8_FAST: |dPhi| <= 2.8e-5,
-        bins within 1, < 2e-3 of them moved on identical inputs -- tests/test_geglu_fast_gpu.py).  Reported beside `value` (VERDICT r4)."""
-        old = os.environ.get("TFMQ_GELU_EXACT")
-        os.environ["TFMQ_GELU_EXACT"] = "1"
-        try:
-            ms = GraphLatentDdimSampler(eng, S, batch, LAT, CTX, scale=scale, alphas_cumprod=alphas_cumprod_linear()).capture()
-        finally:
-            if old is None:
-                del os.environ["TFMQ_GELU_EXACT"]
-            else:
-                os.environ["TFMQ_GELU_EXACT"] = old
-        args_ = (x_T,) if CTX is None else (x_T, cond, uncond)
-        ms.sample_nhwc(*args_)
-        ms.stream.synchronize()
-        t0 = time.perf_counter()
-        out = ms.sample_nhwc(*args_)
-        ms.stream.synchronize()
-        dt = time.perf_counter() - t0
-        ref = sampler.x.float()
-        rel = float((out.float() - ref).norm() / ref.norm()) if sampler.gid is not None else None
-        return {"images_per_s": round(batch / dt, 3), "final_latents_rel_l2_vs_metric_run": None if rel is None else round(rel, 5),
-                "note": "TFMQ_GELU_EXACT=1: erf-form GELU (|error| <= 5e-7) in the GEGLU epilogues, feed-forward as three launches; one sampling after a warm one"}
-
     def cpu():
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         import tfmq_oracle as O
@@ -270,6 +245,31 @@ def setup_sd(args, dev, rank, log, preset="sd"):
                 f"images touched {int((df.reshape(df.shape[0], -1).amax(dim=1) > 0).sum())} of {df.shape[0]}")
         return {"images_per_s": round(batch / dt, 3), "final_latents_equal_to_the_metric_run": same,
                 "note": "guidance pair materialised as a 2B batch (TFMQ_PAIR_PREFIX=0); the metric's run shares the pair's common prefix"}
+
+    def gelu_exact():
+        """The same sampling with the 5e-7 erf GELU in every fused GEGLU epilogue (TFMQ_GELU_EXACT=1: out_mode 2 of the pointwise kernel, the
+        feed-forward as three launches) instead of the consumer-sized form the metric's run uses (TFMQ_OUT_GEGLU_Q8_FAST: |dPhi| <= 2.8e-5,
+        bins within 1, < 2e-3 of them moved on identical inputs -- tests/test_geglu_fast_gpu.py).  Reported beside `value` (VERDICT r4)."""
+        old = os.environ.get("TFMQ_GELU_EXACT")
+        os.environ["TFMQ_GELU_EXACT"] = "1"
+        try:
+            ms = GraphLatentDdimSampler(eng, S, batch, LAT, CTX, scale=scale, alphas_cumprod=alphas_cumprod_linear()).capture()
+        finally:
+            if old is None:
+                del os.environ["TFMQ_GELU_EXACT"]
+            else:
+                os.environ["TFMQ_GELU_EXACT"] = old
+        args_ = (x_T,) if CTX is None else (x_T, cond, uncond)
+        ms.sample_nhwc(*args_)
+        ms.stream.synchronize()
+        t0 = time.perf_counter()
+        out = ms.sample_nhwc(*args_)
+        ms.stream.synchronize()
+        dt = time.perf_counter() - t0
+        ref = sampler.x.float()
+        rel = float((out.float() - ref).norm() / ref.norm()) if sampler.gid is not None else None
+        return {"images_per_s": round(batch / dt, 3), "final_latents_rel_l2_vs_metric_run": None if rel is None else round(rel, 5),
+                "note": "TFMQ_GELU_EXACT=1: erf-form GELU (|error| <= 5e-7) in the GEGLU epilogues, feed-forward as three launches; one sampling after a warm one"}
 
     def cpu():
         sys.path.insert(0, os.path.join(ROOT, "oracle"))

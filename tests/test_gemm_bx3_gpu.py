@@ -4,11 +4,16 @@ default, engine/recon.py) and both operands take 16-byte loads.  Against float64
 relative error <= 2^-16, accumulated in fp32 -- the bound below is that of tests/test_recon_precision_gpu.py (which also runs the reference's
 400-iteration loss curve, fixture F8b, through this kernel).  The reference runs these products as fp32 torch.matmul / F.conv2d backward
 (quant/reconstruction.py:63-78,182-198 via autograd)."""
+import os
+import subprocess
+import sys
+
 import pytest
 import torch
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.fixture(scope="module")
@@ -105,3 +110,12 @@ def test_bx3_large_values_and_exact_zeros(ops):
     ref2 = A2.double() @ B2.double().T
     assert float((C2.double() - ref2).abs().max()) / float(ref2.abs().max()) <= 2e-5
     del As, Bs
+
+
+def test_bx3_forced_for_short_reductions_in_a_fresh_process():
+    """The launcher gives k_gemm_bx3 the launches with K >= 1024 (where it measured faster); the short-K shapes of the table above reach it
+    only under TFMQ_GEMM_BX3=2, which is read once per process: the whole table again in a child process with the kernel forced."""
+    env = dict(os.environ, TFMQ_GEMM_BX3="2")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-k", "vs_float64 or epilogue or batched"],
+                       env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]

@@ -432,7 +432,10 @@ __device__ __forceinline__ void bx3_split2(float x0, float x1, unsigned& hi, uns
   lo = __builtin_bit_cast(unsigned, l);
 }
 // byte offset of 16-byte slot `slot` (0-3 hi octets, 4-7 lo octets) of row `row` in a [128 rows][128 B] bx3 tile
-__device__ __forceinline__ int bx3_off(int row, int slot) { return row * 128 + ((slot ^ (row & 7)) << 4); }
+// The swizzle term f(row) = ((row >> 1) & 7) ^ ((row & 1) << 2): the 16 rows of a ds_read_b128 lane group ({0-3, 12-15, 20-27}, ...; banks =
+// (a / 4) mod 64, two 128-byte rows per bank line) land on 16 distinct 16-byte positions, and the two rows an 8-lane ds_write_b128 group
+// touches (2 rows x 4 octets; banks = (a / 4) mod 32) use disjoint slot sets -- row & 7 alone is two-way conflicted on both sides.
+__device__ __forceinline__ int bx3_off(int row, int slot) { return row * 128 + ((slot ^ (((row >> 1) & 7) ^ ((row & 1) << 2))) << 4); }
 
 template <int MODE>
 struct Bx3Loader {
@@ -565,7 +568,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_bx3(GemmP p) {
   la.template store<0>(smem);
   lb.template store<0>(smem + 2 * TILE);
   __syncthreads();
-  // fragment rows of this lane (row bits 0-2 = l32 bits 0-2 for every tile: one swizzle term)
+  // fragment rows of this lane (row bits 0-3 = l32 bits 0-3 for every tile: one swizzle term)
   const int ra = (wm * 2) * 32 + l32, rb = (wn * 2) * 32 + l32;
   auto step = [&](int s, auto par_tag, auto chk_tag) {
     constexpr int PAR = decltype(par_tag)::value;
@@ -591,10 +594,14 @@ __global__ __launch_bounds__(256, 2) void k_gemm_bx3(GemmP p) {
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
+#ifdef TFMQ_DBG_GEMM_NO_MFMA      // diagnostics build (results are garbage): the K loop without its MFMAs
+          acc[i][j][0] += static_cast<float>(al[i][0]) + static_cast<float>(bh[j][1]) + static_cast<float>(ah[i][2]) + static_cast<float>(bl[j][3]);
+#else
           // small terms first: they are not absorbed by the large partial sum's rounding
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+#endif
         }
 #ifndef TFMQ_DBG_GEMM_NO_STORE
       // the next K-step's tile (loaded one step ago) is split and stored to the other buffer under the second half's MFMAs
@@ -679,11 +686,13 @@ int tfmq_gemm_f32_mfma_launch(tfmq_handle h, GemmP& p, int batch, hipStream_t st
       mb = mode_of(p.B, p.sbn, p.sbk, N, batch > 1 ? (p.bsb | p.bsb2) : 0);
   if (getenv("TFMQ_GEMM_GENERIC_LOADER")) ma = mb = 0;
   const int prec = h->gemm_prec;
-  // round 5: bf16x3 operands with 16-byte loads on both sides take k_gemm_bx3 (hi / lo split once per block, 128 x 128 tiles);
-  // TFMQ_GEMM_BX3=0 keeps the in-register split of k_gemm_f32_mfma<PREC = 1> (A/B runs, tests).  Skinny outputs (N <= 64: the per-head
-  // attention products) stay on the 128 x 64 tiles.
-  static const bool bx3_on = !(getenv("TFMQ_GEMM_BX3") && atoi(getenv("TFMQ_GEMM_BX3")) == 0);
-  const bool bx3 = bx3_on && prec == 1 && ma >= 1 && mb >= 1 && N > 64 && M > 64 && p.K >= 64;
+  // round 5: bf16x3 operands with 16-byte loads on both sides and a LONG reduction take k_gemm_bx3 (hi / lo split once per block, 128 x 128
+  // tiles): +20 ... 28 % on the 3x3-conv forward shapes (K = 2880 ... 11520), +6 % on the weight-gradient shape (K = 32768); with K = 320
+  // (ten K-steps per tile) the smaller tiles of k_gemm_f32_mfma<PREC = 1> and their five blocks per CU win by 10-25 % and keep those
+  // launches (same-box A/B: profiles/r05_ab_gemm_bx3.txt).  TFMQ_GEMM_BX3=0 switches the kernel off, =2 forces it for every K >= 64
+  // (A/B runs, tests).  Skinny outputs (N <= 64: the per-head attention products) stay on the 128 x 64 tiles.
+  static const int bx3_mode = getenv("TFMQ_GEMM_BX3") ? atoi(getenv("TFMQ_GEMM_BX3")) : 1;
+  const bool bx3 = bx3_mode != 0 && prec == 1 && ma >= 1 && mb >= 1 && N > 64 && M > 64 && p.K >= (bx3_mode == 2 ? 64 : 1024);
   // 128 x 64 tiles (4 waves along M) measured faster than 128 x 128 at every SD unit shape (no column waste at
   // N = 320 / 640, twice the blocks for the mid-sized problems); TFMQ_GEMM_BN128 keeps the wide tile for A/B runs
   const int BN = bx3 ? 128 : ((N > 64 && getenv("TFMQ_GEMM_BN128")) ? 128 : 64);

@@ -143,11 +143,11 @@ class LatentRunner:
                                              plms=_get(o, "plms", False), eta=self.eta)
             tmp = [[cali[0][i * n:(i + 1) * n], cali[1][i * n:(i + 1) * n]] for i in range(0, self.steps, int(o.interval_length))]
             w_cali = [torch.cat([x[0] for x in tmp]), torch.cat([x[1] for x in tmp])]
-            interval, bs = n, 32
+            interval, bs = n, self.CALI_RECIPE["uncond"][1]
         elif self.flow == "class":
             cali = DG.generate_cali_data_ldm_imagenet(model=self.model, T=self.steps, c=1, batch_size=int(_get(o, "cali_batch", 8)),
                                                       shape=shape, eta=self.eta, scale=float(o.scale))
-            w_cali, interval, bs = cali, int(_get(o, "cali_interval", 512)), 8
+            w_cali, interval, bs = cali, int(_get(o, "cali_interval", self.CALI_RECIPE["class"][0])), self.CALI_RECIPE["class"][1]
         else:
             if self.sampler is None:
                 self.make_sampler()
@@ -155,7 +155,7 @@ class LatentRunner:
                 raise TfmqError("LatentRunner.quantize: the text-guided calibration needs prompts")
             cali = DG.generate_cali_text_guided_data(self.model, self.sampler, T=self.steps, c=1, batch_size=1, prompts=tuple(prompts),
                                                      shape=shape)
-            w_cali, interval, bs = cali, int(_get(o, "cali_interval", 256)), 8       # txt2img.py:473-486 (32 only in its mp.spawn kwargs)
+            w_cali, interval, bs = cali, int(_get(o, "cali_interval", self.CALI_RECIPE["text"][0])), self.CALI_RECIPE["text"][1]       # txt2img.py:473-486 (32 only in its mp.spawn kwargs)
         logger.info("Calibration data generated.")
         torch.cuda.empty_cache()
         setattr(unet, "split", True)
