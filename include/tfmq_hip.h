@@ -408,7 +408,11 @@ int tfmq_attention(tfmq_handle h, const float* q, const float* k, const float* v
  * vt = V transposed, fp16 [B][heads*d][Tk_stride] (tfmq_conv_desc.yt).  Tk_stride >= Tk keys per batch item are
  * present in memory (k: [B][Tk_stride][ldk]); keys >= Tk are masked (a 77-token context is stored padded to 80).
  * d % 8 == 0, d <= 384 (above 256 a block computes the scores over the whole head and the 128 output channels of its slice;
- * larger heads: TFMQ_ERR_UNSUPPORTED, use tfmq_attention), Tk_stride % 8 == 0. */
+ * larger heads: TFMQ_ERR_UNSUPPORTED, use tfmq_attention), Tk_stride % 8 == 0.
+ * Which kernel serves a call follows from the shape AND from the outputs asked for: with yq only (out == NULL), d = 40, Tq % 128 == 0 and
+ * Tk_stride <= 96 the all-heads context kernel (attention_ctx.hip) takes the launch; it sums the softmax denominator in another order than the
+ * tiled kernel, so the int8 bins of the two agree within 1 on < 1 % of the outputs, not bit for bit (tests/test_attention_f16_gpu.py).  A
+ * caller that needs the same bins with and without `out` sets TFMQ_ATTN_CTX=0. */
 int tfmq_attention_f16(tfmq_handle h, const uint16_t* q, const uint16_t* k, const uint16_t* vt, int ldq, int ldk,
                        float* out, int ldo, int8_t* yq, tfmq_qsel aq, int B, int heads, int Tq, int Tk, int Tk_stride,
                        int d, float scale, void* stream);

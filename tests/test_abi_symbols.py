@@ -32,6 +32,17 @@ def test_header_symbols_all_exported(lib):
     assert l.tfmq_abi_version() == 8
 
 
+def test_docs_quote_the_real_abi_size_and_version(lib):
+    """DESIGN.md / README.md state the number of entry points and the ABI version; the round-4 review found them two versions stale."""
+    hdr = open(os.path.join(ROOT, "include", "tfmq_hip.h")).read()
+    n = len(set(re.findall(r"\b(tfmq_[a-z0-9_]+)\s*\(", hdr)) - {"tfmq_ctx"})
+    v = lib.load().tfmq_abi_version()
+    design = open(os.path.join(ROOT, "DESIGN.md")).read()
+    readme = open(os.path.join(ROOT, "README.md")).read()
+    assert f'({n} `extern "C"` entry points, `tfmq_abi_version()` = {v}' in design
+    assert f"C ABI version {v}, {n} entry points" in readme
+
+
 def test_struct_layouts_match_header(lib):
     import ctypes as C
     # tfmq_qsel: 2 pointers + 2 int32; tfmq_conv_desc / tfmq_gn_desc sizes as laid out by the C compiler

@@ -104,12 +104,20 @@ UNITS = [("block", "down.1.block.0", False), ("block", "mid.attn_1", False), ("l
          ("block", "output_blocks.1.0", True)]
 
 
+# bars of the 20-iteration run per operand mode of the reconstruction GEMMs: (loss-curve deviation, masks equal, max / mean alpha deviation).
+# f32 = exact products (what the fixture was pinned with in round 3); bf16x3 = the SHIPPED default of the reconstruction iterations
+# (2^-16 per product; VERDICT r4: "F23 is still pinned only under TFMQ_RECON_GEMM=f32")
+BARS = {"f32": (1e-4, 0.999, 2e-3, 1e-5), "bf16x3": (5e-4, 0.998, 4e-3, 5e-5)}
+
+
+@pytest.mark.parametrize("gemm", ["f32", "bf16x3"])
 @pytest.mark.parametrize("kind,name,ldm", UNITS)
-def test_fisher_reconstruction_matches_reference_run(golden, monkeypatch, kind, name, ldm):
+def test_fisher_reconstruction_matches_reference_run(golden, monkeypatch, kind, name, ldm, gemm):
     import quant.reconstruction as REC
     import quant.data_utill as DU
     from quant.reconstruction_util import RLOSS
-    monkeypatch.setenv("TFMQ_RECON_GEMM", "f32")
+    monkeypatch.setenv("TFMQ_RECON_GEMM", gemm)
+    b_loss, b_mask, b_dmax, b_dmean = BARS[gemm]
     monkeypatch.setenv("TFMQ_EXACT_FP", "1")      # unit inputs / targets captured with fp32 operands upstream, as the reference captures them
     qnn, g8, g = _state(golden, ldm)
     unit = dict(qnn.model.named_modules())[name]
@@ -149,8 +157,8 @@ def test_fisher_reconstruction_matches_reference_run(golden, monkeypatch, kind, 
     loss = np.array([r[2] + r[3] for r in trace["rows"]])
     assert len(loss) == iters
     dev = np.max(np.abs(loss - ref_loss) / ref_loss)
-    print(f"[{name}] total loss {loss[0]:.5f} ... {loss[-1]:.3f} (reference {ref_loss[0]:.5f} ... {ref_loss[-1]:.3f}); worst deviation {dev:.2e}")
-    assert dev <= 1e-4, (name, dev)
+    print(f"[{name}] [{gemm}] total loss {loss[0]:.5f} ... {loss[-1]:.3f} (reference {ref_loss[0]:.5f} ... {ref_loss[-1]:.3f}); worst deviation {dev:.2e}")
+    assert dev <= b_loss, (name, gemm, dev)
     # ---- final alphas
     mods = dict(qnn.model.named_modules())
     # Adam moves an element by lr = 1e-3 per iteration whatever the size of its gradient: an element whose gradient is zero to rounding
@@ -159,8 +167,8 @@ def test_fisher_reconstruction_matches_reference_run(golden, monkeypatch, kind, 
         a, ra = mods[full].wqtizer.alpha.detach().cpu(), T(g[f"{fname}/alpha/{full}"])
         assert a.shape == ra.shape
         mask, dmax, dmean = float(((a >= 0) == (ra >= 0)).float().mean()), float((a - ra).abs().max()), float((a - ra).abs().mean())
-        print(f"[{name}] {full}: masks equal {mask:.4%}, |alpha - reference| max {dmax:.2e} mean {dmean:.2e}")
-        assert mask >= 0.999 and dmax <= 2e-3 and dmean <= 1e-5, (full, mask, dmax, dmean)
+        print(f"[{name}] [{gemm}] {full}: masks equal {mask:.4%}, |alpha - reference| max {dmax:.2e} mean {dmean:.2e}")
+        assert mask >= b_mask and dmax <= b_dmax and dmean <= b_dmean, (full, gemm, mask, dmax, dmean)
 
 
 def test_save_grad_weights_and_state_restore(golden, monkeypatch):

@@ -28,7 +28,7 @@ struct AttnCtxP {
   tfmq_qsel aq;
   int B, heads, Tq, Tk, Tks;
   float scale;
-  long q_bs, q_hs;       // element strides of q: batch, head (token stride = ldq): [B][T][heads * d] rows, or head-major [B][heads][T][d]
+  long q_bs, q_hs;       // element strides of q: batch, head (token stride = ldq): [B][T][heads * d] rows
 };
 
 template <int D>
@@ -217,7 +217,10 @@ int launch_ctx(tfmq_handle h, const AttnCtxP& p, hipStream_t st) {
 int launch_attention_ctx(tfmq_handle h, const uint16_t* q, const uint16_t* k, const uint16_t* vt, int ldq, int ldk, int8_t* yq, tfmq_qsel aq, int B,
                          int heads, int Tq, int Tk, int Tks, int d, float scale, void* stream, bool* taken) {
   *taken = false;
-  const char* ev = getenv("TFMQ_ATTN_CTX");          // (read per call: tests and A/B runs switch it inside one process)
+  // TFMQ_ATTN_CTX: 0 off, 2 also d = 80 (read per call: tests/test_attention_f16_gpu.py switches it inside one process; a getenv is noise beside
+  // a launch).  `tfmq_attention_f16` documents that the kernel -- hence the last fp16 rounding of a bin -- follows from which outputs are asked
+  // for: this kernel exists for the int8-only call of the sampling path.
+  const char* ev = getenv("TFMQ_ATTN_CTX");
   const bool on = !(ev && atoi(ev) == 0);
   // (d = 80, the 32 x 32 level: measured 190 us against k_attention_h's 178 at UNet batch 128 -- not taken unless TFMQ_ATTN_CTX=2;
   //  d = 40, the 64 x 64 level: 291 against 347)
@@ -226,10 +229,8 @@ int launch_attention_ctx(tfmq_handle h, const uint16_t* q, const uint16_t* k, co
   const size_t smem = (d == 40 ? CtxGeo<40>::KBYTES + CtxGeo<40>::VBYTES : CtxGeo<80>::KBYTES + CtxGeo<80>::VBYTES) + 128 * static_cast<size_t>(heads) * d;
   if (smem > 160 * 1024) return TFMQ_OK;
   *taken = true;
-  // ldq == d: the queries are stored head-major, [B][heads][Tq][d] (tfmq_chain_gemm.head_major: a head's 128-query tile is one contiguous
-  // piece of memory); otherwise token rows [B][Tq][ldq]
-  const bool hm = ldq == d && heads > 1;
+  // queries as token rows [B][Tq][ldq], head hd at columns hd * d (the only layout the ABI describes)
   AttnCtxP p{reinterpret_cast<const __half*>(q), reinterpret_cast<const __half*>(k), reinterpret_cast<const __half*>(vt), ldq, ldk, yq, aq,
-             B, heads, Tq, Tk, Tks, scale, hm ? static_cast<long>(heads) * Tq * d : static_cast<long>(Tq) * ldq, hm ? static_cast<long>(Tq) * d : d};
+             B, heads, Tq, Tk, Tks, scale, static_cast<long>(Tq) * ldq, d};
   return d == 40 ? launch_ctx<40>(h, p, as_stream(stream)) : launch_ctx<80>(h, p, as_stream(stream));
 }

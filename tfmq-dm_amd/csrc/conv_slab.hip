@@ -52,6 +52,7 @@ struct SlabP {
   int SW;         // slab row width = W + 2
   int SI;         // slab rows per image (imgs > 1); imgs == 1: rows of the whole slab
   int slab_rows;  // rows of the slab that carry pixels (<= 512)
+  int prio;       // TFMQ_SETPRIO=1 (A/B runs): the second-dispatched half of an 8-wave block runs at s_setprio 1 (MI355X_MICROARCH.md: static priority)
 };
 
 // Geometry of a variant: NWM waves along M (4: 256-pixel tiles, 8 waves, one block per CU; 2: 128-pixel tiles, 4 waves, two per CU)
@@ -292,6 +293,7 @@ __global__ __launch_bounds__(64 * 2 * NWM, 2) void k_conv3_slab(SlabP sp) {
       slab_toggle = SLAB_BYTES - slab_toggle;
     }
   };
+  if (sp.prio && wid >= NW / 2) __builtin_amdgcn_s_setprio(1);
   if (NBP % NW != 0 && wid < NBP % NW) kloop(std::integral_constant<int, NBP / NW + 1>{});
   else kloop(std::integral_constant<int, NBP / NW>{});
   SLAB_MARK(1);
@@ -466,6 +468,8 @@ bool launch_conv_slab(tfmq_handle h, ConvP& p, hipStream_t st, bool forced, bool
   const int BM = half_m ? 128 : 256, cap = half_m ? SlabGeo<2>::CAP : SlabGeo<4>::CAP;
   if (d.stats && BM % d.stats_seg != 0) return false;
   SlabP sp;
+  static const int prio_env = getenv("TFMQ_SETPRIO") ? atoi(getenv("TFMQ_SETPRIO")) : 0;
+  sp.prio = prio_env;
   sp.HW = Hv * Wv;
   sp.SW = Wv + 2;
   if (sp.HW % BM == 0 && BM % Wv == 0) {

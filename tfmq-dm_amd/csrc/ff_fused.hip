@@ -38,6 +38,7 @@ namespace {
 struct FfP {
   tfmq_ff_desc d;
   const unsigned char* pad_table;
+  int prio;            // TFMQ_SETPRIO=1 (A/B runs): waves 4-7 at s_setprio 1
 };
 
 template <int N>
@@ -116,6 +117,7 @@ __global__ __launch_bounds__(512, 2) void k_ff_fused(FfP p) {
   const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, pl = lane & 31;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int m0 = blockIdx.x * 256;
+  if (p.prio && wid >= 4) __builtin_amdgcn_s_setprio(1);
   const int m = m0 + wid * 32 + pl;
   const int mc = m < d.M ? m : d.M - 1;
   const bool mok = m < d.M;
@@ -651,6 +653,8 @@ extern "C" int tfmq_ff_fused(tfmq_handle h, const tfmq_ff_desc* dd, void* stream
   FfP p;
   p.d = d;
   p.pad_table = h->pad_table;
+  static const int prio_env = getenv("TFMQ_SETPRIO") ? atoi(getenv("TFMQ_SETPRIO")) : 0;
+  p.prio = prio_env;
   hipLaunchKernelGGL(k_ff_fold, dim3((d.inner + 255) / 256), dim3(256), 0, st, d);
   if (pre || post) hipLaunchKernelGGL(k_ff_fold_lin, dim3((d.C + 255) / 256, 2), dim3(256), 0, st, d);
   const dim3 grid((d.M + 255) / 256);

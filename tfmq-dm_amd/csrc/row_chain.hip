@@ -49,6 +49,7 @@ struct ChainP {
   tfmq_chain_desc d;
   int nphase;
   int ph0[4];          // first phase of GEMM g (ph0[n_gemm] = nphase); a GEMM has (N / 64) * W phases
+  int prio;            // TFMQ_SETPRIO=1 (A/B runs): waves 4-7 at s_setprio 1
 };
 
 template <int N>
@@ -84,6 +85,7 @@ __global__ __launch_bounds__(512, 2) void k_row_chain(ChainP p) {
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int tg = wid / W, part = wid % W;            // token group of this wave, its share of the group's tiles
   const int m0 = blockIdx.x * G::BT;
+  if (p.prio && wid >= 4) __builtin_amdgcn_s_setprio(1);
   const int m = m0 + tg * 32 + pl;                   // (M % BT == 0: the launcher's condition -- no ragged rows, fixed store counts per phase)
 
   // ---- weight stream: phase = two output tiles (64 columns) x five K-steps of the GEMM that owns it
@@ -435,6 +437,8 @@ extern "C" int tfmq_row_chain(tfmq_handle h, const tfmq_chain_desc* dd, void* st
   TFMQ_CHECK_ARG(h, static_cast<size_t>(d.M) * 3 * d.C < (static_cast<size_t>(1) << 31), "row_chain: M too large");
   ChainP p;
   p.d = d;
+  static const int prio_env = getenv("TFMQ_SETPRIO") ? atoi(getenv("TFMQ_SETPRIO")) : 0;
+  p.prio = prio_env;
   int ph = 0, cols = 0, n_ln = 0;
   for (int g = 0; g < 4; ++g) p.ph0[g] = 1 << 30;
   for (int g = 0; g < d.n_gemm; ++g) {
