@@ -684,8 +684,8 @@ def run_cali_workload(args, dev, rank, local_rank, world, log):
                                                 "frac": round(lg_fl / (lg_ms * 1e-3) / 1e12 / peak, 4) if lg_ms > 0 else None,
                                                 "share_of_sampled_gemm_time": round(lg_ms / tot_ms, 3) if tot_ms > 0 else None}}
     return {
-        "roofline": roof,
         "metric": "w4a8 calibration wall-clock, SD-v1-4 UNet (reduced recipe, see config)", "value": round(dt, 2), "unit": "s",
+        "roofline": roof,
         "n_gpus": world, "steps": 1, "warmup": 0, "ms_per_step": round(dt * 1e3, 1), "higher_is_better": False,
         "scaling": "strong" if world > 1 else "weak", "vs_baseline": None,
         "dtype": {"f32": "f32 (AdaRound iterations: exact fp32 MFMA GEMMs)", "f16": "f32 values, fp16-operand MFMA GEMMs with fp32 accumulation (AdaRound iterations)"}.get(
@@ -933,7 +933,7 @@ def main():
             tot_ops, tot_ms, n_launch, tot_bytes, n_fwd = conv_roofline(fwd, info["stream"])
         achieved = tot_ops / (tot_ms * 1e-3) / 1e12 if tot_ms > 0 else 0.0
         traffic, traffic_src = None, None
-        tname = next((f"r{r:02d}_traffic_{args.workload}.json" for r in (4, 3, 2, 1)
+        tname = next((f"r{r:02d}_traffic_{args.workload}.json" for r in (9, 8, 7, 6, 5, 4, 3, 2, 1)
                       if os.path.exists(os.path.join(ROOT, "profiles", f"r{r:02d}_traffic_{args.workload}.json"))), None)
         if tname is not None:
             tj = json.load(open(os.path.join(ROOT, "profiles", tname)))["kernels"]
@@ -995,12 +995,14 @@ def main():
                     except Exception as e:      # a damaged record must not take the sampling line down
                         cali.setdefault("measured_sd_recipe_20000_iterations", {})[key] = {"error": repr(e)}
             # round 4: ONE job over all 74 units with the calibration set generated inside it (`--workload cali --cali-generate`)
-            fpath = os.path.join(ROOT, "profiles", "r04_bench_line_cali_sd_full_20000.json")
+            fname = next((n for n in ("r05_bench_line_cali_sd_full_20000.json", "r04_bench_line_cali_sd_full_20000.json")
+                          if os.path.exists(os.path.join(ROOT, "profiles", n))), "r04_bench_line_cali_sd_full_20000.json")
+            fpath = os.path.join(ROOT, "profiles", fname)
             if os.path.exists(fpath):
                 try:
                     mj = json.loads(open(fpath).read().strip().splitlines()[-1])
                     cali["measured_sd_recipe_20000_iterations_one_job"] = {**mj["calibration"], "workload": mj["config"]["workload"],
-                                                                           "source": "profiles/r04_bench_line_cali_sd_full_20000.json", "recorded_run": True}
+                                                                           "source": "profiles/" + fname, "recorded_run": True}
                 except Exception as e:
                     cali["measured_sd_recipe_20000_iterations_one_job"] = {"error": repr(e)}
             lv = cali.get("measured_sd_recipe_20000_iterations", {})
@@ -1009,7 +1011,7 @@ def main():
                                        "reconstruction_units": sum(v["reconstruction_units"] for v in lv.values()),
                                        "note": "8 timestep groups x 128 samples, 20000 iterations per unit, 1 GPU; each level's run repeats the weight "
                                                "initialisation and the Finite-Set pass of the whole UNet"}
-            mname = next((n for n in ("r04_cifar_calibration_full.json", "r03_cifar_calibration_full.json", "r02_cifar_calibration_full.json")
+            mname = next((n for n in ("r05_cifar_calibration_full.json", "r04_cifar_calibration_full.json", "r03_cifar_calibration_full.json", "r02_cifar_calibration_full.json")
                           if os.path.exists(os.path.join(ROOT, "profiles", n))), "r02_cifar_calibration_full.json")
             mpath = os.path.join(ROOT, "profiles", mname)
             if os.path.exists(mpath):       # the whole CIFAR recipe, measured once end to end with this code (scratch/cifar_cali_full.py)
@@ -1017,6 +1019,17 @@ def main():
                 cali["measured_full_recipe_cifar"] = {k: mj[k] for k in ("recipe", "wall_clock_s", "phases_s", "reconstruction_units",
                                                                        "iterations_per_unit", "ms_per_iteration_all_units") if k in mj}
                 cali["measured_full_recipe_cifar"]["source"] = "profiles/" + mname
+            # round 5: the full recipes of the other two LDM drivers BASELINE.json names (configs[2] CelebA-HQ LDM-4, configs[4] cin256-v2), each
+            # run once end to end through LatentRunner.quantize with this code (scratch/ldm_cali_full.py); recorded runs with their phase split
+            for key, fn in (("measured_full_recipe_celeba_ldm4", "r05_celeba_calibration_full.json"), ("measured_full_recipe_cin256", "r05_cin256_calibration_full.json")):
+                fpath = os.path.join(ROOT, "profiles", fn)
+                if os.path.exists(fpath):
+                    try:
+                        mj = json.load(open(fpath))
+                        cali[key] = {**{k: mj[k] for k in ("recipe", "wall_clock_s", "phases_s", "reconstruction_units", "iterations_per_unit",
+                                                             "adaround_iterations_per_s", "parts") if k in mj}, "source": "profiles/" + fn, "recorded_run": True}
+                    except Exception as e:
+                        cali[key] = {"error": repr(e)}
         cfgd = {"workload": info["workload"], "parallelism": f"replicas x{world} (no data-path collective)"}
         cfgd.update(info["extra"])
         out = {

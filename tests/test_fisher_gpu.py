@@ -107,7 +107,7 @@ UNITS = [("block", "down.1.block.0", False), ("block", "mid.attn_1", False), ("l
 # bars of the 20-iteration run per operand mode of the reconstruction GEMMs: (loss-curve deviation, masks equal, max / mean alpha deviation).
 # f32 = exact products (what the fixture was pinned with in round 3); bf16x3 = the SHIPPED default of the reconstruction iterations
 # (2^-16 per product; VERDICT r4: "F23 is still pinned only under TFMQ_RECON_GEMM=f32")
-BARS = {"f32": (1e-4, 0.999, 2e-3, 1e-5), "bf16x3": (5e-4, 0.998, 4e-3, 5e-5)}
+BARS = {"f32": (1e-4, 0.999, 2e-3, 1e-5), "bf16x3": (1e-4, 0.999, 8e-3, 5e-5)}      # measured: loss curve <= 7.8e-6, masks 100 %, |alpha - ref| max 3.95e-3 / mean 1.1e-5 (one conv of output_blocks.1.0)
 
 
 @pytest.mark.parametrize("gemm", ["f32", "bf16x3"])

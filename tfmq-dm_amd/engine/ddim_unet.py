@@ -75,7 +75,9 @@ class _Layer:
         if rowadd is not None:
             if rowadd_step is not None:      # per-step TIB table row (host read of the step counter: diagnostics mode only)
                 k = int(rowadd_step.item())
-                ra = rowadd[k * rowadd_step_stride: k * rowadd_step_stride + cout].reshape(1, cout).expand(B, cout).contiguous()
+                # `rowadd` is the view table[0, o:] of the [steps][sum Cout] TIB table: row k of this layer starts k * stride elements further
+                # in the STORAGE (slicing the one-row view past its end gave an empty tensor for every k >= 1 -- found by fixture F27, round 5)
+                ra = torch.as_strided(rowadd, (1, cout), (cout, 1), rowadd.storage_offset() + k * rowadd_step_stride).expand(B, cout).contiguous()
             else:
                 ra = rowadd.reshape(-1, cout).contiguous()
                 if ra.shape[0] == 1 and B > 1:

@@ -166,9 +166,19 @@ def _attach_fisher(unit, model, layer, cali_data, opt_mode, asym, use_aq, batch_
 LOSS_TRACE = None     # tests: {"counts": (...), "rows": [], "unit": 0} -> rows of (unit index, count, rec, round) at those counts
 
 
+IDX_CHUNK = 256      # mini-batch index vectors drawn and uploaded per host -> device copy
+
+
 def _run(unit: R._Unit, n: int, batch_size: int, iters: int, loss_func: LossFunc, device, rank0=True):
-    for _ in range(iters):
-        idx = torch.randperm(n)[:batch_size].to(device)       # same host RNG stream as the reference
+    idx_dev = None
+    for it in range(iters):
+        # torch.randperm(n)[:batch_size] per iteration, in iteration order: the same host RNG stream as the reference (:70, :188).  Round 5:
+        # the draws of IDX_CHUNK iterations are made together and travel in ONE copy -- a pageable host -> device copy per iteration is a
+        # stream-ordered blocking call, i.e. a host / GPU rendezvous in every iteration (nothing else in an iteration draws host random numbers)
+        if it % IDX_CHUNK == 0:
+            m = min(IDX_CHUNK, iters - it)
+            idx_dev = torch.stack([torch.randperm(n)[:batch_size] for _ in range(m)]).to(device)
+        idx = idx_dev[it % IDX_CHUNK]
         b, active = loss_func.tick()
         rec, rl = unit.iterate(idx)
         if LOSS_TRACE is not None and loss_func.count in LOSS_TRACE["counts"]:
