@@ -513,6 +513,14 @@ int tfmq_adaround_soft_fwd(tfmq_handle h, const float* w, const float* alpha, co
 int tfmq_adaround_bwd_adam(tfmq_handle h, const float* w, float* alpha, const float* delta, const float* zp,
                            const float* g_what, float* m, float* v, size_t rows, size_t cols, int level, float w_reg,
                            float b_temp, float lr, int t, float* round_loss_or_null, void* stream);
+/* Round 5 (ABI 9): the same launch with its four per-iteration scalars in DEVICE memory -- scalars_dev[4] = what tfmq_adaround_scalars
+ * computes for (w_reg, b_temp, lr, t) -- so that a whole reconstruction iteration (quant/reconstruction.py:63-78,182-198: forward, loss,
+ * backward, optimizer step) can be captured once as a hipGraph and replayed with a 16-byte copy in front of every replay.  Bit-identical to
+ * tfmq_adaround_bwd_adam.  tfmq_adaround_scalars is a host function (no handle, no launch). */
+int tfmq_adaround_scalars(float w_reg, float b_temp, float lr, int t, float* out4);
+int tfmq_adaround_bwd_adam_dyn(tfmq_handle h, const float* w, float* alpha, const float* delta, const float* zp,
+                               const float* g_what, float* m, float* v, size_t rows, size_t cols, int level,
+                               const float* scalars_dev, float* round_loss_or_null, void* stream);
 /* rec = mean over all-but-dim1 of sum_dim1 |pred-tgt|^2 for NHWC tensors == sum(|d|^2)/(n/C)
  * (lp_loss, quant_layer.py:152-153); also writes g = dL/dpred.  loss: one device float. */
 int tfmq_recon_loss(tfmq_handle h, const float* pred, const float* tgt, float* g_or_null, size_t n, size_t denom,

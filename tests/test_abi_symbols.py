@@ -29,7 +29,7 @@ def test_header_symbols_all_exported(lib):
     l = lib.load()
     for name in declared:
         assert hasattr(l, name), name
-    assert l.tfmq_abi_version() == 8
+    assert l.tfmq_abi_version() == 9
 
 
 def test_docs_quote_the_real_abi_size_and_version(lib):

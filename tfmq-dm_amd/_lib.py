@@ -154,6 +154,9 @@ _SIGS = {
     "tfmq_adaround_soft_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_size_t, c_int, c_int, c_void_p]),
     "tfmq_adaround_bwd_adam": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_size_t,
                                        c_int, c_float, c_float, c_float, c_int, c_void_p, c_void_p]),
+    "tfmq_adaround_scalars": (c_int, [c_float, c_float, c_float, c_int, c_void_p]),
+    "tfmq_adaround_bwd_adam_dyn": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_size_t,
+                                           c_int, c_void_p, c_void_p, c_void_p]),
     "tfmq_recon_loss": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_size_t, c_void_p, c_void_p]),
     "tfmq_gemm_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, C.c_long, C.c_long, C.c_long, C.c_long,
                               C.c_long, c_int, C.c_long, C.c_long, C.c_long, c_float, c_void_p, c_void_p, c_int, c_int, c_void_p,

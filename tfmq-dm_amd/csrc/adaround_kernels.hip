@@ -101,8 +101,11 @@ __global__ __launch_bounds__(256) void k_adaround_bwd_adam(const float* __restri
                                                            const float* __restrict__ g_what, float* __restrict__ m,
                                                            float* __restrict__ v, size_t rows, size_t cols, float lmax,
                                                            float w_reg, float b_temp, float step_size, float bc2_sqrt,
-                                                           float* __restrict__ round_loss) {
+                                                           float* __restrict__ round_loss, const float* __restrict__ dyn) {
   const float beta1 = 0.9f, beta2 = 0.999f, eps = 1e-8f;
+  if (dyn) {      // tfmq_adaround_bwd_adam_dyn: the four per-iteration scalars come from device memory (a captured iteration replays them)
+    w_reg = dyn[0]; b_temp = dyn[1]; step_size = dyn[2]; bc2_sqrt = dyn[3];
+  }
   const size_t n = rows * cols, stride = static_cast<size_t>(gridDim.x) * blockDim.x;
   float rl = 0.0f;
   for (size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) {
@@ -144,8 +147,11 @@ __global__ __launch_bounds__(256) void k_adaround_bwd_adam4(const float* __restr
                                                             const float* __restrict__ g_what, float* __restrict__ m,
                                                             float* __restrict__ v, unsigned rows, unsigned cols4, float lmax,
                                                             float w_reg, float b_temp, float step_size, float bc2_sqrt,
-                                                            float* __restrict__ round_loss) {
+                                                            float* __restrict__ round_loss, const float* __restrict__ dyn) {
   const float beta1 = 0.9f, beta2 = 0.999f, eps = 1e-8f;
+  if (dyn) {
+    w_reg = dyn[0]; b_temp = dyn[1]; step_size = dyn[2]; bc2_sqrt = dyn[3];
+  }
   const unsigned n4 = rows * cols4, stride = gridDim.x * blockDim.x;
   float rl = 0.0f;
   for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
@@ -194,30 +200,62 @@ __global__ __launch_bounds__(256) void k_adaround_bwd_adam4(const float* __restr
   }
 }
 
-extern "C" int tfmq_adaround_bwd_adam(tfmq_handle h, const float* w, float* alpha, const float* delta, const float* zp,
-                                      const float* g_what, float* m, float* v, size_t rows, size_t cols, int level,
-                                      float w_reg, float b_temp, float lr, int t, float* round_loss, void* stream) {
-  TFMQ_CHECK_ARG(h, h && w && alpha && delta && zp && g_what && m && v && rows > 0 && cols > 0 && t >= 1,
-                 "adaround_bwd_adam: bad argument");
+// {w_reg, b_temp, lr / (1 - 0.9^t), sqrt(1 - 0.999^t)}: the per-iteration scalars of the fused kernel, computed in ONE place for both entry points
+static void adam_scalars(float w_reg, float b_temp, float lr, int t, float* out4) {
   const double bc1 = 1.0 - pow(0.9, t), bc2 = 1.0 - pow(0.999, t);
+  out4[0] = w_reg;
+  out4[1] = b_temp;
+  out4[2] = static_cast<float>(lr / bc1);
+  out4[3] = static_cast<float>(sqrt(bc2));
+}
+
+static int launch_bwd_adam(tfmq_handle h, const float* w, float* alpha, const float* delta, const float* zp, const float* g_what, float* m,
+                           float* v, size_t rows, size_t cols, int level, const float* s4, const float* dyn, float* round_loss, void* stream) {
   const bool al16 = ((reinterpret_cast<uintptr_t>(w) | reinterpret_cast<uintptr_t>(alpha) | reinterpret_cast<uintptr_t>(g_what) |
                       reinterpret_cast<uintptr_t>(m) | reinterpret_cast<uintptr_t>(v)) & 15) == 0;
   if (cols % 4 == 0 && al16 && rows * cols < (1ull << 32)) {
     int blocks4 = ceil_div(static_cast<long>(rows * cols / 4), 256);
     if (blocks4 > h->cu_count * 4) blocks4 = h->cu_count * 4;
     hipLaunchKernelGGL(k_adaround_bwd_adam4, dim3(blocks4), dim3(256), 0, as_stream(stream), w, alpha, delta, zp, g_what, m, v,
-                       static_cast<unsigned>(rows), static_cast<unsigned>(cols / 4), static_cast<float>(level - 1), w_reg, b_temp,
-                       static_cast<float>(lr / bc1), static_cast<float>(sqrt(bc2)), round_loss);
+                       static_cast<unsigned>(rows), static_cast<unsigned>(cols / 4), static_cast<float>(level - 1), s4[0], s4[1], s4[2], s4[3],
+                       round_loss, dyn);
     TFMQ_LAUNCH_CHECK(h);
     return TFMQ_OK;
   }
   int blocks = ceil_div(static_cast<long>(rows * cols), 256);
   if (blocks > h->cu_count * 8) blocks = h->cu_count * 8;
   hipLaunchKernelGGL(k_adaround_bwd_adam, dim3(blocks), dim3(256), 0, as_stream(stream), w, alpha, delta, zp, g_what, m,
-                     v, rows, cols, static_cast<float>(level - 1), w_reg, b_temp, static_cast<float>(lr / bc1),
-                     static_cast<float>(sqrt(bc2)), round_loss);
+                     v, rows, cols, static_cast<float>(level - 1), s4[0], s4[1], s4[2], s4[3], round_loss, dyn);
   TFMQ_LAUNCH_CHECK(h);
   return TFMQ_OK;
+}
+
+extern "C" int tfmq_adaround_bwd_adam(tfmq_handle h, const float* w, float* alpha, const float* delta, const float* zp,
+                                      const float* g_what, float* m, float* v, size_t rows, size_t cols, int level,
+                                      float w_reg, float b_temp, float lr, int t, float* round_loss, void* stream) {
+  TFMQ_CHECK_ARG(h, h && w && alpha && delta && zp && g_what && m && v && rows > 0 && cols > 0 && t >= 1,
+                 "adaround_bwd_adam: bad argument");
+  float s4[4];
+  adam_scalars(w_reg, b_temp, lr, t, s4);
+  return launch_bwd_adam(h, w, alpha, delta, zp, g_what, m, v, rows, cols, level, s4, nullptr, round_loss, stream);
+}
+
+// Round 5: the same launch with its four per-iteration scalars read from DEVICE memory, so that a reconstruction iteration can be captured
+// once as a hipGraph and replayed: the host writes scalars[4] = tfmq_adaround_scalars(w_reg, b_temp, lr, t) (a 16-byte copy on the stream)
+// in front of each replay.  Same kernels, same arithmetic: equal to tfmq_adaround_bwd_adam bit for bit.
+extern "C" int tfmq_adaround_scalars(float w_reg, float b_temp, float lr, int t, float* out4) {
+  if (!out4 || t < 1) return TFMQ_ERR_ARG;
+  adam_scalars(w_reg, b_temp, lr, t, out4);
+  return TFMQ_OK;
+}
+
+extern "C" int tfmq_adaround_bwd_adam_dyn(tfmq_handle h, const float* w, float* alpha, const float* delta, const float* zp,
+                                          const float* g_what, float* m, float* v, size_t rows, size_t cols, int level,
+                                          const float* scalars_dev, float* round_loss, void* stream) {
+  TFMQ_CHECK_ARG(h, h && w && alpha && delta && zp && g_what && m && v && rows > 0 && cols > 0 && scalars_dev,
+                 "adaround_bwd_adam_dyn: bad argument");
+  const float s4[4] = {0.0f, 0.0f, 0.0f, 1.0f};
+  return launch_bwd_adam(h, w, alpha, delta, zp, g_what, m, v, rows, cols, level, s4, scalars_dev, round_loss, stream);
 }
 
 // loss = sum |pred - tgt|^2 / denom  (lp_loss p=2: sum over dim 1, mean over the rest => denom =

@@ -1,7 +1,7 @@
 // Handle, device query, hipGraph capture helpers and HIP-event timing.
 #include "common.hpp"
 
-extern "C" int tfmq_abi_version(void) { return 8; }   // 8: tfmq_ff_fused, TFMQ_OUT_GEGLU_Q8_FAST (round 4); 7: tfmq_conv_desc.ksplit (split-K of the w4a8 tile kernel); 6: + Fisher-weighted reconstruction (upsample2x_bwd, kl_softmax_grad, fisher_loss); 3: tfmq_conv_desc grew x2 / cin1; 4: + w64 (round 2); 5: + W8A8 / attention-quantizer / GEMM-precision entry points, TFMQ_TILE_SLAB128 (round 3)
+extern "C" int tfmq_abi_version(void) { return 9; }   // 9: tfmq_adaround_scalars / tfmq_adaround_bwd_adam_dyn (captured reconstruction iterations, round 5); 8: tfmq_ff_fused, TFMQ_OUT_GEGLU_Q8_FAST (round 4); 7: tfmq_conv_desc.ksplit (split-K of the w4a8 tile kernel); 6: + Fisher-weighted reconstruction (upsample2x_bwd, kl_softmax_grad, fisher_loss); 3: tfmq_conv_desc grew x2 / cin1; 4: + w64 (round 2); 5: + W8A8 / attention-quantizer / GEMM-precision entry points, TFMQ_TILE_SLAB128 (round 3)
 
 extern "C" int tfmq_create(int device, tfmq_handle* out) {
   if (!out) return TFMQ_ERR_ARG;

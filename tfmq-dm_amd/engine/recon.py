@@ -62,6 +62,10 @@ class AdaLayer:
         ops.adaround_bwd_adam(self.w, self.alpha, self.delta, self.zp, g_what.contiguous(), self.m, self.v, self.level,
                               w_reg, b_temp, lr, t, round_loss)
 
+    def step_dyn(self, g_what: torch.Tensor, scalars: torch.Tensor, round_loss: torch.Tensor):
+        """The same step with (w_reg, b_temp, lr / bc1, sqrt bc2) read from the device tensor `scalars` (a captured iteration)."""
+        ops.adaround_bwd_adam_dyn(self.w, self.alpha, self.delta, self.zp, g_what.contiguous(), self.m, self.v, self.level, scalars, round_loss)
+
 
 def _chunk_cuts(sizes: Sequence[int], n_chunks: int):
     """Cut a list of layer gradient sizes into <= n_chunks contiguous pieces of roughly equal bytes, at layer boundaries.
@@ -110,9 +114,52 @@ class _Unit:
         self._comm_stream = None
         self.gemm_mode = os.environ.get("TFMQ_RECON_GEMM", "bf16x3")
         self.exchange_chunks = max(1, int(os.environ.get("TFMQ_EXCHANGE_CHUNKS", "2")))
+        # Round 5: an iteration (forward, loss, backward, AdaRound backward + Adam of every layer) is ~60-130 launches of 10-100 us at the
+        # 16 x 16 / 8 x 8 levels of SD -- the host cannot issue them as fast as the GPU runs them.  Single-GPU units capture the
+        # iteration ONCE (hipGraph through torch.cuda.graph: every launch of the C ABI goes to torch's current stream) after two eager
+        # iterations and replay it; what changes per iteration travels in device memory: the mini-batch indices (a static index tensor)
+        # and the four scalars of the optimizer kernel (tfmq_adaround_bwd_adam_dyn).  Same kernels in the same order: bit-identical
+        # (tests/test_recon_graph_gpu.py).  TFMQ_RECON_GRAPH=0 keeps every iteration eager.
+        self.graph_on = os.environ.get("TFMQ_RECON_GRAPH", "1") != "0" and dev.type == "cuda" and not (world_size > 1 and allreduce is not None)
+        self._graph = None
+
+    GRAPH_AFTER = 2      # eager iterations in front of the capture (workspaces of the GEMM's split-K path are allocated by then)
+
+    SC_CHUNK = 256       # iterations whose optimizer scalars are computed on the host and uploaded together
+
+    def _graph_iterate(self, idx):
+        if self._graph is None:
+            self._idx_static = idx.clone()
+            self._sc_dev = torch.zeros(4, dtype=torch.float32, device=idx.device)
+            self._sc_chunk, self._sc_base = None, 0
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                if self.gemm_mode != "f32":
+                    with ops.gemm_precision(self.gemm_mode, self._rl.device.index):
+                        rec, grads = self._forward_backward(self._idx_static)
+                else:
+                    rec, grads = self._forward_backward(self._idx_static)
+                self._rl.zero_()
+                for layer, gg in zip(self.layers, grads):
+                    layer.step_dyn(gg, self._sc_dev, self._rl)
+            self._graph, self._rec_static = g, rec
+        if self._sc_chunk is None or self.count - self._sc_base >= self._sc_chunk.shape[0]:
+            # {w_reg, b (0 during the warm-up), lr / (1 - 0.9^t), sqrt(1 - 0.999^t)} of the next SC_CHUNK iterations, computed by the library's
+            # own host function (the values tfmq_adaround_bwd_adam would compute for each t); one upload, then device-to-device rows
+            rows = []
+            for c in range(self.count, min(self.count + self.SC_CHUNK, self.iters + 1)):
+                b = temp_decay(c, self.iters, self.warmup, self.b_range[0], self.b_range[1])
+                rows.append(ops.adaround_scalars(self.w_reg, b if c >= self.iters * self.warmup else 0.0, self.lr, c))
+            self._sc_chunk, self._sc_base = torch.tensor(rows, dtype=torch.float32).to(idx.device), self.count
+        self._idx_static.copy_(idx)
+        self._sc_dev.copy_(self._sc_chunk[self.count - self._sc_base])
+        self._graph.replay()
+        return self._rec_static, self._rl
 
     def iterate(self, idx: torch.Tensor):
         self.count += 1
+        if self.graph_on and self.count > self.GRAPH_AFTER and self.fisher is None and _Unit.trace is None:
+            return self._graph_iterate(idx)
         # TFMQ_RECON_GEMM = bf16x3 (default) | f32 | f16: operand precision of the unit's forward / backward GEMMs on the matrix cores
         # (ops.gemm_precision; csrc/gemm_f32_mfma.hip).  bf16x3 = each fp32 operand split hi + lo in bf16, three MFMAs per product,
         # fp32 accumulation: 2^-16 relative error per product (measured 4.5e-6 max-normalised on SD shapes against 5e-7..1.6e-6 of the

@@ -62,7 +62,10 @@ def _device_identity(dev):
     import socket
     p = _torch.cuda.get_device_properties(dev)
     pci = tuple(getattr(p, k, None) for k in ("pci_domain_id", "pci_bus_id", "pci_device_id"))
-    return f"{socket.gethostname()}|{getattr(p, 'uuid', None)}|{pci}"
+    uuid = getattr(p, "uuid", None)
+    if uuid is None and all(v is None for v in pci):
+        return ""            # this torch build exposes neither: no identity, no check (never a false refusal on a real 8-GPU node)
+    return f"{socket.gethostname()}|{uuid}|{pci}"
 
 
 def duplicate_devices(identities):
@@ -95,7 +98,7 @@ def _refuse_duplicate_devices(mine):
     else:
         ids = [None] * world
         dist.all_gather_object(ids, mine)
-    dup = duplicate_devices(ids)
+    dup = [] if any(not i for i in ids) else duplicate_devices(ids)
     if dup:
         raise TfmqError(f"tfmq_comm_init: ranks {dup} share a GPU ({ids[dup[0][0]]}); RCCL needs one device per rank "
                         "(set the device before the first device all-reduce: quant/calibration.py:241-245)")

@@ -1358,6 +1358,26 @@ def adaround_bwd_adam(w, alpha, delta, zp, g_what, m, v, level: int, w_reg: floa
                    _p(round_loss), _stream(d))
 
 
+def adaround_scalars(w_reg: float, b_temp: float, lr: float, t: int):
+    """The four per-iteration scalars of the fused AdaRound-backward + Adam kernel as the library computes them for tfmq_adaround_bwd_adam:
+    [w_reg, b_temp, lr / (1 - 0.9^t), sqrt(1 - 0.999^t)] (fp32).  Host function; feeds adaround_bwd_adam(..., dyn=...)."""
+    from ._lib import load
+    out = (C.c_float * 4)()
+    rc = load().tfmq_adaround_scalars(float(w_reg), float(b_temp), float(lr), int(t), out)
+    if rc != 0:
+        raise TfmqError(f"tfmq_adaround_scalars failed ({rc})")
+    return [out[0], out[1], out[2], out[3]]
+
+
+def adaround_bwd_adam_dyn(w, alpha, delta, zp, g_what, m, v, level: int, scalars: torch.Tensor, round_loss: Optional[torch.Tensor] = None):
+    """adaround_bwd_adam with its per-iteration scalars read from the device tensor `scalars` [4] (adaround_scalars): capturable."""
+    d = _dev(w)
+    _chk(scalars, torch.float32, "scalars")
+    rows = delta.numel()
+    handle(d).call("adaround_bwd_adam_dyn", _p(w), _p(alpha), _p(delta.reshape(-1).contiguous()), _p(zp.reshape(-1).contiguous()),
+                   _p(g_what), _p(m), _p(v), rows, w.numel() // rows, level, _p(scalars), _p(round_loss), _stream(d))
+
+
 # ------------------------------------------------------------------------------ K15 (reconstruction fwd/bwd pieces)
 GEMM_PRECISIONS = {"f32": 0, "bf16x3": 1, "f16": 2}
 
@@ -1396,7 +1416,7 @@ def set_gemm_profile(rec, every: int = 1, cap: int = 2048):
 def _gemm_call(d, name, flops, shape, *args):
     h = handle(d)
     P = _gemm_prof
-    if P is None:
+    if P is None or torch.cuda.is_current_stream_capturing():      # (an event recorded inside a capture is a graph node, not a timestamp)
         h.call(name, *args)
         return
     P["n"] += 1

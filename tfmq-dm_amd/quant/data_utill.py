@@ -42,7 +42,37 @@ def save_inout(model, layer, cali_data: Tuple[torch.Tensor], asym: bool = False,
     dev = next(model.model.parameters()).device
     xs, ts = cali_data[0], cali_data[1]
     cs = cali_data[2] if len(cali_data) > 2 else None
-    ins, outs, tembs, ctxs = [], [], [], []
+    # Round 5: every cached tensor is allocated ONCE at its final size and filled batch by batch -- collecting the batches in a list and
+    # torch.cat'ing them at the end needs twice the memory for a moment, which the 64 x 64 up-path units of the cin256 recipe (10 240
+    # samples x 64 x 64 x 576 channels = 90 GiB of input) do not have even on 288 GB.
+    n_total = int(xs.size(0))
+
+    class _Rows:
+        def __init__(self):
+            self.buf, self.n = None, 0
+
+        def append(self, t, bsz):
+            if self.buf is None and self.n == 0 and not getattr(self, "parts", None):
+                if t.shape[0] % bsz == 0:      # rows per sample: 1, or heads for the [(b h), ...] tensors of the stand-alone matmul units
+                    self.rows = n_total * (t.shape[0] // bsz)
+                    self.buf = torch.empty((self.rows,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+                else:                          # (a tensor that does not scale with the batch: collected and concatenated as before)
+                    self.parts = []
+            if self.buf is None:
+                self.parts.append(t)
+                return
+            self.buf[self.n:self.n + t.shape[0]].copy_(t)
+            self.n += t.shape[0]
+
+        def __bool__(self):
+            return self.buf is not None or bool(getattr(self, "parts", None))
+
+        def tensor(self):
+            if self.buf is None:
+                return torch.cat(self.parts)
+            assert self.n == self.rows, (self.n, self.rows)
+            return self.buf
+    ins, outs, tembs, ctxs = _Rows(), _Rows(), _Rows(), _Rows()
     # `batch_size` is the reconstruction mini-batch (8 in the SD recipe); the capture forwards are per-sample
     # independent (tests/test_full_size_properties_gpu.py: batch 12 == 6 + 6 bit for bit), so they run at a batch that
     # fills the GPU instead of a launch-bound one
@@ -64,25 +94,25 @@ def save_inout(model, layer, cali_data: Tuple[torch.Tensor], asym: bool = False,
         fwd(x, t, c, taps)
         if name not in taps:
             raise KeyError(f"save_inout: the engine exposes no tap for unit '{name}'")
-        outs.append(taps[name][1])
+        outs.append(taps[name][1], x.shape[0])
         if asym:                                        # input: upstream with the already-quantised weights
             taps = StopAt(name)
             model.set_quant_state(True, use_act)
             fwd(x, t, c, taps)
         tin = taps[name][0]
         if isinstance(layer, (QuantBasicTransformerBlock, QuantQKMatMul, QuantSMVMatMul)):      # two-input units: (tokens, context) / (q, k) / (weight, v)
-            ins.append(tin[0])
-            ctxs.append(tin[1])
+            ins.append(tin[0], x.shape[0])
+            ctxs.append(tin[1], x.shape[0])
             continue
         if isinstance(tin, tuple):       # (h, skip): concatenated input of an up-path block
             tin = torch.cat(tin, dim=-1)
-        ins.append(tin)
+        ins.append(tin, x.shape[0])
         if isinstance(layer, (QuantResnetBlock, QuantResBlock)):
-            tembs.append(taps["__temb__"])
+            tembs.append(taps["__temb__"], x.shape[0])
     model.set_quant_state(False, False)
     layer.set_quant_state(True, use_act)
-    cached_out = torch.cat(outs)
-    cached_in = (torch.cat(ins),) + ((torch.cat(tembs),) if tembs else ()) + ((torch.cat(ctxs),) if ctxs else ())
+    cached_out = outs.tensor()
+    cached_in = (ins.tensor(),) + ((tembs.tensor(),) if tembs else ()) + ((ctxs.tensor(),) if ctxs else ())
     logger.info(f"input shapes: {[tuple(c.shape) for c in cached_in]} output shape: {tuple(cached_out.shape)}")
     return cached_in, cached_out
 
