@@ -1,7 +1,7 @@
 """Round 5: a reconstruction iteration captured once as a hipGraph and replayed (engine/recon.py: _Unit._graph_iterate;
 tfmq_adaround_bwd_adam_dyn reads the optimizer's per-iteration scalars from device memory) against the same iterations issued eagerly
-(TFMQ_RECON_GRAPH=0): same kernels in the same order, so alphas, Adam moments, reconstruction and rounding losses must agree BIT FOR BIT at
-every iteration -- across the warm-up boundary where the rounding regulariser switches on (reference quant/reconstruction.py:63-78,
+(the default): same kernels in the same order, so the alphas and Adam moments must agree BIT FOR BIT after every iteration count -- the
+reported loss values are sums of fp32 atomics and agree to rounding -- across the warm-up boundary where the rounding regulariser switches on (reference quant/reconstruction.py:63-78,
 LossFunc / LinearTempDecay of reconstruction_util.py)."""
 import pytest
 import torch
@@ -68,7 +68,8 @@ def _run(kind, graph, monkeypatch, gemm):
 def test_replayed_iterations_equal_eager_iterations_bit_for_bit(kind, gemm, monkeypatch):
     h0, s0 = _run(kind, False, monkeypatch, gemm)
     h1, s1 = _run(kind, True, monkeypatch, gemm)
-    assert h0 == h1                                            # reconstruction and rounding loss of every iteration
+    for (r0, q0), (r1, q1) in zip(h0, h1):                      # reported losses: fp32 atomic sums, equal to rounding
+        assert abs(r0 - r1) <= 1e-5 * abs(r0) and abs(q0 - q1) <= 1e-5 * abs(q0) + 1e-12
     assert any(q > 0 for _, q in h0[8:]) and all(q == 0 for _, q in h0[:7])      # the regulariser switched on at 20 % of the iterations
     for (a0, m0, v0), (a1, m1, v1) in zip(s0, s1):
         assert torch.equal(a0, a1) and torch.equal(m0, m1) and torch.equal(v0, v1)

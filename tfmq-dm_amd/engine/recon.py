@@ -114,13 +114,14 @@ class _Unit:
         self._comm_stream = None
         self.gemm_mode = os.environ.get("TFMQ_RECON_GEMM", "bf16x3")
         self.exchange_chunks = max(1, int(os.environ.get("TFMQ_EXCHANGE_CHUNKS", "2")))
-        # Round 5: an iteration (forward, loss, backward, AdaRound backward + Adam of every layer) is ~60-130 launches of 10-100 us at the
-        # 16 x 16 / 8 x 8 levels of SD -- the host cannot issue them as fast as the GPU runs them.  Single-GPU units capture the
-        # iteration ONCE (hipGraph through torch.cuda.graph: every launch of the C ABI goes to torch's current stream) after two eager
-        # iterations and replay it; what changes per iteration travels in device memory: the mini-batch indices (a static index tensor)
-        # and the four scalars of the optimizer kernel (tfmq_adaround_bwd_adam_dyn).  Same kernels in the same order: bit-identical
-        # (tests/test_recon_graph_gpu.py).  TFMQ_RECON_GRAPH=0 keeps every iteration eager.
-        self.graph_on = os.environ.get("TFMQ_RECON_GRAPH", "1") != "0" and dev.type == "cuda" and not (world_size > 1 and allreduce is not None)
+        # Round 5 (measured, OFF by default): TFMQ_RECON_GRAPH=1 captures the iteration (forward, loss, backward, AdaRound backward + Adam of
+        # every layer: 60-130 launches) ONCE as a hipGraph through torch.cuda.graph after two eager iterations and replays it; what changes
+        # per iteration travels in device memory -- the mini-batch indices (a static index tensor) and the four scalars of the optimizer
+        # kernel (tfmq_adaround_bwd_adam_dyn).  Same kernels in the same order: alphas and Adam moments bit-identical
+        # (tests/test_recon_graph_gpu.py).  Same-box A/B on the whole SD job (74 units x 1000 iterations): 149.3 s replayed against 147.2 s
+        # eager (profiles/r05_ab_recon_graph.txt) -- the eager host already runs ahead of the GPU at every level; the job is bound by its
+        # kernels, not by launch rate.  Single-GPU units only (the multi-GPU exchange runs on a side stream between the kernels).
+        self.graph_on = os.environ.get("TFMQ_RECON_GRAPH", "0") == "1" and dev.type == "cuda" and not (world_size > 1 and allreduce is not None)
         self._graph = None
 
     GRAPH_AFTER = 2      # eager iterations in front of the capture (workspaces of the GEMM's split-K path are allocated by then)
