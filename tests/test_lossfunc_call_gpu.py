@@ -1,0 +1,71 @@
+"""LossFunc / LossFuncTimeEmbedding called like the reference calls them (quant/reconstruction_util.py:36-91, 117-173): value of
+rec + round against the reference's torch expressions evaluated on the host.  (The reconstruction drivers use the fused kernels and
+tick() / log(); the call form exists for code that drove the classes directly -- VERDICT r4, row C3.)"""
+import sys
+import os
+
+import pytest
+import torch
+import torch.nn as nn
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tfmq-dm_amd"))
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _layer():
+    from quant.quant_layer import QMODE, QuantLayer, Scaler
+    from quant.reconstruction import _to_adaround
+    torch.manual_seed(3)
+    conv = nn.Conv2d(16, 24, 3, padding=1).to(DEV)
+    wq = {"bits": 4, "channel_wise": True, "scaler": Scaler.MINMAX}
+    aq = {"bits": 8, "channel_wise": False, "scaler": Scaler.MINMAX, "leaf_param": True}
+    layer = QuantLayer(conv, wq, aq, aq_mode=[QMODE.NORMAL.value, QMODE.QDIFF.value]).eval()
+    layer.set_quant_state(True, False)
+    layer(torch.randn(2, 16, 8, 8, device=DEV))          # initialises the weight quantizer
+    _to_adaround(layer)
+    return layer
+
+
+def test_lossfunc_call_matches_reference_expressions():
+    from quant.reconstruction_util import RLOSS, LossFunc
+    layer = _layer()
+    g = torch.Generator().manual_seed(1)
+    pred, tgt, grad = (torch.randn(6, 24, 8, 8, generator=g) for _ in range(3))
+    rv = layer.wqtizer.get_soft_tgt().detach().cpu()
+    for mode in (RLOSS.MSE, RLOSS.FISHER_DIAG, RLOSS.FISHER_FULL):
+        lf = LossFunc(o=layer, round_loss=RLOSS.RELAXATION, w=0.01, max_count=10, rec_loss=mode, b_range=(20, 2), decay_start=0.0, warmup=0.2)
+        for it in range(1, 5):
+            tot = float(lf(pred.to(DEV), tgt.to(DEV), grad.to(DEV) if mode != RLOSS.MSE else None))
+            if mode == RLOSS.MSE:
+                rec = (pred - tgt).abs().pow(2).sum(1).mean()
+            elif mode == RLOSS.FISHER_DIAG:
+                rec = ((pred - tgt).pow(2) * grad.pow(2)).sum(1).mean()
+            else:
+                a, gg = (pred - tgt).abs(), grad.abs()
+                rec = (torch.sum(a * gg, (1, 2, 3)).view(-1, 1, 1, 1) * a * gg).mean() / 100
+            b = lf.temp_decay(it)
+            rnd = 0.0 if it < 2 else 0.01 * float((1 - ((rv - 0.5).abs() * 2).pow(b)).sum())       # warm-up: 0.2 * 10 = 2 calls
+            ref = float(rec) + rnd
+            assert lf.count == it and abs(tot - ref) <= 2e-5 * abs(ref), (mode, it, tot, ref)
+
+
+def test_lossfunc_time_embedding_call():
+    from quant.reconstruction_util import RLOSS, LossFuncTimeEmbedding
+
+    class Holder(nn.Module):           # stands for a TIB: the QuantLayers are found by named_modules()
+        def __init__(self, layer):
+            super().__init__()
+            self.l = layer
+            self.temb_projs = []
+    layer = _layer()
+    lf = LossFuncTimeEmbedding(o=Holder(layer), round_loss=RLOSS.RELAXATION, w=0.01, max_count=10, rec_loss=RLOSS.MSE, b_range=(20, 2), warmup=0.0)
+    g = torch.Generator().manual_seed(2)
+    preds = [torch.randn(4, 32, generator=g) for _ in range(3)]
+    tgts = [torch.randn(4, 32, generator=g) for _ in range(3)]
+    tot = float(lf([p.to(DEV) for p in preds], [t.to(DEV) for t in tgts]))
+    rec = sum(float((p - t).abs().pow(2).sum(1).mean()) for p, t in zip(preds, tgts))
+    rv = layer.wqtizer.get_soft_tgt().detach().cpu()
+    ref = rec + 0.01 * float((1 - ((rv - 0.5).abs() * 2).pow(lf.temp_decay(1))).sum())
+    assert abs(tot - ref) <= 2e-5 * abs(ref), (tot, ref)

@@ -54,6 +54,43 @@ class LossFunc:
         active = not (self.count < self.loss_start or self.round_loss == RLOSS.NONE)
         return (b if active else 0.0), active
 
+    def __call__(self, pred, tgt, grad=None):
+        """The reference's call signature (reconstruction_util.py:36-91), VALUE ONLY: total = rec + round as a device scalar, count advanced, the
+        reference's log line every `print_freq` calls.  layer_ / block_reconstruction do not come through here -- their units compute the same
+        two terms and their gradients in the fused kernels (K12 / K13) and use tick() / log() -- but code that drove the class like the
+        reference does keeps working.  rec: tfmq_recon_loss (p = 2) / tfmq_fisher_loss on the device; the rounding term is the reference's
+        expression over `wqtizer.get_soft_tgt()` of every eligible layer of `o`."""
+        import torch
+        from tfmq_dm_amd import ops
+        self.count += 1
+        pred, tgt = pred.detach().float().contiguous(), tgt.detach().float().contiguous()
+        if self.rec_loss == RLOSS.MSE:
+            rec = ops.recon_loss(pred, tgt, pred.numel() // pred.shape[1], want_grad=False)[0][0]
+        else:
+            if grad is None:
+                raise ValueError("LossFunc: the Fisher-weighted losses need `grad`")
+            mode = fisher_mode(self.rec_loss)
+            denom = pred.numel() // pred.shape[1]        # (FISHER_FULL: the kernel takes its own mean / 100)
+            fg = grad.detach().float().contiguous()
+            # the kernel takes the cached weights |dL/d out| (DIAG squares them, FULL uses them as they are) -- reference :53-59
+            rec = ops.fisher_loss(pred, tgt, fg.abs().contiguous(), mode, denom, want_grad=False)[0][0]
+        b = self.temp_decay(self.count)
+        rnd = torch.zeros((), device=pred.device)
+        if self.count < self.loss_start or self.round_loss == RLOSS.NONE:
+            b = 0
+        elif self.round_loss == RLOSS.RELAXATION:
+            from .quant_layer import QuantLayer
+            layers = [self.o] if isinstance(self.o, QuantLayer) else [m for _, m in self.o.named_modules()
+                                                                      if isinstance(m, QuantLayer) and not m.quant_emb and not m.ignore_recon]
+            for m in layers:
+                rv = m.wqtizer.get_soft_tgt()
+                rnd = rnd + self.w * (1 - ((rv - 0.5).abs() * 2).pow(b)).sum()
+        else:
+            raise NotImplementedError
+        total = rec + rnd
+        self.log(total, rec, rnd, b)
+        return total
+
     def log(self, total, rec, rnd, b, rank0: bool = True):
         if self.count % print_freq == 0 and rank0:
             logger.info("Total loss:\t{:.8f} (rec:{:.8f}, round:{:.8f})\tb={:.2f}\tcount={}".format(
@@ -68,3 +105,43 @@ def fisher_mode(rec_loss: RLOSS):
 
 class LossFuncTimeEmbedding(LossFunc):
     """TIB variant: `rec` is the sum of lp_loss over the projections (reference :94-173)."""
+
+    def __call__(self, preds, tgts):
+        """Value only, the reference's signature (:117-173): sum of lp_loss over the (prediction, target) pairs of the TIB's projections + the
+        rounding term over the block's QuantLayers, walked exactly as the reference walks them (named_modules(), then emb_layers / temb_projs
+        again -- what is registered twice is counted twice there too)."""
+        import torch
+        from tfmq_dm_amd import ops
+        from .quant_layer import QuantLayer
+        if self.rec_loss != RLOSS.MSE:
+            raise ValueError("Not supported reconstruction loss function: {}".format(self.rec_loss))
+        self.count += 1
+        rec = torch.zeros((), device=preds[0].device)
+        for pred, tgt in zip(preds, tgts):
+            pr, tg = pred.detach().float().contiguous(), tgt.detach().float().contiguous()
+            rec = rec + ops.recon_loss(pr, tg, pr.numel() // pr.shape[1], want_grad=False)[0][0]
+        b = self.temp_decay(self.count)
+        rnd = torch.zeros((), device=preds[0].device)
+        if self.count < self.loss_start or self.round_loss == RLOSS.NONE:
+            b = 0
+        elif self.round_loss == RLOSS.RELAXATION:
+            def term(m):
+                rv = m.wqtizer.get_soft_tgt()
+                return self.w * (1 - ((rv - 0.5).abs() * 2).pow(b)).sum()
+            for _, m in self.o.named_modules():
+                if isinstance(m, QuantLayer) and not m.ignore_recon:
+                    rnd = rnd + term(m)
+            if hasattr(self.o, "emb_layers"):
+                for emb in self.o.emb_layers:
+                    for _, m in emb.named_modules():
+                        if isinstance(m, QuantLayer) and not m.ignore_recon:
+                            rnd = rnd + term(m)
+            else:
+                for m in getattr(self.o, "temb_projs", ()):
+                    if not m.ignore_recon:
+                        rnd = rnd + term(m)
+        else:
+            raise NotImplementedError
+        total = rec + rnd
+        self.log(total, rec, rnd, b)
+        return total
