@@ -91,4 +91,5 @@ def test_device_scalars_are_the_librarys_own(monkeypatch):
         ops.adaround_bwd_adam(w, st[0], d, z, g, mv[0][0], mv[0][1], 16, 0.01, b, 1e-3, t, rl[0])
         sc = torch.tensor(ops.adaround_scalars(0.01, b, 1e-3, t), dtype=torch.float32, device=DEV)
         ops.adaround_bwd_adam_dyn(w, st[1], d, z, g, mv[1][0], mv[1][1], 16, sc, rl[1])
-        assert torch.equal(st[0], st[1]) and torch.equal(mv[0][0], mv[1][0]) and torch.equal(mv[0][1], mv[1][1]) and torch.equal(rl[0], rl[1])
+        assert torch.equal(st[0], st[1]) and torch.equal(mv[0][0], mv[1][0]) and torch.equal(mv[0][1], mv[1][1])
+        assert abs(float(rl[0]) - float(rl[1])) <= 1e-5 * abs(float(rl[0])) + 1e-12      # (the rounding loss is a sum of fp32 atomics: equal to rounding)

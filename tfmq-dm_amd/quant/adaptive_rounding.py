@@ -38,7 +38,9 @@ class AdaRoundQuantizer(nn.Module):
         self.alpha = nn.Parameter(ops.adaround_init(x.detach().float().contiguous(), self.delta.float().contiguous()))
 
     def get_soft_tgt(self) -> torch.Tensor:
-        raise NotImplementedError("the soft target is fused into adaround_soft_fwd / adaround_bwd_adam on the device")
+        """h(alpha) = clamp(sigmoid(alpha) (zeta - gamma) + gamma, 0, 1) (reference :40-41).  The reconstruction kernels evaluate it inside
+        adaround_soft_fwd / adaround_bwd_adam; this accessor serves callers of the reference's API (LossFunc.__call__)."""
+        return torch.clamp(torch.sigmoid(self.alpha.detach()) * (self.zeta - self.gamma) + self.gamma, 0, 1)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         d = self.delta.detach().float().contiguous()
