@@ -168,3 +168,26 @@ def test_fp_and_weight_only_states_in_the_exact_mode(golden, monkeypatch, which)
     taps = {}
     eng.forward(*args, taps=taps)
     assert len(taps) > 3
+
+
+def test_exact_mode_keeps_the_erf_gelu(golden, monkeypatch):
+    """the consumer-sized GELU of the fused GEGLU epilogue (TFMQ_OUT_GEGLU_Q8_FAST, bins within 1) must not leak into
+    the exact-fp diagnostics engine: every fused GEGLU projection it launches asks for the erf form (geglu_exact), the fast engine's do not."""
+    import tfmq_dm_amd.ops as ops
+    seen = {}
+    real = ops.conv2d_w4a8
+    for exact in (True, False):
+        calls = []
+
+        def spy(*a, **k):
+            if k.get("geglu_oq") is not None:
+                calls.append(bool(k.get("geglu_exact", False)))
+            return real(*a, **k)
+        monkeypatch.setattr(ops, "conv2d_w4a8", spy)
+        g, sd, cfg, eng, wq, qtable, act_names, args = _setup(golden, "ldm", monkeypatch, exact)
+        eng.prepare(wq(True), qtable.to(DEV))
+        y = eng.forward(*args)
+        assert torch.isfinite(y).all()
+        seen[exact] = calls
+    assert seen[True] and all(seen[True]), seen            # exact mode: every GEGLU launch with the erf GELU
+    assert seen[False] and not any(seen[False]), seen      # fast mode: the consumer-sized form where the kernel offers it
