@@ -115,7 +115,8 @@ def test_bx3_large_values_and_exact_zeros(ops):
 def test_bx3_forced_for_short_reductions_in_a_fresh_process():
     """The launcher gives k_gemm_bx3 the launches with K >= 1024 (where it measured faster); the short-K shapes of the table above reach it
     only under TFMQ_GEMM_BX3=2, which is read once per process: the whole table again in a child process with the kernel forced."""
-    env = dict(os.environ, TFMQ_GEMM_BX3="2")
-    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-k", "vs_float64 or epilogue or batched"],
-                       env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
-    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    for mode in ("2", "3"):       # 2: the 128 x 128 form for every K >= 64; 3: the 128 x 64 short-K form below K = 1024
+        env = dict(os.environ, TFMQ_GEMM_BX3=mode)
+        r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-k", "vs_float64 or epilogue or batched"],
+                           env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+        assert r.returncode == 0, (mode, r.stdout[-3000:] + r.stderr[-2000:])

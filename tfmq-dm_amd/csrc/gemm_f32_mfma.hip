@@ -437,13 +437,19 @@ __device__ __forceinline__ void bx3_split2(float x0, float x1, unsigned& hi, uns
 // touches (2 rows x 4 octets; banks = (a / 4) mod 32) use disjoint slot sets -- row & 7 alone is two-way conflicted on both sides.
 __device__ __forceinline__ int bx3_off(int row, int slot) { return row * 128 + ((slot ^ (((row >> 1) & 7) ^ ((row & 1) << 2))) << 4); }
 
-template <int MODE>
+template <int MODE, int R = 128>
 struct Bx3Loader {
-  static constexpr int NU = MODE == 1 ? 2 : 1;     // units per thread: MODE 1 (row, k-octet) x 2, MODE 2 (row quad, k quad) x 1
-  float4 reg[2][4];
+  // tile: R rows x 32 k.  MODE 1: units (row, k-octet), R * 4 of them -> R / 64 per thread; MODE 2: units (row quad, k quad), 2 R of them ->
+  // one per thread at R = 128; at R = 64 threads 128 .. 255 repeat the work of threads 0 .. 127 (same loads, same values to the same LDS bytes)
+  static constexpr int NU = MODE == 1 ? R / 64 : 1;
+  static constexpr int NI = MODE == 1 ? 2 * NU : 4;      // 16-byte items per thread and K-step
+  static constexpr int RQ = R / 4;                       // row quads (MODE 2)
+  float4 reg[2][NI];
   __amdgpu_buffer_rsrc_t rsrc;
   unsigned off[NU];                                // byte offset of the unit at the slice's first K-step; 0x80000000 (out of range: zeros) for rows past the operand
   unsigned kstep, kone;                            // bytes per K-step; MODE 2: bytes per k
+  __device__ __forceinline__ int m2_rq() const { return (threadIdx.x & (2 * R - 1)) & (RQ - 1); }
+  __device__ __forceinline__ int m2_kq4() const { return (threadIdx.x & (2 * R - 1)) / RQ; }
   __device__ __forceinline__ void init(const float* b, long rs, long ks, int r0, int kb, int rows, int K) {
     const int tid = threadIdx.x;
     if constexpr (MODE == 1) {
@@ -451,7 +457,7 @@ struct Bx3Loader {
       kstep = 32 * 4;
       kone = 4;
 #pragma unroll
-      for (int u = 0; u < 2; ++u) {
+      for (int u = 0; u < NU; ++u) {
         const int e = tid + 256 * u, gr = r0 + (e >> 2);
         off[u] = gr < rows ? static_cast<unsigned>(gr * rs + kb + (e & 3) * 8) * 4u : 0x80000000u;
       }
@@ -459,14 +465,14 @@ struct Bx3Loader {
       rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(b), 0, static_cast<int>(((K - 1) * ks + rows) * 4), 0x00020000);
       kstep = static_cast<unsigned>(32 * ks) * 4u;
       kone = static_cast<unsigned>(ks) * 4u;
-      const int gr = r0 + (tid & 31) * 4;
-      off[0] = gr < rows ? static_cast<unsigned>((kb + (tid >> 5) * 4) * ks + gr) * 4u : 0x80000000u;
+      const int gr = r0 + m2_rq() * 4;
+      off[0] = gr < rows ? static_cast<unsigned>((kb + m2_kq4() * 4) * ks + gr) * 4u : 0x80000000u;
     }
   }
   // k (relative to the K-step's first k) of the first value of item j
   __device__ __forceinline__ int item_k(int j) const {
     if constexpr (MODE == 1) return (threadIdx.x & 3) * 8 + (j & 1) * 4;
-    else return (threadIdx.x >> 5) * 4 + j;
+    else return m2_kq4() * 4 + j;
   }
   // K-step `step` of the slice.  CHECKED = false: every k of the step is inside the slice -- the per-thread offsets never change, the step
   // rides in the SCALAR offset of the buffer instruction (no VALU address arithmetic in the loop; with it the compiler put the temporaries
@@ -476,7 +482,7 @@ struct Bx3Loader {
   __device__ __forceinline__ void load(int step, int klen) {
     const unsigned sb = static_cast<unsigned>(step) * kstep;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < NI; ++j) {
       const int u = MODE == 1 ? (j >> 1) : 0;
       const unsigned o = off[u] + (MODE == 1 ? static_cast<unsigned>((j & 1) * 16) : static_cast<unsigned>(j) * kone);
       v4i32 v;
@@ -494,7 +500,7 @@ struct Bx3Loader {
     const int tid = threadIdx.x;
     if constexpr (MODE == 1) {
 #pragma unroll
-      for (int u = 0; u < 2; ++u) {
+      for (int u = 0; u < NU; ++u) {
         const int e = tid + 256 * u, row = e >> 2, oct = e & 3;
         const float4 a = reg[S][2 * u], b = reg[S][2 * u + 1];
         uint4 hi, lo;
@@ -506,7 +512,7 @@ struct Bx3Loader {
         *reinterpret_cast<uint4*>(lds + bx3_off(row, 4 + oct)) = lo;
       }
     } else {
-      const int rq = tid & 31, kq4 = tid >> 5;
+      const int rq = m2_rq(), kq4 = m2_kq4();
       const float r[4][4] = {{reg[S][0].x, reg[S][1].x, reg[S][2].x, reg[S][3].x}, {reg[S][0].y, reg[S][1].y, reg[S][2].y, reg[S][3].y},
                              {reg[S][0].z, reg[S][1].z, reg[S][2].z, reg[S][3].z}, {reg[S][0].w, reg[S][1].w, reg[S][2].w, reg[S][3].w}};
 #pragma unroll
@@ -522,10 +528,13 @@ struct Bx3Loader {
   }
 };
 
-template <int MA, int MB>
-__global__ __launch_bounds__(256, 2) void k_gemm_bx3(GemmP p) {
-  constexpr int BM = 128, BN = 128, BK = 32, TILE = 128 * 128;
-  __shared__ __attribute__((aligned(128))) unsigned char smem[4 * TILE];      // A[2] | B[2]: 64 KiB, two blocks per CU
+// BN = 128: 2 x 2 waves of 64 x 64 (the long-K form); BN = 64: 4 x 1 waves of 32 x 64, 48 KiB of LDS and three blocks per CU -- the short-K
+// form (K = 320 ... 1280: the Linears of the transformer units), 6 splitting instructions per MFMA against the 12 of k_gemm_f32_mfma<PREC = 1>
+template <int MA, int MB, int BN = 128>
+__global__ __launch_bounds__(256, BN == 128 ? 2 : 3) void k_gemm_bx3(GemmP p) {
+  constexpr int BM = 128, BK = 32, TILE = 128 * 128, TILE_B = BN * 128;
+  constexpr int WMT = BN == 128 ? 2 : 1, WNT = 2;     // MFMA tiles per wave along M / N
+  __shared__ __attribute__((aligned(128))) unsigned char smem[2 * TILE + 2 * TILE_B];      // A[2] | B[2]: 64 KiB (two blocks per CU) / 48 KiB (three)
   int bz = blockIdx.z, kb = 0, ke = p.K;
   if (p.ksplit > 1) {
     const int sp = bz % p.ksplit;
@@ -544,19 +553,19 @@ __global__ __launch_bounds__(256, 2) void k_gemm_bx3(GemmP p) {
   const int tn = p.tiles_n > 0 ? p.tiles_n : -p.tiles_n;
   const int m0 = (tile / tn) * BM, n0 = (tile % tn) * BN;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int wm = wid >> 1, wn = wid & 1;
+  const int wm = BN == 128 ? (wid >> 1) : wid, wn = BN == 128 ? (wid & 1) : 0;
   const int l32 = lane & 31, hh = lane >> 5;
 
-  Bx3Loader<MA> la;
-  Bx3Loader<MB> lb;
+  Bx3Loader<MA, 128> la;
+  Bx3Loader<MB, BN> lb;
   la.init(A, p.sam, p.sak, m0, kb, p.M, p.K);
   lb.init(B, p.sbn, p.sbk, n0, kb, p.N, p.K);
 
-  v16f acc[2][2];
+  v16f acc[WMT][WNT];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < WMT; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < WNT; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
@@ -569,7 +578,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_bx3(GemmP p) {
   lb.template store<0>(smem + 2 * TILE);
   __syncthreads();
   // fragment rows of this lane (row bits 0-3 = l32 bits 0-3 for every tile: one swizzle term)
-  const int ra = (wm * 2) * 32 + l32, rb = (wn * 2) * 32 + l32;
+  const int ra = (wm * WMT) * 32 + l32, rb = (wn * WNT) * 32 + l32;
   auto step = [&](int s, auto par_tag, auto chk_tag) {
     constexpr int PAR = decltype(par_tag)::value;
     constexpr bool CHK = decltype(chk_tag)::value;
@@ -579,21 +588,24 @@ __global__ __launch_bounds__(256, 2) void k_gemm_bx3(GemmP p) {
     __builtin_amdgcn_sched_barrier(0);   // the loads stay first in the step
 #endif
     const unsigned char* a_b = smem + PAR * TILE;
-    const unsigned char* b_b = smem + (2 + PAR) * TILE;
+    const unsigned char* b_b = smem + 2 * TILE + PAR * TILE_B;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      v8bf ah[2], al[2], bh[2], bl[2];
+      v8bf ah[WMT], al[WMT], bh[WNT], bl[WNT];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
+      for (int i = 0; i < WMT; ++i) {
         ah[i] = *reinterpret_cast<const v8bf*>(a_b + bx3_off(ra + 32 * i, 2 * ks + hh));
         al[i] = *reinterpret_cast<const v8bf*>(a_b + bx3_off(ra + 32 * i, 4 + 2 * ks + hh));
+      }
+#pragma unroll
+      for (int i = 0; i < WNT; ++i) {
         bh[i] = *reinterpret_cast<const v8bf*>(b_b + bx3_off(rb + 32 * i, 2 * ks + hh));
         bl[i] = *reinterpret_cast<const v8bf*>(b_b + bx3_off(rb + 32 * i, 4 + 2 * ks + hh));
       }
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < WMT; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < WNT; ++j) {
 #ifdef TFMQ_DBG_GEMM_NO_MFMA      // diagnostics build (results are garbage): the K loop without its MFMAs
           acc[i][j][0] += static_cast<float>(al[i][0]) + static_cast<float>(bh[j][1]) + static_cast<float>(ah[i][2]) + static_cast<float>(bl[j][3]);
 #else
@@ -607,7 +619,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_bx3(GemmP p) {
       // the next K-step's tile (loaded one step ago) is split and stored to the other buffer under the second half's MFMAs
       if (ks == 0) {
         la.template store<PAR ^ 1>(smem + (PAR ^ 1) * TILE);
-        lb.template store<PAR ^ 1>(smem + (2 + (PAR ^ 1)) * TILE);
+        lb.template store<PAR ^ 1>(smem + 2 * TILE + (PAR ^ 1) * TILE_B);
       }
 #endif
     }
@@ -625,15 +637,15 @@ __global__ __launch_bounds__(256, 2) void k_gemm_bx3(GemmP p) {
 
   // C/D layout: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)   (the epilogue of k_gemm_f32_mfma)
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < WMT; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int n = n0 + (wn * 2 + j) * 32 + l32;
+    for (int j = 0; j < WNT; ++j) {
+      const int n = n0 + (wn * WNT + j) * 32 + l32;
       if (n >= p.N) continue;
       const float bv = p.bias ? p.bias[n] : 0.0f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int m = m0 + (wm * 2 + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+        const int m = m0 + (wm * WMT + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
         if (m >= p.M) continue;
         if (p.ksplit > 1) {
           p.partial[(static_cast<size_t>(blockIdx.z % p.ksplit) * gridDim.z / p.ksplit + bz) * p.M * p.N +
@@ -692,7 +704,10 @@ int tfmq_gemm_f32_mfma_launch(tfmq_handle h, GemmP& p, int batch, hipStream_t st
   // launches (same-box A/B: profiles/r05_ab_gemm_bx3.txt).  TFMQ_GEMM_BX3=0 switches the kernel off, =2 forces it for every K >= 64
   // (A/B runs, tests).  Skinny outputs (N <= 64: the per-head attention products) stay on the 128 x 64 tiles.
   static const int bx3_mode = getenv("TFMQ_GEMM_BX3") ? atoi(getenv("TFMQ_GEMM_BX3")) : 1;
-  const bool bx3 = bx3_mode != 0 && prec == 1 && ma >= 1 && mb >= 1 && N > 64 && M > 64 && p.K >= (bx3_mode == 2 ? 64 : 1024);
+  const bool bx3_ok = bx3_mode != 0 && prec == 1 && ma >= 1 && mb >= 1 && N > 64 && M > 64 && p.K >= 64;
+  const bool bx3 = bx3_ok && p.K >= (bx3_mode == 2 ? 64 : 1024);
+  // the short-K form (128 x 64 tiles, three blocks per CU) for what is left: TFMQ_GEMM_BX3=3 (A/B, round 5)
+  const bool bx3s = bx3_ok && !bx3 && bx3_mode == 3;
   // 128 x 64 tiles (4 waves along M) measured faster than 128 x 128 at every SD unit shape (no column waste at
   // N = 320 / 640, twice the blocks for the mid-sized problems); TFMQ_GEMM_BN128 keeps the wide tile for A/B runs
   const int BN = bx3 ? 128 : ((N > 64 && getenv("TFMQ_GEMM_BN128")) ? 128 : 64);
@@ -739,6 +754,12 @@ int tfmq_gemm_f32_mfma_launch(tfmq_handle h, GemmP& p, int batch, hipStream_t st
   if (getenv("TFMQ_GEMM_NO_XCD")) p.tiles_n = -p.tiles_n;     // A/B runs: plain row-major tile order
   dim3 grid(((N + BN - 1) / BN) * ((M + 127) / 128), 1, batch * (ks > 1 ? ks : 1));
   const bool bk32 = getenv("TFMQ_GEMM_BK32") != nullptr;
+  if (bx3s) {
+    if (ma == 1 && mb == 1) hipLaunchKernelGGL((k_gemm_bx3<1, 1, 64>), grid, dim3(256), 0, st, p);
+    else if (ma == 1 && mb == 2) hipLaunchKernelGGL((k_gemm_bx3<1, 2, 64>), grid, dim3(256), 0, st, p);
+    else if (ma == 2 && mb == 1) hipLaunchKernelGGL((k_gemm_bx3<2, 1, 64>), grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((k_gemm_bx3<2, 2, 64>), grid, dim3(256), 0, st, p);
+  } else
   if (bx3) {
     if (ma == 1 && mb == 1) hipLaunchKernelGGL((k_gemm_bx3<1, 1>), grid, dim3(256), 0, st, p);
     else if (ma == 1 && mb == 2) hipLaunchKernelGGL((k_gemm_bx3<1, 2>), grid, dim3(256), 0, st, p);
