@@ -533,7 +533,10 @@ int tfmq_recon_loss(tfmq_handle h, const float* pred, const float* tgt, float* g
  * (v_mfma_f32_32x32x2f32; default, what every exactness-critical caller relies on), 1 = "bf16x3" (each fp32 operand value split into
  * bf16 hi + lo, three bf16 MFMAs per product: relative error 2^-16 per product, fp32 accumulation), 2 = fp16 operands (2^-11).
  * Meant for the AdaRound reconstruction iterations only (reference quant/reconstruction.py:63-78,182-198 runs them in fp32 autograd;
- * SURVEY section 7-1); small problems on the FMA tile stay exact. */
+ * SURVEY section 7-1); small problems on the FMA tile stay exact.
+ * Intended use: a property of the handle, set ONCE after tfmq_create -- a host that wants both precisions keeps one handle per precision
+ * (handles are independent: own workspaces, own error state) and picks the handle per launch, as the Python host does
+ * (_lib.handle(device, precision), ops.gemm_precision).  Nothing in the library changes it behind the caller's back. */
 int tfmq_set_gemm_precision(tfmq_handle h, int mode);
 /* batched strided GEMM: C[z] (M x N, row stride scm) = alpha * A[z] B[z] (+bias[n]) (+rowadd) (+residual), or C += ...
  * A(m,k) = A[m*sam + k*sak], B(k,n) = B[k*sbk + n*sbn]; rowadd[(m / rows_per_img)*rowadd_ld + n] */

@@ -36,11 +36,17 @@ def _case(ops, B, heads, Tq, Tk, d, w_level, seed, sharp=1.0):
     return q.to(DEV), k.to(DEV), v.to(DEV), qt, sel
 
 
-def _int_reference(ops, q, k, v, heads, scale, qt, sel, w_level):
-    """float64 restatement over the library's own input bins -> (out fp32 [B, Tq, C], rows with a value near a boundary [B, heads, Tq])"""
+def _int_reference(ops, q, k, v, heads, scale, qt, sel, w_level, oracle_bins=False):
+    """float64 restatement over the input bins -> (out fp32 [B, Tq, C], rows with a value near a boundary [B, heads, Tq]).  The bins of q, k, v
+    come from the library's own quantizer, or (oracle_bins) from the oracle's restatement of UniformAffineQuantizer on the host
+    (oracle/tfmq_oracle.py: quant_index, reference quant/quant_layer.py:225) -- the form that pins the kernel without trusting the library."""
     B, Tq, C = q.shape
     d = C // heads
-    bins = [ops.quantize_act(x.contiguous(), s).to(torch.int32) + 128 for x, s in zip((q, k, v), sel[:3])]
+    if oracle_bins:
+        import tfmq_oracle as O
+        bins = [O.quant_index(x.cpu(), qt[0, i, 0].cpu(), qt[0, i, 1].cpu(), 256).to(torch.int32).to(DEV) for i, x in enumerate((q, k, v))]
+    else:
+        bins = [ops.quantize_act(x.contiguous(), s).to(torch.int32) + 128 for x, s in zip((q, k, v), sel[:3])]
     (dq, zq), (dk, zk), (dv, zv), (dw, _) = [(float(qt[0, i, 0]), float(qt[0, i, 1])) for i in range(4)]
     iq = (bins[0].double() - zq).reshape(B, Tq, heads, d).permute(0, 2, 1, 3)
     ik = (bins[1].double() - zk).reshape(B, -1, heads, d).permute(0, 2, 1, 3)
@@ -79,6 +85,30 @@ def test_q8_attention_vs_integer_restatement(ops, B, heads, Tq, Tk, d, w_level):
     assert worst <= 4 * 255                                                                  # a moved row: a few bins times |b_v - z_v|
     again = ops.attention_q8(q, k, v, heads, scale, *sel, w_level)
     assert torch.equal(again, out)
+
+
+@pytest.mark.parametrize("B,heads,Tq,Tk,d,w_level", [(2, 8, 256, 256, 40, 256), (2, 4, 200, 77, 40, 256), (2, 8, 128, 77, 80, 256), (1, 3, 64, 640, 128, 64)])
+def test_q8_attention_vs_oracle_restatement(ops, B, heads, Tq, Tk, d, w_level):
+    """The same bar with the ORACLE deciding the bins of q, k, v (host restatement of quant/quant_layer.py:225) and of the softmax
+    (round-half-even of p / delta_w in float64, clamped): what makes tfmq_attention_q8 the default of a block with live quantizers."""
+    scale = float(d ** -0.5)
+    q, k, v, qt, sel = _case(ops, B, heads, Tq, Tk, d, w_level, 4000 + Tq + d)
+    out = ops.attention_q8(q, k, v, heads, scale, *sel, w_level)
+    ref, near, so = _int_reference(ops, q, k, v, heads, scale, qt, sel, w_level, oracle_bins=True)
+    lib_bins = [ops.quantize_act(x.contiguous(), s).to(torch.int32) + 128 for x, s in zip((q, k, v), sel[:3])]
+    import tfmq_oracle as O
+    for i, (x, lb) in enumerate(zip((q, k, v), lib_bins)):
+        ob = O.quant_index(x.cpu(), qt[0, i, 0].cpu(), qt[0, i, 1].cpu(), 256).to(torch.int32)
+        assert torch.equal(ob, lb.cpu()), f"input quantizer {i}: the library's bins differ from the oracle's"
+    clean = ~near
+    o4, r4 = out.reshape(B, Tq, heads, d).permute(0, 2, 1, 3), ref.reshape(B, Tq, heads, d).permute(0, 2, 1, 3)
+    same = (o4 == r4).all(dim=-1)
+    n_clean, n_same_clean = int(clean.sum()), int((same & clean).sum())
+    print(f"[q8 attention vs oracle bins B{B} h{heads} Tq{Tq} Tk{Tk} d{d} L{w_level}] {n_same_clean} of the {n_clean} rows without a boundary value "
+          f"bit-identical ({int(same.sum())} of {same.numel()} overall)")
+    assert n_clean > 0.5 * clean.numel()
+    assert n_same_clean >= n_clean - max(2, n_clean // 500), (n_clean, n_same_clean)
+    assert float((o4 - r4).abs().max()) / so <= 4 * 255
 
 
 @pytest.mark.parametrize("B,heads,Tq,Tk,d,pre", [(2, 8, 256, 256, 40, 1.0), (2, 8, 128, 77, 40, 1.0), (2, 4, 256, 256, 64, 64 ** -0.25)])
@@ -123,3 +153,29 @@ def test_engines_with_the_q8_attention_kernel(golden, monkeypatch, which):
     # a softmax bin on a rounding boundary moves between the two paths and avalanches through the W4A8 layers behind it, like the functional
     # path's own distance from the reference (tests/_avalanche.py)
     assert r1 <= max(5e-3, 3 * r0) and r01 <= max(5e-3, 2 * r0)
+
+
+@pytest.mark.parametrize("which", ["ddim", "ldm"])
+def test_q8_attention_is_the_default_of_live_quantizers(golden, monkeypatch, which):
+    """A (non exact-fp) engine whose attention quantizers are on routes through tfmq_attention_q8 without any switch; TFMQ_ATTN_Q8=0 takes
+    it back to the functional path, an observer (calibration) always does."""
+    import test_attention_quant_gpu as TA
+    g, eng, args, pre, anames, n_act, qtable = TA._setup(golden, which, monkeypatch, exact=False)
+    import tfmq_dm_amd.ops as ops_
+    calls = []
+    orig = ops_.attention_q8
+    monkeypatch.setattr(ops_, "attention_q8", lambda *a, **k: (calls.append(1), orig(*a, **k))[1])
+    monkeypatch.delenv("TFMQ_ATTN_Q8", raising=False)
+    e1 = TA.nchw(eng.forward(*args))
+    n_default = len(calls)
+    eng.set_calibration("record", 0)
+    eng.forward(*args)
+    eng.set_calibration(None)
+    n_record = len(calls) - n_default
+    monkeypatch.setenv("TFMQ_ATTN_Q8", "0")
+    e0 = TA.nchw(eng.forward(*args))
+    n_off = len(calls) - n_default - n_record
+    ref = TA.T(g[pre + "eps_w4a8_attnq"])
+    print(f"[{which}] default: {n_default} tfmq_attention_q8 launches, eps vs reference {TA.rel_l2(e1, ref):.3e}; TFMQ_ATTN_Q8=0: {TA.rel_l2(e0, ref):.3e}")
+    assert n_default > 0 and n_record == 0 and n_off == 0
+    assert TA.rel_l2(e1, ref) <= 4e-2 and TA.rel_l2(e0, ref) <= 4e-2

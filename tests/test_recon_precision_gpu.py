@@ -47,6 +47,35 @@ def test_gemm_precision_modes_vs_float64(M, N, K, ta, tb):
     assert err["f16"] <= 2e-3
 
 
+def test_precision_is_a_property_of_the_handle():
+    """ops.gemm_precision selects a second handle of the device (precision set once, at creation); the base handle is never toggled: a
+    launch through it from INSIDE the context is the exact-fp32 product, bit for bit."""
+    import ctypes as C
+    import tfmq_dm_amd.ops as ops
+    from tfmq_dm_amd import _lib
+    gen = torch.Generator().manual_seed(11)
+    A, B = torch.randn(512, 2880, generator=gen).to(DEV), torch.randn(2880, 320, generator=gen).to(DEV)
+    exact = ops.gemm(A, B)
+    base = _lib.handle(0)
+    assert ops.handle(0) is base
+    with ops.gemm_precision("bf16x3"):
+        hp = ops.handle(0)
+        assert hp is not base and hp is _lib.handle(0, 1) and hp.gemm_precision == 1
+        split = ops.gemm(A, B)
+        token = ops._gemm_prec.set(0)                  # what another thread / context sees: the base handle, untouched
+        try:
+            assert ops.handle(0) is base
+            again = ops.gemm(A, B)
+        finally:
+            ops._gemm_prec.reset(token)
+        with ops.gemm_precision("f16"):
+            assert ops.handle(0) is _lib.handle(0, 2)
+        assert ops.handle(0) is hp
+    assert ops.handle(0) is base
+    assert torch.equal(again, exact) and not torch.equal(split, exact)
+    assert torch.equal(ops.gemm(A, B), exact)
+
+
 def _loss_curve(golden, mode, monkeypatch):
     import tfmq_dm_amd.ddim.models as M
     import quant.reconstruction as REC

@@ -268,10 +268,22 @@ class Handle:
             pass
 
 
-_handles = {}
+_handles = {}           # device -> the exact-fp32 handle (the one the communicator and the samplers are bound to)
+_prec_handles = {}      # (device, precision != 0) -> a handle whose fp32 GEMMs run at that operand precision
 
 
-def handle(device: int = 0) -> Handle:
-    if device not in _handles:
-        _handles[device] = Handle(device)
-    return _handles[device]
+def handle(device: int = 0, gemm_precision: int = 0) -> Handle:
+    """The process's tfmq_handle of `device` whose fp32 GEMMs run at `gemm_precision` (0 exact fp32, 1 bf16x3, 2 fp16).  The precision is a
+    property a handle gets ONCE, right after tfmq_create, and keeps: ops.gemm_precision selects the handle, nothing toggles
+    tfmq_set_gemm_precision between launches."""
+    if not gemm_precision:
+        if device not in _handles:
+            _handles[device] = Handle(device)
+        return _handles[device]
+    key = (device, int(gemm_precision))
+    if key not in _prec_handles:
+        h = Handle(device)
+        h.call("set_gemm_precision", key[1])
+        h.gemm_precision = key[1]
+        _prec_handles[key] = h
+    return _prec_handles[key]

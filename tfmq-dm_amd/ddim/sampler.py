@@ -156,7 +156,7 @@ class GraphDdimSampler:
         self.x = torch.empty(batch, cfg["resolution"], cfg["resolution"], cfg.get("in_channels", 3), device=self.dev)
         self.stream = torch.cuda.Stream(self.dev)
         self.arena = ops.Arena()
-        self.h = handle(self.dev.index or 0)
+        self.h = handle(self.x.device.index)      # (the tensor's device is concrete even when the engine was given a bare "cuda")
         self.gid = None
 
     def _step_body(self):

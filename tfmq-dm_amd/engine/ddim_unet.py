@@ -493,9 +493,13 @@ class DdimUNetEngine:
         if self.calib is not None:
             def obs(which, t):
                 self._observe(sel[which], t, level=cfg["w_level"] if which == "w" else 256, always_zero=which == "w")
-        if obs is None and os.environ.get("TFMQ_ATTN_Q8", "0") == "1" and ops.attention_q8_ok(q.shape[-1] // heads, cfg["w_level"]) and _tape() is None:
-            # both products on the int8 matrix cores over the quantizers' bins (tfmq_attention_q8); off by default: ops.attention_quant's fp32
-            # products of the dequantised values are what the fixtures (F21) were pinned with
+        # Both products on the int8 matrix cores over the quantizers' bins (tfmq_attention_q8) whenever the quantizers are live and nothing
+        # needs the intermediate tensors (no observer, no gradient tape): exact integer sums, pinned against the oracle's restatement
+        # (tests/test_attention_q8_gpu.py).  The exact-fp32 engine keeps ops.attention_quant -- fp32 products of the dequantised values in the
+        # reference's order, what F21 was pinned with -- unless TFMQ_ATTN_Q8=1 forces the kernel; TFMQ_ATTN_Q8=0 switches it off everywhere.
+        env = os.environ.get("TFMQ_ATTN_Q8", "")
+        want_q8 = env == "1" or (env != "0" and not self.exact_fp)
+        if obs is None and want_q8 and ops.attention_q8_ok(q.shape[-1] // heads, cfg["w_level"]) and _tape() is None:
             return ops.attention_q8(q, k, v, heads, scale, sel["q"], sel["k"], sel["v"], sel["w"], cfg["w_level"], pre)
         return ops.attention_quant(q, k, v, heads, scale, sel["q"], sel["k"], sel["v"], sel["w"], cfg["w_level"], pre, obs)
 

@@ -74,7 +74,7 @@ class GraphLatentDdimSampler:
         self.pair_prefix = (not self.uncond) and os.environ.get("TFMQ_PAIR_PREFIX", "1") != "0" and hasattr(engine, "_dup")
         self.stream = torch.cuda.Stream(self.dev)
         self.arena = ops.Arena()
-        self.h = handle(self.dev.index or 0)
+        self.h = handle(self.x.device.index)      # (the tensor's device is concrete even when the engine was given a bare "cuda")
         self.gid = None
 
     def _step_body(self):

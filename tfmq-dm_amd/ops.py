@@ -7,14 +7,24 @@ current stream.  There is no CPU path: a CPU tensor raises TfmqError.
 from __future__ import annotations
 
 import ctypes as C
+import contextvars
 import os
 from typing import Optional, Tuple
 
 import torch
 
-from ._lib import ChainDesc, ConvDesc, FfDesc, GnDesc, QSel, TfmqError, handle
+from ._lib import ChainDesc, ConvDesc, FfDesc, GnDesc, QSel, TfmqError
+from ._lib import handle as _lib_handle
 
 NULL = None
+
+# operand precision of the fp32 GEMMs launched from this context (ops.gemm_precision): selects WHICH handle of the device a launch goes through
+_gemm_prec = contextvars.ContextVar("tfmq_gemm_precision", default=0)
+
+
+def handle(device: int = 0):
+    """The tfmq_handle this context launches through on `device` (_lib.handle(device, current ops.gemm_precision))."""
+    return _lib_handle(device, _gemm_prec.get())
 
 
 class Arena:
@@ -465,10 +475,21 @@ def set_conv_profile(rec):
     _conv_prof = rec
 
 
-def event_elapsed_ms(e0: int, e1: int, device: int = 0) -> float:
+def event_elapsed_ms(e0: int, e1: int, device: int = None) -> float:
+    """ms between two events of the profiling hooks (set_conv_profile / set_gemm_profile): they live on the base handle of the device the
+    launches ran on (default: the current device), whatever ops.gemm_precision context created or reads them."""
     ms = C.c_float()
-    handle(device).call("event_elapsed_ms", e0, e1, C.byref(ms))
+    _lib_handle(torch.cuda.current_device() if device is None else device).call("event_elapsed_ms", e0, e1, C.byref(ms))
     return float(ms.value)
+
+
+def _event_pair(d: int):
+    """Two fresh events on the base handle of device d -> (handle, id0, id1)"""
+    hb = _lib_handle(d)
+    e0, e1 = C.c_int(), C.c_int()
+    hb.call("event_create", C.byref(e0))
+    hb.call("event_create", C.byref(e1))
+    return hb, e0.value, e1.value
 
 
 def stats_segment(hw: int) -> int:
@@ -587,7 +608,9 @@ def _tune_conv(h, name, kind, d, dsc):
         for _ in range(3):
             h.call(name, C.byref(dsc), _stream(d))
         h.call("event_record", e1.value, _stream(d))
-        ms = event_elapsed_ms(e0.value, e1.value)        # synchronises on e1
+        ms_ = C.c_float()
+        h.call("event_elapsed_ms", e0.value, e1.value, C.byref(ms_))        # synchronises on e1; the events live on THIS device's handle
+        ms = ms_.value
         if best_ms is None or ms < best_ms:
             best, best_ms = t, ms
     _AUTOTUNE[key] = best
@@ -644,13 +667,11 @@ def _profiled_conv(name, kind, d, dsc, nops, nbytes=0.0):
     if _conv_prof is None:
         h.call(name, C.byref(dsc), _stream(d))
         return
-    e0, e1 = C.c_int(), C.c_int()
-    h.call("event_create", C.byref(e0))
-    h.call("event_create", C.byref(e1))
-    h.call("event_record", e0.value, _stream(d))
+    hb, e0, e1 = _event_pair(d)
+    hb.call("event_record", e0, _stream(d))
     h.call(name, C.byref(dsc), _stream(d))
-    h.call("event_record", e1.value, _stream(d))
-    _conv_prof.append((e0.value, e1.value, nops, kind, nbytes))
+    hb.call("event_record", e1, _stream(d))
+    _conv_prof.append((e0, e1, nops, kind, nbytes))
 
 
 def _conv_desc(x, B, H, W, cin, cout, kh, kw, stride, pad_t, pad_l, Ho, Wo, up2x, y, ldy, y_coff, rowadd, residual,
@@ -1054,13 +1075,11 @@ def row_chain(x: torch.Tensor, T: int, gemms, gn=None, ln=None):
     if _conv_prof is None:
         h.call("row_chain", C.byref(dsc), _stream(d))
         return outs
-    e0, e1 = C.c_int(), C.c_int()
-    h.call("event_create", C.byref(e0))
-    h.call("event_create", C.byref(e1))
-    h.call("event_record", e0.value, _stream(d))
+    hb, e0, e1 = _event_pair(d)
+    hb.call("event_record", e0, _stream(d))
     h.call("row_chain", C.byref(dsc), _stream(d))
-    h.call("event_record", e1.value, _stream(d))
-    _conv_prof.append((e0.value, e1.value, nops, "w4a8", nbytes))
+    hb.call("event_record", e1, _stream(d))
+    _conv_prof.append((e0, e1, nops, "w4a8", nbytes))
     return outs
 
 
@@ -1142,15 +1161,13 @@ def ff_fused(x: Optional[torch.Tensor], gamma: torch.Tensor, beta: torch.Tensor,
     if _conv_prof is None:
         h.call("ff_fused", C.byref(dsc), _stream(d))
         return ret
-    e0, e1 = C.c_int(), C.c_int()
-    h.call("event_create", C.byref(e0))
-    h.call("event_create", C.byref(e1))
-    h.call("event_record", e0.value, _stream(d))
+    hb, e0, e1 = _event_pair(d)
+    hb.call("event_record", e0, _stream(d))
     h.call("ff_fused", C.byref(dsc), _stream(d))
-    h.call("event_record", e1.value, _stream(d))
+    hb.call("event_record", e1, _stream(d))
     # algorithmic bytes: the fp16 row in and out (or int8 out), both weight operands
     nl = (pre is not None) + (post is not None)
-    _conv_prof.append((e0.value, e1.value, 2.0 * M * (2 * inner * Cc + inner * Cc + nl * Cc * Cc), "w4a8",
+    _conv_prof.append((e0, e1, 2.0 * M * (2 * inner * Cc + inner * Cc + nl * Cc * Cc), "w4a8",
                        M * Cc * (2.0 + (1.0 if (out_q8 is not None and post is None) else 2.0) + 3.0 * (pre is not None) + 2.0 * (post is not None))
                        + 3.0 * inner * Cc + nl * Cc * Cc))
     return ret
@@ -1383,8 +1400,11 @@ GEMM_PRECISIONS = {"f32": 0, "bf16x3": 1, "f16": 2}
 
 
 class gemm_precision:
-    """with ops.gemm_precision("bf16x3"): the fp32 GEMMs inside run their matrix-core path on split-bf16 operands (tfmq_set_gemm_precision);
-    restored to exact fp32 on exit.  Used by the AdaRound reconstruction iterations when TFMQ_RECON_GEMM asks for it."""
+    """with ops.gemm_precision("bf16x3"): the launches inside go through the device's bf16x3 HANDLE (_lib.handle(device, 1): its precision was
+    set once when it was created), so the fp32 GEMMs run their matrix-core path on split-bf16 operands; outside, and on every other thread /
+    context, launches keep the exact-fp32 handle -- no handle's state is toggled.  `device` is accepted for the callers that name it; the
+    selection itself is per context (a contextvars.ContextVar), the handle is looked up per launch from the tensor's device.  Used by the
+    AdaRound reconstruction iterations (TFMQ_RECON_GEMM)."""
 
     def __init__(self, mode: str, device: int = None):
         if mode not in GEMM_PRECISIONS:
@@ -1392,14 +1412,13 @@ class gemm_precision:
         self.mode, self.dev = GEMM_PRECISIONS[mode], device
 
     def __enter__(self):
-        self.d = torch.cuda.current_device() if self.dev is None else self.dev
-        if self.mode:
-            handle(self.d).call("set_gemm_precision", self.mode)
+        if self.mode and torch.cuda.is_available():
+            _lib_handle(torch.cuda.current_device() if self.dev is None else self.dev, self.mode)    # created outside any stream capture
+        self._tok = _gemm_prec.set(self.mode)
         return self
 
     def __exit__(self, *exc):
-        if self.mode:
-            handle(self.d).call("set_gemm_precision", 0)
+        _gemm_prec.reset(self._tok)
         return False
 
 
@@ -1423,13 +1442,11 @@ def _gemm_call(d, name, flops, shape, *args):
     if P["n"] % P["every"] or len(P["rec"]) >= P["cap"]:
         h.call(name, *args)
         return
-    e0, e1 = C.c_int(), C.c_int()
-    h.call("event_create", C.byref(e0))
-    h.call("event_create", C.byref(e1))
-    h.call("event_record", e0.value, args[-1])
+    hb, e0, e1 = _event_pair(d)   # the events belong to the device's base handle (event_elapsed_ms reads them there), whatever handle launches
+    hb.call("event_record", e0, args[-1])
     h.call(name, *args)
-    h.call("event_record", e1.value, args[-1])
-    P["rec"].append((e0.value, e1.value, flops, shape))
+    hb.call("event_record", e1, args[-1])
+    P["rec"].append((e0, e1, flops, shape))
 
 
 def gemm(A: torch.Tensor, B: torch.Tensor, trans_a: bool = False, trans_b: bool = False, alpha: float = 1.0,
