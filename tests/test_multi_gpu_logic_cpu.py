@@ -187,6 +187,16 @@ def test_rccl_communicator_refuses_two_ranks_on_one_gpu(tmp_path):
         assert not any(c[0] == "comm_init" for c in res["calls"])           # librccl was never entered
 
 
+def test_identity_match_contradicted_by_the_local_index_is_not_a_refusal():
+    """Two ranks of one host that see the same visible-device mask and chose different indices cannot share a GPU: if the driver reports the
+    same identity for both (an all-zero uuid on a build without PCI ids), the match is dropped instead of refusing a real 8-GPU node."""
+    import tfmq_dm_amd.linklink as link
+    assert link._contradicted((0, 1), ["||| 0".replace(" ", ""), "|||1"])             # same mask, indices 0 / 1
+    assert not link._contradicted((0, 1), ["|||0", "|||0"])                            # same mask, same index: a real duplicate
+    assert not link._contradicted((0, 1), ["0|||0", "1|||0"])                          # per-rank masks (index 0 on both): the identity decides
+    assert link._device_hint(3).endswith("|3")
+
+
 def test_duplicate_devices_is_a_pure_function():
     sys.path.insert(0, os.path.join(ROOT, "tfmq-dm_amd"))
     import linklink as link

@@ -65,7 +65,16 @@ def _device_identity(dev):
     uuid = getattr(p, "uuid", None)
     if uuid is None and all(v is None for v in pci):
         return ""            # this torch build exposes neither: no identity, no check (never a false refusal on a real 8-GPU node)
+    if all(v is None for v in pci) and not str(uuid).strip("0-"):
+        return ""            # no PCI address and an all-zero uuid (some ROCm builds): nothing that tells two GPUs apart
     return f"{socket.gethostname()}|{uuid}|{pci}"
+
+
+def _device_hint(dev):
+    """What the rank believes about its device besides the identity: the visible-device mask and the local index.  Two ranks of one host
+    that see the SAME mask and chose DIFFERENT indices cannot share a GPU, whatever the driver reports as identity."""
+    import os
+    return "|".join([os.environ.get("HIP_VISIBLE_DEVICES", ""), os.environ.get("ROCR_VISIBLE_DEVICES", ""), os.environ.get("CUDA_VISIBLE_DEVICES", ""), str(int(dev))])
 
 
 def duplicate_devices(identities):
@@ -79,7 +88,14 @@ def duplicate_devices(identities):
     return dup
 
 
-def _refuse_duplicate_devices(mine):
+def _contradicted(pair, hints):
+    """An identity match between two ranks whose hints say otherwise (same visible-device mask, different local index): the identity the
+    driver reports is not trustworthy on this box -- never refuse a real multi-GPU node on its account."""
+    a, b = (hints[r].rsplit("|", 1) for r in pair)
+    return a[0] == b[0] and a[1] != b[1]
+
+
+def _refuse_duplicate_devices(mine, hint=""):
     """Every rank publishes its device identity through the rendezvous store and reads the others': two ranks on one GPU would sit in
     ncclCommInitRank until its bootstrap times out (or for ever), so the mismatch is refused HERE, on every rank at once, before any
     RCCL call.  TFMQ_COMM_ALLOW_SHARED_DEVICE=1 skips the check (never useful with RCCL; kept for experiments)."""
@@ -92,13 +108,15 @@ def _refuse_duplicate_devices(mine):
         store = dist.distributed_c10d._get_default_store()
     except Exception:
         store = None
+    mine_h = mine + "\t" + (hint or "|")
     if store is not None:
-        store.set(f"tfmq_comm_dev_{_comm_epoch}_{rank}", mine.encode())
-        ids = [bytes(store.get(f"tfmq_comm_dev_{_comm_epoch}_{r}")).decode() for r in range(world)]
+        store.set(f"tfmq_comm_dev_{_comm_epoch}_{rank}", mine_h.encode())
+        both = [bytes(store.get(f"tfmq_comm_dev_{_comm_epoch}_{r}")).decode() for r in range(world)]
     else:
-        ids = [None] * world
-        dist.all_gather_object(ids, mine)
-    dup = [] if any(not i for i in ids) else duplicate_devices(ids)
+        both = [None] * world
+        dist.all_gather_object(both, mine_h)
+    ids, hints = [b.split("\t", 1)[0] for b in both], [b.split("\t", 1)[1] for b in both]
+    dup = [] if any(not i for i in ids) else [p for p in duplicate_devices(ids) if not _contradicted(p, hints)]
     if dup:
         raise TfmqError(f"tfmq_comm_init: ranks {dup} share a GPU ({ids[dup[0][0]]}); RCCL needs one device per rank "
                         "(set the device before the first device all-reduce: quant/calibration.py:241-245)")
@@ -115,7 +133,7 @@ def init_comm(device=None):
     dev = _torch.cuda.current_device() if device is None else int(device)
     lib = load()
     world, rank = dist.get_world_size(), dist.get_rank()
-    _refuse_duplicate_devices(_device_identity(dev))
+    _refuse_duplicate_devices(_device_identity(dev), _device_hint(dev))
     ident = None
     if rank == 0:
         buf = (_C.c_uint8 * 128)()
