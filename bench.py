@@ -29,6 +29,9 @@ import os
 import sys
 import time
 
+# multi-process GPU work on this host driver needs dmabuf IPC (RCCL / tensor sharing across ranks fail with the legacy mode); set before HIP starts
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))

@@ -91,14 +91,30 @@ def check_fsc_rows(engine, n_steps: int, who: str) -> None:
                         "(calibrate with one group per sampling step, or install a matching table)")
 
 
-def fp16_stream_overflowed(sampler, probe) -> bool:
+STREAM_GUARD_REL_L2 = 0.25     # eps of the two streams further apart than this: the fp16 stream lost something (bin flips alone: 2 ... 3 %)
+
+
+def streams_disagree(pairs) -> bool:
+    """The guard's decision over [(eps with the fp16 stream, eps with the fp32 stream), ...] of the probed steps (pure function): an fp16
+    result that is not finite, or further than STREAM_GUARD_REL_L2 from a finite fp32 result, at ANY probed step."""
+    for e16, e32 in pairs:
+        if not bool(torch.isfinite(e16).all()):
+            return True
+        if bool(torch.isfinite(e32).all()) and float((e16 - e32).norm() / e32.norm().clamp_min(1e-30)) > STREAM_GUARD_REL_L2:
+            return True
+    return False
+
+
+def fp16_stream_overflowed(sampler, probe, probe_last=None) -> bool:
     """The fp16 activation stream stores the tensors that travel between blocks as fp16: a checkpoint whose
     residual stream exceeds 65504 somewhere turns into inf there -- and an inf that meets an activation quantizer is clamped to the top
     bin, i.e. the result can be finite and wrong -- where the reference's fp32 stream is fine.  After the FIRST sampling of a graph
-    sampler, `probe()` (one eager UNet evaluation of the sampler's first step) is therefore run with the fp16 and with the fp32 stream:
-    non-finite latents, or eps further apart than 25 % rel-L2 (bin flips alone put them 2 ... 3 % apart), switch the engine to the fp32
-    stream, drop the captured graphs and tell the caller to sample again.  Later samplings are not checked (overflow is a property of the
-    weights, not of the noise).  TFMQ_STREAM_GUARD=0 switches the check off."""
+    sampler the UNet is therefore evaluated eagerly with the fp16 and with the fp32 stream at BOTH ENDS of the trajectory: `probe()` = the
+    first step on x_T, `probe_last()` = the last step (its time embedding, its row of the activation table) on the latents the sampling
+    ended with -- activation ranges drift along the trajectory, which is why the table has a row per step.  Non-finite latents, or eps
+    further apart than 25 % rel-L2 at either end, switch the engine to the fp32 stream, drop the captured graphs and tell the caller to
+    sample again.  Later samplings are not checked (overflow is a property of the weights and the schedule, not of the noise).
+    TFMQ_STREAM_GUARD=0 switches the check off."""
     if getattr(sampler, "_stream_checked", False) or os.environ.get("TFMQ_STREAM_GUARD", "1") == "0":
         return False
     sampler._stream_checked = True
@@ -115,17 +131,22 @@ def fp16_stream_overflowed(sampler, probe) -> bool:
     if finite:
         with torch.cuda.stream(sampler.stream), ops.use_arena(None):
             step_after = sampler.step.clone()
-            sampler.step.zero_()
-            e16 = probe().float().clone()
-            eng.stream_f16 = False
-            try:
-                e32 = probe().float()
-            finally:
-                eng.stream_f16 = True
+            pairs = []
+            n_steps = int(getattr(sampler, "n_steps", 0) or sampler.coef.shape[0])
+            for k, fn in ((0, probe), (n_steps - 1, probe_last)):
+                if fn is None:
+                    continue
+                sampler.step.fill_(k)
+                e16 = fn().float().clone()
+                eng.stream_f16 = False
+                try:
+                    e32 = fn().float().clone()
+                finally:
+                    eng.stream_f16 = True
+                pairs.append((e16, e32))
             sampler.step.copy_(step_after)          # (callers read the device step counter after a sampling)
             sampler.stream.synchronize()
-        apart = float((e16 - e32).norm() / e32.norm().clamp_min(1e-30)) if bool(torch.isfinite(e32).all()) else 0.0
-        if bool(torch.isfinite(e16).all()) and apart <= 0.25:
+        if not streams_disagree(pairs):
             return False
     import warnings
     warnings.warn("tfmq: the fp16 activation stream overflows on this checkpoint -- falling back to the fp32 stream (TFMQ_STREAM_F32=1 selects it up front)")
@@ -210,7 +231,7 @@ class GraphDdimSampler:
                 self.h.call("graph_launch", self.gid, sp)
                 if sync_every and (i + 1) % sync_every == 0:
                     self.stream.synchronize()
-        if fp16_stream_overflowed(self, lambda: self.eng.forward(x_T.float().contiguous(), None)):
+        if fp16_stream_overflowed(self, lambda: self.eng.forward(x_T.float().contiguous(), None), lambda: self.eng.forward(self.x.float().clone(), None)):
             return self.sample_nhwc(x_T, steps)
         return self.x
 

@@ -154,7 +154,8 @@ class GraphLatentDdimSampler:
                 if sync_every and (i + 1) % sync_every == 0:
                     self.stream.synchronize()
         if fp16_stream_overflowed(self, lambda: (self.eng.forward(x_T.float().contiguous(), None, None) if self.uncond
-                                                 else self._eps_pair(x_T.float().contiguous()))):
+                                                 else self._eps_pair(x_T.float().contiguous())),
+                                  lambda: (self.eng.forward(self.x.float().clone(), None, None) if self.uncond else self._eps_pair(self.x.float().clone()))):
             return self.sample_nhwc(x_T, cond, uncond, steps)
         return self.x
 
@@ -260,6 +261,7 @@ class GraphLatentPlmsSampler(GraphLatentDdimSampler):
                 if sync_every and (i + 1) % sync_every == 0:
                     self.stream.synchronize()
         if fp16_stream_overflowed(self, lambda: (self.eng.forward(x_T.float().contiguous(), None, None) if self.uncond
-                                                 else self._eps_pair(x_T.float().contiguous()))):
+                                                 else self._eps_pair(x_T.float().contiguous())),
+                                  lambda: (self.eng.forward(self.x.float().clone(), None, None) if self.uncond else self._eps_pair(self.x.float().clone()))):
             return self.sample_nhwc(x_T, cond, uncond, steps)
         return self.x

@@ -13,6 +13,11 @@ between the unit's backward GEMMs and the fused AdaRound-backward + Adam kernel,
 (quant/reconstruction.py:72-75,193-195,298-300).  Everything else (CPU tensors, other dtypes, gloo) goes to
 torch.distributed unchanged."""
 import ctypes as _C
+import os as _os
+
+# the host driver supports dmabuf IPC only: without it RCCL's intra-node transport fails in hipIpcGetMemHandle.  Effective when this module is
+# imported before the process's first HIP call (the launchers -- bench.py, mp.spawn parents -- export it as well; children inherit it).
+_os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 import torch as _torch
 import torch.distributed as dist
