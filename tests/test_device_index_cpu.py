@@ -76,3 +76,27 @@ def test_gemm_precision_selects_a_handle_and_toggles_nothing(monkeypatch):
         assert ops.handle(3) is made[(3, 1)]
     assert ops.handle(3) is made[(3, 0)]
     assert all("set_gemm_precision" not in h.calls for h in made.values())      # (the real _lib.handle sets it once, at creation)
+
+
+def test_lib_handle_sets_the_precision_once_at_creation(monkeypatch):
+    """_lib.handle(device, precision): one handle per (device, precision); tfmq_set_gemm_precision is called on it exactly once, when it is
+    created, never on the base handle."""
+    import tfmq_dm_amd._lib as _lib
+    made = []
+
+    class H(FakeHandle):
+        def __init__(self, dev):
+            super().__init__(dev)
+            made.append(self)
+    monkeypatch.setattr(_lib, "Handle", H)
+    monkeypatch.setattr(_lib, "_handles", {})
+    monkeypatch.setattr(_lib, "_prec_handles", {})
+    base = _lib.handle(2)
+    p1 = _lib.handle(2, 1)
+    assert _lib.handle(2) is base and _lib.handle(2, 1) is p1 and _lib.handle(2, 0) is base and p1 is not base
+    p2 = _lib.handle(2, 2)
+    other = _lib.handle(5, 1)
+    assert len(made) == 4 and len({id(h) for h in (base, p1, p2, other)}) == 4
+    assert base.calls == [] and p1.calls == ["set_gemm_precision"] and p2.calls == ["set_gemm_precision"] and other.dev == 5
+    assert (p1.gemm_precision, p2.gemm_precision) == (1, 2)
+    assert set(_lib._handles) == {2}                      # linklink.comm_device walks the base handles only
