@@ -853,10 +853,15 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("gloo" if ONE_DEVICE else "nccl", rank=rank, world_size=world)
         import tfmq_dm_amd.linklink as link
+
+    def init_c_abi_comm():
+        """The C ABI's own RCCL communicator (calibration exchange step).  Sampling needs no collective, so for the sampling workloads it is
+        created AFTER the timed region, under the calibration leg's watchdog: a communicator that cannot be built (or a bootstrap that never
+        returns) costs that leg, never the sampling number."""
         try:
-            if not ONE_DEVICE:
-                link.init_comm(local_rank)   # the C ABI's own RCCL communicator (calibration exchange step)
-        except Exception as e:           # noqa: BLE001 -- sampling needs no collective: keep the number, report the leg's error
+            if world > 1 and not ONE_DEVICE:
+                link.init_comm(local_rank)
+        except Exception as e:           # noqa: BLE001 -- keep the number, report the leg's error
             print(f"[bench] rank {rank}: tfmq_comm_init failed ({type(e).__name__}: {e}); the calibration leg falls back to torch.distributed",
                   file=sys.stderr, flush=True)
 
@@ -865,6 +870,7 @@ def main():
             print("[bench]", *a, file=sys.stderr, flush=True)
 
     if args.workload == "cali":
+        init_c_abi_comm()
         out = run_cali_workload(args, dev, rank, local_rank, world, log)
         if rank == 0:
             print(json.dumps(out), flush=True)
@@ -916,13 +922,16 @@ def main():
             if rank == 0 and state["partial"] is not None:
                 state["partial"]["calibration"] = {"sharded": {"error": "calibration leg exceeded its deadline"}}
                 emit(state["partial"])
-            os._exit(0 if rank == 0 and state["partial"] is not None else 3)
+            # (the watchdog only runs at world > 1, where rank 0 always holds the partial line: the other ranks leave quietly as well, so the
+            # launcher reports the run whose line was printed as a success)
+            os._exit(0 if world > 1 or (rank == 0 and state["partial"] is not None) else 3)
         wd = threading.Timer(420.0, bail)
         wd.daemon = True
         if world > 1:
             state["partial"] = dict(_partial_line(args, info, world, dt, finite)) if rank == 0 else None
             wd.start()
         try:
+            init_c_abi_comm()
             sharded = calibration_sharded(dev, world)
         except Exception as e:        # noqa: BLE001 -- reported in the line, never fatal for the sampling number
             sharded = {"error": f"{type(e).__name__}: {e}"}
