@@ -42,6 +42,8 @@ sys.path.insert(0, ROOT)
 # communicator is not created (linklink falls back to torch.distributed).  A test mode: its number means nothing.
 ONE_DEVICE = os.environ.get("TFMQ_BENCH_ONE_DEVICE") == "1"
 INT8_PEAK_TOPS = 5000.0  # dense int8 MFMA peak of MI355X (2x the 2.5 PF bf16 dense peak, MI355X_MICROARCH.md)
+F16_PEAK_TFLOPS = 2500.0  # dense fp16 / bf16 MFMA peak (the un-quantised convs run fp16 operands)
+HBM_ACHIEVABLE_TBPS = 6.3  # what a float4 copy reaches of the 8 TB/s (MI355X_MICROARCH.md): the HBM roof the per-launch floors are priced at
 
 
 # ------------------------------------------------------------------------------------------------ cifar
@@ -695,7 +697,7 @@ def run_cali_workload(args, dev, rank, local_rank, world, log):
             os.environ.get("TFMQ_RECON_GEMM", "bf16x3"), "f32 values, split-bf16 (hi + lo, 3 MFMAs per product, fp32 accumulation: 2^-16 per product) GEMMs (AdaRound iterations)")
         + " + int8/f16 (capture forwards)", "data": "synthetic",
         "config": {"workload": (f"cali_model{'_multi' if world > 1 else ''} on the SD v1-4 UNet (859.5M, random init): {G} timestep groups x {N} "
-                                f"samples, {ITERS} AdaRound iterations per unit at mini-batch 8/rank (the recipe: 25 groups x 512, 20000), "
+                                f"samples, {ITERS} AdaRound iterations per unit at mini-batch 8/rank (the recipe, txt2img.py:421-429,486: 50 DDIM steps x 256 samples -- 128 prompts x {cond, uncond} --, 20000), "
                                 "w4 channel-wise + a8 Finite-Set, running_stat; " + gen_note
                                 + (f"; reconstruction restricted to the units under {args.cali_only}" if args.cali_only else "")),
                    "parallelism": "single GPU" if world == 1 else f"timestep-group shards x{world}, one RCCL SUM all-reduce per iteration"},
@@ -786,14 +788,36 @@ def conv_roofline(fwd, stream, n_fwd=2):
     finally:
         ops.set_conv_profile(None)
     tot_ops, tot_ms, tot_bytes, n = 0.0, 0.0, 0.0, 0
-    for (e0, e1, nops, kind, nbytes) in rec:
+    fam = {}
+    for (e0, e1, nops, kind, nbytes, family) in rec:
+        ms = ops.event_elapsed_ms(e0, e1)
+        # per launch: the floor each roof sets (dense int8 / fp16 MFMA peak; the 6.3 TB/s a float4 copy reaches on this chip,
+        # MI355X_MICROARCH.md) -- the larger one is the launch's binding roof
+        mfma_ms = nops / ((INT8_PEAK_TOPS if kind == "w4a8" else F16_PEAK_TFLOPS) * 1e12) * 1e3
+        hbm_ms = nbytes / (HBM_ACHIEVABLE_TBPS * 1e12) * 1e3
+        f = fam.setdefault(family, {"launches": 0, "ms": 0.0, "mfma_floor_ms": 0.0, "hbm_floor_ms": 0.0, "binding_floor_ms": 0.0, "hbm_bound_launches": 0})
+        f["launches"] += 1
+        f["ms"] += ms
+        f["mfma_floor_ms"] += mfma_ms
+        f["hbm_floor_ms"] += hbm_ms
+        f["binding_floor_ms"] += max(mfma_ms, hbm_ms)
+        f["hbm_bound_launches"] += int(hbm_ms > mfma_ms)
         if kind != "w4a8":
             continue
         tot_ops += nops
         tot_bytes += nbytes
-        tot_ms += ops.event_elapsed_ms(e0, e1)
+        tot_ms += ms
         n += 1
+    global _FAMILY_TABLE
+    _FAMILY_TABLE = [{"family": k, "launches_per_forward": round(v["launches"] / n_fwd, 1), "hbm_bound_launches_per_forward": round(v["hbm_bound_launches"] / n_fwd, 1),
+                      "ms_per_forward": round(v["ms"] / n_fwd, 3), "mfma_floor_ms": round(v["mfma_floor_ms"] / n_fwd, 3),
+                      "hbm_floor_ms": round(v["hbm_floor_ms"] / n_fwd, 3),
+                      "frac_of_binding_roof": round(v["binding_floor_ms"] / v["ms"], 4) if v["ms"] > 0 else None}
+                     for k, v in sorted(fam.items(), key=lambda kv: -kv[1]["ms"])]
     return tot_ops, tot_ms, n, tot_bytes, n_fwd
+
+
+_FAMILY_TABLE = None
 
 
 def _partial_line(args, info, world, dt, finite):
@@ -965,7 +989,10 @@ def main():
                 "algorithmic_bytes_per_launch": round(tot_bytes / max(n_launch, 1)),
                 "hbm_achieved_TBps": round(tot_bytes / (tot_ms * 1e-3) / 1e12, 3) if tot_ms > 0 else None,
                 "launches_timed": n_launch, "avg_launch_us": round(tot_ms * 1e3 / max(n_launch, 1), 2),
-                "algorithmic_ops_per_forward": tot_ops / n_fwd}
+                "algorithmic_ops_per_forward": tot_ops / n_fwd,
+                # which roof binds, per launch: floor = max(ops / MFMA peak, algorithmic bytes / 6.3 TB/s), summed per kernel family over the
+                # same live HIP events; "bound" above names the roof of the family as a whole
+                "families": _FAMILY_TABLE}
         cpu_b = None
         if world == 1 and not args.no_cpu_baseline:
             v, sample = cpu()

@@ -34,7 +34,7 @@ with torch.cuda.stream(info["stream"]):
         info["stream"].synchronize()
         ops.set_conv_profile(None)
 agg = collections.OrderedDict()
-for s, (e0, e1, nops, kind, nbytes) in zip(shapes, rec):
+for s, (e0, e1, nops, kind, nbytes, _fam) in zip(shapes, rec):
     ms = ops.event_elapsed_ms(e0, e1)
     a = agg.setdefault(s, [0, 0.0, 0.0, 0.0]); a[0] += 1; a[1] += ms; a[2] += nops; a[3] += nbytes
 tot = sum(a[1] for a in agg.values())

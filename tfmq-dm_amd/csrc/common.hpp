@@ -95,11 +95,29 @@ struct GemmP {
 static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
 // ---------------------------------------------------------------- device helpers
+// A device scalar (the Finite-Set step counter, written by an earlier launch) through the SCALAR cache.  As a plain `*p` of a
+// pointer out of a by-value struct the compiler emits global_load_dword + s_waitcnt vmcnt(0) + v_readfirstlane -- and vmcnt(0)
+// also waits for every LDS-DMA piece / prefetch load the kernel issued before it (the compiler does not see the asm-issued ones):
+// round 6 found k_lin_direct's blocks spending 2.6 ... 3 us there, in front of their first K-step (profiles/r06_phase_lin_direct.txt).
+// s_load counts on lgkmcnt only; the scalar cache is invalidated at every kernel boundary, so a value an earlier launch wrote is seen.
+template <typename T>
+__device__ __forceinline__ const T* uniform_ptr(const T* p) {      // the (wave-uniform) pointer in an SGPR pair, wherever the compiler keeps it
+  const unsigned long long a = reinterpret_cast<unsigned long long>(p);
+  const unsigned lo = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(a)), hi = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(a >> 32));
+  return reinterpret_cast<const T*>((static_cast<unsigned long long>(hi) << 32) | lo);
+}
+__device__ __forceinline__ int load_scalar_i32(const int32_t* p) {
+  int v;
+  asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(uniform_ptr(p)) : "memory");
+  return v;
+}
 __device__ __forceinline__ float2 load_qparam(const tfmq_qsel& qs) {
   // {delta, zero_point} of the current FSC group
-  int k = qs.step ? *qs.step : 0;
+  const int k = qs.step ? load_scalar_i32(qs.step) : 0;
   const float* p = qs.qtable + (static_cast<size_t>(k) * qs.q_stride + qs.qid) * 2;
-  return make_float2(p[0], p[1]);
+  unsigned long long v;
+  asm volatile("s_load_dwordx2 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(uniform_ptr(p)) : "memory");
+  return make_float2(__uint_as_float(static_cast<unsigned>(v)), __uint_as_float(static_cast<unsigned>(v >> 32)));
 }
 
 // q = clamp(rint(x/delta)+zp, 0, L-1): true IEEE division, round-half-even

@@ -26,6 +26,7 @@ struct ConvP {
   int* ks_cnt;                     // tfmq_ctx::ksplit_cnt: arrival tickets, zero between launches
 #ifdef TFMQ_PHASE_TIMERS
   unsigned long long* dbg;         // [blocks][4] shader-clock stamps: start, loop start, loop end, end
+  unsigned long long* dbg2;        // [blocks][8] shader cycles wave 0 spent in the parts of its K loop (k_lin_direct)
 #endif
 };
 

@@ -97,7 +97,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, unsigned char* lds
   float2* ldsG = ldsP + (RPT == 8 ? 2 * NTR : NTR) * BN;           // [BN] running segment sums (behind the fp16 pass's 4-row partials)
   const int hw = d.Ho * d.Wo;
   const float* rowadd = d.rowadd;
-  if (rowadd && d.rowadd_step) rowadd += static_cast<size_t>(*d.rowadd_step) * d.rowadd_step_stride;
+  if (rowadd && d.rowadd_step) rowadd += static_cast<size_t>(load_scalar_i32(d.rowadd_step)) * d.rowadd_step_stride;
   const bool vec_ok = ((d.Cout | d.ldy | d.y_coff) & 3) == 0 && (!d.rowadd || (d.rowadd_ld & 3) == 0);
   const int seg = d.stats ? d.stats_seg : 0;
   const int tr = tid / TPR, c4 = (tid % TPR) * 4;

@@ -398,13 +398,25 @@ __global__ __launch_bounds__(256, 3) void k_lin_direct(ConvP p) {
   const bool has_res = !lin_is_geglu<MODE> && d.residual != nullptr;
   if (has_res && d.res_f16) lin_load_res<MODE>(p, rres, m0, n0, wm, wn, lane);
 
+#ifdef TFMQ_PHASE_TIMERS
+  // where a wave's K-step goes: [0] counted vmcnt wait, [1] barrier, [2] DMA issue, [3] fragment reads until their data is there,
+  // [4] MFMA issue (the wave is held while the matrix pipe is busy), [5] steps  (shader cycles, wave 0 of the block; s_memtime costs ~10 %)
+  unsigned long long kacc[6] = {0, 0, 0, 0, 0, 0};
+#define KT(i) do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); const unsigned long long t_ = clock64(); kacc[i] += t_ - kt; kt = t_; } while (0)
+  unsigned long long kt = clock64();
+#else
+#define KT(i) do { } while (0)
+#endif
   int st_c = 0, st_i = 2;
   for (int s = 0; s < p.nsteps; ++s) {
     if (s + 1 < p.nsteps) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLOAD) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    KT(0);
     asm volatile("s_barrier" ::: "memory");
+    KT(1);
     if (s == 0) LIN_MARK(1);
     if (s + 2 < p.nsteps) issue(s + 2, st_i);
+    KT(2);
     const unsigned char* sa = lds + st_c * STAGE;
     const unsigned char* sb = sa + BM * 64;
     // GEGLU modes (round 4): both K halves' fragments are requested up front, the second half's reads travel under the first half's MFMAs
@@ -420,6 +432,10 @@ __global__ __launch_bounds__(256, 3) void k_lin_direct(ConvP p) {
     };
     read_frags(0);
     if constexpr (PF) read_frags(1);
+#ifdef TFMQ_PHASE_TIMERS
+    asm volatile("" : "+v"(af[0][0]), "+v"(af[0][1]), "+v"(bf[0][0]), "+v"(bf[0][1]));
+    KT(3);
+#endif
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       if constexpr (!PF) {
@@ -442,7 +458,16 @@ __global__ __launch_bounds__(256, 3) void k_lin_direct(ConvP p) {
     }
     st_c = st_c == NST - 1 ? 0 : st_c + 1;
     st_i = st_i == NST - 1 ? 0 : st_i + 1;
+#ifdef TFMQ_PHASE_TIMERS
+    asm volatile("" : "+v"(acc[0][0]), "+v"(acc[1][1]));
+    KT(4);
+    kacc[5] += 1;
+#endif
   }
+#ifdef TFMQ_PHASE_TIMERS
+  if (p.dbg2 && tid == 0)
+    for (int i = 0; i < 6; ++i) p.dbg2[static_cast<size_t>(blockIdx.x) * 8 + i] = kacc[i];
+#endif
 
   LIN_MARK(2);
   // ---- per-column constants -> LDS table {scale, zero-point correction (as float bits of an int), bias}
@@ -527,6 +552,9 @@ bool launch_conv_lin(tfmq_handle h, ConvP& p, hipStream_t st) {
   static unsigned long long* dbuf2 = nullptr;
   if (!dbuf2) (void)hipMalloc(reinterpret_cast<void**>(&dbuf2), sizeof(unsigned long long) * 4 * (1u << 18));
   p.dbg = grid.x <= (1u << 18) ? dbuf2 : nullptr;
+  static unsigned long long* dbuf3 = nullptr;
+  if (!dbuf3) (void)hipMalloc(reinterpret_cast<void**>(&dbuf3), sizeof(unsigned long long) * 8 * (1u << 18));
+  p.dbg2 = grid.x <= (1u << 18) ? dbuf3 : nullptr;
 #endif
   if (mode == LIN_F16) hipLaunchKernelGGL((k_lin_direct<LIN_F16>), grid, dim3(256), 0, st, p);
   else if (mode == LIN_Q8) hipLaunchKernelGGL((k_lin_direct<LIN_Q8>), grid, dim3(256), 0, st, p);
@@ -545,6 +573,16 @@ bool launch_conv_lin(tfmq_handle h, ConvP& p, hipStream_t st) {
       c += double(hb[i * 4 + 3] - hb[i * 4 + 2]);
       t0 = hb[i * 4] < t0 ? hb[i * 4] : t0;
       t1 = hb[i * 4 + 3] > t1 ? hb[i * 4 + 3] : t1;
+    }
+    {
+      std::vector<unsigned long long> kb(static_cast<size_t>(grid.x) * 8);
+      (void)hipMemcpy(kb.data(), dbuf3, kb.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+      double ks[6] = {0, 0, 0, 0, 0, 0};
+      for (unsigned i = 0; i < grid.x; ++i)
+        for (int q = 0; q < 6; ++q) ks[q] += double(kb[i * 8 + q]);
+      const double st = ks[5] > 0 ? ks[5] : 1;
+      fprintf(stderr, "[lin_direct Cin%d Cout%d mode%d] K-step of wave 0, shader cycles: vmcnt wait %.0f, barrier %.0f, DMA issue %.0f, fragment reads %.0f, MFMA issue %.0f = %.0f per step\n",
+              d.Cin, d.Cout, mode, ks[0] / st, ks[1] / st, ks[2] / st, ks[3] / st, ks[4] / st, (ks[0] + ks[1] + ks[2] + ks[3] + ks[4]) / st);
     }
     const double span = double(t1 - t0) / 100.0, blocks_per_cu = double(grid.x) / h->cu_count;
     fprintf(stderr, "[lin_direct Cin%d Cout%d mode%d] blocks %u (%.1f per CU): start->first data %.2f us, K loop %.2f us, epilogue (to last store issued) %.2f us per block; span %.1f us = %.2f us per block slot of 3 per CU\n",

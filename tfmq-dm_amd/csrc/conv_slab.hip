@@ -309,7 +309,7 @@ __global__ __launch_bounds__(64 * 2 * NWM, 2) void k_conv3_slab(SlabP sp) {
   float* cs = reinterpret_cast<float*>(lds + (BM / 8) * BN * 8);         // scale[BN], corr[BN] (int), bias[BN], rowadd[imgs][BN]
   const int hw = sp.HW;
   const float* rowadd = d.rowadd;
-  if (rowadd && d.rowadd_step) rowadd += static_cast<size_t>(*d.rowadd_step) * d.rowadd_step_stride;
+  if (rowadd && d.rowadd_step) rowadd += static_cast<size_t>(load_scalar_i32(d.rowadd_step)) * d.rowadd_step_stride;
   const int seg = d.stats ? d.stats_seg : 0;
   const bool q8 = d.out_mode == TFMQ_OUT_Q8, o16 = d.out_mode == TFMQ_OUT_F16;
   float2 oqp = make_float2(1.0f, 0.0f);

@@ -466,7 +466,7 @@ def pack_w_f16(w: torch.Tensor, bias: Optional[torch.Tensor] = None, delta: Opti
 
 
 # ------------------------------------------------------------------------------ K5 / K6
-_conv_prof = None  # list collecting (start_event, stop_event, algorithmic_ops, kind) per conv launch
+_conv_prof = None  # list collecting (start_event, stop_event, algorithmic_ops, kind, algorithmic_bytes, family) per conv launch
 
 
 def set_conv_profile(rec):
@@ -671,7 +671,12 @@ def _profiled_conv(name, kind, d, dsc, nops, nbytes=0.0):
     hb.call("event_record", e0, _stream(d))
     h.call(name, C.byref(dsc), _stream(d))
     hb.call("event_record", e1, _stream(d))
-    _conv_prof.append((e0, e1, nops, kind, nbytes))
+    # family of the launch (bench.py's per-family roofline table): which roof binds differs between them
+    if kind == "w4a8":
+        fam = ("w4a8 3x3 conv" if dsc.KH == 3 else ("w4a8 GEGLU projection" if dsc.out_mode in (3, 4) else "w4a8 pointwise")) if dsc.KH in (1, 3) else "w4a8 other conv"
+    else:
+        fam = "fp16 3x3 conv" if dsc.KH == 3 else ("fp16 pointwise" if dsc.KH == 1 else "fp16 other conv")
+    _conv_prof.append((e0, e1, nops, kind, nbytes, fam))
 
 
 def _conv_desc(x, B, H, W, cin, cout, kh, kw, stride, pad_t, pad_l, Ho, Wo, up2x, y, ldy, y_coff, rowadd, residual,
@@ -1079,7 +1084,7 @@ def row_chain(x: torch.Tensor, T: int, gemms, gn=None, ln=None):
     hb.call("event_record", e0, _stream(d))
     h.call("row_chain", C.byref(dsc), _stream(d))
     hb.call("event_record", e1, _stream(d))
-    _conv_prof.append((e0, e1, nops, "w4a8", nbytes))
+    _conv_prof.append((e0, e1, nops, "w4a8", nbytes, "w4a8 row chain (token per lane)"))
     return outs
 
 
@@ -1169,7 +1174,7 @@ def ff_fused(x: Optional[torch.Tensor], gamma: torch.Tensor, beta: torch.Tensor,
     nl = (pre is not None) + (post is not None)
     _conv_prof.append((e0, e1, 2.0 * M * (2 * inner * Cc + inner * Cc + nl * Cc * Cc), "w4a8",
                        M * Cc * (2.0 + (1.0 if (out_q8 is not None and post is None) else 2.0) + 3.0 * (pre is not None) + 2.0 * (post is not None))
-                       + 3.0 * inner * Cc + nl * Cc * Cc))
+                       + 3.0 * inner * Cc + nl * Cc * Cc, "w4a8 fused feed-forward (token per lane)"))
     return ret
 
 
