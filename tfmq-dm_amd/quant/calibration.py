@@ -68,6 +68,13 @@ def _recon_walk(qnn: QuantModel, model: nn.Module, cali_data, kwargs, rank0=True
         path = prefix + name
         if rank0:
             logger.info(f"block name: {name} quant: {isinstance(module, BaseQuantBlock)}")
+        # the reference's cache placement (calibration.py:62-67; sticky once set): Stable Diffusion from its first input block on, and the up
+        # path from output block 8 on, cache on the CPU.  Here it is a hint -- save_inout keeps a cache on the device whenever it fits
+        # (288 GB) and moves it to pinned host memory only when it does not (TFMQ_CACHE_HOST=1 follows the hint literally)
+        if name == "0" and cali_data[0].shape[-1] == 64 and len(cali_data) == 3:
+            kwargs["keep_gpu"] = False
+        if prefix.endswith("output_blocks.") and name.isdigit() and int(name) >= 8:
+            kwargs["keep_gpu"] = False
         if name == "tib":
             continue
         if name in ("time_embed", "temb"):

@@ -30,13 +30,54 @@ def unit_name(model, unit) -> str:
     raise KeyError("unit is not a sub-module of the quantised model")
 
 
+class HostRows:
+    """Rows of a reconstruction cache kept in PINNED HOST memory -- the reference's `keep_gpu=False` (quant/calibration.py:62-67 switches it on
+    for the widest SD units; quant/data_utill.py:39-46 keeps the cache on the CPU, quant/reconstruction.py:66,184 moves each mini-batch
+    `.to(device)`).  The reconstruction units only ever `index_select(0, idx)` their caches, so this class answers that call: the selected rows
+    (contiguous in the cache) travel as one asynchronous host -> device copy each on the current stream.  Used by save_inout when a cached
+    tensor does not fit beside the device memory the capture and the iterations need (12 800 samples x 64 x 64 x 960 fp32 channels of the SD
+    recipe's `output_blocks.9` input are 201 GB)."""
+
+    def __init__(self, shape, dtype, device):
+        self.buf = torch.empty(tuple(shape), dtype=dtype, pin_memory=True)
+        self.device, self.dtype, self.shape = torch.device(device), dtype, torch.Size(shape)
+        self.is_host_rows = True
+
+    def size(self, d=None):
+        return self.shape if d is None else self.shape[d]
+
+    def __len__(self):
+        return self.shape[0]
+
+    def fill(self, start: int, rows: torch.Tensor):
+        self.buf[start:start + rows.shape[0]].copy_(rows)              # device -> pinned host
+
+    def index_select(self, dim: int, idx: torch.Tensor) -> torch.Tensor:
+        assert dim == 0
+        host = getattr(idx, "_host", None)       # reconstruction._run keeps the host copy of the indices it drew on the host
+        ids = (host if host is not None else idx.cpu()).tolist()
+        out = torch.empty((len(ids),) + tuple(self.shape[1:]), dtype=self.dtype, device=self.device)
+        for j, i in enumerate(ids):
+            out[j].copy_(self.buf[i], non_blocking=True)
+        return out
+
+
+def _device_room(dev) -> int:
+    """Bytes a new cache tensor may take on `dev`: what the driver reports free plus what the caching allocator holds unused, minus a reserve
+    for the capture forwards and the iterations' buffers (TFMQ_CACHE_RESERVE_GB, default 40)."""
+    free, _ = torch.cuda.mem_get_info(dev)
+    idle = torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev)
+    return int(free + idle - float(os.environ.get("TFMQ_CACHE_RESERVE_GB", "40")) * (1 << 30))
+
+
 def save_inout(model, layer, cali_data: Tuple[torch.Tensor], asym: bool = False, use_act: bool = False,
                batch_size: int = 128, keep_gpu: bool = True):
     """-> (cached_inputs: tuple of tensors, cached_output).  Unit inputs (reference DataSaverHook, :79-104):
     ResnetBlock / ResBlock (x NHWC, temb | emb); BasicTransformerBlock (tokens [N,T,C], context [N,L,D]);
     attention block / single layer (x,).  cali_data = (xs, ts) or (xs, ts, cs) for context-conditioned UNets.
-    Everything stays on the device (288 GB HBM; the reference spills to host RAM for the largest units,
-    calibration.py:62-67)."""
+    A cached tensor stays on the device (288 GB HBM) when it fits beside a reserve for the passes themselves; one that does not -- or every
+    one, with `keep_gpu=False` and TFMQ_CACHE_HOST=1 -- lives in pinned host memory as `HostRows` (the reference's keep_gpu=False,
+    calibration.py:62-67), from which the iterations fetch their mini-batches."""
     from .quant_block import QuantBasicTransformerBlock, QuantQKMatMul, QuantResBlock, QuantResnetBlock, QuantSMVMatMul
     name = unit_name(model, layer)
     dev = next(model.model.parameters()).device
@@ -48,20 +89,30 @@ def save_inout(model, layer, cali_data: Tuple[torch.Tensor], asym: bool = False,
     n_total = int(xs.size(0))
 
     class _Rows:
-        def __init__(self):
-            self.buf, self.n = None, 0
+        def __init__(self, host_ok=False):
+            self.buf, self.n, self.host_ok = None, 0, host_ok      # host_ok: a tensor the units only index_select (unit input / target)
 
         def append(self, t, bsz):
             if self.buf is None and self.n == 0 and not getattr(self, "parts", None):
                 if t.shape[0] % bsz == 0:      # rows per sample: 1, or heads for the [(b h), ...] tensors of the stand-alone matmul units
                     self.rows = n_total * (t.shape[0] // bsz)
-                    self.buf = torch.empty((self.rows,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+                    shape = (self.rows,) + tuple(t.shape[1:])
+                    nbytes = t.element_size() * self.rows * int(t[0].numel())
+                    force = os.environ.get("TFMQ_CACHE_HOST")          # "1": every cache with keep_gpu=False on the host; "all": every cache (tests)
+                    if t.is_cuda and self.host_ok and (force == "all" or (force == "1" and not keep_gpu) or nbytes > _device_room(t.device)):
+                        self.buf = HostRows(shape, t.dtype, t.device)
+                        logger.info(f"save_inout: {nbytes / 2**30:.1f} GiB of cache for '{name}' kept in pinned host memory")
+                    else:
+                        self.buf = torch.empty(shape, dtype=t.dtype, device=t.device)
                 else:                          # (a tensor that does not scale with the batch: collected and concatenated as before)
                     self.parts = []
             if self.buf is None:
                 self.parts.append(t)
                 return
-            self.buf[self.n:self.n + t.shape[0]].copy_(t)
+            if isinstance(self.buf, HostRows):
+                self.buf.fill(self.n, t)
+            else:
+                self.buf[self.n:self.n + t.shape[0]].copy_(t)
             self.n += t.shape[0]
 
         def __bool__(self):
@@ -72,7 +123,8 @@ def save_inout(model, layer, cali_data: Tuple[torch.Tensor], asym: bool = False,
                 return torch.cat(self.parts)
             assert self.n == self.rows, (self.n, self.rows)
             return self.buf
-    ins, outs, tembs, ctxs = _Rows(), _Rows(), _Rows(), _Rows()
+    # (the delta-learning units -- use_act -- reshape their caches: those stay on the device)
+    ins, outs, tembs, ctxs = _Rows(not use_act), _Rows(not use_act), _Rows(), _Rows()
     # `batch_size` is the reconstruction mini-batch (8 in the SD recipe); the capture forwards are per-sample
     # independent (tests/test_full_size_properties_gpu.py: batch 12 == 6 + 6 bit for bit), so they run at a batch that
     # fills the GPU instead of a launch-bound one

@@ -177,8 +177,10 @@ def _run(unit: R._Unit, n: int, batch_size: int, iters: int, loss_func: LossFunc
         # stream-ordered blocking call, i.e. a host / GPU rendezvous in every iteration (nothing else in an iteration draws host random numbers)
         if it % IDX_CHUNK == 0:
             m = min(IDX_CHUNK, iters - it)
-            idx_dev = torch.stack([torch.randperm(n)[:batch_size] for _ in range(m)]).to(device)
+            idx_host = torch.stack([torch.randperm(n)[:batch_size] for _ in range(m)])
+            idx_dev = idx_host.to(device)
         idx = idx_dev[it % IDX_CHUNK]
+        idx._host = idx_host[it % IDX_CHUNK]      # (caches in pinned host memory -- data_utill.HostRows -- select their rows on the host)
         b, active = loss_func.tick()
         rec, rl = unit.iterate(idx)
         if LOSS_TRACE is not None and loss_func.count in LOSS_TRACE["counts"]:
