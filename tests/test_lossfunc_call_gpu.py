@@ -69,3 +69,44 @@ def test_lossfunc_time_embedding_call():
     rv = torch.clamp(torch.sigmoid(layer.wqtizer.alpha.detach().cpu()) * 1.2 - 0.1, 0, 1)       # adaptive_rounding.py:40-41, on the host
     ref = rec + 0.01 * float((1 - ((rv - 0.5).abs() * 2).pow(lf.temp_decay(1))).sum())
     assert abs(tot - ref) <= 2e-5 * abs(ref), (tot, ref)
+
+
+def test_lossfunc_call_weights_the_two_quantizers_of_a_split_layer():
+    """A QDIFF-split QuantLayer inside a block carries wqtizer (input channels [:split]) and wqtizer1 ([split:]); the rounding term is
+    (sum(wqtizer) * split + sum(wqtizer1) * (C - split)) / C (reference quant/reconstruction_util.py:72-79)."""
+    from quant.adaptive_rounding import AdaRoundQuantizer, RMODE
+    from quant.quant_layer import QMODE, QuantLayer, Scaler
+    from quant.reconstruction_util import RLOSS, LossFunc
+    torch.manual_seed(4)
+    conv = nn.Conv2d(24, 16, 1).to(DEV)
+    wq = {"bits": 4, "channel_wise": True, "scaler": Scaler.MINMAX}
+    aq = {"bits": 8, "channel_wise": False, "scaler": Scaler.MINMAX, "leaf_param": True}
+    layer = QuantLayer(conv, wq, aq, aq_mode=[QMODE.NORMAL.value, QMODE.QDIFF.value]).eval()
+    layer.set_quant_state(True, False)
+    split = 8
+    layer(torch.randn(2, 24, 8, 8, device=DEV), split=split)           # records the split, creates wqtizer1 / aqtizer1
+    assert layer.split == split and hasattr(layer, "wqtizer1")
+    ow = layer.original_w.data.to(DEV)
+    layer._wq_state(layer.wqtizer, layer.w.data[:, :split])
+    layer._wq_state(layer.wqtizer1, layer.w.data[:, split:])
+    layer.wqtizer = AdaRoundQuantizer(layer.wqtizer, rmode=RMODE.LEARNED_HARD_SIGMOID, w=ow[:, :split, ...])      # calibration.py: uaq2adar
+    layer.wqtizer1 = AdaRoundQuantizer(layer.wqtizer1, rmode=RMODE.LEARNED_HARD_SIGMOID, w=ow[:, split:, ...])
+    layer.wqtizer.soft_tgt = layer.wqtizer1.soft_tgt = True
+
+    class Block(nn.Module):
+        def __init__(self, l):
+            super().__init__()
+            self.skip_connection = l
+
+    soft = lambda q: torch.clamp(torch.sigmoid(q.alpha.detach().cpu()) * 1.2 - 0.1, 0, 1)
+    rv, rv1 = soft(layer.wqtizer), soft(layer.wqtizer1)
+    g = torch.Generator().manual_seed(2)
+    pred, tgt = torch.randn(4, 16, 8, 8, generator=g), torch.randn(4, 16, 8, 8, generator=g)
+    lf = LossFunc(o=Block(layer), round_loss=RLOSS.RELAXATION, w=0.01, max_count=10, rec_loss=RLOSS.MSE, b_range=(20, 2), decay_start=0.0, warmup=0.0)
+    for it in range(1, 4):
+        tot = float(lf(pred.to(DEV), tgt.to(DEV)))
+        b = lf.temp_decay(it)
+        t0, t1 = (1 - ((rv - 0.5).abs() * 2).pow(b)).sum(), (1 - ((rv1 - 0.5).abs() * 2).pow(b)).sum()
+        ref = float((pred - tgt).abs().pow(2).sum(1).mean()) + 0.01 * float((t0 * split + t1 * (24 - split)) / 24)
+        plain = float((pred - tgt).abs().pow(2).sum(1).mean()) + 0.01 * float(t0)
+        assert abs(tot - ref) <= 2e-5 * abs(ref) and abs(ref - plain) > 1e-3 * abs(ref), (it, tot, ref, plain)

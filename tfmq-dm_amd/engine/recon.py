@@ -148,7 +148,8 @@ class _Unit:
             # {w_reg, b (0 during the warm-up), lr / (1 - 0.9^t), sqrt(1 - 0.999^t)} of the next SC_CHUNK iterations, computed by the library's
             # own host function (the values tfmq_adaround_bwd_adam would compute for each t); one upload, then device-to-device rows
             rows = []
-            for c in range(self.count, min(self.count + self.SC_CHUNK, self.iters + 1)):
+            # (a unit iterated past `iters` keeps getting rows, as the eager path accepts any count: ADVICE r5)
+            for c in range(self.count, max(self.count + 1, min(self.count + self.SC_CHUNK, self.iters + 1))):
                 b = temp_decay(c, self.iters, self.warmup, self.b_range[0], self.b_range[1])
                 rows.append(ops.adaround_scalars(self.w_reg, b if c >= self.iters * self.warmup else 0.0, self.lr, c))
             self._sc_chunk, self._sc_base = torch.tensor(rows, dtype=torch.float32).to(idx.device), self.count

@@ -116,7 +116,22 @@ def _refuse_duplicate_devices(mine, hint=""):
     mine_h = mine + "\t" + (hint or "|")
     if store is not None:
         store.set(f"tfmq_comm_dev_{_comm_epoch}_{rank}", mine_h.encode())
-        both = [bytes(store.get(f"tfmq_comm_dev_{_comm_epoch}_{r}")).decode() for r in range(world)]
+        # a rank that died before its store.set must not park the others for the store's default timeout (30 min): wait a bounded time,
+        # then name the missing ranks
+        import datetime
+        keys = [f"tfmq_comm_dev_{_comm_epoch}_{r}" for r in range(world)]
+        try:
+            store.wait(keys, datetime.timedelta(seconds=float(os.environ.get("TFMQ_COMM_RENDEZVOUS_TIMEOUT_S", "120"))))
+        except Exception as e:      # noqa: BLE001 -- a timeout of the store (the class differs between store kinds)
+            missing = []
+            for r, k in enumerate(keys):
+                try:
+                    store.wait([k], datetime.timedelta(milliseconds=10))
+                except Exception:      # noqa: BLE001
+                    missing.append(r)
+            raise TfmqError(f"tfmq_comm_init: rank(s) {missing} never published their device identity ({type(e).__name__}); "
+                            "did they fail before the first device all-reduce?") from e
+        both = [bytes(store.get(k)).decode() for k in keys]
     else:
         both = [None] * world
         dist.all_gather_object(both, mine_h)

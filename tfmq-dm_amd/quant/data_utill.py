@@ -121,7 +121,9 @@ def save_inout(model, layer, cali_data: Tuple[torch.Tensor], asym: bool = False,
         def tensor(self):
             if self.buf is None:
                 return torch.cat(self.parts)
-            assert self.n == self.rows, (self.n, self.rows)
+            if self.n != self.rows:       # (a tap whose leading dimension divides the capture batch without scaling with it)
+                from tfmq_dm_amd._lib import TfmqError
+                raise TfmqError(f"save_inout: cache of '{name}' filled {self.n} of {self.rows} rows -- a tensor that does not scale with the batch")
             return self.buf
     # (the delta-learning units -- use_act -- reshape their caches: those stay on the device)
     ins, outs, tembs, ctxs = _Rows(not use_act), _Rows(not use_act), _Rows(), _Rows()

@@ -82,9 +82,16 @@ class LossFunc:
             from .quant_layer import QuantLayer
             layers = [self.o] if isinstance(self.o, QuantLayer) else [m for _, m in self.o.named_modules()
                                                                       if isinstance(m, QuantLayer) and not m.quant_emb and not m.ignore_recon]
+            from .quant_layer import QMODE
             for m in layers:
-                rv = m.wqtizer.get_soft_tgt()
-                rnd = rnd + self.w * (1 - ((rv - 0.5).abs() * 2).pow(b)).sum()
+                term = (1 - ((m.wqtizer.get_soft_tgt() - 0.5).abs() * 2).pow(b)).sum()
+                split = int(getattr(m, "split", 0) or 0)
+                if not isinstance(self.o, QuantLayer) and split != 0 and QMODE.QDIFF.value in m.aq_mode and getattr(m, "wqtizer1", None) is not None:
+                    # a QDIFF-split layer inside a block (reference :72-79): its two weight quantizers' terms weighted by their share of the input channels
+                    cin = m.w.shape[1]
+                    term1 = (1 - ((m.wqtizer1.get_soft_tgt() - 0.5).abs() * 2).pow(b)).sum()
+                    term = (term * split + term1 * (cin - split)) / cin
+                rnd = rnd + self.w * term
         else:
             raise NotImplementedError
         total = rec + rnd
