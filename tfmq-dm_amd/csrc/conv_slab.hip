@@ -189,6 +189,15 @@ __global__ __launch_bounds__(64 * 2 * NWM, 2) void k_conv3_slab(SlabP sp) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0;
 
+#ifdef TFMQ_PHASE_TIMERS
+  // where a wave's K-step goes (shader cycles, wave 0): [0] counted vmcnt wait, [1] barrier, [2] fragment reads until their data is there,
+  // [3] first half's MFMA issue, [4] DMA issue of the next steps, [5] second half's MFMA issue, [6] steps
+  unsigned long long kacc[7] = {0, 0, 0, 0, 0, 0, 0};
+  unsigned long long kt = clock64();
+#define SKT(i) do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); const unsigned long long t_ = clock64(); kacc[i] += t_ - kt; kt = t_; } while (0)
+#else
+#define SKT(i) do { } while (0)
+#endif
   auto kloop = [&](auto bch_tag) {
     constexpr int B_CH = decltype(bch_tag)::value;
     auto issue_b = [&](int c, int tap, int stage) {
@@ -207,7 +216,9 @@ __global__ __launch_bounds__(64 * 2 * NWM, 2) void k_conv3_slab(SlabP sp) {
         if constexpr (SLAB_ABLATE & 1) wait_vmcnt<0>();
         else if (pos + 1 < p.nsteps) wait_vmcnt<(NST - 2) * B_CH + X>();
         else wait_vmcnt<0>();
+        SKT(0);
         asm volatile("s_barrier" ::: "memory");
+        SKT(1);
       }
       // stage of a K-step: NST = 3 -> tap % 3 (9 taps a chunk); NST = 2 -> parity of the step index
       const int st_next = NST == 3 ? (TAP + 2) % 3 : ((pos + 1) & 1);
@@ -251,6 +262,10 @@ __global__ __launch_bounds__(64 * 2 * NWM, 2) void k_conv3_slab(SlabP sp) {
       };
       read_frags(0);
       if constexpr (SLAB_PREFETCH) read_frags(1);
+#ifdef TFMQ_PHASE_TIMERS
+      asm volatile("" : "+v"(af[0][0]), "+v"(af[0][1]), "+v"(bf[0][0]), "+v"(bf[0][WN - 1]), "+v"(bf[1][WN - 1]));
+      SKT(2);
+#endif
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
         if constexpr (!SLAB_PREFETCH) {
@@ -273,7 +288,15 @@ __global__ __launch_bounds__(64 * 2 * NWM, 2) void k_conv3_slab(SlabP sp) {
           }
         // the DMA issue of the next K-steps (SALU M0 moves + VMEM, ~100 clk a piece) sits behind the first half's MFMAs:
         // the matrix pipe works through them while the wave issues the loads, instead of idling right after the barrier
-        if (ks == 0) issue_next();
+#ifdef TFMQ_PHASE_TIMERS
+        asm volatile("" : "+v"(acc[0][0]), "+v"(acc[1][WN - 1]));
+        if (ks == 0) SKT(3);
+        else { SKT(5); kacc[6] += 1; }
+#endif
+        if (ks == 0) {
+          issue_next();
+          SKT(4);
+        }
       }
     };
 #pragma unroll
@@ -297,6 +320,11 @@ __global__ __launch_bounds__(64 * 2 * NWM, 2) void k_conv3_slab(SlabP sp) {
   if (NBP % NW != 0 && wid < NBP % NW) kloop(std::integral_constant<int, NBP / NW + 1>{});
   else kloop(std::integral_constant<int, NBP / NW>{});
   SLAB_MARK(1);
+#ifdef TFMQ_PHASE_TIMERS
+  if (p.dbg2 && tid == 0)
+    for (int i = 0; i < 7; ++i) p.dbg2[static_cast<size_t>(blockIdx.x) * 16 + i] = kacc[i];
+  unsigned long long et0 = clock64();
+#endif
 
   // ================================================================================ epilogue (out of the registers)
   // acc[i][j][8u .. 8u+7] = channels (wn*WN + j)*32 + 16h + 8u .. +7 of pixel row wm*64 + i*32 + lane%32 (lin_brow).
@@ -358,6 +386,9 @@ __global__ __launch_bounds__(64 * 2 * NWM, 2) void k_conv3_slab(SlabP sp) {
     for (int st = 0; st < PD; ++st) load_rq(st, rq[st]);
   }
   __syncthreads();                       // table visible
+#ifdef TFMQ_PHASE_TIMERS
+  unsigned long long et1 = clock64();
+#endif
 
 #pragma unroll
   for (int st = 0; st < NS; ++st) {
@@ -436,6 +467,17 @@ __global__ __launch_bounds__(64 * 2 * NWM, 2) void k_conv3_slab(SlabP sp) {
       __builtin_amdgcn_sched_barrier(0);
     }
   }
+#ifdef TFMQ_PHASE_TIMERS
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  unsigned long long et2 = clock64();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  unsigned long long et3 = clock64();
+  if (p.dbg2 && tid == 0) {
+    p.dbg2[static_cast<size_t>(blockIdx.x) * 16 + 8] = et1 - et0;      // constants table + residual prefetch + two barriers
+    p.dbg2[static_cast<size_t>(blockIdx.x) * 16 + 9] = et2 - et1;      // the (i, j) loop: affine map, residual, stores issued, statistics
+    p.dbg2[static_cast<size_t>(blockIdx.x) * 16 + 10] = et3 - et2;    // until the last store is acknowledged
+  }
+#endif
   if (seg) {
     __syncthreads();
     const int nseg = BM / seg, gps = seg / 8;
@@ -496,6 +538,9 @@ bool launch_conv_slab(tfmq_handle h, ConvP& p, hipStream_t st, bool forced, bool
   static unsigned long long* dbuf = nullptr;
   if (!dbuf) (void)hipMalloc(reinterpret_cast<void**>(&dbuf), sizeof(unsigned long long) * 4 * (1u << 16));
   sp.p.dbg = grid.x <= (1u << 16) ? dbuf : nullptr;
+  static unsigned long long* dbuf3 = nullptr;
+  if (!dbuf3) (void)hipMalloc(reinterpret_cast<void**>(&dbuf3), sizeof(unsigned long long) * 16 * (1u << 16));
+  sp.p.dbg2 = grid.x <= (1u << 16) ? dbuf3 : nullptr;
 #endif
   if (half_m) {
     if (f16) {
@@ -524,6 +569,20 @@ bool launch_conv_slab(tfmq_handle h, ConvP& p, hipStream_t st, bool forced, bool
       t1 = hb[i * 4 + 2] > t1 ? hb[i * 4 + 2] : t1;
       kl += double(hb[i * 4 + 1] - hb[i * 4]);
       ep += double(hb[i * 4 + 2] - hb[i * 4 + 1]);
+    }
+    {
+      std::vector<unsigned long long> kb(static_cast<size_t>(grid.x) * 16);
+      (void)hipMemcpy(kb.data(), dbuf3, kb.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+      double ks[7] = {0, 0, 0, 0, 0, 0, 0}, es[3] = {0, 0, 0};
+      for (unsigned i = 0; i < grid.x; ++i) {
+        for (int q = 0; q < 7; ++q) ks[q] += double(kb[i * 16 + q]);
+        for (int q = 0; q < 3; ++q) es[q] += double(kb[i * 16 + 8 + q]);
+      }
+      fprintf(stderr, "[slab %dx%dx%d Cin%d Cout%d] epilogue of wave 0, shader cycles per block: table + barriers %.0f, (i, j) loop %.0f, store drain %.0f\n",
+              d.B, d.H, d.W, d.Cin, d.Cout, es[0] / grid.x, es[1] / grid.x, es[2] / grid.x);
+      const double stn = ks[6] > 0 ? ks[6] : 1;
+      fprintf(stderr, "[slab %dx%dx%d Cin%d Cout%d] K-step of wave 0, shader cycles: vmcnt wait %.0f, barrier %.0f, fragment reads %.0f, MFMA issue (first half) %.0f, DMA issue %.0f, MFMA issue (second half) %.0f = %.0f per step\n",
+              d.B, d.H, d.W, d.Cin, d.Cout, ks[0] / stn, ks[1] / stn, ks[2] / stn, ks[3] / stn, ks[4] / stn, ks[5] / stn, (ks[0] + ks[1] + ks[2] + ks[3] + ks[4] + ks[5]) / stn);
     }
     // how synchronised are the blocks: histogram of epilogue-start times over the launch span, 20 bins
     int hist[20] = {0};
