@@ -665,6 +665,8 @@ def run_cali_workload(args, dev, rank, local_rank, world, log):
         dt = float(tt.item())
     if rank != 0:
         return None
+    # (the measured numbers go to stderr first: a long job must not lose them to a formatting slip further down)
+    print("[cali] wall-clock %.2f s; phases %s; calls %s" % (dt, json.dumps({k: round(v, 2) for k, v in acc.items()}), json.dumps(dict(calls))), file=sys.stderr, flush=True)
     ck = torch.load(path, map_location="cpu")
     n_units = calls["tib_reconstruction"] + calls["block_reconstruction"] + calls["layer_reconstruction"]
     rec_s = acc["tib_reconstruction"] + acc["block_reconstruction"] + acc["layer_reconstruction"]
@@ -697,7 +699,7 @@ def run_cali_workload(args, dev, rank, local_rank, world, log):
             os.environ.get("TFMQ_RECON_GEMM", "bf16x3"), "f32 values, split-bf16 (hi + lo, 3 MFMAs per product, fp32 accumulation: 2^-16 per product) GEMMs (AdaRound iterations)")
         + " + int8/f16 (capture forwards)", "data": "synthetic",
         "config": {"workload": (f"cali_model{'_multi' if world > 1 else ''} on the SD v1-4 UNet (859.5M, random init): {G} timestep groups x {N} "
-                                f"samples, {ITERS} AdaRound iterations per unit at mini-batch 8/rank (the recipe, txt2img.py:421-429,486: 50 DDIM steps x 256 samples -- 128 prompts x {cond, uncond} --, 20000), "
+                                f"samples, {ITERS} AdaRound iterations per unit at mini-batch 8/rank (the recipe, txt2img.py:421-429,486: 50 DDIM steps x 256 samples -- 128 prompts x (cond, uncond) --, 20000), "
                                 "w4 channel-wise + a8 Finite-Set, running_stat; " + gen_note
                                 + (f"; reconstruction restricted to the units under {args.cali_only}" if args.cali_only else "")),
                    "parallelism": "single GPU" if world == 1 else f"timestep-group shards x{world}, one RCCL SUM all-reduce per iteration"},

@@ -52,6 +52,7 @@ struct SlabP {
   int SW;         // slab row width = W + 2
   int SI;         // slab rows per image (imgs > 1); imgs == 1: rows of the whole slab
   int slab_rows;  // rows of the slab that carry pixels (<= 512)
+  int stats_lds;  // GroupNorm statistics through a wave-private LDS transpose (round 6; TFMQ_SLAB_STATS_LDS=0: the DPP sums of round 2)
   int prio;       // TFMQ_SETPRIO=1 (A/B runs): the second-dispatched half of an 8-wave block runs at s_setprio 1 (MI355X_MICROARCH.md: static priority)
 };
 
@@ -67,12 +68,23 @@ struct SlabGeo {
   static constexpr int STRIDE = CAP * 64;            // 32 KiB / 20 KiB
 };
 
+// Statistics through LDS (round 6).  The DPP form (group8_sum) spends 72 VALU instructions per register octet -- four dependent DPP adds per
+// value and statistic, of which only the lanes with lane % 8 == 0 keep the result: 55 % of the epilogue's VALU work, and the epilogue is a third
+// of a short-K block's life (profiles/r06_phase_slab.txt).  Here a wave writes the fp32 values of a 32-row x 32-channel tile to a private block
+// (rows 144 bytes apart: conflict-free 16-byte writes and 4-byte column reads) and every lane sums ONE (8-row group, channel) column for two
+// groups, serially, in the canonical order ((r0 + r1) + r2) + r3 + (((r4 + r5) + r6) + r7) -- the same additions on the same values, so the
+// partial sums are bit-identical (tests/test_conv_epilogue_modes_gpu.py compares every tile kernel's statistics): 44 VALU + 20 DS per tile
+// instead of 144 VALU.
+constexpr int SLAB_T_ROW = 36;                       // dwords per transposed row: 32 channels + 4
+constexpr int SLAB_T_BYTES = 32 * SLAB_T_ROW * 4;    // per wave
+
 template <int WN, int NWM>
 __host__ __device__ constexpr int slab_lds_bytes() {
   using G = SlabGeo<NWM>;
   constexpr int BN = 64 * WN;
   constexpr int main_ = 2 * G::STRIDE + G::NST * BN * 64;
-  constexpr int epi = (G::BM / 8) * BN * 8 + (3 + 4) * BN * 4;      // 8-row-group partial sums + the table of per-column constants
+  // 8-row-group partial sums + the table of per-column constants + a 32-row x 32-channel fp32 transpose block per wave (statistics)
+  constexpr int epi = (G::BM / 8) * BN * 8 + (3 + 4) * BN * 4 + G::NW * SLAB_T_BYTES;
   return main_ > epi ? main_ : epi;
 }
 
@@ -343,6 +355,8 @@ __global__ __launch_bounds__(64 * 2 * NWM, 2) void k_conv3_slab(SlabP sp) {
   float2 oqp = make_float2(1.0f, 0.0f);
   if (q8) oqp = load_qparam(d.oq);
   const QuantP qP = make_quantp(oqp);
+  float* Tw = reinterpret_cast<float*>(lds + (BM / 8) * BN * 8 + (3 + 4) * BN * 4 + wid * SLAB_T_BYTES);      // this wave's transpose block
+  const bool st_lds = seg != 0 && sp.stats_lds != 0;
   __syncthreads();                       // every wave has left the K loop: its LDS becomes the table and the partial sums
   for (int tc = tid; tc < BN; tc += NT) {
     const int n = n0 + tc;
@@ -452,7 +466,11 @@ __global__ __launch_bounds__(64 * 2 * NWM, 2) void k_conv3_slab(SlabP sp) {
           *reinterpret_cast<float4*>(dst + 4) = make_float4(v[2].x, v[2].y, v[3].x, v[3].y);
         }
       }
-      if (seg) {
+      if (st_lds) {
+        float* dst = Tw + (lane & 31) * SLAB_T_ROW + 16 * h + 8 * u;
+        *reinterpret_cast<float4*>(dst) = ok ? make_float4(v[0].x, v[0].y, v[1].x, v[1].y) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        *reinterpret_cast<float4*>(dst + 4) = ok ? make_float4(v[2].x, v[2].y, v[3].x, v[3].y) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+      } else if (seg) {
         // per channel: the 8-row group's (sum, sum of squares) of the fp32 values (before any rounding of the output);
         // rows / columns outside the tensor add exact zeros
         const int grp = wm * 8 + i * 4 + ((lane & 31) >> 3);
@@ -464,6 +482,23 @@ __global__ __launch_bounds__(64 * 2 * NWM, 2) void k_conv3_slab(SlabP sp) {
           if ((lane & 7) == 0) *reinterpret_cast<float4*>(ldsP + grp * BN + ct + 2 * e) = make_float4(s0, q0, s1, q1);
         }
       }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (st_lds) {
+      // column sums of the tile just written: lane = (channel c, group pair), two 8-row groups each
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      const int c = lane & 31;
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const int g = 2 * h + k;
+        const float* col = Tw + (g * 8) * SLAB_T_ROW + c;
+        const float x0 = col[0], x1 = col[SLAB_T_ROW], x2 = col[2 * SLAB_T_ROW], x3 = col[3 * SLAB_T_ROW];
+        const float x4 = col[4 * SLAB_T_ROW], x5 = col[5 * SLAB_T_ROW], x6 = col[6 * SLAB_T_ROW], x7 = col[7 * SLAB_T_ROW];
+        const float sa = ((x0 + x1) + x2) + x3, sb = ((x4 + x5) + x6) + x7;
+        const float qa = ((x0 * x0 + x1 * x1) + x2 * x2) + x3 * x3, qb = ((x4 * x4 + x5 * x5) + x6 * x6) + x7 * x7;
+        ldsP[(wm * 8 + i * 4 + g) * BN + (wn * WN + j) * 32 + c] = make_float2(sa + sb, qa + qb);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       __builtin_amdgcn_sched_barrier(0);
     }
   }
@@ -512,6 +547,8 @@ bool launch_conv_slab(tfmq_handle h, ConvP& p, hipStream_t st, bool forced, bool
   SlabP sp;
   static const int prio_env = getenv("TFMQ_SETPRIO") ? atoi(getenv("TFMQ_SETPRIO")) : 0;
   sp.prio = prio_env;
+  static const int stats_lds_env = getenv("TFMQ_SLAB_STATS_LDS") ? atoi(getenv("TFMQ_SLAB_STATS_LDS")) : 1;
+  sp.stats_lds = stats_lds_env;
   sp.HW = Hv * Wv;
   sp.SW = Wv + 2;
   if (sp.HW % BM == 0 && BM % Wv == 0) {
