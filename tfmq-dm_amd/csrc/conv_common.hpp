@@ -24,6 +24,7 @@ struct ConvP {
   int ksplit;                      // >= 1: workgroups per output tile (k_conv_dma, w4a8)
   int* ks_ws;                      // tfmq_ctx::ksplit_ws: [tile][slice][BM * BN] int32 partial sums
   int* ks_cnt;                     // tfmq_ctx::ksplit_cnt: arrival tickets, zero between launches
+  int issue_split;                 // k_lin_direct, TFMQ_LIN_ISSUE_SPLIT=1 (round 6 A/B): waves 2-3 issue their LDS-DMA pieces behind the first half's MFMAs
 #ifdef TFMQ_PHASE_TIMERS
   unsigned long long* dbg;         // [blocks][4] shader-clock stamps: start, loop start, loop end, end
   unsigned long long* dbg2;        // [blocks][8] shader cycles wave 0 spent in the parts of its K loop (k_lin_direct)

@@ -1011,6 +1011,7 @@ static int launch_conv(tfmq_handle h, const tfmq_conv_desc* dd, void* stream) {
                  "conv: stats_seg must be 16/32/64/128 and divide Ho*Wo");
   ConvP p;
   p.d = d;
+  p.issue_split = 0;
   p.M = d.B * d.Ho * d.Wo;
   p.Hv = d.up2x ? 2 * d.H : d.H;
   p.Wv = d.up2x ? 2 * d.W : d.W;

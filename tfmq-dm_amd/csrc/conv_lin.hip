@@ -415,7 +415,8 @@ __global__ __launch_bounds__(256, 3) void k_lin_direct(ConvP p) {
     asm volatile("s_barrier" ::: "memory");
     KT(1);
     if (s == 0) LIN_MARK(1);
-    if (s + 2 < p.nsteps) issue(s + 2, st_i);
+    const bool late = p.issue_split && wid >= 2;      // (wave-uniform)
+    if (!late && s + 2 < p.nsteps) issue(s + 2, st_i);
     KT(2);
     const unsigned char* sa = lds + st_c * STAGE;
     const unsigned char* sb = sa + BM * 64;
@@ -455,6 +456,7 @@ __global__ __launch_bounds__(256, 3) void k_lin_direct(ConvP p) {
             acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(bf[ks][j], af[ks][i], acc[i][j], 0, 0, 0);
           }
         }
+      if (ks == 0 && late && s + 2 < p.nsteps) issue(s + 2, st_i);
     }
     st_c = st_c == NST - 1 ? 0 : st_c + 1;
     st_i = st_i == NST - 1 ? 0 : st_i + 1;
@@ -545,6 +547,8 @@ bool launch_conv_lin(tfmq_handle h, ConvP& p, hipStream_t st) {
     return false;
   }
   p.tiles_n = (d.Cout + 127) / 128;
+  static const int issue_split_env = getenv("TFMQ_LIN_ISSUE_SPLIT") ? atoi(getenv("TFMQ_LIN_ISSUE_SPLIT")) : 0;
+  p.issue_split = issue_split_env;
   const int tiles_m = (p.M + 127) / 128;
   const int n_tiles = p.tiles_n * tiles_m;
   dim3 grid(static_cast<unsigned>(n_tiles));
@@ -604,6 +608,7 @@ bool launch_conv_lin_f16(tfmq_handle h, ConvP& p, hipStream_t st) {
   if (d.residual && !d.res_f16) return false;
   if (d.stats && 128 % d.stats_seg != 0) return false;
   (void)h;
+  p.issue_split = 0;
   p.tiles_n = (d.Cout + 127) / 128;
   const int tiles_m = (p.M + 127) / 128;
   dim3 grid(static_cast<unsigned>(p.tiles_n) * tiles_m);

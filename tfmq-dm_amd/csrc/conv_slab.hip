@@ -52,6 +52,9 @@ struct SlabP {
   int SW;         // slab row width = W + 2
   int SI;         // slab rows per image (imgs > 1); imgs == 1: rows of the whole slab
   int slab_rows;  // rows of the slab that carry pixels (<= 512)
+  int issue_split; // TFMQ_SLAB_ISSUE_SPLIT=1 (round 6 A/B): the second-dispatched half of the waves issues its LDS-DMA pieces right behind the step's barrier,
+                  // the first half behind its first-half MFMAs (as every wave did): the 24-piece burst of a step (~17 cycles of the CU's L1 -> LDS path per piece,
+                  // profiles/r06_ubench_ldsdma_stream.txt) was queued in front of every wave at once -- 660 ... 720 cycles of a 2400-cycle step (profiles/r06_kstep_slab.txt)
   int stats_lds;  // GroupNorm statistics through a wave-private LDS transpose (round 6; TFMQ_SLAB_STATS_LDS=0: the DPP sums of round 2)
   int prio;       // TFMQ_SETPRIO=1 (A/B runs): the second-dispatched half of an 8-wave block runs at s_setprio 1 (MI355X_MICROARCH.md: static priority)
 };
@@ -272,6 +275,8 @@ __global__ __launch_bounds__(64 * 2 * NWM, 2) void k_conv3_slab(SlabP sp) {
           else bf[ks][j] = *reinterpret_cast<const v4i*>(sb + ((b_rel ^ (ks << 5)) + j * 2048));
         }
       };
+      const bool early = sp.issue_split && wid >= NW / 2;      // (wave-uniform)
+      if (early) issue_next();
       read_frags(0);
       if constexpr (SLAB_PREFETCH) read_frags(1);
 #ifdef TFMQ_PHASE_TIMERS
@@ -306,7 +311,7 @@ __global__ __launch_bounds__(64 * 2 * NWM, 2) void k_conv3_slab(SlabP sp) {
         else { SKT(5); kacc[6] += 1; }
 #endif
         if (ks == 0) {
-          issue_next();
+          if (!early) issue_next();
           SKT(4);
         }
       }
@@ -547,6 +552,8 @@ bool launch_conv_slab(tfmq_handle h, ConvP& p, hipStream_t st, bool forced, bool
   SlabP sp;
   static const int prio_env = getenv("TFMQ_SETPRIO") ? atoi(getenv("TFMQ_SETPRIO")) : 0;
   sp.prio = prio_env;
+  static const int issue_split_env = getenv("TFMQ_SLAB_ISSUE_SPLIT") ? atoi(getenv("TFMQ_SLAB_ISSUE_SPLIT")) : 0;
+  sp.issue_split = issue_split_env;
   static const int stats_lds_env = getenv("TFMQ_SLAB_STATS_LDS") ? atoi(getenv("TFMQ_SLAB_STATS_LDS")) : 1;
   sp.stats_lds = stats_lds_env;
   sp.HW = Hv * Wv;
