@@ -624,6 +624,8 @@ def run_cali_workload(args, dev, rank, local_rank, world, log):
             torch.cuda.synchronize()
             acc[name] += time.perf_counter() - t
             calls[name] += 1
+            if rank == 0 and ITERS >= 1000:      # a long job keeps its per-unit times even when it is cut off
+                print("[cali] %s #%d: %.1f s" % (name, calls[name], time.perf_counter() - t), file=sys.stderr, flush=True)
             return r
         setattr(mod, name, g_)
     for mod, name in ((QC, "tib_reconstruction"), (QC, "block_reconstruction"), (QC, "layer_reconstruction"), (QC, "_calibrate_activations")):

@@ -11,6 +11,6 @@ case "$PART" in
   *) echo "PART=a|b|c"; exit 2;;
 esac
 ITERS=${ITERS:-20000}
-timeout ${LIMIT:-5400} python bench.py --workload cali --cali-generate --cali-groups 50 --cali-samples 256 --cali-iters $ITERS --cali-only "$ONLY" \
+timeout ${LIMIT:-3300} python bench.py --workload cali --cali-generate --cali-groups 50 --cali-samples 256 --cali-iters $ITERS --cali-only "$ONLY" \
   > $O/sd_cali_50x256_part_$PART.json 2> $O/sd_cali_50x256_part_$PART.err
-echo "rc=$?"; tail -c 600 $O/sd_cali_50x256_part_$PART.json; grep -i "pinned host\|error\|Traceback" $O/sd_cali_50x256_part_$PART.err | tail -5
+echo "rc=$?"; (free -g; grep "\[cali\]" $O/sd_cali_50x256_part_$PART.err | tail -80) > $O/sd_cali_50x256_part_$PART.units.txt; tail -c 600 $O/sd_cali_50x256_part_$PART.json; grep -i "pinned host\|error\|Traceback" $O/sd_cali_50x256_part_$PART.err | tail -5

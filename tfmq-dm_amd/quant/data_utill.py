@@ -15,6 +15,7 @@ import torch
 
 from tfmq_dm_amd import ops
 from tfmq_dm_amd.engine import StopAt
+from tfmq_dm_amd._lib import TfmqError
 
 logger = logging.getLogger(__name__)
 
@@ -39,6 +40,11 @@ class HostRows:
     recipe's `output_blocks.9` input are 201 GB)."""
 
     def __init__(self, shape, dtype, device):
+        need = torch.empty((), dtype=dtype).element_size() * int(torch.Size(shape).numel())
+        avail = _host_available()
+        if avail is not None and need + (16 << 30) > avail:     # fail before the allocation, not in the host's OOM killer
+            raise TfmqError(f"HostRows: {need / 2**30:.1f} GiB of pinned host memory wanted for a reconstruction cache, "
+                            f"{avail / 2**30:.1f} GiB available on this host")
         self.buf = torch.empty(tuple(shape), dtype=dtype, pin_memory=True)
         self.device, self.dtype, self.shape = torch.device(device), dtype, torch.Size(shape)
         self.is_host_rows = True
@@ -60,6 +66,18 @@ class HostRows:
         for j, i in enumerate(ids):
             out[j].copy_(self.buf[i], non_blocking=True)
         return out
+
+
+def _host_available():
+    """MemAvailable of /proc/meminfo in bytes (None where the file is missing)."""
+    try:
+        with open("/proc/meminfo") as f:
+            for line in f:
+                if line.startswith("MemAvailable:"):
+                    return int(line.split()[1]) * 1024
+    except OSError:
+        pass
+    return None
 
 
 def _device_room(dev) -> int:
