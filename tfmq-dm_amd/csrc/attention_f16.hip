@@ -837,8 +837,346 @@ __global__ __launch_bounds__(64 * NW, OCC) void k_attention_d40(AttnHP p) {
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// K10pp (round 6): the d = 40 self-attention in PING-PONG form.  k_attention_d40 mixes the MFMAs and the softmax VALU work of three
+// key tiles inside every wave and relies on the two pipes overlapping within one instruction stream; measured (PMC, profiles/
+// r04_pmc_attention_d40.json) the matrix pipe is 58 % busy, the VALU 64 %, and only a fifth of the VALU time runs beside an MFMA:
+// an in-order wave issues one instruction at a time, and the two waves of a SIMD -- from two different 4-wave blocks -- drift freely.
+// Here a block has EIGHT waves (256 queries), waves w and w + 4 share a SIMD, and the two halves run the same key tile HALF A TILE
+// APART, two workgroup barriers per tile (the "compute segment | load segment" pairing of MI355X_MICROARCH.md, two waves per SIMD):
+//       V segment   softmax of tile t (row maximum, the rare re-base, 32 exp2, 16 cvt_pk -> P(t)), the fragment reads of
+//                   K(t+1) and V^T(t), this wave's LDS-DMA pieces of K(t+4) / V^T(t+3): VALU + LDS + VMEM, no MFMA
+//       M segment   S(t+1) = K(t+1) Q^T (6 MFMAs) and O += V^T(t) P(t) (8 MFMAs): nothing else
+// so on every SIMD one wave's 14 MFMAs (448 matrix-pipe cycles) lie beside the other wave's ~75 VALU instructions.  A wave's own
+// chain V(t) -> M(t) -> V(t+1) is serial -- no software pipelining inside a wave, one score buffer, no second P buffer, the re-base
+// happens before any exponential is taken (none is taken twice).  Same operand roles, LDS image, folded shift and ones-row
+// denominator as k_attention_d40; rings of four K and four V^T buffers, K four tiles ahead of its fragment read and V^T three,
+// counted waits at the END of a V segment (everything but the pieces of this and the previous V segment has landed: >= 4 segments
+// of latency) in front of the barrier that publishes them.
+template <int DBG = 0>
+__global__ __launch_bounds__(512, 2) void k_attention_d40_pp(AttnHP p) {
+  constexpr int NW = 8, NTH = 64 * NW, QB = 32 * NW;
+  constexpr int NSLOT = 2, NFULL = 2;                            // DMA wave-instructions per wave and tile: 2 for waves 0, 1, else 1
+  constexpr int KROW = 80, KSUB = 32 * KROW, KBUF = 64 * KROW;   // 2560, 5120
+  constexpr int ONES = 4 * KBUF;                                // constant pieces at ONES, ONES + KSUB
+  constexpr int VBASE = 23552, VROW = 128, VBUF = 64 * VROW;    // 8192
+  constexpr int LDS_BYTES = VBASE + 4 * VBUF;                   // 56320
+  __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = wid >> 2;                                      // waves w and w + 4 share a SIMD: the late half runs half a tile behind
+  const int j = lane & 31, hh = lane >> 5;
+  int bid = blockIdx.x;
+  {
+    const int nb = gridDim.x, xcd = bid & 7, qn = nb >> 3, r = nb & 7;
+    bid = (xcd < r ? xcd * (qn + 1) : r * (qn + 1) + (xcd - r) * qn) + (bid >> 3);
+  }
+  const int nqb = p.Tq / QB;
+  const int bh = bid / nqb;
+  const int b = bh / p.heads, hd = bh % p.heads;
+  const int q0 = (bid - bh * nqb) * QB;
+  constexpr int d = 40;
+
+  for (int i = tid; i < LDS_BYTES / 16; i += NTH) reinterpret_cast<uint4*>(smem)[i] = make_uint4(0, 0, 0, 0);
+
+  // ---- Q fragments, pre-multiplied by scale * log2(e) (rounded once to fp16); column 40 carries -shift
+  v8h qf[3];
+  {
+    const int qrow = q0 + wid * 32 + j;
+    const float c2q = p.scale * 1.44269504088896340736f;
+#pragma unroll
+    for (int ks = 0; ks < 3; ++ks) {
+      uint4 v = make_uint4(0, 0, 0, 0);
+      const int c = ks * 16 + hh * 8;
+      if (c < d) v = *reinterpret_cast<const uint4*>(p.q + (static_cast<size_t>(b) * p.Tq + qrow) * p.ldq + hd * d + c);
+      qf[ks] = *reinterpret_cast<v8h*>(&v);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) qf[ks][e] = static_cast<_Float16>(static_cast<float>(qf[ks][e]) * c2q);
+    }
+#pragma unroll
+    for (int ks = 0; ks < 3; ++ks) asm volatile("" : "+v"(qf[ks]));
+  }
+
+  // ---- DMA plan (as k_attention_d40<8>): wave-instructions 0..4 = a K tile, 5..9 = a V^T tile; wave w issues w and w + 8
+  const unsigned char* kptr = reinterpret_cast<const unsigned char*>(p.k + static_cast<size_t>(b) * p.Tks * p.ldk + hd * d);
+  const unsigned char* vptr = reinterpret_cast<const unsigned char*>(p.vt + (static_cast<size_t>(b) * p.heads + hd) * d * p.Tks);
+  const size_t kstep = static_cast<size_t>(64) * p.ldk * 2;     // bytes per K tile (a V^T tile: 128)
+  unsigned dma_off[NSLOT], slot_dst[NSLOT];
+  bool slot_k[NSLOT];
+#pragma unroll
+  for (int s = 0; s < NSLOT; ++s) {
+    const int id = wid + NW * s;
+    slot_k[s] = id < 5;
+    if (id < 5) {
+      const int n = id * 64 + lane, rho = n / 5, c = n - rho * 5;
+      const int key = (rho & 0x33) | ((rho & 4) << 1) | ((rho & 8) >> 1);
+      dma_off[s] = static_cast<unsigned>(key * p.ldk * 2 + c * 16);
+      slot_dst[s] = id * 1024;
+    } else {
+      const int n = (id - 5) * 64 + lane, r = n >> 3, sl = n & 7;
+      dma_off[s] = static_cast<unsigned>(r * p.Tks * 2 + ((sl ^ ((r >> 1) & 7)) << 4));
+      slot_dst[s] = VBASE + (id - 5) * 1024;
+    }
+  }
+  const bool slot2 = wid < NFULL;  // the second slot exists only for waves 0, 1
+  const unsigned lds0 = static_cast<unsigned>(reinterpret_cast<uintptr_t>(smem));
+  unsigned slot_lds[NSLOT];
+#pragma unroll
+  for (int s = 0; s < NSLOT; ++s) slot_lds[s] = __builtin_amdgcn_readfirstlane(lds0 + slot_dst[s]);
+  auto dma = [&](const unsigned char* kp, const unsigned char* vp, int kb, int vb, bool do_k, bool do_v) {
+#pragma unroll
+    for (int s = 0; s < NSLOT; ++s) {
+      if (s == NSLOT - 1 && !slot2) continue;
+      const bool isk = slot_k[s];          // wave-uniform
+      if (isk ? do_k : do_v) glds16_s(isk ? kp : vp, dma_off[s], slot_lds[s] + (isk ? kb * KBUF : vb * VBUF));
+    }
+  };
+
+  // ---- fragment addresses (bytes; + buffer offset as an immediate)
+  const unsigned ka = j * KROW + hh * 16;                         // k-steps 0, 1 at +0, +32
+  unsigned ka2[4];                                                // k-step 2: the upper lane half reads the constant piece
+#pragma unroll
+  for (int kb = 0; kb < 4; ++kb) ka2[kb] = hh ? static_cast<unsigned>(ONES - kb * KBUF) : static_cast<unsigned>(j * KROW + 64);
+  unsigned va[4];
+  {
+    const int g = (j >> 1) & 7;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) va[u] = VBASE + j * VROW + (((2 * u + hh) ^ g) << 4);      // row j + 32 tt: + 4096 tt, same g
+  }
+
+  float m_run = 0.0f;
+  v16f o[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[t][r] = 0.0f;
+
+  __syncthreads();                 // zero fill done
+  if (tid < 2) *reinterpret_cast<uint4*>(smem + ONES + tid * KSUB) = make_uint4(0x00003C00u, 0, 0, 0);
+  if (tid >= 64 && tid < 96) {
+    const uint4 ones = make_uint4(0x3C003C00u, 0x3C003C00u, 0x3C003C00u, 0x3C003C00u);
+    *reinterpret_cast<uint4*>(smem + VBASE + ((tid - 64) >> 3) * VBUF + 40 * VROW + ((tid - 64) & 7) * 16) = ones;
+  }
+  const int nt = p.Tk >> 6;        // a multiple of 4
+  dma(kptr, vptr, 0, 0, true, true);                          // K(0), V(0)
+  dma(kptr + kstep, vptr + 128, 1, 1, true, true);            // K(1), V(1)
+  dma(kptr + 2 * kstep, vptr, 2, 0, true, false);             // K(2)
+  dma(kptr + 3 * kstep, vptr + 256, 3, 2, true, true);        // K(3), V(2): the batch that may still fly behind the first barrier
+  if (slot2) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(NSLOT) : "memory");
+  else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(NSLOT - 1) : "memory");
+
+  // (volatile: the tree keeps its place behind the volatile s_nop that separates it from the MFMAs whose results it reads)
+  auto row_max = [&](const v16f (&s)[2]) {
+    float m0 = vmax3v(s[0][0], s[0][1], s[0][2]), m1 = vmax3v(s[0][3], s[0][4], s[0][5]);
+    float m2 = vmax3v(s[1][0], s[1][1], s[1][2]), m3 = vmax3v(s[1][3], s[1][4], s[1][5]);
+    m0 = vmax3v(m0, s[0][6], s[0][7]);   m1 = vmax3v(m1, s[0][8], s[0][9]);
+    m2 = vmax3v(m2, s[1][6], s[1][7]);   m3 = vmax3v(m3, s[1][8], s[1][9]);
+    m0 = vmax3v(m0, s[0][10], s[0][11]); m1 = vmax3v(m1, s[0][12], s[0][13]);
+    m2 = vmax3v(m2, s[1][10], s[1][11]); m3 = vmax3v(m3, s[1][12], s[1][13]);
+    m0 = vmax3v(m0, s[0][14], s[0][15]); m2 = vmax3v(m2, s[1][14], s[1][15]);
+    m0 = vmax3v(m0, m1, m2);
+    m0 = vmax3v(m0, m3, m3);
+    const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(m0), __float_as_uint(m0), false, false);   // lane ^ 32: the query's other 32 keys
+    return vmax3v(__uint_as_float(sw[0]), __uint_as_float(sw[1]), __uint_as_float(sw[1]));
+  };
+  constexpr int ksb = 2, qe = 0;       // Q column 40 = k-step 2, upper lane half, element 0
+
+  v16f sc[2];                      // the scores of the tile whose softmax comes next
+  {   // scores of tile 0 (every wave, before the halves part); its row maximum is the first shift (fp16-representable)
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sc[sub][r] = 0.0f;
+      const v8h k0 = *reinterpret_cast<const v8h*>(smem + ka + sub * KSUB), k1 = *reinterpret_cast<const v8h*>(smem + ka + sub * KSUB + 32);
+      const v8h k2 = *reinterpret_cast<const v8h*>(smem + ka2[0] + sub * KSUB);
+      sc[sub] = __builtin_amdgcn_mfma_f32_32x32x16_f16(k0, qf[0], sc[sub], 0, 0, 0);
+      sc[sub] = __builtin_amdgcn_mfma_f32_32x32x16_f16(k1, qf[1], sc[sub], 0, 0, 0);
+      sc[sub] = __builtin_amdgcn_mfma_f32_32x32x16_f16(k2, qf[2], sc[sub], 0, 0, 0);
+    }
+    asm volatile("s_nop 15" : "+v"(sc[0]), "+v"(sc[1]));     // MFMA results -> inline-asm VALU readers: the wait states the compiler cannot count
+    const float mx = row_max(sc);
+    m_run = static_cast<float>(static_cast<_Float16>(mx));
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sc[sub][r] -= m_run;
+    if (hh) qf[ksb][qe] = static_cast<_Float16>(-m_run);
+  }
+
+  unsigned pp[16];                 // packed fp16 P of the tile: pp[4 u + e] = keys 16 u + 8 hh + 2 e, +1
+  v8h vf[4][2];                    // V^T fragments of the same tile
+  v8h kf[2][3];                    // K fragments of the next tile
+
+  // ---- V segment of tile t (B = t & 3): in sc the scores of tile t; out pp = P(t), vf = V^T(t) fragments, kf = K(t+1) fragments
+  auto vseg = [&](auto b_tag, auto kdma_tag, auto vdma_tag, auto last_tag, auto counted_tag, const unsigned char* kp, const unsigned char* vp) {
+    constexpr int B = decltype(b_tag)::value, KB = (B + 1) & 3;
+    constexpr bool KDMA = decltype(kdma_tag)::value, VDMA = decltype(vdma_tag)::value, LAST = decltype(last_tag)::value;
+    constexpr bool COUNTED = decltype(counted_tag)::value;
+    if constexpr (!(DBG & 64)) dma(kp, vp, B, (B + 3) & 3, KDMA, VDMA);          // K(t+4) -> buffer t & 3, V^T(t+3) -> buffer (t+3) & 3
+    if constexpr (!LAST) {
+#pragma unroll
+      for (int sub = 0; sub < 2; ++sub) {
+        kf[sub][0] = *reinterpret_cast<const v8h*>(smem + KB * KBUF + ka + sub * KSUB);
+        kf[sub][1] = *reinterpret_cast<const v8h*>(smem + KB * KBUF + ka + sub * KSUB + 32);
+        kf[sub][2] = *reinterpret_cast<const v8h*>(smem + KB * KBUF + ka2[KB] + sub * KSUB);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt) vf[u][tt] = *reinterpret_cast<const v8h*>(smem + B * VBUF + va[u] + tt * 32 * VROW);
+    // (the maximum tree is inline asm reading MFMA results: the barrier and the DMA issue lie in between; pad for the iterations without DMA)
+    asm volatile("s_nop 7");
+    float mx;
+    if constexpr (DBG & 16) mx = sc[0][3] + sc[1][5];
+    else mx = row_max(sc);
+    // ---- the re-base (rare): before any exponential of this tile is taken
+    if (__builtin_amdgcn_ballot_w64(mx > 8.0f) != 0) {
+      const float m_new = mx > 8.0f ? static_cast<float>(static_cast<_Float16>(m_run + mx)) : m_run;
+      const float delta = m_new - m_run;                 // exact: both fp16-representable
+      const float alpha = __builtin_amdgcn_exp2f(-delta);
+#pragma unroll
+      for (int i = 0; i < 32; ++i) sc[i >> 4][i & 15] -= delta;
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[tt][r] *= alpha;
+      m_run = m_new;
+      if (hh) qf[ksb][qe] = static_cast<_Float16>(-m_run);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int i0 = 16 * (u >> 1) + 8 * (u & 1) + 2 * e;
+        float e0, e1;
+        if constexpr (DBG & 1) { e0 = sc[i0 >> 4][i0 & 15]; e1 = sc[(i0 + 1) >> 4][(i0 + 1) & 15]; }
+        else { e0 = __builtin_amdgcn_exp2f(sc[i0 >> 4][i0 & 15]); e1 = __builtin_amdgcn_exp2f(sc[(i0 + 1) >> 4][(i0 + 1) & 15]); }
+        const __half2 h2 = __floats2half2_rn(e0, e1);
+        pp[4 * u + e] = *reinterpret_cast<const unsigned*>(&h2);
+      }
+    // The packed P and the fragments are operands of an (empty) volatile statement in front of the barrier: otherwise the instruction
+    // selector orders the exponentials, conversions and reads behind the barrier, into the M segment.
+    asm volatile(""
+                 : "+v"(pp[0]), "+v"(pp[1]), "+v"(pp[2]), "+v"(pp[3]), "+v"(pp[4]), "+v"(pp[5]), "+v"(pp[6]), "+v"(pp[7]),
+                   "+v"(pp[8]), "+v"(pp[9]), "+v"(pp[10]), "+v"(pp[11]), "+v"(pp[12]), "+v"(pp[13]), "+v"(pp[14]), "+v"(pp[15]),
+                   "+v"(vf[0][0]), "+v"(vf[0][1]), "+v"(vf[1][0]), "+v"(vf[1][1]), "+v"(vf[2][0]), "+v"(vf[2][1]), "+v"(vf[3][0]), "+v"(vf[3][1]));
+    if constexpr (!LAST)
+      asm volatile("" : "+v"(kf[0][0]), "+v"(kf[0][1]), "+v"(kf[0][2]), "+v"(kf[1][0]), "+v"(kf[1][1]), "+v"(kf[1][2]));
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (DBG & 256) {
+    } else if constexpr (COUNTED) {
+      if (slot2) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(2 * NSLOT) : "memory");
+      else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(2 * (NSLOT - 1)) : "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  // ---- M segment of tile t: S(t+1) = K(t+1) Q^T into sc (its old content is spent), O += V^T(t) P(t)
+  auto mseg = [&](auto last_tag, bool tail_barrier) {
+    constexpr bool LAST = decltype(last_tag)::value;
+    if constexpr (!LAST) {
+#pragma unroll
+      for (int sub = 0; sub < 2; ++sub) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sc[sub][r] = 0.0f;
+#pragma unroll
+        for (int ks = 0; ks < 3; ++ks) {
+          if constexpr (DBG & 4) sc[sub][ks] += static_cast<float>(kf[sub][ks][0]);
+          else sc[sub] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[sub][ks], qf[ks], sc[sub], 0, 0, 0);
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      v8h bp;
+      unsigned* bw = reinterpret_cast<unsigned*>(&bp);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) bw[e] = pp[4 * u + e];
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt) {
+        if constexpr (DBG & 2) o[tt][u] += static_cast<float>(vf[u][tt][0]) + __uint_as_float(bw[tt]);
+        else o[tt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[u][tt], bp, o[tt], 0, 0, 0);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (!(DBG & 256)) {
+      if (tail_barrier) asm volatile("s_barrier" ::: "memory");
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  using I2 = std::integral_constant<int, 2>;
+  using I3 = std::integral_constant<int, 3>;
+  using Y = std::true_type;
+  using N = std::false_type;
+  if constexpr (!(DBG & 256)) {
+    if (grp == 1) asm volatile("s_barrier" ::: "memory");       // the late half: half a tile behind
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  const unsigned char* kp = kptr + 4 * kstep;     // K(t + 4)
+  const unsigned char* vp = vptr + 384;           // V^T(t + 3)
+  for (int t = 0; t + 4 < nt; t += 4) {
+    vseg(I0{}, Y{}, Y{}, N{}, Y{}, kp, vp);                       mseg(N{}, true);
+    vseg(I1{}, Y{}, Y{}, N{}, Y{}, kp + kstep, vp + 128);         mseg(N{}, true);
+    vseg(I2{}, Y{}, Y{}, N{}, Y{}, kp + 2 * kstep, vp + 256);     mseg(N{}, true);
+    vseg(I3{}, Y{}, Y{}, N{}, Y{}, kp + 3 * kstep, vp + 384);     mseg(N{}, true);
+    kp += 4 * kstep;
+    vp += 512;
+  }
+  vseg(I0{}, N{}, Y{}, N{}, N{}, kp, vp);     mseg(N{}, true);     // t = nt-4: V^T(nt-1); the last tiles drain the queue
+  vseg(I1{}, N{}, N{}, N{}, N{}, kp, vp);     mseg(N{}, true);     // t = nt-3
+  vseg(I2{}, N{}, N{}, N{}, N{}, kp, vp);     mseg(N{}, true);     // t = nt-2
+  vseg(I3{}, N{}, N{}, Y{}, N{}, kp, vp);     mseg(Y{}, grp == 0); // t = nt-1: no scores left to compute; the late half's last M segment has no partner
+
+  // ---- normalise and store (as k_attention_d40)
+  const int qg = q0 + wid * 32 + j;
+  float l_run;
+  {
+    constexpr int lr = 40 % 32, hh_one = (lr >> 2) & 1, r_one = (lr & 3) + 4 * (lr >> 3);
+    const float mine = o[1][r_one];
+    const float other = __shfl_xor(mine, 32, 64);
+    l_run = hh == hh_one ? mine : other;
+  }
+  const float inv = 1.0f / l_run;
+  const bool quant = p.yq != nullptr;
+  float2 qp = make_float2(1.0f, 0.0f);
+  if (quant) qp = load_qparam(p.aq);
+  const size_t tok = static_cast<size_t>(b) * p.Tq + qg;
+#pragma unroll
+  for (int tt = 0; tt < 2; ++tt) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int dc = tt * 32 + 8 * g + 4 * hh;
+      if (dc >= d) continue;
+      float4 v = make_float4(o[tt][4 * g] * inv, o[tt][4 * g + 1] * inv, o[tt][4 * g + 2] * inv, o[tt][4 * g + 3] * inv);
+      if (p.out) *reinterpret_cast<float4*>(p.out + tok * p.ldo + hd * d + dc) = v;
+      if (quant) {
+        char4 c = quant_char4(v.x, v.y, v.z, v.w, make_quantp(qp));
+        *reinterpret_cast<char4*>(p.yq + tok * (static_cast<size_t>(p.heads) * d) + hd * d + dc) = c;
+      }
+    }
+  }
+}
+
 static int launch_attn_d40(tfmq_handle h, const AttnHP& p, void* stream) {
   static const int nw = getenv("TFMQ_ATTN_PIPE_NW") ? atoi(getenv("TFMQ_ATTN_PIPE_NW")) : 4;
+  static const int pp = getenv("TFMQ_ATTN_PP") ? atoi(getenv("TFMQ_ATTN_PP")) : 1;        // ping-pong form (round 6) where its 256-query blocks fit
+  if (pp && p.Tq % 256 == 0) {
+    dim3 gridp(static_cast<unsigned>(p.Tq / 256) * p.B * p.heads);
+#ifdef TFMQ_ATTN_ABLATE
+    static const int dbgp = getenv("TFMQ_ATTN_DBG") ? atoi(getenv("TFMQ_ATTN_DBG")) : 0;
+#define TFMQ_ABLP(D) if (dbgp == D) { hipLaunchKernelGGL((k_attention_d40_pp<D>), gridp, dim3(512), 0, as_stream(stream), p); TFMQ_LAUNCH_CHECK(h); return TFMQ_OK; }
+    TFMQ_ABLP(1) TFMQ_ABLP(2) TFMQ_ABLP(4) TFMQ_ABLP(6) TFMQ_ABLP(16) TFMQ_ABLP(17) TFMQ_ABLP(64) TFMQ_ABLP(256)
+#endif
+    hipLaunchKernelGGL((k_attention_d40_pp<0>), gridp, dim3(512), 0, as_stream(stream), p);
+    TFMQ_LAUNCH_CHECK(h);
+    return TFMQ_OK;
+  }
   if (nw == 8 && p.Tq % 256 == 0) {
     dim3 grid8(static_cast<unsigned>(p.Tq / 256) * p.B * p.heads);
 #ifdef TFMQ_ATTN_ABLATE

@@ -60,12 +60,13 @@ struct SlabP {
 };
 
 // Geometry of a variant: NWM waves along M (4: 256-pixel tiles, 8 waves, one block per CU; 2: 128-pixel tiles, 4 waves, two per CU)
-template <int NWM>
+// PP (round 6): the two waves of a SIMD in barrier-enforced anti-phase (see the kernel), FOUR weight stages
+template <int NWM, bool PP = false>
 struct SlabGeo {
   static constexpr int NW = 2 * NWM;                 // waves per block
   static constexpr int NT = 64 * NW;                 // threads
   static constexpr int BM = 64 * NWM;                // pixels per tile
-  static constexpr int NST = NWM == 4 ? 3 : 2;       // weight K-step stages in LDS
+  static constexpr int NST = PP ? 4 : (NWM == 4 ? 3 : 2);       // weight K-step stages in LDS
   static constexpr int NIT = NWM == 4 ? 4 : 5;       // slab DMA pieces per wave and chunk (one per K-step of taps 0 .. NIT-1)
   static constexpr int CAP = NIT * NW * 16;          // rows per slab buffer: 512 / 320
   static constexpr int STRIDE = CAP * 64;            // 32 KiB / 20 KiB
@@ -81,9 +82,9 @@ struct SlabGeo {
 constexpr int SLAB_T_ROW = 36;                       // dwords per transposed row: 32 channels + 4
 constexpr int SLAB_T_BYTES = 32 * SLAB_T_ROW * 4;    // per wave
 
-template <int WN, int NWM>
+template <int WN, int NWM, bool PP = false>
 __host__ __device__ constexpr int slab_lds_bytes() {
-  using G = SlabGeo<NWM>;
+  using G = SlabGeo<NWM, PP>;
   constexpr int BN = 64 * WN;
   constexpr int main_ = 2 * G::STRIDE + G::NST * BN * 64;
   // 8-row-group partial sums + the table of per-column constants + a 32-row x 32-channel fp32 transpose block per wave (statistics)
@@ -99,16 +100,29 @@ __device__ __forceinline__ void wait_vmcnt() {
 // F16OP: the un-quantised / weight-only 3x3 layers on the same pipeline -- fp16 activations (a 64-byte slab row = 32 channels), fp16
 // weights [cout][tap][cin_pad] row-major (tfmq_pack_w_f16), v_mfma_f32_32x32x16_f16, value = scale * acc + bias (k_conv_dma<true>'s
 // arithmetic; the K order differs from its tap-major one, so the two agree to fp32 summation noise, not bit for bit).
-template <int WN, bool F16OP = false, int NWM = 4>
+//
+// PP = true (round 6, 8-wave form only): PING-PONG.  In the one-barrier-per-step loop above the two waves of a SIMD (w and w + 4) run in
+// lockstep: both read fragments, both issue their 20 MFMAs, both issue LDS-DMA -- and an in-order wave issues no MFMA while it does anything
+// else, so the matrix pipe idles through every wave's reads / DMA issue / waits (profiles/r06_kstep_slab.txt: 1280 of ~2400 cycles of a
+// K-step are MFMA time on a SIMD).  Here waves 0-3 and waves 4-7 run the same step HALF A STEP APART, two barriers per step:
+//     load phase     fragment reads of step s, LDS-DMA issue for step s + 3, counted wait for the pieces of step s + 1
+//     compute phase  the 20 MFMAs of step s, nothing else
+// so on every SIMD one wave's compute phase lies beside the other's load phase (the "compute | load" pairing of MI355X_MICROARCH.md,
+// two waves per SIMD).  Visibility: a wave's pieces for step s are issued in its load phase of step s - 3, waited for at the END of its
+// load phase of step s - 1 (in-order vmcnt: everything but what it issued in its last two load phases may still fly) and a barrier closes
+// that phase -- before the first fragment read of step s by either group.  Four weight stages (stage = step & 3): the stage a load phase
+// fills was last read two phases earlier.  Same MFMAs on the same operands in the same order per accumulator: bit-identical.
+template <int WN, bool F16OP = false, int NWM = 4, bool PP = false>
 __global__ __launch_bounds__(64 * 2 * NWM, 2) void k_conv3_slab(SlabP sp) {
-  using G = SlabGeo<NWM>;
+  static_assert(!PP || NWM == 4, "ping-pong needs two waves per SIMD in one block");
+  using G = SlabGeo<NWM, PP>;
   constexpr int NW = G::NW, NT = G::NT, NST = G::NST, NIT = G::NIT, SLAB_BYTES = G::STRIDE;
   constexpr int BM = G::BM, BN = 64 * WN;
   constexpr int BST = BN * 64;                 // bytes of one weight K-step stage
   constexpr int BOFF = 2 * SLAB_BYTES;
   constexpr int NBP = BN / 16;                 // 1-KiB weight pieces per K-step
   constexpr int MAXCH = (NBP + NW - 1) / NW;   // weight pieces a wave moves per K-step
-  __shared__ __attribute__((aligned(1024))) unsigned char lds[slab_lds_bytes<WN, NWM>()];
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[slab_lds_bytes<WN, NWM, PP>()];
 
   const ConvP& p = sp.p;
   const tfmq_conv_desc& d = p.d;
@@ -166,7 +180,11 @@ __global__ __launch_bounds__(64 * 2 * NWM, 2) void k_conv3_slab(SlabP sp) {
   const unsigned lds0 = static_cast<unsigned>(reinterpret_cast<uintptr_t>(lds));
 
   auto issue_slab = [&](int it, int c, int buf) {
-    const unsigned char* src = s_off[it] >= 0 ? xb + static_cast<size_t>(static_cast<unsigned>(s_off[it])) * EB + c * 64 + dcol : padp;
+    int so = s_off[it];
+    // (PP: the offset is made opaque at every use -- the compiler otherwise hoists four 64-bit per-lane source pointers out of the K loop,
+    // spills them, and the reload inside the loop is a scratch load behind an s_waitcnt vmcnt(0): a full drain of the LDS-DMA queue per chunk)
+    if constexpr (PP) asm volatile("" : "+v"(so));
+    const unsigned char* src = so >= 0 ? xb + static_cast<size_t>(static_cast<unsigned>(so)) * EB + c * 64 + dcol : padp;
     glds16(src, lds0 + buf * SLAB_BYTES + __builtin_amdgcn_readfirstlane((it * NW + wid) * 1024));
   };
 
@@ -333,9 +351,102 @@ __global__ __launch_bounds__(64 * 2 * NWM, 2) void k_conv3_slab(SlabP sp) {
       slab_toggle = SLAB_BYTES - slab_toggle;
     }
   };
+  // ---- the ping-pong loop (PP)
+  auto kloop_pp = [&](auto bch_tag) {
+    constexpr int B_CH = decltype(bch_tag)::value;
+    const int grp = wid >> 2;                          // waves w and w + 4 share a SIMD (wave-uniform)
+    auto issue_b = [&](int c, int tap, int stage) {
+      const size_t boff = F16OP ? static_cast<size_t>(tap * p.cin_pad + c * 32) * 2 : static_cast<size_t>(tap * p.chunks + c) * 2048;
+#pragma unroll
+      for (int k = 0; k < B_CH; ++k)
+        glds16_sv(wbase + boff, b_off[k], lds0 + BOFF + stage * BST + __builtin_amdgcn_readfirstlane((wid + NW * k) * 1024));
+    };
+    int pos = 0;
+    auto step = [&](int c, auto tap_tag) {
+      constexpr int TAP = decltype(tap_tag)::value;
+      // ---------------- load phase
+      constexpr int KH = TAP / 3, KW = TAP % 3;
+      const int toff = KH * SW + KW;
+      int a_rel[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int srow = srow0[i] + toff;
+        const int ar = (srow << 6) + (((h ^ (srow >> 2)) & 3) << 4);
+        a_rel[i] = ar ^ slab_toggle;                   // 32 KiB buffers toggle by XOR
+      }
+      const unsigned char* sb = lds + BOFF + (pos & 3) * BST;
+      v4i af[2][2], bf[2][WN];
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) af[ks][i] = *reinterpret_cast<const v4i*>(lds + (a_rel[i] ^ (ks << 5)));
+#pragma unroll
+        for (int j = 0; j < WN; ++j) bf[ks][j] = *reinterpret_cast<const v4i*>(sb + ((b_rel ^ (ks << 5)) + j * 2048));
+      }
+      const bool more = pos + 3 < p.nsteps;
+      if (more) {
+        if constexpr (TAP + 3 < 9) issue_b(c, TAP + 3, (pos + 3) & 3);
+        else issue_b(c + 1, TAP + 3 - 9, (pos + 3) & 3);
+      }
+      if constexpr (TAP < NIT) issue_slab(TAP, c + 1 < p.chunks ? c + 1 : 0, ((c + 1) & 1));
+      // may still fly: what this phase issued and what the previous load phase issued (weights of steps s + 3, s + 2; a slab piece each at
+      // taps 0 .. NIT-1).  Everything older -- the weights of step s + 1 among it -- has landed.  The last steps simply drain.
+      constexpr int X2 = (TAP < NIT ? 1 : 0) + ((TAP >= 1 && TAP <= NIT) ? 1 : 0);
+      if (more) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(2 * B_CH + X2) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      // ---------------- compute phase
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < WN; ++j) {
+            if constexpr (F16OP) {
+              typedef _Float16 v8h_t __attribute__((ext_vector_type(8)));
+              typedef float v16f_t __attribute__((ext_vector_type(16)));
+              v16f_t& af32 = *reinterpret_cast<v16f_t*>(&acc[i][j]);
+              af32 = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<v8h_t*>(&bf[ks][j]), *reinterpret_cast<v8h_t*>(&af[ks][i]), af32, 0, 0, 0);
+            } else {
+              acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(bf[ks][j], af[ks][i], acc[i][j], 0, 0, 0);
+            }
+          }
+      __builtin_amdgcn_sched_barrier(0);
+      ++pos;
+      if (!(grp == 1 && pos == p.nsteps)) asm volatile("s_barrier" ::: "memory");      // (the late group's last compute phase has no partner)
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    // prologue: chunk 0's slab, the weights of steps 0, 1, 2; the slab and step 0 have landed behind the first barrier
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) issue_slab(it, 0, 0);
+    issue_b(0, 0, 0);
+    if (p.nsteps > 1) issue_b(0, 1, 1);
+    if (p.nsteps > 2) issue_b(0, 2, 2);
+    if (p.nsteps > 2) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(2 * B_CH) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    if (grp == 1) asm volatile("s_barrier" ::: "memory");          // half a step behind
+    __builtin_amdgcn_sched_barrier(0);
+    for (int c = 0; c < p.chunks; ++c) {
+      step(c, std::integral_constant<int, 0>{});
+      step(c, std::integral_constant<int, 1>{});
+      step(c, std::integral_constant<int, 2>{});
+      step(c, std::integral_constant<int, 3>{});
+      step(c, std::integral_constant<int, 4>{});
+      step(c, std::integral_constant<int, 5>{});
+      step(c, std::integral_constant<int, 6>{});
+      step(c, std::integral_constant<int, 7>{});
+      step(c, std::integral_constant<int, 8>{});
+      slab_toggle = SLAB_BYTES - slab_toggle;
+    }
+  };
   if (sp.prio && wid >= NW / 2) __builtin_amdgcn_s_setprio(1);
-  if (NBP % NW != 0 && wid < NBP % NW) kloop(std::integral_constant<int, NBP / NW + 1>{});
-  else kloop(std::integral_constant<int, NBP / NW>{});
+  if constexpr (PP) {
+    if (NBP % NW != 0 && wid < NBP % NW) kloop_pp(std::integral_constant<int, NBP / NW + 1>{});
+    else kloop_pp(std::integral_constant<int, NBP / NW>{});
+  } else {
+    if (NBP % NW != 0 && wid < NBP % NW) kloop(std::integral_constant<int, NBP / NW + 1>{});
+    else kloop(std::integral_constant<int, NBP / NW>{});
+  }
   SLAB_MARK(1);
 #ifdef TFMQ_PHASE_TIMERS
   if (p.dbg2 && tid == 0)
@@ -554,6 +665,7 @@ bool launch_conv_slab(tfmq_handle h, ConvP& p, hipStream_t st, bool forced, bool
   sp.prio = prio_env;
   static const int issue_split_env = getenv("TFMQ_SLAB_ISSUE_SPLIT") ? atoi(getenv("TFMQ_SLAB_ISSUE_SPLIT")) : 0;
   sp.issue_split = issue_split_env;
+  static const int pp_env = getenv("TFMQ_SLAB_PP") ? atoi(getenv("TFMQ_SLAB_PP")) : 1;      // ping-pong K loop of the 8-wave w4a8 form (round 6)
   static const int stats_lds_env = getenv("TFMQ_SLAB_STATS_LDS") ? atoi(getenv("TFMQ_SLAB_STATS_LDS")) : 1;
   sp.stats_lds = stats_lds_env;
   sp.HW = Hv * Wv;
@@ -598,7 +710,9 @@ bool launch_conv_slab(tfmq_handle h, ConvP& p, hipStream_t st, bool forced, bool
     if (WN == 5) hipLaunchKernelGGL((k_conv3_slab<5, true>), grid, dim3(512), 0, st, sp);
     else if (WN == 4) hipLaunchKernelGGL((k_conv3_slab<4, true>), grid, dim3(512), 0, st, sp);
     else hipLaunchKernelGGL((k_conv3_slab<2, true>), grid, dim3(512), 0, st, sp);
-  } else if (WN == 5) hipLaunchKernelGGL((k_conv3_slab<5>), grid, dim3(512), 0, st, sp);
+  } else if (pp_env && WN == 5) hipLaunchKernelGGL((k_conv3_slab<5, false, 4, true>), grid, dim3(512), 0, st, sp);
+  else if (pp_env && WN == 4) hipLaunchKernelGGL((k_conv3_slab<4, false, 4, true>), grid, dim3(512), 0, st, sp);
+  else if (WN == 5) hipLaunchKernelGGL((k_conv3_slab<5>), grid, dim3(512), 0, st, sp);
   else if (WN == 4) hipLaunchKernelGGL((k_conv3_slab<4>), grid, dim3(512), 0, st, sp);
   else hipLaunchKernelGGL((k_conv3_slab<2>), grid, dim3(512), 0, st, sp);
 #ifdef TFMQ_PHASE_TIMERS
