@@ -15,8 +15,9 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-OBJ = os.path.join(HERE, "build")
-LIB = os.path.join(HERE, "libtfmq_hip.so")
+# TFMQ_BUILD_DIR / TFMQ_LIB_OUT: a variant build (diagnostics flags, A/B arms) beside the product library, loaded with TFMQ_LIB_PATH
+OBJ = os.environ.get("TFMQ_BUILD_DIR") or os.path.join(HERE, "build")
+LIB = os.environ.get("TFMQ_LIB_OUT") or os.path.join(HERE, "libtfmq_hip.so")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
          "-Wall", "-Wno-unused-function"] + os.environ.get("TFMQ_EXTRA_HIPCC_FLAGS", "").split()
 # Per-file additions.  VGPR-form MFMA: the softmax works on the score accumulators with VALU instructions, and with

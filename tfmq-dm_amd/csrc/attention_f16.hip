@@ -12,6 +12,10 @@
 #include "common.hpp"
 #include <cstdlib>
 #include <type_traits>
+#ifdef TFMQ_PHASE_TIMERS
+#include <cstdio>
+#include <vector>
+#endif
 
 typedef float v16f __attribute__((ext_vector_type(16)));
 typedef _Float16 v8h __attribute__((ext_vector_type(8)));
@@ -29,6 +33,9 @@ struct AttnHP {
   int B, heads, Tq, Tk, Tks, d;   // Tks: keys per batch item in memory (K rows, V^T row length), >= Tk, % 8 == 0
   float scale;
   int nsl;                        // output slices of 32*NT channels (1 unless 16*NKS > 32*NT: wide heads, see below)
+#ifdef TFMQ_PHASE_TIMERS
+  unsigned long long* dbg;        // diagnostics build: [blocks][2 waves][8] shader cycles per segment of k_attention_d40_pp
+#endif
 };
 
 // NKS = k-steps of the score MFMA (16 channels each), NT = 32-column output tiles: compile-time, so that the MFMA
@@ -1005,6 +1012,14 @@ __global__ __launch_bounds__(512, 2) void k_attention_d40_pp(AttnHP p) {
     if (hh) qf[ksb][qe] = static_cast<_Float16>(-m_run);
   }
 
+#ifdef TFMQ_PHASE_TIMERS
+  // [0] V segment up to its wait, [1] the counted wait, [2] barrier behind the V segment, [3] M segment (MFMA issue), [4] barrier behind it, [5] tiles
+  unsigned long long kacc[6] = {0, 0, 0, 0, 0, 0};
+  unsigned long long kt = clock64();
+#define AKT(i) do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); const unsigned long long t_ = clock64(); kacc[i] += t_ - kt; kt = t_; } while (0)
+#else
+#define AKT(i) do { } while (0)
+#endif
   unsigned pp[16];                 // packed fp16 P of the tile: pp[4 u + e] = keys 16 u + 8 hh + 2 e, +1
   v8h vf[4][2];                    // V^T fragments of the same tile
   v8h kf[2][3];                    // K fragments of the next tile
@@ -1066,6 +1081,18 @@ __global__ __launch_bounds__(512, 2) void k_attention_d40_pp(AttnHP p) {
     if constexpr (!LAST)
       asm volatile("" : "+v"(kf[0][0]), "+v"(kf[0][1]), "+v"(kf[0][2]), "+v"(kf[1][0]), "+v"(kf[1][1]), "+v"(kf[1][2]));
     __builtin_amdgcn_sched_barrier(0);
+#ifdef TFMQ_PHASE_TIMERS
+    AKT(0);
+    if constexpr (COUNTED) {
+      if (slot2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NSLOT) : "memory");
+      else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (NSLOT - 1)) : "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    AKT(1);
+    asm volatile("s_barrier" ::: "memory");
+    AKT(2);
+#else
     if constexpr (DBG & 256) {
     } else if constexpr (COUNTED) {
       if (slot2) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(2 * NSLOT) : "memory");
@@ -1073,6 +1100,7 @@ __global__ __launch_bounds__(512, 2) void k_attention_d40_pp(AttnHP p) {
     } else {
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     }
+#endif
     __builtin_amdgcn_sched_barrier(0);
   };
   // ---- M segment of tile t: S(t+1) = K(t+1) Q^T into sc (its old content is spent), O += V^T(t) P(t)
@@ -1103,9 +1131,17 @@ __global__ __launch_bounds__(512, 2) void k_attention_d40_pp(AttnHP p) {
       }
     }
     __builtin_amdgcn_sched_barrier(0);
+#ifdef TFMQ_PHASE_TIMERS
+    asm volatile("" : "+v"(o[0]), "+v"(o[1]));
+    AKT(3);
+#endif
     if constexpr (!(DBG & 256)) {
       if (tail_barrier) asm volatile("s_barrier" ::: "memory");
     }
+#ifdef TFMQ_PHASE_TIMERS
+    AKT(4);
+    kacc[5] += 1;
+#endif
     __builtin_amdgcn_sched_barrier(0);
   };
   using I0 = std::integral_constant<int, 0>;
@@ -1133,6 +1169,10 @@ __global__ __launch_bounds__(512, 2) void k_attention_d40_pp(AttnHP p) {
   vseg(I2{}, N{}, N{}, N{}, N{}, kp, vp);     mseg(N{}, true);     // t = nt-2
   vseg(I3{}, N{}, N{}, Y{}, N{}, kp, vp);     mseg(Y{}, grp == 0); // t = nt-1: no scores left to compute; the late half's last M segment has no partner
 
+#ifdef TFMQ_PHASE_TIMERS
+  if (p.dbg && (tid == 0 || tid == 256))
+    for (int i = 0; i < 6; ++i) p.dbg[(static_cast<size_t>(blockIdx.x) * 2 + (tid >> 8)) * 8 + i] = kacc[i];
+#endif
   // ---- normalise and store (as k_attention_d40)
   const int qg = q0 + wid * 32 + j;
   float l_run;
@@ -1172,6 +1212,30 @@ static int launch_attn_d40(tfmq_handle h, const AttnHP& p, void* stream) {
     static const int dbgp = getenv("TFMQ_ATTN_DBG") ? atoi(getenv("TFMQ_ATTN_DBG")) : 0;
 #define TFMQ_ABLP(D) if (dbgp == D) { hipLaunchKernelGGL((k_attention_d40_pp<D>), gridp, dim3(512), 0, as_stream(stream), p); TFMQ_LAUNCH_CHECK(h); return TFMQ_OK; }
     TFMQ_ABLP(1) TFMQ_ABLP(2) TFMQ_ABLP(4) TFMQ_ABLP(6) TFMQ_ABLP(16) TFMQ_ABLP(17) TFMQ_ABLP(64) TFMQ_ABLP(256)
+#endif
+#ifdef TFMQ_PHASE_TIMERS
+    {
+      static unsigned long long* dbuf = nullptr;
+      if (!dbuf) (void)hipMalloc(reinterpret_cast<void**>(&dbuf), sizeof(unsigned long long) * 16 * (1u << 16));
+      AttnHP pd = p;
+      pd.dbg = gridp.x <= (1u << 16) ? dbuf : nullptr;
+      hipLaunchKernelGGL((k_attention_d40_pp<0>), gridp, dim3(512), 0, as_stream(stream), pd);
+      if (pd.dbg && getenv("TFMQ_PHASE_PRINT")) {
+        (void)hipStreamSynchronize(as_stream(stream));
+        std::vector<unsigned long long> hb(static_cast<size_t>(gridp.x) * 16);
+        (void)hipMemcpy(hb.data(), dbuf, hb.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+        double a[2][6] = {{0}};
+        for (unsigned i = 0; i < gridp.x; ++i)
+          for (int g = 0; g < 2; ++g)
+            for (int q = 0; q < 6; ++q) a[g][q] += double(hb[(static_cast<size_t>(i) * 2 + g) * 8 + q]);
+        const double n0 = a[0][5] > 0 ? a[0][5] : 1, n1 = a[1][5] > 0 ? a[1][5] : 1;
+        fprintf(stderr, "[attention_d40_pp B%d h%d T%d] per key tile, shader cycles, wave 0 | wave 4: V segment %.0f | %.0f, vmcnt wait %.0f | %.0f, barrier (V) %.0f | %.0f, M segment %.0f | %.0f, barrier (M) %.0f | %.0f = %.0f | %.0f\n",
+                p.B, p.heads, p.Tq, a[0][0] / n0, a[1][0] / n1, a[0][1] / n0, a[1][1] / n1, a[0][2] / n0, a[1][2] / n1, a[0][3] / n0, a[1][3] / n1, a[0][4] / n0, a[1][4] / n1,
+                (a[0][0] + a[0][1] + a[0][2] + a[0][3] + a[0][4]) / n0, (a[1][0] + a[1][1] + a[1][2] + a[1][3] + a[1][4]) / n1);
+      }
+      TFMQ_LAUNCH_CHECK(h);
+      return TFMQ_OK;
+    }
 #endif
     hipLaunchKernelGGL((k_attention_d40_pp<0>), gridp, dim3(512), 0, as_stream(stream), p);
     TFMQ_LAUNCH_CHECK(h);

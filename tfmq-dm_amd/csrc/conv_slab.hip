@@ -392,8 +392,19 @@ __global__ __launch_bounds__(64 * 2 * NWM, 2) void k_conv3_slab(SlabP sp) {
       // may still fly: what this phase issued and what the previous load phase issued (weights of steps s + 3, s + 2; a slab piece each at
       // taps 0 .. NIT-1).  Everything older -- the weights of step s + 1 among it -- has landed.  The last steps simply drain.
       constexpr int X2 = (TAP < NIT ? 1 : 0) + ((TAP >= 1 && TAP <= NIT) ? 1 : 0);
+#ifdef TFMQ_PHASE_TIMERS
+      // where a wave's step goes (wave 0 = early half, wave 4 = late half): [0] fragment reads + DMA issue until the fragments are there,
+      // [1] counted vmcnt wait, [2] barrier closing the load phase, [3] MFMA issue, [4] barrier closing the compute phase, [6] steps
+      SKT(0);
+      if (more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * B_CH + X2) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      SKT(1);
+      asm volatile("s_barrier" ::: "memory");
+      SKT(2);
+#else
       if (more) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(2 * B_CH + X2) : "memory");
       else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
       __builtin_amdgcn_sched_barrier(0);
       // ---------------- compute phase
 #pragma unroll
@@ -413,7 +424,15 @@ __global__ __launch_bounds__(64 * 2 * NWM, 2) void k_conv3_slab(SlabP sp) {
           }
       __builtin_amdgcn_sched_barrier(0);
       ++pos;
+#ifdef TFMQ_PHASE_TIMERS
+      asm volatile("" : "+v"(acc[0][0]), "+v"(acc[1][WN - 1]));
+      SKT(3);
+#endif
       if (!(grp == 1 && pos == p.nsteps)) asm volatile("s_barrier" ::: "memory");      // (the late group's last compute phase has no partner)
+#ifdef TFMQ_PHASE_TIMERS
+      SKT(4);
+      kacc[6] += 1;
+#endif
       __builtin_amdgcn_sched_barrier(0);
     };
     // prologue: chunk 0's slab, the weights of steps 0, 1, 2; the slab and step 0 have landed behind the first barrier
@@ -451,6 +470,8 @@ __global__ __launch_bounds__(64 * 2 * NWM, 2) void k_conv3_slab(SlabP sp) {
 #ifdef TFMQ_PHASE_TIMERS
   if (p.dbg2 && tid == 0)
     for (int i = 0; i < 7; ++i) p.dbg2[static_cast<size_t>(blockIdx.x) * 16 + i] = kacc[i];
+  if (PP && p.dbg2 && tid == 256)        // the late half's wave 4: rows behind the 65536 block rows
+    for (int i = 0; i < 7; ++i) p.dbg2[static_cast<size_t>(65536 + blockIdx.x) * 16 + i] = kacc[i];
   unsigned long long et0 = clock64();
 #endif
 
@@ -695,7 +716,7 @@ bool launch_conv_slab(tfmq_handle h, ConvP& p, hipStream_t st, bool forced, bool
   if (!dbuf) (void)hipMalloc(reinterpret_cast<void**>(&dbuf), sizeof(unsigned long long) * 4 * (1u << 16));
   sp.p.dbg = grid.x <= (1u << 16) ? dbuf : nullptr;
   static unsigned long long* dbuf3 = nullptr;
-  if (!dbuf3) (void)hipMalloc(reinterpret_cast<void**>(&dbuf3), sizeof(unsigned long long) * 16 * (1u << 16));
+  if (!dbuf3) (void)hipMalloc(reinterpret_cast<void**>(&dbuf3), sizeof(unsigned long long) * 16 * (2u << 16));
   sp.p.dbg2 = grid.x <= (1u << 16) ? dbuf3 : nullptr;
 #endif
   if (half_m) {
@@ -739,6 +760,17 @@ bool launch_conv_slab(tfmq_handle h, ConvP& p, hipStream_t st, bool forced, bool
       fprintf(stderr, "[slab %dx%dx%d Cin%d Cout%d] epilogue of wave 0, shader cycles per block: table + barriers %.0f, (i, j) loop %.0f, store drain %.0f\n",
               d.B, d.H, d.W, d.Cin, d.Cout, es[0] / grid.x, es[1] / grid.x, es[2] / grid.x);
       const double stn = ks[6] > 0 ? ks[6] : 1;
+      if (pp_env && WN >= 4 && !half_m && !f16) {
+        std::vector<unsigned long long> kb2(static_cast<size_t>(grid.x) * 16);
+        (void)hipMemcpy(kb2.data(), dbuf3 + static_cast<size_t>(65536) * 16, kb2.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+        double k2[7] = {0, 0, 0, 0, 0, 0, 0};
+        for (unsigned i = 0; i < grid.x; ++i)
+          for (int q = 0; q < 7; ++q) k2[q] += double(kb2[i * 16 + q]);
+        const double s2 = k2[6] > 0 ? k2[6] : 1;
+        fprintf(stderr, "[slab %dx%dx%d Cin%d Cout%d] PING-PONG step, shader cycles, wave 0 | wave 4: reads + DMA issue %.0f | %.0f, vmcnt wait %.0f | %.0f, barrier (load phase) %.0f | %.0f, MFMA issue %.0f | %.0f, barrier (compute phase) %.0f | %.0f = %.0f | %.0f per step\n",
+                d.B, d.H, d.W, d.Cin, d.Cout, ks[0] / stn, k2[0] / s2, ks[1] / stn, k2[1] / s2, ks[2] / stn, k2[2] / s2, ks[3] / stn, k2[3] / s2, ks[4] / stn, k2[4] / s2,
+                (ks[0] + ks[1] + ks[2] + ks[3] + ks[4]) / stn, (k2[0] + k2[1] + k2[2] + k2[3] + k2[4]) / s2);
+      } else
       fprintf(stderr, "[slab %dx%dx%d Cin%d Cout%d] K-step of wave 0, shader cycles: vmcnt wait %.0f, barrier %.0f, fragment reads %.0f, MFMA issue (first half) %.0f, DMA issue %.0f, MFMA issue (second half) %.0f = %.0f per step\n",
               d.B, d.H, d.W, d.Cin, d.Cout, ks[0] / stn, ks[1] / stn, ks[2] / stn, ks[3] / stn, ks[4] / stn, ks[5] / stn, (ks[0] + ks[1] + ks[2] + ks[3] + ks[4] + ks[5]) / stn);
     }
