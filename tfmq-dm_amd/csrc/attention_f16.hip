@@ -429,14 +429,17 @@ __device__ __forceinline__ void acc_scale32(v16f& o0, v16f& o1, float alpha) {
                : "+{a[0:15]}"(o0), "+{a[16:31]}"(o1), "=&v"(tmp)
                : "v"(alpha));
 }
-template <int NW, int DBG = 0, int OCC = 2, bool ACC = false>
+// COMPACT (round 6): the two constant pieces live in zero rows 41 and 61 of V^T buffer 0 (rows the DMA never writes; as V^T rows they
+// only feed output channels 41 and 61, which are not stored) instead of a 3 KiB region of their own: 53 248 bytes of LDS, so that THREE
+// 4-wave blocks share a CU (168 VGPRs allow three waves per SIMD; 56 320 bytes allowed two blocks).
+template <int NW, int DBG = 0, int OCC = 2, bool ACC = false, bool COMPACT = false>
 __global__ __launch_bounds__(64 * NW, OCC) void k_attention_d40(AttnHP p) {
   constexpr int NTH = 64 * NW, QB = 32 * NW;
   constexpr int NSLOT = (10 + NW - 1) / NW, NFULL = 10 % NW;      // DMA wave-instructions per wave: NSLOT for waves < NFULL, else NSLOT - 1
   constexpr int KROW = 80, KSUB = 32 * KROW, KBUF = 64 * KROW;   // 2560, 5120
-  constexpr int ONES = 4 * KBUF;                                // constant pieces at ONES, ONES + KSUB
-  constexpr int VBASE = 23552, VROW = 128, VBUF = 64 * VROW;    // 8192
-  constexpr int LDS_BYTES = VBASE + 4 * VBUF;                   // 56320
+  constexpr int VBASE = COMPACT ? 4 * KBUF : 23552, VROW = 128, VBUF = 64 * VROW;    // 8192
+  constexpr int ONES = COMPACT ? VBASE + 41 * VROW : 4 * KBUF;  // constant pieces at ONES, ONES + KSUB (COMPACT: rows 41 and 61 of V^T buffer 0)
+  constexpr int LDS_BYTES = VBASE + 4 * VBUF;                   // 56320 (COMPACT: 53248)
   constexpr int NE1 = 20;                                       // exponentials taken before the rescale decision
   __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES];
 
@@ -1205,7 +1208,7 @@ __global__ __launch_bounds__(512, 2) void k_attention_d40_pp(AttnHP p) {
 
 static int launch_attn_d40(tfmq_handle h, const AttnHP& p, void* stream) {
   static const int nw = getenv("TFMQ_ATTN_PIPE_NW") ? atoi(getenv("TFMQ_ATTN_PIPE_NW")) : 4;
-  static const int pp = getenv("TFMQ_ATTN_PP") ? atoi(getenv("TFMQ_ATTN_PP")) : 1;        // ping-pong form (round 6) where its 256-query blocks fit
+  static const int pp = getenv("TFMQ_ATTN_PP") ? atoi(getenv("TFMQ_ATTN_PP")) : 0;        // ping-pong form (round 6; measured 8 % SLOWER: opt-in)
   if (pp && p.Tq % 256 == 0) {
     dim3 gridp(static_cast<unsigned>(p.Tq / 256) * p.B * p.heads);
 #ifdef TFMQ_ATTN_ABLATE
@@ -1260,7 +1263,9 @@ static int launch_attn_d40(tfmq_handle h, const AttnHP& p, void* stream) {
   if (dbg == 1000) { hipLaunchKernelGGL((k_attention_d40<4, 0, 3>), grid, dim3(256), 0, as_stream(stream), p); TFMQ_LAUNCH_CHECK(h); return TFMQ_OK; }
 #endif
   static const int acc = getenv("TFMQ_ATTN_ACC") ? atoi(getenv("TFMQ_ATTN_ACC")) : 0;
+  static const int lds3 = getenv("TFMQ_ATTN_LDS3") ? atoi(getenv("TFMQ_ATTN_LDS3")) : 1;      // three blocks per CU (round 6)
   if (acc) hipLaunchKernelGGL((k_attention_d40<4, 0, 1, true>), grid, dim3(256), 0, as_stream(stream), p);
+  else if (lds3) hipLaunchKernelGGL((k_attention_d40<4, 0, 2, false, true>), grid, dim3(256), 0, as_stream(stream), p);
   else hipLaunchKernelGGL((k_attention_d40<4>), grid, dim3(256), 0, as_stream(stream), p);
   TFMQ_LAUNCH_CHECK(h);
   return TFMQ_OK;

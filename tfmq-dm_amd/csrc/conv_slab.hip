@@ -61,7 +61,7 @@ struct SlabP {
 
 // Geometry of a variant: NWM waves along M (4: 256-pixel tiles, 8 waves, one block per CU; 2: 128-pixel tiles, 4 waves, two per CU)
 // PP (round 6): the two waves of a SIMD in barrier-enforced anti-phase (see the kernel), FOUR weight stages
-template <int NWM, bool PP = false>
+template <int NWM, int PP = 0>
 struct SlabGeo {
   static constexpr int NW = 2 * NWM;                 // waves per block
   static constexpr int NT = 64 * NW;                 // threads
@@ -82,7 +82,7 @@ struct SlabGeo {
 constexpr int SLAB_T_ROW = 36;                       // dwords per transposed row: 32 channels + 4
 constexpr int SLAB_T_BYTES = 32 * SLAB_T_ROW * 4;    // per wave
 
-template <int WN, int NWM, bool PP = false>
+template <int WN, int NWM, int PP = 0>
 __host__ __device__ constexpr int slab_lds_bytes() {
   using G = SlabGeo<NWM, PP>;
   constexpr int BN = 64 * WN;
@@ -112,7 +112,7 @@ __device__ __forceinline__ void wait_vmcnt() {
 // load phase of step s - 1 (in-order vmcnt: everything but what it issued in its last two load phases may still fly) and a barrier closes
 // that phase -- before the first fragment read of step s by either group.  Four weight stages (stage = step & 3): the stage a load phase
 // fills was last read two phases earlier.  Same MFMAs on the same operands in the same order per accumulator: bit-identical.
-template <int WN, bool F16OP = false, int NWM = 4, bool PP = false>
+template <int WN, bool F16OP = false, int NWM = 4, int PP = 0>
 __global__ __launch_bounds__(64 * 2 * NWM, 2) void k_conv3_slab(SlabP sp) {
   static_assert(!PP || NWM == 4, "ping-pong needs two waves per SIMD in one block");
   using G = SlabGeo<NWM, PP>;
@@ -384,25 +384,43 @@ __global__ __launch_bounds__(64 * 2 * NWM, 2) void k_conv3_slab(SlabP sp) {
         for (int j = 0; j < WN; ++j) bf[ks][j] = *reinterpret_cast<const v4i*>(sb + ((b_rel ^ (ks << 5)) + j * 2048));
       }
       const bool more = pos + 3 < p.nsteps;
-      if (more) {
-        if constexpr (TAP + 3 < 9) issue_b(c, TAP + 3, (pos + 3) & 3);
-        else issue_b(c + 1, TAP + 3 - 9, (pos + 3) & 3);
+      // PP == 1: this wave's LDS-DMA pieces (weights of step s + 3, a slab piece at taps 0 .. NIT-1) are issued HERE, in the load phase.
+      // PP == 2: they are issued between the LAST MFMAs of the compute phase (profiles/r06_pp_phases.txt: with the issue in the load phase
+      // that phase takes ~1000 cycles beside a 680-cycle compute phase, whose wave then waits ~300 cycles at the barrier).
+      auto issue_piece = [&](int k) {        // piece k of this step's batch: weights 0 .. B_CH-1, then the slab piece
+        if (k < B_CH) {
+          if (more) {
+            const int cc = TAP + 3 < 9 ? c : c + 1, tt = TAP + 3 < 9 ? TAP + 3 : TAP + 3 - 9;
+            const size_t boff = F16OP ? static_cast<size_t>(tt * p.cin_pad + cc * 32) * 2 : static_cast<size_t>(tt * p.chunks + cc) * 2048;
+            glds16_sv(wbase + boff, b_off[k], lds0 + BOFF + ((pos + 3) & 3) * BST + __builtin_amdgcn_readfirstlane((wid + NW * k) * 1024));
+          }
+        } else {
+          if constexpr (TAP < NIT) issue_slab(TAP, c + 1 < p.chunks ? c + 1 : 0, ((c + 1) & 1));
+        }
+      };
+      if constexpr (PP == 1) {
+#pragma unroll
+        for (int k = 0; k <= B_CH; ++k) issue_piece(k);
       }
-      if constexpr (TAP < NIT) issue_slab(TAP, c + 1 < p.chunks ? c + 1 : 0, ((c + 1) & 1));
-      // may still fly: what this phase issued and what the previous load phase issued (weights of steps s + 3, s + 2; a slab piece each at
-      // taps 0 .. NIT-1).  Everything older -- the weights of step s + 1 among it -- has landed.  The last steps simply drain.
-      constexpr int X2 = (TAP < NIT ? 1 : 0) + ((TAP >= 1 && TAP <= NIT) ? 1 : 0);
+      // PP == 1 -- may still fly: what this phase issued and what the previous load phase issued (weights of steps s + 3, s + 2; a slab
+      // piece each at taps 0 .. NIT-1).  Everything older -- the weights of step s + 1 among it -- has landed.  The last steps simply drain.
+      // PP == 2 -- may still fly: the batch of the previous compute phase (weights of step s + 2, its slab piece) and the slab piece of the
+      // one before (issued behind the weights of step s + 1, which must have landed).
+      constexpr int X2 = PP == 1 ? (TAP < NIT ? 1 : 0) + ((TAP >= 1 && TAP <= NIT) ? 1 : 0)
+                                 : (((TAP + 8) % 9) < NIT ? 1 : 0) + (((TAP + 7) % 9) < NIT ? 1 : 0);
+      constexpr int NB2 = PP == 1 ? 2 * B_CH : B_CH;
+      const bool counted = PP == 1 ? more : (pos + 2 < p.nsteps && pos >= 2);       // (PP == 2: the first two steps wait for the prologue's batches)
 #ifdef TFMQ_PHASE_TIMERS
       // where a wave's step goes (wave 0 = early half, wave 4 = late half): [0] fragment reads + DMA issue until the fragments are there,
       // [1] counted vmcnt wait, [2] barrier closing the load phase, [3] MFMA issue, [4] barrier closing the compute phase, [6] steps
       SKT(0);
-      if (more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * B_CH + X2) : "memory");
+      if (counted) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NB2 + X2) : "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       SKT(1);
       asm volatile("s_barrier" ::: "memory");
       SKT(2);
 #else
-      if (more) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(2 * B_CH + X2) : "memory");
+      if (counted) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(NB2 + X2) : "memory");
       else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
 #endif
       __builtin_amdgcn_sched_barrier(0);
@@ -413,6 +431,17 @@ __global__ __launch_bounds__(64 * 2 * NWM, 2) void k_conv3_slab(SlabP sp) {
         for (int i = 0; i < 2; ++i)
 #pragma unroll
           for (int j = 0; j < WN; ++j) {
+            if constexpr (PP == 2) {
+              // one piece in front of each of the last MFMAs but two: the piece's issue (SALU M0 moves + the TA's ~26 cycles) runs under the
+              // 32 matrix-pipe cycles of the MFMA issued before it
+              constexpr int NP = B_CH + 1;
+              const int q = (ks * 2 + i) * WN + j, first = 4 * WN - 2 * NP;
+              if (q >= first && ((q - first) & 1) == 0) {
+                __builtin_amdgcn_sched_barrier(0);
+                issue_piece((q - first) >> 1);
+                __builtin_amdgcn_sched_barrier(0);
+              }
+            }
             if constexpr (F16OP) {
               typedef _Float16 v8h_t __attribute__((ext_vector_type(8)));
               typedef float v16f_t __attribute__((ext_vector_type(16)));
@@ -731,8 +760,10 @@ bool launch_conv_slab(tfmq_handle h, ConvP& p, hipStream_t st, bool forced, bool
     if (WN == 5) hipLaunchKernelGGL((k_conv3_slab<5, true>), grid, dim3(512), 0, st, sp);
     else if (WN == 4) hipLaunchKernelGGL((k_conv3_slab<4, true>), grid, dim3(512), 0, st, sp);
     else hipLaunchKernelGGL((k_conv3_slab<2, true>), grid, dim3(512), 0, st, sp);
-  } else if (pp_env && WN == 5) hipLaunchKernelGGL((k_conv3_slab<5, false, 4, true>), grid, dim3(512), 0, st, sp);
-  else if (pp_env && WN == 4) hipLaunchKernelGGL((k_conv3_slab<4, false, 4, true>), grid, dim3(512), 0, st, sp);
+  } else if (pp_env == 2 && WN == 5) hipLaunchKernelGGL((k_conv3_slab<5, false, 4, 2>), grid, dim3(512), 0, st, sp);
+  else if (pp_env == 2 && WN == 4) hipLaunchKernelGGL((k_conv3_slab<4, false, 4, 2>), grid, dim3(512), 0, st, sp);
+  else if (pp_env && WN == 5) hipLaunchKernelGGL((k_conv3_slab<5, false, 4, 1>), grid, dim3(512), 0, st, sp);
+  else if (pp_env && WN == 4) hipLaunchKernelGGL((k_conv3_slab<4, false, 4, 1>), grid, dim3(512), 0, st, sp);
   else if (WN == 5) hipLaunchKernelGGL((k_conv3_slab<5>), grid, dim3(512), 0, st, sp);
   else if (WN == 4) hipLaunchKernelGGL((k_conv3_slab<4>), grid, dim3(512), 0, st, sp);
   else hipLaunchKernelGGL((k_conv3_slab<2>), grid, dim3(512), 0, st, sp);
