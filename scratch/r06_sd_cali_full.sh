@@ -5,9 +5,9 @@
 R=${GRAFT_REPO_ROOT:-$PWD}; O=$R/gpurun_out/r06; mkdir -p $O; cd $R
 export TMPDIR=/tmp
 case "$PART" in
-  a) ONLY="tib,model.input_blocks,model.middle_block";;
+  a) ONLY="tib,model.input_blocks";;
   b) ONLY="model.output_blocks.0.,model.output_blocks.1.,model.output_blocks.2.,model.output_blocks.3.,model.output_blocks.4.,model.output_blocks.5.,model.output_blocks.6.,model.output_blocks.7.";;
-  c) ONLY="model.output_blocks.8.,model.output_blocks.9.,model.output_blocks.10.,model.output_blocks.11.,model.out.";;
+  c) ONLY="model.middle_block,model.output_blocks.8.,model.output_blocks.9.,model.output_blocks.10.,model.output_blocks.11.,model.out.";;
   *) echo "PART=a|b|c"; exit 2;;
 esac
 ITERS=${ITERS:-20000}
