@@ -215,7 +215,9 @@ typedef struct tfmq_conv_desc {
                                     TFMQ_TILE_SLAB128 (7): the slab kernel on 128-pixel tiles and four waves, two blocks per CU (one block's
                                     epilogue runs under the other's MFMAs; twice the blocks at the 8x8 / 16x16 levels) -- same bits.
                                     (8 was a persistent variant of TFMQ_TILE_DIRECT in round 2 -- measured slower on every shape and
-                                    removed in round 3; the value falls back to the rule) */
+                                    removed in round 3; the value falls back to the rule)
+                                    TFMQ_TILE_DIRECT256 (9; round 6): TFMQ_TILE_DIRECT on 256 x 128 tiles, two blocks per CU (a quarter fewer
+                                    LDS-DMA pieces per MFMA); layers without a residual, else the 128-row form runs -- same bits. */
   int32_t res_f16;               /* != 0: `residual` is an fp16 buffer [B][Ho][Wo][Cout] (a tensor of the fp16 activation stream:
                                     the TFMQ_OUT_F16 output of an earlier launch) */
   const void* x2;                /* tfmq_conv2d_f16, pointwise, x_f16 only; NULL = one source.  Input channels [cin1, Cin) are read
@@ -243,7 +245,7 @@ typedef struct tfmq_conv_desc {
 } tfmq_conv_desc;
 enum { TFMQ_OUT_F32 = 0, TFMQ_OUT_F16 = 1, TFMQ_OUT_GEGLU_Q8 = 2, TFMQ_OUT_Q8 = 3, TFMQ_OUT_GEGLU_Q8_FAST = 4 };
 enum { TFMQ_TILE_AUTO = 0, TFMQ_TILE_128 = 1, TFMQ_TILE_64 = 2, TFMQ_TILE_256 = 3, TFMQ_TILE_128x64 = 4, TFMQ_TILE_SLAB = 5, TFMQ_TILE_DIRECT = 6,
-       TFMQ_TILE_SLAB128 = 7 };
+       TFMQ_TILE_SLAB128 = 7, TFMQ_TILE_DIRECT256 = 9 };
 int tfmq_conv2d_w4a8(tfmq_handle h, const tfmq_conv_desc* d, void* stream);
 int tfmq_conv2d_f16(tfmq_handle h, const tfmq_conv_desc* d, void* stream);
 

@@ -87,7 +87,7 @@ def test_slab_kernel_launch_geometry_rule(lib):
     assert all(ops.slab_ok(desc(r, r), 128) for r in (64, 32, 16, 8, 4)) and ops.slab_ok(desc(32, 32, up=1), 128)
     assert not ops.slab_ok(desc(128, 128), 128)                                        # (1 + 2) * 130 = 390 slab rows > 320
     assert not ops.slab_ok(desc(24, 24), 128)
-    assert set(ops._TILE_NAMES) == {1, 2, 3, 4, 5, 6, 7}
+    assert set(ops._TILE_NAMES) == {1, 2, 3, 4, 5, 6, 7, 9}      # (9: the 256 x 128 form of the register-direct pointwise kernel, round 6)
 
 
 def test_split_k_candidate_rule(lib):

@@ -430,7 +430,7 @@ def test_direct_pointwise_kernel_is_bit_identical_to_the_tile_kernels(ops, T, ci
         if mode.endswith("+stats"):      # the SpatialTransformer's proj_out: GroupNorm statistics of the consumer (DPP sums)
             kw["want_stats"] = True
     outs, stats = [], []
-    for tile in (1, 6):          # the tile kernel and the register-direct pointwise kernel
+    for tile in (1, 6, 9):       # the tile kernel, the register-direct pointwise kernel and its 256 x 128 form (round 6; layers with a residual: the 128-row form)
         ops.set_conv_autotune({})
         orig = _o._tune_conv
         try:
@@ -442,9 +442,9 @@ def test_direct_pointwise_kernel_is_bit_identical_to_the_tile_kernels(ops, T, ci
         finally:
             _o._tune_conv = orig
             ops.set_conv_autotune(None)
-    assert torch.equal(outs[0], outs[1])
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
     if stats:
-        assert torch.equal(stats[0], stats[1])
+        assert torch.equal(stats[0], stats[1]) and torch.equal(stats[0], stats[2])
     if mode == "geglu":     # and against the arithmetic spelled out: x * gelu(gate) of the un-fused projection, then the quantizer
         h = ops.conv2d_w4a8(xq, ops.pack_w4(w.to(DEV), wd.to(DEV), wz.to(DEV), bias=b.to(DEV)), sel)
         ref = ops.geglu(h.reshape(B * T, cout), oq)[0].reshape(B, T, 1, cout // 2)
@@ -467,7 +467,7 @@ def test_direct_kernel_transposed_region_is_bit_identical(ops, B, T, C):
     pw = ops.pack_w4(w.to(DEV), wd.to(DEV), wz.to(DEV), bias=None)
     t0 = 2 * C if (2 * C) % 128 == 0 else 256
     outs = []
-    for tile in (1, 6):
+    for tile in (1, 6, 9):       # (9: the 256 x 128 form of round 6)
         ops.set_conv_autotune({})
         orig = _o._tune_conv
         try:
@@ -477,8 +477,8 @@ def test_direct_kernel_transposed_region_is_bit_identical(ops, B, T, C):
         finally:
             _o._tune_conv = orig
             ops.set_conv_autotune(None)
-    assert torch.equal(outs[0][0], outs[1][0])
-    assert torch.equal(outs[0][1], outs[1][1])
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][0], outs[2][0])
+    assert torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][1], outs[2][1])
 
 
 def test_f16_conv_tile_variants_are_bit_identical(ops):

@@ -66,3 +66,33 @@ def test_fast_geglu_epilogue_within_one_bin(ops, B, T, cin, inner, gain):
         assert torch.equal(exact, ops.conv2d_w4a8(xq, pwp, sel, geglu_oq=osel))
     finally:
         del os.environ["TFMQ_GELU_EXACT"]
+
+
+@pytest.mark.parametrize("B,T,cin,inner", [(2, 1024, 640, 2560), (1, 700, 320, 1280), (3, 256, 128, 192)])
+def test_fast_geglu_on_256_row_tiles_is_bit_identical(ops, B, T, cin, inner):
+    """Round 6: the register-direct pointwise kernel on 256 x 128 tiles (TFMQ_TILE_DIRECT256, two blocks per CU) carries the same
+    consumer-sized GEGLU epilogue: the same int32 sums, the same arithmetic -- the same bins as the 128-row form (ragged last row tile included)."""
+    import tfmq_dm_amd.ops as _o
+    gen = torch.Generator().manual_seed(5 + inner)
+    x = torch.randn(B, T, 1, cin, generator=gen) * 1.3 - 0.2
+    w = torch.randn(2 * inner, cin, 1, 1, generator=gen) * (2.0 / cin ** 0.5)
+    b = torch.randn(2 * inner, generator=gen) * 0.2
+    wd, wz = O.init_channelwise(w, 16, "minmax")
+    ad, az = O.minmax(x, 256)
+    sel = ops.qsel(qtab(ad, az))
+    xq = ops.quantize_act(x.to(DEV), sel)
+    osel = ops.qsel(qtab(0.04, 131.0))
+    perm = ops.geglu_perm(inner)
+    pwp = ops.pack_w4(w[perm].contiguous().to(DEV), wd.reshape(-1)[perm].contiguous().to(DEV),
+                      wz.reshape(-1)[perm].contiguous().to(DEV), bias=b[perm].contiguous().to(DEV))
+    outs = []
+    for tile in (6, 9):
+        ops.set_conv_autotune({})
+        orig = _o._tune_conv
+        try:
+            _o._tune_conv = lambda h, name, kind, d, dsc, t=tile: t
+            outs.append(ops.conv2d_w4a8(xq, pwp, sel, geglu_oq=osel).clone())
+        finally:
+            _o._tune_conv = orig
+            ops.set_conv_autotune(None)
+    assert torch.equal(outs[0], outs[1])

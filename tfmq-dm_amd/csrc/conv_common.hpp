@@ -121,6 +121,6 @@ __device__ __forceinline__ float4 load_res4(const tfmq_conv_desc& d, int m, int 
 // 3x3 / stride 1 / pad 1 w4a8 convolutions on the slab kernel (conv_slab.hip): true when the launch was taken
 bool launch_conv_slab(tfmq_handle h, ConvP& p, hipStream_t st, bool forced, bool f16 = false, bool half_m = false);
 // pointwise w4a8 layers with fp16 / int8 / GEGLU-int8 output on the register-direct-epilogue kernel (conv_lin.hip)
-bool launch_conv_lin(tfmq_handle h, ConvP& p, hipStream_t st);
+bool launch_conv_lin(tfmq_handle h, ConvP& p, hipStream_t st, bool m256 = false);      // m256: 256 x 128 tiles (TFMQ_TILE_DIRECT256), layers without a residual
 // fp16-operand pointwise layers (tfmq_conv2d_f16 with x_f16) on the same kernel
 bool launch_conv_lin_f16(tfmq_handle h, ConvP& p, hipStream_t st);

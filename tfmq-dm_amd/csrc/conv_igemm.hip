@@ -1070,8 +1070,8 @@ static int launch_conv(tfmq_handle h, const tfmq_conv_desc* dd, void* stream) {
   TFMQ_CHECK_ARG(h, !d.x2, "conv2d: a second input source (x2) is only read by the fp16 pointwise kernel (tfmq_conv_desc.x2)");
   if constexpr (INT8) {
     // token Linears / 1x1 convs writing fp16, int8 or GEGLU-int8: the register-direct-epilogue kernel (conv_lin.hip)
-    if ((d.tile == TFMQ_TILE_AUTO || d.tile == TFMQ_TILE_DIRECT) && d.wmeta && d.wscale && d.aq.qtable &&
-        launch_conv_lin(h, p, as_stream(stream))) {
+    if ((d.tile == TFMQ_TILE_AUTO || d.tile == TFMQ_TILE_DIRECT || d.tile == TFMQ_TILE_DIRECT256) && d.wmeta && d.wscale && d.aq.qtable &&
+        launch_conv_lin(h, p, as_stream(stream), d.tile == TFMQ_TILE_DIRECT256)) {
       TFMQ_LAUNCH_CHECK(h);
       return TFMQ_OK;
     }

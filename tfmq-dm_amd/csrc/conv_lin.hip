@@ -52,8 +52,8 @@ template <int MODE> constexpr bool lin_is_geglu = MODE == LIN_GEGLU || MODE == L
 // (scale = 1 unless the weight-only integer grid carries one), the arithmetic of k_conv_dma<true>.
 constexpr int LIN_STG_ROW_Q8 = 80;        // int8 rows: 64 + 16
 constexpr int LIN_STG_ROW = 144;          // bytes per staged pixel row: 64 fp16 + 16 (rows 16 bytes apart in the banks: conflict-free)
-template <int MODE, int PHASE = 0, bool F16OP = false>
-__device__ __forceinline__ void lin_epilogue(const ConvP& p, v16i (&acc)[2][2], const float* cs, uint4 (&rres)[2][2][2], bool has_res,
+template <int MODE, int PHASE = 0, bool F16OP = false, int NI = 2>
+__device__ __forceinline__ void lin_epilogue(const ConvP& p, v16i (&acc)[NI][2], const float* cs, uint4 (&rres)[NI][2][2], bool has_res,
                                              int m0, int n0, int wm, int wn, int lane, float2 oqp, float2* ldsP = nullptr,
                                              unsigned char* stg = nullptr) {
   constexpr int BN = 128;
@@ -84,8 +84,8 @@ __device__ __forceinline__ void lin_epilogue(const ConvP& p, v16i (&acc)[2][2], 
     constexpr bool EX = decltype(exact_div)::value;
     const QuantP qP = make_quantp(oqp);
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int m = m0 + (wm * 2 + i) * 32 + (lane & 31);
+    for (int i = 0; i < NI; ++i) {
+      const int m = m0 + (wm * NI + i) * 32 + (lane & 31);
       const bool mok = m < p.M;
       const int thw = d.Ho * d.Wo;
       const int tb = transposed ? m / thw : 0, tt = m - tb * thw;
@@ -160,7 +160,7 @@ __device__ __forceinline__ void lin_epilogue(const ConvP& p, v16i (&acc)[2][2], 
               // GroupNorm statistics of the consumer: per channel the 8-row group's (sum, sum of squares) of the fp32 values,
               // DPP sums over the 8 lanes of a pixel-row group in the canonical order (conv_common.hpp: group8_sum)
               const bool ok = mok && n < d.Cout;
-              const int grp = (wm * 2 + i) * 4 + ((lane & 31) >> 3);
+              const int grp = (wm * NI + i) * 4 + ((lane & 31) >> 3);
 #pragma unroll
               for (int e = 0; e < 4; ++e) {
                 const float x0 = ok ? v[e].x : 0.0f, x1 = ok ? v[e].y : 0.0f;
@@ -226,7 +226,7 @@ __device__ __forceinline__ void lin_epilogue(const ConvP& p, v16i (&acc)[2][2], 
             for (int t = 0; t < 4; ++t) {
               const int row = t * 8 + (lane >> 3), pc = lane & 7;
               const uint4 w = *reinterpret_cast<const uint4*>(stg + row * LIN_STG_ROW + pc * 16);
-              const int m2 = m0 + (wm * 2 + i) * 32 + row, n2 = n0 + wn * 64 + pc * 8;
+              const int m2 = m0 + (wm * NI + i) * 32 + row, n2 = n0 + wn * 64 + pc * 8;
               if (m2 < p.M && n2 < d.Cout)
                 *reinterpret_cast<uint4*>(reinterpret_cast<__half*>(d.y) + static_cast<size_t>(m2) * d.ldy + d.y_coff + n2) = w;
             }
@@ -240,7 +240,7 @@ __device__ __forceinline__ void lin_epilogue(const ConvP& p, v16i (&acc)[2][2], 
             for (int t = 0; t < 2; ++t) {
               const int row = t * 16 + (lane >> 2), pc = lane & 3;
               const uint4 w = *reinterpret_cast<const uint4*>(stg + row * LIN_STG_ROW_Q8 + pc * 16);
-              const int m2 = m0 + (wm * 2 + i) * 32 + row, n2 = n0 + wn * 64 + pc * 16;
+              const int m2 = m0 + (wm * NI + i) * 32 + row, n2 = n0 + wn * 64 + pc * 16;
               if (m2 < p.M && n2 < d.Cout) *reinterpret_cast<uint4*>(d.yq + static_cast<size_t>(m2) * d.Cout + n2) = w;
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -277,12 +277,16 @@ __device__ __forceinline__ void lin_load_res(const ConvP& p, uint4 (&rres)[2][2]
   }
 }
 
-template <int MODE, bool F16OP = false>
-__global__ __launch_bounds__(256, 3) void k_lin_direct(ConvP p) {
-  constexpr int BM = 128, BN = 128;
+// NI (round 6): 32-row tiles per wave along M.  NI = 2: 128 x 128 output tiles, three blocks per CU (the form of rounds 2-5).  NI = 4: 256 x 128
+// tiles, two blocks per CU -- 24 KB of operands per 64 MFMAs of a block instead of 16 KB per 32: a quarter fewer LDS-DMA pieces per MFMA on
+// K loops that run at the DMA issue rate of their waves (profiles/r06_kstep_lin_direct.txt); layers WITHOUT a residual only (the residual
+// octets of a 64 x 64 ... 128 x 64 wave tile would not fit beside 128 accumulator registers).  Same int32 sums, same epilogue: same bits.
+template <int MODE, bool F16OP = false, int NI = 2>
+__global__ __launch_bounds__(256, NI == 2 ? 3 : 2) void k_lin_direct(ConvP p) {
+  constexpr int BM = 64 * NI, BN = 128;
   constexpr int STAGE = (BM + BN) * 64;
   constexpr int NST = 3;
-  constexpr int NLOAD = 4;                       // DMA pieces per wave per K-step: 2 of A, 2 of B
+  constexpr int NLOAD = NI + 2;                  // DMA pieces per wave per K-step: NI of A, 2 of B
   constexpr int CONST_OFF = NST * STAGE;
   __shared__ __attribute__((aligned(1024))) unsigned char lds[NST * STAGE + 3 * BN * 4];
 
@@ -313,17 +317,24 @@ __global__ __launch_bounds__(256, 3) void k_lin_direct(ConvP p) {
   const unsigned lds0 = static_cast<unsigned>(reinterpret_cast<uintptr_t>(lds));
   const unsigned char* xb = static_cast<const unsigned char*>(d.x);
   const int dcol = ((lane & 3) ^ ((lane >> 4) & 3)) * 16;
-  const unsigned char* a_ptr[2];
-  const unsigned char* a2_ptr[2] = {nullptr, nullptr};
+  const unsigned char* a_ptr[NI];
+  const unsigned char* a2_ptr[NI];
   const unsigned char* b_ptr[2];
+  bool a_live[NI];
 #pragma unroll
-  for (int it = 0; it < 2; ++it) {
-    const int piece = wid * 2 + it;
+  for (int it = 0; it < NI; ++it) {
+    const int piece = wid * NI + it;
     const int m = m0 + piece * 16 + (lane >> 2);
+    a_live[it] = m < p.M;
     a_ptr[it] = m < p.M ? xb + static_cast<size_t>(m) * (F16OP && d.x2 ? d.cin1 : d.Cin) * (F16OP ? 2 : 1) + dcol : p.pad_table + dcol;
+    a2_ptr[it] = nullptr;
     if constexpr (F16OP) {         // second source of a virtual channel concat (tfmq_conv_desc.x2): K-steps >= cin1 / 32 read it
       a2_ptr[it] = (d.x2 && m < p.M) ? static_cast<const unsigned char*>(d.x2) + static_cast<size_t>(m) * (d.Cin - d.cin1) * 2 + dcol : a_ptr[it];
     }
+  }
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int piece = wid * 2 + it;
     int n = n0 + piece * 16 + (lane >> 2);
     if constexpr (F16OP) {           // fp16 weights [cout][cin_pad] row-major (tfmq_pack_w_f16), fp16 activations: 32 channels per K-step
       n = n < d.Cout ? n : d.Cout - 1;
@@ -334,16 +345,13 @@ __global__ __launch_bounds__(256, 3) void k_lin_direct(ConvP p) {
     }
   }
   constexpr size_t BSTEP = F16OP ? 64 : 2048;
-  const bool a_live0 = m0 + (wid * 2) * 16 + (lane >> 2) < p.M, a_live1 = m0 + (wid * 2 + 1) * 16 + (lane >> 2) < p.M;
   const int s_split = (F16OP && d.x2) ? d.cin1 / 32 : (1 << 30);
   auto issue = [&](int s, int stage) {
     const unsigned sbase = lds0 + stage * STAGE;
-    if (F16OP && s >= s_split) {
-      glds16(a2_ptr[0] + (a_live0 ? (s - s_split) * 64 : 0), sbase + __builtin_amdgcn_readfirstlane((wid * 2) * 1024));
-      glds16(a2_ptr[1] + (a_live1 ? (s - s_split) * 64 : 0), sbase + __builtin_amdgcn_readfirstlane((wid * 2 + 1) * 1024));
-    } else {
-      glds16(a_ptr[0] + (a_live0 ? s * 64 : 0), sbase + __builtin_amdgcn_readfirstlane((wid * 2) * 1024));
-      glds16(a_ptr[1] + (a_live1 ? s * 64 : 0), sbase + __builtin_amdgcn_readfirstlane((wid * 2 + 1) * 1024));
+#pragma unroll
+    for (int it = 0; it < NI; ++it) {
+      if (F16OP && s >= s_split) glds16(a2_ptr[it] + (a_live[it] ? (s - s_split) * 64 : 0), sbase + __builtin_amdgcn_readfirstlane((wid * NI + it) * 1024));
+      else glds16(a_ptr[it] + (a_live[it] ? s * 64 : 0), sbase + __builtin_amdgcn_readfirstlane((wid * NI + it) * 1024));
     }
     glds16(b_ptr[0] + static_cast<size_t>(s) * BSTEP, sbase + __builtin_amdgcn_readfirstlane(BM * 64 + (wid * 2) * 1024));
     glds16(b_ptr[1] + static_cast<size_t>(s) * BSTEP, sbase + __builtin_amdgcn_readfirstlane(BM * 64 + (wid * 2 + 1) * 1024));
@@ -356,9 +364,9 @@ __global__ __launch_bounds__(256, 3) void k_lin_direct(ConvP p) {
   const int brow = lin_brow(lane & 31);                    // weight rows in the permuted order (see lin_brow)
   const int bsw = (h ^ ((brow >> 2) & 3)) << 4;
 
-  v16i acc[2][2];
+  v16i acc[NI][2];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < NI; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -394,9 +402,11 @@ __global__ __launch_bounds__(256, 3) void k_lin_direct(ConvP p) {
   if constexpr (!F16OP) aqp = load_qparam(d.aq);
   float2 oqp = make_float2(1.0f, 0.0f);
   if constexpr (MODE != LIN_F16) oqp = load_qparam(d.oq);
-  uint4 rres[2][2][2];                     // MODE F16 / Q8 with a residual: 8 channels x fp16 per (i, j, register octet)
-  const bool has_res = !lin_is_geglu<MODE> && d.residual != nullptr;
-  if (has_res && d.res_f16) lin_load_res<MODE>(p, rres, m0, n0, wm, wn, lane);
+  uint4 rres[NI][2][2];                    // MODE F16 / Q8 with a residual: 8 channels x fp16 per (i, j, register octet)
+  const bool has_res = NI == 2 && !lin_is_geglu<MODE> && d.residual != nullptr;      // (the launcher keeps residual layers on NI = 2)
+  if constexpr (NI == 2) {
+    if (has_res && d.res_f16) lin_load_res<MODE>(p, rres, m0, n0, wm, wn, lane);
+  }
 
 #ifdef TFMQ_PHASE_TIMERS
   // where a wave's K-step goes: [0] counted vmcnt wait, [1] barrier, [2] DMA issue, [3] fragment reads until their data is there,
@@ -424,10 +434,10 @@ __global__ __launch_bounds__(256, 3) void k_lin_direct(ConvP p) {
     // (same-box A/B, gpurun_out/r04/lin_prefetch_ab.txt: GEGLU 640 -> 5120 and 1280 -> 10240 -6.5 %; the fp16 / int8-output modes
     // -2 ... +7 %: they keep the read-then-multiply order per half)
     constexpr bool PF = LIN_PREFETCH && lin_is_geglu<MODE>;
-    v4i af[2][2], bf[2][2];
+    v4i af[2][NI], bf[2][2];
     auto read_frags = [&](int ks) {
 #pragma unroll
-      for (int i = 0; i < 2; ++i) af[ks][i] = *reinterpret_cast<const v4i*>(sa + ((wm * 2 + i) * 32 + (lane & 31)) * 64 + (fsw ^ (ks << 5)));
+      for (int i = 0; i < NI; ++i) af[ks][i] = *reinterpret_cast<const v4i*>(sa + ((wm * NI + i) * 32 + (lane & 31)) * 64 + (fsw ^ (ks << 5)));
 #pragma unroll
       for (int j = 0; j < 2; ++j) bf[ks][j] = *reinterpret_cast<const v4i*>(sb + (ncol0(j) + brow) * 64 + (bsw ^ (ks << 5)));
     };
@@ -444,7 +454,7 @@ __global__ __launch_bounds__(256, 3) void k_lin_direct(ConvP p) {
       }
       // operands swapped: the accumulator tile is (channels x pixels) -- lane = pixel, register quad = 4 consecutive channels
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < NI; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
           if constexpr (F16OP) {
@@ -491,12 +501,12 @@ __global__ __launch_bounds__(256, 3) void k_lin_direct(ConvP p) {
   }
   __syncthreads();
 
-  // statistics partials [16 eight-row groups][BN] live in the (now idle) DMA stages
+  // statistics partials [BM / 8 eight-row groups][BN] live in the (now idle) DMA stages
   float2* ldsP = (MODE == LIN_F16 && d.stats) ? reinterpret_cast<float2*>(lds) : nullptr;
-  // (store staging: 32 rows x 144 bytes per wave behind the 16 KB of statistics partials, all inside the idle DMA stages)
-  unsigned char* stg = MODE == LIN_F16 ? lds + 16384 + wid * (32 * LIN_STG_ROW) : nullptr;
+  // (store staging: 32 rows x 144 bytes per wave behind the 16 (32) KB of statistics partials, all inside the idle DMA stages)
+  unsigned char* stg = MODE == LIN_F16 ? lds + (BM / 8) * BN * 8 + wid * (32 * LIN_STG_ROW) : nullptr;
   if constexpr (MODE == LIN_Q8) stg = (d.Cout & 15) == 0 ? lds + wid * (32 * LIN_STG_ROW_Q8) : nullptr;
-  lin_epilogue<MODE, 0, F16OP>(p, acc, cs, rres, has_res, m0, n0, wm, wn, lane, oqp, ldsP, stg);
+  lin_epilogue<MODE, 0, F16OP, NI>(p, acc, cs, rres, has_res, m0, n0, wm, wn, lane, oqp, ldsP, stg);
   if constexpr (MODE == LIN_F16) {
     if (d.stats) {
       __syncthreads();
@@ -527,8 +537,9 @@ __global__ __launch_bounds__(256, 3) void k_lin_direct(ConvP p) {
 
 }  // namespace
 
-bool launch_conv_lin(tfmq_handle h, ConvP& p, hipStream_t st) {
+bool launch_conv_lin(tfmq_handle h, ConvP& p, hipStream_t st, bool m256) {
   const tfmq_conv_desc& d = p.d;
+  if (m256 && (d.residual || p.M < 256 || (d.stats && 256 % d.stats_seg != 0))) m256 = false;      // (falls back to the 128-row form)
   if (d.KH != 1 || d.KW != 1 || d.stride != 1 || d.up2x || d.pad_t != 0 || d.pad_l != 0 || d.Ho != d.H || d.Wo != d.W) return false;
   if (d.Cin % 32 != 0 || p.chunks != (d.Cin + 63) / 64 || static_cast<size_t>(d.B) * d.H * d.W * d.Cin >= (static_cast<size_t>(1) << 31)) return false;
   if (d.rowadd || (d.Cout & 7) != 0) return false;                 // a lane moves whole 8-channel octets
@@ -549,7 +560,7 @@ bool launch_conv_lin(tfmq_handle h, ConvP& p, hipStream_t st) {
   p.tiles_n = (d.Cout + 127) / 128;
   static const int issue_split_env = getenv("TFMQ_LIN_ISSUE_SPLIT") ? atoi(getenv("TFMQ_LIN_ISSUE_SPLIT")) : 0;
   p.issue_split = issue_split_env;
-  const int tiles_m = (p.M + 127) / 128;
+  const int tiles_m = m256 ? (p.M + 255) / 256 : (p.M + 127) / 128;
   const int n_tiles = p.tiles_n * tiles_m;
   dim3 grid(static_cast<unsigned>(n_tiles));
 #ifdef TFMQ_PHASE_TIMERS
@@ -560,7 +571,12 @@ bool launch_conv_lin(tfmq_handle h, ConvP& p, hipStream_t st) {
   if (!dbuf3) (void)hipMalloc(reinterpret_cast<void**>(&dbuf3), sizeof(unsigned long long) * 8 * (1u << 18));
   p.dbg2 = grid.x <= (1u << 18) ? dbuf3 : nullptr;
 #endif
-  if (mode == LIN_F16) hipLaunchKernelGGL((k_lin_direct<LIN_F16>), grid, dim3(256), 0, st, p);
+  if (m256) {
+    if (mode == LIN_F16) hipLaunchKernelGGL((k_lin_direct<LIN_F16, false, 4>), grid, dim3(256), 0, st, p);
+    else if (mode == LIN_Q8) hipLaunchKernelGGL((k_lin_direct<LIN_Q8, false, 4>), grid, dim3(256), 0, st, p);
+    else if (mode == LIN_GEGLU) hipLaunchKernelGGL((k_lin_direct<LIN_GEGLU, false, 4>), grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((k_lin_direct<LIN_GEGLU_FAST, false, 4>), grid, dim3(256), 0, st, p);
+  } else if (mode == LIN_F16) hipLaunchKernelGGL((k_lin_direct<LIN_F16>), grid, dim3(256), 0, st, p);
   else if (mode == LIN_Q8) hipLaunchKernelGGL((k_lin_direct<LIN_Q8>), grid, dim3(256), 0, st, p);
   else if (mode == LIN_GEGLU) hipLaunchKernelGGL((k_lin_direct<LIN_GEGLU>), grid, dim3(256), 0, st, p);
   else hipLaunchKernelGGL((k_lin_direct<LIN_GEGLU_FAST>), grid, dim3(256), 0, st, p);

@@ -757,7 +757,9 @@ bool launch_conv_slab(tfmq_handle h, ConvP& p, hipStream_t st, bool forced, bool
     else if (WN == 4) hipLaunchKernelGGL((k_conv3_slab<4, false, 2>), grid, dim3(256), 0, st, sp);
     else hipLaunchKernelGGL((k_conv3_slab<2, false, 2>), grid, dim3(256), 0, st, sp);
   } else if (f16) {
-    if (WN == 5) hipLaunchKernelGGL((k_conv3_slab<5, true>), grid, dim3(512), 0, st, sp);
+    if (pp_env && WN == 5) hipLaunchKernelGGL((k_conv3_slab<5, true, 4, 1>), grid, dim3(512), 0, st, sp);
+    else if (pp_env && WN == 4) hipLaunchKernelGGL((k_conv3_slab<4, true, 4, 1>), grid, dim3(512), 0, st, sp);
+    else if (WN == 5) hipLaunchKernelGGL((k_conv3_slab<5, true>), grid, dim3(512), 0, st, sp);
     else if (WN == 4) hipLaunchKernelGGL((k_conv3_slab<4, true>), grid, dim3(512), 0, st, sp);
     else hipLaunchKernelGGL((k_conv3_slab<2, true>), grid, dim3(512), 0, st, sp);
   } else if (pp_env == 2 && WN == 5) hipLaunchKernelGGL((k_conv3_slab<5, false, 4, 2>), grid, dim3(512), 0, st, sp);

@@ -519,7 +519,7 @@ def _attach_stats(dsc, y: torch.Tensor, B: int, hw: int, cout: int, want_stats: 
 # captured into the sampler's hipGraph -- use the winner.  The result does not depend on the tile shape.
 _AUTOTUNE = None      # None = off, else {shape key: tile id}
 _TILE_NAMES = {1: "128x128", 2: "64x64", 3: "256x128", 4: "128x64", 5: "slab 256xN (3x3)", 6: "direct 128x128 (pointwise)",
-               7: "slab 128xN (3x3, two blocks per CU)"}
+               7: "slab 128xN (3x3, two blocks per CU)", 9: "direct 256x128 (pointwise, two blocks per CU)"}
 
 
 def set_conv_autotune(cache) -> None:
@@ -584,9 +584,11 @@ def _tune_conv(h, name, kind, d, dsc):
         return 0                      # cannot time inside a capture / nothing to choose / not idempotent
     if kind == "f16" and dsc.x2:
         return 6                      # two sources: only the register-direct pointwise kernel reads them
-    if dsc.out_mode == 4:
-        return 6                      # TFMQ_OUT_GEGLU_Q8_FAST: only the register-direct pointwise kernel carries that epilogue
-    if kind == "f16" and dsc.x_f16 and slab_ok(dsc):
+    if dsc.out_mode == 4:             # TFMQ_OUT_GEGLU_Q8_FAST: only the register-direct pointwise kernel carries that epilogue -- its two tile heights
+        cands = [6] + ([9] if dsc.B * dsc.Ho * dsc.Wo >= 256 * 256 and os.environ.get("TFMQ_LIN_M256", "1") != "0" else [])
+        if len(cands) == 1:
+            return 6
+    elif kind == "f16" and dsc.x_f16 and slab_ok(dsc):
         # fp16 3x3: the slab kernel's K order differs from the tile kernels' -- one rule for every batch size; its 256- and 128-pixel
         # forms accumulate every output in the same order (bit-identical), so THAT choice may be measured
         cands = [5] + ([7] if slab_ok(dsc, 128) else [])
@@ -653,6 +655,9 @@ def _tile_candidates(kind, dsc):
     if (kind == "w4a8" and dsc.KH == 1 and dsc.KW == 1 and dsc.stride == 1 and not dsc.up2x and k64 and dsc.Cout % 4 == 0
             and dsc.out_mode in (1, 2, 3) and not dsc.rowadd and not (dsc.stats and dsc.out_mode != 1) and not (dsc.yt and dsc.residual)):
         cands.append(6)
+        if (not dsc.residual and dsc.B * dsc.Ho * dsc.Wo >= 256 * 256 and not (dsc.stats and 256 % dsc.stats_seg != 0)
+                and os.environ.get("TFMQ_LIN_M256", "1") != "0"):
+            cands.append(9)         # the same kernel on 256 x 128 tiles (round 6): layers without a residual, grids that still fill the chip
     if (kind == "f16" and dsc.x_f16 and dsc.KH == 1 and dsc.KW == 1 and dsc.stride == 1 and not dsc.up2x and dsc.Cin % 32 == 0
             and dsc.Cout % 8 == 0 and dsc.out_mode == 1 and not dsc.rowadd and not (dsc.yt and (dsc.residual or dsc.stats))):
         cands.append(6)             # the same register-direct kernel on fp16 operands (skip-connection 1x1 convs, un-quantised q|k|v)
