@@ -585,7 +585,7 @@ def _tune_conv(h, name, kind, d, dsc):
     if kind == "f16" and dsc.x2:
         return 6                      # two sources: only the register-direct pointwise kernel reads them
     if dsc.out_mode == 4:             # TFMQ_OUT_GEGLU_Q8_FAST: only the register-direct pointwise kernel carries that epilogue -- its two tile heights
-        cands = [6] + ([9] if dsc.B * dsc.Ho * dsc.Wo >= 256 * 256 and os.environ.get("TFMQ_LIN_M256", "1") != "0" else [])
+        cands = [6] + ([9] if dsc.B * dsc.Ho * dsc.Wo >= 256 * 256 and os.environ.get("TFMQ_LIN_M256", "0") == "1" else [])
         if len(cands) == 1:
             return 6
     elif kind == "f16" and dsc.x_f16 and slab_ok(dsc):
@@ -656,8 +656,9 @@ def _tile_candidates(kind, dsc):
             and dsc.out_mode in (1, 2, 3) and not dsc.rowadd and not (dsc.stats and dsc.out_mode != 1) and not (dsc.yt and dsc.residual)):
         cands.append(6)
         if (not dsc.residual and dsc.B * dsc.Ho * dsc.Wo >= 256 * 256 and not (dsc.stats and 256 % dsc.stats_seg != 0)
-                and os.environ.get("TFMQ_LIN_M256", "1") != "0"):
-            cands.append(9)         # the same kernel on 256 x 128 tiles (round 6): layers without a residual, grids that still fill the chip
+                and os.environ.get("TFMQ_LIN_M256", "0") == "1"):
+            cands.append(9)         # the same kernel on 256 x 128 tiles (round 6; opt-in: measured within +-5 % of the 128-row form on the SD shapes,
+                                    # profiles/r06_ab_lin_m256.txt -- not worth a candidate whose 3-launch timing is as noisy as its gain)
     if (kind == "f16" and dsc.x_f16 and dsc.KH == 1 and dsc.KW == 1 and dsc.stride == 1 and not dsc.up2x and dsc.Cin % 32 == 0
             and dsc.Cout % 8 == 0 and dsc.out_mode == 1 and not dsc.rowadd and not (dsc.yt and (dsc.residual or dsc.stats))):
         cands.append(6)             # the same register-direct kernel on fp16 operands (skip-connection 1x1 convs, un-quantised q|k|v)
