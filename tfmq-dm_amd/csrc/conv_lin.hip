@@ -281,11 +281,14 @@ __device__ __forceinline__ void lin_load_res(const ConvP& p, uint4 (&rres)[2][2]
 // tiles, two blocks per CU -- 24 KB of operands per 64 MFMAs of a block instead of 16 KB per 32: a quarter fewer LDS-DMA pieces per MFMA on
 // K loops that run at the DMA issue rate of their waves (profiles/r06_kstep_lin_direct.txt); layers WITHOUT a residual only (the residual
 // octets of a 64 x 64 ... 128 x 64 wave tile would not fit beside 128 accumulator registers).  Same int32 sums, same epilogue: same bits.
-template <int MODE, bool F16OP = false, int NI = 2>
-__global__ __launch_bounds__(256, NI == 2 ? 3 : 2) void k_lin_direct(ConvP p) {
+// NST2 (round 6, GEGLU modes on 128-row tiles): two operand stages instead of three -- 34 KB of LDS and <= 128 VGPRs, FOUR blocks per CU; the
+// pieces of step s + 1 are issued behind the barrier of step s (one step of prefetch instead of two).
+template <int MODE, bool F16OP = false, int NI = 2, bool NST2 = false>
+__global__ __launch_bounds__(256, NST2 ? 4 : (NI == 2 ? 3 : 2)) void k_lin_direct(ConvP p) {
+  static_assert(!NST2 || (NI == 2 && lin_is_geglu<MODE>), "two stages: the GEGLU forms on 128-row tiles");
   constexpr int BM = 64 * NI, BN = 128;
   constexpr int STAGE = (BM + BN) * 64;
-  constexpr int NST = 3;
+  constexpr int NST = NST2 ? 2 : 3;
   constexpr int NLOAD = NI + 2;                  // DMA pieces per wave per K-step: NI of A, 2 of B
   constexpr int CONST_OFF = NST * STAGE;
   __shared__ __attribute__((aligned(1024))) unsigned char lds[NST * STAGE + 3 * BN * 4];
@@ -373,7 +376,7 @@ __global__ __launch_bounds__(256, NI == 2 ? 3 : 2) void k_lin_direct(ConvP p) {
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0;
 
   issue(0, 0);
-  if (p.nsteps > 1) issue(1, 1);
+  if (!NST2 && p.nsteps > 1) issue(1, 1);
 
   // ---- requested now, consumed after the K loop: per-column constants (threads < BN), the quantizer parameters, and the
   // residual values of this lane's outputs (branch-free: clamped addresses).  They are younger than the first DMA
@@ -417,16 +420,17 @@ __global__ __launch_bounds__(256, NI == 2 ? 3 : 2) void k_lin_direct(ConvP p) {
 #else
 #define KT(i) do { } while (0)
 #endif
-  int st_c = 0, st_i = 2;
+  int st_c = 0, st_i = NST2 ? 1 : 2;
   for (int s = 0; s < p.nsteps; ++s) {
-    if (s + 1 < p.nsteps) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLOAD) : "memory");
+    if (!NST2 && s + 1 < p.nsteps) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLOAD) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     KT(0);
     asm volatile("s_barrier" ::: "memory");
     KT(1);
     if (s == 0) LIN_MARK(1);
     const bool late = p.issue_split && wid >= 2;      // (wave-uniform)
-    if (!late && s + 2 < p.nsteps) issue(s + 2, st_i);
+    constexpr int AHEAD = NST2 ? 1 : 2;
+    if (!late && s + AHEAD < p.nsteps) issue(s + AHEAD, st_i);
     KT(2);
     const unsigned char* sa = lds + st_c * STAGE;
     const unsigned char* sb = sa + BM * 64;
@@ -466,7 +470,7 @@ __global__ __launch_bounds__(256, NI == 2 ? 3 : 2) void k_lin_direct(ConvP p) {
             acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(bf[ks][j], af[ks][i], acc[i][j], 0, 0, 0);
           }
         }
-      if (ks == 0 && late && s + 2 < p.nsteps) issue(s + 2, st_i);
+      if (ks == 0 && late && s + AHEAD < p.nsteps) issue(s + AHEAD, st_i);
     }
     st_c = st_c == NST - 1 ? 0 : st_c + 1;
     st_i = st_i == NST - 1 ? 0 : st_i + 1;
@@ -560,6 +564,7 @@ bool launch_conv_lin(tfmq_handle h, ConvP& p, hipStream_t st, bool m256) {
   p.tiles_n = (d.Cout + 127) / 128;
   static const int issue_split_env = getenv("TFMQ_LIN_ISSUE_SPLIT") ? atoi(getenv("TFMQ_LIN_ISSUE_SPLIT")) : 0;
   p.issue_split = issue_split_env;
+  static const int nst2_env = getenv("TFMQ_LIN_GEGLU_NST2") ? atoi(getenv("TFMQ_LIN_GEGLU_NST2")) : 0;      // (round 6 A/B: two stages, four blocks per CU)
   const int tiles_m = m256 ? (p.M + 255) / 256 : (p.M + 127) / 128;
   const int n_tiles = p.tiles_n * tiles_m;
   dim3 grid(static_cast<unsigned>(n_tiles));
@@ -579,6 +584,7 @@ bool launch_conv_lin(tfmq_handle h, ConvP& p, hipStream_t st, bool m256) {
   } else if (mode == LIN_F16) hipLaunchKernelGGL((k_lin_direct<LIN_F16>), grid, dim3(256), 0, st, p);
   else if (mode == LIN_Q8) hipLaunchKernelGGL((k_lin_direct<LIN_Q8>), grid, dim3(256), 0, st, p);
   else if (mode == LIN_GEGLU) hipLaunchKernelGGL((k_lin_direct<LIN_GEGLU>), grid, dim3(256), 0, st, p);
+  else if (nst2_env) hipLaunchKernelGGL((k_lin_direct<LIN_GEGLU_FAST, false, 2, true>), grid, dim3(256), 0, st, p);
   else hipLaunchKernelGGL((k_lin_direct<LIN_GEGLU_FAST>), grid, dim3(256), 0, st, p);
 #ifdef TFMQ_PHASE_TIMERS
   if (p.dbg && getenv("TFMQ_PHASE_PRINT")) {
