@@ -4,6 +4,7 @@
 # weight initialisation and the Finite-Set pass).  PART=a | b | c
 R=${GRAFT_REPO_ROOT:-$PWD}; O=$R/gpurun_out/r06; mkdir -p $O; cd $R
 export TMPDIR=/tmp
+export TFMQ_CACHE_F16=1      # (a cache that fits neither the device in fp32 nor the host cap: fp16 on the device, logged with its inexact count)
 case "$PART" in
   a) ONLY="tib,model.input_blocks";;
   b) ONLY="model.output_blocks.0.,model.output_blocks.1.,model.output_blocks.2.,model.output_blocks.3.,model.output_blocks.4.,model.output_blocks.5.,model.output_blocks.6.,model.output_blocks.7.";;

@@ -13,7 +13,7 @@ because the weight scales and the synthetic Finite-Set table of bench.py's SD wo
 
     python tests/golden/gen_golden_sd_traj.py [--steps 50] [--threads 96] [--out gpurun_out/f27_sd_traj.npz]
 
-Round 6 (fixture F27b): `--seeds 2026,2027,2028,2029 --out .../f27b_sd_traj4.npz` runs the oracle on SEVERAL images at once
+Round 6 (fixture F27b): `--seeds 2026,2027 --out .../f27b_sd_traj_multi.npz` runs the oracle on SEVERAL images at once
 (one batch: different latents AND different contexts per image; per-sample arithmetic is batch independent) so that the stated tolerance
 rests on more than one sample.  `final` / `x_norm` / `eps_norm` then carry a leading image dimension; intermediate latents are kept for image 0.
 

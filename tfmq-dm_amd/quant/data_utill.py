@@ -41,10 +41,10 @@ class HostRows:
 
     def __init__(self, shape, dtype, device):
         need = torch.empty((), dtype=dtype).element_size() * int(torch.Size(shape).numel())
-        avail = _host_available()
-        if avail is not None and need + (16 << 30) > avail:     # fail before the allocation, not in the host's OOM killer
+        room = host_room()
+        if need > room:      # fail before the allocation, not in the host's OOM killer (or the sandbox's: see host_room)
             raise TfmqError(f"HostRows: {need / 2**30:.1f} GiB of pinned host memory wanted for a reconstruction cache, "
-                            f"{avail / 2**30:.1f} GiB available on this host")
+                            f"{room / 2**30:.1f} GiB allowed on this host (MemAvailable, cgroup limit, TFMQ_CACHE_HOST_MAX_GB)")
         self.buf = torch.empty(tuple(shape), dtype=dtype, pin_memory=True)
         self.device, self.dtype, self.shape = torch.device(device), dtype, torch.Size(shape)
         self.is_host_rows = True
@@ -66,6 +66,54 @@ class HostRows:
         for j, i in enumerate(ids):
             out[j].copy_(self.buf[i], non_blocking=True)
         return out
+
+
+class HalfRows:
+    """LAST RESORT, opt-in (TFMQ_CACHE_F16=1): a reconstruction cache that fits neither beside the passes on the device in its own dtype nor
+    in the host memory this process may pin is kept ON THE DEVICE AS fp16 and widened row by row at selection.  The reference has no such
+    case (it needs the host RAM); here it happens for ONE tensor of the SD recipe -- the 960-channel input of `output_blocks.9.0` over 12 800
+    samples, 201 GB in fp32 -- on a box whose sandbox dies under a pinned allocation of that size.  `inexact` counts the elements the
+    narrowing changed (0 when the tapped tensor came out of the fp16 activation stream); the caller logs it."""
+
+    def __init__(self, shape, dtype, device):
+        self.buf = torch.empty(tuple(shape), dtype=torch.float16, device=device)
+        self.device, self.dtype, self.shape = torch.device(device), dtype, torch.Size(shape)
+        self.inexact = 0
+
+    def size(self, d=None):
+        return self.shape if d is None else self.shape[d]
+
+    def __len__(self):
+        return self.shape[0]
+
+    def fill(self, start: int, rows: torch.Tensor):
+        h = rows.to(torch.float16)
+        self.inexact += int((h.to(rows.dtype) != rows).sum())
+        self.buf[start:start + rows.shape[0]].copy_(h)
+
+    def index_select(self, dim: int, idx: torch.Tensor) -> torch.Tensor:
+        assert dim == 0
+        return self.buf.index_select(0, idx.to(self.buf.device)).to(self.dtype)
+
+
+def host_room() -> int:
+    """Bytes of pinned host memory a new cache may take: MemAvailable minus 16 GiB, the cgroup's memory limit minus what it already uses,
+    and TFMQ_CACHE_HOST_MAX_GB (default 64: round 6 lost a GPU box -- a microVM reporting 3 TB of RAM -- to a 201 GB pinned allocation)."""
+    room = int(float(os.environ.get("TFMQ_CACHE_HOST_MAX_GB", "64")) * (1 << 30))
+    avail = _host_available()
+    if avail is not None:
+        room = min(room, avail - (16 << 30))
+    for lim, use in (("/sys/fs/cgroup/memory.max", "/sys/fs/cgroup/memory.current"),
+                     ("/sys/fs/cgroup/memory/memory.limit_in_bytes", "/sys/fs/cgroup/memory/memory.usage_in_bytes")):
+        try:
+            with open(lim) as f:
+                v = f.read().strip()
+            if v.isdigit() and int(v) < (1 << 60):
+                with open(use) as f:
+                    room = min(room, int(v) - int(f.read().strip()) - (4 << 30))
+        except (OSError, ValueError):
+            pass
+    return max(room, 0)
 
 
 def _host_available():
@@ -118,8 +166,14 @@ def save_inout(model, layer, cali_data: Tuple[torch.Tensor], asym: bool = False,
                     nbytes = t.element_size() * self.rows * int(t[0].numel())
                     force = os.environ.get("TFMQ_CACHE_HOST")          # "1": every cache with keep_gpu=False on the host; "all": every cache (tests)
                     if t.is_cuda and self.host_ok and (force == "all" or (force == "1" and not keep_gpu) or nbytes > _device_room(t.device)):
-                        self.buf = HostRows(shape, t.dtype, t.device)
-                        logger.info(f"save_inout: {nbytes / 2**30:.1f} GiB of cache for '{name}' kept in pinned host memory")
+                        if (nbytes > host_room() and force is None and os.environ.get("TFMQ_CACHE_F16") == "1" and t.dtype == torch.float32
+                                and nbytes // 2 <= _device_room(t.device)):
+                            self.buf = HalfRows(shape, t.dtype, t.device)
+                            logger.warning(f"save_inout: {nbytes / 2**30:.1f} GiB of cache for '{name}' fit neither on the device nor in "
+                                           f"{host_room() / 2**30:.0f} GiB of host memory: kept on the device as fp16 (TFMQ_CACHE_F16=1)")
+                        else:
+                            self.buf = HostRows(shape, t.dtype, t.device)
+                            logger.info(f"save_inout: {nbytes / 2**30:.1f} GiB of cache for '{name}' kept in pinned host memory")
                     else:
                         self.buf = torch.empty(shape, dtype=t.dtype, device=t.device)
                 else:                          # (a tensor that does not scale with the batch: collected and concatenated as before)
@@ -127,7 +181,7 @@ def save_inout(model, layer, cali_data: Tuple[torch.Tensor], asym: bool = False,
             if self.buf is None:
                 self.parts.append(t)
                 return
-            if isinstance(self.buf, HostRows):
+            if isinstance(self.buf, (HostRows, HalfRows)):
                 self.buf.fill(self.n, t)
             else:
                 self.buf[self.n:self.n + t.shape[0]].copy_(t)
@@ -185,6 +239,11 @@ def save_inout(model, layer, cali_data: Tuple[torch.Tensor], asym: bool = False,
     layer.set_quant_state(True, use_act)
     cached_out = outs.tensor()
     cached_in = (ins.tensor(),) + ((tembs.tensor(),) if tembs else ()) + ((ctxs.tensor(),) if ctxs else ())
+    for c_ in (cached_out,) + cached_in:
+        if isinstance(c_, HalfRows):
+            msg = f"save_inout: fp16 cache of '{name}' {tuple(c_.shape)}: {c_.inexact} of {c_.buf.numel()} elements changed by the narrowing"
+            logger.warning(msg)
+            print("[cali] " + msg, file=__import__("sys").stderr, flush=True)
     logger.info(f"input shapes: {[tuple(c.shape) for c in cached_in]} output shape: {tuple(cached_out.shape)}")
     return cached_in, cached_out
 
