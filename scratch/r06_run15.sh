@@ -8,12 +8,3 @@ for s in 0 1 0 1 0 1; do
   TFMQ_LIN_GEGLU_NST2=$s TILES=6 ONLY=0,4,7 timeout 300 python scratch/bench_lin.py 2>&1 | grep -v amdgpu.ids >> $O
 done
 cat $O
-# d = 80 attention (32x32 level) held to 168 VGPRs for a third block per CU (variant library) vs the product (190 VGPRs, two blocks)
-O2=gpurun_out/r06/run15_attn80_occ3.txt; : > $O2
-for lib in product occ3 product occ3; do
-  if [ $lib = product ]; then unset TFMQ_LIB_PATH; else export TFMQ_LIB_PATH=$PWD/scratch/ab/libtfmq_attn80.so; fi
-  echo "== $lib" >> $O2
-  BATCH=128 timeout 300 python scratch/bench_attn.py 2>&1 | grep -v amdgpu.ids | grep "d80" >> $O2
-done
-unset TFMQ_LIB_PATH
-cat $O2

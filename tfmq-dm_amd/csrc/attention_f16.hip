@@ -53,11 +53,9 @@ struct AttnHP {
 template <int NKS, int NT, int ONES_ROW, bool FOLD = false>
 // (the d = 40 self-attention variant is held to 128 VGPRs = four waves per SIMD -- its 37 KB of LDS allow four blocks per CU: 4.21 -> 4.08 ms
 // at UNet batch 128, same-box A/B)
-#ifdef TFMQ_ATTN80_OCC3      // (round 6 experiment: the d = 80 form held to 168 VGPRs -- 12 spilled -- for a third block per CU; 3 x 54 272 B of LDS fit)
-__global__ __launch_bounds__(256, (NT <= 2 && FOLD) ? 4 : ((NT == 3 && NKS == 5 && ONES_ROW == 80) ? 3 : 1)) void k_attention_h(AttnHP p) {
-#else
+// (round 6, measured and dropped: the d = 80 form <5, 3, 80> held to 168 VGPRs by __launch_bounds__(256, 3) for a third block per CU -- 3 x 54 272 B
+// of LDS fit -- spills 12 registers and is 5 % SLOWER, 523 / 512 -> 549 / 555 us at UNet batch 128: profiles/r06_ab_lin_geglu_nst2_attn80.txt)
 __global__ __launch_bounds__(256, (NT <= 2 && FOLD) ? 4 : 1) void k_attention_h(AttnHP p) {
-#endif
   constexpr int DPAD = NT * 32;
   static_assert(!FOLD || (ONES_ROW >= 0 && 16 * NKS > ONES_ROW && ONES_ROW % 8 == 0), "FOLD: spare score column + ones-row");
   // Wide heads (16 * NKS > 32 * NT; the single 384-channel head of cin256-v2): the scores need the whole head dimension, the
