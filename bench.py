@@ -1050,6 +1050,29 @@ def main():
                                                                            "source": "profiles/" + fname, "recorded_run": True}
                 except Exception as e:
                     cali["measured_sd_recipe_20000_iterations_one_job"] = {"error": repr(e)}
+            # round 6: the SD job ON THE RECIPE'S OWN SET (txt2img.py:421-429,486: 50 DDIM steps x 256 samples = 12 800, generated inside the job),
+            # all 74 units x 20 000 iterations, measured in three jobs that partition the units (scratch/r06_sd_cali_full.sh); every job repeats set
+            # generation and the Finite-Set pass, so ONE job = the reconstruction phases of all three + one generation + one Finite-Set pass
+            try:
+                parts = {}
+                for part in "abc":
+                    mj = json.loads(open(os.path.join(ROOT, "profiles", f"r06_sd_calibration_50x256_part_{part}.json")).read().strip().splitlines()[-1])
+                    parts[part] = {"wall_clock_s": mj["calibration"]["wall_clock_s"], "reconstruction_units": mj["calibration"]["reconstruction_units"],
+                                   "phases_s": mj["calibration"]["phases_s"], "source": f"profiles/r06_sd_calibration_50x256_part_{part}.json"}
+                rec = sum(v for pt in parts.values() for k, v in pt["phases_s"].items() if "reconstruction" in k)
+                gen = [pt["phases_s"]["generate_cali_text_guided_data"] for pt in parts.values()]
+                fsc = [pt["phases_s"]["finite_set_activation_calibration"] for pt in parts.values()]
+                cali["measured_sd_recipe_50x256_set_20000_iterations"] = {
+                    "recorded_run": True, "reconstruction_units": sum(pt["reconstruction_units"] for pt in parts.values()), "iterations_per_unit": 20000,
+                    "calibration_set": "50 DDIM steps x 256 samples (128 prompts x {cond, uncond}) = 12 800, FP sampling inside each job",
+                    "sum_of_the_three_jobs_s": round(sum(pt["wall_clock_s"] for pt in parts.values()), 1),
+                    "one_job_s": round(rec + sum(gen) / 3 + sum(fsc) / 3, 1),
+                    "one_job_is": "sum of the reconstruction phases of the three jobs + one set generation + one Finite-Set pass (means of the three)",
+                    "reconstruction_s": round(rec, 1), "parts": parts,
+                    "note": "two cached tensors of part c (the 187.5 GiB input of output_blocks.9.0, the 125 GiB target of output_blocks.8.2.conv) were held "
+                            "on the device as fp16 (TFMQ_CACHE_F16=1): the box's sandbox does not survive a pinned host allocation of that size"}
+            except Exception as e:
+                cali["measured_sd_recipe_50x256_set_20000_iterations"] = {"error": repr(e)}
             lv = cali.get("measured_sd_recipe_20000_iterations", {})
             if len(lv) == 4 and all("wall_clock_s" in v for v in lv.values()):
                 lv["sum_of_levels"] = {"wall_clock_s": round(sum(v["wall_clock_s"] for v in lv.values()), 1),
