@@ -567,6 +567,8 @@ bool launch_conv_lin(tfmq_handle h, ConvP& p, hipStream_t st, bool m256) {
   // round 6: the consumer-sized GEGLU form on TWO operand stages, four blocks per CU (-5 % on 640 -> 5120, -1 ... -2 % on the others, same bits:
   // profiles/r06_ab_lin_geglu_nst2_attn80.txt); TFMQ_LIN_GEGLU_NST2=0 restores three stages / three blocks
   static const int nst2_env = getenv("TFMQ_LIN_GEGLU_NST2") ? atoi(getenv("TFMQ_LIN_GEGLU_NST2")) : 1;
+  // (measured and dropped: the fp16 / int8-output forms held to 128 VGPRs for a fourth block -- 16-24 registers spilled, the residual octets among
+  // them: residual layers 10-20 % SLOWER, the others equal; and two stages leave no room for the epilogue's staging: profiles/r06_ab_lin_geglu_nst2_attn80.txt)
   const int tiles_m = m256 ? (p.M + 255) / 256 : (p.M + 127) / 128;
   const int n_tiles = p.tiles_n * tiles_m;
   dim3 grid(static_cast<unsigned>(n_tiles));
