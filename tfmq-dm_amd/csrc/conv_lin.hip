@@ -587,6 +587,7 @@ bool launch_conv_lin(tfmq_handle h, ConvP& p, hipStream_t st, bool m256) {
     else hipLaunchKernelGGL((k_lin_direct<LIN_GEGLU_FAST, false, 4>), grid, dim3(256), 0, st, p);
   } else if (mode == LIN_F16) hipLaunchKernelGGL((k_lin_direct<LIN_F16>), grid, dim3(256), 0, st, p);
   else if (mode == LIN_Q8) hipLaunchKernelGGL((k_lin_direct<LIN_Q8>), grid, dim3(256), 0, st, p);
+  else if (mode == LIN_GEGLU && nst2_env) hipLaunchKernelGGL((k_lin_direct<LIN_GEGLU, false, 2, true>), grid, dim3(256), 0, st, p);
   else if (mode == LIN_GEGLU) hipLaunchKernelGGL((k_lin_direct<LIN_GEGLU>), grid, dim3(256), 0, st, p);
   else if (nst2_env) hipLaunchKernelGGL((k_lin_direct<LIN_GEGLU_FAST, false, 2, true>), grid, dim3(256), 0, st, p);
   else hipLaunchKernelGGL((k_lin_direct<LIN_GEGLU_FAST>), grid, dim3(256), 0, st, p);
