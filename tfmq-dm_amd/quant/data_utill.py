@@ -153,6 +153,12 @@ def save_inout(model, layer, cali_data: Tuple[torch.Tensor], asym: bool = False,
     # torch.cat'ing them at the end needs twice the memory for a moment, which the 64 x 64 up-path units of the cin256 recipe (10 240
     # samples x 64 x 64 x 576 channels = 90 GiB of input) do not have even on 288 GB.
     n_total = int(xs.size(0))
+    # (round 6: the previous unit's caches must be gone before this unit's are sized -- in the recipe-size SD job a 125 GiB target was judged not
+    # to fit because the 187 GiB of the unit before it were still waiting for the collector)
+    import gc
+    gc.collect()
+    if torch.cuda.is_available():
+        torch.cuda.empty_cache()
 
     class _Rows:
         def __init__(self, host_ok=False):
